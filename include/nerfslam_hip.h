@@ -1,0 +1,184 @@
+/*
+ * nerfslam_hip.h -- C ABI of libnerfslam_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the two hot paths of ToniRV/NeRF-SLAM:
+ *   (1) the `droid_backends` operator table  (reference: src/droid.cpp:347-363)
+ *   (2) the `pyngp` training-step surface    (reference: fusion/nerf_fusion.py:57-101,285-300)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - tensors are dense row-major ("contiguous", the only thing the reference checks:
+ *     src/droid.cpp:129-130); shapes are given in the comments;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream). Nothing in this
+ *     library synchronises the device or allocates memory: outputs and workspaces are
+ *     caller-owned (the Python shim allocates them with torch);
+ *   - return value: 0 on success, negative NS_E* code otherwise; ns_last_error() returns a
+ *     thread-local message for the last failure;
+ *   - int64 index tensors (`ii`, `jj`) keep the reference's dtype (torch.long).
+ *
+ * No torch / pybind types cross this boundary.
+ */
+#ifndef NERFSLAM_HIP_H
+#define NERFSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NS_OK 0
+#define NS_EINVAL (-1)  /* bad argument (shape / dtype / null pointer)            */
+#define NS_ELAUNCH (-2) /* hipGetLastError() after a launch reported a failure    */
+#define NS_ENOSUP (-3)  /* configuration not supported by this build              */
+
+#define NS_F16 1
+#define NS_F32 2
+
+const char* ns_last_error(void);
+int ns_version(void);          /* ABI version of this header: 1                          */
+const char* ns_arch(void);     /* "gfx950"                                               */
+
+/* ------------------------------------------------------------------------------------------
+ * Correlation volumes
+ * ---------------------------------------------------------------------------------------- */
+
+/* corr_index_forward  (src/droid.cpp:280-288 -> src/correlation_kernels.cu:126-155, kernel :20-70)
+ *   volume [B,h1,w1,h2,w2] dtype (NS_F16|NS_F32), coords [B,2,h1,w1] f32,
+ *   corr   [B,2r+1,2r+1,h1,w1] dtype  (written completely; no zero-init needed).            */
+int ns_corr_index_forward(const void* volume, const float* coords, void* corr, int dtype, int B, int h1,
+                          int w1, int h2, int w2, int radius, void* stream);
+
+/* corr_index_backward (src/droid.cpp:290-301 -> correlation_kernels.cu:157-185, kernel :73-124)
+ *   volume_grad [B,h1,w1,h2,w2] f32 must be zero-filled by the caller; corr_grad [B,2r+1,2r+1,h1,w1]. */
+int ns_corr_index_backward(const float* coords, const float* corr_grad, float* volume_grad, int B, int h1,
+                           int w1, int h2, int w2, int radius, void* stream);
+
+/* Fused CorrBlock.__call__ (networks/modules/corr.py:40-50): all `num_levels` (<=4) pyramid
+ * levels in one launch, radius 3, f16.  pyr[l] is [E,h1,w1,h1>>l,w1>>l]; coords is the frontend's
+ * native [E,h1,w1,2] layout when coords_interleaved=1, else [E,2,h1,w1]; it is divided by 2^l
+ * inside the kernel (corr.py:47).  out [E, num_levels*49, h1, w1] f16 == torch.cat(out_pyramid,2). */
+int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_levels, const float* coords,
+                           int coords_interleaved, void* out, int E, int h1, int w1, void* stream);
+
+/* CorrBlock.__init__ pyramid (corr.py:23-38): one 2x2 average-pool step over the last two dims,
+ * f16 in/out, f32 accumulate, one rounding.  in [nslices,h,w] -> out [nslices,h/2,w/2].       */
+int ns_corr_pool2x2(const void* in, void* out, long nslices, int h, int w, void* stream);
+
+/* CorrBlock.corr + pyramid fused (corr.py:63-72 + :35-38): fmap1,fmap2 [n,C=128,HW] f16
+ * (channel-major exactly as the reference reshapes them), each divided by 4 in f16;
+ * writes pyr[0..num_levels-1] (pyr[l] = [n,ht,wd,ht>>l,wd>>l] f16).                          */
+int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, void* const* pyr_host, int num_levels,
+                           int n, int C, int ht, int wd, void* stream);
+
+/* altcorr_forward (src/droid.cpp:303-313 -> src/altcorr_kernel.cu:290-319, kernel :28-149)
+ *   fmap1 [B,H1,W1,C] f32, fmap2 [B,H2,W2,C] f32 (channels-last), coords [B,N,H1,W1,2] f32,
+ *   corr [B,N,(2r+1)^2,H1,W1] f32 (written completely).                                      */
+int ns_altcorr_forward(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B,
+                       int H1, int W1, int H2, int W2, int C, int N, int radius, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Geometry
+ * ---------------------------------------------------------------------------------------- */
+
+/* frame_distance (src/droid.cpp:230-246 -> src/droid_kernels.cu:1572-1594, kernel :630-769)
+ *   poses [n,7] (t,q xyzw), disps [n,ht,wd], intrinsics [4], ii,jj [num] i64 -> dist [num].   */
+int ns_frame_distance(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,
+                      const int64_t* jj, float* dist, int num, int ht, int wd, float beta, void* stream);
+
+/* projmap (src/droid.cpp:249-264 -> droid_kernels.cu:1597-1622, kernel :539-628)
+ *   coords [num,ht,wd,3] must be zero-filled (channel 2 is never written), valid [num,ht,wd,1]. */
+int ns_projmap(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,
+               const int64_t* jj, float* coords, float* valid, int num, int ht, int wd, void* stream);
+
+/* iproj (src/droid.cpp:267-276 -> droid_kernels.cu:1652-1675, kernel :896-967)  points [nm,ht,wd,3]. */
+int ns_iproj(const float* poses, const float* disps, const float* intrinsics, float* points, int nm, int ht,
+             int wd, void* stream);
+
+/* depth_filter (src/droid.cpp:330-344 -> droid_kernels.cu:1625-1649, kernel :773-892)
+ *   counter [num,ht,wd] must be zero-filled.                                                 */
+int ns_depth_filter(const float* poses, const float* disps, const float* intrinsics, const int64_t* inds,
+                    const float* thresh, float* counter, int num, int nframes, int ht, int wd, void* stream);
+
+/* solve_poses (src/droid.cpp:220-228 -> droid_kernels.cu:1837-1847, kernel :1015-1048):
+ *   poses[k] <- Exp(dx[k-kf0]) * poses[k], dx = [tau, phi].                                   */
+int ns_pose_retr(float* poses, const float* dx, int kf0, int kf1, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense bundle adjustment
+ *
+ * Graph plan.  The reference rebuilds, on the host and on every call, the expanded edge list
+ * (self loops kf0..kf1-1 prepended), its unique source ids and the Schur pair list
+ * (droid_kernels.cu:1702-1710, 1065-1103, 1359-1402).  Here the caller builds these small index
+ * arrays once per graph change with ns_ba_plan_* (pure host code, no device work) and uploads
+ * them; the kernels only read them.
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct ns_ba_plan {
+  int M;        /* edges given to BA                                                          */
+  int P;        /* kf1 - kf0 window poses                                                     */
+  int K;        /* K' = #unique(cat(arange(kf0,kf1), ii))                                     */
+  int kf0, kf1;
+  int n_pairs;  /* Schur pairs (row n, row m, depth slot), n,m in window, same depth slot     */
+  int n_rows;   /* P + M rows of E                                                            */
+} ns_ba_plan;
+
+/* Sizes of the int32 index block the plan needs (in int32 elements).                          */
+size_t ns_ba_plan_index_count(const int64_t* ii_host, const int64_t* jj_host, int M, int kf0, int kf1);
+
+/* Fills `plan` and `index_host` (int32[ns_ba_plan_index_count]).  Layout of the index block
+ * (all int32, offsets returned in `offsets_host[8]`):
+ *   [0] kx[K]            sorted unique source-frame ids           (droid_kernels.cu:1706-1710)
+ *   [1] kk[P+M]          depth slot of every E row
+ *   [2] row_pose[P+M]    jj_expanded - kf0  (window pose of the row, may be <0 or >=P)
+ *   [3] src_ptr[K+1]     CSR over edges grouped by depth slot      (accum_cuda :1065-1103)
+ *   [4] src_edge[M]      edge ids in CSR order (stable: ascending edge id inside a slot)
+ *   [5] pairs[3*n_pairs] (row n, row m, slot) in the reference's enumeration order (:1384-1399)
+ *   [6] slot_rows_ptr[K+1], [7] slot_rows[...]  E rows (self loop + edges) per slot, any pose  */
+int ns_ba_plan_build(const int64_t* ii_host, const int64_t* jj_host, int M, int kf0, int kf1,
+                     ns_ba_plan* plan, int32_t* index_host, size_t* offsets_host);
+
+/* reduced_camera_matrix (src/droid.cpp:167-196 -> droid_kernels.cu:1681-1768): K1 (:192-536),
+ * accum (:971-991), EEt6x6 (:1118-1173), Ev6x1 (:1176-1210), SparseBlock (:1240-1316).
+ *   poses [*,7], disps [*,ht,wd], intrinsics[4], extrinsics[7], disps_sens [*,ht,wd],
+ *   targets, weights [M,2,ht,wd], eta [K,ht,wd], ii,jj [M] i64 (device), index = device copy of
+ *   the plan's index block.
+ * outputs: H [6P,6P] f32, v [6P] f32, Q [K,HW], E [P+M,6,HW], w [K,HW]  (all fully written).
+ * workspace: ns_ba_workspace_bytes(plan, ht*wd) bytes, 256-byte aligned, contents undefined.    */
+size_t ns_ba_workspace_bytes(const ns_ba_plan* plan, int HW);
+int ns_reduced_camera_matrix(const float* poses, const float* disps, const float* intrinsics,
+                             const float* extrinsics, const float* disps_sens, const float* targets,
+                             const float* weights, const float* eta, const int64_t* ii, const int64_t* jj,
+                             const ns_ba_plan* plan, const int32_t* index, const size_t* offsets_host, int ht,
+                             int wd, float* H, float* v, float* Q, float* E, float* w, void* workspace,
+                             void* stream);
+
+/* solve_depth (src/droid.cpp:198-218 -> droid_kernels.cu:1772-1825): EvT6x1 (:1213-1238),
+ * accum, dz = Q*(w - .), disp_retr (:1050-1063); disps updated in place, then optionally
+ * clamped to >= clamp_min (visual_frontend.py:1162; pass a negative value to skip).           */
+int ns_solve_depth(const float* dx, float* disps, const float* Q, const float* E, const float* w,
+                   const ns_ba_plan* plan, const int32_t* index, const size_t* offsets_host, int ht, int wd,
+                   float clamp_min, void* stream);
+
+/* Device-resident replacement of the GTSAM round trip in ba() (visual_frontend.py:1123-1158):
+ *   delta = (H [+ prior]) ^-1 v in f64 (dense Cholesky, one workgroup, 6P <= 192),
+ *   world_T_body[kf0+i] <- world_T_body[kf0+i] * Exp(delta_i)   (delta = [omega, v]),
+ *   cam_T_world[kf0+i]  <- cam_T_body * world_T_body[kf0+i]^-1,
+ *   dx [P,6] f32 = delta.  prior_pose (7 floats, device) may be NULL; with a prior, 1/sigma^2 is
+ *   added to the first pose block and -Log(prior^-1 * x0)/sigma^2 to its rhs.
+ *   info (int32, device): 0 ok, k>0 = Cholesky pivot k not positive (dx is zero then).        */
+int ns_ba_solve_retract(const float* H, const float* v, float* world_T_body, float* cam_T_world,
+                        const float* cam_T_body, const float* prior_pose, float prior_sigma, int kf0, int kf1,
+                        float* dx, double* Hfull_out, int32_t* info, void* stream);
+
+/* Depth / pose covariances of ba() (visual_frontend.py:1164-1230): Linv (6P x 6P f32,
+ * inverse Cholesky factor of Hfull) is computed by ns_ba_solve_retract's factor; here
+ *   z_cov[k,px] = Q + sum_j ( sum_rows Q * E_row[:,px] . Linv[6*pose+:, j] )^2               */
+int ns_ba_depth_cov(const float* Linv, const float* Q, const float* E, const ns_ba_plan* plan,
+                    const int32_t* index, const size_t* offsets_host, int HW, float* z_cov, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFSLAM_HIP_H */

@@ -1,0 +1,331 @@
+// corr_lookup.hip -- 4D correlation-volume lookup for gfx950 (MI355X).
+//
+// Replaces corr_index_forward_kernel / corr_index_backward_kernel of the reference
+// (src/correlation_kernels.cu:20-70, 73-124) and fuses the 4-level loop of CorrBlock.__call__
+// (networks/modules/corr.py:40-50) into one launch.
+//
+// Design (HBM-bound gather): one lane per (edge, pixel).  The 8x8 tap window of a pixel is
+// eight 16-byte runs of its private [h2,w2] slice, so each lane issues eight unaligned
+// global_load_dwordx4 up front (8 x 16 B in flight per lane, 8 KiB per wave) instead of the
+// reference's 64 two-byte loads, masks the out-of-image columns with four ANDs per row, and
+// interpolates in packed f16.  The 49 outputs are written channel by channel, each wave store
+// covering 128 contiguous bytes of one channel plane; the reference's zero-fill pass and its
+// 256 global read-modify-writes per pixel do not exist.
+//
+// Numerics (f16): the reference accumulates in c10::Half -- every product and every running sum
+// is rounded to half (float op, then round; double rounding is innocuous for +,* at 24 >= 2*11+2
+// bits) in the loop order tap(a,b), tap(a,b+1), tap(a+1,b), tap(a+1,b+1) for output (a,b), and
+// out-of-image taps are skipped.  Adding a +0 product is the identity on every value the
+// accumulator can hold (it can never be -0), so masking taps to +0 reproduces the skip and the
+// result is bit-identical to the reference's arithmetic.  FP contraction is off in this file.
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+#pragma clang fp contract(off)
+
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct __attribute__((packed, aligned(2))) Run16 {
+  uint32_t d[4];
+};
+
+struct LookupLevels {
+  const _Float16* vol[4];
+  int h2[4];
+  int w2[4];
+  float scale[4];
+  long slice_elems[4];  // h2*w2
+  long total_elems[4];  // E*HW1*h2*w2
+  int num_levels;
+};
+
+__device__ __forceinline__ h2_t as_h2(uint32_t u) { return __builtin_bit_cast(h2_t, u); }
+__device__ __forceinline__ uint32_t as_u32(h2_t h) { return __builtin_bit_cast(uint32_t, h); }
+
+// One (edge,pixel,level).  out points at channel 0 of this pixel; channel stride = HW1 elements.
+__device__ __forceinline__ void lookup_r3_f16(const _Float16* __restrict__ vol, long slice_off, long total,
+                                              int h2, int w2, float x0, float y0,
+                                              _Float16* __restrict__ out, long HW1) {
+  const float fx0 = floorf(x0), fy0 = floorf(y0);
+  // non-finite or far-away coordinates: every tap is outside -> zeros
+  const bool sane = (fabsf(x0) < 1.0e6f) && (fabsf(y0) < 1.0e6f);
+  const float dx = sane ? x0 - fx0 : 0.0f, dy = sane ? y0 - fy0 : 0.0f;
+  const int xb = sane ? (int)fx0 - 3 : -100000;
+  const int yb = sane ? (int)fy0 - 3 : -100000;
+
+  // column masks: half i of the run is a real tap iff 0 <= xb+i < w2
+  uint32_t cm[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int xl = xb + 2 * k, xh = xl + 1;
+    cm[k] = ((xl >= 0 && xl < w2) ? 0x0000ffffu : 0u) | ((xh >= 0 && xh < w2) ? 0xffff0000u : 0u);
+  }
+  const bool any_col = (xb > -8) && (xb < w2);
+
+  // Issue all eight row loads unconditionally (no per-row branches, 8 x 16 B in flight per lane):
+  // rows that are not real taps read the start of the pixel's own slice and are zeroed afterwards.
+  uint32_t row[8][4];
+  bool rv[8];
+  bool need_slow = false;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int y1 = yb + j;
+    const long g0 = slice_off + (long)y1 * w2 + xb;
+    const bool valid = any_col && y1 >= 0 && y1 < h2;
+    const bool inb = g0 >= 0 && g0 + 8 <= total;
+    rv[j] = valid && inb;
+    need_slow |= valid && !inb;
+    const Run16 r = *reinterpret_cast<const Run16*>(vol + (rv[j] ? g0 : slice_off));
+    row[j][0] = r.d[0];
+    row[j][1] = r.d[1];
+    row[j][2] = r.d[2];
+    row[j][3] = r.d[3];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) row[j][k] = rv[j] ? (row[j][k] & cm[k]) : 0u;
+  }
+  if (__builtin_expect(need_slow, 0)) {
+    // a run pokes outside the tensor (first / last slice only): element-wise, bounds-checked
+    const uint16_t* v16 = reinterpret_cast<const uint16_t*>(vol);
+#pragma unroll 1
+    for (int j = 0; j < 8; j++) {
+      const int y1 = yb + j;
+      const long g0 = slice_off + (long)y1 * w2 + xb;
+      const bool valid = any_col && y1 >= 0 && y1 < h2;
+      if (valid && !(g0 >= 0 && g0 + 8 <= total)) {
+        uint32_t t[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int xl = xb + 2 * k;
+          const uint32_t lo = (xl >= 0 && xl < w2) ? v16[g0 + 2 * k] : 0u;
+          const uint32_t hi = (xl + 1 >= 0 && xl + 1 < w2) ? v16[g0 + 2 * k + 1] : 0u;
+          t[k] = lo | (hi << 16);
+        }
+        // static indexing only (runtime-indexed register arrays would spill to scratch)
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++)
+          if (jj == j) {
+            row[jj][0] = t[0]; row[jj][1] = t[1]; row[jj][2] = t[2]; row[jj][3] = t[3];
+          }
+      }
+    }
+  }
+
+  // weights, rounded to half exactly as `scalar_t(dx*dy)` etc. (correlation_kernels.cu:56-65)
+  // The f32 product must be rounded to f32 BEFORE the conversion (the reference converts a float
+  // expression); without the empty asm the compiler fuses mul+cvt into v_fma_mixlo_f16, which
+  // rounds once and differs from the reference in double-rounding cases.
+  float p00 = (1.0f - dx) * (1.0f - dy), p01 = (1.0f - dx) * dy, p10 = dx * (1.0f - dy), p11 = dx * dy;
+  asm volatile("" : "+v"(p00), "+v"(p01), "+v"(p10), "+v"(p11));
+  const _Float16 w00 = (_Float16)p00, w01 = (_Float16)p01, w10 = (_Float16)p10, w11 = (_Float16)p11;
+  const h2_t W00 = {w00, w00}, W01 = {w01, w01}, W10 = {w10, w10}, W11 = {w11, w11};
+
+  // shifted rows: S[j][a] = T[a+1][j]
+  uint32_t sh[8][4];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    sh[j][0] = __builtin_amdgcn_alignbit(row[j][1], row[j][0], 16);
+    sh[j][1] = __builtin_amdgcn_alignbit(row[j][2], row[j][1], 16);
+    sh[j][2] = __builtin_amdgcn_alignbit(row[j][3], row[j][2], 16);
+    sh[j][3] = row[j][3] >> 16;
+  }
+
+  uint16_t* o16 = reinterpret_cast<uint16_t*>(out);
+#pragma unroll
+  for (int b = 0; b < 7; b++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      h2_t acc = as_h2(row[b][k]) * W00;           // tap (a  , b  )
+      acc = acc + as_h2(row[b + 1][k]) * W01;      // tap (a  , b+1)
+      acc = acc + as_h2(sh[b][k]) * W10;           // tap (a+1, b  )
+      acc = acc + as_h2(sh[b + 1][k]) * W11;       // tap (a+1, b+1)
+      const uint32_t u = as_u32(acc);
+      const int a0 = 2 * k;
+      o16[(long)(a0 * 7 + b) * HW1] = (uint16_t)(u & 0xffffu);
+      if (a0 + 1 < 7) o16[(long)((a0 + 1) * 7 + b) * HW1] = (uint16_t)(u >> 16);
+    }
+  }
+}
+
+// Fused pyramid lookup: grid = (ceil(E*HW1/256), num_levels)
+__global__ __launch_bounds__(256) void corr_lookup_pyramid_kernel(LookupLevels L, const float* __restrict__ coords,
+                                                                  int interleaved, _Float16* __restrict__ out,
+                                                                  int E, int HW1) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)E * HW1) return;
+  const int lvl = blockIdx.y;
+  const int n = (int)(idx / HW1);
+  const int p = (int)(idx - (long)n * HW1);
+  float cx, cy;
+  if (interleaved) {
+    const float2 c = *reinterpret_cast<const float2*>(coords + 2 * idx);
+    cx = c.x;
+    cy = c.y;
+  } else {
+    cx = coords[((long)n * 2 + 0) * HW1 + p];
+    cy = coords[((long)n * 2 + 1) * HW1 + p];
+  }
+  const float s = L.scale[lvl];
+  _Float16* o = out + ((long)n * (L.num_levels * 49) + lvl * 49) * HW1 + p;
+  lookup_r3_f16(L.vol[lvl], idx * L.slice_elems[lvl], L.total_elems[lvl], L.h2[lvl], L.w2[lvl], cx * s, cy * s, o,
+                HW1);
+}
+
+// Generic single-level kernel (any radius, f16 or f32): one lane per pixel, scalar taps.
+// Same arithmetic order as the reference; used by the drop-in op when radius != 3 or dtype f32.
+template <typename T>
+__global__ __launch_bounds__(256) void corr_index_generic_kernel(const T* __restrict__ vol,
+                                                                 const float* __restrict__ coords,
+                                                                 T* __restrict__ out, int B, int HW1, int h2, int w2,
+                                                                 int r) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * HW1) return;
+  const int n = (int)(idx / HW1);
+  const int p = (int)(idx - (long)n * HW1);
+  const float x0 = coords[((long)n * 2 + 0) * HW1 + p];
+  const float y0 = coords[((long)n * 2 + 1) * HW1 + p];
+  const float fx0 = floorf(x0), fy0 = floorf(y0);
+  const bool sane = (fabsf(x0) < 1.0e6f) && (fabsf(y0) < 1.0e6f);
+  const float dx = sane ? x0 - fx0 : 0.0f, dy = sane ? y0 - fy0 : 0.0f;
+  const int xb = sane ? (int)fx0 - r : -100000;
+  const int yb = sane ? (int)fy0 - r : -100000;
+  const int rd = 2 * r + 1;
+  float p00 = (1.0f - dx) * (1.0f - dy), p01 = (1.0f - dx) * dy, p10 = dx * (1.0f - dy), p11 = dx * dy;
+  asm volatile("" : "+v"(p00), "+v"(p01), "+v"(p10), "+v"(p11));  // no mul+cvt fusion (see lookup_r3_f16)
+  const T w00 = (T)p00, w01 = (T)p01, w10 = (T)p10, w11 = (T)p11;
+  const T* v = vol + idx * (long)h2 * w2;
+  T* o = out + (long)n * rd * rd * HW1 + p;
+  auto tap = [&](int i, int j) -> T {
+    const int x1 = xb + i, y1 = yb + j;
+    return (x1 >= 0 && x1 < w2 && y1 >= 0 && y1 < h2) ? v[(long)y1 * w2 + x1] : (T)0;
+  };
+  for (int a = 0; a < rd; a++)
+    for (int b = 0; b < rd; b++) {
+      T acc;
+      if constexpr (sizeof(T) == 2) {
+        acc = tap(a, b) * w00;
+        acc = acc + tap(a, b + 1) * w01;
+        acc = acc + tap(a + 1, b) * w10;
+        acc = acc + tap(a + 1, b + 1) * w11;
+      } else {
+        // float: `corr += s*w` contracts to an FMA under nvcc's default -fmad=true
+        acc = __builtin_fmaf(tap(a, b), w00, 0.0f);
+        acc = __builtin_fmaf(tap(a, b + 1), w01, acc);
+        acc = __builtin_fmaf(tap(a + 1, b), w10, acc);
+        acc = __builtin_fmaf(tap(a + 1, b + 1), w11, acc);
+      }
+      o[(long)(a * rd + b) * HW1] = acc;
+    }
+}
+
+// corr_index_backward_kernel<float>: one lane per pixel, each lane owns its private slice of
+// volume_grad, so the `+=` needs no atomics (same as the reference).
+__global__ __launch_bounds__(256) void corr_index_backward_kernel(const float* __restrict__ coords,
+                                                                  const float* __restrict__ cg,
+                                                                  float* __restrict__ vg, int B, int HW1, int h2,
+                                                                  int w2, int r) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * HW1) return;
+  const int n = (int)(idx / HW1);
+  const int p = (int)(idx - (long)n * HW1);
+  const float x0 = coords[((long)n * 2 + 0) * HW1 + p];
+  const float y0 = coords[((long)n * 2 + 1) * HW1 + p];
+  const float fx0 = floorf(x0), fy0 = floorf(y0);
+  const float dx = x0 - fx0, dy = y0 - fy0;
+  const bool sane = (fabsf(x0) < 1.0e6f) && (fabsf(y0) < 1.0e6f);
+  const int xb = sane ? (int)fx0 - r : -100000;
+  const int yb = sane ? (int)fy0 - r : -100000;
+  const int rd = 2 * r + 1;
+  const float* g = cg + (long)n * rd * rd * HW1 + p;
+  float* v = vg + idx * (long)h2 * w2;
+  for (int i = 0; i < rd + 1; i++)
+    for (int j = 0; j < rd + 1; j++) {
+      const int x1 = xb + i, y1 = yb + j;
+      if (x1 >= 0 && x1 < w2 && y1 >= 0 && y1 < h2) {
+        float acc = 0.0f;
+        if (i > 0 && j > 0) acc += g[(long)((i - 1) * rd + (j - 1)) * HW1] * (dx * dy);
+        if (i > 0 && j < rd) acc += g[(long)((i - 1) * rd + j) * HW1] * (dx * (1.0f - dy));
+        if (i < rd && j > 0) acc += g[(long)(i * rd + (j - 1)) * HW1] * ((1.0f - dx) * dy);
+        if (i < rd && j < rd) acc += g[(long)(i * rd + j) * HW1] * ((1.0f - dx) * (1.0f - dy));
+        v[(long)y1 * w2 + x1] += acc;
+      }
+    }
+}
+
+extern "C" int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_levels, const float* coords,
+                                      int coords_interleaved, void* out, int E, int h1, int w1, void* stream) {
+  NS_REQUIRE(pyr_host && coords && out, "ns_corr_lookup_pyramid: null pointer");
+  NS_REQUIRE(num_levels >= 1 && num_levels <= 4, "ns_corr_lookup_pyramid: num_levels=%d not in 1..4", num_levels);
+  NS_REQUIRE(E >= 0 && h1 > 0 && w1 > 0, "ns_corr_lookup_pyramid: bad shape E=%d h1=%d w1=%d", E, h1, w1);
+  if (E == 0) return NS_OK;
+  LookupLevels L;
+  L.num_levels = num_levels;
+  const long HW1 = (long)h1 * w1;
+  for (int l = 0; l < 4; l++) {
+    const int ll = l < num_levels ? l : num_levels - 1;
+    L.vol[l] = (const _Float16*)pyr_host[ll];
+    NS_REQUIRE(L.vol[l] != nullptr, "ns_corr_lookup_pyramid: pyr[%d] is null", ll);
+    L.h2[l] = h1 >> ll;
+    L.w2[l] = w1 >> ll;
+    L.scale[l] = 1.0f / (float)(1 << ll);
+    L.slice_elems[l] = (long)L.h2[l] * L.w2[l];
+    L.total_elems[l] = (long)E * HW1 * L.slice_elems[l];
+    NS_REQUIRE(L.h2[l] > 0 && L.w2[l] > 0, "ns_corr_lookup_pyramid: level %d is empty", ll);
+  }
+  dim3 grid(ns_cdiv((long)E * HW1, 256), num_levels);
+  hipLaunchKernelGGL(corr_lookup_pyramid_kernel, grid, dim3(256), 0, (hipStream_t)stream, L, coords,
+                     coords_interleaved, (_Float16*)out, E, (int)HW1);
+  NS_CHECK_LAUNCH("corr_lookup_pyramid_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_corr_index_forward(const void* volume, const float* coords, void* corr, int dtype, int B, int h1,
+                                     int w1, int h2, int w2, int radius, void* stream) {
+  NS_REQUIRE(volume && coords && corr, "ns_corr_index_forward: null pointer");
+  NS_REQUIRE(dtype == NS_F16 || dtype == NS_F32, "ns_corr_index_forward: dtype %d unsupported", dtype);
+  NS_REQUIRE(B >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0 && radius >= 0,
+             "ns_corr_index_forward: bad shape B=%d h1=%d w1=%d h2=%d w2=%d r=%d", B, h1, w1, h2, w2, radius);
+  if (B == 0) return NS_OK;
+  const long HW1 = (long)h1 * w1;
+  if (dtype == NS_F16 && radius == 3) {
+    LookupLevels L;
+    L.num_levels = 1;
+    for (int l = 0; l < 4; l++) {
+      L.vol[l] = (const _Float16*)volume;
+      L.h2[l] = h2;
+      L.w2[l] = w2;
+      L.scale[l] = 1.0f;
+      L.slice_elems[l] = (long)h2 * w2;
+      L.total_elems[l] = (long)B * HW1 * h2 * w2;
+    }
+    dim3 grid(ns_cdiv((long)B * HW1, 256), 1);
+    hipLaunchKernelGGL(corr_lookup_pyramid_kernel, grid, dim3(256), 0, (hipStream_t)stream, L, coords, 0,
+                       (_Float16*)corr, B, (int)HW1);
+    NS_CHECK_LAUNCH("corr_lookup_pyramid_kernel");
+    return NS_OK;
+  }
+  dim3 grid(ns_cdiv((long)B * HW1, 256));
+  if (dtype == NS_F16)
+    hipLaunchKernelGGL(corr_index_generic_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)volume, coords, (_Float16*)corr, B, (int)HW1, h2, w2, radius);
+  else
+    hipLaunchKernelGGL(corr_index_generic_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const float*)volume, coords, (float*)corr, B, (int)HW1, h2, w2, radius);
+  NS_CHECK_LAUNCH("corr_index_generic_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_corr_index_backward(const float* coords, const float* corr_grad, float* volume_grad, int B, int h1,
+                                      int w1, int h2, int w2, int radius, void* stream) {
+  NS_REQUIRE(coords && corr_grad && volume_grad, "ns_corr_index_backward: null pointer");
+  NS_REQUIRE(B >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0 && radius >= 0, "ns_corr_index_backward: bad shape");
+  if (B == 0) return NS_OK;
+  dim3 grid(ns_cdiv((long)B * h1 * w1, 256));
+  hipLaunchKernelGGL(corr_index_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, coords, corr_grad,
+                     volume_grad, B, h1 * w1, h2, w2, radius);
+  NS_CHECK_LAUNCH("corr_index_backward_kernel");
+  return NS_OK;
+}

@@ -1,0 +1,72 @@
+"""ctypes loader for libnerfslam_hip.so (the C-ABI of include/nerfslam_hip.h).
+
+The product path has NO fallback: if the shared library is missing or an entry point is
+absent, importing / calling raises.  torch must be imported first so that the library binds
+to the HIP runtime torch already loaded (same soname libamdhip64.so.7) and can therefore use
+torch's streams and device pointers.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch  # noqa: F401  (must precede CDLL: see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libnerfslam_hip.so")
+
+_lock = threading.Lock()
+_lib = None
+
+
+class NerfSlamHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise NerfSlamHipError(
+                        f"{LIB_PATH} is missing: build it with `make -C nerf-slam_amd/csrc` "
+                        "(or __graft_entry__.build()). There is no CPU fallback.")
+                L = C.CDLL(LIB_PATH)
+                L.ns_last_error.restype = C.c_char_p
+                L.ns_arch.restype = C.c_char_p
+                for name in [n for n in ("ns_ba_plan_index_count", "ns_ba_workspace_bytes") if hasattr(L, n)]:
+                    getattr(L, name).restype = C.c_size_t
+                _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().ns_last_error().decode("utf-8", "replace")
+        raise NerfSlamHipError(f"{what} failed ({status}): {msg}")
+
+
+def ptr(t):
+    """Device (or host) address of a tensor as void*; None -> NULL."""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    if not torch.cuda.is_available():
+        raise NerfSlamHipError("no HIP device visible: the nerfslam kernels need an MI355X (gfx950)")
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NerfSlamHipError("nerfslam ops take device tensors; got a CPU tensor (there is no CPU fallback)")
+
+
+def check_contiguous(**named):
+    """The reference's only input validation: TORCH_CHECK(x.is_contiguous()) (src/droid.cpp:129-130)."""
+    for name, t in named.items():
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} must be contiguous")
