@@ -66,17 +66,18 @@ int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_levels, const fl
  * f16 in/out, f32 accumulate, one rounding.  in [nslices,h,w] -> out [nslices,h/2,w/2].       */
 int ns_corr_pool2x2(const void* in, void* out, long nslices, int h, int w, void* stream);
 
-/* CorrBlock.corr + pyramid fused (corr.py:63-72 + :35-38): fmap1,fmap2 [n,C=128,HW] f16
- * (channel-major exactly as the reference reshapes them), each divided by 4 in f16;
- * writes pyr[0..num_levels-1] (pyr[l] = [n,ht,wd,ht>>l,wd>>l] f16).                          */
-int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, void* const* pyr_host, int num_levels,
-                           int n, int C, int ht, int wd, void* stream);
-
 /* altcorr_forward (src/droid.cpp:303-313 -> src/altcorr_kernel.cu:290-319, kernel :28-149)
  *   fmap1 [B,H1,W1,C] f32, fmap2 [B,H2,W2,C] f32 (channels-last), coords [B,N,H1,W1,2] f32,
  *   corr [B,N,(2r+1)^2,H1,W1] f32 (written completely).                                      */
 int ns_altcorr_forward(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B,
                        int H1, int W1, int H2, int W2, int C, int N, int radius, void* stream);
+
+/* Fused AltCorrBlock.__call__ (networks/modules/corr.py:107-126): every pyramid level in one launch.
+ *   fmaps_host[l] -> [nframes, H1>>l, W1>>l, C] f32 channels-last (features already divided by 4 and
+ *   average-pooled as corr.py:98-105 does), ii,jj [E] i64 frame ids, coords [E,H1,W1,2] f32 (divided
+ *   by 2^l in the kernel); out [E, num_levels*49, H1, W1] f32 == cat over levels of altcorr_forward. */
+int ns_altcorr_pyramid(const float* const* fmaps_host, int num_levels, const int64_t* ii, const int64_t* jj,
+                       const float* coords, float* out, int E, int H1, int W1, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Geometry
@@ -161,20 +162,38 @@ int ns_solve_depth(const float* dx, float* disps, const float* Q, const float* E
                    const ns_ba_plan* plan, const int32_t* index, const size_t* offsets_host, int ht, int wd,
                    float clamp_min, void* stream);
 
-/* Device-resident replacement of the GTSAM round trip in ba() (visual_frontend.py:1123-1158):
- *   delta = (H [+ prior]) ^-1 v in f64 (dense Cholesky, one workgroup, 6P <= 192),
- *   world_T_body[kf0+i] <- world_T_body[kf0+i] * Exp(delta_i)   (delta = [omega, v]),
- *   cam_T_world[kf0+i]  <- cam_T_body * world_T_body[kf0+i]^-1,
+/* K1 alone -- projective_transform_kernel with the reference kernel's own per-edge outputs
+ * (droid_kernels.cu:192-536): Hs [4,M,6,6], vs [2,M,6], Eiz/Ejz [M,6,HW], Cii/bz [M,HW].
+ * etab_ws: scratch of M*80 floats.                                                            */
+int ns_projective_transform(const float* targets, const float* weights, const float* poses, const float* disps,
+                            const float* intrinsics, const float* extrinsics, const int64_t* ii,
+                            const int64_t* jj, int M, int ht, int wd, float* Hs, float* vs, float* Eiz,
+                            float* Ejz, float* Cii, float* bz, float* etab_ws, void* stream);
+
+/* Device-resident replacement of the GTSAM round trip in ba() (visual_frontend.py:1123-1158),
+ * one workgroup, f64 in LDS, 6P <= 192 (NS_ENOSUP above that: the host falls back to rocSOLVER
+ * via torch.linalg + ns_ba_retract):
+ *   (triu(H) mirrored [+ ep + lm*diag] [+ prior]) delta = v      (dense blocked Cholesky)
+ *   mode 0:  world_T_body[kf0+i] <- world_T_body[kf0+i] * Exp(delta_i)   (delta = [omega, v]),
+ *            cam_T_world[kf0+i]  <- cam_T_body * world_T_body[kf0+i]^-1
+ *   mode 1:  solve only
  *   dx [P,6] f32 = delta.  prior_pose (7 floats, device) may be NULL; with a prior, 1/sigma^2 is
  *   added to the first pose block and -Log(prior^-1 * x0)/sigma^2 to its rhs.
- *   info (int32, device): 0 ok, k>0 = Cholesky pivot k not positive (dx is zero then).        */
-int ns_ba_solve_retract(const float* H, const float* v, float* world_T_body, float* cam_T_world,
-                        const float* cam_T_body, const float* prior_pose, float prior_sigma, int kf0, int kf1,
-                        float* dx, double* Hfull_out, int32_t* info, void* stream);
+ *   Optional outputs (NULL to skip): Hfull_out [6P,6P] f64 (the system actually solved),
+ *   Linv_out [6P,6P] f32 (inverse Cholesky factor; needs Linv_ws [6P,6P] f64 scratch),
+ *   sigma_g_out [P,6,6] f32 (diagonal blocks of the inverse, visual_frontend.py:1178-1189).
+ *   info (int32, device): 0 ok, k>0 = pivot k not positive (dx is zero, nothing retracted).   */
+int ns_ba_solve(const float* H, const float* v, float* world_T_body, float* cam_T_world,
+                const float* cam_T_body, const float* prior_pose, float prior_sigma, float ep, float lm, int kf0,
+                int kf1, int mode, float* dx, double* Hfull_out, float* Linv_out, double* Linv_ws,
+                float* sigma_g_out, int32_t* info, void* stream);
 
-/* Depth / pose covariances of ba() (visual_frontend.py:1164-1230): Linv (6P x 6P f32,
- * inverse Cholesky factor of Hfull) is computed by ns_ba_solve_retract's factor; here
- *   z_cov[k,px] = Q + sum_j ( sum_rows Q * E_row[:,px] . Linv[6*pose+:, j] )^2               */
+/* The retraction of ns_ba_solve mode 0 on its own (dx given).                                 */
+int ns_ba_retract(const float* dx, float* world_T_body, float* cam_T_world, const float* cam_T_body, int kf0,
+                  int kf1, void* stream);
+
+/* Depth covariances of ba() (visual_frontend.py:1191-1219):
+ *   z_cov[k,px] = Q + sum_j ( sum_{rows n of slot k, pose a in window} Q * E_n[:,px] . Linv[6a+:, j] )^2 */
 int ns_ba_depth_cov(const float* Linv, const float* Q, const float* E, const ns_ba_plan* plan,
                     const int32_t* index, const size_t* offsets_host, int HW, float* z_cov, void* stream);
 

@@ -1,0 +1,186 @@
+// altcorr.hip -- on-the-fly correlation lookup (no HW^2 volume) for gfx950.
+//
+// Replaces altcorr_forward_kernel (src/altcorr_kernel.cu:28-149; caller networks/modules/corr.py:92-140).
+// The reference runs 32-thread blocks (half a CDNA wavefront), stages 32x32 tiles through shared
+// memory with one barrier per tap and does 4 global read-modify-writes per tap and channel slab.
+//
+// Here one wave64 owns one (edge, pixel) at a time:
+//   * channels-last features make a window row (8 taps x C floats) ONE contiguous 4 KiB run, so
+//     the 8x8 window is fetched as 32 fully coalesced 1 KiB wave loads (lane = 4 channels of a tap);
+//   * each lane forms 32 four-channel partial dot products; a 31-step reduce-scatter butterfly
+//     inside each 32-lane half (instead of 32 x 5 full reductions) leaves exactly one finished tap
+//     per lane;
+//   * the bilinear blend of the 4 neighbouring taps is three lane permutes; 49 lanes store.
+// No LDS, no barriers, no atomics, no zero-fill.  Arithmetic is f32 like the reference's float
+// dispatch (corr.py:121); summation order differs from the reference's 32-channel slabs, so the
+// parity tolerance is relative 1e-5 of max|corr| (tests/test_altcorr.py).
+#include "common.h"
+
+#define ALT_PIX_PER_WAVE 8
+
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+// One (edge, pixel, level) by one wave: f1 = 128-channel-slab feature of the pixel, f2 = feature map
+// of the target frame at this level.  `out` points at channel 0 of this pixel, channel stride cs.
+__device__ __forceinline__ void altcorr_pixel(const float* __restrict__ f1, const float* __restrict__ f2b, int H2,
+                                              int W2, int C, float x2, float y2, float* __restrict__ out, long cs,
+                                              int lane) {
+  const int half = lane >> 5;   // which of the two interleaved tap columns
+  const int cl = lane & 31;     // channel quad inside a 128-channel slab
+  // output lane layout == finished-tap layout: y = cl>>2, x = half + 2*(cl&3)
+  const int oy = cl >> 2, ox = half + 2 * (cl & 3);
+  // lanes holding taps (y, x+1), (y+1, x), (y+1, x+1)
+  const int src_x1 = (half == 0) ? lane + 32 : lane - 32 + 1;
+  const int src_y1 = lane + 4;
+  const int src_xy = src_x1 + 4;
+
+  const bool sane = (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
+  const float fx0 = floorf(x2), fy0 = floorf(y2);
+  const float dx = sane ? x2 - fx0 : 0.0f, dy = sane ? y2 - fy0 : 0.0f;
+  const int xb = sane ? (int)fx0 - 3 : -100000;
+  const int yb = sane ? (int)fy0 - 3 : -100000;
+
+  float p[32];
+#pragma unroll
+  for (int v = 0; v < 32; v++) p[v] = 0.0f;
+
+  for (int c0 = 0; c0 < C; c0 += 128) {
+    const int ch = c0 + 4 * cl;
+    const bool chok = ch < C;  // C % 4 == 0 is required by the entry points
+    const float4 a = chok ? *reinterpret_cast<const float4*>(f1 + ch) : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int iy = 0; iy < 8; iy++) {
+      const int h2 = yb + iy;
+      const bool rowok = chok && h2 >= 0 && h2 < H2;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int w2 = xb + half + 2 * k;
+        if (rowok && w2 >= 0 && w2 < W2) {
+          const float4 f = *reinterpret_cast<const float4*>(f2b + ((long)h2 * W2 + w2) * C + ch);
+          p[iy * 4 + k] += dot4(a, f);
+        }
+      }
+    }
+  }
+
+  // reduce-scatter over the 32 lanes of this half: after the step on lane bit s, a lane keeps the
+  // values whose index has bit s equal to its own; after 5 steps lane cl holds the total of value cl.
+#pragma unroll
+  for (int s = 4; s >= 0; s--) {
+    const int cnt = 1 << s;
+    const bool up = (cl >> s) & 1;
+#pragma unroll
+    for (int i = 0; i < cnt; i++) {
+      const float lo = p[i], hi = p[i + cnt];
+      const float send = up ? lo : hi;
+      const float keep = up ? hi : lo;
+      p[i] = keep + __shfl_xor(send, cnt, 64);
+    }
+  }
+  const float s00 = p[0];  // tap (oy, ox)
+  const float s01 = __shfl(s00, src_x1, 64);
+  const float s10 = __shfl(s00, src_y1, 64);
+  const float s11 = __shfl(s00, src_xy, 64);
+  if (oy < 7 && ox < 7) {
+    // reference weights (altcorr_kernel.cu:112-115): se, sw, ne, nw as seen from the output cell
+    const float val = s00 * ((1.0f - dy) * (1.0f - dx)) + s01 * ((1.0f - dy) * dx) + s10 * (dy * (1.0f - dx)) +
+                      s11 * (dy * dx);
+    out[(long)(oy + 7 * ox) * cs] = val;  // channel = iy + 7*ix (:102-105)
+  }
+}
+
+// drop-in op: pre-gathered per-edge feature maps, one level, N coordinate sets
+__global__ __launch_bounds__(256) void altcorr_forward_kernel(const float* __restrict__ fmap1,
+                                                              const float* __restrict__ fmap2,
+                                                              const float* __restrict__ coords,
+                                                              float* __restrict__ corr, int B, int H1, int W1,
+                                                              int H2, int W2, int C, int N) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long HW1 = (long)H1 * W1;
+  const long ntask = (long)B * N * HW1;
+  const long first = ((long)blockIdx.x * 4 + wave) * ALT_PIX_PER_WAVE;
+  for (int t = 0; t < ALT_PIX_PER_WAVE; t++) {
+    const long task = first + t;
+    if (task >= ntask) return;  // wave-uniform
+    const long pix = task % HW1;
+    const long bn = task / HW1;
+    const int b = (int)(bn / N);
+    const float2 c = *reinterpret_cast<const float2*>(coords + task * 2);
+    altcorr_pixel(fmap1 + ((long)b * HW1 + pix) * C, fmap2 + (long)b * H2 * W2 * C, H2, W2, C, c.x, c.y,
+                  corr + bn * 49 * HW1 + pix, HW1, lane);
+  }
+}
+
+// Fused AltCorrBlock.__call__ (networks/modules/corr.py:107-126): all pyramid levels in one launch,
+// feature maps addressed by frame index (no per-edge gather copies, no .float() copies, no cat).
+struct AltPyramid {
+  const float* fmap[4];  // level l: [nframes, H>>l, W>>l, C] channels-last f32 (already / 4)
+  int num_levels;
+};
+
+__global__ __launch_bounds__(256) void altcorr_pyramid_kernel(AltPyramid P, const int64_t* __restrict__ ii,
+                                                              const int64_t* __restrict__ jj,
+                                                              const float* __restrict__ coords,
+                                                              float* __restrict__ out, int E, int H1, int W1, int C) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int lvl = blockIdx.y;
+  const long HW1 = (long)H1 * W1;
+  const long ntask = (long)E * HW1;
+  const int H2 = H1 >> lvl, W2 = W1 >> lvl;
+  const float scale = 1.0f / (float)(1 << lvl);
+  const long first = ((long)blockIdx.x * 4 + wave) * ALT_PIX_PER_WAVE;
+  for (int t = 0; t < ALT_PIX_PER_WAVE; t++) {
+    const long task = first + t;
+    if (task >= ntask) return;
+    const long pix = task % HW1;
+    const int e = (int)(task / HW1);
+    const long fi = ii[e], fj = jj[e];
+    const float2 c = *reinterpret_cast<const float2*>(coords + task * 2);
+    altcorr_pixel(P.fmap[0] + (fi * HW1 + pix) * C, P.fmap[lvl] + fj * (long)H2 * W2 * C, H2, W2, C, c.x * scale,
+                  c.y * scale, out + ((long)e * P.num_levels * 49 + lvl * 49) * HW1 + pix, HW1, lane);
+  }
+}
+
+extern "C" int ns_altcorr_pyramid(const float* const* fmaps_host, int num_levels, const int64_t* ii,
+                                  const int64_t* jj, const float* coords, float* out, int E, int H1, int W1, int C,
+                                  void* stream) {
+  NS_REQUIRE(fmaps_host && ii && jj && coords && out, "ns_altcorr_pyramid: null pointer");
+  NS_REQUIRE(num_levels >= 1 && num_levels <= 4, "ns_altcorr_pyramid: num_levels=%d not in 1..4", num_levels);
+  NS_REQUIRE(E >= 0 && H1 > 0 && W1 > 0 && C > 0 && C % 4 == 0, "ns_altcorr_pyramid: bad shape");
+  NS_REQUIRE((H1 >> (num_levels - 1)) > 0 && (W1 >> (num_levels - 1)) > 0, "ns_altcorr_pyramid: level is empty");
+  if (E == 0) return NS_OK;
+  AltPyramid P;
+  P.num_levels = num_levels;
+  for (int l = 0; l < 4; l++) {
+    P.fmap[l] = fmaps_host[l < num_levels ? l : num_levels - 1];
+    NS_REQUIRE(P.fmap[l] != nullptr, "ns_altcorr_pyramid: fmaps[%d] is null", l);
+  }
+  const long ntask = (long)E * H1 * W1;
+  dim3 grid(ns_cdiv(ntask, 4 * ALT_PIX_PER_WAVE), num_levels);
+  hipLaunchKernelGGL(altcorr_pyramid_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, out, E, H1,
+                     W1, C);
+  NS_CHECK_LAUNCH("altcorr_pyramid_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_altcorr_forward(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B,
+                                  int H1, int W1, int H2, int W2, int C, int N, int radius, void* stream) {
+  NS_REQUIRE(fmap1 && fmap2 && coords && corr, "ns_altcorr_forward: null pointer");
+  NS_REQUIRE(B >= 0 && N >= 0 && H1 > 0 && W1 > 0 && H2 > 0 && W2 > 0 && C > 0, "ns_altcorr_forward: bad shape");
+  if (radius != 3) {
+    ns_set_error("ns_altcorr_forward: only radius 3 is built (the reference never uses another, corr.py:93)");
+    return NS_ENOSUP;
+  }
+  NS_REQUIRE(C % 4 == 0, "ns_altcorr_forward: C=%d must be a multiple of 4", C);
+  const long ntask = (long)B * N * H1 * W1;
+  if (ntask == 0) return NS_OK;
+  const int blocks = ns_cdiv(ntask, 4 * ALT_PIX_PER_WAVE);
+  hipLaunchKernelGGL(altcorr_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, fmap1, fmap2, coords,
+                     corr, B, H1, W1, H2, W2, C, N);
+  NS_CHECK_LAUNCH("altcorr_forward_kernel");
+  return NS_OK;
+}

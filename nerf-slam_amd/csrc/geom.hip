@@ -1,0 +1,204 @@
+// geom.hip -- frame distance, projection maps, back-projection, depth filter (gfx950).
+//
+//   K3 frame_distance_kernel   src/droid_kernels.cu:630-769   (live: keyframe selection, proximity edges)
+//   K2 projmap_kernel          :539-628                        (dead in the live path, kept for API parity)
+//   K5 iproj_kernel            :896-967                        (dead)
+//   K4 depth_filter_kernel     :773-892                        (dead)
+#include "common.h"
+#include "se3.h"
+
+// One workgroup per frame pair.  The three sums are reduced in a FIXED order (lane-strided
+// partials, xor-butterfly inside each wave, waves 0..3 added in order) so the result is
+// bit-reproducible run to run: add_proximity_factors argsorts these distances
+// (visual_frontend.py:750) and the factor-graph indices must not depend on scheduling.
+__global__ __launch_bounds__(256) void frame_distance_kernel(const float* __restrict__ poses,
+                                                             const float* __restrict__ disps,
+                                                             const float* __restrict__ intr,
+                                                             const int64_t* __restrict__ ii,
+                                                             const int64_t* __restrict__ jj, float* __restrict__ dist,
+                                                             int HW, int wd, float beta) {
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int ix = (int)ii[b], jx = (int)jj[b];
+  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  float tij[3], qij[4];
+  se3::rel_se3(poses + (long)ix * 7, poses + (long)ix * 7 + 3, poses + (long)jx * 7, poses + (long)jx * 7 + 3, tij,
+               qij);
+  float accum = 0.0f, valid = 0.0f, total = 0.0f;
+  const float omb = 1.0f - beta;
+  const float* __restrict__ disp = disps + (long)ix * HW;
+  for (int k = tid; k < HW; k += 256) {
+    const int i = k / wd, j = k - i * wd;
+    const float u = (float)j, v = (float)i;
+    float Xi[4], Xj[4];
+    Xi[0] = (u - cx) / fx;
+    Xi[1] = (v - cy) / fy;
+    Xi[2] = 1.0f;
+    Xi[3] = disp[k];
+    se3::act_se3(tij, qij, Xi, Xj);
+    float du = fx * (Xj[0] / Xj[2]) + cx - u;
+    float dv = fy * (Xj[1] / Xj[2]) + cy - v;
+    float d = sqrtf(du * du + dv * dv);
+    total += beta;
+    if (Xj[2] > NS_MIN_DEPTH) {
+      accum += beta * d;
+      valid += beta;
+    }
+    // translation-only flow (:730-748)
+    const float X0 = Xi[0] + Xi[3] * tij[0];
+    const float X1 = Xi[1] + Xi[3] * tij[1];
+    const float X2 = Xi[2] + Xi[3] * tij[2];
+    du = fx * (X0 / X2) + cx - u;
+    dv = fy * (X1 / X2) + cy - v;
+    d = sqrtf(du * du + dv * dv);
+    total += omb;
+    if (X2 > NS_MIN_DEPTH) {
+      accum += omb * d;
+      valid += omb;
+    }
+  }
+  __shared__ float red[3][4];
+  const int wave = tid >> 6, lane = tid & 63;
+  accum = wave_sum(accum);
+  valid = wave_sum(valid);
+  total = wave_sum(total);
+  if (lane == 0) {
+    red[0][wave] = accum;
+    red[1][wave] = valid;
+    red[2][wave] = total;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float A = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    const float V = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    const float Tt = ((red[2][0] + red[2][1]) + red[2][2]) + red[2][3];
+    dist[b] = ((double)V / ((double)Tt + 1e-8) < 0.75) ? 1000.0f : A / V;  // (:767)
+  }
+}
+
+__global__ __launch_bounds__(256) void projmap_kernel(const float* __restrict__ poses,
+                                                      const float* __restrict__ disps,
+                                                      const float* __restrict__ intr, const int64_t* __restrict__ ii,
+                                                      const int64_t* __restrict__ jj, float* __restrict__ coords,
+                                                      float* __restrict__ valid, int HW, int wd) {
+  const int b = blockIdx.x;
+  const int k = blockIdx.y * 256 + threadIdx.x;
+  if (k >= HW) return;
+  const int ix = (int)ii[b], jx = (int)jj[b];
+  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  float tij[3], qij[4];
+  se3::rel_se3(poses + (long)ix * 7, poses + (long)ix * 7 + 3, poses + (long)jx * 7, poses + (long)jx * 7 + 3, tij,
+               qij);
+  const int i = k / wd, j = k - i * wd;
+  const float u = (float)j, v = (float)i;
+  float Xi[4] = {(u - cx) / fx, (v - cy) / fy, 1.0f, disps[(long)ix * HW + k]}, Xj[4];
+  se3::act_se3(tij, qij, Xi, Xj);
+  float c0 = u, c1 = v;
+  if (Xj[2] > 0.01f) {
+    c0 = fx * (Xj[0] / Xj[2]) + cx;
+    c1 = fy * (Xj[1] / Xj[2]) + cy;
+  }
+  float* c = coords + ((long)b * HW + k) * 3;
+  c[0] = c0;
+  c[1] = c1;
+  valid[(long)b * HW + k] = (Xj[2] > NS_MIN_DEPTH) ? 1.0f : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void iproj_kernel(const float* __restrict__ poses, const float* __restrict__ disps,
+                                                    const float* __restrict__ intr, float* __restrict__ points,
+                                                    int HW, int wd) {
+  const int b = blockIdx.x;
+  const int k = blockIdx.y * 256 + threadIdx.x;
+  if (k >= HW) return;
+  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  const int i = k / wd, j = k - i * wd;
+  float Xi[4] = {((float)j - cx) / fx, ((float)i - cy) / fy, 1.0f, disps[(long)b * HW + k]}, Xj[4];
+  se3::act_se3(poses + (long)b * 7, poses + (long)b * 7 + 3, Xi, Xj);
+  float* p = points + ((long)b * HW + k) * 3;
+  p[0] = Xj[0] / Xj[3];
+  p[1] = Xj[1] / Xj[3];
+  p[2] = Xj[2] / Xj[3];
+}
+
+// grid (num, 6 neighbours, pixel chunks); every (block_id, pixel) is touched by at most six
+// workgroups (one per neighbour), so the count uses float atomics exactly like the reference.
+__global__ __launch_bounds__(256) void depth_filter_kernel(const float* __restrict__ poses,
+                                                           const float* __restrict__ disps,
+                                                           const float* __restrict__ intr,
+                                                           const int64_t* __restrict__ inds,
+                                                           const float* __restrict__ thresh,
+                                                           float* __restrict__ counter, int nframes, int ht, int wd) {
+  const int b = blockIdx.x;
+  const int nb = blockIdx.y;
+  const int HW = ht * wd;
+  const int k = blockIdx.z * 256 + threadIdx.x;
+  const int ix = (int)inds[b];
+  const int jx = (nb < 3) ? ix - nb - 1 : ix + nb;
+  if (jx < 0 || jx >= nframes || k >= HW) return;
+  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  const float t = thresh[b];
+  float tij[3], qij[4];
+  se3::rel_se3(poses + (long)ix * 7, poses + (long)ix * 7 + 3, poses + (long)jx * 7, poses + (long)jx * 7 + 3, tij,
+               qij);
+  const int i = k / wd, j = k - i * wd;
+  float Xi[4] = {((float)j - cx) / fx, ((float)i - cy) / fy, 1.0f, disps[(long)ix * HW + k]}, Xj[4];
+  se3::act_se3(tij, qij, Xi, Xj);
+  const float uj = fx * (Xj[0] / Xj[2]) + cx;
+  const float vj = fy * (Xj[1] / Xj[2]) + cy;
+  const float dj = Xj[3] / Xj[2];
+  const int u0 = (int)floorf(uj), v0 = (int)floorf(vj);
+  if (u0 >= 0 && v0 >= 0 && u0 < wd - 1 && v0 < ht - 1) {
+    const float* dm = disps + (long)jx * HW;
+    const double idj = 1.0 / (double)dj;
+    const double d00 = dm[(v0 + 0) * wd + u0 + 0], d01 = dm[(v0 + 0) * wd + u0 + 1];
+    const double d10 = dm[(v0 + 1) * wd + u0 + 0], d11 = dm[(v0 + 1) * wd + u0 + 1];
+    if (fabs(idj - 1.0 / d00) < t || fabs(idj - 1.0 / d01) < t || fabs(idj - 1.0 / d10) < t ||
+        fabs(idj - 1.0 / d11) < t)
+      atomicAdd(&counter[(long)b * HW + k], 1.0f);
+  }
+}
+
+extern "C" int ns_frame_distance(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,
+                                 const int64_t* jj, float* dist, int num, int ht, int wd, float beta, void* stream) {
+  NS_REQUIRE(poses && disps && intrinsics && dist, "ns_frame_distance: null pointer");
+  NS_REQUIRE(num >= 0 && ht > 0 && wd > 0, "ns_frame_distance: bad shape");
+  if (num == 0) return NS_OK;
+  NS_REQUIRE(ii && jj, "ns_frame_distance: null index");
+  hipLaunchKernelGGL(frame_distance_kernel, dim3(num), dim3(256), 0, (hipStream_t)stream, poses, disps, intrinsics, ii,
+                     jj, dist, ht * wd, wd, beta);
+  NS_CHECK_LAUNCH("frame_distance_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_projmap(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,
+                          const int64_t* jj, float* coords, float* valid, int num, int ht, int wd, void* stream) {
+  NS_REQUIRE(poses && disps && intrinsics && coords && valid, "ns_projmap: null pointer");
+  if (num <= 0) return NS_OK;
+  NS_REQUIRE(ii && jj, "ns_projmap: null index");
+  hipLaunchKernelGGL(projmap_kernel, dim3(num, ns_cdiv(ht * wd, 256)), dim3(256), 0, (hipStream_t)stream, poses, disps,
+                     intrinsics, ii, jj, coords, valid, ht * wd, wd);
+  NS_CHECK_LAUNCH("projmap_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_iproj(const float* poses, const float* disps, const float* intrinsics, float* points, int nm, int ht,
+                        int wd, void* stream) {
+  NS_REQUIRE(poses && disps && intrinsics && points, "ns_iproj: null pointer");
+  if (nm <= 0) return NS_OK;
+  hipLaunchKernelGGL(iproj_kernel, dim3(nm, ns_cdiv(ht * wd, 256)), dim3(256), 0, (hipStream_t)stream, poses, disps,
+                     intrinsics, points, ht * wd, wd);
+  NS_CHECK_LAUNCH("iproj_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_depth_filter(const float* poses, const float* disps, const float* intrinsics, const int64_t* inds,
+                               const float* thresh, float* counter, int num, int nframes, int ht, int wd,
+                               void* stream) {
+  NS_REQUIRE(poses && disps && intrinsics && counter, "ns_depth_filter: null pointer");
+  if (num <= 0) return NS_OK;
+  NS_REQUIRE(inds && thresh, "ns_depth_filter: null index");
+  hipLaunchKernelGGL(depth_filter_kernel, dim3(num, 6, ns_cdiv(ht * wd, 256)), dim3(256), 0, (hipStream_t)stream, poses,
+                     disps, intrinsics, inds, thresh, counter, nframes, ht, wd);
+  NS_CHECK_LAUNCH("depth_filter_kernel");
+  return NS_OK;
+}

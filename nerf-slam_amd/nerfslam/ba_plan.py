@@ -1,0 +1,214 @@
+"""Graph plan + launch helpers for the dense bundle adjustment kernels (csrc/ba*.hip).
+
+`BaPlan` is the host-side index structure the reference rebuilds on every BA call
+(src/droid_kernels.cu:1702-1710, 1065-1103, 1359-1402); here it is built once per factor-graph
+change (host C++: ns_ba_plan_build), uploaded once and reused by every linearisation until the
+edge lists change.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import NerfSlamHipError, check, lib, ptr, stream_ptr
+
+
+class _CPlan(C.Structure):
+    _fields_ = [("M", C.c_int), ("P", C.c_int), ("K", C.c_int), ("kf0", C.c_int), ("kf1", C.c_int),
+                ("n_pairs", C.c_int), ("n_rows", C.c_int)]
+
+
+class BaPlan:
+    """Index block of one (ii, jj, kf0, kf1) configuration, resident on `device`."""
+
+    def __init__(self, ii_host, jj_host, kf0, kf1, device):
+        ii_host = np.ascontiguousarray(ii_host, dtype=np.int64)
+        jj_host = np.ascontiguousarray(jj_host, dtype=np.int64)
+        if ii_host.shape != jj_host.shape or ii_host.ndim != 1:
+            raise NerfSlamHipError("BaPlan: ii and jj must be 1-D and of equal length")
+        L = lib()
+        M = int(ii_host.shape[0])
+        pi = ii_host.ctypes.data_as(C.c_void_p)
+        pj = jj_host.ctypes.data_as(C.c_void_p)
+        count = L.ns_ba_plan_index_count(pi, pj, M, int(kf0), int(kf1))
+        self.c = _CPlan()
+        idx = np.zeros((max(int(count), 1),), np.int32)
+        self.offsets = (C.c_size_t * 8)()
+        check(L.ns_ba_plan_build(pi, pj, M, int(kf0), int(kf1), C.byref(self.c), idx.ctypes.data_as(C.c_void_p),
+                                 self.offsets), "ns_ba_plan_build")
+        self.index_host = idx
+        self.index = torch.from_numpy(idx).to(device, non_blocking=False)
+        self.device = torch.device(device)
+        self.ii_host, self.jj_host = ii_host, jj_host
+        self.kx_host = idx[self.offsets[0]:self.offsets[0] + self.c.K].astype(np.int64)
+        self._ws = None
+        self._ws_hw = -1
+
+    @classmethod
+    def from_tensors(cls, ii, jj, kf0, kf1):
+        """One device->host copy of the edge lists (the reference does several per call)."""
+        return cls(ii.detach().cpu().numpy(), jj.detach().cpu().numpy(), kf0, kf1, ii.device)
+
+    M = property(lambda s: s.c.M)
+    P = property(lambda s: s.c.P)
+    K = property(lambda s: s.c.K)
+    kf0 = property(lambda s: s.c.kf0)
+    kf1 = property(lambda s: s.c.kf1)
+    n_pairs = property(lambda s: s.c.n_pairs)
+
+    def workspace(self, HW):
+        if self._ws is None or self._ws_hw != HW:
+            nbytes = lib().ns_ba_workspace_bytes(C.byref(self.c), int(HW))
+            self._ws = torch.empty((nbytes + 256,), dtype=torch.uint8, device=self.device)
+            self._ws_hw = HW
+        off = (-self._ws.data_ptr()) % 256
+        return C.c_void_p(self._ws.data_ptr() + off)
+
+
+def reduced_camera_matrix(plan, poses, disps, intrinsics, extrinsics, disps_sens, targets, weights, eta, ii, jj):
+    """-> (H [6P,6P], v [6P,1], Q [K,HW], E [P+M,6,HW], w [K,HW]) exactly like the reference op."""
+    dev = poses.device
+    _, ht, wd = disps.shape
+    HW = ht * wd
+    P, M, K = plan.P, plan.M, plan.K
+    if targets.shape[0] != M:
+        raise NerfSlamHipError(f"reduced_camera_matrix: plan has M={M} edges, targets has {targets.shape[0]}")
+    if eta.numel() != K * HW:
+        # the reference fails the same way on its broadcast (droid_kernels.cu:1752)
+        raise RuntimeError(f"eta has {eta.numel() // HW} rows but the graph has K'={K} depth maps")
+    H = torch.empty((6 * P, 6 * P), dtype=torch.float32, device=dev)
+    v = torch.empty((6 * P, 1), dtype=torch.float32, device=dev)
+    Q = torch.empty((K, HW), dtype=torch.float32, device=dev)
+    w = torch.empty((K, HW), dtype=torch.float32, device=dev)
+    E = torch.empty((P + M, 6, HW), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().ns_reduced_camera_matrix(ptr(poses), ptr(disps), ptr(intrinsics), ptr(extrinsics),
+                                             ptr(disps_sens), ptr(targets), ptr(weights), ptr(eta), ptr(ii), ptr(jj),
+                                             C.byref(plan.c), ptr(plan.index), plan.offsets, ht, wd, ptr(H), ptr(v),
+                                             ptr(Q), ptr(E), ptr(w), plan.workspace(HW), stream_ptr()),
+              "reduced_camera_matrix")
+    return H, v, Q, E, w
+
+
+def solve_depth(plan, dx, disps, Q, E, w, clamp_min=-1.0):
+    _, ht, wd = disps.shape
+    with torch.cuda.device(disps.device):
+        check(lib().ns_solve_depth(ptr(dx), ptr(disps), ptr(Q), ptr(E), ptr(w), C.byref(plan.c), ptr(plan.index),
+                                   plan.offsets, ht, wd, C.c_float(clamp_min), stream_ptr()), "solve_depth")
+
+
+def projective_transform(targets, weights, poses, disps, intrinsics, extrinsics, ii, jj):
+    """K1 alone, with the reference kernel's own per-edge outputs (droid_kernels.cu:192-536):
+    -> dict(Hs[4,M,6,6], vs[2,M,6], Eiz[M,6,HW], Ejz[M,6,HW], Cii[M,HW], bz[M,HW])."""
+    dev = poses.device
+    M = ii.shape[0]
+    _, ht, wd = disps.shape
+    HW = ht * wd
+    f = dict(dtype=torch.float32, device=dev)
+    o = dict(Hs=torch.zeros((4, M, 6, 6), **f), vs=torch.zeros((2, M, 6), **f), Eiz=torch.empty((M, 6, HW), **f),
+             Ejz=torch.empty((M, 6, HW), **f), Cii=torch.empty((M, HW), **f), bz=torch.empty((M, HW), **f))
+    etab = torch.empty((max(M, 1), 80), **f)
+    with torch.cuda.device(dev):
+        check(lib().ns_projective_transform(ptr(targets), ptr(weights), ptr(poses), ptr(disps), ptr(intrinsics),
+                                            ptr(extrinsics), ptr(ii), ptr(jj), M, ht, wd, ptr(o["Hs"]), ptr(o["vs"]),
+                                            ptr(o["Eiz"]), ptr(o["Ejz"]), ptr(o["Cii"]), ptr(o["bz"]), ptr(etab),
+                                            stream_ptr()), "projective_transform")
+    return o
+
+
+MAX_SMALL_SYSTEM = 192  # 6P handled by the single-workgroup LDS Cholesky (csrc/ba_solve.hip)
+
+
+def ba_solve(H, v, kf0, kf1, world_T_body=None, cam_T_world=None, cam_T_body=None, prior_pose=None,
+             prior_sigma=1e-4, ep=0.0, lm=0.0, retract=True, want_cov=False):
+    """Device-resident replacement of the GTSAM round trip (visual_frontend.py:1123-1158).
+
+    Solves (H [+prior]) dx = v in f64, optionally retracts world_T_body / recomputes cam_T_world in place.
+    Returns dict(dx [P,6], info [1] int32, Hfull [n,n] f64, Linv [n,n] f32|None, sigma_g [P,6,6]|None)."""
+    dev = H.device
+    P = int(kf1) - int(kf0)
+    n = 6 * P
+    dx = torch.empty((P, 6), dtype=torch.float32, device=dev)
+    info = torch.zeros((1,), dtype=torch.int32, device=dev)
+    Hfull = torch.empty((n, n), dtype=torch.float64, device=dev)
+    Linv = torch.empty((n, n), dtype=torch.float32, device=dev) if want_cov else None
+    Lws = torch.empty((n, n), dtype=torch.float64, device=dev) if want_cov else None
+    sig = torch.empty((P, 6, 6), dtype=torch.float32, device=dev) if want_cov else None
+    if n > MAX_SMALL_SYSTEM:
+        return _ba_solve_large(H, v, kf0, kf1, world_T_body, cam_T_world, cam_T_body, prior_pose, prior_sigma, ep, lm,
+                               retract, want_cov)
+    with torch.cuda.device(dev):
+        check(lib().ns_ba_solve(ptr(H), ptr(v), ptr(world_T_body), ptr(cam_T_world), ptr(cam_T_body),
+                                ptr(prior_pose), C.c_float(prior_sigma), C.c_float(ep), C.c_float(lm), int(kf0),
+                                int(kf1), 0 if retract else 1, ptr(dx), ptr(Hfull), ptr(Linv), ptr(Lws), ptr(sig),
+                                ptr(info), stream_ptr()), "ba_solve")
+    return dict(dx=dx, info=info, Hfull=Hfull, Linv=Linv, sigma_g=sig)
+
+
+def _ba_solve_large(H, v, kf0, kf1, world_T_body, cam_T_world, cam_T_body, prior_pose, prior_sigma, ep, lm, retract,
+                    want_cov):
+    """6P > 192 (global BA over the whole buffer): dense f64 Cholesky through rocSOLVER
+    (torch.linalg), then the retraction kernel.  Same semantics as the LDS path."""
+    from . import se3 as _se3
+    dev = H.device
+    P = int(kf1) - int(kf0)
+    n = 6 * P
+    Hd = torch.triu(H.double())
+    Hd = Hd + torch.triu(Hd, 1).t()
+    d = torch.diagonal(Hd)
+    d += ep + lm * d
+    vd = v.double().reshape(n, 1).clone()
+    if prior_pose is not None:
+        e = _se3.log_wv(_se3.mul(_se3.inv(prior_pose.double()), world_T_body[kf0].double()))
+        Hd[:6, :6] += torch.eye(6, dtype=torch.float64, device=dev) / prior_sigma ** 2
+        vd[:6, 0] += -e / prior_sigma ** 2
+    L, info = torch.linalg.cholesky_ex(Hd)
+    dxd = torch.cholesky_solve(vd, L).reshape(P, 6)
+    dx = torch.where(info == 0, dxd, torch.zeros_like(dxd)).float().contiguous()
+    if retract:
+        with torch.cuda.device(dev):
+            check(lib().ns_ba_retract(ptr(dx), ptr(world_T_body), ptr(cam_T_world), ptr(cam_T_body), int(kf0),
+                                      int(kf1), stream_ptr()), "ba_retract")
+    out = dict(dx=dx, info=info.to(torch.int32).reshape(1), Hfull=Hd, Linv=None, sigma_g=None)
+    if want_cov:
+        Linv = torch.linalg.solve_triangular(L, torch.eye(n, dtype=torch.float64, device=dev), upper=False)
+        sig = (Linv.t() @ Linv).view(P, 6, P, 6)
+        out["Linv"] = Linv.float().contiguous()
+        out["sigma_g"] = torch.stack([sig[i, :, i, :] for i in range(P)]).float().contiguous()
+    return out
+
+
+def depth_cov(plan, Linv, Q, E, HW):
+    """z_cov [K,HW] (visual_frontend.py:1191-1219)."""
+    z = torch.empty((plan.K, HW), dtype=torch.float32, device=Q.device)
+    with torch.cuda.device(Q.device):
+        check(lib().ns_ba_depth_cov(ptr(Linv), ptr(Q), ptr(E), C.byref(plan.c), ptr(plan.index), plan.offsets, int(HW),
+                                    ptr(z), stream_ptr()), "ba_depth_cov")
+    return z
+
+
+def ba_reference_loop(plan, poses, disps, intrinsics, extrinsics, disps_sens, targets, weights, eta, ii, jj,
+                      iterations, lm, ep, motion_only):
+    """The reference's dead `ba` op (ba_cuda, droid_kernels.cu:1441-1568) on the live kernels:
+    per iteration linearise, (Schur-)solve with (ep + lm*diag) damping, retract poses with
+    Exp(dx)*T (pose_retr_kernel) and, unless motion_only, update the disparities.  -> (dx, dz)."""
+    _, ht, wd = disps.shape
+    HW = ht * wd
+    dx = dz = None
+    for _ in range(iterations):
+        before = disps.clone()
+        H, v, Q, E, w = reduced_camera_matrix(plan, poses, disps, intrinsics, extrinsics, disps_sens, targets, weights,
+                                              eta, ii, jj)
+        if motion_only:
+            raise NotImplementedError("ba(motion_only=True): the reference solves the un-reduced pose block here; "
+                                      "unused by NeRF-SLAM")
+        # SparseBlock::solve adds the damping to A-S, get_dense() transposes: H is symmetric
+        sol = ba_solve(H, v, plan.kf0, plan.kf1, ep=ep, lm=lm, retract=False)
+        dx = sol["dx"]
+        # ba_cuda's [tau,phi] ordering is whatever the system's ordering is; apply as is (:1554)
+        solve_depth(plan, dx, disps, Q, E, w, clamp_min=-1.0)
+        with torch.cuda.device(poses.device):
+            check(lib().ns_pose_retr(ptr(poses), ptr(dx), plan.kf0, plan.kf1, stream_ptr()), "pose_retr")
+        kx = torch.as_tensor(plan.kx_host, device=disps.device)
+        dz = (disps - before)[kx].reshape(-1, HW)
+    return dx, dz

@@ -1,0 +1,146 @@
+"""CorrBlock / AltCorrBlock -- host mirror of networks/modules/corr.py (reference lines cited inline).
+
+Same class names, constructor arguments, call signatures and output layouts as the reference, so
+`RaftVisualFrontend`-style callers work unchanged; the arithmetic runs in the HIP kernels of
+libnerfslam_hip.so:
+  * pyramid construction  -> torch.matmul for the plain GEMM (hipBLASLt) + ns_corr_pool2x2,
+    or the fused ns_corr_volume_pyramid kernel when available;
+  * lookup                -> ns_corr_lookup_pyramid: all four levels in one launch, reading the
+    frontend's native [.., ht, wd, 2] coordinate layout and writing the concatenated
+    [.., 196, ht, wd] tensor directly (the reference does 4 launches + permute + cat).
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import NerfSlamHipError, check, lib, ptr, require_cuda, stream_ptr
+
+
+class CorrBlock:
+    """networks/modules/corr.py:23-60."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
+        self.num_levels = num_levels
+        self.radius = radius
+        self.corr_pyramid = []
+        if fmap1 is None:
+            return
+        require_cuda(fmap1, fmap2)
+        batch, num, dim, ht, wd = fmap1.shape
+        # all pairs correlation (corr.py:63-72): both operands / 4, matmul in the features' dtype
+        corr = CorrBlock.corr(fmap1, fmap2)
+        corr = corr.reshape(batch * num, ht, wd, ht, wd)
+        self.corr_pyramid.append(corr)
+        h, w = ht, wd
+        for _ in range(1, num_levels):  # corr.py:35-38
+            src = self.corr_pyramid[-1]
+            dst = torch.empty((batch * num, ht, wd, h // 2, w // 2), dtype=src.dtype, device=src.device)
+            if src.dtype != torch.float16:
+                raise NerfSlamHipError("CorrBlock: the pyramid kernels are built for float16 volumes "
+                                       "(the reference builds them under autocast)")
+            with torch.cuda.device(src.device):
+                check(lib().ns_corr_pool2x2(ptr(src), ptr(dst), C.c_long(batch * num * ht * wd), h, w, stream_ptr()),
+                      "corr_pool2x2")
+            self.corr_pyramid.append(dst)
+            h, w = h // 2, w // 2
+
+    @classmethod
+    def from_pyramid(cls, pyramid, radius=3):
+        blk = cls(None, None, num_levels=len(pyramid), radius=radius)
+        blk.corr_pyramid = list(pyramid)
+        return blk
+
+    def __call__(self, coords):
+        """coords [batch, num, ht, wd, 2] float -> [batch, num, num_levels*49, ht, wd] (corr.py:40-50)."""
+        batch, num, ht, wd, _ = coords.shape
+        E = batch * num
+        p0 = self.corr_pyramid[0]
+        require_cuda(coords)
+        if self.radius != 3 or p0.dtype != torch.float16 or self.num_levels > 4:
+            return self._call_per_level(coords)
+        coords = coords.contiguous().float()
+        out = torch.empty((batch, num, self.num_levels * 49, ht, wd), dtype=torch.float16, device=coords.device)
+        for p in self.corr_pyramid:
+            if not p.is_contiguous():
+                raise RuntimeError("volume must be contiguous")
+        arr = (C.c_void_p * 4)(*[self.corr_pyramid[min(l, self.num_levels - 1)].data_ptr() for l in range(4)])
+        with torch.cuda.device(coords.device):
+            check(lib().ns_corr_lookup_pyramid(arr, self.num_levels, ptr(coords), 1, ptr(out), E, ht, wd,
+                                               stream_ptr()), "corr_lookup_pyramid")
+        return out
+
+    def _call_per_level(self, coords):
+        import droid_backends
+        batch, num, ht, wd, _ = coords.shape
+        c = coords.permute(0, 1, 4, 2, 3).contiguous().view(batch * num, 2, ht, wd)
+        outs = []
+        for i in range(self.num_levels):
+            corr, = droid_backends.corr_index_forward(self.corr_pyramid[i], c / 2 ** i, self.radius)
+            outs.append(corr.view(batch, num, -1, ht, wd))
+        return torch.cat(outs, dim=2)
+
+    def cat(self, other):  # corr.py:52-55
+        for i in range(self.num_levels):
+            self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], 0)
+        return self
+
+    def __getitem__(self, index):  # corr.py:57-60
+        for i in range(self.num_levels):
+            self.corr_pyramid[i] = self.corr_pyramid[i][index].contiguous()
+        return self
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        """all-pairs correlation (corr.py:63-72); plain library GEMM."""
+        batch, num, dim, ht, wd = fmap1.shape
+        fmap1 = fmap1.reshape(batch * num, dim, ht * wd) / 4.0
+        fmap2 = fmap2.reshape(batch * num, dim, ht * wd) / 4.0
+        corr = torch.matmul(fmap1.transpose(1, 2), fmap2)
+        return corr.view(batch, num, ht, wd, ht, wd)
+
+
+class AltCorrBlock:
+    """On-the-fly correlation for the global BA (reference: networks/modules/corr.py:92-140).
+
+    Same constructor and call signature as the reference class.  Differences in mechanism only:
+    the feature pyramid is kept as frame-indexed channels-last f32 tensors, and one call runs every
+    level for every edge in a single launch that reads frames through (ii, jj) -- the reference
+    gathers and `.float()`-copies both feature maps per edge and per level (corr.py:114-121) and
+    concatenates four outputs."""
+
+    def __init__(self, fmaps, num_levels=4, radius=3):
+        if radius != 3 or not 1 <= num_levels <= 4:
+            raise NerfSlamHipError("AltCorrBlock: built for radius 3 and at most 4 levels (the reference's setting)")
+        require_cuda(fmaps)
+        self.num_levels, self.radius = num_levels, radius
+        B, N, Cc, H, W = fmaps.shape
+        if B != 1:
+            raise NerfSlamHipError("AltCorrBlock: batch size 1 only (visual_frontend.py:479 always passes 1)")
+        self.shape = (N, Cc, H, W)
+        level = fmaps.reshape(N, Cc, H, W).float() / 4.0  # corr.py:98
+        self.pyramid = []
+        for _ in range(num_levels):
+            self.pyramid.append(level.permute(0, 2, 3, 1).contiguous())  # [N, h, w, C]
+            level = torch.nn.functional.avg_pool2d(level, 2, stride=2)   # corr.py:105
+
+    def __call__(self, coords, ii, jj):
+        """coords [1, E, H, W, 2] (or [1, E, H, W, S, 2]); ii, jj [E] frame ids
+        -> [1, E, 196, H, W] (or [1, E, 196, H, W, S])."""
+        N, Cc, H, W = self.shape
+        squeeze = coords.dim() == 5
+        if squeeze:
+            coords = coords.unsqueeze(-2)
+        _, E, _, _, S, _ = coords.shape
+        ii = torch.as_tensor(ii, dtype=torch.long, device=coords.device).contiguous()
+        jj = torch.as_tensor(jj, dtype=torch.long, device=coords.device).contiguous()
+        outs = []
+        arr = (C.c_void_p * 4)(*[self.pyramid[min(l, self.num_levels - 1)].data_ptr() for l in range(4)])
+        for s in range(S):
+            cs = coords[0, :, :, :, s].contiguous().float()
+            out = torch.empty((E, self.num_levels * 49, H, W), dtype=torch.float32, device=coords.device)
+            with torch.cuda.device(coords.device):
+                check(lib().ns_altcorr_pyramid(arr, self.num_levels, ptr(ii), ptr(jj), ptr(cs), ptr(out), E, H, W, Cc,
+                                               stream_ptr()), "altcorr_pyramid")
+            outs.append(out)
+        out = outs[0][None] if squeeze else torch.stack(outs, dim=-1)[None]
+        return out.contiguous()

@@ -319,21 +319,16 @@ def ba_solve_retract(H, v, world_T_body, cam_T_body, kf0, kf1, prior_pose=None, 
     identity (exact at zero error) -- parity unpinned.
     """
     P = kf1 - kf0
-    Hd = np.asarray(H, np.float64).copy()
-    # only the upper-triangular blocks H[i,j], i<=j are handed to GTSAM (:1127-1134)
-    Hb = Hd.reshape(P, 6, P, 6).transpose(0, 2, 1, 3)
-    Hs = np.zeros_like(Hb)
-    for i in range(P):
-        Hs[i, i] = Hb[i, i]
-        for j in range(i + 1, P):
-            Hs[i, j] = Hb[i, j]
-            Hs[j, i] = Hb[i, j].T
-    Hd = Hs.transpose(0, 2, 1, 3).reshape(6 * P, 6 * P)
+    # GTSAM's HessianFactor keeps the upper triangle of what it is given (SymmetricBlockMatrix):
+    # the system is triu(H) mirrored, element-wise (H as returned is symmetric only to f32 rounding)
+    Hd = np.triu(np.asarray(H, np.float64))
+    Hd = Hd + np.triu(Hd, 1).T
     vd = np.asarray(v, np.float64).reshape(-1).copy()
     if prior_pose is not None:
         e = se3_log64(se3_mul64(se3_inv64(prior_pose), world_T_body[kf0]))
-        Hd[:6, :6] += np.eye(6) / prior_sigma ** 2
-        vd[:6] += -e / prior_sigma ** 2
+        info = 1.0 / (float(np.float32(prior_sigma)) ** 2)  # sigma travels as f32 through the C ABI
+        Hd[:6, :6] += np.eye(6) * info
+        vd[:6] += -e * info
     delta = np.linalg.solve(Hd, vd).reshape(P, 6)
     wTb = np.asarray(world_T_body, np.float64)[kf0:kf1].copy()
     cTw = np.zeros_like(wTb)
@@ -358,6 +353,10 @@ def ba_covariances(Hfull, E, Q, ii, jj, kf0, kf1, HW):
     kx, kk = np.unique(ii, return_inverse=True)
     K = kx.shape[0]
     mn = min(ii.min(), jj.min())
+    if K != np.asarray(Q).shape[0] or max(ii.max(), jj.max()) - mn >= K or kf1 - mn > K:
+        # the reference's dense scatter (visual_frontend.py:1204-1214) only works when every frame of
+        # [min(ii,jj), kf1) has an outgoing edge; it raises an index / shape error otherwise
+        raise ValueError("covariance block not applicable to this graph (same failure as the reference)")
     Ej = np.zeros((K, K, 6, HW))
     Ej[jj - mn, ii - mn] = np.asarray(E[P:P + ii.shape[0]], np.float64)
     Ej = Ej[kf0 - mn:kf1 - mn].copy()

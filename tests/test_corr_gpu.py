@@ -1,0 +1,163 @@
+"""GPU parity of the correlation kernels against the CPU oracle (through the C ABI shim)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits_equal(a, b):
+    """bit-exact, except that +0 and -0 compare equal."""
+    return ((a.view(np.uint16) == b.view(np.uint16)) | ((a == 0) & (b == 0))).all()
+
+
+@pytest.mark.parametrize("shape", [(3, 12, 16), (2, 30, 40), (1, 43, 77)])
+def test_corr_index_forward_f16_bitexact(oracle_mod, dev, shape):
+    import droid_backends
+    E, ht, wd = shape
+    pyr, coords = synth.lookup_inputs(E, ht, wd, seed=1)
+    # edge cases: first / last slice runs poking outside the tensor, NaN / inf / huge coordinates
+    coords[0, 0, 0] = [-2.5, -2.25]
+    coords[-1, -1, -1] = [wd + 1.5, ht + 0.75]
+    coords[0, 1, 1] = [1e9, 3.0]
+    coords[0, 1, 2] = [3.0, -np.inf]
+    cf = np.ascontiguousarray(coords.transpose(0, 3, 1, 2))
+    for l in range(4):
+        c = (cf / np.float32(2 ** l)).astype(np.float32)
+        got, = droid_backends.corr_index_forward(torch.from_numpy(pyr[l]).to(dev), torch.from_numpy(c).to(dev), 3)
+        assert got.shape == (E, 7, 7, ht, wd) and got.dtype == torch.float16
+        c_or = np.where(np.isfinite(c), c, np.float32(-1e5))
+        ref = oracle_mod.corr_index_forward(pyr[l], c_or, 3)
+        assert _bits_equal(got.cpu().numpy(), ref), f"level {l}"
+
+
+def test_corr_lookup_pyramid_matches_cat_of_levels(oracle_mod, dev):
+    from nerfslam.corr import CorrBlock
+    E, ht, wd = 3, 16, 24
+    pyr, coords = synth.lookup_inputs(E, ht, wd, seed=2)
+    blk = CorrBlock.from_pyramid([torch.from_numpy(p).to(dev) for p in pyr])
+    out = blk(torch.from_numpy(coords).to(dev)[None])  # [1,E,196,ht,wd]
+    assert out.shape == (1, E, 196, ht, wd)
+    cf = np.ascontiguousarray(coords.transpose(0, 3, 1, 2))
+    ref = np.concatenate([oracle_mod.corr_index_forward(pyr[l], cf / np.float32(2 ** l), 3).reshape(E, 49, ht, wd)
+                          for l in range(4)], 1)
+    assert _bits_equal(out[0].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("radius", [1, 3, 4])
+def test_corr_index_forward_f32_and_generic_radius(oracle_mod, dev, radius):
+    import droid_backends
+    E, ht, wd = 2, 10, 14
+    pyr, coords = synth.lookup_inputs(E, ht, wd, seed=3, dtype=np.float32)
+    cf = np.ascontiguousarray(coords.transpose(0, 3, 1, 2))
+    got, = droid_backends.corr_index_forward(torch.from_numpy(pyr[0]).to(dev), torch.from_numpy(cf).to(dev), radius)
+    ref = oracle_mod.corr_index_forward(pyr[0], cf, radius)
+    # f32: the reference's `+=` contracts to FMA on nvcc; tolerance 1e-6 of max|ref|
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=1e-6 * np.abs(ref).max())
+    if radius != 3:
+        h = pyr[0].astype(np.float16)
+        got16, = droid_backends.corr_index_forward(torch.from_numpy(h).to(dev), torch.from_numpy(cf).to(dev), radius)
+        assert _bits_equal(got16.cpu().numpy(), oracle_mod.corr_index_forward(h, cf, radius))
+
+
+def test_corr_index_backward(oracle_mod, dev):
+    import droid_backends
+    E, ht, wd = 2, 8, 10
+    pyr, coords = synth.lookup_inputs(E, ht, wd, seed=4, dtype=np.float32)
+    cf = np.ascontiguousarray(coords.transpose(0, 3, 1, 2))
+    g = np.random.default_rng(0).standard_normal((E, 7, 7, ht, wd)).astype(np.float32)
+    got, = droid_backends.corr_index_backward(torch.from_numpy(pyr[0]).to(dev), torch.from_numpy(cf).to(dev),
+                                              torch.from_numpy(g).to(dev), 3)
+    ref = oracle_mod.corr_index_backward(cf, g, ht, wd, 3)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=2e-6 * np.abs(ref).max())
+
+
+def test_contiguity_error_like_reference(dev):
+    import droid_backends
+    v = torch.zeros((1, 4, 4, 4, 8), dtype=torch.float16, device=dev)[..., ::2]
+    c = torch.zeros((1, 2, 4, 4), device=dev)
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        droid_backends.corr_index_forward(v, c, 3)
+
+
+def test_cpu_tensors_fail_loudly():
+    import droid_backends
+    from nerfslam._lib import NerfSlamHipError
+    with pytest.raises(NerfSlamHipError):
+        droid_backends.corr_index_forward(torch.zeros((1, 4, 4, 4, 4), dtype=torch.float16), torch.zeros((1, 2, 4, 4)), 3)
+
+
+@pytest.mark.parametrize("hw", [(12, 16), (15, 21), (60, 80)])
+def test_corr_pyramid_build(oracle_mod, dev, hw):
+    """CorrBlock(fmap1, fmap2): all-pairs volume + 3 pooled levels (corr.py:23-38, 63-72).
+    Level 0 is a half-rounded f32-accumulated GEMM: the BLAS summation order is unspecified, so the
+    bar is <= 1 half-ulp of the exactly-accumulated oracle; pooled levels are compared to the oracle's
+    pooling of the *device's* level below them, bit-exactly."""
+    from nerfslam.corr import CorrBlock
+    ht, wd = hw
+    n, Cc = (2, 128) if ht < 60 else (1, 128)
+    rng = np.random.default_rng(5)
+    f1 = rng.standard_normal((1, n, Cc, ht, wd)).astype(np.float16)
+    f2 = rng.standard_normal((1, n, Cc, ht, wd)).astype(np.float16)
+    blk = CorrBlock(torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev))
+    lv = [p.cpu().numpy() for p in blk.corr_pyramid]
+    assert [p.shape for p in lv] == [(n, ht, wd, ht >> l, wd >> l) for l in range(4)]
+    if ht < 60:
+        ref = oracle_mod.corr_pyramid(f1[0], f2[0])
+        d = np.abs(lv[0].astype(np.float32) - ref[0].astype(np.float32))
+        ulp = np.maximum(np.spacing(np.abs(ref[0]).astype(np.float16)).astype(np.float32), 2.0 ** -24)
+        # torch.matmul(half) may reduce in f16 inside the BLAS (allow_fp16_reduced_precision_reduction, the
+        # default on CUDA and ROCm alike): a few half-ulps, exactly like the reference's cuBLAS call
+        assert (d <= 4 * ulp).all(), f"max {float((d / ulp).max()):.2f} ulp"
+        assert (d > ulp).mean() < 0.02
+    for l in range(3):
+        h, w = ht >> l, wd >> l
+        out = np.empty((n, ht, wd, h // 2, w // 2), np.uint16)
+        oracle_mod.lib().orc_corr_pool_f16(lv[l].ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                           C.c_long(n * ht * wd), h, w)
+        assert _bits_equal(lv[l + 1], out.view(np.float16)), f"pool level {l + 1}"
+
+
+@pytest.mark.parametrize("cfg", [(2, 1, 12, 16, 12, 16, 128), (1, 2, 9, 11, 4, 5, 64), (1, 1, 16, 20, 8, 10, 256)])
+def test_altcorr_forward(oracle_mod, dev, cfg):
+    import droid_backends
+    B, N, H1, W1, H2, W2, Cc = cfg
+    rng = np.random.default_rng(6)
+    f1 = rng.standard_normal((B, H1, W1, Cc)).astype(np.float32)
+    f2 = rng.standard_normal((B, H2, W2, Cc)).astype(np.float32)
+    gy, gx = np.meshgrid(np.arange(H1), np.arange(W1), indexing="ij")
+    coords = (np.stack([gx, gy], -1)[None, None] * (W2 / W1) + rng.uniform(-6, 6, (B, N, H1, W1, 2))).astype(np.float32)
+    coords[0, 0, 0, 0] = [-20.0, 3.0]
+    got, = droid_backends.altcorr_forward(torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev),
+                                          torch.from_numpy(coords).to(dev), 3)
+    ref = oracle_mod.altcorr_forward(f1, f2, coords, 3)
+    assert got.shape == ref.shape
+    # f32, different summation order than the reference's 32-channel slabs: 1e-5 of max|ref|
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=1e-5 * np.abs(ref).max())
+
+
+def test_altcorr_block_fused_pyramid(oracle_mod, dev):
+    """AltCorrBlock (fused, frame-indexed) == per-level altcorr_forward of the oracle on gathered maps."""
+    from nerfslam.corr import AltCorrBlock
+    rng = np.random.default_rng(7)
+    nfr, Cc, H, W, E = 5, 128, 16, 24, 6
+    fm = rng.standard_normal((1, nfr, Cc, H, W)).astype(np.float16)
+    ii = rng.integers(0, nfr, E).astype(np.int64)
+    jj = rng.integers(0, nfr, E).astype(np.int64)
+    gy, gx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    coords = (np.stack([gx, gy], -1)[None, None] + rng.uniform(-7, 7, (1, E, H, W, 2))).astype(np.float32)
+    blk = AltCorrBlock(torch.from_numpy(fm).to(dev))
+    got = blk(torch.from_numpy(coords).to(dev), torch.from_numpy(ii).to(dev), torch.from_numpy(jj).to(dev))
+    assert got.shape == (1, E, 196, H, W)
+    lv = torch.from_numpy(fm[0]).float() / 4.0
+    f0 = lv.permute(0, 2, 3, 1).contiguous().numpy()
+    for l in range(4):
+        f = lv.permute(0, 2, 3, 1).contiguous().numpy()
+        ref = oracle_mod.altcorr_forward(f0[ii], f[jj], coords[0][:, None] / np.float32(2 ** l), 3)[:, 0]
+        g = got[0, :, 49 * l:49 * (l + 1)].cpu().numpy()
+        np.testing.assert_allclose(g, ref, rtol=0, atol=1e-5 * np.abs(ref).max())
+        lv = torch.nn.functional.avg_pool2d(lv, 2, stride=2)
