@@ -66,6 +66,13 @@ int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_levels, const fl
  * f16 in/out, f32 accumulate, one rounding.  in [nslices,h,w] -> out [nslices,h/2,w/2].       */
 int ns_corr_pool2x2(const void* in, void* out, long nslices, int h, int w, void* stream);
 
+/* CorrBlock.corr + pyramid fused (corr.py:63-72 + :35-38), f16 MFMA, every output byte written once.
+ *   fmap1 [n1,HW,C], fmap2 [n2,HW,C] f16 CHANNELS-LAST and already divided by 4 (corr.py:67-68);
+ *   ii,jj [E] i64 frame ids into fmap1/fmap2 (both NULL: edge e uses row e of each);
+ *   writes pyr_host[l] = [E,ht,wd,ht>>l,wd>>l] f16 for l < num_levels.  C must be 128.          */
+int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, const int64_t* ii, const int64_t* jj,
+                           void* const* pyr_host, int num_levels, int E, int C, int ht, int wd, void* stream);
+
 /* altcorr_forward (src/droid.cpp:303-313 -> src/altcorr_kernel.cu:290-319, kernel :28-149)
  *   fmap1 [B,H1,W1,C] f32, fmap2 [B,H2,W2,C] f32 (channels-last), coords [B,N,H1,W1,2] f32,
  *   corr [B,N,(2r+1)^2,H1,W1] f32 (written completely).                                      */
@@ -146,14 +153,17 @@ int ns_ba_plan_build(const int64_t* ii_host, const int64_t* jj_host, int M, int 
  *   targets, weights [M,2,ht,wd], eta [K,ht,wd], ii,jj [M] i64 (device), index = device copy of
  *   the plan's index block.
  * outputs: H [6P,6P] f32, v [6P] f32, Q [K,HW], E [P+M,6,HW], w [K,HW]  (all fully written).
- * workspace: ns_ba_workspace_bytes(plan, ht*wd) bytes, 256-byte aligned, contents undefined.    */
+ * workspace: ns_ba_workspace_bytes(plan, ht*wd) bytes, 256-byte aligned.  ws_zeroed = 0: contents
+ * undefined (the call clears what it needs); 1: the caller promises the workspace was either
+ * zero-filled or last used by a successful call of this function with the same plan (which leaves
+ * its accumulators zeroed again) -- saves a memset node per linearisation.                       */
 size_t ns_ba_workspace_bytes(const ns_ba_plan* plan, int HW);
 int ns_reduced_camera_matrix(const float* poses, const float* disps, const float* intrinsics,
                              const float* extrinsics, const float* disps_sens, const float* targets,
                              const float* weights, const float* eta, const int64_t* ii, const int64_t* jj,
                              const ns_ba_plan* plan, const int32_t* index, const size_t* offsets_host, int ht,
                              int wd, float* H, float* v, float* Q, float* E, float* w, void* workspace,
-                             void* stream);
+                             int ws_zeroed, void* stream);
 
 /* solve_depth (src/droid.cpp:198-218 -> droid_kernels.cu:1772-1825): EvT6x1 (:1213-1238),
  * accum, dz = Q*(w - .), disp_retr (:1050-1063); disps updated in place, then optionally

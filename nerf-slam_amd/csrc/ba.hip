@@ -9,10 +9,10 @@
 //   K7  pose_retr_kernel                     :1015-1048
 // and the GTSAM solve/retract of RaftVisualFrontend.ba() (visual_frontend.py:1123-1158).
 //
-// Structure of one linearisation (5 launches, 0 host syncs):
-//   edge_prep   per-edge constants: G_ij and the two 6x6 maps A_i, A_j with  J_i = J_raw A_i,
-//               J_j = J_raw A_j  (the reference applies them per pixel, :376-403; they are linear)
-//   linearize   grid (edge, pixel chunk): per pixel residual/weights/J_raw, writes Ejz/Eiz/C/b,
+// Structure of one linearisation (4 launches + 1 memset, 0 host syncs):
+//   linearize   grid (edge, pixel chunk).  Prologue: per-edge constants G_ij and the two 6x6 maps A_i, A_j
+//               with J_i = J_raw A_i, J_j = J_raw A_j (the reference applies them per pixel, :376-403;
+//               they are linear) into LDS.  Per pixel residual/weights/J_raw, writes Ejz/Eiz/C/b,
 //               accumulates only G = sum w J_raw^T J_raw (21) and g = sum w r J_raw (6) per lane
 //               instead of the reference's 78+12 (Hii = A_i^T G A_i, Hij = A_i^T G A_j, ...),
 //               block-reduces them with wave shuffles and adds the transformed 6x6 blocks into a
@@ -45,55 +45,89 @@ __device__ __forceinline__ void reorder_wt(float* J) {  // [t,w] -> [w,t]   (:38
   J[5] = c;
 }
 
-__global__ void ba_edge_prep_kernel(const float* __restrict__ poses, const float* __restrict__ extr,
-                                    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, int M,
-                                    float* __restrict__ etab) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= M) return;
-  const int ix = (int)ii[e], jx = (int)jj[e];
-  float tij[3], qij[4];
-  float stereo = 0.0f;
-  if (ix == jx) {  // stereo pair (:249-259)
-    tij[0] = -0.1f;
-    tij[1] = 0.0f;
-    tij[2] = 0.0f;
-    qij[0] = qij[1] = qij[2] = 0.0f;
-    qij[3] = 1.0f;
-    stereo = 1.0f;
-  } else {
-    se3::rel_se3(poses + (long)ix * 7, poses + (long)ix * 7 + 3, poses + (long)jx * 7, poses + (long)jx * 7 + 3, tij,
-                 qij);
+// Per-edge constants, computed by the first lanes of every workgroup of that edge into LDS:
+//   Ts[0..2] t_ij, Ts[3..6] q_ij, Ts[7] stereo flag, Ts[8..43] A_i, Ts[44..79] A_j   (row-major 6x6)
+__device__ __forceinline__ void edge_constants(const float* __restrict__ poses, const float* __restrict__ extr,
+                                               int ix, int jx, float* Ts) {
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    float tij[3], qij[4];
+    float stereo = 0.0f;
+    if (ix == jx) {  // stereo pair (:249-259)
+      tij[0] = -0.1f;
+      tij[1] = 0.0f;
+      tij[2] = 0.0f;
+      qij[0] = qij[1] = qij[2] = 0.0f;
+      qij[3] = 1.0f;
+      stereo = 1.0f;
+    } else {
+      se3::rel_se3(poses + (long)ix * 7, poses + (long)ix * 7 + 3, poses + (long)jx * 7, poses + (long)jx * 7 + 3,
+                   tij, qij);
+    }
+    Ts[ET_T + 0] = tij[0];
+    Ts[ET_T + 1] = tij[1];
+    Ts[ET_T + 2] = tij[2];
+    Ts[ET_Q + 0] = qij[0];
+    Ts[ET_Q + 1] = qij[1];
+    Ts[ET_Q + 2] = qij[2];
+    Ts[ET_Q + 3] = qij[3];
+    Ts[ET_STEREO] = stereo;
   }
-  float* T = etab + (long)e * ET_STRIDE;
-  T[ET_T + 0] = tij[0];
-  T[ET_T + 1] = tij[1];
-  T[ET_T + 2] = tij[2];
-  T[ET_Q + 0] = qij[0];
-  T[ET_Q + 1] = qij[1];
-  T[ET_Q + 2] = qij[2];
-  T[ET_Q + 3] = qij[3];
-  T[ET_STEREO] = stereo;
-  const float ext_t[3] = {extr[0], extr[1], extr[2]};
-  const float ext_q[4] = {extr[3], extr[4], extr[5], extr[6]};
-  for (int k = 0; k < 6; k++) {
+  __syncthreads();
+  if (tid < 6) {
+    const int k = tid;
+    const float tij[3] = {Ts[ET_T], Ts[ET_T + 1], Ts[ET_T + 2]};
+    const float qij[4] = {Ts[ET_Q], Ts[ET_Q + 1], Ts[ET_Q + 2], Ts[ET_Q + 3]};
+    const float ext_t[3] = {extr[0], extr[1], extr[2]};
+    const float ext_q[4] = {extr[3], extr[4], extr[5], extr[6]};
     float X[6] = {0, 0, 0, 0, 0, 0};
-    X[k] = 1.0f;
+#pragma unroll
+    for (int n = 0; n < 6; n++) X[n] = (n == k) ? 1.0f : 0.0f;
     float Ji[6], Jj[6], tmp[6];
     // Ji = -adj(G_ij, Jj)                        (:376-377)
     se3::adj_se3(tij, qij, X, Ji, false);
+#pragma unroll
     for (int n = 0; n < 6; n++) Ji[n] = -Ji[n];
     // camera-to-body adjoint, applied in place by the reference (:380-381)
     se3::adj_se3(ext_t, ext_q, X, tmp, true);
+#pragma unroll
     for (int n = 0; n < 6; n++) Jj[n] = -tmp[n];  // (:384)
     se3::adj_se3(ext_t, ext_q, Ji, tmp, true);
+#pragma unroll
     for (int n = 0; n < 6; n++) Ji[n] = -tmp[n];  // (:385)
     reorder_wt(Jj);
     reorder_wt(Ji);
+#pragma unroll
     for (int c = 0; c < 6; c++) {
-      T[ET_AI + k * 6 + c] = Ji[c];
-      T[ET_AJ + k * 6 + c] = Jj[c];
+      Ts[ET_AI + k * 6 + c] = Ji[c];
+      Ts[ET_AJ + k * 6 + c] = Jj[c];
     }
   }
+  __syncthreads();
+}
+
+// Entry `t` of the per-edge pose blocks from G (21 upper-triangular sums) and g (6):
+//   t < 144: block t/36 of {Hii, Hij, Hji, Hjj} = X^T G Y, entry ((t%36)/6, t%6);  t in [144,156): vi / vj = X^T g
+__device__ __forceinline__ double edge_block_entry(const float* Ai, const float* Aj, const double* Gs, int t) {
+  double val = 0.0;
+  if (t < 144) {
+    const int blk = t / 36, r = (t % 36) / 6, c = t % 6;
+    const float* X = (blk < 2) ? Ai : Aj;
+    const float* Y = (blk % 2 == 0) ? Ai : Aj;
+    for (int k = 0; k < 6; k++) {
+      double s = 0.0;
+      for (int m = 0; m < 6; m++) {
+        const int lo = k < m ? k : m, hi = k < m ? m : k;
+        s += Gs[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)] * (double)Y[m * 6 + c];
+      }
+      val += (double)X[k * 6 + r] * s;
+    }
+  } else {
+    const int side = (t - 144) / 6, r = (t - 144) % 6;
+    const float* X = side == 0 ? Ai : Aj;
+    for (int k = 0; k < 6; k++) val += (double)X[k * 6 + r] * Gs[21 + k];
+  }
+  return val;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -106,26 +140,27 @@ struct LinArgs {
   const float* intr;     // [4]
   const int64_t* ii;
   const int64_t* jj;
-  const float* etab;     // [M,80]
+  const float* poses;    // [*,7]
+  const float* extr;     // [7]
   float* Eiz;            // [M,6,HW]
   float* Ejz;            // [M,6,HW]
   float* Cii;            // [M,HW]
   float* bz;             // [M,HW]
-  double* Hd;            // [6P,6P]   (assemble mode)
-  double* vd;            // [6P]
+  float* partial;        // [M,nch,32]: per-(edge,chunk) sums G(21), g(6)   (assemble mode)
   float* Hs;             // [4,M,6,6] (per-edge mode, nch == 1)
   float* vs;             // [2,M,6]
   int M, HW, wd, nch, kf0, P;
 };
 
 template <bool PER_EDGE>
-__global__ __launch_bounds__(256) void ba_linearize_kernel(LinArgs a) {
+__global__ __launch_bounds__(256, 4) void ba_linearize_kernel(LinArgs a) {
   const int e = blockIdx.x;
   const int ch = blockIdx.y;
   const int tid = threadIdx.x;
   const int HW = a.HW;
   const int ix = (int)a.ii[e], jx = (int)a.jj[e];
-  const float* __restrict__ T = a.etab + (long)e * ET_STRIDE;
+  __shared__ float T[ET_STRIDE];
+  edge_constants(a.poses, a.extr, ix, jx, T);
 
   const float fx = a.intr[0], fy = a.intr[1], cx = a.intr[2], cy = a.intr[3];
   const float tij[3] = {T[ET_T], T[ET_T + 1], T[ET_T + 2]};
@@ -148,8 +183,15 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(LinArgs a) {
   const float* __restrict__ tv = a.target + ((long)e * 2 + 1) * HW;
   const float* __restrict__ wu_ = a.weight + ((long)e * 2 + 0) * HW;
   const float* __restrict__ wv_ = a.weight + ((long)e * 2 + 1) * HW;
+  float* __restrict__ oC = a.Cii + (long)e * HW;
+  float* __restrict__ ob = a.bz + (long)e * HW;
+  float* __restrict__ oEi = a.Eiz + (long)e * 6 * HW;
+  float* __restrict__ oEj = a.Ejz + (long)e * 6 * HW;
 
   for (int p = p0 + tid; p < p1; p += 256) {
+    // keep the 72 entries of A_i/A_j in LDS (broadcast reads) instead of letting the compiler hoist
+    // them into 72 VGPRs per lane, which halves the occupancy of this latency-bound kernel
+    asm volatile("" ::: "memory");
     const int i = p / a.wd, j = p - i * a.wd;
     const float u = (float)j, v = (float)i;
     float Xi[4], Xj[4];
@@ -170,8 +212,8 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(LinArgs a) {
 
     const float Jzu = fx * (tij[0] * d - tij[2] * (x * d2));
     const float Jzv = fy * (tij[1] * d - tij[2] * (y * d2));
-    a.Cii[(long)e * HW + p] = wu * Jzu * Jzu + wv * Jzv * Jzv;
-    a.bz[(long)e * HW + p] = wu * ru * Jzu + wv * rv * Jzv;
+    oC[p] = wu * Jzu * Jzu + wv * Jzv * Jzv;
+    ob[p] = wu * ru * Jzu + wv * rv * Jzv;
 
     if (stereo) {  // pose weights are zeroed for stereo pairs (:367,432)
       wu = 0.0f;
@@ -207,15 +249,13 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(LinArgs a) {
         ei += q[k] * T[ET_AI + k * 6 + c];
         ej += q[k] * T[ET_AJ + k * 6 + c];
       }
-      a.Eiz[((long)e * 6 + c) * HW + p] = ei;
-      a.Ejz[((long)e * 6 + c) * HW + p] = ej;
+      oEi[(long)c * HW + p] = ei;
+      oEj[(long)c * HW + p] = ej;
     }
   }
 
   // ---- block reduction of the 27 partial sums ----
   __shared__ float red[4][27];
-  __shared__ double Gs[27];
-  __shared__ float As[72];
   const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
   for (int l = 0; l < 21; l++) {
@@ -227,47 +267,25 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(LinArgs a) {
     const float s = wave_sum(g[l]);
     if (lane == 0) red[wave][21 + l] = s;
   }
-  if (tid < 72) As[tid] = T[ET_AI + tid];
   __syncthreads();
+  if (!PER_EDGE) {
+    // deterministic: the (edge, chunk) partial is written once, summed by the assembly blocks of
+    // the Schur launch in chunk order
+    if (tid < 27)
+      a.partial[((long)e * a.nch + ch) * 32 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    return;
+  }
+  __shared__ double Gs[27];
   if (tid < 27) Gs[tid] = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
   __syncthreads();
-
-  // ---- transform to the four 6x6 blocks and the two 6-vectors, scatter ----
   if (tid < 156) {
-    const float* Ai = As;
-    const float* Aj = As + 36;
-    double val = 0.0;
+    const double val = edge_block_entry(T + ET_AI, T + ET_AJ, Gs, tid);
     if (tid < 144) {
       const int blk = tid / 36, r = (tid % 36) / 6, c = tid % 6;
-      const float* X = (blk < 2) ? Ai : Aj;
-      const float* Y = (blk % 2 == 0) ? Ai : Aj;
-      for (int k = 0; k < 6; k++) {
-        double s = 0.0;
-        for (int m = 0; m < 6; m++) {
-          const int lo = k < m ? k : m, hi = k < m ? m : k;
-          const int idx = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
-          s += Gs[idx] * (double)Y[m * 6 + c];
-        }
-        val += (double)X[k * 6 + r] * s;
-      }
-      if (PER_EDGE) {
-        a.Hs[(((long)blk * a.M + e) * 6 + r) * 6 + c] = (float)val;
-      } else {
-        const int rp = ((blk < 2) ? ix : jx) - a.kf0;
-        const int cp = ((blk % 2 == 0) ? ix : jx) - a.kf0;
-        if (rp >= 0 && rp < a.P && cp >= 0 && cp < a.P)
-          atomicAdd(&a.Hd[(long)(6 * rp + r) * (6 * a.P) + 6 * cp + c], val);
-      }
+      a.Hs[(((long)blk * a.M + e) * 6 + r) * 6 + c] = (float)val;
     } else {
       const int side = (tid - 144) / 6, r = (tid - 144) % 6;
-      const float* X = side == 0 ? Ai : Aj;
-      for (int k = 0; k < 6; k++) val += (double)X[k * 6 + r] * Gs[21 + k];
-      if (PER_EDGE) {
-        a.vs[((long)side * a.M + e) * 6 + r] = (float)val;
-      } else {
-        const int rp = (side == 0 ? ix : jx) - a.kf0;
-        if (rp >= 0 && rp < a.P) atomicAdd(&a.vd[6 * rp + r], val);
-      }
+      a.vs[((long)side * a.M + e) * 6 + r] = (float)val;
     }
   }
 }
@@ -315,17 +333,65 @@ __global__ __launch_bounds__(256) void ba_accum_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// schur (K9 + K10): one workgroup per pair (n <= m) of E rows sharing a depth slot
+// schur (K9 + K10) + pose-block assembly, one launch:
+//   blocks [0, n_pairs*sch)   : pair (n <= m) of E rows sharing a depth slot, pixel chunk b % sch
+//   blocks [n_pairs*sch, +M)  : edge e: sum its linearize partials over the chunks (fixed order),
+//                               transform with A_i, A_j and add the four 6x6 blocks / two 6-vectors
+// Both kinds accumulate into the dense fp64 system with fp64 atomics.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__ E, const float* __restrict__ Q,
-                                                       const float* __restrict__ w,
-                                                       const int32_t* __restrict__ pairs,
-                                                       const int32_t* __restrict__ row_pose, int HW, int P,
-                                                       double* __restrict__ Hd, double* __restrict__ vd) {
-  const int n = pairs[3 * blockIdx.x + 0];
-  const int m = pairs[3 * blockIdx.x + 1];
-  const int k = pairs[3 * blockIdx.x + 2];
+struct SchurArgs {
+  const float* E;
+  const float* Q;
+  const float* w;
+  const int32_t* pairs;
+  const int32_t* row_pose;
+  const float* partial;
+  const float* poses;
+  const float* extr;
+  const int64_t* ii;
+  const int64_t* jj;
+  double* Hd;
+  double* vd;
+  int HW, P, kf0, n_pairs, sch, nch, M;
+};
+
+__global__ __launch_bounds__(256) void ba_schur_kernel(SchurArgs a) {
   const int tid = threadIdx.x;
+  const int n6 = 6 * a.P;
+  if ((int)blockIdx.x >= a.n_pairs * a.sch) {
+    // ---------------- edge assembly ----------------
+    const int e = blockIdx.x - a.n_pairs * a.sch;
+    const int ix = (int)a.ii[e], jx = (int)a.jj[e];
+    __shared__ float T[ET_STRIDE];
+    __shared__ double Gs[27];
+    edge_constants(a.poses, a.extr, ix, jx, T);
+    if (tid < 27) {
+      double s = 0.0;
+      for (int c = 0; c < a.nch; c++) s += (double)a.partial[((long)e * a.nch + c) * 32 + tid];
+      Gs[tid] = s;
+    }
+    __syncthreads();
+    if (tid < 156) {
+      const double val = edge_block_entry(T + ET_AI, T + ET_AJ, Gs, tid);
+      if (tid < 144) {
+        const int blk = tid / 36, r = (tid % 36) / 6, c = tid % 6;
+        const int rp = ((blk < 2) ? ix : jx) - a.kf0;
+        const int cp = ((blk % 2 == 0) ? ix : jx) - a.kf0;
+        if (rp >= 0 && rp < a.P && cp >= 0 && cp < a.P) atomicAdd(&a.Hd[(long)(6 * rp + r) * n6 + 6 * cp + c], val);
+      } else {
+        const int side = (tid - 144) / 6, r = (tid - 144) % 6;
+        const int rp = (side == 0 ? ix : jx) - a.kf0;
+        if (rp >= 0 && rp < a.P) atomicAdd(&a.vd[6 * rp + r], val);
+      }
+    }
+    return;
+  }
+  // ---------------- Schur pair ----------------
+  const int pid = blockIdx.x / a.sch, chunk = blockIdx.x % a.sch;
+  const int n = a.pairs[3 * pid + 0];
+  const int m = a.pairs[3 * pid + 1];
+  const int k = a.pairs[3 * pid + 2];
+  const int HW = a.HW;
   const bool diag = (n == m);
   float S[36];
   float bb[6];
@@ -333,11 +399,13 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
   for (int q = 0; q < 36; q++) S[q] = 0.0f;
 #pragma unroll
   for (int q = 0; q < 6; q++) bb[q] = 0.0f;
-  const float* __restrict__ En = E + (long)n * 6 * HW;
-  const float* __restrict__ Em = E + (long)m * 6 * HW;
-  const float* __restrict__ Qk = Q + (long)k * HW;
-  const float* __restrict__ wk = w + (long)k * HW;
-  for (int p = tid; p < HW; p += 256) {
+  const float* __restrict__ En = a.E + (long)n * 6 * HW;
+  const float* __restrict__ Em = a.E + (long)m * 6 * HW;
+  const float* __restrict__ Qk = a.Q + (long)k * HW;
+  const float* __restrict__ wk = a.w + (long)k * HW;
+  const int csz = (HW + a.sch - 1) / a.sch;
+  const int p0 = chunk * csz, p1 = min(HW, p0 + csz);
+  for (int p = p0 + tid; p < p1; p += 256) {
     const float q = Qk[p];
     float ei[6], ej[6], en[6];
 #pragma unroll
@@ -371,27 +439,32 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  const int pn = row_pose[n], pm = row_pose[m];
-  const int n6 = 6 * P;
+  const int pn = a.row_pose[n], pm = a.row_pose[m];
   if (tid < 36) {
     const double val = (double)(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
     const int c = tid / 6, d = tid % 6;
-    atomicAdd(&Hd[(long)(6 * pn + c) * n6 + 6 * pm + d], -val);
-    if (!diag) atomicAdd(&Hd[(long)(6 * pm + d) * n6 + 6 * pn + c], -val);
+    atomicAdd(&a.Hd[(long)(6 * pn + c) * n6 + 6 * pm + d], -val);
+    if (!diag) atomicAdd(&a.Hd[(long)(6 * pm + d) * n6 + 6 * pn + c], -val);
   } else if (diag && tid < 42) {
     const double val = (double)(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
-    atomicAdd(&vd[6 * pn + (tid - 36)], -val);
+    atomicAdd(&a.vd[6 * pn + (tid - 36)], -val);
   }
 }
 
-__global__ void ba_finalize_kernel(const double* __restrict__ Hd, const double* __restrict__ vd, int n6,
+// fp64 -> fp32, and re-zero the accumulators for the next linearisation (every element is read by
+// exactly one thread, so the system buffer needs a memset only once, when it is allocated)
+__global__ void ba_finalize_kernel(double* __restrict__ Hd, double* __restrict__ vd, int n6,
                                    float* __restrict__ H, float* __restrict__ v) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < n6 * n6) {
     const int r = idx / n6, c = idx - r * n6;
     H[idx] = (float)Hd[(long)c * n6 + r];  // get_dense() hands the column-major data over as row-major (:1305-1316)
+    Hd[(long)c * n6 + r] = 0.0;
   }
-  if (idx < n6) v[idx] = (float)vd[idx];
+  if (idx < n6) {
+    v[idx] = (float)vd[idx];
+    vd[idx] = 0.0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -502,9 +575,10 @@ __global__ void pose_retr_kernel(float* __restrict__ poses, const float* __restr
 // C ABI
 // ---------------------------------------------------------------------------------------------
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static int max_nch(int HW);
 
 struct WsLayout {
-  size_t Hd, vd, etab, Eiz, Cii, bz, total;
+  size_t Hd, vd, partial, Eiz, Cii, bz, total;
 };
 
 static WsLayout ws_layout(int M, int P, int HW) {
@@ -514,8 +588,8 @@ static WsLayout ws_layout(int M, int P, int HW) {
   off += align256(sizeof(double) * (size_t)36 * P * P + 8);
   L.vd = off;
   off += align256(sizeof(double) * (size_t)6 * P + 8);
-  L.etab = off;
-  off += align256(sizeof(float) * (size_t)ET_STRIDE * (M > 0 ? M : 1));
+  L.partial = off;
+  off += align256(sizeof(float) * (size_t)32 * (M > 0 ? M : 1) * max_nch(HW));
   L.Eiz = off;
   off += align256(sizeof(float) * (size_t)M * 6 * HW + 4);
   L.Cii = off;
@@ -531,13 +605,22 @@ extern "C" size_t ns_ba_workspace_bytes(const ns_ba_plan* plan, int HW) {
   return ws_layout(plan->M, plan->P, HW).total;
 }
 
+static int max_nch(int HW) { return (HW + 511) / 512; }
+
 static int choose_nch(int M, int HW) {
-  // ~256 workgroups of 4 waves fill the chip once; more chunks only add reduction epilogues
-  int nch = (256 + (M > 0 ? M : 1) - 1) / (M > 0 ? M : 1);
-  const int maxch = (HW + 255) / 256;
-  if (nch > maxch) nch = maxch;
-  if (nch < 1) nch = 1;
+  // The kernel is latency bound at tracking sizes (a few pixels per lane, dependent loads): use
+  // two pixels per lane until ~4096 workgroups are in flight, then grow the chunks instead.
+  int nch = max_nch(HW);
+  while (nch > 1 && (long)M * nch > 4096) nch = (nch + 1) / 2;
   return nch;
+}
+
+static int choose_sch(int n_pairs, int HW) {
+  int sch = 2048 / (n_pairs > 0 ? n_pairs : 1);
+  const int maxch = (HW + 255) / 256;
+  if (sch > maxch) sch = maxch;
+  if (sch < 1) sch = 1;
+  return sch;
 }
 
 // K1 as its own op (per-edge outputs, exactly the reference kernel's contract).
@@ -548,13 +631,11 @@ extern "C" int ns_projective_transform(const float* targets, const float* weight
                                        void* stream) {
   NS_REQUIRE(targets && weights && poses && disps && intrinsics && extrinsics && ii && jj,
              "ns_projective_transform: null input");
-  NS_REQUIRE(Hs && vs && Eiz && Ejz && Cii && bz && etab_ws, "ns_projective_transform: null output");
+  NS_REQUIRE(Hs && vs && Eiz && Ejz && Cii && bz, "ns_projective_transform: null output");
   NS_REQUIRE(M >= 0 && ht > 0 && wd > 0, "ns_projective_transform: bad shape");
   if (M == 0) return NS_OK;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ba_edge_prep_kernel, dim3(ns_cdiv(M, 64)), dim3(64), 0, st, poses, extrinsics, ii, jj, M,
-                     etab_ws);
-  NS_CHECK_LAUNCH("ba_edge_prep_kernel");
+  (void)etab_ws;  // kept in the signature for ABI stability; the constants now live in LDS
   LinArgs a;
   a.target = targets;
   a.weight = weights;
@@ -562,13 +643,13 @@ extern "C" int ns_projective_transform(const float* targets, const float* weight
   a.intr = intrinsics;
   a.ii = ii;
   a.jj = jj;
-  a.etab = etab_ws;
+  a.poses = poses;
+  a.extr = extrinsics;
   a.Eiz = Eiz;
   a.Ejz = Ejz;
   a.Cii = Cii;
   a.bz = bz;
-  a.Hd = nullptr;
-  a.vd = nullptr;
+  a.partial = nullptr;
   a.Hs = Hs;
   a.vs = vs;
   a.M = M;
@@ -587,7 +668,7 @@ extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, 
                                         const float* weights, const float* eta, const int64_t* ii, const int64_t* jj,
                                         const ns_ba_plan* plan, const int32_t* index, const size_t* off, int ht,
                                         int wd, float* H, float* v, float* Q, float* E, float* w, void* workspace,
-                                        void* stream) {
+                                        int ws_zeroed, void* stream) {
   NS_REQUIRE(plan && index && off, "ns_reduced_camera_matrix: null plan");
   NS_REQUIRE(poses && disps && intrinsics && extrinsics && disps_sens && eta, "ns_reduced_camera_matrix: null input");
   NS_REQUIRE(H && v && Q && E && w && workspace, "ns_reduced_camera_matrix: null output/workspace");
@@ -600,18 +681,18 @@ extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, 
   char* ws = (char*)workspace;
   double* Hd = (double*)(ws + L.Hd);
   double* vd = (double*)(ws + L.vd);
-  float* etab = (float*)(ws + L.etab);
   float* Eiz = (float*)(ws + L.Eiz);
   float* Cii = (float*)(ws + L.Cii);
   float* bz = (float*)(ws + L.bz);
-  // Hd and vd are adjacent in the layout: one memset
-  if (hipMemsetAsync(Hd, 0, L.etab - L.Hd, st) != hipSuccess) {
+  float* partial = (float*)(ws + L.partial);
+  // Hd and vd are adjacent in the layout: one memset, needed only the first time a workspace is used
+  // (ba_finalize_kernel re-zeroes what it reads)
+  if (!ws_zeroed && hipMemsetAsync(Hd, 0, L.partial - L.Hd, st) != hipSuccess) {
     ns_set_error("ns_reduced_camera_matrix: hipMemsetAsync failed");
     return NS_ELAUNCH;
   }
+  int nch = 1;
   if (M > 0) {
-    hipLaunchKernelGGL(ba_edge_prep_kernel, dim3(ns_cdiv(M, 64)), dim3(64), 0, st, poses, extrinsics, ii, jj, M, etab);
-    NS_CHECK_LAUNCH("ba_edge_prep_kernel");
     LinArgs a;
     a.target = targets;
     a.weight = weights;
@@ -619,19 +700,19 @@ extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, 
     a.intr = intrinsics;
     a.ii = ii;
     a.jj = jj;
-    a.etab = etab;
+    a.poses = poses;
+    a.extr = extrinsics;
     a.Eiz = Eiz;
     a.Ejz = E + (long)P * 6 * HW;
     a.Cii = Cii;
     a.bz = bz;
-    a.Hd = Hd;
-    a.vd = vd;
+    a.partial = partial;
     a.Hs = nullptr;
     a.vs = nullptr;
     a.M = M;
     a.HW = HW;
     a.wd = wd;
-    a.nch = choose_nch(M, HW);
+    a.nch = nch = choose_nch(M, HW);
     a.kf0 = plan->kf0;
     a.P = P;
     hipLaunchKernelGGL(ba_linearize_kernel<false>, dim3(M, a.nch), dim3(256), 0, st, a);
@@ -647,9 +728,28 @@ extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, 
                        eta, kx, src_ptr, src_edge, HW, plan->kf0, P, Q, w, E);
     NS_CHECK_LAUNCH("ba_accum_kernel");
   }
-  if (plan->n_pairs > 0) {
-    hipLaunchKernelGGL(ba_schur_kernel, dim3(plan->n_pairs), dim3(256), 0, st, E, Q, w, pairs, row_pose, HW, P, Hd,
-                       vd);
+  if (plan->n_pairs + M > 0) {
+    SchurArgs sa;
+    sa.E = E;
+    sa.Q = Q;
+    sa.w = w;
+    sa.pairs = pairs;
+    sa.row_pose = row_pose;
+    sa.partial = partial;
+    sa.poses = poses;
+    sa.extr = extrinsics;
+    sa.ii = ii;
+    sa.jj = jj;
+    sa.Hd = Hd;
+    sa.vd = vd;
+    sa.HW = HW;
+    sa.P = P;
+    sa.kf0 = plan->kf0;
+    sa.n_pairs = plan->n_pairs;
+    sa.sch = choose_sch(plan->n_pairs, HW);
+    sa.nch = nch;
+    sa.M = M;
+    hipLaunchKernelGGL(ba_schur_kernel, dim3(plan->n_pairs * sa.sch + M), dim3(256), 0, st, sa);
     NS_CHECK_LAUNCH("ba_schur_kernel");
   }
   if (n6 > 0) {

@@ -29,33 +29,55 @@ struct SolveArgs {
   float ep, lm;        // (H + ep + lm*diag(H)) as SparseBlock::solve (:1318-1340); 0,0 in the live path
   int kf0, P;
   int mode;            // 0: live path (right retraction of world_T_body), 1: solve only
+  int want_inv;        // 1: carry n identity border rows through the factorisation (they become L^-1)
   float* dx;           // [P,6]
   double* Hfull;       // [n,n] or null: the symmetric system actually solved (with prior)
   float* Linv;         // [n,n] or null: inverse Cholesky factor, lower triangular, f32
-  double* Linv_ws;     // [n,n] scratch (required when Linv or sigma_g is requested)
+  double* Linv_ws;     // unused (kept for ABI stability)
   float* sigma_g;      // [P,6,6] or null: diagonal blocks of (L L^T)^-1
   int32_t* info;
 };
 
+// 6x6 lower-triangular block helpers; D[r(r+1)/2+c] = L[j0+r][j0+c]
+__device__ __forceinline__ void load_diag(const double* Lp, int j0, double* D) {
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int c = 0; c <= r; c++) D[r * (r + 1) / 2 + c] = Lp[tri(j0 + r, j0 + c)];
+}
+
+// The system is stored as a packed lower triangle with ONE EXTRA ROW holding the right-hand side:
+// factoring the bordered matrix [[A, b],[b^T, .]] leaves y = L^-1 b in that row, so the forward
+// substitution costs no extra barriers.
 __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x;
   const int P = a.P, n = 6 * P;
-  double* Lp = lds;                       // n(n+1)/2
-  double* rhs = lds + (size_t)n * (n + 1) / 2;  // n
-  double* x = rhs + n;                    // n
+  const int ntri = n * (n + 1) / 2;
+  double* Lp = lds;          // rows 0..n-1: factor; row n (offset ntri): rhs -> y
+  double* yrow = lds + ntri;  // n
+  double* x = yrow + n;       // n
+  double* rd = x + n;         // n: reciprocals of the factor's diagonal
+  double* Xb = rd + n;        // [n][n] identity border rows -> Xb[c][k] = (L^-1)[k][c]  (only when a.want_inv)
+  const int nrows = a.want_inv ? 2 * n + 1 : n + 1;  // matrix rows + rhs row (+ n identity rows)
+  auto rowp = [&](int i, int c0) -> double* {  // address of entry (i, c0); border rows are dense
+    return (i < n) ? Lp + tri(i, c0) : (i == n ? yrow + c0 : Xb + (long)(i - n - 1) * n + c0);
+  };
   __shared__ int fail;
   if (tid == 0) fail = 0;
 
   // ---- load the upper triangle of H (what the HessianFactors keep) ----
-  for (int r = tid; r < n; r += SOLVE_THREADS) {
-    for (int c = 0; c <= r; c++) {
+  for (int idx = tid; idx < n * n; idx += SOLVE_THREADS) {
+    const int r = idx / n, c = idx - r * n;
+    if (c <= r) {
       double h = (double)a.H[(long)c * n + r];
       if (c == r) h += (double)a.ep + (double)a.lm * h;
       Lp[tri(r, c)] = h;
     }
-    rhs[r] = (double)a.v[r];
   }
+  for (int r = tid; r < n; r += SOLVE_THREADS) yrow[r] = (double)a.v[r];
+  if (a.want_inv)
+    for (int idx = tid; idx < n * n; idx += SOLVE_THREADS) Xb[idx] = (idx / n == idx % n) ? 1.0 : 0.0;
   __syncthreads();
   if (a.prior != nullptr && tid == 0) {
     double pr[7], x0[7], pinv[7], rel[7], e[6];
@@ -69,101 +91,116 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(SolveArgs a) {
     const double info = 1.0 / ((double)a.prior_sigma * (double)a.prior_sigma);
     for (int k = 0; k < 6; k++) {
       Lp[tri(k, k)] += info;
-      rhs[k] += -e[k] * info;
+      yrow[k] += -e[k] * info;
     }
   }
   __syncthreads();
   if (a.Hfull != nullptr) {
-    for (int r = tid; r < n; r += SOLVE_THREADS)
-      for (int c = 0; c <= r; c++) {
-        const double h = Lp[tri(r, c)];
-        a.Hfull[(long)r * n + c] = h;
-        a.Hfull[(long)c * n + r] = h;
-      }
+    for (int idx = tid; idx < n * n; idx += SOLVE_THREADS) {
+      const int r = idx / n, c = idx - r * n;
+      a.Hfull[idx] = (c <= r) ? Lp[tri(r, c)] : Lp[tri(c, r)];
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
-  // ---- blocked Cholesky, block = one pose (6) ----
+  // ---- blocked right-looking Cholesky of the bordered system, block = one pose (6) ----
   for (int jb = 0; jb < P; jb++) {
     const int j0 = 6 * jb;
-    if (tid == 0) {
-      for (int j = j0; j < j0 + 6; j++) {
-        double s = Lp[tri(j, j)];
-        for (int k = j0; k < j; k++) s -= Lp[tri(j, k)] * Lp[tri(j, k)];
+    if (tid == 0) {  // diagonal block in registers (one LDS round trip instead of ~100 dependent ones)
+      double D[21];
+      load_diag(Lp, j0, D);
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        double s = D[j * (j + 1) / 2 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= D[j * (j + 1) / 2 + k] * D[j * (j + 1) / 2 + k];
         if (!(s > 0.0)) {
-          fail = j + 1;
+          fail = j0 + j + 1;
           s = 1.0;
         }
         const double d = sqrt(s);
-        Lp[tri(j, j)] = d;
-        for (int i = j + 1; i < j0 + 6; i++) {
-          double t = Lp[tri(i, j)];
-          for (int k = j0; k < j; k++) t -= Lp[tri(i, k)] * Lp[tri(j, k)];
-          Lp[tri(i, j)] = t / d;
+        const double di = 1.0 / d;
+        D[j * (j + 1) / 2 + j] = d;
+        rd[j0 + j] = di;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+          double t = D[i * (i + 1) / 2 + j];
+#pragma unroll
+          for (int k = 0; k < j; k++) t -= D[i * (i + 1) / 2 + k] * D[j * (j + 1) / 2 + k];
+          D[i * (i + 1) / 2 + j] = t * di;
         }
       }
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c <= r; c++) Lp[tri(j0 + r, j0 + c)] = D[r * (r + 1) / 2 + c];
     }
     __syncthreads();
-    // panel: rows below the diagonal block,  X * Ljj^T = A_ij
-    for (int i = j0 + 6 + tid; i < n; i += SOLVE_THREADS) {
-      double X[6];
+    // panel: rows below the diagonal block (row n = rhs),  X * Ljj^T = A_ij
+    for (int i = j0 + 6 + tid; i < nrows; i += SOLVE_THREADS) {
+      double D[21], X[6], R[6];
+      load_diag(Lp, j0, D);
+      double* row = rowp(i, j0);
 #pragma unroll
       for (int c = 0; c < 6; c++) {
-        double t = Lp[tri(i, j0 + c)];
-        for (int k = 0; k < c; k++) t -= X[k] * Lp[tri(j0 + c, j0 + k)];
-        X[c] = t / Lp[tri(j0 + c, j0 + c)];
+        X[c] = row[c];
+        R[c] = rd[j0 + c];
       }
 #pragma unroll
-      for (int c = 0; c < 6; c++) Lp[tri(i, j0 + c)] = X[c];
+      for (int c = 0; c < 6; c++) {
+        double t = X[c];
+#pragma unroll
+        for (int k = 0; k < c; k++) t -= X[k] * D[c * (c + 1) / 2 + k];
+        X[c] = t * R[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) row[c] = X[c];
     }
     __syncthreads();
-    // trailing update on a 16x16 thread grid
+    // trailing update on a 16x16 thread grid; the row's panel entries stay in registers
     const int tx = tid & 15, ty = tid >> 4;
-    for (int i = j0 + 6 + ty; i < n; i += 16)
-      for (int k = j0 + 6 + tx; k <= i; k += 16) {
+    for (int i = j0 + 6 + ty; i < nrows; i += 16) {
+      double Ri[6];
+      const double* ri = rowp(i, j0);
+#pragma unroll
+      for (int c = 0; c < 6; c++) Ri[c] = ri[c];
+      const int kmax = (i < n) ? i : n - 1;  // border rows have no diagonal entry
+      double* out = rowp(i, 0);
+      for (int k = j0 + 6 + tx; k <= kmax; k += 16) {
+        const double* rk = Lp + tri(k, j0);
         double s = 0.0;
 #pragma unroll
-        for (int c = 0; c < 6; c++) s += Lp[tri(i, j0 + c)] * Lp[tri(k, j0 + c)];
-        Lp[tri(i, k)] -= s;
+        for (int c = 0; c < 6; c++) s += Ri[c] * rk[c];
+        out[k] -= s;
       }
+    }
     __syncthreads();
   }
 
-  // ---- forward substitution L y = rhs (y overwrites rhs) ----
-  for (int jb = 0; jb < P; jb++) {
-    const int j0 = 6 * jb;
-    if (tid == 0) {
-      for (int c = 0; c < 6; c++) {
-        double t = rhs[j0 + c];
-        for (int k = 0; k < c; k++) t -= Lp[tri(j0 + c, j0 + k)] * rhs[j0 + k];
-        rhs[j0 + c] = t / Lp[tri(j0 + c, j0 + c)];
-      }
-    }
-    __syncthreads();
-    for (int i = j0 + 6 + tid; i < n; i += SOLVE_THREADS) {
-      double s = 0.0;
-#pragma unroll
-      for (int c = 0; c < 6; c++) s += Lp[tri(i, j0 + c)] * rhs[j0 + c];
-      rhs[i] -= s;
-    }
-    __syncthreads();
-  }
   // ---- backward substitution L^T x = y ----
   for (int jb = P - 1; jb >= 0; jb--) {
     const int j0 = 6 * jb;
     if (tid == 0) {
+      double D[21], Y[6], X[6];
+      load_diag(Lp, j0, D);
+#pragma unroll
+      for (int c = 0; c < 6; c++) Y[c] = yrow[j0 + c];
+#pragma unroll
       for (int c = 5; c >= 0; c--) {
-        double t = rhs[j0 + c];
-        for (int k = c + 1; k < 6; k++) t -= Lp[tri(j0 + k, j0 + c)] * x[j0 + k];
-        x[j0 + c] = t / Lp[tri(j0 + c, j0 + c)];
+        double t = Y[c];
+#pragma unroll
+        for (int k = c + 1; k < 6; k++) t -= D[k * (k + 1) / 2 + c] * X[k];
+        X[c] = t * rd[j0 + c];
       }
+#pragma unroll
+      for (int c = 0; c < 6; c++) x[j0 + c] = X[c];
     }
     __syncthreads();
     for (int i = tid; i < j0; i += SOLVE_THREADS) {
       double s = 0.0;
 #pragma unroll
       for (int c = 0; c < 6; c++) s += Lp[tri(j0 + c, i)] * x[j0 + c];
-      rhs[i] -= s;
+      yrow[i] -= s;
     }
     __syncthreads();
   }
@@ -194,29 +231,26 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(SolveArgs a) {
     }
   }
 
-  // ---- L^-1 (one lane per column) and the pose marginals ----
-  if ((a.Linv != nullptr || a.sigma_g != nullptr) && a.Linv_ws != nullptr) {
-    for (int c = tid; c < n; c += SOLVE_THREADS) {
-      double* col = a.Linv_ws + (long)c * n;  // col[r] = Linv[r][c]
-      for (int r = 0; r < c; r++) col[r] = 0.0;
-      col[c] = 1.0 / Lp[tri(c, c)];
-      for (int r = c + 1; r < n; r++) {
-        double s = 0.0;
-        for (int k = c; k < r; k++) s += Lp[tri(r, k)] * col[k];
-        col[r] = -s / Lp[tri(r, r)];
+  // ---- L^-1 (already sitting in the identity border rows) and the pose marginals ----
+  if (a.want_inv) {
+    if (a.Linv != nullptr)
+      for (int idx = tid; idx < n * n; idx += SOLVE_THREADS) {
+        const int r = idx / n, c = idx - r * n;
+        a.Linv[idx] = (failed || c > r) ? 0.0f : (float)Xb[(long)c * n + r];
       }
-      if (a.Linv != nullptr)
-        for (int r = 0; r < n; r++) a.Linv[(long)r * n + c] = failed ? 0.0f : (float)col[r];
-    }
-    __syncthreads();
     if (a.sigma_g != nullptr) {
       for (int t = tid; t < 36 * P; t += SOLVE_THREADS) {
         const int i = t / 36, aa = (t % 36) / 6, bb = t % 6;
-        const double* ca = a.Linv_ws + (long)(6 * i + aa) * n;
-        const double* cb = a.Linv_ws + (long)(6 * i + bb) * n;
-        double s = 0.0;
-        for (int r = 6 * i; r < n; r++) s += ca[r] * cb[r];
-        a.sigma_g[t] = failed ? 0.0f : (float)s;
+        const double* ca = Xb + (long)(6 * i + aa) * n;
+        const double* cb = Xb + (long)(6 * i + bb) * n;
+        double s0 = 0.0, s1 = 0.0;
+        int r = 6 * i;
+        for (; r + 1 < n; r += 2) {
+          s0 += ca[r] * cb[r];
+          s1 += ca[r + 1] * cb[r + 1];
+        }
+        if (r < n) s0 += ca[r] * cb[r];
+        a.sigma_g[t] = failed ? 0.0f : (float)(s0 + s1);
       }
     }
   }
@@ -228,21 +262,28 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(SolveArgs a) {
 // (the reference right-multiplies by L^-1, :1215; reproduced as is).  Column tiles of 48 keep the
 // accumulators in registers; Linv entries are wave-uniform scalar operands.
 // ---------------------------------------------------------------------------------------------
-#define COV_TILE 48
+#define COV_TILE 32
 __global__ __launch_bounds__(256) void ba_depth_cov_kernel(const float* __restrict__ Linv,
                                                            const float* __restrict__ Q, const float* __restrict__ E,
                                                            const int32_t* __restrict__ row_pose,
                                                            const int32_t* __restrict__ slot_rows_ptr,
                                                            const int32_t* __restrict__ slot_rows, int HW, int P,
                                                            float* __restrict__ z_cov) {
+  extern __shared__ __attribute__((aligned(16))) float Ls[];  // Linv, row stride ns (multiple of 32)
   const int k = blockIdx.x;
   const int p = blockIdx.y * 256 + threadIdx.x;
-  if (p >= HW) return;
   const int n = 6 * P;
+  const int ns = (n + COV_TILE - 1) / COV_TILE * COV_TILE;
+  for (int idx = threadIdx.x; idx < n * ns; idx += 256) {
+    const int r = idx / ns, c = idx - r * ns;
+    Ls[idx] = (c < n) ? Linv[(long)r * n + c] : 0.0f;
+  }
+  __syncthreads();
+  if (p >= HW) return;
   const float q = Q[(long)k * HW + p];
   float total = 0.0f;
   const int r0 = slot_rows_ptr[k], r1 = slot_rows_ptr[k + 1];
-  for (int j0 = 0; j0 < n; j0 += COV_TILE) {
+  for (int j0 = 0; j0 < ns; j0 += COV_TILE) {
     float acc[COV_TILE];
 #pragma unroll
     for (int j = 0; j < COV_TILE; j++) acc[j] = 0.0f;
@@ -254,10 +295,15 @@ __global__ __launch_bounds__(256) void ba_depth_cov_kernel(const float* __restri
 #pragma unroll
       for (int c = 0; c < 6; c++) {
         const float e = E[((long)row * 6 + c) * HW + p] * q;
-        const float* __restrict__ Lr = Linv + (long)(6 * pose + c) * n + j0;
+        const float4* __restrict__ Lr = reinterpret_cast<const float4*>(Ls + (6 * pose + c) * ns + j0);
 #pragma unroll
-        for (int j = 0; j < COV_TILE; j++)
-          if (j0 + j < n) acc[j] += e * Lr[j];
+        for (int j = 0; j < COV_TILE / 4; j++) {
+          const float4 l = Lr[j];  // wave-uniform address: LDS broadcast
+          acc[4 * j + 0] += e * l.x;
+          acc[4 * j + 1] += e * l.y;
+          acc[4 * j + 2] += e * l.z;
+          acc[4 * j + 3] += e * l.w;
+        }
       }
     }
 #pragma unroll
@@ -309,12 +355,22 @@ extern "C" int ns_ba_solve(const float* H, const float* v, float* world_T_body, 
   const int P = kf1 - kf0, n = 6 * P;
   NS_REQUIRE(P >= 0, "ns_ba_solve: kf1 < kf0");
   NS_REQUIRE(mode == 1 || (world_T_body && cam_T_world && cam_T_body), "ns_ba_solve: mode 0 needs the pose buffers");
-  NS_REQUIRE(!(Linv_out || sigma_g_out) || Linv_ws, "ns_ba_solve: Linv/sigma_g need the Linv_ws scratch");
   if (P == 0) return NS_OK;
-  const size_t lds = sizeof(double) * ((size_t)n * (n + 1) / 2 + 2 * (size_t)n);
-  if (lds > 160 * 1024 - 64) {
+  const size_t tri_b = sizeof(double) * ((size_t)n * (n + 1) / 2);
+  size_t lds = tri_b + sizeof(double) * 3 * (size_t)n;
+  const size_t lds_max = 160 * 1024 - 256;
+  if (lds > lds_max) {
     ns_set_error("ns_ba_solve: 6P=%d needs %zu B of LDS (> 160 KiB): use the large-system path", n, lds);
     return NS_ENOSUP;
+  }
+  const int want_inv = (Linv_out || sigma_g_out) ? 1 : 0;
+  if (want_inv) {
+    lds += sizeof(double) * (size_t)n * n;
+    if (lds > lds_max) {
+      ns_set_error("ns_ba_solve: 6P=%d with covariances needs %zu B of LDS (> 160 KiB): use the large-system path", n,
+                   lds);
+      return NS_ENOSUP;
+    }
   }
   static thread_local size_t configured = 0;
   if (lds > configured) {
@@ -339,6 +395,7 @@ extern "C" int ns_ba_solve(const float* H, const float* v, float* world_T_body, 
   a.kf0 = kf0;
   a.P = P;
   a.mode = mode;
+  a.want_inv = want_inv;
   a.dx = dx;
   a.Hfull = Hfull_out;
   a.Linv = Linv_out;
@@ -354,7 +411,22 @@ extern "C" int ns_ba_depth_cov(const float* Linv, const float* Q, const float* E
                                const int32_t* index, const size_t* off, int HW, float* z_cov, void* stream) {
   NS_REQUIRE(Linv && Q && E && plan && index && off && z_cov, "ns_ba_depth_cov: null pointer");
   if (plan->K == 0) return NS_OK;
-  hipLaunchKernelGGL(ba_depth_cov_kernel, dim3(plan->K, ns_cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream, Linv, Q, E,
+  const int n = 6 * plan->P, ns = (n + COV_TILE - 1) / COV_TILE * COV_TILE;
+  const size_t lds = sizeof(float) * (size_t)n * ns;
+  if (lds > 160 * 1024 - 256) {
+    ns_set_error("ns_ba_depth_cov: 6P=%d does not fit LDS (the reference skips covariances in global BA too)", n);
+    return NS_ENOSUP;
+  }
+  static thread_local size_t configured = 0;
+  if (lds > configured && lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)ba_depth_cov_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess) {
+      ns_set_error("ns_ba_depth_cov: hipFuncSetAttribute failed");
+      return NS_ELAUNCH;
+    }
+    configured = lds;
+  }
+  hipLaunchKernelGGL(ba_depth_cov_kernel, dim3(plan->K, ns_cdiv(HW, 256)), dim3(256), lds, (hipStream_t)stream, Linv, Q, E,
                      index + off[2], index + off[6], index + off[7], HW, plan->P, z_cov);
   NS_CHECK_LAUNCH("ba_depth_cov_kernel");
   return NS_OK;

@@ -32,15 +32,27 @@ void ns_set_error(const char* fmt, ...);
 static inline int ns_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------
-// wave64 / block reductions.  DPP row shifts inside 16-lane rows, then row broadcasts: six
-// full-rate VALU adds, no LDS traffic.  Result is valid in lane 63.
+// wave64 reductions on the VALU: six DPP-modified adds (quad swaps, half-row / row mirrors, then
+// the row broadcasts), no LDS crossbar traffic and no waitcnt per step -- `__shfl_xor` lowers to
+// ds_bpermute_b32 on gfx950, whose ~100-cycle latency per step made the 27- and 42-value epilogues
+// of the BA kernels cost more than their pixel loops.  The total ends in lane 63; wave_sum()
+// broadcasts it with one readlane so every lane (and any later scalar use) sees the same value.
+// The order of the additions is fixed, so results are bit-reproducible.
 // ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true);
+  return v + __builtin_bit_cast(float, moved);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-  // __shfl_xor lowers to DPP / ds_swizzle / permlane on gfx950; the butterfly leaves the total in
-  // every lane, which the callers rely on (any lane may publish it).
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);  // row_mirror      -> every lane holds its 16-lane row total
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast15 into rows 1,3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast31 into rows 2,3 -> lane 63 holds the wave total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {

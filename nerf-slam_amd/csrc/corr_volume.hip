@@ -1,0 +1,276 @@
+// corr_volume.hip -- all-pairs correlation volume + 4-level pyramid in ONE kernel (gfx950, MFMA).
+//
+// Replaces CorrBlock.__init__ of the reference (networks/modules/corr.py:23-38, 63-72):
+//   corr = (fmap1/4)^T (fmap2/4)            torch.matmul -> [HW, HW] per edge, f16 out
+//   3 x F.avg_pool2d(corr, 2)               three more full passes over the volume
+// i.e. the volume is written once and then re-read 1.33x and the pooled levels written by separate
+// launches.  The job is OUTPUT-WRITE bound (K = 128: 96 flop per written byte, far under the f16
+// MFMA ridge), so what matters is writing every byte exactly once AND in whole 128-byte lines
+// (a first version that stored 16-byte pieces of 256 open lines per wave ran at 0.7 TB/s: with
+// thousands of waves the open lines overflow the L2 and reach HBM as masked partial writes):
+//
+//   * features are channels-last [HW][128] f16, so both MFMA operands (8 consecutive k of one
+//     row per lane) are plain 16-byte loads of L2-resident data;
+//   * a wave owns 32 source pixels p (MFMA B operand, all of K resident in 32 VGPRs) and walks the
+//     target image row by row in chunks of 64 pixels: two v_mfma_f32_32x32x16_f16 tiles whose
+//     A-operand rows are PERMUTED target pixels, chosen so that the 2 x 16 accumulators of a lane
+//     are 32 consecutive x of one (p, y) row: a lane stores 64 contiguous bytes, the lane pair
+//     (l, l+32) a complete 128-byte line -- every volume line is written once, whole;
+//   * the 2x2 / 4x4 / 8x8 average pools run in the lane's own registers across the 8 rows of a
+//     band (no cross-lane traffic at all) and are stored as 32 / 16 / 8-byte runs;
+//   * rounding follows the reference exactly: level 0 = f16(f32 accumulator), level l+1 =
+//     f16((a+b+c+d in f32, row-major order)/4) of the ROUNDED level-l values.
+#include "common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct VolArgs {
+  const _Float16* f1;  // [n1][HW][C] channels-last, already divided by 4
+  const _Float16* f2;  // [n2][HW][C]
+  const int64_t* ii;   // optional frame indices into f1 / f2 (null: edge e uses row e)
+  const int64_t* jj;
+  _Float16* pyr[4];    // level l: [E][HW][h>>l][w>>l]
+  int E, ht, wd, num_levels;
+};
+
+__device__ __forceinline__ _Float16 pool4(_Float16 a, _Float16 b, _Float16 c, _Float16 d) {
+  float acc = 0.0f;
+  acc += (float)a;
+  acc += (float)b;
+  acc += (float)c;
+  acc += (float)d;
+  return (_Float16)(acc / 4.0f);
+}
+
+// store N consecutive halves (N = 2,4,8 -> 4/8/16-byte store), element-wise at the image border
+template <int N>
+__device__ __forceinline__ void store_run(_Float16* dst, const _Float16* v, int nvalid) {
+  typedef _Float16 vec_t __attribute__((ext_vector_type(N)));
+  if (nvalid >= N) {
+    struct __attribute__((packed, aligned(2))) U { vec_t v; };
+    vec_t o;
+#pragma unroll
+    for (int k = 0; k < N; k++) o[k] = v[k];
+    reinterpret_cast<U*>(dst)->v = o;
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      if (k < nvalid) dst[k] = v[k];
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void store_row(_Float16* dst, const _Float16* v, int nvalid) {
+  if (W >= 8) {
+#pragma unroll
+    for (int k = 0; k < W; k += 8) store_run<8>(dst + k, v + k, nvalid - k);
+  } else if (W == 4) {
+    store_run<4>(dst, v, nvalid);
+  } else {
+    store_run<2>(dst, v, nvalid);
+  }
+}
+
+// ---- LDS staging of the target-image rows --------------------------------------------------------
+// One row chunk = up to 64 consecutive target pixels x 128 channels = 16 KiB.  The four waves of a
+// workgroup (4 x 32 source pixels) all multiply against the same chunk, so it is fetched ONCE per
+// workgroup with fully coalesced 1 KiB wave loads (lane = 16 bytes, 16 lanes per pixel row) instead
+// of 16 scattered 16-byte loads per lane and wave (which made the first version address-coalescer
+// bound).  Row stride 272 B (256 + 16) puts the 16-byte slot of (row r, slot s) at (17 r + s) mod 16,
+// which makes both the staging writes and the fragment reads (row = permuted x, see below) conflict
+// free.  Two buffers: the loads of the next row are in flight while the current one is multiplied.
+#define ROWB 272
+#define TILEB (64 * ROWB)
+
+template <int C>
+__device__ __forceinline__ void stage_load(const _Float16* __restrict__ F2row, int x0, int wd, int tid, uint4* regs) {
+  // 64 rows x 256 B = 1024 pieces of 16 B over 256 lanes: 4 per lane; piece id = tid + 256*k
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int piece = tid + 256 * k;
+    const int r = piece >> 4, sl = piece & 15;
+    const int x = x0 + r;
+    regs[k] = (x < wd) ? *reinterpret_cast<const uint4*>(F2row + (long)x * C + sl * 8) : make_uint4(0, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void stage_store(char* tile, int tid, const uint4* regs) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int piece = tid + 256 * k;
+    const int r = piece >> 4, sl = piece & 15;
+    *reinterpret_cast<uint4*>(tile + r * ROWB + sl * 16) = regs[k];
+  }
+}
+
+// NT tiles (NT*32 target pixels of the staged row) against the wave's 32 source pixels.
+// Lane (col, half) ends up with v[0 .. 16*NT) = corr(p, y, x0 + 16*NT*half + k).
+template <int C, int NT>
+__device__ __forceinline__ void row_chunk(const char* tile, const f16x8* src, int col, int half, _Float16* v) {
+  constexpr int KS = C / 16;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) acc[t] = (f32x16)0.0f;
+  // A-operand row i of tile t  <->  staged row  xr = (i&3) + 4*(i>>3) + 16*t + 16*NT*((i>>2)&1)
+  const char* rows[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+    rows[t] = tile + ((col & 3) + 4 * (col >> 3) + 16 * t + 16 * NT * ((col >> 2) & 1)) * ROWB + half * 16;
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) {  // interleave the independent accumulator chains
+      const f16x8 tgt = *reinterpret_cast<const f16x8*>(rows[t] + kk * 32);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tgt, src[kk], acc[t], 0, 0, 0);
+    }
+  }
+  // accumulator r of tile t (this lane's half h): i = (r&3) + 8*(r>>2) + 4*h  ->  x - x0 - 16*NT*h = r + 16*t
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[16 * t + r] = (_Float16)acc[t][r];
+}
+
+// One band (8 target rows) x one chunk of 32*NT target columns, for the whole workgroup.
+template <int C, int NT>
+__device__ __forceinline__ void band_chunk(const VolArgs& a, const _Float16* __restrict__ F2, const f16x8* src,
+                                           char* lds, int y0, int x0, int col, int half, bool pok, _Float16* o0,
+                                           _Float16* o1, _Float16* o2, _Float16* o3) {
+  constexpr int W = 16 * NT;  // consecutive x held by a lane
+  const int wd = a.wd, ht = a.ht, tid = threadIdx.x;
+  const int w1 = wd >> 1, w2 = wd >> 2, w3 = wd >> 3, h1 = ht >> 1, h2 = ht >> 2, h3 = ht >> 3;
+  const int xl = x0 + W * half;  // first x of this lane
+  const int nrows = min(8, ht - y0);
+  uint4 regs[4];
+  // prologue: row 0 of the band into buffer 0
+  __syncthreads();  // every wave is done reading both buffers (previous chunk)
+  stage_load<C>(F2 + (long)y0 * wd * C, x0, wd, tid, regs);
+  stage_store(lds, tid, regs);
+  __syncthreads();
+  _Float16 prev0[W], prev1[W / 2], prev2[W / 4];
+#pragma unroll 1
+  for (int yy = 0; yy < nrows; yy++) {
+    const int y = y0 + yy;
+    const char* cur = lds + (yy & 1) * TILEB;
+    char* nxt = lds + ((yy + 1) & 1) * TILEB;
+    const bool more = yy + 1 < nrows;
+    if (more) stage_load<C>(F2 + (long)(y + 1) * wd * C, x0, wd, tid, regs);  // in flight during the MFMAs
+    _Float16 v[W];
+    row_chunk<C, NT>(cur, src, col, half, v);
+    if (more) stage_store(nxt, tid, regs);
+    if (pok) store_row<W>(o0 + (long)y * wd + xl, v, wd - xl);
+    if (a.num_levels > 1) {
+      if (yy & 1) {
+        _Float16 l1[W / 2];
+#pragma unroll
+        for (int c = 0; c < W / 2; c++) l1[c] = pool4(prev0[2 * c], prev0[2 * c + 1], v[2 * c], v[2 * c + 1]);
+        if (pok && (y >> 1) < h1) store_row<W / 2>(o1 + (long)(y >> 1) * w1 + (xl >> 1), l1, w1 - (xl >> 1));
+        if (a.num_levels > 2) {
+          if ((yy & 3) == 3) {
+            _Float16 l2[W / 4];
+#pragma unroll
+            for (int c = 0; c < W / 4; c++) l2[c] = pool4(prev1[2 * c], prev1[2 * c + 1], l1[2 * c], l1[2 * c + 1]);
+            if (pok && (y >> 2) < h2) store_row<W / 4>(o2 + (long)(y >> 2) * w2 + (xl >> 2), l2, w2 - (xl >> 2));
+            if (a.num_levels > 3) {
+              if (yy == 7) {
+                _Float16 l3[W / 8];
+#pragma unroll
+                for (int c = 0; c < W / 8; c++) l3[c] = pool4(prev2[2 * c], prev2[2 * c + 1], l2[2 * c], l2[2 * c + 1]);
+                if (pok && (y >> 3) < h3) store_row<W / 8>(o3 + (long)(y >> 3) * w3 + (xl >> 3), l3, w3 - (xl >> 3));
+              } else {
+#pragma unroll
+                for (int c = 0; c < W / 4; c++) prev2[c] = l2[c];
+              }
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < W / 2; c++) prev1[c] = l1[c];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < W; c++) prev0[c] = v[c];
+      }
+    }
+    __syncthreads();  // next buffer filled by all waves, current buffer free for the row after next
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void corr_volume_pyramid_kernel(VolArgs a) {
+  constexpr int KS = C / 16;  // k-steps of the 32x32x16 MFMA
+  __shared__ __attribute__((aligned(16))) char lds[2 * TILEB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int HW = a.ht * a.wd;
+  const int e = blockIdx.y;
+  const int p0 = (blockIdx.x * 4 + wave) * 32;
+  const long fi = a.ii ? a.ii[e] : e, fj = a.jj ? a.jj[e] : e;
+  const _Float16* __restrict__ F1 = a.f1 + fi * (long)HW * C;
+  const _Float16* __restrict__ F2 = a.f2 + fj * (long)HW * C;
+
+  // B operand of the MFMA = this wave's 32 source pixels, all K, resident in registers.
+  // Waves past the end of the image stay alive (they take part in the staging and the barriers).
+  const int p = p0 + col;
+  const bool pok = p < HW;
+  f16x8 src[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) {
+    src[kk] = *reinterpret_cast<const f16x8*>(F1 + (long)(pok ? p : 0) * C + kk * 16 + half * 8);
+    if (!pok) src[kk] = (f16x8)(_Float16)0;
+  }
+  const long pp = (long)e * HW + (pok ? p : 0);
+  _Float16* o0 = a.pyr[0] + pp * (long)HW;
+  _Float16* o1 = a.num_levels > 1 ? a.pyr[1] + pp * (long)(a.ht >> 1) * (a.wd >> 1) : nullptr;
+  _Float16* o2 = a.num_levels > 2 ? a.pyr[2] + pp * (long)(a.ht >> 2) * (a.wd >> 2) : nullptr;
+  _Float16* o3 = a.num_levels > 3 ? a.pyr[3] + pp * (long)(a.ht >> 3) * (a.wd >> 3) : nullptr;
+
+  const int nby = (a.ht + 7) >> 3;
+  for (int by = blockIdx.z; by < nby; by += gridDim.z) {
+    int x0 = 0;
+    for (; x0 + 32 < a.wd; x0 += 64) band_chunk<C, 2>(a, F2, src, lds, by * 8, x0, col, half, pok, o0, o1, o2, o3);
+    if (x0 < a.wd) band_chunk<C, 1>(a, F2, src, lds, by * 8, x0, col, half, pok, o0, o1, o2, o3);
+  }
+}
+
+extern "C" int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, const int64_t* ii, const int64_t* jj,
+                                      void* const* pyr_host, int num_levels, int E, int C, int ht, int wd,
+                                      void* stream) {
+  NS_REQUIRE(fmap1 && fmap2 && pyr_host, "ns_corr_volume_pyramid: null pointer");
+  NS_REQUIRE(num_levels >= 1 && num_levels <= 4, "ns_corr_volume_pyramid: num_levels=%d not in 1..4", num_levels);
+  NS_REQUIRE(E >= 0 && ht > 0 && wd > 0, "ns_corr_volume_pyramid: bad shape");
+  NS_REQUIRE((ii == nullptr) == (jj == nullptr), "ns_corr_volume_pyramid: pass both index arrays or neither");
+  if (C != 128) {
+    ns_set_error("ns_corr_volume_pyramid: built for C=128 feature channels (the reference's setting, "
+                 "visual_frontend.py:134), got %d", C);
+    return NS_ENOSUP;
+  }
+  if (E == 0) return NS_OK;
+  VolArgs a;
+  a.f1 = (const _Float16*)fmap1;
+  a.f2 = (const _Float16*)fmap2;
+  a.ii = ii;
+  a.jj = jj;
+  for (int l = 0; l < 4; l++) {
+    a.pyr[l] = (_Float16*)(l < num_levels ? pyr_host[l] : nullptr);
+    NS_REQUIRE(l >= num_levels || a.pyr[l] != nullptr, "ns_corr_volume_pyramid: pyr[%d] is null", l);
+  }
+  a.E = E;
+  a.ht = ht;
+  a.wd = wd;
+  a.num_levels = num_levels;
+  const int HW = ht * wd;
+  // The sweep over the target image is latency bound per wave (16 dependent 16-byte loads per 8x8
+  // block); split it over 8-row bands until ~4 workgroups per CU are in flight.
+  const int nby = (ht + 7) / 8;
+  int zs = ns_cdiv(1024, (long)ns_cdiv(HW, 128) * E);
+  if (zs > nby) zs = nby;
+  if (zs < 1) zs = 1;
+  dim3 grid(ns_cdiv(HW, 128), E, zs);
+  hipLaunchKernelGGL(corr_volume_pyramid_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  NS_CHECK_LAUNCH("corr_volume_pyramid_kernel");
+  return NS_OK;
+}

@@ -59,7 +59,7 @@ class BaPlan:
     def workspace(self, HW):
         if self._ws is None or self._ws_hw != HW:
             nbytes = lib().ns_ba_workspace_bytes(C.byref(self.c), int(HW))
-            self._ws = torch.empty((nbytes + 256,), dtype=torch.uint8, device=self.device)
+            self._ws = torch.zeros((nbytes + 256,), dtype=torch.uint8, device=self.device)
             self._ws_hw = HW
         off = (-self._ws.data_ptr()) % 256
         return C.c_void_p(self._ws.data_ptr() + off)
@@ -85,7 +85,7 @@ def reduced_camera_matrix(plan, poses, disps, intrinsics, extrinsics, disps_sens
         check(lib().ns_reduced_camera_matrix(ptr(poses), ptr(disps), ptr(intrinsics), ptr(extrinsics),
                                              ptr(disps_sens), ptr(targets), ptr(weights), ptr(eta), ptr(ii), ptr(jj),
                                              C.byref(plan.c), ptr(plan.index), plan.offsets, ht, wd, ptr(H), ptr(v),
-                                             ptr(Q), ptr(E), ptr(w), plan.workspace(HW), stream_ptr()),
+                                             ptr(Q), ptr(E), ptr(w), plan.workspace(HW), 1, stream_ptr()),
               "reduced_camera_matrix")
     return H, v, Q, E, w
 
@@ -117,6 +117,7 @@ def projective_transform(targets, weights, poses, disps, intrinsics, extrinsics,
 
 
 MAX_SMALL_SYSTEM = 192  # 6P handled by the single-workgroup LDS Cholesky (csrc/ba_solve.hip)
+MAX_SMALL_SYSTEM_COV = 108  # ... when the identity border rows (L^-1) must fit in LDS as well
 
 
 def ba_solve(H, v, kf0, kf1, world_T_body=None, cam_T_world=None, cam_T_body=None, prior_pose=None,
@@ -129,12 +130,12 @@ def ba_solve(H, v, kf0, kf1, world_T_body=None, cam_T_world=None, cam_T_body=Non
     P = int(kf1) - int(kf0)
     n = 6 * P
     dx = torch.empty((P, 6), dtype=torch.float32, device=dev)
-    info = torch.zeros((1,), dtype=torch.int32, device=dev)
+    info = torch.empty((1,), dtype=torch.int32, device=dev)
     Hfull = torch.empty((n, n), dtype=torch.float64, device=dev)
     Linv = torch.empty((n, n), dtype=torch.float32, device=dev) if want_cov else None
-    Lws = torch.empty((n, n), dtype=torch.float64, device=dev) if want_cov else None
+    Lws = None
     sig = torch.empty((P, 6, 6), dtype=torch.float32, device=dev) if want_cov else None
-    if n > MAX_SMALL_SYSTEM:
+    if n > MAX_SMALL_SYSTEM or (want_cov and n > MAX_SMALL_SYSTEM_COV):
         return _ba_solve_large(H, v, kf0, kf1, world_T_body, cam_T_world, cam_T_body, prior_pose, prior_sigma, ep, lm,
                                retract, want_cov)
     with torch.cuda.device(dev):

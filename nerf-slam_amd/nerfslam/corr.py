@@ -19,7 +19,12 @@ from ._lib import NerfSlamHipError, check, lib, ptr, require_cuda, stream_ptr
 class CorrBlock:
     """networks/modules/corr.py:23-60."""
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3, fused=None):
+        """fmap1, fmap2 [batch, num, 128, ht, wd] (reference layout, corr.py:23-38).
+
+        fused=None picks the single-launch MFMA kernel (ns_corr_volume_pyramid) whenever it applies
+        (f16, 128 channels, <= 4 levels); fused=False forces the reference's own decomposition
+        (library GEMM + one pooling launch per level)."""
         self.num_levels = num_levels
         self.radius = radius
         self.corr_pyramid = []
@@ -27,6 +32,17 @@ class CorrBlock:
             return
         require_cuda(fmap1, fmap2)
         batch, num, dim, ht, wd = fmap1.shape
+        can_fuse = fmap1.dtype == torch.float16 and dim == 128 and 1 <= num_levels <= 4
+        if fused is None:
+            fused = can_fuse
+        if fused:
+            if not can_fuse:
+                raise NerfSlamHipError("CorrBlock(fused=True) needs float16 features with 128 channels")
+            # channels-last, pre-divided by 4 exactly as corr.py:67-68 does (in half)
+            f1 = (fmap1.reshape(batch * num, dim, ht * wd) / 4.0).transpose(1, 2).contiguous()
+            f2 = (fmap2.reshape(batch * num, dim, ht * wd) / 4.0).transpose(1, 2).contiguous()
+            self.corr_pyramid = CorrBlock.build_pyramid(f1, f2, None, None, batch * num, ht, wd, num_levels)
+            return
         # all pairs correlation (corr.py:63-72): both operands / 4, matmul in the features' dtype
         corr = CorrBlock.corr(fmap1, fmap2)
         corr = corr.reshape(batch * num, ht, wd, ht, wd)
@@ -43,6 +59,18 @@ class CorrBlock:
                       "corr_pool2x2")
             self.corr_pyramid.append(dst)
             h, w = h // 2, w // 2
+
+    @staticmethod
+    def build_pyramid(f1, f2, ii, jj, E, ht, wd, num_levels=4):
+        """f1, f2: channels-last feature banks [n, ht*wd, 128] f16 already divided by 4; ii, jj: optional
+        int64 frame ids (None: edge e uses row e).  One launch, every output byte written once."""
+        dev = f1.device
+        pyr = [torch.empty((E, ht, wd, ht >> l, wd >> l), dtype=torch.float16, device=dev) for l in range(num_levels)]
+        arr = (C.c_void_p * 4)(*[pyr[min(l, num_levels - 1)].data_ptr() for l in range(4)])
+        with torch.cuda.device(dev):
+            check(lib().ns_corr_volume_pyramid(ptr(f1), ptr(f2), ptr(ii), ptr(jj), arr, num_levels, E, f1.shape[-1], ht,
+                                               wd, stream_ptr()), "corr_volume_pyramid")
+        return pyr
 
     @classmethod
     def from_pyramid(cls, pyramid, radius=3):

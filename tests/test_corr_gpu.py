@@ -91,8 +91,9 @@ def test_cpu_tensors_fail_loudly():
         droid_backends.corr_index_forward(torch.zeros((1, 4, 4, 4, 4), dtype=torch.float16), torch.zeros((1, 2, 4, 4)), 3)
 
 
-@pytest.mark.parametrize("hw", [(12, 16), (15, 21), (60, 80)])
-def test_corr_pyramid_build(oracle_mod, dev, hw):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("hw", [(12, 16), (15, 21), (16, 24), (60, 80)])
+def test_corr_pyramid_build(oracle_mod, dev, hw, fused):
     """CorrBlock(fmap1, fmap2): all-pairs volume + 3 pooled levels (corr.py:23-38, 63-72).
     Level 0 is a half-rounded f32-accumulated GEMM: the BLAS summation order is unspecified, so the
     bar is <= 1 half-ulp of the exactly-accumulated oracle; pooled levels are compared to the oracle's
@@ -103,7 +104,7 @@ def test_corr_pyramid_build(oracle_mod, dev, hw):
     rng = np.random.default_rng(5)
     f1 = rng.standard_normal((1, n, Cc, ht, wd)).astype(np.float16)
     f2 = rng.standard_normal((1, n, Cc, ht, wd)).astype(np.float16)
-    blk = CorrBlock(torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev))
+    blk = CorrBlock(torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev), fused=fused)
     lv = [p.cpu().numpy() for p in blk.corr_pyramid]
     assert [p.shape for p in lv] == [(n, ht, wd, ht >> l, wd >> l) for l in range(4)]
     if ht < 60:
@@ -112,8 +113,12 @@ def test_corr_pyramid_build(oracle_mod, dev, hw):
         ulp = np.maximum(np.spacing(np.abs(ref[0]).astype(np.float16)).astype(np.float32), 2.0 ** -24)
         # torch.matmul(half) may reduce in f16 inside the BLAS (allow_fp16_reduced_precision_reduction, the
         # default on CUDA and ROCm alike): a few half-ulps, exactly like the reference's cuBLAS call
-        assert (d <= 4 * ulp).all(), f"max {float((d / ulp).max()):.2f} ulp"
-        assert (d > ulp).mean() < 0.02
+        if fused:  # f32 MFMA accumulation (error <= ~2e-6 absolute here) then ONE rounding to half
+            assert (d <= ulp + 2e-6).all(), f"max {float((d / ulp).max()):.2f} ulp"
+            assert (d > 0).mean() < 0.05
+        else:
+            assert (d <= 4 * ulp).all(), f"max {float((d / ulp).max()):.2f} ulp"
+            assert (d > ulp).mean() < 0.02
     for l in range(3):
         h, w = ht >> l, wd >> l
         out = np.empty((n, ht, wd, h // 2, w // 2), np.uint16)

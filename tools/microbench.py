@@ -1,0 +1,36 @@
+"""Kernel microbench for profiling runs: a few launches of the heavy kernels at C640 sizes.
+usage: python tools/microbench.py [volume|lookup|ba|all] [iters]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "nerf-slam_amd"))
+import torch
+import bench
+
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device("cuda:0")
+torch.set_grad_enabled(False)
+hp = bench.HotPath(dev)
+
+def timeit(name, fn, n=iters):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    print(f"{name}: {1e3 * s.elapsed_time(e) / n:.1f} us/call")
+
+if which in ("volume", "all"):
+    from nerfslam.corr import CorrBlock
+    f1 = (hp.fmaps[hp.new_i].reshape(10, 128, -1) / 4.0).transpose(1, 2).contiguous()
+    f2 = (hp.fmaps[hp.new_j].reshape(10, 128, -1) / 4.0).transpose(1, 2).contiguous()
+    timeit("volume10 (kernel only)", lambda: CorrBlock.build_pyramid(f1, f2, None, None, 10, bench.HT, bench.WD))
+    timeit("volume1  (kernel only)", lambda: CorrBlock.build_pyramid(f1[:1], f2[:1], None, None, 1, bench.HT, bench.WD))
+    timeit("build10 (torch prep + kernel)", lambda: hp.op_build(hp.new_i, hp.new_j))
+    timeit("build10 unfused (matmul+pool)", lambda: CorrBlock(hp.fmaps[None, hp.new_i], hp.fmaps[None, hp.new_j], fused=False))
+if which in ("lookup", "all"):
+    timeit("lookup48", hp.op_lookup48)
+if which in ("ba", "all"):
+    timeit("ba_iteration(no cov)", lambda: hp.op_ba_iteration(False))
+    timeit("ba_iteration(cov)", lambda: hp.op_ba_iteration(True))
