@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE'S OWN PYTHON MODULES (read-only import from
+/root/reference) on seeded inputs.  Run in the build container only; the fixtures it writes are
+committed and are what tests/test_oracle_pins.py checks the CPU oracle against on any machine.
+
+What can be imported from the reference without its un-vendored dependencies:
+  networks/geom/projective_ops.py   (needs `lietorch.SE3`: provided here by a ~40-line stand-in on top
+                                     of nerfslam.se3 -- group algebra only, cross-checked in the pin
+                                     tests against the reference's own CUDA formulas restated in the
+                                     oracle, src/droid_kernels.cu:66-120)
+  networks/geom/chol.py             (pure torch)
+  networks/modules/corr.py          (needs a `droid_backends` module object at import time only)
+Nothing from the reference is copied into the repository.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "nerf-slam_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from nerfslam import se3  # noqa: E402  (plain torch SE3 algebra; no HIP involved)
+
+
+# ---------------------------------------------------------------------------------------------
+# stand-ins for the reference's missing third-party modules (import-time needs only)
+# ---------------------------------------------------------------------------------------------
+class SE3:
+    """Minimal lietorch.SE3 look-alike: data [...,7] = [t, q(xyzw)]."""
+
+    manifold_dim = 6
+
+    def __init__(self, data):
+        self.data = data
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @property
+    def shape(self):
+        return self.data.shape[:-1]
+
+    def __mul__(self, other):
+        if isinstance(other, SE3):
+            return SE3(se3.mul(self.data, other.data))
+        return se3.act(self.data, other)  # action on homogeneous points [...,4]
+
+    def inv(self):
+        return SE3(se3.inv(self.data))
+
+    def adjT(self, J):
+        return se3.adjT(self.data, J)
+
+    def __getitem__(self, idx):
+        return SE3(self.data[idx])
+
+    def matrix(self):
+        return se3.matrix(self.data)
+
+    def vec(self):
+        return self.data
+
+
+def install_stubs():
+    lt = types.ModuleType("lietorch")
+    lt.SE3 = SE3
+    lt.Sim3 = type("Sim3", (), {})
+    sys.modules["lietorch"] = lt
+    ic = types.ModuleType("icecream")
+    ic.ic = lambda *a, **k: None
+    sys.modules["icecream"] = ic
+    sys.modules["droid_backends"] = types.ModuleType("droid_backends")
+    sys.path.insert(0, REF)
+
+
+def main():
+    install_stubs()
+    import synth
+    import oracle
+    from networks.geom import projective_ops as pops  # REFERENCE code
+    from networks.geom.chol import schur_solve         # REFERENCE code
+    from networks.modules.corr import CorrBlock        # REFERENCE code
+
+    out = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out, exist_ok=True)
+    torch.manual_seed(0)
+
+    # ---- (1) reprojection + Jacobians of projective_transform (projective_ops.py:98-145) ----
+    p = synth.make_problem(ht=6, wd=8, P=4, M=6, seed=21)
+    poses = SE3(torch.from_numpy(p["poses"])[None])
+    ii, jj = torch.from_numpy(p["ii"]), torch.from_numpy(p["jj"])
+    x1, valid, (Ji, Jj, Jz) = pops.projective_transform(
+        poses, torch.from_numpy(p["disps"])[None], torch.from_numpy(p["intr"])[None, None].repeat(1, p["poses"].shape[0], 1),
+        ii, jj, cam_T_body=torch.from_numpy(p["extr"]), jacobian=True)
+    np.savez_compressed(os.path.join(out, "projective_transform.npz"), poses=p["poses"], disps=p["disps"], intr=p["intr"],
+                        extr=p["extr"], ii=p["ii"], jj=p["jj"], coords=x1[0].numpy(), valid=valid[0].numpy(),
+                        Ji=Ji[0].numpy(), Jj=Jj[0].numpy(), Jz=Jz[0].numpy())
+
+    # ---- (2) Schur-complement solve of chol.py:46-73 on the oracle's per-edge blocks ----
+    q = synth.make_problem(ht=6, wd=8, P=4, M=10, seed=22)
+    k1 = oracle.projective_transform(q["targets"], q["weights"], q["poses"], q["disps"], q["intr"], q["extr"], q["ii"], q["jj"])
+    P, HW, M = 4, q["HW"], q["ii"].shape[0]
+    kx, kk = np.unique(q["ii"], return_inverse=True)
+    K = kx.shape[0]
+    H = np.zeros((P, P, 6, 6)); E = np.zeros((P, K, 6, HW)); v = np.zeros((P, 6)); Cc = np.zeros((K, HW)); w = np.zeros((K, HW))
+    for e in range(M):  # the scatter of networks/geom/ba.py:69-83, with every pose free (fixedp = 0)
+        i, j, k = q["ii"][e], q["jj"][e], kk[e]
+        H[i, i] += k1["Hs"][0, e]; H[i, j] += k1["Hs"][1, e]; H[j, i] += k1["Hs"][2, e]; H[j, j] += k1["Hs"][3, e]
+        v[i] += k1["vs"][0, e]; v[j] += k1["vs"][1, e]
+        E[i, k] += k1["Eiz"][e]; E[j, k] += k1["Ejz"][e]
+        Cc[k] += k1["Cii"][e]; w[k] += k1["bz"][e]
+    eta = q["eta"][:K].reshape(K, HW)
+    Cc = Cc + eta
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None].double()
+    dx, dz = schur_solve(t(H), t(E), t(Cc), t(v), t(w), ep=0.1, lm=0.0)
+    # the live CUDA path skips rows whose window pose index is <= 0 in the back-substitution
+    # (src/droid_kernels.cu:1225); same formula as chol.py:68 with that row of dx masked
+    dxm = dx.clone(); dxm[:, 0] = 0
+    Et = t(E).permute(0, 1, 3, 2, 4).reshape(1, P * 6, K * HW).transpose(1, 2)
+    Qv = (1.0 / t(Cc)).view(1, K * HW, 1)
+    dz_masked = (Qv * (t(w).view(1, K * HW, 1) - Et @ dxm.reshape(1, P * 6, 1))).reshape(K, HW)
+    np.savez_compressed(os.path.join(out, "schur_solve.npz"), **{k_: q[k_] for k_ in
+                        ("poses", "disps", "disps_sens", "intr", "extr", "ii", "jj", "targets", "weights")},
+                        eta=eta.reshape(K, q["ht"], q["wd"]), kf0=0, kf1=P, dx=dx[0].numpy(), dz=dz[0].numpy(),
+                        dz_masked=dz_masked.numpy(), kx=kx)
+
+    # ---- (3) CorrBlock pyramid (corr.py:23-38, 63-72) in half on the CPU ----
+    g = torch.Generator().manual_seed(23)
+    f1 = torch.randn((1, 2, 128, 16, 16), generator=g).half()
+    f2 = torch.randn((1, 2, 128, 16, 16), generator=g).half()
+    blk = CorrBlock(f1, f2)
+    np.savez_compressed(os.path.join(out, "corr_pyramid.npz"), fmap1=f1.numpy(), fmap2=f2.numpy(),
+                        **{f"level{l}": blk.corr_pyramid[l].numpy() for l in range(4)})
+    # float32 run of the same reference code: the unrounded volume (for the 1-ulp statement)
+    blk32 = CorrBlock(f1.float(), f2.float())
+    np.savez_compressed(os.path.join(out, "corr_pyramid_f32_level0.npz"), level0=blk32.corr_pyramid[0].numpy())
+    for f in sorted(os.listdir(out)):
+        print(f, os.path.getsize(os.path.join(out, f)))
+
+
+if __name__ == "__main__":
+    main()
