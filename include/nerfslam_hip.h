@@ -207,6 +207,60 @@ int ns_ba_retract(const float* dx, float* world_T_body, float* cam_T_world, cons
 int ns_ba_depth_cov(const float* Linv, const float* Q, const float* E, const ns_ba_plan* plan,
                     const int32_t* index, const size_t* offsets_host, int HW, float* z_cov, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Mapping path: instant-ngp style NeRF training step.
+ * Reference boundary: the `pyngp` calls of fusion/nerf_fusion.py:57-101, 285-303, 388-424 (the
+ * arithmetic is an un-vendored fork of NVIDIA instant-ngp -> parity unpinned).
+ * Hash grid: n_levels <= 16, 2 features/level, f16 table; positions in the unit cube.
+ * ---------------------------------------------------------------------------------------- */
+
+/* host-only: per-level scale / resolution / table offset (entries); offset_host has n_levels+1 slots */
+int ns_ngp_grid_layout(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                       float* scale_host, int* res_host, uint32_t* offset_host);
+
+/* multiresolution hash encoding: positions [N,3] f32, params f16 [entries*2] -> out [N, n_levels*2] f16 */
+int ns_ngp_encode_forward(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                          const float* positions, const void* params, void* out, long N, void* stream);
+
+/* grad_params f32 [entries*2] += trilinear weights * dLdout [N, n_levels*2] f16 (atomic scatter) */
+int ns_ngp_encode_backward(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                           const float* positions, const void* dLdout, float* grad_params, long N, void* stream);
+
+/* density MLP 32->64->16 + colour MLP (16 + SH16)->64->64->16, f16 weights packed row-major
+ * [W1 64x32 | W2 16x64 | W3 64x32 | W4 64x64 | W5 16x64]; out [N,4] f16 = (r,g,b raw, log-density).
+ * Training: pass the five unit-major activation buffers (featT [32,N], h1T [64,N], cinT [32,N],
+ * h3T, h4T [64,N]); inference: all NULL.                                                        */
+int ns_ngp_mlp_forward(const void* weights, const void* feat, const float* dirs, void* out, void* featT, void* h1T,
+                       void* cinT, void* h3T, void* h4T, long N, void* stream);
+
+/* backward of the MLP pair: weightsT = the same five matrices TRANSPOSED ([in][out]) in the same
+ * packing; dLdout [N,4] f16; writes dLdfeat [N,32] f16 and ADDS the f32 weight gradients
+ * (MFMA split-K GEMMs) into grad_weights[10240].  d5T [16,N], d4T/d3T/d1T [64,N], ddT [16,N] and
+ * partial_ws [ksplit*10240] f32 are scratch.  N must be a multiple of 8.                          */
+int ns_ngp_mlp_backward(const void* weightsT, const void* dLdout, const void* featT, const void* h1T,
+                        const void* cinT, const void* h3T, const void* h4T, void* dLdfeat, void* d5T, void* d4T,
+                        void* d3T, void* ddT, void* d1T, float* partial_ws, int ksplit, float* grad_weights, long N,
+                        void* stream);
+
+/* Adam on f32 master parameters with an f16 working copy; zeroes `grad` behind itself. step >= 1. */
+int ns_ngp_adam(float* master, void* half_params, float* grad, float* m1, float* m2, long n, int step, float lr,
+                float beta1, float beta2, float eps, float l2, float grad_scale, void* stream);
+
+/* occupancy-grid ray marching: bits = ncasc cascades of G^3 bits; rays_o/rays_d [R,3] (unit dirs),
+ * t_range [R,2].  counter[2] (zeroed by the caller) receives (#samples, #rays with samples);
+ * ray_start/ray_n [R]; pos/dirs [max_samples,3]; dt/tmid [max_samples].                          */
+int ns_ngp_march(const uint8_t* bits, int G, int ncasc, const float* rays_o, const float* rays_d,
+                 const float* t_range, int R, float cone, float min_step, float max_step, int max_per_ray,
+                 long max_samples, int* counter, int* ray_start, int* ray_n, float* pos, float* dirs, float* dt,
+                 float* tmid, void* stream);
+
+/* volume rendering; with dLdout != NULL also the loss (rgb L2 + depth_lambda * (d - gt)^2 / cov,
+ * summed over rays into *loss) and its gradient w.r.t. net_out [S,4] (scaled by loss_scale / R). */
+int ns_ngp_composite(const void* net_out, const float* dt, const float* tmid, const int* ray_start,
+                     const int* ray_n, int R, const float* gt_rgb, const float* gt_depth, const float* gt_depth_cov,
+                     float depth_lambda, float loss_scale, float* out_rgb, float* out_depth, float* loss,
+                     void* dLdout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,434 @@
+// ngp.hip -- instant-ngp style NeRF mapping kernels for gfx950 (MI355X): multiresolution hash-grid
+// encoding (forward / backward), occupancy-grid ray marching, volume-rendering loss with the
+// NeRF-SLAM depth + uncertainty term, Adam.  The fully-fused MLP lives in ngp_mlp.hip.
+//
+// Reference boundary: the `pyngp` calls of /root/reference/fusion/nerf_fusion.py:57-101, 285-303,
+// 388-424.  The arithmetic behind that boundary is an un-vendored fork of
+// NVIDIA instant-ngp (commit unknown): what is implemented here is the published algorithm with
+// the configuration of DESIGN.md 7; parity is against oracle/ngp_oracle.c ("parity unpinned").
+//
+// Roofline: the hash-grid gather/scatter and Adam are HBM-bound (random 4-byte gathers out of a
+// 2^19-entry table per fine level; fine levels miss the caches), marching and compositing are
+// latency-bound.  Nothing here is GEMM-shaped.
+#include "common.h"
+
+struct GridCfg {
+  int n_levels, n_features, log2_hashmap, base_res;
+  float per_level_scale;
+};
+
+struct GridLayout {
+  float scale[16];
+  int res[16];
+  uint32_t offset[17];
+};
+
+// identical to oracle/ngp_oracle.c:orc_ngp_grid_layout (and to what tiny-cuda-nn's GridEncoding does)
+static int grid_layout_host(const GridCfg& c, GridLayout& g) {
+  if (c.n_levels < 1 || c.n_levels > 16 || c.n_features != 2) return NS_ENOSUP;
+  uint32_t off = 0;
+  const uint32_t T = 1u << c.log2_hashmap;
+  for (int l = 0; l < c.n_levels; l++) {
+    g.scale[l] = exp2f(l * log2f(c.per_level_scale)) * (float)c.base_res - 1.0f;
+    g.res[l] = (int)ceilf(g.scale[l]) + 1;
+    uint64_t dense = (uint64_t)g.res[l] * g.res[l] * g.res[l];
+    dense = (dense + 7) / 8 * 8;
+    const uint32_t n = dense > T ? T : (uint32_t)dense;
+    g.offset[l] = off;
+    off += n;
+  }
+  g.offset[c.n_levels] = off;
+  for (int l = c.n_levels; l < 16; l++) {
+    g.scale[l] = 0;
+    g.res[l] = 1;
+    g.offset[l + 1] = off;
+  }
+  return NS_OK;
+}
+
+__device__ __forceinline__ uint32_t grid_index(uint32_t hashmap_size, uint32_t res, uint32_t x, uint32_t y,
+                                               uint32_t z) {
+  // dense (x + y*res + z*res^2) while it fits, spatial hash otherwise
+  uint32_t stride = 1, index = 0;
+  index += x * stride;
+  stride *= res;
+  if (stride <= hashmap_size) {
+    index += y * stride;
+    stride *= res;
+    if (stride <= hashmap_size) {
+      index += z * stride;
+      stride *= res;
+    }
+  }
+  if (hashmap_size < stride) index = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
+  return index % hashmap_size;
+}
+
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+
+// grid (ceil(N/256), n_levels): all lanes of a workgroup gather from the same level's table, so the
+// coarse (dense, small) levels stay in L1/L2 and only the hashed fine levels go to HBM.
+__global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const float* __restrict__ pos,
+                                                             const h2_t* __restrict__ params,
+                                                             h2_t* __restrict__ out, long N, int L) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int l = blockIdx.y;
+  const uint32_t hs = g.offset[l + 1] - g.offset[l];
+  const float scale = g.scale[l];
+  const uint32_t res = (uint32_t)g.res[l];
+  float w[3];
+  uint32_t c[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const float p = fmaf(scale, pos[i * 3 + d], 0.5f);
+    const float fl = floorf(p);
+    c[d] = (uint32_t)(int)fl;
+    w[d] = p - fl;
+  }
+  const h2_t* __restrict__ tab = params + g.offset[l];
+  h2_t v[8];
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++)
+    v[corner] = tab[grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2))];
+  float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) {
+    float wt = 1.0f;
+    wt *= (corner & 1) ? w[0] : 1.0f - w[0];
+    wt *= (corner & 2) ? w[1] : 1.0f - w[1];
+    wt *= (corner & 4) ? w[2] : 1.0f - w[2];
+    a0 = fmaf(wt, (float)v[corner][0], a0);
+    a1 = fmaf(wt, (float)v[corner][1], a1);
+  }
+  h2_t o = {(_Float16)a0, (_Float16)a1};
+  out[i * L + l] = o;
+}
+
+__global__ __launch_bounds__(256) void ngp_encode_bwd_kernel(GridLayout g, const float* __restrict__ pos,
+                                                             const h2_t* __restrict__ dLdout,
+                                                             float* __restrict__ grad, long N, int L) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int l = blockIdx.y;
+  const h2_t d = dLdout[i * L + l];
+  const float d0 = (float)d[0], d1 = (float)d[1];
+  if (d0 == 0.0f && d1 == 0.0f) return;
+  const uint32_t hs = g.offset[l + 1] - g.offset[l];
+  const float scale = g.scale[l];
+  const uint32_t res = (uint32_t)g.res[l];
+  float w[3];
+  uint32_t c[3];
+#pragma unroll
+  for (int dd = 0; dd < 3; dd++) {
+    const float p = fmaf(scale, pos[i * 3 + dd], 0.5f);
+    const float fl = floorf(p);
+    c[dd] = (uint32_t)(int)fl;
+    w[dd] = p - fl;
+  }
+  float* __restrict__ tab = grad + (long)g.offset[l] * 2;
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) {
+    float wt = 1.0f;
+    wt *= (corner & 1) ? w[0] : 1.0f - w[0];
+    wt *= (corner & 2) ? w[1] : 1.0f - w[1];
+    wt *= (corner & 4) ? w[2] : 1.0f - w[2];
+    const uint32_t idx = grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2));
+    atomicAdd(&tab[(long)idx * 2 + 0], wt * d0);
+    atomicAdd(&tab[(long)idx * 2 + 1], wt * d1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam: f32 master parameters + moments, f16 working copy refreshed (tiny-cuda-nn semantics:
+// entries with a zero gradient and no weight decay are skipped so untouched hash cells keep their
+// moments).  One streaming pass, float4-vectorised.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ngp_adam_kernel(float* __restrict__ master, _Float16* __restrict__ hp,
+                                                       float* __restrict__ grad, float* __restrict__ m1,
+                                                       float* __restrict__ m2, long n, float c1, float c2, float lr,
+                                                       float beta1, float beta2, float eps, float l2,
+                                                       float inv_grad_scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float g = grad[i] * inv_grad_scale;
+  grad[i] = 0.0f;  // leaves the gradient buffer ready for the next step
+  float p = master[i];
+  if (!(g == 0.0f && l2 == 0.0f)) {
+    g += l2 * p;
+    const float a = beta1 * m1[i] + (1.0f - beta1) * g;
+    const float b = beta2 * m2[i] + (1.0f - beta2) * g * g;
+    m1[i] = a;
+    m2[i] = b;
+    p -= lr * (a / c1) / (sqrtf(b / c2) + eps);
+    master[i] = p;
+  }
+  hp[i] = (_Float16)p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Occupancy grid: `ncasc` cascades of G^3 bits; cascade m covers [0.5 - 2^(m-1), 0.5 + 2^(m-1)]^3.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mip_of(float x, float y, float z, float dt, int G, int ncasc) {
+  const float m = fmaxf(fabsf(x - 0.5f), fmaxf(fabsf(y - 0.5f), fabsf(z - 0.5f)));
+  int mip = 0;
+  while (mip < ncasc - 1 && m >= 0.5f * (float)(1 << mip)) mip++;
+  while (mip < ncasc - 1 && dt * (float)G > (float)(1 << mip)) mip++;
+  return mip;
+}
+
+__device__ __forceinline__ bool occupied(const uint8_t* __restrict__ bits, float x, float y, float z, float dt,
+                                         int G, int ncasc) {
+  const int mip = mip_of(x, y, z, dt, G, ncasc);
+  const float s = 1.0f / (float)(1 << mip);
+  const int cx = (int)floorf(((x - 0.5f) * s + 0.5f) * (float)G);
+  const int cy = (int)floorf(((y - 0.5f) * s + 0.5f) * (float)G);
+  const int cz = (int)floorf(((z - 0.5f) * s + 0.5f) * (float)G);
+  if (cx < 0 || cx >= G || cy < 0 || cy >= G || cz < 0 || cz >= G) return false;
+  const long idx = ((long)mip * G + cz) * G * G + (long)cy * G + cx;
+  return (bits[idx >> 3] >> (idx & 7)) & 1;
+}
+
+struct MarchArgs {
+  const uint8_t* bits;
+  const float* rays_o;   // [R,3]
+  const float* rays_d;   // [R,3] unit
+  const float* t_range;  // [R,2] entry / exit distance of the ray through the render box
+  float cone, min_step, max_step;
+  int G, ncasc, max_per_ray;
+  long max_samples;
+  int* counter;          // [2]: samples, rays-with-samples (device, zeroed by the caller)
+  int* ray_start;        // [R]
+  int* ray_n;            // [R]
+  float* pos;            // [max_samples,3]
+  float* dirs;           // [max_samples,3]
+  float* dt;             // [max_samples]
+  float* tmid;           // [max_samples]
+  int R;
+};
+
+// One lane per ray: count the occupied steps, reserve a contiguous range with one atomic, march
+// again and write.  (The ray marcher of instant-ngp does the same two passes.)
+__global__ __launch_bounds__(128) void ngp_march_kernel(MarchArgs a) {
+  const int r = blockIdx.x * 128 + threadIdx.x;
+  if (r >= a.R) return;
+  const float ox = a.rays_o[r * 3], oy = a.rays_o[r * 3 + 1], oz = a.rays_o[r * 3 + 2];
+  const float dx = a.rays_d[r * 3], dy = a.rays_d[r * 3 + 1], dz = a.rays_d[r * 3 + 2];
+  const float t0 = a.t_range[r * 2], t1 = a.t_range[r * 2 + 1];
+  int n = 0;
+  for (float t = t0; t < t1 && n < a.max_per_ray;) {
+    const float dt = fminf(fmaxf(t * a.cone, a.min_step), a.max_step);
+    if (occupied(a.bits, ox + t * dx, oy + t * dy, oz + t * dz, dt, a.G, a.ncasc)) n++;
+    t += dt;
+  }
+  int base = 0;
+  if (n > 0) {
+    base = atomicAdd(&a.counter[0], n);
+    if ((long)base + n > a.max_samples) n = 0;  // batch is full: the ray contributes nothing this step
+  }
+  a.ray_start[r] = base;
+  a.ray_n[r] = n;
+  if (n == 0) return;
+  atomicAdd(&a.counter[1], 1);
+  int k = 0;
+  for (float t = t0; t < t1 && k < n;) {
+    const float dt = fminf(fmaxf(t * a.cone, a.min_step), a.max_step);
+    const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+    if (occupied(a.bits, x, y, z, dt, a.G, a.ncasc)) {
+      const long s = (long)base + k;
+      a.pos[s * 3] = x;
+      a.pos[s * 3 + 1] = y;
+      a.pos[s * 3 + 2] = z;
+      a.dirs[s * 3] = dx;
+      a.dirs[s * 3 + 1] = dy;
+      a.dirs[s * 3 + 2] = dz;
+      a.dt[s] = dt;
+      a.tmid[s] = t;
+      k++;
+    }
+    t += dt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Volume rendering + loss + gradients w.r.t. the network outputs; one lane per ray, two passes.
+// net_out [S,4] f16 = (r,g,b raw, log-density).  pos is given in the unit cube; the MLP reads
+// warped positions, the compositing only needs dt and the distances.
+// ---------------------------------------------------------------------------------------------
+struct CompositeArgs {
+  const _Float16* net_out;  // [S,4]
+  const float* dt;
+  const float* tmid;
+  const int* ray_start;
+  const int* ray_n;
+  const float* gt_rgb;        // [R,3]
+  const float* gt_depth;      // [R]  (<= 0: no depth supervision for this ray)
+  const float* gt_depth_cov;  // [R]
+  float depth_lambda, loss_scale;
+  float* out_rgb;    // [R,3]
+  float* out_depth;  // [R]
+  float* loss;       // [1] accumulated sum over rays of the per-ray loss (caller zeroes, divides by R)
+  _Float16* dLdout;  // [S,4] or null (inference)
+  int R;
+};
+
+__global__ __launch_bounds__(128) void ngp_composite_kernel(CompositeArgs a) {
+  const int r = blockIdx.x * 128 + threadIdx.x;
+  float l = 0.0f;
+  if (r < a.R) {
+    const int s0 = a.ray_start[r], n = a.ray_n[r];
+    float T = 1.0f, C0 = 0, C1 = 0, C2 = 0, D = 0;
+    for (int k = 0; k < n; k++) {
+      const long s = (long)s0 + k;
+      const float sigma = __expf((float)a.net_out[s * 4 + 3]);
+      const float alpha = 1.0f - __expf(-sigma * a.dt[s]);
+      const float wgt = alpha * T;
+      C0 += wgt / (1.0f + __expf(-(float)a.net_out[s * 4 + 0]));
+      C1 += wgt / (1.0f + __expf(-(float)a.net_out[s * 4 + 1]));
+      C2 += wgt / (1.0f + __expf(-(float)a.net_out[s * 4 + 2]));
+      D += wgt * a.tmid[s];
+      T *= 1.0f - alpha;
+    }
+    a.out_rgb[r * 3] = C0;
+    a.out_rgb[r * 3 + 1] = C1;
+    a.out_rgb[r * 3 + 2] = C2;
+    a.out_depth[r] = D;
+    if (a.dLdout != nullptr) {
+      const float e0 = C0 - a.gt_rgb[r * 3], e1 = C1 - a.gt_rgb[r * 3 + 1], e2 = C2 - a.gt_rgb[r * 3 + 2];
+      l = (e0 * e0 + e1 * e1 + e2 * e2) / 3.0f;
+      const float dC0 = 2.0f * e0 / 3.0f, dC1 = 2.0f * e1 / 3.0f, dC2 = 2.0f * e2 / 3.0f;
+      float dD = 0.0f;
+      const float gd = a.gt_depth[r];
+      if (gd > 0.0f && a.depth_lambda > 0.0f) {
+        const float ed = D - gd, icov = 1.0f / a.gt_depth_cov[r];
+        l += a.depth_lambda * ed * ed * icov;
+        dD = a.depth_lambda * 2.0f * ed * icov;
+      }
+      const float sc = a.loss_scale / (float)a.R;
+      T = 1.0f;
+      float P0 = 0, P1 = 0, P2 = 0, PD = 0;
+      for (int k = 0; k < n; k++) {
+        const long s = (long)s0 + k;
+        const float sigma = __expf((float)a.net_out[s * 4 + 3]);
+        const float alpha = 1.0f - __expf(-sigma * a.dt[s]);
+        const float wgt = alpha * T;
+        const float c0 = 1.0f / (1.0f + __expf(-(float)a.net_out[s * 4 + 0]));
+        const float c1 = 1.0f / (1.0f + __expf(-(float)a.net_out[s * 4 + 1]));
+        const float c2 = 1.0f / (1.0f + __expf(-(float)a.net_out[s * 4 + 2]));
+        const float tm = a.tmid[s];
+        P0 += wgt * c0;
+        P1 += wgt * c1;
+        P2 += wgt * c2;
+        PD += wgt * tm;
+        const float Tn = T * (1.0f - alpha);
+        const float gsum = dC0 * (Tn * c0 - (C0 - P0)) + dC1 * (Tn * c1 - (C1 - P1)) + dC2 * (Tn * c2 - (C2 - P2)) +
+                           dD * (Tn * tm - (D - PD));
+        a.dLdout[s * 4 + 0] = (_Float16)(sc * wgt * dC0 * c0 * (1.0f - c0));
+        a.dLdout[s * 4 + 1] = (_Float16)(sc * wgt * dC1 * c1 * (1.0f - c1));
+        a.dLdout[s * 4 + 2] = (_Float16)(sc * wgt * dC2 * c2 * (1.0f - c2));
+        a.dLdout[s * 4 + 3] = (_Float16)(sc * a.dt[s] * gsum * sigma);
+        T = Tn;
+      }
+    }
+  }
+  if (a.dLdout != nullptr) {
+    l = wave_sum(l);
+    if ((threadIdx.x & 63) == 0) atomicAdd(a.loss, l);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int ns_ngp_grid_layout(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                  float per_level_scale, float* scale_host, int* res_host, uint32_t* offset_host) {
+  GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
+  GridLayout g;
+  if (grid_layout_host(c, g) != NS_OK) {
+    ns_set_error("ns_ngp_grid_layout: need 1..16 levels and 2 features per level");
+    return NS_ENOSUP;
+  }
+  for (int l = 0; l < n_levels; l++) {
+    if (scale_host) scale_host[l] = g.scale[l];
+    if (res_host) res_host[l] = g.res[l];
+    if (offset_host) offset_host[l] = g.offset[l];
+  }
+  if (offset_host) offset_host[n_levels] = g.offset[n_levels];
+  return NS_OK;
+}
+
+extern "C" int ns_ngp_encode_forward(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                     float per_level_scale, const float* positions, const void* params, void* out,
+                                     long N, void* stream) {
+  NS_REQUIRE(positions && params && out, "ns_ngp_encode_forward: null pointer");
+  GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
+  GridLayout g;
+  if (grid_layout_host(c, g) != NS_OK) {
+    ns_set_error("ns_ngp_encode_forward: need 1..16 levels and 2 features per level");
+    return NS_ENOSUP;
+  }
+  if (N <= 0) return NS_OK;
+  hipLaunchKernelGGL(ngp_encode_fwd_kernel, dim3(ns_cdiv(N, 256), n_levels), dim3(256), 0, (hipStream_t)stream, g,
+                     positions, (const h2_t*)params, (h2_t*)out, N, n_levels);
+  NS_CHECK_LAUNCH("ngp_encode_fwd_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                      float per_level_scale, const float* positions, const void* dLdout,
+                                      float* grad_params, long N, void* stream) {
+  NS_REQUIRE(positions && dLdout && grad_params, "ns_ngp_encode_backward: null pointer");
+  GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
+  GridLayout g;
+  if (grid_layout_host(c, g) != NS_OK) {
+    ns_set_error("ns_ngp_encode_backward: need 1..16 levels and 2 features per level");
+    return NS_ENOSUP;
+  }
+  if (N <= 0) return NS_OK;
+  hipLaunchKernelGGL(ngp_encode_bwd_kernel, dim3(ns_cdiv(N, 256), n_levels), dim3(256), 0, (hipStream_t)stream, g,
+                     positions, (const h2_t*)dLdout, grad_params, N, n_levels);
+  NS_CHECK_LAUNCH("ngp_encode_bwd_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_ngp_adam(float* master, void* half_params, float* grad, float* m1, float* m2, long n, int step,
+                           float lr, float beta1, float beta2, float eps, float l2, float grad_scale, void* stream) {
+  NS_REQUIRE(master && half_params && grad && m1 && m2, "ns_ngp_adam: null pointer");
+  NS_REQUIRE(step >= 1 && grad_scale > 0.0f, "ns_ngp_adam: step must be >= 1 and grad_scale > 0");
+  if (n <= 0) return NS_OK;
+  const float c1 = 1.0f - powf(beta1, (float)step), c2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(ngp_adam_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, master,
+                     (_Float16*)half_params, grad, m1, m2, n, c1, c2, lr, beta1, beta2, eps, l2, 1.0f / grad_scale);
+  NS_CHECK_LAUNCH("ngp_adam_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_ngp_march(const uint8_t* bits, int G, int ncasc, const float* rays_o, const float* rays_d,
+                            const float* t_range, int R, float cone, float min_step, float max_step, int max_per_ray,
+                            long max_samples, int* counter, int* ray_start, int* ray_n, float* pos, float* dirs,
+                            float* dt, float* tmid, void* stream) {
+  NS_REQUIRE(bits && rays_o && rays_d && t_range && counter && ray_start && ray_n && pos && dirs && dt && tmid,
+             "ns_ngp_march: null pointer");
+  NS_REQUIRE(G > 0 && ncasc >= 1 && ncasc <= 8 && min_step > 0.0f, "ns_ngp_march: bad grid");
+  if (R <= 0) return NS_OK;
+  MarchArgs a{bits, rays_o, rays_d, t_range, cone, min_step, max_step, G, ncasc, max_per_ray, max_samples, counter,
+              ray_start, ray_n, pos, dirs, dt, tmid, R};
+  hipLaunchKernelGGL(ngp_march_kernel, dim3(ns_cdiv(R, 128)), dim3(128), 0, (hipStream_t)stream, a);
+  NS_CHECK_LAUNCH("ngp_march_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_ngp_composite(const void* net_out, const float* dt, const float* tmid, const int* ray_start,
+                                const int* ray_n, int R, const float* gt_rgb, const float* gt_depth,
+                                const float* gt_depth_cov, float depth_lambda, float loss_scale, float* out_rgb,
+                                float* out_depth, float* loss, void* dLdout, void* stream) {
+  NS_REQUIRE(net_out && dt && tmid && ray_start && ray_n && out_rgb && out_depth, "ns_ngp_composite: null pointer");
+  NS_REQUIRE(dLdout == nullptr || (gt_rgb && gt_depth && gt_depth_cov && loss),
+             "ns_ngp_composite: training mode needs the ground truth and the loss pointer");
+  if (R <= 0) return NS_OK;
+  CompositeArgs a{(const _Float16*)net_out, dt, tmid, ray_start, ray_n, gt_rgb, gt_depth, gt_depth_cov,
+                  depth_lambda, loss_scale, out_rgb, out_depth, loss, (_Float16*)dLdout, R};
+  hipLaunchKernelGGL(ngp_composite_kernel, dim3(ns_cdiv(R, 128)), dim3(128), 0, (hipStream_t)stream, a);
+  NS_CHECK_LAUNCH("ngp_composite_kernel");
+  return NS_OK;
+}

@@ -242,6 +242,119 @@ def se3_exp(xi):
     return out
 
 
+# --------------------------------------------------------------------------- mapping path (ngp_oracle.c)
+class _GridCfg(C.Structure):
+    _fields_ = [("n_levels", C.c_int), ("n_features", C.c_int), ("log2_hashmap", C.c_int), ("base_res", C.c_int),
+                ("per_level_scale", C.c_float)]
+
+
+def ngp_cfg(n_levels=16, log2_hashmap=19, base_res=16, per_level_scale=1.5157165665):
+    return _GridCfg(n_levels, 2, log2_hashmap, base_res, per_level_scale)
+
+
+def ngp_grid_layout(cfg):
+    scale = np.zeros(cfg.n_levels, np.float32)
+    res = np.zeros(cfg.n_levels, np.int32)
+    off = np.zeros(cfg.n_levels + 1, np.uint32)
+    lib().orc_ngp_grid_layout(C.byref(cfg), _p(scale), _p(res), _p(off))
+    return scale, res, off
+
+
+def ngp_encode_fwd(cfg, pos, params):
+    pos = _f32(pos)
+    params = np.ascontiguousarray(params, np.float16)
+    out = np.zeros((pos.shape[0], cfg.n_levels * 2), np.float16)
+    lib().orc_ngp_encode_fwd(C.byref(cfg), _p(pos), _p(params), _p(out), C.c_long(pos.shape[0]))
+    return out
+
+
+def ngp_encode_bwd(cfg, pos, dLdout, n_params):
+    pos = _f32(pos)
+    dLdout = np.ascontiguousarray(dLdout, np.float16)
+    grad = np.zeros((n_params,), np.float32)
+    lib().orc_ngp_encode_bwd(C.byref(cfg), _p(pos), _p(dLdout), _p(grad), C.c_long(pos.shape[0]))
+    return grad
+
+
+class _Mlp(C.Structure):
+    _fields_ = [("W1", C.c_void_p), ("W2", C.c_void_p), ("W3", C.c_void_p), ("W4", C.c_void_p), ("W5", C.c_void_p)]
+
+
+MLP_SHAPES = [(64, 32), (16, 64), (64, 32), (64, 64), (16, 64)]
+
+
+def _mlp_struct(Ws):
+    Ws = [np.ascontiguousarray(w, np.float16) for w in Ws]
+    return _Mlp(*[w.ctypes.data for w in Ws]), Ws
+
+
+def ngp_mlp_fwd(Ws, feat, dirs):
+    """-> dict(h1, dens, cin, h3, h4, rgb) f16 arrays."""
+    m, keep = _mlp_struct(Ws)
+    feat = np.ascontiguousarray(feat, np.float16)
+    dirs = _f32(dirs)
+    N = feat.shape[0]
+    o = dict(h1=np.zeros((N, 64), np.float16), dens=np.zeros((N, 16), np.float16), cin=np.zeros((N, 32), np.float16),
+             h3=np.zeros((N, 64), np.float16), h4=np.zeros((N, 64), np.float16), rgb=np.zeros((N, 16), np.float16))
+    lib().orc_ngp_mlp_fwd(C.byref(m), _p(feat), _p(dirs), C.c_long(N), _p(o["h1"]), _p(o["dens"]), _p(o["cin"]),
+                          _p(o["h3"]), _p(o["h4"]), _p(o["rgb"]))
+    return o
+
+
+def ngp_mlp_bwd(Ws, feat, act, dLdrgb, dLddens):
+    """-> (dLdfeat [N,32] f16, [dW1..dW5] float64)."""
+    m, keep = _mlp_struct(Ws)
+    feat = np.ascontiguousarray(feat, np.float16)
+    N = feat.shape[0]
+    dLdrgb = np.ascontiguousarray(dLdrgb, np.float16)
+    dLddens = np.ascontiguousarray(dLddens, np.float16)
+    dfeat = np.zeros((N, 32), np.float16)
+    dW = [np.zeros(s, np.float64) for s in MLP_SHAPES]
+    lib().orc_ngp_mlp_bwd(C.byref(m), _p(feat), C.c_long(N), _p(act["h1"]), _p(act["dens"]), _p(act["cin"]),
+                          _p(act["h3"]), _p(act["h4"]), _p(act["rgb"]), _p(dLdrgb), _p(dLddens), _p(dfeat),
+                          *[_p(w) for w in dW])
+    return dfeat, dW
+
+
+def ngp_composite_loss(rgb_raw, dens_raw, dt, tmid, ray_start, ray_n, gt_rgb, gt_depth, gt_depth_cov, depth_lambda,
+                       loss_scale):
+    """rgb_raw, dens_raw [S,16] f16.  -> (out_rgb [R,3], out_depth [R], loss, dLdrgb [S,16], dLddens [S,16])."""
+    rgb_raw = np.ascontiguousarray(rgb_raw, np.float16)
+    dens_raw = np.ascontiguousarray(dens_raw, np.float16)
+    dt, tmid, gt_rgb, gt_depth, gt_depth_cov = _f32(dt), _f32(tmid), _f32(gt_rgb), _f32(gt_depth), _f32(gt_depth_cov)
+    ray_start = np.ascontiguousarray(ray_start, np.int32)
+    ray_n = np.ascontiguousarray(ray_n, np.int32)
+    R, S = ray_start.shape[0], rgb_raw.shape[0]
+    out_rgb = np.zeros((R, 3), np.float32)
+    out_depth = np.zeros((R,), np.float32)
+    loss = np.zeros((1,), np.float32)
+    dLdrgb = np.zeros((S, 16), np.float16)
+    dLddens = np.zeros((S, 16), np.float16)
+    lib().orc_ngp_composite_loss(_p(rgb_raw), _p(dens_raw), _p(dt), _p(tmid), _p(ray_start), _p(ray_n), R, _p(gt_rgb),
+                                 _p(gt_depth), _p(gt_depth_cov), C.c_float(depth_lambda), C.c_float(loss_scale),
+                                 _p(out_rgb), _p(out_depth), _p(loss), _p(dLdrgb), _p(dLddens))
+    return out_rgb, out_depth, float(loss[0]), dLdrgb, dLddens
+
+
+def ngp_adam(master, grad, m1, m2, step, lr, beta1=0.9, beta2=0.99, eps=1e-15, l2=0.0, grad_scale=1.0):
+    master, grad, m1, m2 = _f32(master).copy(), _f32(grad), _f32(m1).copy(), _f32(m2).copy()
+    hp = np.zeros(master.shape, np.float16)
+    lib().orc_ngp_adam(_p(master), _p(hp), _p(grad), _p(m1), _p(m2), C.c_long(master.size), int(step), C.c_float(lr),
+                       C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(l2), C.c_float(grad_scale))
+    return master, hp, m1, m2
+
+
+def ngp_march_ray(bits, G, ncasc, o, d, cone, min_step, max_step, t0, t1, max_n):
+    bits = np.ascontiguousarray(bits, np.uint8)
+    pos = np.zeros((max_n, 3), np.float32)
+    dts = np.zeros((max_n,), np.float32)
+    ts = np.zeros((max_n,), np.float32)
+    lib().orc_ngp_march_ray.restype = C.c_int
+    n = lib().orc_ngp_march_ray(_p(bits), G, ncasc, _p(_f32(o)), _p(_f32(d)), C.c_float(cone), C.c_float(min_step),
+                                C.c_float(max_step), C.c_float(t0), C.c_float(t1), max_n, _p(pos), _p(dts), _p(ts))
+    return pos[:n], dts[:n], ts[:n]
+
+
 # --------------------------------------------------------------------------- float64 SE3 (numpy)
 def _qmul(a, b):
     ax, ay, az, aw = a

@@ -1,0 +1,266 @@
+"""GPU parity of the mapping-path kernels against oracle/ngp_oracle.c (parity UNPINNED by the reference:
+instant-ngp is an un-vendored dependency, see the oracle header)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def _cfgs(oracle_mod):
+    return [oracle_mod.ngp_cfg(), oracle_mod.ngp_cfg(n_levels=8, log2_hashmap=14, base_res=4, per_level_scale=2.0)]
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_hash_encode_forward_backward(oracle_mod, dev, which):
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    cfg = _cfgs(oracle_mod)[which]
+    _, res, off = oracle_mod.ngp_grid_layout(cfg)
+    n_par = int(off[-1]) * 2
+    rng = np.random.default_rng(which)
+    params = rng.uniform(-0.5, 0.5, n_par).astype(np.float16)
+    N = 3001
+    pos = rng.uniform(0, 1, (N, 3)).astype(np.float32)
+    pos[0] = [0, 0, 0]
+    pos[1] = [1, 1, 1]
+    pos[2] = [0.5, 1.0, 0.0]
+    L = cfg.n_levels
+    args = (L, 2, cfg.log2_hashmap, cfg.base_res, C.c_float(cfg.per_level_scale))
+    # device layout agrees with the oracle's
+    o2 = (C.c_uint32 * (L + 1))()
+    r2 = (C.c_int * L)()
+    check(lib().ns_ngp_grid_layout(*args, None, r2, o2), "layout")
+    assert list(o2) == list(off) and list(r2) == list(res)
+    out = torch.empty((N, 2 * L), dtype=torch.float16, device=dev)
+    d_pos, d_par = T(pos, dev), T(params, dev)  # keep alive: ptr() of a temporary would dangle
+    check(lib().ns_ngp_encode_forward(*args, ptr(d_pos), ptr(d_par), ptr(out), C.c_long(N), stream_ptr()), "fwd")
+    ref = oracle_mod.ngp_encode_fwd(cfg, pos, params)
+    got = out.cpu().numpy()
+    # f32 trilinear blend of 8 f16 values, one rounding: bit-exact up to FMA order -> 1 half-ulp
+    assert np.abs(got.astype(np.float32) - ref.astype(np.float32)).max() <= 2.0 ** -11 * np.abs(ref).max() + 1e-7
+    assert (got.view(np.uint16) == ref.view(np.uint16)).mean() > 0.995
+    dL = (rng.standard_normal((N, 2 * L)) * 1e-2).astype(np.float16)
+    dL[rng.uniform(size=N) < 0.3] = 0
+    grad = torch.zeros(n_par, dtype=torch.float32, device=dev)
+    d_dL = T(dL, dev)
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dL), ptr(grad), C.c_long(N), stream_ptr()), "bwd")
+    gref = oracle_mod.ngp_encode_bwd(cfg, pos, dL, n_par)
+    # f32 atomics in arbitrary order: 1e-5 of max
+    assert np.abs(grad.cpu().numpy() - gref).max() <= 1e-5 * np.abs(gref).max()
+
+
+def _weights(rng):
+    from oracle import MLP_SHAPES
+    return [(rng.uniform(-1, 1, s) * np.sqrt(6.0 / sum(s))).astype(np.float16) for s in MLP_SHAPES]
+
+
+def test_mlp_forward_backward(oracle_mod, dev):
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(2)
+    N = 1000  # multiple of 8, not of 256
+    Ws = _weights(rng)
+    feat = (rng.standard_normal((N, 32)) * 0.5).astype(np.float16)
+    dirs = rng.standard_normal((N, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    act = oracle_mod.ngp_mlp_fwd(Ws, feat, dirs)
+    Wd = T(np.concatenate([w.reshape(-1) for w in Ws]), dev)
+    out = torch.empty((N, 4), dtype=torch.float16, device=dev)
+    bufs = [torch.empty((u, N), dtype=torch.float16, device=dev) for u in (32, 64, 32, 64, 64)]
+    d_feat, d_dirs = T(feat, dev), T(dirs, dev)
+    check(lib().ns_ngp_mlp_forward(ptr(Wd), ptr(d_feat), ptr(d_dirs), ptr(out), *[ptr(b) for b in bufs],
+                                   C.c_long(N), stream_ptr()), "mlp fwd")
+    o = out.cpu().numpy().astype(np.float32)
+    ref = np.concatenate([act["rgb"][:, :3], act["dens"][:, :1]], 1).astype(np.float32)
+    # same f16 storage / f32 accumulation as the oracle, different accumulation order: a few half-ulps of the
+    # layer scale
+    assert np.abs(o - ref).max() <= 4e-3 * np.abs(ref).max()
+    for b, k in zip(bufs[1:], ("h1", "cin", "h3", "h4")):
+        r = act[k].astype(np.float32).T
+        assert np.abs(b.cpu().numpy().astype(np.float32) - r).max() <= 4e-3 * np.abs(r).max(), k
+    # backward
+    dout = (rng.standard_normal((N, 4)) * 1e-2).astype(np.float16)
+    dLdrgb = np.zeros((N, 16), np.float16)
+    dLdrgb[:, :3] = dout[:, :3]
+    dLddens = np.zeros((N, 16), np.float16)
+    dLddens[:, 0] = dout[:, 3]
+    dfeat_ref, dW_ref = oracle_mod.ngp_mlp_bwd(Ws, feat, act, dLdrgb, dLddens)
+    WT = T(np.concatenate([w.T.copy().reshape(-1) for w in Ws]), dev)
+    dfeat = torch.empty((N, 32), dtype=torch.float16, device=dev)
+    dbufs = [torch.empty((u, N), dtype=torch.float16, device=dev) for u in (16, 64, 64, 16, 64)]
+    ks = 7
+    partial = torch.empty((ks, 10240), dtype=torch.float32, device=dev)
+    gw = torch.zeros(10240, dtype=torch.float32, device=dev)
+    d_dout = T(dout, dev)
+    check(lib().ns_ngp_mlp_backward(ptr(WT), ptr(d_dout), *[ptr(b) for b in bufs], ptr(dfeat),
+                                    *[ptr(b) for b in dbufs], ptr(partial), ks, ptr(gw), C.c_long(N), stream_ptr()),
+          "mlp bwd")
+    d = dfeat.cpu().numpy().astype(np.float32)
+    assert np.abs(d - dfeat_ref.astype(np.float32)).max() <= 1e-2 * np.abs(dfeat_ref.astype(np.float32)).max()
+    g = gw.cpu().numpy()
+    off = 0
+    for w, r in zip(Ws, dW_ref):
+        gg = g[off:off + w.size].reshape(w.shape)
+        assert np.abs(gg - r).max() <= 1e-2 * np.abs(r).max(), w.shape
+        off += w.size
+
+
+def test_composite_loss_and_adam(oracle_mod, dev):
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(3)
+    R = 300
+    ray_n = rng.integers(0, 40, R).astype(np.int32)
+    ray_start = np.concatenate([[0], np.cumsum(ray_n)[:-1]]).astype(np.int32)
+    S = int(ray_n.sum())
+    net = np.zeros((S, 4), np.float16)
+    net[:, :3] = rng.standard_normal((S, 3))
+    net[:, 3] = rng.uniform(-2, 3, S)
+    dt = rng.uniform(0.002, 0.02, S).astype(np.float32)
+    tm = np.concatenate([np.sort(rng.uniform(0.1, 4, n)) for n in ray_n]).astype(np.float32) if S else np.zeros(0, np.float32)
+    gt_rgb = rng.uniform(0, 1, (R, 3)).astype(np.float32)
+    gt_d = rng.uniform(0.5, 3, R).astype(np.float32)
+    gt_d[::3] = -1
+    gt_c = rng.uniform(0.01, 1, R).astype(np.float32)
+    rgb16 = np.zeros((S, 16), np.float16); rgb16[:, :3] = net[:, :3]
+    den16 = np.zeros((S, 16), np.float16); den16[:, 0] = net[:, 3]
+    orgb, odep, loss, dr, dd = oracle_mod.ngp_composite_loss(rgb16, den16, dt, tm, ray_start, ray_n, gt_rgb, gt_d, gt_c,
+                                                            1.0, 128.0)
+    out_rgb = torch.empty((R, 3), device=dev); out_d = torch.empty(R, device=dev)
+    l = torch.zeros(1, device=dev); dout = torch.empty((S, 4), dtype=torch.float16, device=dev)
+    keep = [T(x, dev) for x in (net, dt, tm, ray_start, ray_n, gt_rgb, gt_d, gt_c)]
+    check(lib().ns_ngp_composite(ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]),
+                                 ptr(keep[4]), R, ptr(keep[5]), ptr(keep[6]), ptr(keep[7]),
+                                 C.c_float(1.0), C.c_float(128.0), ptr(out_rgb), ptr(out_d), ptr(l), ptr(dout),
+                                 stream_ptr()), "composite")
+    np.testing.assert_allclose(out_rgb.cpu().numpy(), orgb, atol=2e-5)
+    np.testing.assert_allclose(out_d.cpu().numpy(), odep, rtol=2e-5, atol=2e-5)
+    assert abs(l.item() / R - loss) <= 1e-4 * abs(loss)
+    ref = np.concatenate([dr[:, :3], dd[:, :1]], 1).astype(np.float32)
+    got = dout.cpu().numpy().astype(np.float32)
+    assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()  # fast exp + f16 output
+    # Adam
+    n = 5000
+    m = rng.standard_normal(n).astype(np.float32); g = (rng.standard_normal(n) * 128).astype(np.float32)
+    g[::4] = 0
+    m1 = (rng.standard_normal(n) * 0.1).astype(np.float32); m2 = rng.uniform(0, 0.1, n).astype(np.float32)
+    rm, rh, r1, r2 = oracle_mod.ngp_adam(m, g, m1, m2, step=3, lr=1e-2, l2=0.0, grad_scale=128.0)
+    dm, dg, d1, d2 = T(m, dev), T(g, dev), T(m1, dev), T(m2, dev)
+    hp = torch.empty(n, dtype=torch.float16, device=dev)
+    check(lib().ns_ngp_adam(ptr(dm), ptr(hp), ptr(dg), ptr(d1), ptr(d2), C.c_long(n), 3, C.c_float(1e-2), C.c_float(0.9),
+                            C.c_float(0.99), C.c_float(1e-15), C.c_float(0.0), C.c_float(128.0), stream_ptr()), "adam")
+    np.testing.assert_allclose(dm.cpu().numpy(), rm, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(d1.cpu().numpy(), r1, rtol=2e-6, atol=1e-8)
+    np.testing.assert_allclose(d2.cpu().numpy(), r2, rtol=2e-6, atol=1e-8)
+    assert dg.abs().max().item() == 0 and (hp.cpu().numpy() == rh).mean() > 0.999
+
+
+def test_ray_marching(oracle_mod, dev):
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(4)
+    G, nc = 32, 3
+    bits = rng.integers(0, 256, nc * G ** 3 // 8).astype(np.uint8)
+    bits[rng.uniform(size=bits.shape) < 0.5] = 0
+    R = 200
+    o = rng.uniform(0.2, 0.8, (R, 3)).astype(np.float32)
+    d = rng.standard_normal((R, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tr = np.stack([np.full(R, 0.05), rng.uniform(0.5, 3.0, R)], 1).astype(np.float32)
+    cone, mn, mx = 1 / 256.0, np.sqrt(3) / 1024, np.sqrt(3) / 1024 * 32
+    S = 1 << 17
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    rs = torch.empty(R, dtype=torch.int32, device=dev); rn = torch.empty(R, dtype=torch.int32, device=dev)
+    pos = torch.empty((S, 3), device=dev); dirs = torch.empty((S, 3), device=dev)
+    dt = torch.empty(S, device=dev); tm = torch.empty(S, device=dev)
+    keep = [T(x, dev) for x in (bits, o, d, tr)]
+    check(lib().ns_ngp_march(ptr(keep[0]), G, nc, ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), R,
+                             C.c_float(cone), C.c_float(mn), C.c_float(mx), 1024, C.c_long(S), ptr(cnt), ptr(rs),
+                             ptr(rn), ptr(pos), ptr(dirs), ptr(dt), ptr(tm), stream_ptr()), "march")
+    rs, rn, pos, dt, tm = (x.cpu().numpy() for x in (rs, rn, pos, dt, tm))
+    total = 0
+    for r in range(R):
+        p, dts, ts = oracle_mod.ngp_march_ray(bits, G, nc, o[r], d[r], cone, mn, mx, tr[r, 0], tr[r, 1], 1024)
+        # the cell test is a float comparison on positions computed with FMA contraction on the device:
+        # a sample exactly on a cell face may flip; allow one per ray
+        assert abs(int(rn[r]) - len(ts)) <= 1, r
+        if rn[r] == len(ts) and len(ts):
+            np.testing.assert_allclose(tm[rs[r]:rs[r] + rn[r]], ts, rtol=1e-5)
+            np.testing.assert_allclose(pos[rs[r]:rs[r] + rn[r]], p, atol=1e-5)
+        total += int(rn[r])
+    assert int(cnt[0].item()) == total
+
+
+def test_training_converges_on_a_synthetic_scene(dev):
+    """End-to-end training steps through every kernel: a coloured sphere in front of 6 cameras; loss must drop."""
+    from nerfslam.ngp import NgpConfig, NgpNerf
+    cfg = NgpConfig(n_rays=2048, max_samples=1 << 17)
+    net = NgpNerf(cfg, dev, seed=0)
+    H, W, f = 48, 64, 60.0
+    imgs, deps, covs, poses = [], [], [], []
+    centre = np.array([0.5, 0.5, 0.5])
+    for k in range(6):
+        ang = 2 * np.pi * k / 6
+        eye = centre + 0.9 * np.array([np.cos(ang), 0.2, np.sin(ang)])
+        fwd = (centre - eye) / np.linalg.norm(centre - eye)
+        right = np.cross(fwd, [0, 1, 0]); right /= np.linalg.norm(right)
+        up = np.cross(right, fwd)
+        c2w = np.stack([right, -up, fwd, eye], 1)  # camera looks along +z, y down
+        vv, uu = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        d = np.stack([(uu + 0.5 - W / 2) / f, (vv + 0.5 - H / 2) / f, np.ones_like(uu, float)], -1) @ c2w[:, :3].T
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        oc = eye - centre
+        b = (d * oc).sum(-1); cc = (oc * oc).sum() - 0.25 ** 2
+        disc = b * b - cc
+        hit = disc > 0
+        t = np.where(hit, -b - np.sqrt(np.maximum(disc, 0)), -1.0)
+        pts = eye + t[..., None] * d
+        col = np.where(hit[..., None], 0.5 + 0.5 * (pts - centre) / 0.25, 0.0)
+        imgs.append(np.concatenate([col, hit[..., None].astype(float)], -1)); deps.append(t); covs.append(np.full((H, W), 0.05))
+        poses.append(c2w)
+    net.set_images(torch.tensor(np.array(imgs)), torch.tensor(np.array(deps)), torch.tensor(np.array(covs)),
+                   torch.tensor(np.array(poses)), (f, f, W / 2, H / 2))
+    losses = [float(net.train_step()) for _ in range(200)]
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-10:]) < 0.5 * np.mean(losses[:5]), (losses[:5], losses[-10:])
+    rgb, dep = net.render(torch.tensor(np.array(poses[0])), H, W)
+    assert torch.isfinite(rgb).all() and rgb.shape == (H, W, 3)
+
+
+def test_pyngp_surface_as_nerf_fusion_drives_it(dev):
+    """The call sequence of fusion/nerf_fusion.py:57-101 (init), :285-289 (send_data), :299 (frame),
+    :388-424 (render) against the shim."""
+    import pyngp as ngp
+    tb = ngp.Testbed(ngp.TestbedMode.Nerf, 0)
+    tb.create_empty_nerf_dataset(8, 1.0, np.array([np.inf] * 3), 4, ngp.BoundingBox(np.array([-np.inf] * 3), np.array([np.inf] * 3)))
+    tb.nerf.training.n_images_for_training = 0
+    tb.reload_network_from_file("base.json")
+    tb.shall_train = True
+    tb.dynamic_res = True
+    tb.dynamic_res_target_fps = 15
+    tb.camera_smoothing = True
+    tb.nerf.training.optimize_extrinsics = True
+    tb.nerf.training.depth_supervision_lambda = 1.0
+    tb.nerf.training.depth_loss_type = ngp.LossType.L2
+    assert tb.frame()  # nothing to train on yet
+    H, W, n = 24, 32, 3
+    rng = np.random.default_rng(0)
+    poses = np.tile(np.eye(4, dtype=np.float32)[None, :3], (n, 1, 1))
+    poses[:, :, 3] = rng.uniform(-0.1, 0.1, (n, 3))
+    images = rng.uniform(0, 1, (n, H, W, 4)).astype(np.float32)
+    images[..., 3] = 1
+    depths = rng.uniform(0.5, 2.0, (n, H, W, 1)).astype(np.float32)
+    cov = np.ones((n, H, W, 1), np.float32)
+    tb.nerf.training.update_training_images([0, 1, 2], list(poses), list(images), list(depths), list(cov), [W, H],
+                                            [0.5, 0.5], [30.0, 30.0], 1.0, 1.0)
+    assert tb.nerf.training.n_images_for_training == 3
+    tb.steps_per_frame = 4
+    assert tb.frame() and np.isfinite(tb.loss) and tb.training_step == 4 and tb.elapsed_training_time > 0
+    tb.set_camera_to_training_view(1)
+    tb.render_mode = ngp.Shade
+    img = tb.render(W, H, 1, True)
+    tb.render_mode = ngp.Depth
+    dep = tb.render(W, H, 1, True)
+    assert img.shape == (H, W, 4) and dep.shape == (H, W, 4) and np.isfinite(img).all()
