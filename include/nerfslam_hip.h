@@ -95,6 +95,11 @@ int ns_altcorr_pyramid(const float* const* fmaps_host, int num_levels, const int
 int ns_frame_distance(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,
                       const int64_t* jj, float* dist, int num, int ht, int wd, float beta, void* stream);
 
+/* Reprojection of the frontend's update() (visual_frontend.py:909-918 -> networks/geom/projective_ops.py:98-145,
+ * no Jacobians): coords [num,ht,wd,2] f32 (the layout ns_corr_lookup_pyramid reads), valid [num,ht,wd] or NULL. */
+int ns_reproject(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,
+                 const int64_t* jj, float* coords, float* valid, int num, int ht, int wd, void* stream);
+
 /* projmap (src/droid.cpp:249-264 -> droid_kernels.cu:1597-1622, kernel :539-628)
  *   coords [num,ht,wd,3] must be zero-filled (channel 2 is never written), valid [num,ht,wd,1]. */
 int ns_projmap(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,

@@ -158,6 +158,55 @@ __global__ __launch_bounds__(256) void depth_filter_kernel(const float* __restri
   }
 }
 
+// Reprojection ii -> jj as the frontend's update() needs it every iteration
+// (RaftVisualFrontend.reproject, visual_frontend.py:909-918 -> networks/geom/projective_ops.py:98-145 without
+// the Jacobians, which update() computes and throws away): one launch instead of ~15 torch /
+// lietorch launches.  Conventions of the torch path: depth below 0.5*MIN_DEPTH is replaced by 1 before the
+// division (projective_ops.py:45), MIN_DEPTH = 0.2 for the validity mask (:8, :117), stereo pairs (ii == jj)
+// use the fixed baseline (:100,110).  coords [E,ht,wd,2] (the layout the lookup kernel reads), valid [E,ht,wd].
+__global__ __launch_bounds__(256) void reproject_kernel(const float* __restrict__ poses,
+                                                        const float* __restrict__ disps,
+                                                        const float* __restrict__ intr, const int64_t* __restrict__ ii,
+                                                        const int64_t* __restrict__ jj, float* __restrict__ coords,
+                                                        float* __restrict__ valid, int HW, int wd) {
+  const int e = blockIdx.x;
+  const int k = blockIdx.y * 256 + threadIdx.x;
+  if (k >= HW) return;
+  const int ix = (int)ii[e], jx = (int)jj[e];
+  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  float tij[3], qij[4];
+  if (ix == jx) {
+    tij[0] = -0.1f;
+    tij[1] = tij[2] = 0.0f;
+    qij[0] = qij[1] = qij[2] = 0.0f;
+    qij[3] = 1.0f;
+  } else {
+    se3::rel_se3(poses + (long)ix * 7, poses + (long)ix * 7 + 3, poses + (long)jx * 7, poses + (long)jx * 7 + 3, tij,
+                 qij);
+  }
+  const int i = k / wd, j = k - i * wd;
+  float Xi[4] = {((float)j - cx) / fx, ((float)i - cy) / fy, 1.0f, disps[(long)ix * HW + k]}, Xj[4];
+  se3::act_se3(tij, qij, Xi, Xj);
+  const float Z = (Xj[2] < 0.1f) ? 1.0f : Xj[2];
+  const float d = 1.0f / Z;
+  float2 c;
+  c.x = fx * (Xj[0] * d) + cx;
+  c.y = fy * (Xj[1] * d) + cy;
+  *reinterpret_cast<float2*>(coords + ((long)e * HW + k) * 2) = c;
+  if (valid) valid[(long)e * HW + k] = (Xj[2] > 0.2f) ? 1.0f : 0.0f;
+}
+
+extern "C" int ns_reproject(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,
+                            const int64_t* jj, float* coords, float* valid, int num, int ht, int wd, void* stream) {
+  NS_REQUIRE(poses && disps && intrinsics && coords, "ns_reproject: null pointer");
+  if (num <= 0) return NS_OK;
+  NS_REQUIRE(ii && jj, "ns_reproject: null index");
+  hipLaunchKernelGGL(reproject_kernel, dim3(num, ns_cdiv(ht * wd, 256)), dim3(256), 0, (hipStream_t)stream, poses, disps,
+                     intrinsics, ii, jj, coords, valid, ht * wd, wd);
+  NS_CHECK_LAUNCH("reproject_kernel");
+  return NS_OK;
+}
+
 extern "C" int ns_frame_distance(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,
                                  const int64_t* jj, float* dist, int num, int ht, int wd, float beta, void* stream) {
   NS_REQUIRE(poses && disps && intrinsics && dist, "ns_frame_distance: null pointer");

@@ -1,0 +1,139 @@
+"""Host mirror of the covisibility factor graph (edge lists ii / jj / age + the inactive list).
+
+Behaviour follows RaftVisualFrontend's bookkeeping (/root/reference/slam/visual_frontends/
+visual_frontend.py:530-574, 690-775, 806-907) so that the edge indices handed to
+the BA are identical; the implementation keeps the lists as host numpy arrays (the reference keeps
+them on the device and calls `.item()` / `.cpu()` in Python loops, which synchronises the GPU on
+every edge) and works on a 2-D candidate matrix with precomputed suppression diamonds.
+
+Device-side per-edge payloads (targets, weights, volumes, hidden states) are owned by the caller;
+every mutating method returns the masks / permutations the caller must apply to them.
+"""
+import numpy as np
+
+
+def _diamond(radius):
+    """offsets (di, dj) with |di| + |dj| <= radius."""
+    r = np.arange(-radius, radius + 1)
+    di, dj = np.meshgrid(r, r, indexing="ij")
+    keep = (np.abs(di) + np.abs(dj)) <= radius
+    return di[keep], dj[keep]
+
+
+class FactorGraph:
+    def __init__(self, max_factors=48, stereo=False):
+        self.max_factors = max_factors
+        self.stereo = stereo
+        z = np.zeros((0,), np.int64)
+        self.ii, self.jj, self.age = z.copy(), z.copy(), z.copy()
+        self.ii_inactive, self.jj_inactive = z.copy(), z.copy()
+        self.ii_bad, self.jj_bad = z.copy(), z.copy()
+        self.version = 0  # bumped on every change: consumers cache their BaPlan on it
+
+    # ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def neighborhood_edges(kf0, kf1, radius, stereo=False):
+        """ordered pairs with c < |i-j| <= radius inside [kf0, kf1] (visual_frontend.py:690-708)."""
+        n = kf1 - kf0 + 1
+        i = np.repeat(np.arange(kf0, kf1 + 1), n)
+        j = np.tile(np.arange(kf0, kf1 + 1), n)
+        dist = np.abs(i - j)
+        keep = (dist <= radius) & (dist > (1 if stereo else 0))
+        return i[keep].astype(np.int64), j[keep].astype(np.int64)
+
+    def proximity_edges(self, d, kf_idx, kf0, kf1, rad, nms, thresh):
+        """Greedy distance-ordered edge selection with diamond non-maximum suppression
+        (visual_frontend.py:712-775).  d: bidirectional frame distances over the candidate grid
+        [kf0, t) x [kf1, t), t = kf_idx + 1, row-major.  Returns the ordered list of (i, j)."""
+        t = kf_idx + 1
+        ni, nj = t - kf0, t - kf1
+        D = np.array(d, np.float32).reshape(ni, nj).copy()
+        I = np.arange(kf0, t)[:, None]
+        J = np.arange(kf1, t)[None, :]
+        D[(I - rad) < J] = np.inf
+        D[D > 100] = np.inf
+
+        def suppress(i, j):
+            r = max(min(abs(int(i) - int(j)) - 2, nms), 0)
+            di, dj = _diamond(r)
+            a, b = i + di - kf0, j + dj - kf1
+            ok = (a >= 0) & (a < ni) & (b >= 0) & (b < nj)
+            D[a[ok], b[ok]] = np.inf
+
+        for (i, j) in zip(np.concatenate([self.ii, self.ii_bad, self.ii_inactive]),
+                          np.concatenate([self.jj, self.jj_bad, self.jj_inactive])):
+            suppress(i, j)
+        es = []
+        for i in range(kf0, t):
+            if self.stereo:
+                es.append((i, i))
+                if 0 <= i - kf1 < nj:
+                    D[i - kf0, i - kf1] = np.inf
+            for j in range(max(i - rad - 1, 0), i):
+                es += [(i, j), (j, i)]
+                if 0 <= j - kf1 < nj:
+                    D[i - kf0, j - kf1] = np.inf
+        flat = D.reshape(-1)
+        order = np.argsort(flat, kind="stable")
+        for k in order:
+            if flat[k] > thresh:
+                continue  # (the reference `continue`s here, it does not stop: :752-753)
+            if len(es) > self.max_factors:
+                break
+            i, j = kf0 + int(k) // nj, kf1 + int(k) % nj
+            es += [(i, j), (j, i)]
+            suppress(i, j)
+        return es
+
+    # ---------------------------------------------------------------------------------------------
+    def filter_new(self, ii, jj):
+        """drop pairs already active or inactive (visual_frontend.py:896-907) -> keep mask."""
+        have = set(zip(self.ii.tolist(), self.jj.tolist())) | set(zip(self.ii_inactive.tolist(), self.jj_inactive.tolist()))
+        return np.array([(int(i), int(j)) not in have for i, j in zip(ii, jj)], bool)
+
+    def add(self, ii, jj, remove=False, have_volumes=True):
+        """visual_frontend.py:806-833.  Returns (new_ii, new_jj, removed_mask_or_None): `removed_mask` is
+        over the edges that were active BEFORE the call (already applied to the graph with store=True)."""
+        ii, jj = np.asarray(ii, np.int64).reshape(-1), np.asarray(jj, np.int64).reshape(-1)
+        keep = self.filter_new(ii, jj)
+        ii, jj = ii[keep], jj[keep]
+        if ii.shape[0] == 0:
+            return ii, jj, None
+        removed = None
+        if self.max_factors > 0 and self.ii.shape[0] + ii.shape[0] > self.max_factors and have_volumes and remove:
+            # positional mask through the age permutation (DROID quirk, :826-828)
+            pos = np.arange(self.age.shape[0])[np.argsort(self.age, kind="stable")]
+            removed = pos >= (self.max_factors - ii.shape[0])
+            self.remove(removed, store=True)
+        self.ii = np.concatenate([self.ii, ii])
+        self.jj = np.concatenate([self.jj, jj])
+        self.age = np.concatenate([self.age, np.zeros_like(ii)])
+        self.version += 1
+        return ii, jj, removed
+
+    def remove(self, mask, store=False):
+        """visual_frontend.py:868-892 (edge lists only)."""
+        mask = np.asarray(mask, bool)
+        if store:
+            self.ii_inactive = np.concatenate([self.ii_inactive, self.ii[mask]])
+            self.jj_inactive = np.concatenate([self.jj_inactive, self.jj[mask]])
+        self.ii, self.jj, self.age = self.ii[~mask], self.jj[~mask], self.age[~mask]
+        self.version += 1
+
+    def remove_keyframe(self, k):
+        """visual_frontend.py:552-574 -> (keep mask over the inactive edges, drop mask over the active edges)."""
+        drop_in = (self.ii_inactive == k) | (self.jj_inactive == k)
+        self.ii_inactive = self.ii_inactive - (self.ii_inactive >= k)
+        self.jj_inactive = self.jj_inactive - (self.jj_inactive >= k)
+        self.ii_inactive, self.jj_inactive = self.ii_inactive[~drop_in], self.jj_inactive[~drop_in]
+        drop = (self.ii == k) | (self.jj == k)
+        self.ii = self.ii - (self.ii >= k)
+        self.jj = self.jj - (self.jj >= k)
+        self.remove(drop, store=False)
+        return ~drop_in, drop
+
+    def ba_edges(self, kf0):
+        """edges given to the BA: inactive edges with both ends >= kf0 - 3 first, then the active ones
+        (visual_frontend.py:420-424) -> (ii, jj, inactive_mask)."""
+        m = (self.ii_inactive >= kf0 - 3) & (self.jj_inactive >= kf0 - 3)
+        return np.concatenate([self.ii_inactive[m], self.ii]), np.concatenate([self.jj_inactive[m], self.jj]), m

@@ -1,0 +1,222 @@
+"""TrackingFrontend -- host driver of the tracking hot path, mirroring RaftVisualFrontend
+(/root/reference/slam/visual_frontends/visual_frontend.py; lines cited per method).
+
+What is kept from the reference: the keyframe buffers and their layout (:162-237), the factor-graph
+bookkeeping (nerfslam.factor_graph, index-identical), the update() sequence reproject -> motion features
+-> correlation lookup -> update operator -> dense BA (itrs=2) -> covariances (:370-470), the keyframe
+distance tests (:778-799) and the SLAM -> mapper packet (:1337-1391).
+
+What is different: every numerical step is a HIP kernel launched through the C ABI and nothing in
+update()/ba() synchronises with the host -- the edge lists live on the host already, the BA plan is
+cached per graph version, the reduced camera system is solved on the device.
+
+The two learned components of DROID-SLAM (feature/context encoders and the ConvGRU update operator,
+networks/droid_net.py) are OUT of this project's hot-path scope and their
+weights (`droid.pth`) are missing from the reference tree; they are injected as callables:
+    feature_fn(image [3,H,W] float) -> fmap [128, H/8, W/8]
+    update_op(corr [1,E,196,ht,wd], motion [1,E,4,ht,wd], ii, jj) -> (delta [1,E,ht,wd,2], weight [1,E,ht,wd,2],
+                                                                          damping [n_unique_ii, ht, wd])
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import ba_plan, se3
+from ._lib import check, lib, ptr, stream_ptr
+from .corr import CorrBlock
+from .factor_graph import FactorGraph
+
+
+class TrackingFrontend:
+    def __init__(self, buffer, H, W, intrinsics, device="cuda:0", feature_fn=None, update_op=None, max_factors=48,
+                 compute_covariances=True):
+        self.device = dev = torch.device(device)
+        self.buffer, self.H, self.W = buffer, H, W
+        self.ht, self.wd = H // 8, W // 8
+        self.HW = self.ht * self.wd
+        f = dict(dtype=torch.float32, device=dev)
+        ident = torch.tensor([0, 0, 0, 0, 0, 0, 1.0], **f)
+        # buffers (:162-237)
+        self.cam0_T_world = ident.repeat(buffer, 1)
+        self.world_T_body = ident.repeat(buffer, 1)
+        self.cam0_T_body = ident.clone()                       # vio_slam.py:87
+        self.world_T_body_cov = torch.eye(6, **f).repeat(buffer, 1, 1) * 1e-4
+        self.cam0_idepths = torch.ones((buffer, self.ht, self.wd), **f)
+        self.cam0_idepths_sensed = torch.zeros((buffer, self.ht, self.wd), **f)
+        self.cam0_idepths_cov = torch.ones((buffer, self.ht, self.wd), **f)
+        self.cam0_depths_cov = torch.ones((buffer, self.ht, self.wd), **f)
+        self.damping = 1e-6 * torch.ones((buffer, self.ht, self.wd), **f)
+        self.intr8 = (torch.as_tensor(intrinsics, dtype=torch.float32) / 8.0).to(dev)   # :274
+        self.feat_bank = torch.zeros((buffer, self.HW, 128), dtype=torch.float16, device=dev)  # channels-last, /4
+        self.images = torch.zeros((buffer, 3, H, W), dtype=torch.uint8, device=dev)
+        self.viz_idx = torch.zeros(buffer, dtype=torch.bool, device=dev)
+        gy, gx = torch.meshgrid(torch.arange(self.ht, device=dev), torch.arange(self.wd, device=dev), indexing="ij")
+        self.coords0 = torch.stack([gx, gy], -1).float()        # [ht,wd,2]
+        # graph + per-edge payloads
+        self.graph = FactorGraph(max_factors=max_factors)
+        self.ii = self.jj = torch.zeros(0, dtype=torch.long, device=dev)
+        self.corr = None
+        self.target = torch.zeros((0, self.ht, self.wd, 2), **f)
+        self.weight = torch.zeros((0, self.ht, self.wd, 2), **f)
+        self.target_inactive = torch.zeros((0, self.ht, self.wd, 2), **f)
+        self.weight_inactive = torch.zeros((0, self.ht, self.wd, 2), **f)
+        self.kf_idx = 0
+        self.prior_pose = None            # frame-0 prior (:1089-1095)
+        self.feature_fn, self.update_op = feature_fn, update_op
+        self.compute_covariances = compute_covariances
+        self._plan, self._plan_key = None, None
+        self.beta = 0.3
+        self.keyframe_thresh, self.frontend_thresh = 4.0, 16.0
+        self.frontend_window, self.frontend_radius, self.frontend_nms, self.max_age = 25, 2, 1, 25
+
+    # ---------------------------------------------------------------------------------------------
+    def set_keyframe(self, k, image, fmap=None):
+        """store frame k (:309-318): image uint8 [3,H,W]; features from feature_fn unless given."""
+        self.images[k] = image.to(self.device)
+        if fmap is None:
+            fmap = self.feature_fn(image.to(self.device).float())
+        # channels-last, pre-divided by 4 in half exactly as corr.py:67-68 scales its operands
+        self.feat_bank[k] = (fmap.to(self.device).half().reshape(128, self.HW) / 4.0).t().contiguous()
+
+    def _sync_edges(self):
+        self.ii = torch.from_numpy(self.graph.ii).to(self.device)
+        self.jj = torch.from_numpy(self.graph.jj).to(self.device)
+
+    def reproject(self, ii, jj):
+        """(:909-918) -> coords [E,ht,wd,2]."""
+        E = ii.shape[0]
+        coords = torch.empty((E, self.ht, self.wd, 2), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().ns_reproject(ptr(self.cam0_T_world), ptr(self.cam0_idepths), ptr(self.intr8), ptr(ii), ptr(jj),
+                                     ptr(coords), None, E, self.ht, self.wd, stream_ptr()), "reproject")
+        return coords
+
+    def distance(self, ii, jj, bidirectional=True):
+        """(:778-799)"""
+        import droid_backends
+        ii = torch.as_tensor(ii, dtype=torch.long, device=self.device).reshape(-1).contiguous()
+        jj = torch.as_tensor(jj, dtype=torch.long, device=self.device).reshape(-1).contiguous()
+        d1 = droid_backends.frame_distance(self.cam0_T_world, self.cam0_idepths, self.intr8, ii, jj, self.beta)
+        if not bidirectional:
+            return d1
+        d2 = droid_backends.frame_distance(self.cam0_T_world, self.cam0_idepths, self.intr8, jj, ii, self.beta)
+        return 0.5 * (d1 + d2)
+
+    # ---------------------------------------------------------------------------------------------
+    def add_factors(self, ii, jj, remove=False):
+        """(:806-862): de-duplicate, evict by age when over max_factors, build correlation pyramids for the new
+        edges straight from the feature bank (one fused launch), initialise targets with the reprojection."""
+        ni, nj, removed = self.graph.add(ii, jj, remove=remove, have_volumes=self.corr is not None)
+        if removed is not None:
+            self._drop_payload(torch.from_numpy(removed).to(self.device), store=True)
+        if ni.shape[0] == 0:
+            return
+        di, dj = torch.from_numpy(ni).to(self.device), torch.from_numpy(nj).to(self.device)
+        pyr = CorrBlock.build_pyramid(self.feat_bank, self.feat_bank, di, dj, ni.shape[0], self.ht, self.wd)
+        new = CorrBlock.from_pyramid(pyr)
+        self.corr = new if self.corr is None else self.corr.cat(new)
+        tgt = self.reproject(di, dj)
+        self.target = torch.cat([self.target, tgt], 0)
+        self.weight = torch.cat([self.weight, torch.zeros_like(tgt)], 0)
+        self._sync_edges()
+
+    def _drop_payload(self, mask, store):
+        if store:
+            self.target_inactive = torch.cat([self.target_inactive, self.target[mask]], 0)
+            self.weight_inactive = torch.cat([self.weight_inactive, self.weight[mask]], 0)
+        keep = ~mask
+        self.target, self.weight = self.target[keep], self.weight[keep]
+        if self.corr is not None:
+            self.corr = self.corr[keep]
+        self._sync_edges()
+
+    def rm_factors(self, mask, store=False):
+        """(:868-892); mask: host bool array over the active edges."""
+        mask = np.asarray(mask, bool)
+        self.graph.remove(mask, store=store)
+        self._drop_payload(torch.from_numpy(mask).to(self.device), store)
+
+    def add_neighborhood_factors(self, kf0, kf1, radius=3):
+        ii, jj = FactorGraph.neighborhood_edges(kf0, kf1, radius)
+        self.add_factors(ii, jj)
+
+    def add_proximity_factors(self, kf0=0, kf1=0, rad=2, nms=2, thresh=16.0, remove=False):
+        """(:712-775): distances on the device (one D2H of the distance vector), selection on the host."""
+        t = self.kf_idx + 1
+        I, J = np.meshgrid(np.arange(kf0, t), np.arange(kf1, t), indexing="ij")
+        d = self.distance(I.reshape(-1), J.reshape(-1)).cpu().numpy()
+        es = self.graph.proximity_edges(d, self.kf_idx, kf0, kf1, rad, nms, thresh)
+        if es:
+            e = np.asarray(es, np.int64)
+            self.add_factors(e[:, 0], e[:, 1], remove)
+
+    # ---------------------------------------------------------------------------------------------
+    def update(self, itrs=2):
+        """one update-operator + dense-BA step (:370-470)."""
+        E = self.ii.shape[0]
+        coords1 = self.reproject(self.ii, self.jj)                                    # [E,ht,wd,2]
+        motion = torch.cat([coords1 - self.coords0, self.target - coords1], -1).permute(0, 3, 1, 2).clamp(-64.0, 64.0)
+        corr = self.corr(coords1[None])                                               # [1,E,196,ht,wd]
+        delta, weight, damping = self.update_op(corr, motion[None], self.ii, self.jj)
+        self.target = coords1 + delta[0].float()
+        self.weight = weight[0].float()
+        kx = np.unique(self.graph.ii)
+        self.damping[torch.from_numpy(kx).to(self.device)] = damping
+        kf0 = max(0, int(self.graph.ii.min()))
+        ii_h, jj_h, m = self.graph.ba_edges(kf0)
+        m_d = torch.from_numpy(m).to(self.device)
+        target = torch.cat([self.target_inactive[m_d], self.target], 0).permute(0, 3, 1, 2).contiguous()
+        weight = torch.cat([self.weight_inactive[m_d], self.weight], 0).permute(0, 3, 1, 2).contiguous()
+        out = self.ba(target, weight, ii_h, jj_h, kf0, itrs=itrs)
+        self.graph.age += 1
+        self.viz_idx[kf0:self.kf_idx + 1] = True
+        return out
+
+    def ba(self, target, weight, ii_h, jj_h, kf0, kf1=None, itrs=2):
+        """dense bundle adjustment (:1071-1232) without leaving the device."""
+        if kf1 is None:
+            kf1 = int(max(ii_h.max(), jj_h.max())) + 1
+        key = (self.graph.version, kf0, kf1, ii_h.shape[0])
+        if self._plan_key != key:
+            self._plan, self._plan_key = ba_plan.BaPlan(ii_h, jj_h, kf0, kf1, self.device), key
+            self._ii_ba = torch.from_numpy(ii_h).to(self.device)
+            self._jj_ba = torch.from_numpy(jj_h).to(self.device)
+        plan = self._plan
+        kx = torch.from_numpy(plan.kx_host).to(self.device)
+        damping = (0.2 * self.damping[kx] + 1e-7).contiguous()                        # :428
+        prior = self.prior_pose if (kf0 == 0 and self.prior_pose is not None) else None
+        sol = None
+        for it in range(itrs):
+            H, v, Q, E, w = ba_plan.reduced_camera_matrix(plan, self.cam0_T_world, self.cam0_idepths, self.intr8,
+                                                          self.cam0_T_body, self.cam0_idepths_sensed, target, weight,
+                                                          damping, self._ii_ba, self._jj_ba)
+            last = it == itrs - 1
+            sol = ba_plan.ba_solve(H, v, kf0, kf1, self.world_T_body, self.cam0_T_world, self.cam0_T_body,
+                                   prior_pose=prior, want_cov=self.compute_covariances and last)
+            ba_plan.solve_depth(plan, sol["dx"], self.cam0_idepths, Q, E, w, clamp_min=0.001)   # :1161-1162
+        if self.compute_covariances and sol["Linv"] is not None:
+            z = ba_plan.depth_cov(plan, sol["Linv"], Q, E, self.HW).view(-1, self.ht, self.wd)  # :1191-1219
+            self.world_T_body_cov[kf0:kf1] = sol["sigma_g"]
+            self.cam0_idepths_cov[kx] = z
+            self.cam0_depths_cov[kx] = z / self.cam0_idepths[kx] ** 4                          # :1229
+        return sol
+
+    # ---------------------------------------------------------------------------------------------
+    def get_viz_out(self):
+        """SLAM -> mapper packet (:1337-1391): the dirty keyframes, as DEVICE tensors (the reference moves them to
+        the CPU for --multi_gpu and pickles them; here nerfslam.transport ships them over RCCL)."""
+        idx, = torch.where(self.viz_idx)
+        if idx.numel() == 0:
+            return None
+        up = lambda x: torch.nn.functional.interpolate(x[:, None], size=(self.H, self.W), mode="bilinear",
+                                                       align_corners=False)[:, 0]
+        out = {"cam0_poses": self.cam0_T_world[idx], "world_T_body": self.world_T_body[idx],
+               "world_T_body_cov": self.world_T_body_cov[idx], "cam0_idepths": self.cam0_idepths[idx],
+               "cam0_idepths_up": up(self.cam0_idepths[idx]), "cam0_idepths_sensed": self.cam0_idepths_sensed[idx],
+               "cam0_idepths_cov": self.cam0_idepths_cov[idx], "cam0_depths_cov": self.cam0_depths_cov[idx],
+               "cam0_depths_cov_up": up(self.cam0_depths_cov[idx]), "cam0_images": self.images[idx],
+               "cam0_intrinsics": (self.intr8 * 8.0)[None].repeat(idx.numel(), 1), "viz_idx": idx,
+               "kf_idx": self.kf_idx, "is_last_frame": False}
+        self.viz_idx[:] = False
+        return out

@@ -202,6 +202,17 @@ def projmap(poses, disps, intr, ii, jj):
     return coords, valid
 
 
+def reproject(poses, disps, intr, ii, jj):
+    """torch-path reprojection (projective_ops.py:98-145, no Jacobians) -> coords [n,ht,wd,2], valid [n,ht,wd]."""
+    poses, disps, intr, ii, jj = _f32(poses), _f32(disps), _f32(intr), _i64(ii), _i64(jj)
+    _, ht, wd = disps.shape
+    n = ii.shape[0]
+    coords = np.zeros((n, ht, wd, 2), np.float32)
+    valid = np.zeros((n, ht, wd), np.float32)
+    lib().orc_reproject(_p(poses), _p(disps), _p(intr), _p(ii), _p(jj), n, ht, wd, _p(coords), _p(valid))
+    return coords, valid
+
+
 def iproj(poses, disps, intr):
     poses, disps, intr = _f32(poses), _f32(disps), _f32(intr)
     nm, ht, wd = disps.shape

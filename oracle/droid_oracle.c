@@ -821,6 +821,32 @@ void orc_projmap(const float* poses, const float* disps, const float* intr, cons
   }
 }
 
+/* Torch-path reprojection: networks/geom/projective_ops.py:98-145 with jacobian=False
+ * (iproj :20-39, actp :69-71, proj :41-53, validity :116-118).  coords [num,HW,2], valid [num,HW].   */
+void orc_reproject(const float* poses, const float* disps, const float* intr, const int64_t* ii, const int64_t* jj,
+                   int num, int ht, int wd, float* coords, float* valid) {
+  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  const int HW = ht * wd;
+  for (int b = 0; b < num; b++) {
+    int ix = (int)ii[b], jx = (int)jj[b];
+    float tij[3], qij[4];
+    if (ix == jx) {
+      tij[0] = -0.1f; tij[1] = 0; tij[2] = 0; qij[0] = qij[1] = qij[2] = 0; qij[3] = 1;
+    } else {
+      relSE3(poses + (long)ix * 7, poses + (long)ix * 7 + 3, poses + (long)jx * 7, poses + (long)jx * 7 + 3, tij, qij);
+    }
+    for (int k = 0; k < HW; k++) {
+      float Xi[4] = {((float)(k % wd) - cx) / fx, ((float)(k / wd) - cy) / fy, 1, disps[(long)ix * HW + k]}, Xj[4];
+      actSE3(tij, qij, Xi, Xj);
+      const float Z = (Xj[2] < 0.5f * 0.2f) ? 1.0f : Xj[2];
+      const float d = 1.0f / Z;
+      coords[((long)b * HW + k) * 2 + 0] = fx * (Xj[0] * d) + cx;
+      coords[((long)b * HW + k) * 2 + 1] = fy * (Xj[1] * d) + cy;
+      valid[(long)b * HW + k] = (Xj[2] > 0.2f) ? 1.0f : 0.0f;
+    }
+  }
+}
+
 /* iproj_kernel (:896-967): points [nm,ht,wd,3] */
 void orc_iproj(const float* poses, const float* disps, const float* intr, int nm, int ht, int wd, float* points) {
   const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];

@@ -1,0 +1,88 @@
+"""End-to-end check of the tracking hot path through the host mirror of RaftVisualFrontend:
+a synthetic scene with known poses / depths, an update operator that returns the TRUE induced flow
+(standing in for the ConvGRU, whose weights the reference tree lacks), and the device BA.  The
+estimate must converge to the ground truth (up to the monocular gauge, which is anchored by the frame-0
+prior and a sensed-depth prior on frame 0)."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tracking_converges_to_ground_truth(oracle_mod, dev):
+    from nerfslam import se3
+    from nerfslam.frontend import TrackingFrontend
+    rng = np.random.default_rng(0)
+    H, W, nkf = 96, 128, 6
+    ht, wd = H // 8, W // 8
+    intr = np.array([100.0, 100.0, W / 2, H / 2], np.float32)
+    # ground truth: smooth depth maps, small motion
+    gt_poses = np.zeros((nkf, 7), np.float32); gt_poses[:, 6] = 1
+    for k in range(1, nkf):
+        gt_poses[k, :3] = 0.04 * k * np.array([1.0, 0.2, 0.1]) + rng.normal(0, 0.005, 3)
+        gt_poses[k, 3:] = synth.quat_exp(rng.normal(0, 0.01, 3))
+    yy, xx = np.meshgrid(np.linspace(0, 1, ht), np.linspace(0, 1, wd), indexing="ij")
+    gt_disp = np.stack([0.5 + 0.3 * np.sin(3 * xx + k) * np.cos(2 * yy) for k in range(nkf)]).astype(np.float32)
+    gtP, gtD = torch.from_numpy(gt_poses).to(dev), torch.from_numpy(gt_disp).to(dev)
+
+    def feature_fn(img):
+        g = torch.Generator(device="cpu").manual_seed(int(img.sum().item()) % 1000)
+        return torch.randn((128, ht, wd), generator=g)
+
+    fe = None
+
+    def true_flow_op(corr, motion, ii, jj):
+        # the ConvGRU stand-in: flow correction = (true induced flow) - (current reprojection)
+        E = ii.shape[0]
+        true_c = torch.empty((E, ht, wd, 2), device=dev)
+        from nerfslam._lib import check, lib, ptr, stream_ptr
+        check(lib().ns_reproject(ptr(gtP), ptr(gtD), ptr(fe.intr8), ptr(ii), ptr(jj), ptr(true_c), None, E, ht, wd,
+                                 stream_ptr()), "reproject")
+        cur = fe.reproject(ii, jj)
+        delta = (true_c - cur)[None]
+        weight = torch.ones_like(delta)
+        nk = len(np.unique(fe.graph.ii))
+        return delta, weight, torch.full((nk, ht, wd), 1e-4, device=dev)
+
+    fe = TrackingFrontend(8, H, W, intr, dev, feature_fn=feature_fn, update_op=true_flow_op)
+    for k in range(nkf):
+        fe.set_keyframe(k, torch.full((3, H, W), k, dtype=torch.uint8))
+    fe.kf_idx = nkf - 1
+    # initial state: every pose at frame 0's, constant depth; frame 0 anchored (prior + sensed depth)
+    fe.prior_pose = fe.world_T_body[0].clone()
+    fe.cam0_idepths[:] = 0.6
+    fe.cam0_idepths_sensed[0] = gtD[0]
+    fe.cam0_idepths[0] = gtD[0]
+    fe.add_neighborhood_factors(0, nkf - 1, radius=3)
+    assert fe.ii.shape[0] == len(fe.graph.ii) == 24 and fe.corr.corr_pyramid[0].shape[0] == 24
+
+    def err():
+        c = fe.reproject(fe.ii, fe.jj)
+        t = torch.empty_like(c)
+        from nerfslam._lib import check, lib, ptr, stream_ptr
+        check(lib().ns_reproject(ptr(gtP), ptr(gtD), ptr(fe.intr8), ptr(fe.ii), ptr(fe.jj), ptr(t), None, c.shape[0], ht,
+                                 wd, stream_ptr()), "reproject")
+        return (c - t).norm(dim=-1).mean().item()
+
+    e0 = err()
+    for _ in range(12):
+        sol = fe.update(itrs=2)
+        assert sol["info"].item() == 0
+    e1 = err()
+    assert e0 > 0.2 and e1 < 1e-3 * e0, (e0, e1)
+    # poses: cam0_T_world vs ground truth
+    dT = se3.log_wv(se3.mul(fe.cam0_T_world[:nkf].double(), se3.inv(gtP.double())))
+    assert dT.abs().max().item() < 5e-3, dT
+    assert (fe.cam0_idepths[:nkf] - gtD).abs().mean().item() < 5e-3
+    assert torch.isfinite(fe.cam0_idepths_cov[:nkf]).all() and torch.isfinite(fe.world_T_body_cov[:nkf]).all()
+    pkt = fe.get_viz_out()
+    assert pkt["cam0_poses"].shape == (nkf, 7) and pkt["cam0_idepths_up"].shape == (nkf, H, W)
+    # graph maintenance on the device payloads
+    fe.add_proximity_factors(kf0=0, kf1=0, rad=2, nms=2, thresh=1e9)
+    n = fe.ii.shape[0]
+    assert fe.target.shape[0] == n == fe.corr.corr_pyramid[3].shape[0]
+    fe.rm_factors(fe.graph.age > 5, store=True)
+    assert fe.target_inactive.shape[0] == len(fe.graph.ii_inactive)

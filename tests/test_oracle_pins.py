@@ -197,3 +197,12 @@ def test_se3_algebra_consistency(oracle_mod):
         e2 = oracle_mod.se3_exp(np.concatenate([xi[3:], xi[:3]]).astype(np.float32))
         e2 = e2 * np.sign(e2[6] * T[6])
         np.testing.assert_allclose(e2, T, atol=3e-6)
+
+
+def test_golden_reproject(oracle_mod):
+    """oracle reprojection (the frontend's per-update reproject) == the reference's projective_transform
+    output `x1` / `valid` (tests/golden/projective_transform.npz)."""
+    g = np.load(os.path.join(GOLD, "projective_transform.npz"))
+    coords, valid = oracle_mod.reproject(g["poses"], g["disps"], g["intr"], g["ii"], g["jj"])
+    np.testing.assert_array_equal(valid, g["valid"][..., 0])
+    assert np.abs(coords - g["coords"]).max() <= 2e-5 * np.abs(g["coords"]).max()
