@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Driver with the reference's command line (/root/reference/examples/slam_demo.py:20-61) and wiring
+(:62-190): DataModule -> SlamModule("VioSLAM") -> FusionModule("nerf").
+
+--parallel_run --multi_gpu runs one process per GPU under torch.distributed (RCCL): rank 0 tracks on its GPU
+and ships the dirty keyframes with nerfslam.transport; ranks >= 1 train the NeRF.  Launch with
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 examples/slam_demo.py --slam \
+        --fusion nerf --parallel_run --multi_gpu ...
+Datasets and the DROID weights are not part of this project: `--dataset_dir` takes a .npz sequence
+(images [N,H,W,3] uint8, intrinsics [4], optional depths [N,H,W]) and `--weights` a TorchScript bundle exposing
+features / update / motion; without them the demo runs on a synthetic orbit and cannot track.
+"""
+import argparse
+import os
+import sys
+from queue import Queue
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "nerf-slam_amd"))
+from nerfslam.pipeline import DataModule, FusionModule, SlamModule  # noqa: E402
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="NeRF-SLAM demo (MI355X build)")
+    p.add_argument("--parallel_run", action="store_true")
+    p.add_argument("--multi_gpu", action="store_true")
+    p.add_argument("--initial_k", type=int, default=0)
+    p.add_argument("--final_k", type=int, default=-1)
+    p.add_argument("--img_stride", type=int, default=1)
+    p.add_argument("--stereo", action="store_true")
+    p.add_argument("--weights", default="droid.pth")
+    p.add_argument("--buffer", type=int, default=512)
+    p.add_argument("--dataset_dir", type=str, default="")
+    p.add_argument("--dataset_name", type=str, default="npz")
+    p.add_argument("--mask_type", type=str, default="ours", choices=["no_depth", "raw", "ours", "ours_w_thresh"])
+    p.add_argument("--slam", action="store_true")
+    p.add_argument("--fusion", type=str, default="", choices=["tsdf", "sigma", "nerf", ""])
+    p.add_argument("--gui", action="store_true")
+    p.add_argument("--width", "--screenshot_w", type=int, default=0)
+    p.add_argument("--height", "--screenshot_h", type=int, default=0)
+    p.add_argument("--network", default="")
+    p.add_argument("--eval", action="store_true")
+    return p.parse_args(argv)
+
+
+def load_sequence(args):
+    if not args.dataset_dir:
+        raise SystemExit("slam_demo: --dataset_dir <sequence.npz> is required")
+    z = np.load(args.dataset_dir)
+    n = z["images"].shape[0] if args.final_k < 0 else min(args.final_k, z["images"].shape[0])
+    ks = list(range(args.initial_k, n, args.img_stride))
+    for k in ks:
+        yield {"k": [k], "images": [z["images"][k]], "poses": [np.eye(4, dtype=np.float32)], "t_cams": [float(k)],
+               "depths": [z["depths"][k] if "depths" in z else None], "calibs": [z["intrinsics"]],
+               "is_last_frame": k == ks[-1]}
+
+
+def run(args):
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    split = args.parallel_run and args.multi_gpu and world > 1
+    if split:
+        import torch.distributed as dist
+        from nerfslam import transport
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+        dist.init_process_group("nccl")
+    dev = f"cuda:{torch.cuda.current_device()}"
+    args_seq = argparse.Namespace(**{**vars(args), "parallel_run": False})
+    if split and rank > 0:                                   # NeRF trainer rank
+        fusion = FusionModule("nerf", args_seq, device=dev)
+        fusion.initialize_module()
+        while not fusion.shutdown:
+            pkt = transport.broadcast_packet(None, 0, dev)
+            fusion.spin_once({"slam": [None, pkt]})
+            if pkt["is_last_frame"]:
+                break
+        return
+    data_q, slam_q = Queue(), Queue()
+    data = DataModule(args.dataset_name, args_seq, dataset=load_sequence(args))
+    data.register_output_queue(data_q)
+    slam = fusion = None
+    if args.slam:
+        args_seq.networks = torch.jit.load(args.weights, map_location=dev)
+        slam = SlamModule("VioSLAM", args_seq, device=dev)
+        slam.register_input_queue("data", data_q)
+        if split:
+            slam.register_output_callback(lambda out: transport.broadcast_packet(out[1], 0, dev) if out[1] else None)
+    if args.fusion and not split:
+        fusion = FusionModule(args.fusion, args_seq, device=dev)
+        if slam:
+            slam.register_output_queue(slam_q)
+            fusion.register_input_queue("slam", slam_q)
+    while data.spin() and (slam is None or slam.spin()) and (fusion is None or fusion.spin()):
+        pass
+    while fusion is not None and not fusion.shutdown and fusion.spin():
+        pass
+
+
+if __name__ == "__main__":
+    torch.set_grad_enabled(False)
+    run(parse_args())

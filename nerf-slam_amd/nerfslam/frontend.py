@@ -173,7 +173,7 @@ class TrackingFrontend:
         self.viz_idx[kf0:self.kf_idx + 1] = True
         return out
 
-    def ba(self, target, weight, ii_h, jj_h, kf0, kf1=None, itrs=2):
+    def ba(self, target, weight, ii_h, jj_h, kf0, kf1=None, itrs=2, lm=0.0, ep=0.0, compute_covariances=None):
         """dense bundle adjustment (:1071-1232) without leaving the device."""
         if kf1 is None:
             kf1 = int(max(ii_h.max(), jj_h.max())) + 1
@@ -187,15 +187,16 @@ class TrackingFrontend:
         damping = (0.2 * self.damping[kx] + 1e-7).contiguous()                        # :428
         prior = self.prior_pose if (kf0 == 0 and self.prior_pose is not None) else None
         sol = None
+        cov = self.compute_covariances if compute_covariances is None else compute_covariances
         for it in range(itrs):
             H, v, Q, E, w = ba_plan.reduced_camera_matrix(plan, self.cam0_T_world, self.cam0_idepths, self.intr8,
                                                           self.cam0_T_body, self.cam0_idepths_sensed, target, weight,
                                                           damping, self._ii_ba, self._jj_ba)
             last = it == itrs - 1
             sol = ba_plan.ba_solve(H, v, kf0, kf1, self.world_T_body, self.cam0_T_world, self.cam0_T_body,
-                                   prior_pose=prior, want_cov=self.compute_covariances and last)
+                                   prior_pose=prior, ep=ep, lm=lm, want_cov=cov and last)
             ba_plan.solve_depth(plan, sol["dx"], self.cam0_idepths, Q, E, w, clamp_min=0.001)   # :1161-1162
-        if self.compute_covariances and sol["Linv"] is not None:
+        if cov and sol["Linv"] is not None:
             z = ba_plan.depth_cov(plan, sol["Linv"], Q, E, self.HW).view(-1, self.ht, self.wd)  # :1191-1219
             self.world_T_body_cov[kf0:kf1] = sol["sigma_g"]
             self.cam0_idepths_cov[kx] = z

@@ -1,0 +1,215 @@
+"""TrackingSLAM -- per-frame state machine around TrackingFrontend; the call surface of the reference's
+VioSLAM (/root/reference/slam/vio_slam.py:78-127: `slam(batch) -> [state, viz_out] | False`,
+`stop_condition()`) and the frame logic of RaftVisualFrontend.forward
+(/root/reference/slam/visual_frontends/visual_frontend.py:240-368, 577-688, 1255-1335):
+
+    frame 0 -> keyframe 0;  motion filter;  warm-up until `keyframe_warmup` keyframes;  initialize
+    (neighbourhood edges r=3, 8 updates, proximity edges, 8 updates);  per keyframe: age-out edges,
+    proximity edges, iters1 updates, keyframe distance test (reject -> rm_keyframe), iters2 updates,
+    seed the next keyframe;  at buffer end / last frame: global BA passes (7 and 12 steps) on the
+    on-the-fly correlation (AltCorrBlock).
+
+The learned networks are injected through `args.networks` (see nerfslam.frontend docstring):
+    networks.features(image_u8 [3,H,W]) -> fmap [128,H/8,W/8]
+    networks.update(corr, motion, ii, jj) -> (delta, weight, damping)
+    networks.motion(corr [1,1,196,ht,wd]) -> delta [1,1,ht,wd,2]       (motion filter, :978-1008)
+The GTSAM Values / NonlinearFactorGraph the reference returns empty (:248-250) are returned as None.
+"""
+import numpy as np
+import torch
+
+from .corr import AltCorrBlock, CorrBlock
+from .frontend import TrackingFrontend
+
+
+class TrackingSLAM:
+    def __init__(self, name, args, device):
+        self.name, self.args, self.device = name, args, torch.device(device)
+        self.net = getattr(args, "networks", None)
+        if self.net is None:
+            raise RuntimeError("TrackingSLAM: args.networks (features / update / motion callables) is required; the "
+                               "DROID weights are not part of this project")
+        self.buffer = args.buffer
+        self.global_ba = getattr(args, "slam", True) and getattr(args, "global_ba", True)
+        self.keyframe_warmup, self.motion_filter_thresh = 8, 2.4           # :93-95
+        self.iters1, self.iters2 = 4, 2                                    # :101-102
+        self.backend_thresh, self.backend_radius, self.backend_nms = 22.0, 2, 3
+        self.fe = None
+        self.last_k, self.last_kf = None, 0
+        self.is_initialized, self.stop = False, False
+        self.kf_to_frame = {}
+
+    # the reference's nn.Module call
+    def __call__(self, batch):
+        out = self._frontend(batch["data"])
+        return False if out is False else [None, out]
+
+    def stop_condition(self):
+        return self.stop
+
+    # ---------------------------------------------------------------------------------------------
+    def _store(self, k, data, fmap):
+        fe = self.fe
+        fe.set_keyframe(fe.kf_idx, data["image_u8"], fmap)
+        depth = data.get("depth")
+        if depth is not None:                                              # sensed depth -> 1/8-res inverse depth (:297-305)
+            d = torch.as_tensor(depth, dtype=torch.float32, device=self.device)[3::8, 3::8]
+            fe.cam0_idepths_sensed[fe.kf_idx] = torch.where(d > 0, 1.0 / d, torch.zeros_like(d))
+        self.kf_to_frame[fe.kf_idx] = k
+
+    def _enough_motion(self, fmap):
+        """one update-operator evaluation on the identity lookup between the last keyframe and this frame."""
+        fe = self.fe
+        last = (fe.feat_bank[self.last_kf].float() * 4.0).t().reshape(1, 1, 128, fe.ht, fe.wd)
+        corr = CorrBlock(last, fmap[None, None].float())(fe.coords0[None, None])
+        delta = self.net.motion(corr)
+        return float(delta.norm(dim=-1).mean()) > self.motion_filter_thresh
+
+    def _frontend(self, data):
+        k = int(data["k"][0])
+        img = torch.as_tensor(data["images"][0], device=self.device)[..., :3].permute(2, 0, 1).contiguous()
+        data = dict(data, image_u8=img, depth=(data.get("depths") or [None])[0])
+        last_frame = bool(data.get("is_last_frame", False))
+        if self.fe is None:
+            assert k == 0
+            intr = np.asarray(data["calibs"][0].camera_model.numpy() if hasattr(data["calibs"][0], "camera_model")
+                              else data["calibs"][0], np.float32)
+            self.fe = TrackingFrontend(self.buffer, img.shape[1], img.shape[2], intr, self.device,
+                                       feature_fn=self.net.features, update_op=self.net.update)
+            self._store(k, data, None)
+            self.last_k, self.last_kf = k, 0
+            self.fe.viz_idx[0] = True
+            viz = self._viz(last_frame)
+            self.fe.kf_idx += 1
+            return viz
+        fe = self.fe
+        fmap = self.net.features(img)
+        if not self._enough_motion(fmap):
+            if last_frame:
+                fe.kf_idx -= 1
+                self.terminate()
+                return self._viz(True)
+            return None
+        self._store(k, data, fmap)
+        if not self.is_initialized:
+            if fe.kf_idx >= self.keyframe_warmup:
+                self._initialize()
+        elif not self._track():
+            self.rm_keyframe(fe.kf_idx - 1)
+            return None
+        self.last_k, self.last_kf = k, fe.kf_idx
+        viz = self._viz(last_frame)
+        if fe.kf_idx + 1 >= self.buffer or last_frame:
+            self.terminate()
+            return self._viz(True)
+        fe.kf_idx += 1
+        return viz
+
+    def _viz(self, last):
+        out = self.fe.get_viz_out()
+        if out is None:
+            out = {}
+        out["is_last_frame"] = last
+        out["kf_idx_to_f_idx"] = dict(self.kf_to_frame)
+        return out
+
+    # ---------------------------------------------------------------------------------------------
+    def _seed_next(self, window):
+        fe, k = self.fe, self.fe.kf_idx
+        if k + 1 >= self.buffer:
+            return
+        for buf in (fe.cam0_T_world, fe.world_T_body, fe.world_T_body_cov):
+            buf[k + 1] = buf[k]
+        lo = k + 1 - window
+        fe.cam0_idepths[k + 1] = fe.cam0_idepths[lo:k + 1].mean()
+        fe.cam0_idepths_cov[k + 1] = fe.cam0_idepths_cov[lo:k + 1].mean() if window > 1 else fe.cam0_idepths_cov[k]
+        fe.cam0_depths_cov[k + 1] = fe.cam0_depths_cov[lo:k + 1].mean() if window > 1 else fe.cam0_depths_cov[k]
+
+    def _initialize(self):
+        """:641-688"""
+        fe = self.fe
+        fe.add_neighborhood_factors(0, fe.kf_idx, radius=3)
+        for _ in range(8):
+            fe.update()
+        fe.add_proximity_factors(0, 0, rad=2, nms=2, thresh=fe.frontend_thresh, remove=False)
+        for _ in range(8):
+            fe.update()
+        self._seed_next(4)
+        self.is_initialized = True
+        fe.viz_idx[:fe.kf_idx + 1] = True
+        fe.rm_factors(fe.graph.ii < (self.keyframe_warmup - 4), store=True)
+
+    def _track(self):
+        """:577-638"""
+        fe, k = self.fe, self.fe.kf_idx
+        if fe.corr is not None:
+            fe.rm_factors(fe.graph.age > fe.max_age, store=True)
+        fe.add_proximity_factors(kf0=k - 4, kf1=max(k + 1 - fe.frontend_window, 0), rad=fe.frontend_radius,
+                                 nms=fe.frontend_nms, thresh=fe.frontend_thresh, remove=True)
+        s = fe.cam0_idepths_sensed[k]
+        fe.cam0_idepths[k] = torch.where(s > 0, s, fe.cam0_idepths[k])
+        for _ in range(self.iters1):
+            fe.update()
+        if float(fe.distance([k - 2], [k - 1])) < fe.keyframe_thresh:
+            return False
+        for _ in range(self.iters2):
+            fe.update()
+        self._seed_next(1)
+        return True
+
+    def rm_keyframe(self, k):
+        """:530-574: slide frame k+1 over k in every buffer, drop / renumber the edges that touch it."""
+        fe = self.fe
+        for buf in (fe.images, fe.cam0_T_world, fe.world_T_body, fe.world_T_body_cov, fe.cam0_idepths, fe.cam0_idepths_cov,
+                    fe.cam0_depths_cov, fe.cam0_idepths_sensed, fe.feat_bank):
+            buf[k] = buf[k + 1]
+        keep_inactive, drop_active = fe.graph.remove_keyframe(k)
+        ki = torch.from_numpy(keep_inactive).to(self.device)
+        fe.target_inactive, fe.weight_inactive = fe.target_inactive[ki], fe.weight_inactive[ki]
+        fe._drop_payload(torch.from_numpy(drop_active).to(self.device), store=False)
+
+    # ---------------------------------------------------------------------------------------------
+    def backend(self, steps):
+        """global BA over all keyframes with on-the-fly correlation (:1255-1300, :474-527)."""
+        fe, t = self.fe, self.fe.kf_idx
+        if not bool(torch.any(fe.cam0_idepths_sensed)):                    # normalize (:1302-1307)
+            s = fe.cam0_idepths[:t].mean()
+            fe.cam0_idepths[:t] /= s
+            fe.cam0_T_world[:t, :3] *= s
+        g = fe.graph
+        saved = g.max_factors
+        g.__init__(max_factors=16 * t)
+        fe.corr, fe.damping = None, 1e-6 * torch.ones_like(fe.cam0_idepths)
+        fe.target = fe.weight = fe.target_inactive = fe.weight_inactive = torch.zeros((0, fe.ht, fe.wd, 2), device=self.device)
+        I, J = np.meshgrid(np.arange(0, t + 1), np.arange(0, t + 1), indexing="ij")
+        d = fe.distance(I.reshape(-1), J.reshape(-1)).cpu().numpy()
+        es = np.asarray(g.proximity_edges(d, t, 0, 0, self.backend_radius, self.backend_nms, self.backend_thresh), np.int64)
+        if steps and es.shape[0]:
+            ii_h, jj_h, _ = g.add(es[:, 0], es[:, 1])
+            ii, jj = torch.from_numpy(ii_h).to(self.device), torch.from_numpy(jj_h).to(self.device)
+            fmaps = (fe.feat_bank.float() * 4.0).transpose(1, 2).reshape(1, self.buffer, 128, fe.ht, fe.wd)
+            corr_op = AltCorrBlock(fmaps)
+            target, weight = fe.reproject(ii, jj), torch.zeros((ii.shape[0], fe.ht, fe.wd, 2), device=self.device)
+            for _ in range(steps):
+                coords1 = fe.reproject(ii, jj)
+                motion = torch.cat([coords1 - fe.coords0, target - coords1], -1).permute(0, 3, 1, 2).clamp(-64.0, 64.0)
+                for lo in range(0, int(jj_h.max()) + 1, 8):                # windows of 8 source frames (:494-499)
+                    v = torch.from_numpy((ii_h >= lo) & (ii_h < lo + 8)).to(self.device)
+                    if not bool(v.any()):
+                        continue
+                    corr = corr_op(coords1[None, v], ii[v], jj[v])
+                    delta, w, damping = self.net.update(corr, motion[None, v], ii[v], jj[v])
+                    target[v], weight[v] = coords1[v] + delta[0].float(), w[0].float()
+                    fe.damping[torch.unique(ii[v])] = damping
+                fe.ba(target.permute(0, 3, 1, 2).contiguous(), weight.permute(0, 3, 1, 2).contiguous(), ii_h, jj_h,
+                      kf0=0, itrs=2, lm=1e-5, ep=1e-2, compute_covariances=False)        # :523-526
+        g.__init__(max_factors=saved)
+        fe._sync_edges()
+        fe.viz_idx[:t] = True
+
+    def terminate(self):
+        """:1309-1335"""
+        if self.global_ba:
+            for steps in (7, 12, 0):
+                self.backend(steps)
+        self.stop = True

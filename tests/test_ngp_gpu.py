@@ -264,3 +264,27 @@ def test_pyngp_surface_as_nerf_fusion_drives_it(dev):
     tb.render_mode = ngp.Depth
     dep = tb.render(W, H, 1, True)
     assert img.shape == (H, W, 4) and dep.shape == (H, W, 4) and np.isfinite(img).all()
+
+
+@pytest.mark.gpu
+def test_nerf_fusion_consumes_slam_packet(dev):
+    """SLAM -> mapper packet (visual_frontend.py:1364-1382) through NerfFusion.fuse (nerf_fusion.py:238-262):
+    the first spin ingests (no training, like the reference), later spins train; the loss decreases."""
+    import argparse
+    from nerfslam.nerf_fusion import NerfFusion
+    g = torch.Generator().manual_seed(0)
+    n, H, W = 3, 32, 48
+    poses = torch.tensor([[0.0, 0, 0, 0, 0, 0, 1], [0.05, 0, 0, 0, 0, 0, 1], [-0.05, 0.02, 0, 0, 0, 0, 1]])
+    img = torch.randint(0, 255, (1, 3, 4, 6), generator=g).float()
+    images = torch.nn.functional.interpolate(img, size=(H, W), mode="bilinear").repeat(n, 1, 1, 1).to(torch.uint8)
+    pkt = {"cam0_poses": poses, "cam0_images": images, "cam0_idepths_up": torch.full((n, H, W), 1.0),
+           "cam0_depths_cov_up": torch.full((n, H, W), 0.01), "cam0_intrinsics": torch.tensor([[40.0, 40.0, 24.0, 16.0]] * n),
+           "viz_idx": torch.tensor([0, 1, 2]), "kf_idx": 2, "is_last_frame": False}
+    fusion = NerfFusion("nerf", argparse.Namespace(buffer=8, mask_type="ours"), dev)
+    assert fusion.fuse({"slam": [None, pkt]}) is True
+    assert fusion.ngp.nerf.training.n_images_for_training == 3 and fusion.total_iters == 0
+    fusion.fuse(False)
+    l0, s0 = fusion.ngp.loss, fusion.total_iters
+    for _ in range(8):
+        fusion.fuse(False)
+    assert s0 > 0 and fusion.total_iters > s0 and np.isfinite(fusion.ngp.loss) and fusion.ngp.loss < l0
