@@ -252,7 +252,9 @@ int ns_ngp_adam(float* master, void* half_params, float* grad, float* m1, float*
                 float beta1, float beta2, float eps, float l2, float grad_scale, void* stream);
 
 /* occupancy-grid ray marching: bits = ncasc cascades of G^3 bits; rays_o/rays_d [R,3] (unit dirs),
- * t_range [R,2].  counter[2] (zeroed by the caller) receives (#samples, #rays with samples);
+ * t_range [R,2].  counter[3] (zeroed by the caller) receives (#samples requested by all rays,
+ * #rays that received samples, end of the last reserved range = number of samples to process: a
+ * ray whose range would cross max_samples gets none, which can leave a hole before max_samples);
  * ray_start/ray_n [R]; pos/dirs [max_samples,3]; dt/tmid [max_samples].                          */
 int ns_ngp_march(const uint8_t* bits, int G, int ncasc, const float* rays_o, const float* rays_d,
                  const float* t_range, int R, float cone, float min_step, float max_step, int max_per_ray,

@@ -197,7 +197,7 @@ struct MarchArgs {
   float cone, min_step, max_step;
   int G, ncasc, max_per_ray;
   long max_samples;
-  int* counter;          // [2]: samples, rays-with-samples (device, zeroed by the caller)
+  int* counter;          // [3]: samples requested, rays with samples, end of the last reserved range (zeroed by the caller)
   int* ray_start;        // [R]
   int* ray_n;            // [R]
   float* pos;            // [max_samples,3]
@@ -218,7 +218,8 @@ __global__ __launch_bounds__(128) void ngp_march_kernel(MarchArgs a) {
   int n = 0;
   for (float t = t0; t < t1 && n < a.max_per_ray;) {
     const float dt = fminf(fmaxf(t * a.cone, a.min_step), a.max_step);
-    if (occupied(a.bits, ox + t * dx, oy + t * dy, oz + t * dz, dt, a.G, a.ncasc)) n++;
+    // explicit fma: the counting and the writing pass must see bit-identical positions
+    if (occupied(a.bits, __fmaf_rn(t, dx, ox), __fmaf_rn(t, dy, oy), __fmaf_rn(t, dz, oz), dt, a.G, a.ncasc)) n++;
     t += dt;
   }
   int base = 0;
@@ -230,10 +231,11 @@ __global__ __launch_bounds__(128) void ngp_march_kernel(MarchArgs a) {
   a.ray_n[r] = n;
   if (n == 0) return;
   atomicAdd(&a.counter[1], 1);
+  atomicMax(&a.counter[2], base + n);
   int k = 0;
   for (float t = t0; t < t1 && k < n;) {
     const float dt = fminf(fmaxf(t * a.cone, a.min_step), a.max_step);
-    const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+    const float x = __fmaf_rn(t, dx, ox), y = __fmaf_rn(t, dy, oy), z = __fmaf_rn(t, dz, oz);
     if (occupied(a.bits, x, y, z, dt, a.G, a.ncasc)) {
       const long s = (long)base + k;
       a.pos[s * 3] = x;
@@ -247,6 +249,17 @@ __global__ __launch_bounds__(128) void ngp_march_kernel(MarchArgs a) {
       k++;
     }
     t += dt;
+  }
+  for (; k < n; k++) {  // never taken when both passes agree; keeps the reserved range defined regardless
+    const long s = (long)base + k;
+    a.pos[s * 3] = ox;
+    a.pos[s * 3 + 1] = oy;
+    a.pos[s * 3 + 2] = oz;
+    a.dirs[s * 3] = dx;
+    a.dirs[s * 3 + 1] = dy;
+    a.dirs[s * 3 + 2] = dz;
+    a.dt[s] = 0.0f;
+    a.tmid[s] = t1;
   }
 }
 

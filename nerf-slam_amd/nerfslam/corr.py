@@ -147,9 +147,10 @@ class AltCorrBlock:
         self.shape = (N, Cc, H, W)
         level = fmaps.reshape(N, Cc, H, W).float() / 4.0  # corr.py:98
         self.pyramid = []
-        for _ in range(num_levels):
+        for l in range(num_levels):
             self.pyramid.append(level.permute(0, 2, 3, 1).contiguous())  # [N, h, w, C]
-            level = torch.nn.functional.avg_pool2d(level, 2, stride=2)   # corr.py:105
+            if l + 1 < num_levels:
+                level = torch.nn.functional.avg_pool2d(level, 2, stride=2)   # corr.py:105
 
     def __call__(self, coords, ii, jj):
         """coords [1, E, H, W, 2] (or [1, E, H, W, S, 2]); ii, jj [E] frame ids

@@ -108,8 +108,8 @@ class NgpNerf:
         self.s_dfeat = torch.empty((S, 32), **h)
         self.act = [torch.empty((u, S), **h) for u in (32, 64, 32, 64, 64)]     # featT h1T cinT h3T h4T
         self.dact = [torch.empty((u, S), **h) for u in (16, 64, 64, 16, 64)]    # d5T d4T d3T ddT d1T
-        self.partial = torch.empty((c.wgrad_ksplit, MLP_TOTAL), **f)
-        self.counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.partial = torch.zeros((c.wgrad_ksplit, MLP_TOTAL), **f)
+        self.counter = torch.zeros(3, dtype=torch.int32, device=dev)
 
     # ------------------------------------------------------------------------------------------
     def _grid_args(self):
@@ -174,8 +174,10 @@ class NgpNerf:
                                  c.max_steps_per_ray, C.c_long(c.max_samples), ptr(self.counter), ptr(self.ray_start),
                                  ptr(self.ray_n), ptr(self.s_pos), ptr(self.s_dir), ptr(self.s_dt), ptr(self.s_t),
                                  stream_ptr()), "ngp_march")
-        n = int(self.counter[0].item())  # the one host read-back of a step (instant-ngp reads its ray counter too)
-        return min(n, c.max_samples)
+        # the one host read-back of a step (instant-ngp reads its ray counter too): end of the reserved ranges
+        cnt = self.counter.tolist()
+        self.samples_requested = cnt[0]     # > max_samples: some rays of this batch received no samples
+        return cnt[2]
 
     def train_step(self):
         if self.n_images == 0:
@@ -287,10 +289,14 @@ class NgpNerf:
         dep = torch.empty((H * W,), dtype=torch.float32, device=dev)
         nul = C.c_void_p(0)
         with torch.cuda.device(dev):
-            for s in range(0, H * W, chunk):
+            s = 0
+            while s < H * W:
                 oo, dd = o[s:s + chunk].contiguous(), d[s:s + chunk].contiguous()
                 N = self.march(oo, dd, self._t_range(oo, dd))
                 R = oo.shape[0]
+                if self.samples_requested > c.max_samples and R > 1:
+                    chunk = max(1, R // 2)   # a ray was refused: every pixel must be rendered, retry with fewer rays
+                    continue
                 orgb = torch.zeros((R, 3), dtype=torch.float32, device=dev)
                 odep = torch.zeros(R, dtype=torch.float32, device=dev)
                 if N > 0:
@@ -301,4 +307,5 @@ class NgpNerf:
                                                  ptr(self.ray_n), R, nul, nul, nul, C.c_float(0), C.c_float(1), ptr(orgb),
                                                  ptr(odep), nul, nul, stream_ptr()), "ngp_composite")
                 rgb[s:s + R], dep[s:s + R] = orgb, odep
+                s += R
         return rgb.view(H, W, 3), dep.view(H, W)

@@ -60,8 +60,9 @@ class TrackingSLAM:
     def _enough_motion(self, fmap):
         """one update-operator evaluation on the identity lookup between the last keyframe and this frame."""
         fe = self.fe
-        last = (fe.feat_bank[self.last_kf].float() * 4.0).t().reshape(1, 1, 128, fe.ht, fe.wd)
-        corr = CorrBlock(last, fmap[None, None].float())(fe.coords0[None, None])
+        f1 = fe.feat_bank[self.last_kf][None]                              # channels-last half, already / 4
+        f2 = (fmap.to(self.device).half().reshape(128, fe.HW) / 4.0).t().contiguous()[None]
+        corr = CorrBlock.from_pyramid(CorrBlock.build_pyramid(f1, f2, None, None, 1, fe.ht, fe.wd))(fe.coords0[None, None])
         delta = self.net.motion(corr)
         return float(delta.norm(dim=-1).mean()) > self.motion_filter_thresh
 
@@ -77,6 +78,7 @@ class TrackingSLAM:
             self.fe = TrackingFrontend(self.buffer, img.shape[1], img.shape[2], intr, self.device,
                                        feature_fn=self.net.features, update_op=self.net.update)
             self._store(k, data, None)
+            self.fe.prior_pose = self.fe.world_T_body[0].clone()           # frame-0 prior (:1089-1095, :1234-1253)
             self.last_k, self.last_kf = k, 0
             self.fe.viz_idx[0] = True
             viz = self._viz(last_frame)
@@ -163,6 +165,8 @@ class TrackingSLAM:
         for buf in (fe.images, fe.cam0_T_world, fe.world_T_body, fe.world_T_body_cov, fe.cam0_idepths, fe.cam0_idepths_cov,
                     fe.cam0_depths_cov, fe.cam0_idepths_sensed, fe.feat_bank):
             buf[k] = buf[k + 1]
+        if k + 1 in self.kf_to_frame:       # (the reference leaves its kf -> frame table stale here)
+            self.kf_to_frame[k] = self.kf_to_frame.pop(k + 1)
         keep_inactive, drop_active = fe.graph.remove_keyframe(k)
         ki = torch.from_numpy(keep_inactive).to(self.device)
         fe.target_inactive, fe.weight_inactive = fe.target_inactive[ki], fe.weight_inactive[ki]
@@ -202,7 +206,7 @@ class TrackingSLAM:
                     target[v], weight[v] = coords1[v] + delta[0].float(), w[0].float()
                     fe.damping[torch.unique(ii[v])] = damping
                 fe.ba(target.permute(0, 3, 1, 2).contiguous(), weight.permute(0, 3, 1, 2).contiguous(), ii_h, jj_h,
-                      kf0=0, itrs=2, lm=1e-5, ep=1e-2, compute_covariances=False)        # :523-526
+                      kf0=0, itrs=2, compute_covariances=False)   # :523-526 (its lm / ep arguments are dead: ba() never reads them)
         g.__init__(max_factors=saved)
         fe._sync_edges()
         fe.viz_idx[:t] = True

@@ -171,11 +171,11 @@ def test_ray_marching(oracle_mod, dev):
     tr = np.stack([np.full(R, 0.05), rng.uniform(0.5, 3.0, R)], 1).astype(np.float32)
     cone, mn, mx = 1 / 256.0, np.sqrt(3) / 1024, np.sqrt(3) / 1024 * 32
     S = 1 << 17
-    cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(3, dtype=torch.int32, device=dev)
     rs = torch.empty(R, dtype=torch.int32, device=dev); rn = torch.empty(R, dtype=torch.int32, device=dev)
     pos = torch.empty((S, 3), device=dev); dirs = torch.empty((S, 3), device=dev)
     dt = torch.empty(S, device=dev); tm = torch.empty(S, device=dev)
-    keep = [T(x, dev) for x in (bits, o, d, tr)]
+    keep = [T(x, dev) for x in (bits, o, d, tr)] + [torch.empty_like(pos), torch.empty_like(dirs), torch.empty_like(dt), torch.empty_like(tm)]
     check(lib().ns_ngp_march(ptr(keep[0]), G, nc, ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), R,
                              C.c_float(cone), C.c_float(mn), C.c_float(mx), 1024, C.c_long(S), ptr(cnt), ptr(rs),
                              ptr(rn), ptr(pos), ptr(dirs), ptr(dt), ptr(tm), stream_ptr()), "march")
@@ -190,7 +190,20 @@ def test_ray_marching(oracle_mod, dev):
             np.testing.assert_allclose(tm[rs[r]:rs[r] + rn[r]], ts, rtol=1e-5)
             np.testing.assert_allclose(pos[rs[r]:rs[r] + rn[r]], p, atol=1e-5)
         total += int(rn[r])
-    assert int(cnt[0].item()) == total
+    assert cnt.tolist() == [total, int((rn > 0).sum()), total]
+    # batch smaller than the demand: refused rays get nothing, the accepted ranges tile [0, counter[2]) without holes
+    S2 = total // 3
+    cnt2 = torch.zeros(3, dtype=torch.int32, device=dev)
+    rs2 = torch.empty(R, dtype=torch.int32, device=dev); rn2 = torch.empty(R, dtype=torch.int32, device=dev)
+    check(lib().ns_ngp_march(ptr(keep[0]), G, nc, ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), R,
+                             C.c_float(cone), C.c_float(mn), C.c_float(mx), 1024, C.c_long(S2), ptr(cnt2), ptr(rs2),
+                             ptr(rn2), ptr(keep[4]), ptr(keep[5]), ptr(keep[6]), ptr(keep[7]), stream_ptr()), "march")
+    rs2, rn2, c2 = rs2.cpu().numpy(), rn2.cpu().numpy(), cnt2.tolist()
+    acc = rn2 > 0
+    assert c2[0] == total and c2[1] == acc.sum() and 0 < c2[2] <= S2
+    order = np.argsort(rs2[acc])
+    st, ln = rs2[acc][order], rn2[acc][order]
+    assert st[0] == 0 and (st[1:] == st[:-1] + ln[:-1]).all() and st[-1] + ln[-1] == c2[2]
 
 
 def test_training_converges_on_a_synthetic_scene(dev):

@@ -1,0 +1,78 @@
+"""TrackingSLAM state machine (visual_frontend.py:240-368) on a synthetic sequence with stand-in networks that
+return the TRUE induced flow: warm-up -> initialize -> per-keyframe tracking -> global BA at the last frame."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_state_machine_runs_and_tracks(dev):
+    from nerfslam import se3
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    from nerfslam.slam import TrackingSLAM
+    rng = np.random.default_rng(1)
+    H, W, nfr = 96, 128, 14
+    ht, wd = H // 8, W // 8
+    intr = np.array([100.0, 100.0, W / 2, H / 2], np.float32)
+    gt_poses = np.zeros((nfr + 2, 7), np.float32); gt_poses[:, 6] = 1
+    for k in range(1, nfr + 2):
+        gt_poses[k, :3] = 0.06 * k * np.array([1.0, 0.2, 0.1]) + rng.normal(0, 0.004, 3)
+        gt_poses[k, 3:] = synth.quat_exp(rng.normal(0, 0.01, 3))
+    gt_poses[10] = gt_poses[9]                                           # a frame without parallax: must be rejected
+    yy, xx = np.meshgrid(np.linspace(0, 1, ht), np.linspace(0, 1, wd), indexing="ij")
+    gt_disp = np.stack([0.5 + 0.2 * np.sin(3 * xx + 0.3 * k) * np.cos(2 * yy) for k in range(nfr + 2)]).astype(np.float32)
+    gt_disp[10] = gt_disp[9]
+    gtP, gtD = torch.from_numpy(gt_poses).to(dev), torch.from_numpy(gt_disp).to(dev)
+    slam = None
+
+    class Nets:
+        def features(self, img):
+            g = torch.Generator(device="cpu").manual_seed(int(img[0, 0, 0].item()))
+            return torch.randn((128, ht, wd), generator=g).to(dev)
+
+        def motion(self, corr):
+            assert corr.shape == (1, 1, 196, ht, wd)
+            return torch.full((1, 1, ht, wd, 2), 3.0, device=dev)        # always "enough motion"
+
+        def update(self, corr, motion, ii, jj):
+            fe = slam.fe
+            E = ii.shape[0]
+            assert corr.shape == (1, E, 196, ht, wd) and torch.isfinite(corr).all()
+            true_c = torch.empty((E, ht, wd, 2), device=dev)
+            fr = torch.tensor([slam.kf_to_frame.get(i, 0) for i in range(args.buffer)], device=dev)
+            P, D = gtP[fr].contiguous(), gtD[fr].contiguous()
+            check(lib().ns_reproject(ptr(P), ptr(D), ptr(fe.intr8), ptr(ii), ptr(jj), ptr(true_c), None, E, ht, wd,
+                                     stream_ptr()), "reproject")
+            delta = (true_c - fe.reproject(ii, jj))[None]
+            nk = torch.unique(ii).numel()
+            return delta, torch.ones_like(delta), torch.full((nk, ht, wd), 1e-4, device=dev)
+
+    args = argparse.Namespace(buffer=16, networks=Nets(), slam=True, global_ba=True)
+    slam = TrackingSLAM("VioSLAM", args, dev)
+    packets = []
+    for k in range(nfr):
+        img = np.full((H, W, 4), k, np.uint8)
+        out = slam({"data": {"k": [k], "images": [img], "calibs": [intr], "depths": [1.0 / np.kron(gt_disp[k], np.ones((8, 8), np.float32)) if k == 0 else None],
+                             "is_last_frame": k == nfr - 1}})
+        assert out is not False
+        packets.append(out[1])
+        if k == 0:
+            slam.fe.keyframe_thresh = 0.25                                # px at 1/8 resolution; the scene moves ~0.4 px / frame
+    fe = slam.fe
+    fr = [slam.kf_to_frame[i] for i in range(fe.kf_idx + 1)]
+    assert slam.is_initialized and slam.stop_condition() and fe.kf_idx == nfr - 2, fe.kf_idx
+    assert fr == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13], fr            # frame 10 was dropped by the keyframe test
+    assert packets[-1]["is_last_frame"] and packets[-1]["cam0_poses"].shape[0] >= nfr - 2
+    assert "cam0_poses" not in packets[3]                                 # warm-up: nothing dirty
+    assert len(fe.graph.ii) == 0                                        # global BA cleared the graph (:1297-1300)
+    n = fe.kf_idx + 1
+    gtP = gtP[torch.tensor(fr, device=dev)]
+    assert torch.isfinite(fe.cam0_T_world[:n]).all() and torch.isfinite(fe.cam0_idepths[:n]).all()
+    # sensed depth on frame 0 fixes the scale -> the trajectory must match the ground truth
+    dT = se3.log_wv(se3.mul(fe.cam0_T_world[:n].double(), se3.inv(gtP[:n].double())))
+    assert dT.abs().max().item() < 2e-2, dT.abs().max()
