@@ -254,7 +254,8 @@ int ns_ngp_adam(float* master, void* half_params, float* grad, float* m1, float*
 /* occupancy-grid ray marching: bits = ncasc cascades of G^3 bits; rays_o/rays_d [R,3] (unit dirs),
  * t_range [R,2].  counter[3] (zeroed by the caller) receives (#samples requested by all rays,
  * #rays that received samples, end of the last reserved range = number of samples to process: a
- * ray whose range would cross max_samples gets none, which can leave a hole before max_samples);
+ * ray whose range would cross max_samples is refused: ray_n = -1, it contributes neither samples
+ * nor loss; the accepted ranges tile [0, counter[2]) without holes);
  * ray_start/ray_n [R]; pos/dirs [max_samples,3]; dt/tmid [max_samples].                          */
 int ns_ngp_march(const uint8_t* bits, int G, int ncasc, const float* rays_o, const float* rays_d,
                  const float* t_range, int R, float cone, float min_step, float max_step, int max_per_ray,

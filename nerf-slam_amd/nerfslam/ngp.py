@@ -35,7 +35,8 @@ class NgpConfig:
     max_steps_per_ray: int = 1024
     cone_angle: float = 1.0 / 256.0
     # training
-    n_rays: int = 4096
+    n_rays: int = 4096                   # initial rays per batch; adapted to fill max_samples
+    max_rays: int = 1 << 16
     max_samples: int = 1 << 18
     lr: float = 1e-2
     beta1: float = 0.9
@@ -110,6 +111,8 @@ class NgpNerf:
         self.dact = [torch.empty((u, S), **h) for u in (16, 64, 64, 16, 64)]    # d5T d4T d3T ddT d1T
         self.partial = torch.zeros((c.wgrad_ksplit, MLP_TOTAL), **f)
         self.counter = torch.zeros(3, dtype=torch.int32, device=dev)
+        self.rays_per_batch = c.n_rays
+        self.samples_requested = 0
 
     # ------------------------------------------------------------------------------------------
     def _grid_args(self):
@@ -185,13 +188,16 @@ class NgpNerf:
         c, dev = self.cfg, self.device
         with torch.cuda.device(dev):
             n, H, W = self.images.shape[:3]
-            R = c.n_rays
+            R = self.rays_per_batch
             idx = torch.randint(0, n, (R,), device=dev, generator=self.gen)
             u = torch.randint(0, W, (R,), device=dev, generator=self.gen)
             v = torch.randint(0, H, (R,), device=dev, generator=self.gen)
             o, d = self._rays(idx, u.float(), v.float())
             tr = self._t_range(o, d)
             N = self.march(o, d, tr)
+            # keep the sample budget filled without refusing rays (instant-ngp adapts its rays per batch likewise)
+            want = R * 0.9 * c.max_samples / max(self.samples_requested, 1)
+            self.rays_per_batch = int(min(max(want, 256), c.max_rays)) // 128 * 128
             if N == 0:
                 self.step += 1
                 return 0.0
@@ -236,7 +242,7 @@ class NgpNerf:
                                         C.c_float(l2), C.c_float(c.loss_scale), stream_ptr()), "ngp_adam")
             if self.step % c.grid_update_every == 0:
                 self.update_density_grid()
-            self.loss_tensor = loss / R
+            self.loss_tensor = loss / (self.ray_n >= 0).sum().clamp(min=1)
             self.last_samples, self.last_rays = N, R
         return self.loss_tensor
 

@@ -255,7 +255,7 @@ void orc_ngp_composite_loss(const uint16_t* rgb_raw, const uint16_t* dens_raw, c
       l += depth_lambda * diff * diff / gt_depth_cov[r];
       dD = depth_lambda * 2.0f * diff / gt_depth_cov[r];
     }
-    total += l;
+    if (n >= 0) total += l; /* n < 0: ray refused by the marcher (batch full), not part of the batch */
     out_rgb[r * 3 + 0] = C[0]; out_rgb[r * 3 + 1] = C[1]; out_rgb[r * 3 + 2] = C[2];
     out_depth[r] = D;
     /* backward: d/d(rgb_k) = wgt_k * dC ; d/d(sigma_k) = dt_k * (T_k*(1-alpha_k) * (dC.rgb_k + dD*t_k) - suffix_k) */

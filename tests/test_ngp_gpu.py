@@ -116,12 +116,15 @@ def test_composite_loss_and_adam(oracle_mod, dev):
     R = 300
     ray_n = rng.integers(0, 40, R).astype(np.int32)
     ray_start = np.concatenate([[0], np.cumsum(ray_n)[:-1]]).astype(np.int32)
-    S = int(ray_n.sum())
+    ray_n[[5, 77, 200]] = -1          # rays refused by the marcher: no samples, no loss
+    S = int(np.maximum(ray_n, 0).sum()) + 3 * 40
     net = np.zeros((S, 4), np.float16)
     net[:, :3] = rng.standard_normal((S, 3))
     net[:, 3] = rng.uniform(-2, 3, S)
     dt = rng.uniform(0.002, 0.02, S).astype(np.float32)
-    tm = np.concatenate([np.sort(rng.uniform(0.1, 4, n)) for n in ray_n]).astype(np.float32) if S else np.zeros(0, np.float32)
+    tm = rng.uniform(0.1, 4, S).astype(np.float32)
+    for s0, n in zip(ray_start, ray_n):
+        tm[s0:s0 + max(n, 0)].sort()
     gt_rgb = rng.uniform(0, 1, (R, 3)).astype(np.float32)
     gt_d = rng.uniform(0.5, 3, R).astype(np.float32)
     gt_d[::3] = -1
@@ -131,7 +134,7 @@ def test_composite_loss_and_adam(oracle_mod, dev):
     orgb, odep, loss, dr, dd = oracle_mod.ngp_composite_loss(rgb16, den16, dt, tm, ray_start, ray_n, gt_rgb, gt_d, gt_c,
                                                             1.0, 128.0)
     out_rgb = torch.empty((R, 3), device=dev); out_d = torch.empty(R, device=dev)
-    l = torch.zeros(1, device=dev); dout = torch.empty((S, 4), dtype=torch.float16, device=dev)
+    l = torch.zeros(1, device=dev); dout = torch.zeros((S, 4), dtype=torch.float16, device=dev)
     keep = [T(x, dev) for x in (net, dt, tm, ray_start, ray_n, gt_rgb, gt_d, gt_c)]
     check(lib().ns_ngp_composite(ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]),
                                  ptr(keep[4]), R, ptr(keep[5]), ptr(keep[6]), ptr(keep[7]),
@@ -200,6 +203,7 @@ def test_ray_marching(oracle_mod, dev):
                              ptr(rn2), ptr(keep[4]), ptr(keep[5]), ptr(keep[6]), ptr(keep[7]), stream_ptr()), "march")
     rs2, rn2, c2 = rs2.cpu().numpy(), rn2.cpu().numpy(), cnt2.tolist()
     acc = rn2 > 0
+    assert (rn2 == -1).any() and (rn2 >= -1).all()
     assert c2[0] == total and c2[1] == acc.sum() and 0 < c2[2] <= S2
     order = np.argsort(rs2[acc])
     st, ln = rs2[acc][order], rn2[acc][order]
