@@ -227,9 +227,15 @@ int ns_ngp_grid_layout(int n_levels, int n_features, int log2_hashmap, int base_
 int ns_ngp_encode_forward(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
                           const float* positions, const void* params, void* out, long N, void* stream);
 
-/* grad_params f32 [entries*2] += trilinear weights * dLdout [N, n_levels*2] f16 (atomic scatter) */
+/* grad_params f32 [entries*2] += trilinear weights * dLdout [N, n_levels*2] f16 (atomic scatter).
+ * workspace: NULL, or ns_ngp_encode_backward_workspace_bytes(...) bytes, ZERO-FILLED once by the caller
+ * (left zeroed by every call): private accumulation tables for the coarse levels, where all samples of a
+ * scene hit a few hundred entries and same-address atomics would serialise.                           */
+long ns_ngp_encode_backward_workspace_bytes(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                            float per_level_scale);
 int ns_ngp_encode_backward(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
-                           const float* positions, const void* dLdout, float* grad_params, long N, void* stream);
+                           const float* positions, const void* dLdout, float* grad_params, float* workspace, long N,
+                           void* stream);
 
 /* density MLP 32->64->16 + colour MLP (16 + SH16)->64->64->16, f16 weights packed row-major
  * [W1 64x32 | W2 16x64 | W3 64x32 | W4 64x64 | W5 16x64]; out [N,4] f16 = (r,g,b raw, log-density).

@@ -36,6 +36,7 @@ def lib():
                 L.ns_arch.restype = C.c_char_p
                 for name in [n for n in ("ns_ba_plan_index_count", "ns_ba_workspace_bytes") if hasattr(L, n)]:
                     getattr(L, name).restype = C.c_size_t
+                L.ns_ngp_encode_backward_workspace_bytes.restype = C.c_long
                 _lib = L
     return _lib
 

@@ -111,6 +111,8 @@ class NgpNerf:
         self.dact = [torch.empty((u, S), **h) for u in (16, 64, 64, 16, 64)]    # d5T d4T d3T ddT d1T
         self.partial = torch.zeros((c.wgrad_ksplit, MLP_TOTAL), **f)
         self.counter = torch.zeros(3, dtype=torch.int32, device=dev)
+        ws_bytes = lib().ns_ngp_encode_backward_workspace_bytes(*self._grid_args())
+        self.enc_ws = torch.zeros(max(ws_bytes // 4, 1), **f)   # replicated coarse-level gradient tables (kept zeroed)
         self.rays_per_batch = c.n_rays
         self.samples_requested = 0
 
@@ -232,7 +234,7 @@ class NgpNerf:
                                             c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(N8), stream_ptr()),
                   "ngp_mlp_backward")
             check(lib().ns_ngp_encode_backward(*self._grid_args(), ptr(pos_unit), ptr(self.s_dfeat),
-                                               ptr(self.grid_grad), C.c_long(N8), stream_ptr()), "ngp_encode_backward")
+                                               ptr(self.grid_grad), ptr(self.enc_ws), C.c_long(N8), stream_ptr()), "ngp_encode_backward")
             # optimiser
             self.step += 1
             for (m, hp, g, m1, m2, l2) in ((self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0),

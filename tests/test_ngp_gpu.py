@@ -49,7 +49,13 @@ def test_hash_encode_forward_backward(oracle_mod, dev, which):
     dL[rng.uniform(size=N) < 0.3] = 0
     grad = torch.zeros(n_par, dtype=torch.float32, device=dev)
     d_dL = T(dL, dev)
-    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dL), ptr(grad), C.c_long(N), stream_ptr()), "bwd")
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dL), ptr(grad), None, C.c_long(N), stream_ptr()), "bwd")
+    # same through the replicated coarse-level tables (workspace must come back zeroed)
+    ws = torch.zeros(lib().ns_ngp_encode_backward_workspace_bytes(*args) // 4, device=dev)
+    grad_ws = torch.zeros_like(grad)
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dL), ptr(grad_ws), ptr(ws), C.c_long(N), stream_ptr()), "bwd")
+    assert ws.numel() > 0 and not ws.any()
+    assert (grad_ws - grad).abs().max().item() <= 1e-5 * grad.abs().max().item()
     gref = oracle_mod.ngp_encode_bwd(cfg, pos, dL, n_par)
     # f32 atomics in arbitrary order: 1e-5 of max
     assert np.abs(grad.cpu().numpy() - gref).max() <= 1e-5 * np.abs(gref).max()

@@ -11,7 +11,7 @@ pos = np.array([[0.3, 0.6, 0.2]], np.float32)
 dL = np.array([[1.0, 2.0, 3.0, 4.0]], np.float16)
 args = (2, 2, 14, 4, C.c_float(2.0))
 grad = torch.zeros(n_par, dtype=torch.float32, device="cuda")
-check(lib().ns_ngp_encode_backward(*args, ptr(torch.from_numpy(pos).cuda()), ptr(torch.from_numpy(dL).cuda()), ptr(grad), C.c_long(1), stream_ptr()), "bwd")
+check(lib().ns_ngp_encode_backward(*args, ptr(torch.from_numpy(pos).cuda()), ptr(torch.from_numpy(dL).cuda()), ptr(grad), None, C.c_long(1), stream_ptr()), "bwd")
 g = grad.cpu().numpy(); r = oracle.ngp_encode_bwd(cfg, pos, dL, n_par)
 print("res", res, "off", off)
 print("dev nz", [(i, float(g[i])) for i in np.nonzero(g)[0]])
