@@ -223,33 +223,37 @@ int ns_ba_depth_cov(const float* Linv, const float* Q, const float* E, const ns_
 int ns_ngp_grid_layout(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
                        float* scale_host, int* res_host, uint32_t* offset_host);
 
-/* multiresolution hash encoding: positions [N,3] f32, params f16 [entries*2] -> out [N, n_levels*2] f16 */
+/* multiresolution hash encoding: positions [N,3] f32, params f16 [entries*2] -> out f16,
+ * [N, n_levels*2] (unit_major = 0) or [n_levels*2, N] (unit_major = 1: every store of a wave is one
+ * contiguous 128-byte run, and the layout the MLP kernels consume)                                 */
 int ns_ngp_encode_forward(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
-                          const float* positions, const void* params, void* out, long N, void* stream);
+                          const float* positions, const void* params, void* out, int unit_major, long N, void* stream);
 
-/* grad_params f32 [entries*2] += trilinear weights * dLdout [N, n_levels*2] f16 (atomic scatter).
+/* grad_params f32 [entries*2] += trilinear weights * dLdout f16 ([N, n_levels*2], or [n_levels*2, N] with
+ * unit_major = 1) (atomic scatter).
  * workspace: NULL, or ns_ngp_encode_backward_workspace_bytes(...) bytes, ZERO-FILLED once by the caller
  * (left zeroed by every call): private accumulation tables for the coarse levels, where all samples of a
  * scene hit a few hundred entries and same-address atomics would serialise.                           */
 long ns_ngp_encode_backward_workspace_bytes(int n_levels, int n_features, int log2_hashmap, int base_res,
                                             float per_level_scale);
 int ns_ngp_encode_backward(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
-                           const float* positions, const void* dLdout, float* grad_params, float* workspace, long N,
-                           void* stream);
+                           const float* positions, const void* dLdout, int unit_major, float* grad_params,
+                           float* workspace, long N, void* stream);
 
 /* density MLP 32->64->16 + colour MLP (16 + SH16)->64->64->16, f16 weights packed row-major
- * [W1 64x32 | W2 16x64 | W3 64x32 | W4 64x64 | W5 16x64]; out [N,4] f16 = (r,g,b raw, log-density).
- * Training: pass the five unit-major activation buffers (featT [32,N], h1T [64,N], cinT [32,N],
- * h3T, h4T [64,N]); inference: all NULL.                                                        */
-int ns_ngp_mlp_forward(const void* weights, const void* feat, const float* dirs, void* out, void* featT, void* h1T,
-                       void* cinT, void* h3T, void* h4T, long N, void* stream);
+ * [W1 64x32 | W2 16x64 | W3 64x32 | W4 64x64 | W5 16x64]; featT [32,N] f16 UNIT-MAJOR (what
+ * ns_ngp_encode_forward writes with unit_major = 1); out [N,4] f16 = (r,g,b raw, log-density).
+ * Training: pass the four unit-major activation buffers (h1T [64,N], cinT [32,N], h3T, h4T [64,N]);
+ * inference: all NULL.  N must be even.  (MFMA register chain, csrc/ngp_mlp.hip.)                 */
+int ns_ngp_mlp_forward(const void* weights, const void* featT, const float* dirs, void* out, void* h1T, void* cinT,
+                       void* h3T, void* h4T, long N, void* stream);
 
-/* backward of the MLP pair: weightsT = the same five matrices TRANSPOSED ([in][out]) in the same
- * packing; dLdout [N,4] f16; writes dLdfeat [N,32] f16 and ADDS the f32 weight gradients
+/* backward of the MLP pair: weights as in the forward; dLdout [N,4] f16; writes dLdfeatT [32,N] f16
+ * (unit-major, read by ns_ngp_encode_backward with unit_major = 1) and ADDS the f32 weight gradients
  * (MFMA split-K GEMMs) into grad_weights[10240].  d5T [16,N], d4T/d3T/d1T [64,N], ddT [16,N] and
  * partial_ws [ksplit*10240] f32 are scratch.  N must be a multiple of 8.                          */
-int ns_ngp_mlp_backward(const void* weightsT, const void* dLdout, const void* featT, const void* h1T,
-                        const void* cinT, const void* h3T, const void* h4T, void* dLdfeat, void* d5T, void* d4T,
+int ns_ngp_mlp_backward(const void* weights, const void* dLdout, const void* featT, const void* h1T,
+                        const void* cinT, const void* h3T, const void* h4T, void* dLdfeatT, void* d5T, void* d4T,
                         void* d3T, void* ddT, void* d1T, float* partial_ws, int ksplit, float* grad_weights, long N,
                         void* stream);
 

@@ -97,7 +97,7 @@ typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 // coarse (dense, small) levels stay in L1/L2 and only the hashed fine levels go to HBM.
 __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const float* __restrict__ pos,
                                                              const h2_t* __restrict__ params,
-                                                             h2_t* __restrict__ out, long N, int L) {
+                                                             h2_t* __restrict__ out, long N, int L, int unit_major) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
   const int l = blockIdx.y;
@@ -128,8 +128,14 @@ __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const
     a0 = fmaf(wt, (float)v[corner][0], a0);
     a1 = fmaf(wt, (float)v[corner][1], a1);
   }
-  h2_t o = {(_Float16)a0, (_Float16)a1};
-  out[i * L + l] = o;
+  if (unit_major) {  // [2L][N]: 128 contiguous bytes per wave and feature
+    _Float16* o = reinterpret_cast<_Float16*>(out);
+    o[(long)(2 * l) * N + i] = (_Float16)a0;
+    o[(long)(2 * l + 1) * N + i] = (_Float16)a1;
+  } else {
+    h2_t o = {(_Float16)a0, (_Float16)a1};
+    out[i * L + l] = o;
+  }
 }
 
 // Backward of the encode: scatter-add of the 8 trilinear corner contributions per (sample, level).
@@ -142,15 +148,21 @@ __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const
 __global__ __launch_bounds__(256) void ngp_encode_bwd_kernel(GridLayout g, const float* __restrict__ pos,
                                                              const h2_t* __restrict__ dLdout,
                                                              float* __restrict__ grad, long N, int L, int level0,
-                                                             ReplicaPlan rp, float* __restrict__ ws) {
+                                                             ReplicaPlan rp, float* __restrict__ ws, int unit_major) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int l = blockIdx.y + level0;
   float d0 = 0.0f, d1 = 0.0f;
   if (i < N) {
-    const h2_t d = dLdout[i * L + l];
-    d0 = (float)d[0];
-    d1 = (float)d[1];
+    if (unit_major) {
+      const _Float16* dp = reinterpret_cast<const _Float16*>(dLdout);
+      d0 = (float)dp[(long)(2 * l) * N + i];
+      d1 = (float)dp[(long)(2 * l + 1) * N + i];
+    } else {
+      const h2_t d = dLdout[i * L + l];
+      d0 = (float)d[0];
+      d1 = (float)d[1];
+    }
   }
   const bool valid = d0 != 0.0f || d1 != 0.0f;
   const uint32_t hs = g.offset[l + 1] - g.offset[l];
@@ -528,7 +540,7 @@ extern "C" int ns_ngp_grid_layout(int n_levels, int n_features, int log2_hashmap
 
 extern "C" int ns_ngp_encode_forward(int n_levels, int n_features, int log2_hashmap, int base_res,
                                      float per_level_scale, const float* positions, const void* params, void* out,
-                                     long N, void* stream) {
+                                     int unit_major, long N, void* stream) {
   NS_REQUIRE(positions && params && out, "ns_ngp_encode_forward: null pointer");
   GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
   GridLayout g;
@@ -538,7 +550,7 @@ extern "C" int ns_ngp_encode_forward(int n_levels, int n_features, int log2_hash
   }
   if (N <= 0) return NS_OK;
   hipLaunchKernelGGL(ngp_encode_fwd_kernel, dim3(ns_cdiv(N, 256), n_levels), dim3(256), 0, (hipStream_t)stream, g,
-                     positions, (const h2_t*)params, (h2_t*)out, N, n_levels);
+                     positions, (const h2_t*)params, (h2_t*)out, N, n_levels, unit_major);
   NS_CHECK_LAUNCH("ngp_encode_fwd_kernel");
   return NS_OK;
 }
@@ -576,7 +588,7 @@ extern "C" long ns_ngp_encode_backward_workspace_bytes(int n_levels, int n_featu
 
 extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_hashmap, int base_res,
                                       float per_level_scale, const float* positions, const void* dLdout,
-                                      float* grad_params, float* workspace, long N, void* stream) {
+                                      int unit_major, float* grad_params, float* workspace, long N, void* stream) {
   NS_REQUIRE(positions && dLdout && grad_params, "ns_ngp_encode_backward: null pointer");
   GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
   GridLayout g;
@@ -591,10 +603,10 @@ extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_has
   if (per_level) {
     for (int l = 0; l < n_levels; l++)
       hipLaunchKernelGGL(ngp_encode_bwd_kernel, dim3(ns_cdiv(N, 256), 1), dim3(256), 0, (hipStream_t)stream, g,
-                         positions, (const h2_t*)dLdout, grad_params, N, n_levels, l, rp, workspace);
+                         positions, (const h2_t*)dLdout, grad_params, N, n_levels, l, rp, workspace, unit_major);
   } else {
     hipLaunchKernelGGL(ngp_encode_bwd_kernel, dim3(ns_cdiv(N, 256), n_levels), dim3(256), 0, (hipStream_t)stream, g,
-                       positions, (const h2_t*)dLdout, grad_params, N, n_levels, 0, rp, workspace);
+                       positions, (const h2_t*)dLdout, grad_params, N, n_levels, 0, rp, workspace, unit_major);
   }
   NS_CHECK_LAUNCH("ngp_encode_bwd_kernel");
   if (workspace != nullptr && rp.total_floats > 0) {

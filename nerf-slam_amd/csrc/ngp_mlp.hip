@@ -43,46 +43,99 @@ __device__ __forceinline__ void sh16(float x, float y, float z, float* o) {
   o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
 }
 
-// y[o] = f16( sum_k W[o][k] x[k] ), optional ReLU; W in LDS (wave-uniform address -> broadcast).
-template <int NIN, int NOUT, bool RELU>
-__device__ __forceinline__ void dense(const _Float16* __restrict__ W, const _Float16* x, _Float16* y) {
-#pragma unroll 4
-  for (int o = 0; o < NOUT; o++) {
-    float acc = 0.0f;
+// ---------------------------------------------------------------------------------------------
+// MFMA register chain.
+//
+// Every layer is computed TRANSPOSED: H^T[unit][sample] = W[unit][k] * X^T[k][sample] with
+// v_mfma_f32_32x32x16_f16 (A = 32 weight rows x 16 k, B = 16 k x 32 samples).  The accumulator layout of
+// that instruction gives lane (j = lane & 31, h = lane >> 5) the 16 units {4h + (r & 3) + 8 (r >> 2)} of
+// sample j -- and the B operand of the next layer wants, per 16-wide k chunk, 8 k values of sample j from
+// each half-wave.  A matrix product does not care in which order k is summed, so the k order of every
+// chunk is DEFINED as "what the accumulator already holds": chunk 0 of a 32-unit tile = registers r 0..7
+// (units 4h..4h+3, 8+4h..8+4h+3), chunk 1 = r 8..15; the weight fragments are gathered into LDS in that
+// same order once per workgroup.  A layer's output becomes the next layer's input by ReLU + cvt_f16 in
+// place: no LDS round trip, no shuffles, no transposes between the five layers.
+//
+// A wave handles 64 samples per iteration as two column tiles: tile 0 = even samples, tile 1 = odd ones, so
+// lane j owns samples (2j, 2j+1) and every unit-major load / store is one dword per lane = 128 contiguous
+// bytes per half-wave.  The kernels are HBM-bound on the saved activations (forward ~0.5 KB, backward
+// ~0.9 KB per sample); the 40 MFMAs per 32 samples are a few microseconds per 2^18 samples.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+#define MLP_ITERS 2  // 64-sample iterations per wave
+
+// fragment tables: (weight offset, rows of A, columns of A (= K), first fragment); A = W (forward) or W^T (backward)
+// forward : L1 W1[64][32]  L2 W2[16][64]  L3 W3[64][32]  L4 W4[64][64]  L5 W5[16][64]
+#define FW_L1 0
+#define FW_L2 4
+#define FW_L3 8
+#define FW_L4 12
+#define FW_L5 20
+#define FW_NFRAG 24
+// backward: L5^T [64][16]  L4^T [64][64]  L3^T [32][64]  L2^T [64][16]  L1^T [32][64]
+#define BW_L5 0
+#define BW_L4 2
+#define BW_L3 10
+#define BW_L2 14
+#define BW_L1 16
+#define BW_NFRAG 20
+
+// k (column of A) that lane half h supplies as element q of chunk cc
+__device__ __forceinline__ int frag_k(int cc, int h, int q) { return 16 * cc + 4 * h + (q & 3) + 8 * (q >> 2); }
+// unit (row of D) that lane half h holds in accumulator register r of row tile it
+__device__ __forceinline__ int acc_unit(int it, int h, int r) { return 32 * it + 4 * h + (r & 3) + 8 * (r >> 2); }
+
+// gather the fragments of one layer into LDS: frag (it, cc) -> Wf[(first + it * nchunk + cc) * 64 + lane]
+template <bool TRANSPOSED>
+__device__ __forceinline__ void fill_frags(f16x8* Wf, const _Float16* __restrict__ W, int woff, int nout, int nin,
+                                           int first) {
+  const int rows = TRANSPOSED ? nin : nout, cols = TRANSPOSED ? nout : nin;  // of A
+  const int ntile = (rows + 31) / 32, nchunk = cols / 16;
+  for (int e = threadIdx.x; e < ntile * nchunk * 64; e += 256) {
+    const int lane = e & 63, f = e >> 6, it = f / nchunk, cc = f % nchunk;
+    const int row = 32 * it + (lane & 31), h = lane >> 5;
+    f16x8 v;
 #pragma unroll
-    for (int k = 0; k < NIN; k += 8) {
-      const f16x8 w = *reinterpret_cast<const f16x8*>(W + o * NIN + k);
-#pragma unroll
-      for (int q = 0; q < 8; q++) acc = fmaf((float)w[q], (float)x[k + q], acc);
+    for (int q = 0; q < 8; q++) {
+      const int k = frag_k(cc, h, q);
+      v[q] = row < rows ? (TRANSPOSED ? W[woff + k * nin + row] : W[woff + row * nin + k]) : (_Float16)0;
     }
-    if (RELU) acc = fmaxf(acc, 0.0f);
-    y[o] = (_Float16)acc;
+    Wf[(first + f) * 64 + lane] = v;
   }
 }
 
-// dx[k] = f16( sum_o W[o][k] dy[o] ) with the transposed copy WT[k][o] in LDS
-template <int NIN, int NOUT>
-__device__ __forceinline__ void dense_t(const _Float16* __restrict__ WT, const _Float16* dy, _Float16* dx) {
-#pragma unroll 4
-  for (int k = 0; k < NIN; k++) {
-    float acc = 0.0f;
+// one row tile of one layer: acc = sum over chunks A(it, cc) * B(cc)
+template <int NCHUNK>
+__device__ __forceinline__ f32x16 layer_tile(const f16x8* Wf, int first, int it, int lane, const f16x8* bin) {
+  f32x16 acc = (f32x16)0.0f;
 #pragma unroll
-    for (int o = 0; o < NOUT; o += 8) {
-      const f16x8 w = *reinterpret_cast<const f16x8*>(WT + k * NOUT + o);
+  for (int cc = 0; cc < NCHUNK; cc++)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[(first + it * NCHUNK + cc) * 64 + lane], bin[cc], acc, 0, 0, 0);
+  return acc;
+}
+
+__device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
+  const f16x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ f16x2 unpack2(uint32_t w) { return __builtin_bit_cast(f16x2, w); }
+
+// store the 16 (tile 0, tile 1) pairs of one 32-unit tile unit-major: row acc_unit(it, h, r), samples np, np + 1
+__device__ __forceinline__ void store_tile(_Float16* __restrict__ dst, long N, long np, int it, int h, const f16x8* t0,
+                                           const f16x8* t1) {  // t0/t1: chunks [2 it], [2 it + 1] of tile 0 / 1
 #pragma unroll
-      for (int q = 0; q < 8; q++) acc = fmaf((float)w[q], (float)dy[o + q], acc);
-    }
-    dx[k] = (_Float16)acc;
-  }
+  for (int r = 0; r < 16; r++)
+    *reinterpret_cast<uint32_t*>(dst + (long)acc_unit(it, h, r) * N + np) = pack2(t0[r >> 3][r & 7], t1[r >> 3][r & 7]);
 }
 
 struct MlpFwdArgs {
   const _Float16* W;      // packed weights
-  const _Float16* feat;   // [N,32]
+  const _Float16* featT;  // [32,N] unit-major encoding
   const float* dirs;      // [N,3]
   _Float16* out;          // [N,4] (r,g,b raw, log-density)
   // unit-major activations for the backward pass (all null in inference)
-  _Float16* featT;        // [32,N]
   _Float16* h1T;          // [64,N]
   _Float16* cinT;         // [32,N]
   _Float16* h3T;          // [64,N]
@@ -91,111 +144,200 @@ struct MlpFwdArgs {
 };
 
 __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) _Float16 Ws[W_TOTAL];
-  for (int i = threadIdx.x; i < W_TOTAL / 8; i += 256)
-    reinterpret_cast<f16x8*>(Ws)[i] = reinterpret_cast<const f16x8*>(a.W)[i];
+  __shared__ f16x8 Wf[FW_NFRAG * 64];
+  fill_frags<false>(Wf, a.W, W1_OFF, 64, 32, FW_L1);
+  fill_frags<false>(Wf, a.W, W2_OFF, 16, 64, FW_L2);
+  fill_frags<false>(Wf, a.W, W3_OFF, 64, 32, FW_L3);
+  fill_frags<false>(Wf, a.W, W4_OFF, 64, 64, FW_L4);
+  fill_frags<false>(Wf, a.W, W5_OFF, 16, 64, FW_L5);
   __syncthreads();
-  const long n = (long)blockIdx.x * 256 + threadIdx.x;
-  if (n >= a.N) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   const long N = a.N;
   const bool save = a.h1T != nullptr;
-  _Float16 x[32], h[64], g[64];
+  for (int iter = 0; iter < MLP_ITERS; iter++) {
+    const long n0 = (((long)blockIdx.x * MLP_ITERS + iter) * 4 + wave) * 64;
+    if (n0 >= N) return;  // wave-uniform
+    const bool ok = n0 + 2 * j < N;  // N is even: the pair (np, np + 1) is valid or not as a whole
+    const long np = ok ? n0 + 2 * j : 0;
+    const long nq = np;
+    // input: 2 chunks x 8 units, both tiles in one dword
+    f16x8 x[2][2];  // [tile][chunk]
 #pragma unroll
-  for (int k = 0; k < 32; k += 8) {
-    const f16x8 v = *reinterpret_cast<const f16x8*>(a.feat + n * 32 + k);
+    for (int cc = 0; cc < 2; cc++)
 #pragma unroll
-    for (int q = 0; q < 8; q++) x[k + q] = v[q];
+      for (int q = 0; q < 8; q++) {
+        const f16x2 v = unpack2(*reinterpret_cast<const uint32_t*>(a.featT + (long)frag_k(cc, h, q) * N + nq));
+        x[0][cc][q] = ok ? v[0] : (_Float16)0;
+        x[1][cc][q] = ok ? v[1] : (_Float16)0;
+      }
+    // layer-major over both sample tiles: an activation is stored as soon as it exists and dies after the next layer
+    const bool st = save && ok;
+    _Float16 res[2][4];
+    f16x8 h1[2][4], cin[2][2];
+#pragma unroll
+    for (int it = 0; it < 2; it++) {  // L1 32 -> 64, ReLU
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const f32x16 acc = layer_tile<2>(Wf, FW_L1, it, lane, x[t]);
+#pragma unroll
+        for (int r = 0; r < 16; r++) h1[t][2 * it + (r >> 3)][r & 7] = (_Float16)fmaxf(acc[r], 0.0f);
+      }
+      if (st) store_tile(a.h1T, N, np, it, h, &h1[0][2 * it], &h1[1][2 * it]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {  // L2 64 -> 16 (rows 16..31 of the tile are padding) + direction encoding
+      const f32x16 acc = layer_tile<4>(Wf, FW_L2, 0, lane, h1[t]);
+#pragma unroll
+      for (int r = 0; r < 8; r++) cin[t][0][r] = (_Float16)acc[r];
+      res[t][3] = cin[t][0][0];  // log-density = unit 0 (held by h == 0)
+      float sh[16];
+      const long ns = ok ? np + t : 0;
+      sh16(a.dirs[ns * 3], a.dirs[ns * 3 + 1], a.dirs[ns * 3 + 2], sh);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int lo = (q & 3) + 8 * (q >> 2);  // SH index for h == 0; h == 1 adds 4
+        cin[t][1][q] = (_Float16)(h ? sh[lo + 4] : sh[lo]);
+      }
+    }
+    if (st) store_tile(a.cinT, N, np, 0, h, cin[0], cin[1]);
+    f16x8 h3[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; it++) {  // L3 32 -> 64, ReLU
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const f32x16 acc = layer_tile<2>(Wf, FW_L3, it, lane, cin[t]);
+#pragma unroll
+        for (int r = 0; r < 16; r++) h3[t][2 * it + (r >> 3)][r & 7] = (_Float16)fmaxf(acc[r], 0.0f);
+      }
+      if (st) store_tile(a.h3T, N, np, it, h, &h3[0][2 * it], &h3[1][2 * it]);
+    }
+    f16x8 h4[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; it++) {  // L4 64 -> 64, ReLU
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const f32x16 acc = layer_tile<4>(Wf, FW_L4, it, lane, h3[t]);
+#pragma unroll
+        for (int r = 0; r < 16; r++) h4[t][2 * it + (r >> 3)][r & 7] = (_Float16)fmaxf(acc[r], 0.0f);
+      }
+      if (st) store_tile(a.h4T, N, np, it, h, &h4[0][2 * it], &h4[1][2 * it]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {  // L5 64 -> 16
+      const f32x16 acc = layer_tile<4>(Wf, FW_L5, 0, lane, h4[t]);
+      res[t][0] = (_Float16)acc[0];
+      res[t][1] = (_Float16)acc[1];
+      res[t][2] = (_Float16)acc[2];
+    }
+    if (ok && h == 0) {
+      const f16x8 o = {res[0][0], res[0][1], res[0][2], res[0][3], res[1][0], res[1][1], res[1][2], res[1][3]};
+      *reinterpret_cast<f16x8*>(a.out + np * 4) = o;
+    }
   }
-  if (save)
-#pragma unroll
-    for (int k = 0; k < 32; k++) a.featT[(long)k * N + n] = x[k];
-  dense<32, 64, true>(Ws + W1_OFF, x, h);
-  if (save)
-#pragma unroll
-    for (int k = 0; k < 64; k++) a.h1T[(long)k * N + n] = h[k];
-  _Float16 cin[32];
-  dense<64, 16, false>(Ws + W2_OFF, h, cin);
-  const _Float16 logdens = cin[0];
-  float sh[16];
-  sh16(a.dirs[n * 3], a.dirs[n * 3 + 1], a.dirs[n * 3 + 2], sh);
-#pragma unroll
-  for (int k = 0; k < 16; k++) cin[16 + k] = (_Float16)sh[k];
-  if (save)
-#pragma unroll
-    for (int k = 0; k < 32; k++) a.cinT[(long)k * N + n] = cin[k];
-  dense<32, 64, true>(Ws + W3_OFF, cin, h);
-  if (save)
-#pragma unroll
-    for (int k = 0; k < 64; k++) a.h3T[(long)k * N + n] = h[k];
-  dense<64, 64, true>(Ws + W4_OFF, h, g);
-  if (save)
-#pragma unroll
-    for (int k = 0; k < 64; k++) a.h4T[(long)k * N + n] = g[k];
-  _Float16 rgb[16];
-  dense<64, 16, false>(Ws + W5_OFF, g, rgb);
-  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  const f16x4 o = {rgb[0], rgb[1], rgb[2], logdens};
-  *reinterpret_cast<f16x4*>(a.out + n * 4) = o;
 }
 
 struct MlpBwdArgs {
-  const _Float16* WT;     // packed TRANSPOSED weights: W1T[32,64] W2T[64,16] W3T[32,64] W4T[64,64] W5T[64,16]
+  const _Float16* W;      // packed weights (natural [out][in]; the transposed fragments are gathered in-kernel)
   const _Float16* dLdout; // [N,4]
   const _Float16 *h1T, *h3T, *h4T;  // saved activations (ReLU masks)
-  _Float16* dLdfeat;      // [N,32]
+  _Float16* dLdfeatT;     // [32,N] unit-major
   _Float16 *d5T, *d4T, *d3T, *ddT, *d1T;  // [16,N] [64,N] [64,N] [16,N] [64,N] unit-major output gradients
   long N;
 };
 
+// dy = relu'(h) * f16(acc) for one 32-unit tile of both sample tiles; returns the B chunks and stores unit-major
+__device__ __forceinline__ void mask_tile(const f32x16& acc0, const f32x16& acc1, const _Float16* __restrict__ hT,
+                                          _Float16* __restrict__ dT, long N, long np, bool ok, int it, int h,
+                                          f16x8* o0, f16x8* o1) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const long off = (long)acc_unit(it, h, r) * N + np;
+    const f16x2 act = unpack2(*reinterpret_cast<const uint32_t*>(hT + off));
+    const _Float16 v0 = (float)act[0] > 0.0f ? (_Float16)acc0[r] : (_Float16)0;
+    const _Float16 v1 = (float)act[1] > 0.0f ? (_Float16)acc1[r] : (_Float16)0;
+    o0[r >> 3][r & 7] = v0;
+    o1[r >> 3][r & 7] = v1;
+    if (ok) *reinterpret_cast<uint32_t*>(dT + off) = pack2(v0, v1);
+  }
+}
+
 __global__ __launch_bounds__(256) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) _Float16 Ws[W_TOTAL];
-  for (int i = threadIdx.x; i < W_TOTAL / 8; i += 256)
-    reinterpret_cast<f16x8*>(Ws)[i] = reinterpret_cast<const f16x8*>(a.WT)[i];
+  __shared__ f16x8 Wf[BW_NFRAG * 64];
+  fill_frags<true>(Wf, a.W, W5_OFF, 16, 64, BW_L5);
+  fill_frags<true>(Wf, a.W, W4_OFF, 64, 64, BW_L4);
+  fill_frags<true>(Wf, a.W, W3_OFF, 64, 32, BW_L3);
+  fill_frags<true>(Wf, a.W, W2_OFF, 16, 64, BW_L2);
+  fill_frags<true>(Wf, a.W, W1_OFF, 64, 32, BW_L1);
   __syncthreads();
-  const long n = (long)blockIdx.x * 256 + threadIdx.x;
-  if (n >= a.N) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   const long N = a.N;
-  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  const f16x4 go = *reinterpret_cast<const f16x4*>(a.dLdout + n * 4);
-  _Float16 dy[64], dx[64];
-  // layer 5 (no activation): dY5 = (dr, dg, db, 0, ...)
+  for (int iter = 0; iter < MLP_ITERS; iter++) {
+    const long n0 = (((long)blockIdx.x * MLP_ITERS + iter) * 4 + wave) * 64;
+    if (n0 >= N) return;
+    // every lane runs every MFMA (lane i also supplies row i of A): out-of-range pairs read pair 0 and store nothing
+    const bool ok = n0 + 2 * j < N;
+    const long np = ok ? n0 + 2 * j : 0;
+    const f16x8 go = *reinterpret_cast<const f16x8*>(a.dLdout + np * 4);  // (r,g,b,d) of samples np, np + 1
+    // dY5: units 0..2 = colour gradients (held by h == 0, q = 0..2), rest zero
+    f16x8 d5[2];
 #pragma unroll
-  for (int k = 0; k < 16; k++) dy[k] = (k < 3) ? go[k] : (_Float16)0;
+    for (int t = 0; t < 2; t++) {
+      d5[t] = (f16x8)(_Float16)0;
+      if (h == 0) {
+        d5[t][0] = go[4 * t];
+        d5[t][1] = go[4 * t + 1];
+        d5[t][2] = go[4 * t + 2];
+      }
+    }
 #pragma unroll
-  for (int k = 0; k < 16; k++) a.d5T[(long)k * N + n] = dy[k];
-  dense_t<64, 16>(Ws + W5_OFF, dy, dx);  // W5T [64][16]
+    for (int q = 0; q < 8; q++)
+      if (ok) *reinterpret_cast<uint32_t*>(a.d5T + (long)frag_k(0, h, q) * N + np) = pack2(d5[0][q], d5[1][q]);
+    // layer 5^T (K = 16) -> d(h4), ReLU' of layer 4
+    f16x8 d4[2][4], d3[2][4], dd[2], d1[2][4];
 #pragma unroll
-  for (int k = 0; k < 64; k++) {  // ReLU' of layer 4
-    dy[k] = ((float)a.h4T[(long)k * N + n] > 0.0f) ? dx[k] : (_Float16)0;
-    a.d4T[(long)k * N + n] = dy[k];
-  }
-  dense_t<64, 64>(Ws + W4_OFF, dy, dx);  // W4T [64][64]
+    for (int it = 0; it < 2; it++) {
+      const f32x16 a0 = layer_tile<1>(Wf, BW_L5, it, lane, &d5[0]);
+      const f32x16 a1 = layer_tile<1>(Wf, BW_L5, it, lane, &d5[1]);
+      mask_tile(a0, a1, a.h4T, a.d4T, N, np, ok, it, h, &d4[0][2 * it], &d4[1][2 * it]);
+    }
 #pragma unroll
-  for (int k = 0; k < 64; k++) {  // ReLU' of layer 3
-    dy[k] = ((float)a.h3T[(long)k * N + n] > 0.0f) ? dx[k] : (_Float16)0;
-    a.d3T[(long)k * N + n] = dy[k];
-  }
-  dense_t<32, 64>(Ws + W3_OFF, dy, dx);  // W3T [32][64] -> d(cin); only the density half flows further
+    for (int it = 0; it < 2; it++) {
+      const f32x16 a0 = layer_tile<4>(Wf, BW_L4, it, lane, d4[0]);
+      const f32x16 a1 = layer_tile<4>(Wf, BW_L4, it, lane, d4[1]);
+      mask_tile(a0, a1, a.h3T, a.d3T, N, np, ok, it, h, &d3[0][2 * it], &d3[1][2 * it]);
+    }
+    // layer 3^T -> d(cin); only the density half (units 0..15 = registers 0..7) flows on; the density gradient joins unit 0
+    {
+      const f32x16 a0 = layer_tile<4>(Wf, BW_L3, 0, lane, d3[0]);
+      const f32x16 a1 = layer_tile<4>(Wf, BW_L3, 0, lane, d3[1]);
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    float v = (float)dx[k];
-    if (k == 0) v += (float)go[3];
-    dy[k] = (_Float16)v;
-    a.ddT[(long)k * N + n] = dy[k];
-  }
-  dense_t<64, 16>(Ws + W2_OFF, dy, dx);  // W2T [64][16]
+      for (int r = 0; r < 8; r++) {
+        dd[0][r] = (_Float16)a0[r];
+        dd[1][r] = (_Float16)a1[r];
+      }
+      if (h == 0) {
+        dd[0][0] = (_Float16)((float)dd[0][0] + (float)go[3]);
+        dd[1][0] = (_Float16)((float)dd[1][0] + (float)go[7]);
+      }
 #pragma unroll
-  for (int k = 0; k < 64; k++) {  // ReLU' of layer 1
-    dy[k] = ((float)a.h1T[(long)k * N + n] > 0.0f) ? dx[k] : (_Float16)0;
-    a.d1T[(long)k * N + n] = dy[k];
-  }
-  dense_t<32, 64>(Ws + W1_OFF, dy, dx);  // W1T [32][64]
+      for (int q = 0; q < 8; q++)
+        if (ok) *reinterpret_cast<uint32_t*>(a.ddT + (long)frag_k(0, h, q) * N + np) = pack2(dd[0][q], dd[1][q]);
+    }
 #pragma unroll
-  for (int k = 0; k < 32; k += 8) {
-    f16x8 o;
+    for (int it = 0; it < 2; it++) {
+      const f32x16 a0 = layer_tile<1>(Wf, BW_L2, it, lane, &dd[0]);
+      const f32x16 a1 = layer_tile<1>(Wf, BW_L2, it, lane, &dd[1]);
+      mask_tile(a0, a1, a.h1T, a.d1T, N, np, ok, it, h, &d1[0][2 * it], &d1[1][2 * it]);
+    }
+    {
+      const f32x16 a0 = layer_tile<4>(Wf, BW_L1, 0, lane, d1[0]);
+      const f32x16 a1 = layer_tile<4>(Wf, BW_L1, 0, lane, d1[1]);
 #pragma unroll
-    for (int q = 0; q < 8; q++) o[q] = dx[k + q];
-    *reinterpret_cast<f16x8*>(a.dLdfeat + n * 32 + k) = o;
+      for (int r = 0; r < 16; r++)
+        if (ok)
+          *reinterpret_cast<uint32_t*>(a.dLdfeatT + (long)acc_unit(0, h, r) * N + np) =
+              pack2((_Float16)a0[r], (_Float16)a1[r]);
+    }
   }
 }
 
@@ -287,34 +429,35 @@ __global__ __launch_bounds__(256) void ngp_mlp_wgrad_reduce_kernel(const float* 
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
-extern "C" int ns_ngp_mlp_forward(const void* weights, const void* feat, const float* dirs, void* out, void* featT,
-                                  void* h1T, void* cinT, void* h3T, void* h4T, long N, void* stream) {
-  NS_REQUIRE(weights && feat && dirs && out, "ns_ngp_mlp_forward: null pointer");
-  NS_REQUIRE((h1T == nullptr) == (featT == nullptr) && (h1T == nullptr) == (cinT == nullptr) &&
-                 (h1T == nullptr) == (h3T == nullptr) && (h1T == nullptr) == (h4T == nullptr),
+extern "C" int ns_ngp_mlp_forward(const void* weights, const void* featT, const float* dirs, void* out, void* h1T,
+                                  void* cinT, void* h3T, void* h4T, long N, void* stream) {
+  NS_REQUIRE(weights && featT && dirs && out, "ns_ngp_mlp_forward: null pointer");
+  NS_REQUIRE((h1T == nullptr) == (cinT == nullptr) && (h1T == nullptr) == (h3T == nullptr) &&
+                 (h1T == nullptr) == (h4T == nullptr),
              "ns_ngp_mlp_forward: pass all activation buffers (training) or none (inference)");
+  NS_REQUIRE(N % 2 == 0, "ns_ngp_mlp_forward: N must be even (a lane owns two adjacent samples)");
   if (N <= 0) return NS_OK;
-  MlpFwdArgs a{(const _Float16*)weights, (const _Float16*)feat, dirs, (_Float16*)out, (_Float16*)featT,
-               (_Float16*)h1T, (_Float16*)cinT, (_Float16*)h3T, (_Float16*)h4T, N};
-  hipLaunchKernelGGL(ngp_mlp_fwd_kernel, dim3(ns_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  MlpFwdArgs a{(const _Float16*)weights, (const _Float16*)featT, dirs, (_Float16*)out, (_Float16*)h1T,
+               (_Float16*)cinT, (_Float16*)h3T, (_Float16*)h4T, N};
+  hipLaunchKernelGGL(ngp_mlp_fwd_kernel, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, (hipStream_t)stream, a);
   NS_CHECK_LAUNCH("ngp_mlp_fwd_kernel");
   return NS_OK;
 }
 
-extern "C" int ns_ngp_mlp_backward(const void* weightsT, const void* dLdout, const void* featT, const void* h1T,
-                                   const void* cinT, const void* h3T, const void* h4T, void* dLdfeat, void* d5T,
+extern "C" int ns_ngp_mlp_backward(const void* weights, const void* dLdout, const void* featT, const void* h1T,
+                                   const void* cinT, const void* h3T, const void* h4T, void* dLdfeatT, void* d5T,
                                    void* d4T, void* d3T, void* ddT, void* d1T, float* partial_ws, int ksplit,
                                    float* grad_weights, long N, void* stream) {
-  NS_REQUIRE(weightsT && dLdout && featT && h1T && cinT && h3T && h4T && dLdfeat && d5T && d4T && d3T && ddT && d1T &&
+  NS_REQUIRE(weights && dLdout && featT && h1T && cinT && h3T && h4T && dLdfeatT && d5T && d4T && d3T && ddT && d1T &&
                  partial_ws && grad_weights,
              "ns_ngp_mlp_backward: null pointer");
   NS_REQUIRE(ksplit >= 1 && N % 8 == 0, "ns_ngp_mlp_backward: ksplit >= 1 and N a multiple of 8 are required");
   if (N <= 0) return NS_OK;
   hipStream_t st = (hipStream_t)stream;
-  MlpBwdArgs b{(const _Float16*)weightsT, (const _Float16*)dLdout, (const _Float16*)h1T, (const _Float16*)h3T,
-               (const _Float16*)h4T,      (_Float16*)dLdfeat,      (_Float16*)d5T,       (_Float16*)d4T,
-               (_Float16*)d3T,            (_Float16*)ddT,          (_Float16*)d1T,       N};
-  hipLaunchKernelGGL(ngp_mlp_bwd_kernel, dim3(ns_cdiv(N, 256)), dim3(256), 0, st, b);
+  MlpBwdArgs b{(const _Float16*)weights, (const _Float16*)dLdout, (const _Float16*)h1T, (const _Float16*)h3T,
+               (const _Float16*)h4T,     (_Float16*)dLdfeatT,     (_Float16*)d5T,       (_Float16*)d4T,
+               (_Float16*)d3T,           (_Float16*)ddT,          (_Float16*)d1T,       N};
+  hipLaunchKernelGGL(ngp_mlp_bwd_kernel, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, st, b);
   NS_CHECK_LAUNCH("ngp_mlp_bwd_kernel");
   WgradArgs w;
   w.layer[0] = WgradLayer{(const _Float16*)d1T, (const _Float16*)featT, 64, 32, W1_OFF};

@@ -107,7 +107,7 @@ class NgpNerf:
         self.s_dt, self.s_t = torch.empty(S, **f), torch.empty(S, **f)
         self.s_feat, self.s_out, self.s_dout = torch.empty((S, 32), **h), torch.empty((S, 4), **h), torch.empty((S, 4), **h)
         self.s_dfeat = torch.empty((S, 32), **h)
-        self.act = [torch.empty((u, S), **h) for u in (32, 64, 32, 64, 64)]     # featT h1T cinT h3T h4T
+        self.act = [torch.empty((u, S), **h) for u in (64, 32, 64, 64)]         # h1T cinT h3T h4T
         self.dact = [torch.empty((u, S), **h) for u in (16, 64, 64, 16, 64)]    # d5T d4T d3T ddT d1T
         self.partial = torch.zeros((c.wgrad_ksplit, MLP_TOTAL), **f)
         self.counter = torch.zeros(3, dtype=torch.int32, device=dev)
@@ -121,21 +121,16 @@ class NgpNerf:
         c = self.cfg
         return (c.n_levels, 2, c.log2_hashmap, c.base_res, C.c_float(c.per_level_scale))
 
-    def _mlp_weights_T(self):
-        parts = []
-        for (o, i), off in zip(MLP_SHAPES, MLP_OFFS):
-            parts.append(self.mlp_half[off:off + o * i].view(o, i).t().contiguous().view(-1))
-        return torch.cat(parts)
-
     def to_unit(self, pos):
         """NGP scene coordinates -> [0,1]^3 over the render box [0.5 - s/2, 0.5 + s/2]^3."""
         s = float(self.cfg.aabb_scale)
         return ((pos - (0.5 - 0.5 * s)) / s).contiguous()
 
     def encode(self, pos_unit, out=None):
+        """-> features UNIT-MAJOR [32, N] f16 (the layout the MLP kernels read); `out`: flat scratch to write into."""
         N = pos_unit.shape[0]
-        out = out if out is not None else torch.empty((N, 32), dtype=torch.float16, device=self.device)
-        check(lib().ns_ngp_encode_forward(*self._grid_args(), ptr(pos_unit), ptr(self.grid_half), ptr(out), C.c_long(N),
+        out = out.view(-1)[:32 * N].view(32, N) if out is not None else torch.empty((32, N), dtype=torch.float16, device=self.device)
+        check(lib().ns_ngp_encode_forward(*self._grid_args(), ptr(pos_unit), ptr(self.grid_half), ptr(out), 1, C.c_long(N),
                                           stream_ptr()), "ngp_encode_forward")
         return out
 
@@ -214,10 +209,11 @@ class NgpNerf:
             gt_depth = self.depths[idx, v, u].contiguous()
             gt_cov = self.depth_covs[idx, v, u].clamp(min=1e-6).contiguous()
             # forward
-            self.encode(pos_unit, self.s_feat)
+            featT = self.encode(pos_unit, self.s_feat)
             acts = [a.view(-1)[:a.shape[0] * N8].view(a.shape[0], N8) for a in self.act]
             dacts = [a.view(-1)[:a.shape[0] * N8].view(a.shape[0], N8) for a in self.dact]
-            check(lib().ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(self.s_feat), ptr(self.s_dir), ptr(self.s_out),
+            dfeatT = self.s_dfeat.view(-1)[:32 * N8].view(32, N8)
+            check(lib().ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(featT), ptr(self.s_dir), ptr(self.s_out),
                                            *[ptr(a) for a in acts], C.c_long(N8), stream_ptr()), "ngp_mlp_forward")
             out_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
             out_depth = torch.empty(R, dtype=torch.float32, device=dev)
@@ -229,11 +225,11 @@ class NgpNerf:
                                          C.c_float(c.depth_lambda), C.c_float(c.loss_scale), ptr(out_rgb),
                                          ptr(out_depth), ptr(loss), ptr(self.s_dout), stream_ptr()), "ngp_composite")
             # backward
-            check(lib().ns_ngp_mlp_backward(ptr(self._mlp_weights_T()), ptr(self.s_dout), *[ptr(a) for a in acts],
-                                            ptr(self.s_dfeat), *[ptr(a) for a in dacts], ptr(self.partial),
+            check(lib().ns_ngp_mlp_backward(ptr(self.mlp_half), ptr(self.s_dout), ptr(featT), *[ptr(a) for a in acts],
+                                            ptr(dfeatT), *[ptr(a) for a in dacts], ptr(self.partial),
                                             c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(N8), stream_ptr()),
                   "ngp_mlp_backward")
-            check(lib().ns_ngp_encode_backward(*self._grid_args(), ptr(pos_unit), ptr(self.s_dfeat),
+            check(lib().ns_ngp_encode_backward(*self._grid_args(), ptr(pos_unit), ptr(dfeatT), 1,
                                                ptr(self.grid_grad), ptr(self.enc_ws), C.c_long(N8), stream_ptr()), "ngp_encode_backward")
             # optimiser
             self.step += 1
@@ -252,11 +248,13 @@ class NgpNerf:
     def density_at(self, pos_scene):
         """sigma at scene positions [N,3] (encode + density half of the network)."""
         N = pos_scene.shape[0]
+        if N % 2:  # a lane of the MLP kernel owns two adjacent samples
+            return self.density_at(torch.cat([pos_scene, pos_scene[-1:]], 0))[:N]
         out = torch.empty((N, 4), dtype=torch.float16, device=self.device)
         feat = self.encode(self.to_unit(pos_scene))
         dirs = torch.zeros((N, 3), dtype=torch.float32, device=self.device)
         nul = C.c_void_p(0)
-        check(lib().ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(feat), ptr(dirs), ptr(out), nul, nul, nul, nul, nul,
+        check(lib().ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(feat), ptr(dirs), ptr(out), nul, nul, nul, nul,
                                        C.c_long(N), stream_ptr()), "ngp_mlp_forward")
         return out[:, 3].float().exp()
 
@@ -308,9 +306,12 @@ class NgpNerf:
                 orgb = torch.zeros((R, 3), dtype=torch.float32, device=dev)
                 odep = torch.zeros(R, dtype=torch.float32, device=dev)
                 if N > 0:
-                    self.encode(self.to_unit(self.s_pos[:N]), self.s_feat)
-                    check(lib().ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(self.s_feat), ptr(self.s_dir), ptr(self.s_out),
-                                                   nul, nul, nul, nul, nul, C.c_long(N), stream_ptr()), "ngp_mlp_forward")
+                    Ne = N + (N & 1)
+                    if Ne > N:
+                        self.s_pos[N:Ne], self.s_dir[N:Ne] = 0.5, 0.0
+                    featT = self.encode(self.to_unit(self.s_pos[:Ne]), self.s_feat)
+                    check(lib().ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(featT), ptr(self.s_dir), ptr(self.s_out),
+                                                   nul, nul, nul, nul, C.c_long(Ne), stream_ptr()), "ngp_mlp_forward")
                     check(lib().ns_ngp_composite(ptr(self.s_out), ptr(self.s_dt), ptr(self.s_t), ptr(self.ray_start),
                                                  ptr(self.ray_n), R, nul, nul, nul, C.c_float(0), C.c_float(1), ptr(orgb),
                                                  ptr(odep), nul, nul, stream_ptr()), "ngp_composite")

@@ -39,21 +39,25 @@ def test_hash_encode_forward_backward(oracle_mod, dev, which):
     assert list(o2) == list(off) and list(r2) == list(res)
     out = torch.empty((N, 2 * L), dtype=torch.float16, device=dev)
     d_pos, d_par = T(pos, dev), T(params, dev)  # keep alive: ptr() of a temporary would dangle
-    check(lib().ns_ngp_encode_forward(*args, ptr(d_pos), ptr(d_par), ptr(out), C.c_long(N), stream_ptr()), "fwd")
+    check(lib().ns_ngp_encode_forward(*args, ptr(d_pos), ptr(d_par), ptr(out), 0, C.c_long(N), stream_ptr()), "fwd")
+    outT = torch.empty((2 * L, N), dtype=torch.float16, device=dev)
+    check(lib().ns_ngp_encode_forward(*args, ptr(d_pos), ptr(d_par), ptr(outT), 1, C.c_long(N), stream_ptr()), "fwd")
+    assert torch.equal(outT.t().contiguous(), out)   # unit-major variant: same values, transposed
     ref = oracle_mod.ngp_encode_fwd(cfg, pos, params)
     got = out.cpu().numpy()
-    # f32 trilinear blend of 8 f16 values, one rounding: bit-exact up to FMA order -> 1 half-ulp
-    assert np.abs(got.astype(np.float32) - ref.astype(np.float32)).max() <= 2.0 ** -11 * np.abs(ref).max() + 1e-7
+    # f32 trilinear blend of 8 f16 values, one rounding: bit-exact up to FMA order -> at most one f16 ulp (2^-10 relative)
+    assert np.abs(got.astype(np.float32) - ref.astype(np.float32)).max() <= 2.0 ** -10 * np.abs(ref).max() + 1e-7
     assert (got.view(np.uint16) == ref.view(np.uint16)).mean() > 0.995
     dL = (rng.standard_normal((N, 2 * L)) * 1e-2).astype(np.float16)
     dL[rng.uniform(size=N) < 0.3] = 0
     grad = torch.zeros(n_par, dtype=torch.float32, device=dev)
     d_dL = T(dL, dev)
-    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dL), ptr(grad), None, C.c_long(N), stream_ptr()), "bwd")
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dL), 0, ptr(grad), None, C.c_long(N), stream_ptr()), "bwd")
     # same through the replicated coarse-level tables (workspace must come back zeroed)
     ws = torch.zeros(lib().ns_ngp_encode_backward_workspace_bytes(*args) // 4, device=dev)
     grad_ws = torch.zeros_like(grad)
-    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dL), ptr(grad_ws), ptr(ws), C.c_long(N), stream_ptr()), "bwd")
+    d_dLT = d_dL.t().contiguous()
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(grad_ws), ptr(ws), C.c_long(N), stream_ptr()), "bwd")
     assert ws.numel() > 0 and not ws.any()
     assert (grad_ws - grad).abs().max().item() <= 1e-5 * grad.abs().max().item()
     gref = oracle_mod.ngp_encode_bwd(cfg, pos, dL, n_par)
@@ -77,10 +81,15 @@ def test_mlp_forward_backward(oracle_mod, dev):
     act = oracle_mod.ngp_mlp_fwd(Ws, feat, dirs)
     Wd = T(np.concatenate([w.reshape(-1) for w in Ws]), dev)
     out = torch.empty((N, 4), dtype=torch.float16, device=dev)
-    bufs = [torch.empty((u, N), dtype=torch.float16, device=dev) for u in (32, 64, 32, 64, 64)]
-    d_feat, d_dirs = T(feat, dev), T(dirs, dev)
-    check(lib().ns_ngp_mlp_forward(ptr(Wd), ptr(d_feat), ptr(d_dirs), ptr(out), *[ptr(b) for b in bufs],
+    d_featT, d_dirs = T(np.ascontiguousarray(feat.T), dev), T(dirs, dev)
+    bufs = [d_featT] + [torch.empty((u, N), dtype=torch.float16, device=dev) for u in (64, 32, 64, 64)]
+    check(lib().ns_ngp_mlp_forward(ptr(Wd), ptr(d_featT), ptr(d_dirs), ptr(out), *[ptr(b) for b in bufs[1:]],
                                    C.c_long(N), stream_ptr()), "mlp fwd")
+    out_inf = torch.empty_like(out)   # inference mode (no activation buffers): same outputs
+    nul = C.c_void_p(0)
+    check(lib().ns_ngp_mlp_forward(ptr(Wd), ptr(d_featT), ptr(d_dirs), ptr(out_inf), nul, nul, nul, nul, C.c_long(N),
+                                   stream_ptr()), "mlp fwd")
+    assert torch.equal(out_inf, out)
     o = out.cpu().numpy().astype(np.float32)
     ref = np.concatenate([act["rgb"][:, :3], act["dens"][:, :1]], 1).astype(np.float32)
     # same f16 storage / f32 accumulation as the oracle, different accumulation order: a few half-ulps of the
@@ -96,17 +105,16 @@ def test_mlp_forward_backward(oracle_mod, dev):
     dLddens = np.zeros((N, 16), np.float16)
     dLddens[:, 0] = dout[:, 3]
     dfeat_ref, dW_ref = oracle_mod.ngp_mlp_bwd(Ws, feat, act, dLdrgb, dLddens)
-    WT = T(np.concatenate([w.T.copy().reshape(-1) for w in Ws]), dev)
-    dfeat = torch.empty((N, 32), dtype=torch.float16, device=dev)
+    dfeat = torch.empty((32, N), dtype=torch.float16, device=dev)
     dbufs = [torch.empty((u, N), dtype=torch.float16, device=dev) for u in (16, 64, 64, 16, 64)]
     ks = 7
     partial = torch.empty((ks, 10240), dtype=torch.float32, device=dev)
     gw = torch.zeros(10240, dtype=torch.float32, device=dev)
     d_dout = T(dout, dev)
-    check(lib().ns_ngp_mlp_backward(ptr(WT), ptr(d_dout), *[ptr(b) for b in bufs], ptr(dfeat),
+    check(lib().ns_ngp_mlp_backward(ptr(Wd), ptr(d_dout), *[ptr(b) for b in bufs], ptr(dfeat),
                                     *[ptr(b) for b in dbufs], ptr(partial), ks, ptr(gw), C.c_long(N), stream_ptr()),
           "mlp bwd")
-    d = dfeat.cpu().numpy().astype(np.float32)
+    d = dfeat.t().cpu().numpy().astype(np.float32)
     assert np.abs(d - dfeat_ref.astype(np.float32)).max() <= 1e-2 * np.abs(dfeat_ref.astype(np.float32)).max()
     g = gw.cpu().numpy()
     off = 0
