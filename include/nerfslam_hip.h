@@ -261,15 +261,25 @@ int ns_ngp_mlp_backward(const void* weights, const void* dLdout, const void* fea
 int ns_ngp_adam(float* master, void* half_params, float* grad, float* m1, float* m2, long n, int step, float lr,
                 float beta1, float beta2, float eps, float l2, float grad_scale, void* stream);
 
+/* training rays: ray r picks image / column / row = pcg(seed + 3r + {0,1,2}) mod {n_images, W, H}
+ * (pcg = the 32-bit PCG output hash, csrc/ngp.hip:ns_pcg), direction = normalised c2w[:, :3] ((u + .5 - cx)/fx,
+ * (v + .5 - cy)/fy, 1), origin = c2w[:, 3], t_range = slab test against [box_lo, box_hi]^3 clamped to `near`, and the
+ * pixel's supervision (images [n,H,W,4] linear rgba, depths / depth_covs [n,H,W]; covariance floored at 1e-6). */
+int ns_ngp_sample_rays(const float* images, const float* depths, const float* depth_covs, const float* c2w,
+                       int n_images, int H, int W, float fx, float fy, float cx, float cy, float box_lo, float box_hi,
+                       float near, unsigned seed, int R, float* rays_o, float* rays_d, float* t_range, float* gt_rgb,
+                       float* gt_depth, float* gt_depth_cov, void* stream);
+
 /* occupancy-grid ray marching: bits = ncasc cascades of G^3 bits; rays_o/rays_d [R,3] (unit dirs),
  * t_range [R,2].  counter[3] (zeroed by the caller) receives (#samples requested by all rays,
  * #rays that received samples, end of the last reserved range = number of samples to process: a
  * ray whose range would cross max_samples is refused: ray_n = -1, it contributes neither samples
  * nor loss; the accepted ranges tile [0, counter[2]) without holes);
- * ray_start/ray_n [R]; pos/dirs [max_samples,3]; dt/tmid [max_samples].                          */
+ * ray_start/ray_n [R]; pos/dirs [max_samples,3]; dt/tmid [max_samples].  Positions are written as
+ * (p - pos_lo) * pos_inv (pass 0, 1 for scene coordinates; the trainer asks for unit-cube coordinates). */
 int ns_ngp_march(const uint8_t* bits, int G, int ncasc, const float* rays_o, const float* rays_d,
-                 const float* t_range, int R, float cone, float min_step, float max_step, int max_per_ray,
-                 long max_samples, int* counter, int* ray_start, int* ray_n, float* pos, float* dirs, float* dt,
+                 const float* t_range, int R, float cone, float min_step, float max_step, float pos_lo,
+                 float pos_inv, int max_per_ray, long max_samples, int* counter, int* ray_start, int* ray_n, float* pos, float* dirs, float* dt,
                  float* tmid, void* stream);
 
 /* volume rendering; with dLdout != NULL also the loss (rgb L2 + depth_lambda * (d - gt)^2 / cov,

@@ -250,6 +250,70 @@ __global__ __launch_bounds__(256) void ngp_adam_kernel(float* __restrict__ maste
 }
 
 // ---------------------------------------------------------------------------------------------
+// Training-ray sampling: one lane per ray picks (image, pixel) with a counter-based hash of (seed, ray),
+// builds the ray from the camera-to-world matrix, clips it against the render box and gathers the
+// supervision (linear rgb, depth, depth covariance) of that pixel.  Replaces ~20 small torch launches per
+// training step (randint x3, index gathers, einsum, normalisation, slab test).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t ns_pcg(uint32_t v) {
+  const uint32_t state = v * 747796405u + 2891336453u;
+  const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+  return (word >> 22u) ^ word;
+}
+
+struct SampleRaysArgs {
+  const float* images;  // [n,H,W,4]
+  const float* depths;  // [n,H,W]
+  const float* covs;    // [n,H,W]
+  const float* c2w;     // [n,3,4]
+  float fx, fy, cx, cy, box_lo, box_hi, near;
+  int n, H, W, R;
+  uint32_t seed;
+  float *rays_o, *rays_d, *t_range, *gt_rgb, *gt_depth, *gt_cov;
+};
+
+__global__ __launch_bounds__(256) void ngp_sample_rays_kernel(SampleRaysArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.R) return;
+  const uint32_t base = a.seed + (uint32_t)r * 3u;
+  const int img = (int)(ns_pcg(base) % (uint32_t)a.n);
+  const int u = (int)(ns_pcg(base + 1u) % (uint32_t)a.W);
+  const int v = (int)(ns_pcg(base + 2u) % (uint32_t)a.H);
+  const float* M = a.c2w + (long)img * 12;
+  const float dcx = ((float)u + 0.5f - a.cx) / a.fx, dcy = ((float)v + 0.5f - a.cy) / a.fy;
+  float d[3], o[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    d[k] = M[k * 4] * dcx + M[k * 4 + 1] * dcy + M[k * 4 + 2];
+    o[k] = M[k * 4 + 3];
+  }
+  const float inv_n = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    d[k] *= inv_n;
+    const float inv = 1.0f / (fabsf(d[k]) < 1e-9f ? 1e-9f : d[k]);
+    const float t0 = (a.box_lo - o[k]) * inv, t1 = (a.box_hi - o[k]) * inv;
+    tmin = fmaxf(tmin, fminf(t0, t1));
+    tmax = fminf(tmax, fmaxf(t0, t1));
+  }
+  tmin = fmaxf(tmin, a.near);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    a.rays_o[r * 3 + k] = o[k];
+    a.rays_d[r * 3 + k] = d[k];
+  }
+  a.t_range[r * 2] = tmin;
+  a.t_range[r * 2 + 1] = fmaxf(tmax, tmin);
+  const long pix = ((long)img * a.H + v) * a.W + u;
+  a.gt_rgb[r * 3] = a.images[pix * 4];
+  a.gt_rgb[r * 3 + 1] = a.images[pix * 4 + 1];
+  a.gt_rgb[r * 3 + 2] = a.images[pix * 4 + 2];
+  a.gt_depth[r] = a.depths[pix];
+  a.gt_cov[r] = fmaxf(a.covs[pix], 1e-6f);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Occupancy grid: `ncasc` cascades of G^3 bits; cascade m covers [0.5 - 2^(m-1), 0.5 + 2^(m-1)]^3.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int mip_of(float x, float y, float z, float dt, int G, int ncasc) {
@@ -278,6 +342,7 @@ struct MarchArgs {
   const float* rays_d;   // [R,3] unit
   const float* t_range;  // [R,2] entry / exit distance of the ray through the render box
   float cone, min_step, max_step;
+  float pos_lo, pos_inv;  // written positions = (p - pos_lo) * pos_inv  (0, 1: scene coordinates)
   int G, ncasc, max_per_ray;
   long max_samples;
   int* counter;          // [3]: samples requested, rays with samples, end of the last reserved range (zeroed by the caller)
@@ -415,9 +480,9 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(MarchArgs a) {
       const float dt = march_dt(t, a);
       if ((m >> q) & 1) {
         const long s = (long)base + k;
-        a.pos[s * 3] = __fmaf_rn(t, ry.dx, ry.ox);
-        a.pos[s * 3 + 1] = __fmaf_rn(t, ry.dy, ry.oy);
-        a.pos[s * 3 + 2] = __fmaf_rn(t, ry.dz, ry.oz);
+        a.pos[s * 3] = (__fmaf_rn(t, ry.dx, ry.ox) - a.pos_lo) * a.pos_inv;
+        a.pos[s * 3 + 1] = (__fmaf_rn(t, ry.dy, ry.oy) - a.pos_lo) * a.pos_inv;
+        a.pos[s * 3 + 2] = (__fmaf_rn(t, ry.dz, ry.oz) - a.pos_lo) * a.pos_inv;
         a.dirs[s * 3] = ry.dx;
         a.dirs[s * 3 + 1] = ry.dy;
         a.dirs[s * 3 + 2] = ry.dz;
@@ -629,15 +694,31 @@ extern "C" int ns_ngp_adam(float* master, void* half_params, float* grad, float*
   return NS_OK;
 }
 
+extern "C" int ns_ngp_sample_rays(const float* images, const float* depths, const float* depth_covs, const float* c2w,
+                                  int n_images, int H, int W, float fx, float fy, float cx, float cy, float box_lo,
+                                  float box_hi, float near, unsigned seed, int R, float* rays_o, float* rays_d,
+                                  float* t_range, float* gt_rgb, float* gt_depth, float* gt_depth_cov, void* stream) {
+  NS_REQUIRE(images && depths && depth_covs && c2w && rays_o && rays_d && t_range && gt_rgb && gt_depth && gt_depth_cov,
+             "ns_ngp_sample_rays: null pointer");
+  NS_REQUIRE(n_images > 0 && H > 0 && W > 0 && fx != 0.0f && fy != 0.0f && box_hi > box_lo,
+             "ns_ngp_sample_rays: bad image set / intrinsics / box");
+  if (R <= 0) return NS_OK;
+  SampleRaysArgs a{images, depths, depth_covs, c2w, fx, fy, cx, cy, box_lo, box_hi, near, n_images, H, W, R, seed,
+                   rays_o, rays_d, t_range, gt_rgb, gt_depth, gt_depth_cov};
+  hipLaunchKernelGGL(ngp_sample_rays_kernel, dim3(ns_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  NS_CHECK_LAUNCH("ngp_sample_rays_kernel");
+  return NS_OK;
+}
+
 extern "C" int ns_ngp_march(const uint8_t* bits, int G, int ncasc, const float* rays_o, const float* rays_d,
-                            const float* t_range, int R, float cone, float min_step, float max_step, int max_per_ray,
-                            long max_samples, int* counter, int* ray_start, int* ray_n, float* pos, float* dirs,
+                            const float* t_range, int R, float cone, float min_step, float max_step, float pos_lo,
+                            float pos_inv, int max_per_ray, long max_samples, int* counter, int* ray_start, int* ray_n, float* pos, float* dirs,
                             float* dt, float* tmid, void* stream) {
   NS_REQUIRE(bits && rays_o && rays_d && t_range && counter && ray_start && ray_n && pos && dirs && dt && tmid,
              "ns_ngp_march: null pointer");
   NS_REQUIRE(G > 0 && ncasc >= 1 && ncasc <= 8 && min_step > 0.0f, "ns_ngp_march: bad grid");
   if (R <= 0) return NS_OK;
-  MarchArgs a{bits, rays_o, rays_d, t_range, cone, min_step, max_step, G, ncasc, max_per_ray, max_samples, counter,
+  MarchArgs a{bits, rays_o, rays_d, t_range, cone, min_step, max_step, pos_lo, pos_inv, G, ncasc, max_per_ray, max_samples, counter,
               ray_start, ray_n, pos, dirs, dt, tmid, R};
   hipLaunchKernelGGL(ngp_march_kernel, dim3(ns_cdiv(R, 16)), dim3(256), 0, (hipStream_t)stream, a);
   NS_CHECK_LAUNCH("ngp_march_kernel");

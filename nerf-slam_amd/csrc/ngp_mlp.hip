@@ -298,12 +298,14 @@ __global__ __launch_bounds__(256) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
     for (int it = 0; it < 2; it++) {
       const f32x16 a0 = layer_tile<1>(Wf, BW_L5, it, lane, &d5[0]);
       const f32x16 a1 = layer_tile<1>(Wf, BW_L5, it, lane, &d5[1]);
+      asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
       mask_tile(a0, a1, a.h4T, a.d4T, N, np, ok, it, h, &d4[0][2 * it], &d4[1][2 * it]);
     }
 #pragma unroll
     for (int it = 0; it < 2; it++) {
       const f32x16 a0 = layer_tile<4>(Wf, BW_L4, it, lane, d4[0]);
       const f32x16 a1 = layer_tile<4>(Wf, BW_L4, it, lane, d4[1]);
+      asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
       mask_tile(a0, a1, a.h3T, a.d3T, N, np, ok, it, h, &d3[0][2 * it], &d3[1][2 * it]);
     }
     // layer 3^T -> d(cin); only the density half (units 0..15 = registers 0..7) flows on; the density gradient joins unit 0
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(256) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
     for (int it = 0; it < 2; it++) {
       const f32x16 a0 = layer_tile<1>(Wf, BW_L2, it, lane, &dd[0]);
       const f32x16 a1 = layer_tile<1>(Wf, BW_L2, it, lane, &dd[1]);
+      asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
       mask_tile(a0, a1, a.h1T, a.d1T, N, np, ok, it, h, &d1[0][2 * it], &d1[1][2 * it]);
     }
     {

@@ -96,6 +96,7 @@ class NgpNerf:
         self.step = 0
         self.loss = float("nan")
         self.gen = torch.Generator(device=dev).manual_seed(seed)
+        self.seed = int(seed)
         # training views
         self.images = self.depths = self.depth_covs = self.c2w = None
         self.intr = None
@@ -163,15 +164,17 @@ class NgpNerf:
         tmax = torch.maximum(t0, t1).amin(-1)
         return torch.stack([tmin, torch.maximum(tmax, tmin)], -1).contiguous()
 
-    def march(self, o, d, tr):
+    def march(self, o, d, tr, unit=False):
         c = self.cfg
+        s = float(c.aabb_scale)
+        lo, inv = (0.5 - 0.5 * s, 1.0 / s) if unit else (0.0, 1.0)
         R = o.shape[0]
         self.counter.zero_()
         self.ray_start = torch.empty(R, dtype=torch.int32, device=self.device)
         self.ray_n = torch.empty(R, dtype=torch.int32, device=self.device)
         check(lib().ns_ngp_march(ptr(self.bits), c.grid_size, c.n_cascades, ptr(o), ptr(d), ptr(tr), R,
                                  C.c_float(c.cone_angle), C.c_float(c.min_step), C.c_float(c.max_step),
-                                 c.max_steps_per_ray, C.c_long(c.max_samples), ptr(self.counter), ptr(self.ray_start),
+                                 C.c_float(lo), C.c_float(inv), c.max_steps_per_ray, C.c_long(c.max_samples), ptr(self.counter), ptr(self.ray_start),
                                  ptr(self.ray_n), ptr(self.s_pos), ptr(self.s_dir), ptr(self.s_dt), ptr(self.s_t),
                                  stream_ptr()), "ngp_march")
         # the one host read-back of a step (instant-ngp reads its ray counter too): end of the reserved ranges
@@ -186,12 +189,18 @@ class NgpNerf:
         with torch.cuda.device(dev):
             n, H, W = self.images.shape[:3]
             R = self.rays_per_batch
-            idx = torch.randint(0, n, (R,), device=dev, generator=self.gen)
-            u = torch.randint(0, W, (R,), device=dev, generator=self.gen)
-            v = torch.randint(0, H, (R,), device=dev, generator=self.gen)
-            o, d = self._rays(idx, u.float(), v.float())
-            tr = self._t_range(o, d)
-            N = self.march(o, d, tr)
+            f = dict(dtype=torch.float32, device=dev)
+            o, d, tr = torch.empty((R, 3), **f), torch.empty((R, 3), **f), torch.empty((R, 2), **f)
+            gt_rgb, gt_depth, gt_cov = torch.empty((R, 3), **f), torch.empty(R, **f), torch.empty(R, **f)
+            s = float(c.aabb_scale)
+            fx, fy, cx, cy = self.intr
+            seed = (self.seed * 0x9E3779B1 + self.step * 0x85EBCA77) & 0xFFFFFFFF
+            check(lib().ns_ngp_sample_rays(ptr(self.images), ptr(self.depths), ptr(self.depth_covs), ptr(self.c2w), n, H, W,
+                                           C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                                           C.c_float(0.5 - 0.5 * s), C.c_float(0.5 + 0.5 * s), C.c_float(c.near),
+                                           C.c_uint32(seed), R, ptr(o), ptr(d), ptr(tr), ptr(gt_rgb), ptr(gt_depth),
+                                           ptr(gt_cov), stream_ptr()), "ngp_sample_rays")
+            N = self.march(o, d, tr, unit=True)   # positions come back in unit-cube coordinates
             # keep the sample budget filled without refusing rays (instant-ngp adapts its rays per batch likewise)
             want = R * 0.9 * c.max_samples / max(self.samples_requested, 1)
             self.rays_per_batch = int(min(max(want, 256), c.max_rays)) // 128 * 128
@@ -203,11 +212,7 @@ class NgpNerf:
                 self.s_pos[N:N8] = 0.5
                 self.s_dir[N:N8] = 0.0
                 self.s_dt[N:N8] = 0.0
-            pos_unit = self.to_unit(self.s_pos[:N8])
-            rgba = self.images[idx, v, u]
-            gt_rgb = rgba[:, :3].contiguous()
-            gt_depth = self.depths[idx, v, u].contiguous()
-            gt_cov = self.depth_covs[idx, v, u].clamp(min=1e-6).contiguous()
+            pos_unit = self.s_pos[:N8]
             # forward
             featT = self.encode(pos_unit, self.s_feat)
             acts = [a.view(-1)[:a.shape[0] * N8].view(a.shape[0], N8) for a in self.act]

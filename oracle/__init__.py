@@ -366,6 +366,19 @@ def ngp_march_ray(bits, G, ncasc, o, d, cone, min_step, max_step, t0, t1, max_n)
     return pos[:n], dts[:n], ts[:n]
 
 
+def ngp_sample_rays(images, depths, covs, c2w, intr, box_lo, box_hi, near, seed, R):
+    images, depths, covs, c2w = _f32(images), _f32(depths), _f32(covs), _f32(c2w)
+    n, H, W = depths.shape
+    out = dict(rays_o=np.zeros((R, 3), np.float32), rays_d=np.zeros((R, 3), np.float32), t_range=np.zeros((R, 2), np.float32),
+               gt_rgb=np.zeros((R, 3), np.float32), gt_depth=np.zeros(R, np.float32), gt_cov=np.zeros(R, np.float32),
+               picks=np.zeros((R, 3), np.int32))
+    fx, fy, cx, cy = (C.c_float(float(v)) for v in intr)
+    lib().orc_ngp_sample_rays(_p(images), _p(depths), _p(covs), _p(c2w), n, H, W, fx, fy, cx, cy, C.c_float(box_lo),
+                              C.c_float(box_hi), C.c_float(near), C.c_uint32(seed), R, *[_p(out[k]) for k in
+                              ("rays_o", "rays_d", "t_range", "gt_rgb", "gt_depth", "gt_cov", "picks")])
+    return out
+
+
 # --------------------------------------------------------------------------- float64 SE3 (numpy)
 def _qmul(a, b):
     ax, ay, az, aw = a

@@ -354,3 +354,45 @@ int orc_ngp_march_ray(const uint8_t* bits, int G, int ncasc, const float* o, con
   }
   return n;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* training-ray sampling (restates csrc/ngp.hip:ngp_sample_rays_kernel; the pixel choice is this project's */
+/* own: instant-ngp draws its training pixels from its own RNG stream)                                     */
+/* ------------------------------------------------------------------------------------------ */
+static uint32_t orc_pcg(uint32_t v) {
+  const uint32_t state = v * 747796405u + 2891336453u;
+  const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+  return (word >> 22u) ^ word;
+}
+
+void orc_ngp_sample_rays(const float* images, const float* depths, const float* covs, const float* c2w, int n, int H,
+                         int W, float fx, float fy, float cx, float cy, float box_lo, float box_hi, float near,
+                         uint32_t seed, int R, float* rays_o, float* rays_d, float* t_range, float* gt_rgb,
+                         float* gt_depth, float* gt_cov, int32_t* picks) {
+  for (int r = 0; r < R; r++) {
+    const uint32_t base = seed + (uint32_t)r * 3u;
+    const int img = (int)(orc_pcg(base) % (uint32_t)n), u = (int)(orc_pcg(base + 1u) % (uint32_t)W),
+              v = (int)(orc_pcg(base + 2u) % (uint32_t)H);
+    picks[r * 3] = img; picks[r * 3 + 1] = u; picks[r * 3 + 2] = v;
+    const float* M = c2w + (long)img * 12;
+    const float dcx = ((float)u + 0.5f - cx) / fx, dcy = ((float)v + 0.5f - cy) / fy;
+    float d[3], o[3];
+    for (int k = 0; k < 3; k++) { d[k] = M[k * 4] * dcx + M[k * 4 + 1] * dcy + M[k * 4 + 2]; o[k] = M[k * 4 + 3]; }
+    const float inv_n = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    float tmin = -INFINITY, tmax = INFINITY;
+    for (int k = 0; k < 3; k++) {
+      d[k] *= inv_n;
+      const float inv = 1.0f / (fabsf(d[k]) < 1e-9f ? 1e-9f : d[k]);
+      const float t0 = (box_lo - o[k]) * inv, t1 = (box_hi - o[k]) * inv;
+      tmin = fmaxf(tmin, fminf(t0, t1));
+      tmax = fminf(tmax, fmaxf(t0, t1));
+    }
+    tmin = fmaxf(tmin, near);
+    for (int k = 0; k < 3; k++) { rays_o[r * 3 + k] = o[k]; rays_d[r * 3 + k] = d[k]; }
+    t_range[r * 2] = tmin; t_range[r * 2 + 1] = fmaxf(tmax, tmin);
+    const long pix = ((long)img * H + v) * W + u;
+    for (int k = 0; k < 3; k++) gt_rgb[r * 3 + k] = images[pix * 4 + k];
+    gt_depth[r] = depths[pix];
+    gt_cov[r] = fmaxf(covs[pix], 1e-6f);
+  }
+}

@@ -194,7 +194,7 @@ def test_ray_marching(oracle_mod, dev):
     dt = torch.empty(S, device=dev); tm = torch.empty(S, device=dev)
     keep = [T(x, dev) for x in (bits, o, d, tr)] + [torch.empty_like(pos), torch.empty_like(dirs), torch.empty_like(dt), torch.empty_like(tm)]
     check(lib().ns_ngp_march(ptr(keep[0]), G, nc, ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), R,
-                             C.c_float(cone), C.c_float(mn), C.c_float(mx), 1024, C.c_long(S), ptr(cnt), ptr(rs),
+                             C.c_float(cone), C.c_float(mn), C.c_float(mx), C.c_float(0.0), C.c_float(1.0), 1024, C.c_long(S), ptr(cnt), ptr(rs),
                              ptr(rn), ptr(pos), ptr(dirs), ptr(dt), ptr(tm), stream_ptr()), "march")
     rs, rn, pos, dt, tm = (x.cpu().numpy() for x in (rs, rn, pos, dt, tm))
     total = 0
@@ -213,7 +213,7 @@ def test_ray_marching(oracle_mod, dev):
     cnt2 = torch.zeros(3, dtype=torch.int32, device=dev)
     rs2 = torch.empty(R, dtype=torch.int32, device=dev); rn2 = torch.empty(R, dtype=torch.int32, device=dev)
     check(lib().ns_ngp_march(ptr(keep[0]), G, nc, ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), R,
-                             C.c_float(cone), C.c_float(mn), C.c_float(mx), 1024, C.c_long(S2), ptr(cnt2), ptr(rs2),
+                             C.c_float(cone), C.c_float(mn), C.c_float(mx), C.c_float(-1.5), C.c_float(0.25), 1024, C.c_long(S2), ptr(cnt2), ptr(rs2),
                              ptr(rn2), ptr(keep[4]), ptr(keep[5]), ptr(keep[6]), ptr(keep[7]), stream_ptr()), "march")
     rs2, rn2, c2 = rs2.cpu().numpy(), rn2.cpu().numpy(), cnt2.tolist()
     acc = rn2 > 0
@@ -222,6 +222,41 @@ def test_ray_marching(oracle_mod, dev):
     order = np.argsort(rs2[acc])
     st, ln = rs2[acc][order], rn2[acc][order]
     assert st[0] == 0 and (st[1:] == st[:-1] + ln[:-1]).all() and st[-1] + ln[-1] == c2[2]
+    pos2 = keep[4].cpu().numpy()     # this call asked for positions mapped by (p + 1.5) * 0.25
+    checked = 0
+    for r in np.nonzero(acc)[0][:20]:
+        if rn2[r] == rn[r]:
+            np.testing.assert_allclose(pos2[rs2[r]:rs2[r] + rn2[r]], (pos[rs[r]:rs[r] + rn[r]] + 1.5) * 0.25, atol=1e-6)
+            checked += 1
+    assert checked > 0
+
+
+def test_sample_rays(oracle_mod, dev):
+    """training-ray sampler: same picks (integer hash) and rays / supervision as the C restatement"""
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(5)
+    n, H, W, R = 5, 37, 53, 3000
+    images = rng.uniform(0, 1, (n, H, W, 4)).astype(np.float32)
+    depths = rng.uniform(-0.5, 4, (n, H, W)).astype(np.float32)
+    covs = rng.uniform(0, 1, (n, H, W)).astype(np.float32); covs[covs < 0.1] = 0
+    c2w = np.zeros((n, 3, 4), np.float32)
+    for k in range(n):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        c2w[k, :, :3], c2w[k, :, 3] = q, rng.uniform(-0.5, 1.5, 3)
+    intr = (60.0, 55.0, 26.0, 18.0)
+    ref = oracle_mod.ngp_sample_rays(images, depths, covs, c2w, intr, -1.5, 2.5, 0.05, 12345, R)
+    keep = [T(x, dev) for x in (images, depths, covs, c2w)]
+    f = dict(dtype=torch.float32, device=dev)
+    out = [torch.empty((R, 3), **f), torch.empty((R, 3), **f), torch.empty((R, 2), **f), torch.empty((R, 3), **f),
+           torch.empty(R, **f), torch.empty(R, **f)]
+    check(lib().ns_ngp_sample_rays(*[ptr(k) for k in keep], n, H, W, *[C.c_float(v) for v in intr], C.c_float(-1.5),
+                                   C.c_float(2.5), C.c_float(0.05), C.c_uint32(12345), R, *[ptr(t) for t in out],
+                                   stream_ptr()), "sample_rays")
+    for t, k in zip(out, ("rays_o", "rays_d", "t_range", "gt_rgb", "gt_depth", "gt_cov")):
+        tol = dict(rtol=0, atol=0) if k.startswith("gt") or k == "rays_o" else dict(rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(t.cpu().numpy(), ref[k], err_msg=k, **tol)
+    picks = ref["picks"]
+    assert len(np.unique(picks[:, 0])) == n and picks[:, 1].max() == W - 1 and picks[:, 2].max() == H - 1
 
 
 def test_training_converges_on_a_synthetic_scene(dev):
