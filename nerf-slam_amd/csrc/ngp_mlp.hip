@@ -420,13 +420,18 @@ __global__ __launch_bounds__(256) void ngp_mlp_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// grid W_TOTAL / 64: thread (idx = tid & 63, group = tid >> 6) sums every 4th split of weight 64 * block + idx
+// (256-byte coalesced rows), the four groups meet in LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void ngp_mlp_wgrad_reduce_kernel(const float* __restrict__ partial, int ksplit,
                                                                    float* __restrict__ grad) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= W_TOTAL) return;
+  __shared__ float part[4][64];
+  const int idx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + idx;
   float s = 0.0f;
-  for (int k = 0; k < ksplit; k++) s += partial[(long)k * W_TOTAL + i];
-  grad[i] += s;
+  for (int k = grp; k < ksplit; k += 4) s += partial[(long)k * W_TOTAL + i];
+  part[grp][idx] = s;
+  __syncthreads();
+  if (grp == 0) grad[i] += (part[0][idx] + part[1][idx]) + (part[2][idx] + part[3][idx]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -473,7 +478,7 @@ extern "C" int ns_ngp_mlp_backward(const void* weights, const void* dLdout, cons
   w.ksplit = ksplit;
   hipLaunchKernelGGL(ngp_mlp_wgrad_kernel, dim3(ksplit, 5), dim3(256), 0, st, w);
   NS_CHECK_LAUNCH("ngp_mlp_wgrad_kernel");
-  hipLaunchKernelGGL(ngp_mlp_wgrad_reduce_kernel, dim3(ns_cdiv(W_TOTAL, 256)), dim3(256), 0, st, partial_ws, ksplit,
+  hipLaunchKernelGGL(ngp_mlp_wgrad_reduce_kernel, dim3(W_TOTAL / 64), dim3(256), 0, st, partial_ws, ksplit,
                      grad_weights);
   NS_CHECK_LAUNCH("ngp_mlp_wgrad_reduce_kernel");
   return NS_OK;
