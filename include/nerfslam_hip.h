@@ -233,12 +233,16 @@ int ns_ngp_encode_forward(int n_levels, int n_features, int log2_hashmap, int ba
  * unit_major = 1) (atomic scatter).
  * workspace: NULL, or ns_ngp_encode_backward_workspace_bytes(...) bytes, ZERO-FILLED once by the caller
  * (left zeroed by every call): private accumulation tables for the coarse levels, where all samples of a
- * scene hit a few hundred entries and same-address atomics would serialise.                           */
+ * scene hit a few hundred entries and same-address atomics would serialise.
+ * fixed_scale: 0 -> grad_params holds f32 pairs.  S > 0 -> PACKED fixed point: one 64-bit word per table
+ * entry, word = round(g0*S) + (round(g1*S) << 32) (two signed Q(S) 32-bit fields): one integer atomic per
+ * corner instead of two float atomics, and an order-independent (bit-reproducible) sum.  ns_ngp_adam
+ * decodes the same format when given the same fixed_scale.                                             */
 long ns_ngp_encode_backward_workspace_bytes(int n_levels, int n_features, int log2_hashmap, int base_res,
                                             float per_level_scale);
 int ns_ngp_encode_backward(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
                            const float* positions, const void* dLdout, int unit_major, float* grad_params,
-                           float* workspace, long N, void* stream);
+                           float* workspace, float fixed_scale, long N, void* stream);
 
 /* density MLP 32->64->16 + colour MLP (16 + SH16)->64->64->16, f16 weights packed row-major
  * [W1 64x32 | W2 16x64 | W3 64x32 | W4 64x64 | W5 16x64]; featT [32,N] f16 UNIT-MAJOR (what
@@ -257,9 +261,10 @@ int ns_ngp_mlp_backward(const void* weights, const void* dLdout, const void* fea
                         void* d3T, void* ddT, void* d1T, float* partial_ws, int ksplit, float* grad_weights, long N,
                         void* stream);
 
-/* Adam on f32 master parameters with an f16 working copy; zeroes `grad` behind itself. step >= 1. */
+/* Adam on f32 master parameters with an f16 working copy; zeroes `grad` behind itself. step >= 1.
+ * fixed_scale > 0: `grad` is in the packed fixed-point format of ns_ngp_encode_backward.             */
 int ns_ngp_adam(float* master, void* half_params, float* grad, float* m1, float* m2, long n, int step, float lr,
-                float beta1, float beta2, float eps, float l2, float grad_scale, void* stream);
+                float beta1, float beta2, float eps, float l2, float grad_scale, float fixed_scale, void* stream);
 
 /* training rays: ray r picks image / column / row = pcg(seed + 3r + {0,1,2}) mod {n_images, W, H}
  * (pcg = the 32-bit PCG output hash, csrc/ngp.hip:ns_pcg), direction = normalised c2w[:, :3] ((u + .5 - cx)/fx,

@@ -34,6 +34,7 @@ struct ReplicaPlan {
 };
 #define NS_ENC_REPLICA_BUDGET (8u << 20)  // bytes of replicas per level
 #define NS_ENC_REPLICA_MAX 64u
+#define NS_ENC_REPLICA_TABLE_MAX (2u << 20)  // only tables up to this size are replicated
 
 static void replica_plan_host(const GridLayout& g, int n_levels, ReplicaPlan& r) {
   uint64_t off = 0;
@@ -42,8 +43,10 @@ static void replica_plan_host(const GridLayout& g, int n_levels, ReplicaPlan& r)
     r.ws_off[l] = off;
     if (l >= n_levels) continue;
     const uint64_t bytes = (uint64_t)(g.offset[l + 1] - g.offset[l]) * 2 * sizeof(float);
-    uint32_t rep = 1;
-    while (rep * 2 <= NS_ENC_REPLICA_MAX && (uint64_t)rep * 2 * bytes <= NS_ENC_REPLICA_BUDGET) rep *= 2;
+    uint32_t rep = 1;  // big (hashed) tables: contention is low, no replicas
+    while (bytes <= NS_ENC_REPLICA_TABLE_MAX && rep * 2 <= NS_ENC_REPLICA_MAX &&
+           (uint64_t)rep * 2 * bytes <= NS_ENC_REPLICA_BUDGET)
+      rep *= 2;
     r.rep[l] = rep;
     if (rep > 1) off += (uint64_t)rep * (bytes / sizeof(float));
   }
@@ -138,6 +141,21 @@ __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const
   }
 }
 
+// Packed fixed-point gradient format (fixed_scale > 0): one 64-bit word per table entry holds both features
+// as signed Q(fixed_scale) 32-bit fields, word = round(g0 * S) + (round(g1 * S) << 32).  One 64-bit integer
+// atomic replaces two float atomics (the scatter is atomic-rate bound on the hashed levels), and integer
+// addition commutes: the accumulated gradient is independent of the execution order (bit-reproducible).
+__device__ __forceinline__ unsigned long long pack_fixed(float g0, float g1, float S) {
+  const long long lo = (long long)__float2int_rn(g0 * S), hi = (long long)__float2int_rn(g1 * S);
+  return (unsigned long long)(lo + (hi << 32));
+}
+__device__ __forceinline__ void unpack_fixed(unsigned long long w, float inv_S, float& g0, float& g1) {
+  const int lo = (int)(unsigned)(w & 0xffffffffull);
+  const int hi = (int)(((long long)w - (long long)lo) >> 32);
+  g0 = (float)lo * inv_S;
+  g1 = (float)hi * inv_S;
+}
+
 // Backward of the encode: scatter-add of the 8 trilinear corner contributions per (sample, level).
 // Samples arrive in ray order, so on the coarse levels long runs of consecutive lanes fall into the SAME
 // cell (level 0: every sample of a small scene hits a few dozen table entries); plain atomics then
@@ -148,7 +166,8 @@ __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const
 __global__ __launch_bounds__(256) void ngp_encode_bwd_kernel(GridLayout g, const float* __restrict__ pos,
                                                              const h2_t* __restrict__ dLdout,
                                                              float* __restrict__ grad, long N, int L, int level0,
-                                                             ReplicaPlan rp, float* __restrict__ ws, int unit_major) {
+                                                             ReplicaPlan rp, float* __restrict__ ws, int unit_major,
+                                                             float fixed_scale) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int l = blockIdx.y + level0;
@@ -211,9 +230,18 @@ __global__ __launch_bounds__(256) void ngp_encode_bwd_kernel(GridLayout g, const
   if (!issue) return;
   // coarse levels: all samples of a scene fall on a few hundred entries and device-scope atomics on one address
   // serialise at the memory side (measured: 0.4 ms for level 0 alone); spread them over rep[l] private tables
-  float* __restrict__ tab = (ws != nullptr && rp.rep[l] > 1)
-                                ? ws + rp.ws_off[l] + (uint64_t)(blockIdx.x & (rp.rep[l] - 1)) * hs * 2
-                                : grad + (long)g.offset[l] * 2;
+  const bool replica = ws != nullptr && rp.rep[l] > 1;
+  float* __restrict__ tab = replica ? ws + rp.ws_off[l] + (uint64_t)(blockIdx.x & (rp.rep[l] - 1)) * hs * 2
+                                    : grad + (long)g.offset[l] * 2;
+  if (!replica && fixed_scale > 0.0f) {
+    unsigned long long* __restrict__ tab64 = reinterpret_cast<unsigned long long*>(tab);
+#pragma unroll
+    for (int corner = 0; corner < 8; corner++) {
+      const uint32_t idx = grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2));
+      atomicAdd(&tab64[idx], pack_fixed(v[corner * 2], v[corner * 2 + 1], fixed_scale));
+    }
+    return;
+  }
 #pragma unroll
   for (int corner = 0; corner < 8; corner++) {
     const uint32_t idx = grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2));
@@ -231,11 +259,19 @@ __global__ __launch_bounds__(256) void ngp_adam_kernel(float* __restrict__ maste
                                                        float* __restrict__ grad, float* __restrict__ m1,
                                                        float* __restrict__ m2, long n, float c1, float c2, float lr,
                                                        float beta1, float beta2, float eps, float l2,
-                                                       float inv_grad_scale) {
+                                                       float inv_grad_scale, float inv_fixed_scale) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float g = grad[i] * inv_grad_scale;
-  grad[i] = 0.0f;  // leaves the gradient buffer ready for the next step
+  float g;
+  if (inv_fixed_scale > 0.0f) {  // packed fixed-point pairs (see pack_fixed): both lanes of a pair read the word
+    float g0, g1;
+    unpack_fixed(reinterpret_cast<const unsigned long long*>(grad)[i >> 1], inv_fixed_scale, g0, g1);
+    g = ((i & 1) ? g1 : g0) * inv_grad_scale;
+  } else {
+    g = grad[i] * inv_grad_scale;
+  }
+  __builtin_amdgcn_wave_barrier();
+  grad[i] = 0.0f;  // leaves the gradient buffer ready for the next step (each lane clears its half of the word)
   float p = master[i];
   if (!(g == 0.0f && l2 == 0.0f)) {
     g += l2 * p;
@@ -664,22 +700,32 @@ extern "C" int ns_ngp_encode_forward(int n_levels, int n_features, int log2_hash
 
 // sum the replicas into the gradient and clear them (only entries that were touched are written back)
 __global__ __launch_bounds__(256) void ngp_encode_bwd_reduce_kernel(GridLayout g, ReplicaPlan rp, int n_levels,
-                                                                    float* __restrict__ ws, float* __restrict__ grad) {
+                                                                    float* __restrict__ ws, float* __restrict__ grad,
+                                                                    float fixed_scale) {
   const int l = blockIdx.y;
   const uint32_t rep = rp.rep[l];
   if (rep <= 1) return;
-  const uint64_t n = (uint64_t)(g.offset[l + 1] - g.offset[l]) * 2;
+  const uint64_t n = (uint64_t)(g.offset[l + 1] - g.offset[l]);  // entries (two floats each)
   for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (uint64_t)gridDim.x * 256) {
-    float sum = 0.0f;
-    float* p = ws + rp.ws_off[l] + e;
+    float s0 = 0.0f, s1 = 0.0f;
+    float2* p = reinterpret_cast<float2*>(ws + rp.ws_off[l]) + e;
     for (uint32_t k = 0; k < rep; k++) {
-      const float v = p[(uint64_t)k * n];
-      if (v != 0.0f) {
-        sum += v;
-        p[(uint64_t)k * n] = 0.0f;
+      const float2 v = p[(uint64_t)k * n];
+      if (v.x != 0.0f || v.y != 0.0f) {
+        s0 += v.x;
+        s1 += v.y;
+        p[(uint64_t)k * n] = make_float2(0.0f, 0.0f);
       }
     }
-    if (sum != 0.0f) grad[(uint64_t)g.offset[l] * 2 + e] += sum;
+    if (s0 != 0.0f || s1 != 0.0f) {
+      float* gp = grad + ((uint64_t)g.offset[l] + e) * 2;
+      if (fixed_scale > 0.0f) {
+        *reinterpret_cast<unsigned long long*>(gp) += pack_fixed(s0, s1, fixed_scale);
+      } else {
+        gp[0] += s0;
+        gp[1] += s1;
+      }
+    }
   }
 }
 
@@ -695,7 +741,8 @@ extern "C" long ns_ngp_encode_backward_workspace_bytes(int n_levels, int n_featu
 
 extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_hashmap, int base_res,
                                       float per_level_scale, const float* positions, const void* dLdout,
-                                      int unit_major, float* grad_params, float* workspace, long N, void* stream) {
+                                      int unit_major, float* grad_params, float* workspace, float fixed_scale, long N,
+                                      void* stream) {
   NS_REQUIRE(positions && dLdout && grad_params, "ns_ngp_encode_backward: null pointer");
   GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
   GridLayout g;
@@ -710,28 +757,31 @@ extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_has
   if (per_level) {
     for (int l = 0; l < n_levels; l++)
       hipLaunchKernelGGL(ngp_encode_bwd_kernel, dim3(ns_cdiv(N, 256), 1), dim3(256), 0, (hipStream_t)stream, g,
-                         positions, (const h2_t*)dLdout, grad_params, N, n_levels, l, rp, workspace, unit_major);
+                         positions, (const h2_t*)dLdout, grad_params, N, n_levels, l, rp, workspace, unit_major, fixed_scale);
   } else {
     hipLaunchKernelGGL(ngp_encode_bwd_kernel, dim3(ns_cdiv(N, 256), n_levels), dim3(256), 0, (hipStream_t)stream, g,
-                       positions, (const h2_t*)dLdout, grad_params, N, n_levels, 0, rp, workspace, unit_major);
+                       positions, (const h2_t*)dLdout, grad_params, N, n_levels, 0, rp, workspace, unit_major, fixed_scale);
   }
   NS_CHECK_LAUNCH("ngp_encode_bwd_kernel");
   if (workspace != nullptr && rp.total_floats > 0) {
     hipLaunchKernelGGL(ngp_encode_bwd_reduce_kernel, dim3(256, n_levels), dim3(256), 0, (hipStream_t)stream, g, rp,
-                       n_levels, workspace, grad_params);
+                       n_levels, workspace, grad_params, fixed_scale);
     NS_CHECK_LAUNCH("ngp_encode_bwd_reduce_kernel");
   }
   return NS_OK;
 }
 
 extern "C" int ns_ngp_adam(float* master, void* half_params, float* grad, float* m1, float* m2, long n, int step,
-                           float lr, float beta1, float beta2, float eps, float l2, float grad_scale, void* stream) {
+                           float lr, float beta1, float beta2, float eps, float l2, float grad_scale,
+                           float fixed_scale, void* stream) {
   NS_REQUIRE(master && half_params && grad && m1 && m2, "ns_ngp_adam: null pointer");
   NS_REQUIRE(step >= 1 && grad_scale > 0.0f, "ns_ngp_adam: step must be >= 1 and grad_scale > 0");
+  NS_REQUIRE(fixed_scale == 0.0f || n % 2 == 0, "ns_ngp_adam: packed gradients come in pairs");
   if (n <= 0) return NS_OK;
   const float c1 = 1.0f - powf(beta1, (float)step), c2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(ngp_adam_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, master,
-                     (_Float16*)half_params, grad, m1, m2, n, c1, c2, lr, beta1, beta2, eps, l2, 1.0f / grad_scale);
+                     (_Float16*)half_params, grad, m1, m2, n, c1, c2, lr, beta1, beta2, eps, l2, 1.0f / grad_scale,
+                     fixed_scale > 0.0f ? 1.0f / fixed_scale : 0.0f);
   NS_CHECK_LAUNCH("ngp_adam_kernel");
   return NS_OK;
 }

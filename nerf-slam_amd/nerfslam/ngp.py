@@ -50,6 +50,7 @@ class NgpConfig:
     min_optical_thickness: float = 0.01
     near: float = 0.05
     wgrad_ksplit: int = 256
+    grad_fixed_scale: float = 262144.0   # hash-grid gradients accumulate as packed Q18 fixed point (0: f32 atomics)
 
     @property
     def per_level_scale(self):
@@ -235,14 +236,16 @@ class NgpNerf:
                                             c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(N8), stream_ptr()),
                   "ngp_mlp_backward")
             check(lib().ns_ngp_encode_backward(*self._grid_args(), ptr(pos_unit), ptr(dfeatT), 1,
-                                               ptr(self.grid_grad), ptr(self.enc_ws), C.c_long(N8), stream_ptr()), "ngp_encode_backward")
+                                               ptr(self.grid_grad), ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(N8),
+                                               stream_ptr()), "ngp_encode_backward")
             # optimiser
             self.step += 1
-            for (m, hp, g, m1, m2, l2) in ((self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0),
-                                           (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp)):
+            for (m, hp, g, m1, m2, l2, fx) in (
+                    (self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale),
+                    (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0)):
                 check(lib().ns_ngp_adam(ptr(m), ptr(hp), ptr(g), ptr(m1), ptr(m2), C.c_long(m.numel()), self.step,
                                         C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
-                                        C.c_float(l2), C.c_float(c.loss_scale), stream_ptr()), "ngp_adam")
+                                        C.c_float(l2), C.c_float(c.loss_scale), C.c_float(fx), stream_ptr()), "ngp_adam")
             if self.step % c.grid_update_every == 0:
                 self.update_density_grid()
             self.loss_tensor = loss / (self.ray_n >= 0).sum().clamp(min=1)

@@ -52,14 +52,32 @@ def test_hash_encode_forward_backward(oracle_mod, dev, which):
     dL[rng.uniform(size=N) < 0.3] = 0
     grad = torch.zeros(n_par, dtype=torch.float32, device=dev)
     d_dL = T(dL, dev)
-    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dL), 0, ptr(grad), None, C.c_long(N), stream_ptr()), "bwd")
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dL), 0, ptr(grad), None, C.c_float(0), C.c_long(N), stream_ptr()), "bwd")
     # same through the replicated coarse-level tables (workspace must come back zeroed)
     ws = torch.zeros(lib().ns_ngp_encode_backward_workspace_bytes(*args) // 4, device=dev)
     grad_ws = torch.zeros_like(grad)
     d_dLT = d_dL.t().contiguous()
-    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(grad_ws), ptr(ws), C.c_long(N), stream_ptr()), "bwd")
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(grad_ws), ptr(ws), C.c_float(0), C.c_long(N), stream_ptr()), "bwd")
     assert ws.numel() > 0 and not ws.any()
     assert (grad_ws - grad).abs().max().item() <= 1e-5 * grad.abs().max().item()
+    # packed fixed-point accumulation (Q18 pairs in one 64-bit word): order-independent -> two runs agree bit for bit
+    S = 262144.0
+    packed = []
+    for _ in range(2):
+        gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
+        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(gq), ptr(ws), C.c_float(S), C.c_long(N),
+                                           stream_ptr()), "bwd")
+        packed.append(gq.cpu().numpy())
+    w = packed[0]
+    lo = (w & 0xffffffff).astype(np.uint32).view(np.int32).astype(np.int64)
+    hi = (w - lo) >> 32
+    gq = np.stack([lo, hi], 1).reshape(-1).astype(np.float64) / S
+    gmax = grad.abs().max().item()
+    # each contribution is rounded to 2^-18: error <= (#contributions per entry) * 2^-19
+    assert np.abs(gq - grad.cpu().numpy()).max() <= 64 * 2.0 ** -19 + 1e-5 * gmax
+    for l in range(L):                           # non-replicated levels (tables > 2 MiB): pure integer atomics
+        if (int(off[l + 1]) - int(off[l])) * 8 > (2 << 20):
+            assert np.array_equal(packed[0][int(off[l]):int(off[l + 1])], packed[1][int(off[l]):int(off[l + 1])]), l
     gref = oracle_mod.ngp_encode_bwd(cfg, pos, dL, n_par)
     # f32 atomics in arbitrary order: 1e-5 of max
     assert np.abs(grad.cpu().numpy() - gref).max() <= 1e-5 * np.abs(gref).max()
@@ -169,7 +187,18 @@ def test_composite_loss_and_adam(oracle_mod, dev):
     dm, dg, d1, d2 = T(m, dev), T(g, dev), T(m1, dev), T(m2, dev)
     hp = torch.empty(n, dtype=torch.float16, device=dev)
     check(lib().ns_ngp_adam(ptr(dm), ptr(hp), ptr(dg), ptr(d1), ptr(d2), C.c_long(n), 3, C.c_float(1e-2), C.c_float(0.9),
-                            C.c_float(0.99), C.c_float(1e-15), C.c_float(0.0), C.c_float(128.0), stream_ptr()), "adam")
+                            C.c_float(0.99), C.c_float(1e-15), C.c_float(0.0), C.c_float(128.0), C.c_float(0.0), stream_ptr()), "adam")
+    # packed fixed-point gradient input: same update as the float gradient rounded to 2^-18
+    S = 262144.0
+    gr = np.round(g.astype(np.float64) * S).astype(np.int64)
+    word = torch.from_numpy(gr[0::2] + (gr[1::2] << 32)).to(dev)
+    rm2, rh2, _, _ = oracle_mod.ngp_adam(m, (gr / S).astype(np.float32), m1, m2, step=3, lr=1e-2, l2=0.0, grad_scale=128.0)
+    dm2, d12, d22 = T(m, dev), T(m1, dev), T(m2, dev)
+    check(lib().ns_ngp_adam(ptr(dm2), ptr(hp), ptr(word), ptr(d12), ptr(d22), C.c_long(n), 3, C.c_float(1e-2), C.c_float(0.9),
+                            C.c_float(0.99), C.c_float(1e-15), C.c_float(0.0), C.c_float(128.0), C.c_float(S), stream_ptr()),
+          "adam")
+    np.testing.assert_allclose(dm2.cpu().numpy(), rm2, rtol=2e-6, atol=1e-7)
+    assert not word.any()
     np.testing.assert_allclose(dm.cpu().numpy(), rm, rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(d1.cpu().numpy(), r1, rtol=2e-6, atol=1e-8)
     np.testing.assert_allclose(d2.cpu().numpy(), r2, rtol=2e-6, atol=1e-8)
