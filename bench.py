@@ -217,6 +217,35 @@ def cpu_baseline(hp):
                       "6 lookups, 12 BA iterations" % (t["build_per_edge"], t["lookup48"], t["ba_iteration"])}
 
 
+def mapping_rate(dev, steps=100, warmup=200):
+    """NeRF trainer throughput (configs[2]'s mapping half), reported next to the tracking number: synthetic 8-view scene,
+    default NgpConfig (2^18-sample batches); see tools/ngp_bench.py."""
+    from nerfslam.ngp import NgpConfig, NgpNerf
+    net = NgpNerf(NgpConfig(), dev, seed=0)
+    H, W, f = 120, 160, 150.0
+    g = torch.Generator().manual_seed(0)
+    n = 8
+    c2w = torch.zeros((n, 3, 4))
+    for k in range(n):
+        a = 2 * np.pi * k / n
+        eye = np.array([0.5, 0.5, 0.5]) + 1.2 * np.array([np.cos(a), 0.3, np.sin(a)])
+        fwd = np.array([0.5, 0.5, 0.5]) - eye; fwd /= np.linalg.norm(fwd)
+        right = np.cross(fwd, [0, 1, 0]); right /= np.linalg.norm(right)
+        c2w[k] = torch.tensor(np.stack([right, -np.cross(right, fwd), fwd, eye], 1), dtype=torch.float32)
+    imgs = torch.rand((n, H, W, 4), generator=g)
+    net.set_images(imgs, torch.full((n, H, W), 1.2), torch.full((n, H, W), 0.05), c2w, (f, f, W / 2, H / 2))
+    for _ in range(warmup):
+        net.train_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); ns = 0
+    for _ in range(steps):
+        net.train_step(); ns += net.last_samples
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"nerf_train_steps_per_s": steps / dt, "samples_per_step": ns / steps, "samples_per_s": ns / dt,
+            "note": "instant-ngp style trainer on the HIP kernels (hash encode, MFMA MLPs, ray marching), not part of `value`"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,27 +269,56 @@ def main():
     torch.set_grad_enabled(False)
 
     hp = HotPath(dev, seed=rank)
+    hp.ev = None
     for _ in range(args.warmup):
         hp.step()
     torch.cuda.synchronize()
 
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides ----
+    def timed(run_step):
+        """exactly K steps, barrier + synchronize on both sides, max over ranks"""
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run_step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    # ---- pass A (eager launches): per-kernel HIP events on the launch stream -> roofline, us_per_call ----
     hp.ev = {}
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        hp.step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt_eager = timed(hp.step)
+    ev, hp.ev = hp.ev, None
+    # ---- pass B (the reported number): the same step captured once in a HIP graph and replayed K times.  A step is
+    # ~170 launches of 5-150 us kernels; launched one by one from Python the host is the bottleneck (pass A), which is
+    # what hipGraphs are for.  The captured work is identical (same kernels, same buffers, state carried on). ----
+    launch = "hipGraph replay"
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            hp.step()                      # allocator warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            hp.step()
+        for _ in range(max(1, args.warmup)):
+            graph.replay()
+        torch.cuda.synchronize()
+        dt = timed(graph.replay)
+    except Exception as e:                 # report the eager number rather than nothing
+        launch = "eager (graph capture failed: %s)" % str(e)[:120]
+        dt = dt_eager
+    hp.ev = ev
 
     kern = {k: 1e3 * float(np.mean([s.elapsed_time(e) for s, e in v])) for k, v in hp.ev.items()}  # us / call
     per_step = {k: kern[k] * len(hp.ev[k]) / args.steps for k in kern}
@@ -284,13 +342,22 @@ def main():
                                "step: 11 corr-pyramid builds, 7 four-level lookups (E=48), 12 BA iterations "
                                "(M=96,P=10,K'=13) incl. device solve/retraction/depth update, 6 covariance blocks, "
                                "252 frame distances; conv nets (encoders/ConvGRU) and NeRF fusion NOT included",
-                   "replicas": world, "parallelism": "independent streams, one per GPU" if world > 1 else "single GPU"},
+                   "replicas": world, "parallelism": "independent streams, one per GPU" if world > 1 else "single GPU",
+                   "launch": launch, "eager_ms_per_step": 1e3 * dt_eager / args.steps},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": ALG_BYTES[dom], "avg_launch_us": kern[dom]},
         "us_per_call": {k: round(v, 2) for k, v in sorted(kern.items())},
         "us_per_step": {k: round(v, 1) for k, v in sorted(per_step.items())},
     }
+    traffic_file = os.path.join(ROOT, "profiles", "r01_traffic.json")  # rocprofv3 --pmc passes (tools/pmc.sh), per launch
+    if os.path.exists(traffic_file):
+        tr = json.load(open(traffic_file)).get(dom)
+        if tr:
+            out["roofline"]["traffic"] = tr["traffic_bytes"]
+            out["roofline"]["traffic_note"] = tr["note"]
+    if rank == 0 and world == 1:
+        out["mapping"] = mapping_rate(dev)
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(hp)
     elif rank == 0:
