@@ -20,6 +20,8 @@
 //     band (no cross-lane traffic at all) and are stored as 32 / 16 / 8-byte runs;
 //   * rounding follows the reference exactly: level 0 = f16(f32 accumulator), level l+1 =
 //     f16((a+b+c+d in f32, row-major order)/4) of the ROUNDED level-l values.
+#include <cstdlib>
+
 #include "common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -45,32 +47,49 @@ __device__ __forceinline__ _Float16 pool4(_Float16 a, _Float16 b, _Float16 c, _F
   return (_Float16)(acc / 4.0f);
 }
 
-// store N consecutive halves (N = 2,4,8 -> 4/8/16-byte store), element-wise at the image border
-template <int N>
-__device__ __forceinline__ void store_run(_Float16* dst, const _Float16* v, int nvalid) {
-  typedef _Float16 vec_t __attribute__((ext_vector_type(N)));
-  if (nvalid >= N) {
-    struct __attribute__((packed, aligned(2))) U { vec_t v; };
-    vec_t o;
-#pragma unroll
-    for (int k = 0; k < N; k++) o[k] = v[k];
-    reinterpret_cast<U*>(dst)->v = o;
-  } else {
-#pragma unroll
-    for (int k = 0; k < N; k++)
-      if (k < nvalid) dst[k] = v[k];
-  }
+// f16 values travel in PACKED pairs (one VGPR per two values): the row, its three pooling carries and the
+// pooled rows would otherwise take one VGPR per half and push the kernel to one wave per SIMD.
+__device__ __forceinline__ f16x2 mk2(_Float16 a, _Float16 b) {
+  const f16x2 v = {a, b};
+  return v;
 }
 
-template <int W>
-__device__ __forceinline__ void store_row(_Float16* dst, const _Float16* v, int nvalid) {
-  if (W >= 8) {
+// store NP consecutive pairs (2*NP halves) at dst (2-byte aligned): 16 / 8 / 4-byte pieces, element-wise at the
+// image border (nvalid = number of valid halves from dst on)
+template <int NP>
+__device__ __forceinline__ void store_pairs(_Float16* dst, const f16x2* v, int nvalid) {
+  struct __attribute__((packed, aligned(2))) U8 { f16x8 v; };
+  struct __attribute__((packed, aligned(2))) U4 { f16x4 v; };
+  struct __attribute__((packed, aligned(2))) U2 { f16x2 v; };
+  int k = 0;
 #pragma unroll
-    for (int k = 0; k < W; k += 8) store_run<8>(dst + k, v + k, nvalid - k);
-  } else if (W == 4) {
-    store_run<4>(dst, v, nvalid);
-  } else {
-    store_run<2>(dst, v, nvalid);
+  for (; k + 4 <= NP; k += 4) {
+    if (nvalid - 2 * k >= 8) {
+      const f16x8 o = {v[k][0], v[k][1], v[k + 1][0], v[k + 1][1], v[k + 2][0], v[k + 2][1], v[k + 3][0], v[k + 3][1]};
+      reinterpret_cast<U8*>(dst + 2 * k)->v = o;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        if (2 * k + q < nvalid) dst[2 * k + q] = v[k + (q >> 1)][q & 1];
+    }
+  }
+  if (NP - k >= 2) {
+    if (nvalid - 2 * k >= 4) {
+      const f16x4 o = {v[k][0], v[k][1], v[k + 1][0], v[k + 1][1]};
+      reinterpret_cast<U4*>(dst + 2 * k)->v = o;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (2 * k + q < nvalid) dst[2 * k + q] = v[k + (q >> 1)][q & 1];
+    }
+    k += 2;
+  }
+  if (NP - k >= 1) {
+    if (nvalid - 2 * k >= 2) {
+      reinterpret_cast<U2*>(dst + 2 * k)->v = v[k];
+    } else if (2 * k < nvalid) {
+      dst[2 * k] = v[k][0];
+    }
   }
 }
 
@@ -83,13 +102,13 @@ __device__ __forceinline__ void store_row(_Float16* dst, const _Float16* v, int 
 // which makes both the staging writes and the fragment reads (row = permuted x, see below) conflict
 // free.  Two buffers: the loads of the next row are in flight while the current one is multiplied.
 #define ROWB 272
-#define TILEB (64 * ROWB)
 
-template <int C>
+// One staged row chunk = 32*NT consecutive target pixels x 128 channels (NT <= 3: 26 KiB with the padding).
+template <int C, int NT>
 __device__ __forceinline__ void stage_load(const _Float16* __restrict__ F2row, int x0, int wd, int tid, uint4* regs) {
-  // 64 rows x 256 B = 1024 pieces of 16 B over 256 lanes: 4 per lane; piece id = tid + 256*k
+  // 32*NT rows x 256 B = 512*NT pieces of 16 B over 256 lanes: 2*NT per lane; piece id = tid + 256*k
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < 2 * NT; k++) {
     const int piece = tid + 256 * k;
     const int r = piece >> 4, sl = piece & 15;
     const int x = x0 + r;
@@ -97,9 +116,10 @@ __device__ __forceinline__ void stage_load(const _Float16* __restrict__ F2row, i
   }
 }
 
+template <int NT>
 __device__ __forceinline__ void stage_store(char* tile, int tid, const uint4* regs) {
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < 2 * NT; k++) {
     const int piece = tid + 256 * k;
     const int r = piece >> 4, sl = piece & 15;
     *reinterpret_cast<uint4*>(tile + r * ROWB + sl * 16) = regs[k];
@@ -109,7 +129,7 @@ __device__ __forceinline__ void stage_store(char* tile, int tid, const uint4* re
 // NT tiles (NT*32 target pixels of the staged row) against the wave's 32 source pixels.
 // Lane (col, half) ends up with v[0 .. 16*NT) = corr(p, y, x0 + 16*NT*half + k).
 template <int C, int NT>
-__device__ __forceinline__ void row_chunk(const char* tile, const f16x8* src, int col, int half, _Float16* v) {
+__device__ __forceinline__ void row_chunk(const char* tile, const f16x8* src, int col, int half, f16x2* v) {
   constexpr int KS = C / 16;
   f32x16 acc[NT];
 #pragma unroll
@@ -126,83 +146,94 @@ __device__ __forceinline__ void row_chunk(const char* tile, const f16x8* src, in
       const f16x8 tgt = *reinterpret_cast<const f16x8*>(rows[t] + kk * 32);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tgt, src[kk], acc[t], 0, 0, 0);
     }
+    if (kk & 1) __builtin_amdgcn_sched_barrier(0);  // at most two k-steps of LDS fragments in flight (register budget)
   }
   // accumulator r of tile t (this lane's half h): i = (r&3) + 8*(r>>2) + 4*h  ->  x - x0 - 16*NT*h = r + 16*t
 #pragma unroll
   for (int t = 0; t < NT; t++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[16 * t + r] = (_Float16)acc[t][r];
+    for (int r = 0; r < 16; r += 2) v[8 * t + (r >> 1)] = mk2((_Float16)acc[t][r], (_Float16)acc[t][r + 1]);
 }
 
-// One band (8 target rows) x one chunk of 32*NT target columns, for the whole workgroup.
+// Rows [r0, r1) (r0 a multiple of 8) x one chunk of 32*NT target columns, for the whole workgroup.
+// Software pipeline over the rows with THREE LDS buffers: while row y is multiplied, row y+1 is already in
+// LDS and the global loads of row y+2 are in flight (an L2 round trip is about as long as one row of work;
+// with two buffers every row waited for it).  One barrier per row.
 template <int C, int NT>
-__device__ __forceinline__ void band_chunk(const VolArgs& a, const _Float16* __restrict__ F2, const f16x8* src,
-                                           char* lds, int y0, int x0, int col, int half, bool pok, _Float16* o0,
-                                           _Float16* o1, _Float16* o2, _Float16* o3) {
+__device__ __forceinline__ void rows_chunk(const VolArgs& a, const _Float16* __restrict__ F2, const f16x8* src,
+                                           char* lds, int r0, int r1, int x0, int col, int half, bool pok,
+                                           _Float16* o0, _Float16* o1, _Float16* o2, _Float16* o3) {
   constexpr int W = 16 * NT;  // consecutive x held by a lane
+  constexpr int TILEB = 32 * NT * ROWB;
   const int wd = a.wd, ht = a.ht, tid = threadIdx.x;
   const int w1 = wd >> 1, w2 = wd >> 2, w3 = wd >> 3, h1 = ht >> 1, h2 = ht >> 2, h3 = ht >> 3;
   const int xl = x0 + W * half;  // first x of this lane
-  const int nrows = min(8, ht - y0);
-  uint4 regs[4];
-  // prologue: row 0 of the band into buffer 0
-  __syncthreads();  // every wave is done reading both buffers (previous chunk)
-  stage_load<C>(F2 + (long)y0 * wd * C, x0, wd, tid, regs);
-  stage_store(lds, tid, regs);
+  uint4 regs[2 * NT];
+  __syncthreads();  // every wave is done reading the buffers (previous chunk)
+  stage_load<C, NT>(F2 + (long)r0 * wd * C, x0, wd, tid, regs);
+  stage_store<NT>(lds, tid, regs);
+  if (r0 + 1 < r1) stage_load<C, NT>(F2 + (long)(r0 + 1) * wd * C, x0, wd, tid, regs);
   __syncthreads();
-  _Float16 prev0[W], prev1[W / 2], prev2[W / 4];
+  f16x2 prev0[W / 2], prev1[W / 4], prev2[W / 8];  // pooling carries: last odd..even row of levels 0, 1, 2
+  int buf = 0;
 #pragma unroll 1
-  for (int yy = 0; yy < nrows; yy++) {
-    const int y = y0 + yy;
-    const char* cur = lds + (yy & 1) * TILEB;
-    char* nxt = lds + ((yy + 1) & 1) * TILEB;
-    const bool more = yy + 1 < nrows;
-    if (more) stage_load<C>(F2 + (long)(y + 1) * wd * C, x0, wd, tid, regs);  // in flight during the MFMAs
-    _Float16 v[W];
+  for (int y = r0; y < r1; y++) {
+    const int yy = y & 7;
+    const char* cur = lds + buf * TILEB;
+    const int nb = buf == 2 ? 0 : buf + 1;
+    if (y + 1 < r1) stage_store<NT>(lds + nb * TILEB, tid, regs);                                // row y+1 -> LDS
+    if (y + 2 < r1) stage_load<C, NT>(F2 + (long)(y + 2) * wd * C, x0, wd, tid, regs);           // row y+2 in flight
+    buf = nb;
+    f16x2 v[W / 2];
     row_chunk<C, NT>(cur, src, col, half, v);
-    if (more) stage_store(nxt, tid, regs);
-    if (pok) store_row<W>(o0 + (long)y * wd + xl, v, wd - xl);
+    if (pok) store_pairs<W / 2>(o0 + (long)y * wd + xl, v, wd - xl);
     if (a.num_levels > 1) {
       if (yy & 1) {
-        _Float16 l1[W / 2];
+        f16x2 l1[W / 4];  // element c of level 1 = pool of pair c of the two level-0 rows
 #pragma unroll
-        for (int c = 0; c < W / 2; c++) l1[c] = pool4(prev0[2 * c], prev0[2 * c + 1], v[2 * c], v[2 * c + 1]);
-        if (pok && (y >> 1) < h1) store_row<W / 2>(o1 + (long)(y >> 1) * w1 + (xl >> 1), l1, w1 - (xl >> 1));
+        for (int c = 0; c < W / 4; c++)
+          l1[c] = mk2(pool4(prev0[2 * c][0], prev0[2 * c][1], v[2 * c][0], v[2 * c][1]),
+                      pool4(prev0[2 * c + 1][0], prev0[2 * c + 1][1], v[2 * c + 1][0], v[2 * c + 1][1]));
+        if (pok && (y >> 1) < h1) store_pairs<W / 4>(o1 + (long)(y >> 1) * w1 + (xl >> 1), l1, w1 - (xl >> 1));
         if (a.num_levels > 2) {
           if ((yy & 3) == 3) {
-            _Float16 l2[W / 4];
+            f16x2 l2[W / 8];
 #pragma unroll
-            for (int c = 0; c < W / 4; c++) l2[c] = pool4(prev1[2 * c], prev1[2 * c + 1], l1[2 * c], l1[2 * c + 1]);
-            if (pok && (y >> 2) < h2) store_row<W / 4>(o2 + (long)(y >> 2) * w2 + (xl >> 2), l2, w2 - (xl >> 2));
+            for (int c = 0; c < W / 8; c++)
+              l2[c] = mk2(pool4(prev1[2 * c][0], prev1[2 * c][1], l1[2 * c][0], l1[2 * c][1]),
+                          pool4(prev1[2 * c + 1][0], prev1[2 * c + 1][1], l1[2 * c + 1][0], l1[2 * c + 1][1]));
+            if (pok && (y >> 2) < h2) store_pairs<W / 8>(o2 + (long)(y >> 2) * w2 + (xl >> 2), l2, w2 - (xl >> 2));
             if (a.num_levels > 3) {
               if (yy == 7) {
-                _Float16 l3[W / 8];
+                f16x2 l3[W / 16];
 #pragma unroll
-                for (int c = 0; c < W / 8; c++) l3[c] = pool4(prev2[2 * c], prev2[2 * c + 1], l2[2 * c], l2[2 * c + 1]);
-                if (pok && (y >> 3) < h3) store_row<W / 8>(o3 + (long)(y >> 3) * w3 + (xl >> 3), l3, w3 - (xl >> 3));
+                for (int c = 0; c < W / 16; c++)
+                  l3[c] = mk2(pool4(prev2[2 * c][0], prev2[2 * c][1], l2[2 * c][0], l2[2 * c][1]),
+                              pool4(prev2[2 * c + 1][0], prev2[2 * c + 1][1], l2[2 * c + 1][0], l2[2 * c + 1][1]));
+                if (pok && (y >> 3) < h3) store_pairs<W / 16>(o3 + (long)(y >> 3) * w3 + (xl >> 3), l3, w3 - (xl >> 3));
               } else {
 #pragma unroll
-                for (int c = 0; c < W / 4; c++) prev2[c] = l2[c];
+                for (int c = 0; c < W / 8; c++) prev2[c] = l2[c];
               }
             }
           } else {
 #pragma unroll
-            for (int c = 0; c < W / 2; c++) prev1[c] = l1[c];
+            for (int c = 0; c < W / 4; c++) prev1[c] = l1[c];
           }
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < W; c++) prev0[c] = v[c];
+        for (int c = 0; c < W / 2; c++) prev0[c] = v[c];
       }
     }
-    __syncthreads();  // next buffer filled by all waves, current buffer free for the row after next
+    __syncthreads();  // row y+1 is complete in LDS; the buffer of row y is free for row y+3
   }
 }
 
-template <int C>
+template <int C, int MAXNT>
 __global__ __launch_bounds__(256) void corr_volume_pyramid_kernel(VolArgs a) {
   constexpr int KS = C / 16;  // k-steps of the 32x32x16 MFMA
-  __shared__ __attribute__((aligned(16))) char lds[2 * TILEB];
+  __shared__ __attribute__((aligned(16))) char lds[3 * 32 * MAXNT * ROWB];  // three row buffers of 32*MAXNT pixels
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int HW = a.ht * a.wd;
@@ -228,12 +259,17 @@ __global__ __launch_bounds__(256) void corr_volume_pyramid_kernel(VolArgs a) {
   _Float16* o2 = a.num_levels > 2 ? a.pyr[2] + pp * (long)(a.ht >> 2) * (a.wd >> 2) : nullptr;
   _Float16* o3 = a.num_levels > 3 ? a.pyr[3] + pp * (long)(a.ht >> 3) * (a.wd >> 3) : nullptr;
 
+  // contiguous range of 8-row bands for this z slice (the row pipeline runs across band boundaries)
   const int nby = (a.ht + 7) >> 3;
-  for (int by = blockIdx.z; by < nby; by += gridDim.z) {
-    int x0 = 0;
-    for (; x0 + 32 < a.wd; x0 += 64) band_chunk<C, 2>(a, F2, src, lds, by * 8, x0, col, half, pok, o0, o1, o2, o3);
-    if (x0 < a.wd) band_chunk<C, 1>(a, F2, src, lds, by * 8, x0, col, half, pok, o0, o1, o2, o3);
-  }
+  const int b0 = (int)((long)blockIdx.z * nby / gridDim.z), b1 = (int)((long)(blockIdx.z + 1) * nby / gridDim.z);
+  const int r0 = b0 * 8, r1 = min(b1 * 8, a.ht);
+  if (r0 >= r1) return;  // workgroup-uniform
+  int x0 = 0;
+  if (MAXNT >= 3)
+    for (; x0 + 64 < a.wd; x0 += 96) rows_chunk<C, 3>(a, F2, src, lds, r0, r1, x0, col, half, pok, o0, o1, o2, o3);
+  if (MAXNT >= 2)
+    for (; x0 + 32 < a.wd; x0 += 64) rows_chunk<C, 2>(a, F2, src, lds, r0, r1, x0, col, half, pok, o0, o1, o2, o3);
+  for (; x0 < a.wd; x0 += 32) rows_chunk<C, 1>(a, F2, src, lds, r0, r1, x0, col, half, pok, o0, o1, o2, o3);
 }
 
 extern "C" int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, const int64_t* ii, const int64_t* jj,
@@ -270,7 +306,14 @@ extern "C" int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, cons
   if (zs > nby) zs = nby;
   if (zs < 1) zs = 1;
   dim3 grid(ns_cdiv(HW, 128), E, zs);
-  hipLaunchKernelGGL(corr_volume_pyramid_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  static const int mode = getenv("NS_VOL_NT") ? atoi(getenv("NS_VOL_NT")) : 2;  // tuning switch: widest column chunk
+  if (mode >= 3) {
+    hipLaunchKernelGGL((corr_volume_pyramid_kernel<128, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else if (mode == 2) {
+    hipLaunchKernelGGL((corr_volume_pyramid_kernel<128, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL((corr_volume_pyramid_kernel<128, 1>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   NS_CHECK_LAUNCH("corr_volume_pyramid_kernel");
   return NS_OK;
 }
