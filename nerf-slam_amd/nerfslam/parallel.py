@@ -1,0 +1,90 @@
+"""Edge-sharded bundle adjustment across GPUs (SURVEY.md 8(e), row "BA").
+
+The dense BA shards by SOURCE frame: when all edges that share a depth map (same `ii`) live on one rank, the
+per-edge Hessian blocks, the depth diagonal C (and its damping / sensed-depth prior), Q = 1/C, the coupling blocks
+E and therefore every Schur contribution E Q E^T are local and ADDITIVE.  One all-reduce of the reduced system
+(`(6P)^2 + 6P` floats: 14.6 KB at P = 10, 9.4 MB at P = 256) gives every rank H - S and v; the 6P x 6P solve and the
+pose retraction are replicated; the depth back-substitution touches only the depth maps a rank owns.
+Correlation volumes / lookups shard the same way (edges are independent; no collective).
+
+The reference has no multi-GPU BA (its only split is tracker | mapper, examples/slam_demo.py:63-77).
+`torch.distributed` backend: "nccl" (= RCCL) on the GPUs, "gloo" in tests/test_parallel_ba.py.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def partition_by_source(ii, world):
+    """-> list of `world` sorted index arrays into the edge list; all edges with the same source frame land on the
+    same rank; source frames are dealt largest-first to the least loaded rank (deterministic)."""
+    ii = np.asarray(ii, np.int64)
+    frames, counts = np.unique(ii, return_counts=True)
+    order = np.lexsort((frames, -counts))
+    load = np.zeros(world, np.int64)
+    owner = {}
+    for k in order:
+        r = int(np.argmin(load))          # ties -> lowest rank
+        owner[int(frames[k])] = r
+        load[r] += counts[k]
+    ranks = np.array([owner[int(f)] for f in ii], np.int64) if ii.size else np.zeros(0, np.int64)
+    return [np.nonzero(ranks == r)[0] for r in range(world)]
+
+
+def depth_rows(ii_shard, kf0, kf1):
+    """sorted unique depth-map ids a BA over this shard carries: the window frames and the shard's sources
+    (droid_kernels.cu:1702-1710 applied to the shard)."""
+    return np.unique(np.concatenate([np.arange(kf0, kf1), np.asarray(ii_shard, np.int64)]))
+
+
+def shard_eta(eta, kx_all, kx_shard):
+    """rows of the global damping tensor (ordered like kx_all) for a shard's depth maps."""
+    pos = np.searchsorted(kx_all, kx_shard)
+    assert np.array_equal(np.asarray(kx_all)[pos], kx_shard)
+    if isinstance(eta, torch.Tensor):
+        return eta[torch.as_tensor(pos, device=eta.device)].contiguous()
+    return np.ascontiguousarray(np.asarray(eta)[pos])
+
+
+def allreduce_reduced_system(H, v, group=None):
+    """the one exchange step of a sharded BA iteration: in-place sum of the reduced camera system over the ranks"""
+    dist.all_reduce(H, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+    return H, v
+
+
+class ShardedBA:
+    """One rank's part of a sharded dense BA over the edge list (ii, jj) and the pose window [kf0, kf1)."""
+
+    def __init__(self, ii_host, jj_host, kf0, kf1, device, rank=None, world=None, group=None):
+        from . import ba_plan
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.kf0, self.kf1 = int(kf0), int(kf1)
+        ii_host, jj_host = np.asarray(ii_host, np.int64), np.asarray(jj_host, np.int64)
+        self.mine = partition_by_source(ii_host, self.world)[self.rank]
+        self.kx_all = depth_rows(ii_host, kf0, kf1)
+        self.kx = depth_rows(ii_host[self.mine], kf0, kf1)
+        self.plan = ba_plan.BaPlan(ii_host[self.mine], jj_host[self.mine], kf0, kf1, device)
+        self.ii = torch.from_numpy(ii_host[self.mine]).to(device)
+        self.jj = torch.from_numpy(jj_host[self.mine]).to(device)
+        self._sel = torch.from_numpy(self.mine).to(device)
+
+    def iteration(self, poses, disps, intrinsics, extrinsics, disps_sens, targets, weights, eta, world_T_body,
+                  prior_pose=None, clamp_min=0.001, reduce=True):
+        """targets / weights [M,2,ht,wd] and eta [K',HW] are the GLOBAL tensors (replicated inputs); poses / disps are
+        updated in place: poses identically on every rank, disps only for the depth maps this rank owns."""
+        from . import ba_plan
+        H, v, Q, E, w = ba_plan.reduced_camera_matrix(self.plan, poses, disps, intrinsics, extrinsics, disps_sens,
+                                                      targets[self._sel].contiguous(), weights[self._sel].contiguous(),
+                                                      shard_eta(eta, self.kx_all, self.kx), self.ii, self.jj)
+        if reduce and self.world > 1:
+            allreduce_reduced_system(H, v, self.group)
+        sol = ba_plan.ba_solve(H, v, self.kf0, self.kf1, world_T_body, poses, extrinsics, prior_pose=prior_pose)
+        ba_plan.solve_depth(self.plan, sol["dx"], disps, Q, E, w, clamp_min=clamp_min)
+        return sol
+
+    def owned_depth_maps(self):
+        """depth maps whose update on this rank is the real one (sources of this rank's edges)"""
+        return np.unique(self.plan.ii_host)

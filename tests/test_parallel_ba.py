@@ -1,0 +1,115 @@
+"""Sharded BA: the reduced camera system is additive over shards that keep every source frame's
+edges together.  CPU: world_size-2 gloo processes compute their shard with the ORACLE (the HIP kernels need a GPU)
+through the product partition / all-reduce code; GPU: the HIP kernels on shards, summed in one process."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import synth
+
+
+def test_partition_keeps_sources_together():
+    from nerfslam.parallel import partition_by_source
+    rng = np.random.default_rng(0)
+    ii = rng.integers(3, 14, 120)
+    for world in (1, 2, 3, 8):
+        parts = partition_by_source(ii, world)
+        assert sorted(np.concatenate(parts).tolist()) == list(range(120))
+        owners = {}
+        for r, p in enumerate(parts):
+            for f in np.unique(ii[p]):
+                assert owners.setdefault(int(f), r) == r
+        sizes = [len(p) for p in parts]
+        if world in (2, 3):
+            assert max(sizes) - min(sizes) <= np.bincount(ii).max()
+
+
+def _problem():
+    pr = synth.make_problem(ht=12, wd=16, P=6, M=30, seed=3, kf0=3, extra_fixed=1, sensed_frac=0.2)
+    return pr, pr["ii"], pr["jj"]
+
+
+def _inputs(pr, ii, jj, kf0, kf1):
+    from nerfslam.parallel import depth_rows
+    kx = depth_rows(ii, kf0, kf1)
+    return pr["targets"], pr["weights"], pr["eta"].reshape(len(kx), -1), kx
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from nerfslam.parallel import allreduce_reduced_system, depth_rows, partition_by_source, shard_eta
+    pr, ii, jj = _problem()
+    kf0, kf1 = 3, 9
+    targets, weights, eta, kx = _inputs(pr, ii, jj, kf0, kf1)
+    mine = partition_by_source(ii, world)[rank]
+    kx_r = depth_rows(ii[mine], kf0, kf1)
+    H, v, *_ = oracle.reduced_camera_matrix(pr["poses"], pr["disps"], pr["intr"], pr["extr"], pr["disps_sens"],
+                                            targets[mine], weights[mine], shard_eta(eta, kx, kx_r), ii[mine], jj[mine],
+                                            kf0, kf1)
+    Ht, vt = torch.from_numpy(H.copy()), torch.from_numpy(v.copy())
+    allreduce_reduced_system(Ht, vt)
+    Hf, vf, *_ = oracle.reduced_camera_matrix(pr["poses"], pr["disps"], pr["intr"], pr["extr"], pr["disps_sens"], targets,
+                                              weights, eta, ii, jj, kf0, kf1)
+    ok = np.abs(Ht.numpy() - Hf).max() <= 2e-4 * np.abs(Hf).max() and np.abs(vt.numpy() - vf).max() <= 2e-4 * np.abs(vf).max()
+    q.put((rank, bool(ok), len(mine)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world_size_2_sharded_system_equals_full(oracle_mod):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res) and sum(n for _, _, n in res) == 30 and min(n for _, _, n in res) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_hip_shards_sum_to_the_full_system_and_update(dev, world):
+    from nerfslam import ba_plan
+    from nerfslam.parallel import ShardedBA
+    pr, ii, jj = _problem()
+    kf0, kf1 = 3, 9
+    targets, weights, eta, kx = _inputs(pr, ii, jj, kf0, kf1)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    poses, disps, intr, extr, sens = (t(pr[k]) for k in ("poses", "disps", "intr", "extr", "disps_sens"))
+    T, W, ETA = t(targets), t(weights), t(eta)
+    full = ba_plan.BaPlan(ii, jj, kf0, kf1, dev)
+    Hf, vf, Qf, Ef, wf = ba_plan.reduced_camera_matrix(full, poses, disps, intr, extr, sens, T, W, ETA, t(ii), t(jj))
+    shards = [ShardedBA(ii, jj, kf0, kf1, dev, rank=r, world=world) for r in range(world)]
+    Hs, vs = torch.zeros_like(Hf), torch.zeros_like(vf)
+    parts = []
+    for sh in shards:
+        from nerfslam.parallel import shard_eta
+        H, v, Q, E, w = ba_plan.reduced_camera_matrix(sh.plan, poses, disps, intr, extr, sens, T[sh._sel].contiguous(),
+                                                      W[sh._sel].contiguous(), shard_eta(ETA, sh.kx_all, sh.kx), sh.ii, sh.jj)
+        Hs += H; vs += v
+        parts.append((Q, E, w))
+    assert (Hs - Hf).abs().max().item() <= 2e-4 * Hf.abs().max().item()
+    assert (vs - vf).abs().max().item() <= 2e-4 * vf.abs().max().item()
+    # replicated solve on the summed system, local depth updates: the union equals the unsharded update
+    wTb = poses.clone()
+    sol = ba_plan.ba_solve(Hf, vf, kf0, kf1, wTb.clone(), poses.clone(), extr, retract=False)
+    d_full = disps.clone()
+    ba_plan.solve_depth(full, sol["dx"], d_full, Qf, Ef, wf, clamp_min=0.001)
+    d_sh = disps.clone()
+    for sh, (Q, E, w) in zip(shards, parts):
+        d_r = disps.clone()
+        ba_plan.solve_depth(sh.plan, sol["dx"], d_r, Q, E, w, clamp_min=0.001)
+        own = torch.from_numpy(sh.owned_depth_maps()).to(dev)
+        d_sh[own] = d_r[own]
+    touched = torch.from_numpy(np.unique(ii)).to(dev)
+    assert (d_sh[touched] - d_full[touched]).abs().max().item() <= 1e-5 * d_full.abs().max().item()
