@@ -7,8 +7,9 @@ and ships the dirty keyframes with nerfslam.transport; ranks >= 1 train the NeRF
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 examples/slam_demo.py --slam \
         --fusion nerf --parallel_run --multi_gpu ...
 Datasets and the DROID weights are not part of this project: `--dataset_dir` takes a .npz sequence
-(images [N,H,W,3] uint8, intrinsics [4], optional depths [N,H,W]) and `--weights` a TorchScript bundle exposing
-features / update / motion; without them the demo runs on a synthetic orbit and cannot track.
+(images [N,H,W,3] uint8, intrinsics [4], optional depths [N,H,W]) and `--weights` a DROID-SLAM checkpoint
+(`droid.pth`; loaded into nerfslam.droid_nets with the reference's key remapping).  Without a checkpoint the
+networks run with random weights (plumbing only).
 """
 import argparse
 import os
@@ -42,6 +43,7 @@ def parse_args(argv=None):
     p.add_argument("--height", "--screenshot_h", type=int, default=0)
     p.add_argument("--network", default="")
     p.add_argument("--eval", action="store_true")
+    p.add_argument("--stop_iters", type=int, default=25000, help="NeRF training iterations (nerf_fusion.py:54 hard-codes 25000)")
     return p.parse_args(argv)
 
 
@@ -57,7 +59,7 @@ def load_sequence(args):
                "is_last_frame": k == ks[-1]}
 
 
-def run(args):
+def run(args, return_modules=False, tweak=None):
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     split = args.parallel_run and args.multi_gpu and world > 1
     if split:
@@ -81,7 +83,11 @@ def run(args):
     data.register_output_queue(data_q)
     slam = fusion = None
     if args.slam:
-        args_seq.networks = torch.jit.load(args.weights, map_location=dev)
+        from nerfslam.droid_nets import DroidNetworks
+        have = os.path.exists(args.weights)
+        if not have:
+            print(f"slam_demo: {args.weights} not found -- running the DROID architecture with RANDOM weights (no tracking accuracy)")
+        args_seq.networks = DroidNetworks(dev, weights=args.weights if have else None, buffer=args.buffer)
         slam = SlamModule("VioSLAM", args_seq, device=dev)
         slam.register_input_queue("data", data_q)
         if split:
@@ -91,10 +97,15 @@ def run(args):
         if slam:
             slam.register_output_queue(slam_q)
             fusion.register_input_queue("slam", slam_q)
+    if slam is not None and tweak is not None:
+        slam.initialize_module()
+        tweak(slam)
     while data.spin() and (slam is None or slam.spin()) and (fusion is None or fusion.spin()):
         pass
     while fusion is not None and not fusion.shutdown and fusion.spin():
         pass
+    if return_modules:
+        return {"data": data, "slam": slam, "fusion": fusion}
 
 
 if __name__ == "__main__":

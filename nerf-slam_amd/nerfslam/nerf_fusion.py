@@ -21,7 +21,8 @@ class NerfFusion:
     def __init__(self, name, args, device):
         import pyngp as ngp
         self.name, self.args, self.device = name, args, torch.device(device)
-        self.iters_if_none, self.total_iters, self.stop_iters = 1, 0, 25000   # :51-54
+        self.iters_if_none, self.total_iters = 1, 0                           # :51-54
+        self.stop_iters = getattr(args, "stop_iters", 25000)
         dev_index = self.device.index if self.device.index is not None else 0
         self.ngp = ngp.Testbed(ngp.TestbedMode.Nerf, dev_index)
         self.ngp.create_empty_nerf_dataset(args.buffer, 1.0, np.array([np.inf] * 3), 4, None)    # :67-72

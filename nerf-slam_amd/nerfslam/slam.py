@@ -12,7 +12,9 @@ VioSLAM (/root/reference/slam/vio_slam.py:78-127: `slam(batch) -> [state, viz_ou
 The learned networks are injected through `args.networks` (see nerfslam.frontend docstring):
     networks.features(image_u8 [3,H,W]) -> fmap [128,H/8,W/8]
     networks.update(corr, motion, ii, jj) -> (delta, weight, damping)
-    networks.motion(corr [1,1,196,ht,wd]) -> delta [1,1,ht,wd,2]       (motion filter, :978-1008)
+    networks.motion(corr [1,1,196,ht,wd], last_kf) -> delta [1,1,ht,wd,2]   (motion filter, :978-1008)
+    optional hooks: networks.begin_keyframe(k, image_u8), networks.remove_keyframe(k)   (context features, hidden states)
+nerfslam.droid_nets.DroidNetworks provides all of them on top of the DROID architecture (random or loaded weights).
 The GTSAM Values / NonlinearFactorGraph the reference returns empty (:248-250) are returned as None.
 """
 import numpy as np
@@ -32,6 +34,7 @@ class TrackingSLAM:
         self.buffer = args.buffer
         self.global_ba = getattr(args, "slam", True) and getattr(args, "global_ba", True)
         self.keyframe_warmup, self.motion_filter_thresh = 8, 2.4           # :93-95
+        self.keyframe_thresh = None                                        # None: the frontend's default (4.0, :110)
         self.iters1, self.iters2 = 4, 2                                    # :101-102
         self.backend_thresh, self.backend_radius, self.backend_nms = 22.0, 2, 3
         self.fe = None
@@ -51,6 +54,8 @@ class TrackingSLAM:
     def _store(self, k, data, fmap):
         fe = self.fe
         fe.set_keyframe(fe.kf_idx, data["image_u8"], fmap)
+        if hasattr(self.net, "begin_keyframe"):
+            self.net.begin_keyframe(fe.kf_idx, data["image_u8"])
         depth = data.get("depth")
         if depth is not None:                                              # sensed depth -> 1/8-res inverse depth (:297-305)
             d = torch.as_tensor(depth, dtype=torch.float32, device=self.device)[3::8, 3::8]
@@ -63,7 +68,7 @@ class TrackingSLAM:
         f1 = fe.feat_bank[self.last_kf][None]                              # channels-last half, already / 4
         f2 = (fmap.to(self.device).half().reshape(128, fe.HW) / 4.0).t().contiguous()[None]
         corr = CorrBlock.from_pyramid(CorrBlock.build_pyramid(f1, f2, None, None, 1, fe.ht, fe.wd))(fe.coords0[None, None])
-        delta = self.net.motion(corr)
+        delta = self.net.motion(corr, self.last_kf)
         return float(delta.norm(dim=-1).mean()) > self.motion_filter_thresh
 
     def _frontend(self, data):
@@ -77,6 +82,8 @@ class TrackingSLAM:
                               else data["calibs"][0], np.float32)
             self.fe = TrackingFrontend(self.buffer, img.shape[1], img.shape[2], intr, self.device,
                                        feature_fn=self.net.features, update_op=self.net.update)
+            if self.keyframe_thresh is not None:
+                self.fe.keyframe_thresh = self.keyframe_thresh
             self._store(k, data, None)
             self.fe.prior_pose = self.fe.world_T_body[0].clone()           # frame-0 prior (:1089-1095, :1234-1253)
             self.last_k, self.last_kf = k, 0
@@ -165,6 +172,8 @@ class TrackingSLAM:
         for buf in (fe.images, fe.cam0_T_world, fe.world_T_body, fe.world_T_body_cov, fe.cam0_idepths, fe.cam0_idepths_cov,
                     fe.cam0_depths_cov, fe.cam0_idepths_sensed, fe.feat_bank):
             buf[k] = buf[k + 1]
+        if hasattr(self.net, "remove_keyframe"):
+            self.net.remove_keyframe(k)
         if k + 1 in self.kf_to_frame:       # (the reference leaves its kf -> frame table stale here)
             self.kf_to_frame[k] = self.kf_to_frame.pop(k + 1)
         keep_inactive, drop_active = fe.graph.remove_keyframe(k)

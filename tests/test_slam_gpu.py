@@ -35,7 +35,7 @@ def test_state_machine_runs_and_tracks(dev):
             g = torch.Generator(device="cpu").manual_seed(int(img[0, 0, 0].item()))
             return torch.randn((128, ht, wd), generator=g).to(dev)
 
-        def motion(self, corr):
+        def motion(self, corr, last_kf):
             assert corr.shape == (1, 1, 196, ht, wd)
             return torch.full((1, 1, ht, wd, 2), 3.0, device=dev)        # always "enough motion"
 
@@ -76,3 +76,51 @@ def test_state_machine_runs_and_tracks(dev):
     # sensed depth on frame 0 fixes the scale -> the trajectory must match the ground truth
     dT = se3.log_wv(se3.mul(fe.cam0_T_world[:n].double(), se3.inv(gtP[:n].double())))
     assert dT.abs().max().item() < 2e-2, dT.abs().max()
+
+
+def test_end_to_end_with_the_droid_architecture(dev):
+    """the same state machine driven by the real network architecture (random weights: plumbing and shapes, no accuracy
+    claim): encoders + ConvGRU through MIOpen under autocast, hidden-state bookkeeping across edge add / remove"""
+    from nerfslam.droid_nets import DroidNetworks
+    from nerfslam.slam import TrackingSLAM
+    H, W, nfr = 96, 128, 12
+    g = torch.Generator().manual_seed(0)
+    nets = DroidNetworks(dev, weights=None, seed=0)
+    slam = TrackingSLAM("VioSLAM", argparse.Namespace(buffer=16, networks=nets, slam=True, global_ba=True), dev)
+    slam.motion_filter_thresh = -1.0                     # untrained motion head: accept every frame
+    intr = np.array([100.0, 100.0, W / 2, H / 2], np.float32)
+    base = torch.randint(0, 255, (H + 40, W + 40, 3), generator=g, dtype=torch.uint8).numpy()
+    n_packets = 0
+    for k in range(nfr):
+        img = np.concatenate([base[2 * k:2 * k + H, 3 * k:3 * k + W], np.full((H, W, 1), 255, np.uint8)], -1)
+        out = slam({"data": {"k": [k], "images": [img], "calibs": [intr], "depths": [None], "is_last_frame": k == nfr - 1}})
+        assert out is not False
+        n_packets += out[1] is not None
+        if k == 0:
+            slam.fe.keyframe_thresh = -1.0               # ... and keep every keyframe
+    fe = slam.fe
+    assert slam.is_initialized and slam.stop_condition() and fe.kf_idx == nfr - 1 and n_packets >= nfr - 1
+    assert torch.isfinite(fe.cam0_T_world[:nfr]).all() and torch.isfinite(fe.cam0_idepths[:nfr]).all()
+    assert (fe.cam0_idepths[:nfr] >= 0.001 - 1e-6).all()
+
+
+def test_demo_driver_sequential_slam_plus_nerf(dev, tmp_path):
+    """examples/slam_demo.py wiring (DataModule -> SlamModule -> FusionModule, sequential mode) on a tiny .npz sequence:
+    the tracker's packets reach the NeRF trainer, which trains on them until its stop condition"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("slam_demo", os.path.join(os.path.dirname(__file__), "..", "examples", "slam_demo.py"))
+    demo = importlib.util.module_from_spec(spec); spec.loader.exec_module(demo)
+    H, W, n = 96, 128, 11
+    g = np.random.default_rng(0)
+    base = g.integers(0, 255, (H + 40, W + 40, 3), dtype=np.uint8)
+    imgs = np.stack([base[2 * k:2 * k + H, 3 * k:3 * k + W] for k in range(n)])
+    seq = tmp_path / "seq.npz"
+    np.savez(seq, images=imgs, intrinsics=np.array([100.0, 100.0, W / 2, H / 2], np.float32))
+    args = demo.parse_args(["--slam", "--fusion", "nerf", "--dataset_dir", str(seq), "--buffer", "16", "--weights", "/nonexistent.pth",
+                            "--stop_iters", "400"])      # enough trainer spins for all 11 frames to pass through first
+    mods = demo.run(args, return_modules=True, tweak=lambda m: (setattr(m.slam, "motion_filter_thresh", -1.0), setattr(m.slam, "keyframe_thresh", -1.0)))
+    slam, fusion = mods["slam"], mods["fusion"]
+    assert slam.shutdown and fusion.shutdown
+    assert fusion.fusion.ngp.nerf.training.n_images_for_training >= 9 and fusion.fusion.total_iters > 400
+    assert np.isfinite(fusion.fusion.ngp.loss)

@@ -141,6 +141,43 @@ def main():
     # float32 run of the same reference code: the unrounded volume (for the 1-ulp statement)
     blk32 = CorrBlock(f1.float(), f2.float())
     np.savez_compressed(os.path.join(out, "corr_pyramid_f32_level0.npz"), level0=blk32.corr_pyramid[0].numpy())
+    # ---- (4) the learned modules: parameter names / shapes and seeded forward passes of the REFERENCE's
+    # BasicEncoder / UpdateModule (droid_net.py, extractor.py, gru.py) -> pins nerfslam/droid_nets.py ----
+    ts = types.ModuleType("torch_scatter")
+    def scatter_mean(src, index, dim=1):
+        k = int(index.max()) + 1
+        shape = list(src.shape); shape[dim] = k
+        s = torch.zeros(shape, dtype=src.dtype).index_add_(dim, index, src)
+        c = torch.zeros(k, dtype=src.dtype).index_add_(0, index, torch.ones_like(index, dtype=src.dtype))
+        return s / c.view([-1 if d == dim else 1 for d in range(src.dim())])
+    ts.scatter_mean = scatter_mean
+    ts.scatter_sum = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())   # import-time need of geom/ba.py only
+    sys.modules["torch_scatter"] = ts
+    from networks.droid_net import DroidNet as RefDroidNet   # REFERENCE code
+    import zlib
+    ref = RefDroidNet().eval()
+    sd = ref.state_dict()
+    for k in sd:                                              # deterministic weights keyed by parameter name
+        gk = torch.Generator().manual_seed(zlib.crc32(k.encode()))
+        sd[k] = torch.randn(sd[k].shape, generator=gk) * (0.3 / max(1.0, float(np.sqrt(sd[k][0].numel()))))
+    ref.load_state_dict(sd)
+    g = torch.Generator().manual_seed(24)
+    img = torch.randn((1, 2, 3, 32, 48), generator=g)
+    net = torch.randn((1, 3, 128, 4, 6), generator=g) * 0.5
+    inp = torch.randn((1, 3, 128, 4, 6), generator=g) * 0.5
+    corr = torch.randn((1, 3, 196, 4, 6), generator=g)
+    flow = torch.randn((1, 3, 4, 4, 6), generator=g)
+    ii, jj = torch.tensor([0, 0, 1]), torch.tensor([1, 2, 0])
+    with torch.no_grad():
+        fm, cm = ref.feature_net(img), ref.context_net(img)
+        h, delta, weight, eta, upmask = ref.update_net(net, inp, corr, flow, ii, jj)
+        _, d0, w0 = ref.update_net(net[:, :1], inp[:, :1], corr[:, :1])
+    import json
+    json.dump({k: list(v.shape) for k, v in sd.items()}, open(os.path.join(out, "droid_state_dict_shapes.json"), "w"), indent=0)
+    np.savez_compressed(os.path.join(out, "droid_nets_forward.npz"), img=img.numpy(), net=net.numpy(), inp=inp.numpy(),
+                        corr=corr.numpy(), flow=flow.numpy(), ii=ii.numpy(), jj=jj.numpy(), fmap=fm.numpy(), cmap=cm.numpy(),
+                        h=h.numpy(), delta=delta.numpy(), weight=weight.numpy(), eta=eta.numpy(),
+                        upmask=upmask.numpy()[:, :, ::16], delta_noflow=d0.numpy(), weight_noflow=w0.numpy())
     for f in sorted(os.listdir(out)):
         print(f, os.path.getsize(os.path.join(out, f)))
 
