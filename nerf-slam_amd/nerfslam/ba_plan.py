@@ -121,17 +121,18 @@ MAX_SMALL_SYSTEM_COV = 108  # ... when the identity border rows (L^-1) must fit 
 
 
 def ba_solve(H, v, kf0, kf1, world_T_body=None, cam_T_world=None, cam_T_body=None, prior_pose=None,
-             prior_sigma=1e-4, ep=0.0, lm=0.0, retract=True, want_cov=False):
+             prior_sigma=1e-4, ep=0.0, lm=0.0, retract=True, want_cov=False, want_hfull=False):
     """Device-resident replacement of the GTSAM round trip (visual_frontend.py:1123-1158).
 
     Solves (H [+prior]) dx = v in f64, optionally retracts world_T_body / recomputes cam_T_world in place.
-    Returns dict(dx [P,6], info [1] int32, Hfull [n,n] f64, Linv [n,n] f32|None, sigma_g [P,6,6]|None)."""
+    Returns dict(dx [P,6], info [1] int32, Hfull [n,n] f64|None (the damped system, on request), Linv [n,n] f32|None,
+    sigma_g [P,6,6]|None)."""
     dev = H.device
     P = int(kf1) - int(kf0)
     n = 6 * P
     dx = torch.empty((P, 6), dtype=torch.float32, device=dev)
     info = torch.empty((1,), dtype=torch.int32, device=dev)
-    Hfull = torch.empty((n, n), dtype=torch.float64, device=dev)
+    Hfull = torch.empty((n, n), dtype=torch.float64, device=dev) if want_hfull else None
     Linv = torch.empty((n, n), dtype=torch.float32, device=dev) if want_cov else None
     Lws = None
     sig = torch.empty((P, 6, 6), dtype=torch.float32, device=dev) if want_cov else None

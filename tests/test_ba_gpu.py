@@ -132,7 +132,7 @@ def test_ba_solve_retract(oracle_mod, dev, cfg, with_prior):
                                                                  kf0, kf1, prior_pose=prior)
     wd_, cd_ = T(wTb, dev), T(p["poses"], dev).clone()
     sol = ba_plan.ba_solve(H, got[1], kf0, kf1, wd_, cd_, T(p["extr"], dev),
-                           prior_pose=None if prior is None else T(prior, dev), want_cov=True)
+                           prior_pose=None if prior is None else T(prior, dev), want_cov=True, want_hfull=True)
     assert sol["info"].item() == 0
     close(sol["Hfull"], Hfull, 1e-12, "Hfull")
     close(sol["dx"], delta.astype(np.float32), 1e-4, "dx")
