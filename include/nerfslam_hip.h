@@ -273,7 +273,21 @@ int ns_ngp_adam(float* master, void* half_params, float* grad, float* m1, float*
 int ns_ngp_sample_rays(const float* images, const float* depths, const float* depth_covs, const float* c2w,
                        int n_images, int H, int W, float fx, float fy, float cx, float cy, float box_lo, float box_hi,
                        float near, unsigned seed, int R, float* rays_o, float* rays_d, float* t_range, float* gt_rgb,
-                       float* gt_depth, float* gt_depth_cov, void* stream);
+                       float* gt_depth, float* gt_depth_cov, int* ray_img /* optional [R] */, void* stream);
+
+/* camera-pose refinement (`optimize_extrinsics`, nerf_fusion.py:99,123; arithmetic [EXTERNAL]):
+ * (1) dLdpos [N,3] = gradient of the loss w.r.t. the unit-cube sample positions through the hash encoding
+ *     (dLdoutT [n_levels*2, N] f16 unit-major = what ns_ngp_mlp_backward wrote);
+ * (2) per ray g_o = sum dL/dp, g_d = sum t dL/dp (dL/dp = dLdpos * pos_inv), added into cam_grad[ray_img][6] =
+ *     (sum g_o, sum d x g_d): gradient w.r.t. the camera translation and a left rotation perturbation exp(w) R;
+ * (3) Adam on the 6 dof of every image that received gradient, c2w [n,3,4] <- [exp(dw) R | t + dt]; clears cam_grad. */
+int ns_ngp_encode_backward_input(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                                 const float* positions, const void* params, const void* dLdoutT, float* dLdpos, long N,
+                                 void* stream);
+int ns_ngp_camera_gradient(const float* dLdpos, const float* tmid, const float* rays_d, const int* ray_start,
+                           const int* ray_n, const int* ray_img, float pos_inv, float* cam_grad, int R, void* stream);
+int ns_ngp_camera_step(float* c2w, float* cam_grad, float* m1, float* m2, int n_images, int step, float lr_pos,
+                       float lr_rot, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 /* occupancy-grid ray marching: bits = ncasc cascades of G^3 bits; rays_o/rays_d [R,3] (unit dirs),
  * t_range [R,2].  counter[3] (zeroed by the caller) receives (#samples requested by all rays,

@@ -251,6 +251,137 @@ __global__ __launch_bounds__(256) void ngp_encode_bwd_kernel(GridLayout g, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Camera-pose refinement (`optimize_extrinsics`, nerf_fusion.py:99,123 [EXTERNAL arithmetic: instant-ngp]).
+//   dL/dpos of every sample  = the encoding's input gradient (trilinear weights differentiated),
+//   per ray:  g_o = sum dL/dpos,   g_d = sum t * dL/dpos            (pos = o + t d)
+//   per image: dL/d(translation) = sum g_o,   dL/d(rotation, left perturbation exp(w) R) = sum d x g_d
+//   Adam on the 6 dof of every image, applied as c2w <- [exp(dw) R | t + dt].
+// ---------------------------------------------------------------------------------------------
+// one lane per sample, loop over the levels (no atomics); positions in the unit cube; dLdfeatT unit-major [2L][N];
+// out[N,3] = dL/d(unit position)
+__global__ __launch_bounds__(256) void ngp_encode_bwd_input_kernel(GridLayout g, const float* __restrict__ pos,
+                                                                   const h2_t* __restrict__ params,
+                                                                   const _Float16* __restrict__ dLdfeatT,
+                                                                   float* __restrict__ dLdpos, long N, int L) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float px = pos[i * 3], py = pos[i * 3 + 1], pz = pos[i * 3 + 2];
+  float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+  for (int l = 0; l < L; l++) {
+    const float d0 = (float)dLdfeatT[(long)(2 * l) * N + i], d1 = (float)dLdfeatT[(long)(2 * l + 1) * N + i];
+    if (d0 == 0.0f && d1 == 0.0f) continue;
+    const uint32_t hs = g.offset[l + 1] - g.offset[l];
+    const float scale = g.scale[l];
+    const uint32_t res = (uint32_t)g.res[l];
+    float w[3];
+    uint32_t c[3];
+    const float pp[3] = {px, py, pz};
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const float p = fmaf(scale, pp[d], 0.5f);
+      const float fl = floorf(p);
+      c[d] = (uint32_t)(int)fl;
+      w[d] = p - fl;
+    }
+    const h2_t* __restrict__ tab = params + g.offset[l];
+    float s[8];  // dL/dfeat . value of corner
+#pragma unroll
+    for (int corner = 0; corner < 8; corner++) {
+      const h2_t v = tab[grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2))];
+      s[corner] = d0 * (float)v[0] + d1 * (float)v[1];
+    }
+    // d/dx of sum_c wx(c) wy(c) wz(c) s_c = sum over the 4 (y,z) edges of wy wz (s_{x=1} - s_{x=0}), times scale
+    const float wy0 = 1.0f - w[1], wy1 = w[1], wz0 = 1.0f - w[2], wz1 = w[2], wx0 = 1.0f - w[0], wx1 = w[0];
+    gx += scale * (wy0 * wz0 * (s[1] - s[0]) + wy1 * wz0 * (s[3] - s[2]) + wy0 * wz1 * (s[5] - s[4]) + wy1 * wz1 * (s[7] - s[6]));
+    gy += scale * (wx0 * wz0 * (s[2] - s[0]) + wx1 * wz0 * (s[3] - s[1]) + wx0 * wz1 * (s[6] - s[4]) + wx1 * wz1 * (s[7] - s[5]));
+    gz += scale * (wx0 * wy0 * (s[4] - s[0]) + wx1 * wy0 * (s[5] - s[1]) + wx0 * wy1 * (s[6] - s[2]) + wx1 * wy1 * (s[7] - s[3]));
+  }
+  dLdpos[i * 3] = gx;
+  dLdpos[i * 3 + 1] = gy;
+  dLdpos[i * 3 + 2] = gz;
+}
+
+// one wave per ray: reduce the sample gradients to the 6-dof gradient of the ray's camera, atomically into cam_grad[img]
+__global__ __launch_bounds__(256) void ngp_camera_grad_kernel(const float* __restrict__ dLdpos, const float* __restrict__ tmid,
+                                                              const float* __restrict__ rays_d,
+                                                              const int* __restrict__ ray_start, const int* __restrict__ ray_n,
+                                                              const int* __restrict__ ray_img, float pos_inv,
+                                                              float* __restrict__ cam_grad, int R) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int s0 = ray_start[r], n = ray_n[r];
+  if (n <= 0) return;
+  float o0 = 0, o1 = 0, o2 = 0, d0 = 0, d1 = 0, d2 = 0;
+  for (int k = lane; k < n; k += 64) {
+    const long s = (long)s0 + k;
+    const float t = tmid[s];
+    const float a = dLdpos[s * 3] * pos_inv, b = dLdpos[s * 3 + 1] * pos_inv, c = dLdpos[s * 3 + 2] * pos_inv;
+    o0 += a; o1 += b; o2 += c;
+    d0 += t * a; d1 += t * b; d2 += t * c;
+  }
+  o0 = wave_sum(o0); o1 = wave_sum(o1); o2 = wave_sum(o2);
+  d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
+  if (lane == 0) {
+    const float x = rays_d[r * 3], y = rays_d[r * 3 + 1], z = rays_d[r * 3 + 2];
+    float* gp = cam_grad + (long)ray_img[r] * 6;
+    atomicAdd(gp + 0, o0);
+    atomicAdd(gp + 1, o1);
+    atomicAdd(gp + 2, o2);
+    atomicAdd(gp + 3, y * d2 - z * d1);  // d x g_d
+    atomicAdd(gp + 4, z * d0 - x * d2);
+    atomicAdd(gp + 5, x * d1 - y * d0);
+  }
+}
+
+// one lane per image: Adam on (dt, dw), then c2w <- [exp(dw) R | t + dt]; clears the gradient
+__global__ __launch_bounds__(64) void ngp_camera_step_kernel(float* __restrict__ c2w, float* __restrict__ cam_grad,
+                                                             float* __restrict__ m1, float* __restrict__ m2, int n, float c1,
+                                                             float c2, float lr_pos, float lr_rot, float beta1, float beta2,
+                                                             float eps, float inv_grad_scale) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  float step[6];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float gk = cam_grad[i * 6 + k] * inv_grad_scale;
+    cam_grad[i * 6 + k] = 0.0f;
+    step[k] = 0.0f;
+    if (gk != 0.0f) {
+      any = true;
+      const float a = beta1 * m1[i * 6 + k] + (1.0f - beta1) * gk;
+      const float b = beta2 * m2[i * 6 + k] + (1.0f - beta2) * gk * gk;
+      m1[i * 6 + k] = a;
+      m2[i * 6 + k] = b;
+      step[k] = -(k < 3 ? lr_pos : lr_rot) * (a / c1) / (sqrtf(b / c2) + eps);
+    }
+  }
+  if (!any) return;  // image not hit by a ray this step
+  float* M = c2w + (long)i * 12;
+  M[3] += step[0];
+  M[7] += step[1];
+  M[11] += step[2];
+  // Rodrigues: exp(w) = I + sin(th)/th K + (1 - cos th)/th^2 K^2
+  const float wx = step[3], wy = step[4], wz = step[5];
+  const float th2 = wx * wx + wy * wy + wz * wz, th = sqrtf(th2);
+  const float A = th < 1e-6f ? 1.0f - th2 / 6.0f : sinf(th) / th;
+  const float B = th < 1e-6f ? 0.5f - th2 / 24.0f : (1.0f - cosf(th)) / th2;
+  const float E[9] = {1.0f - B * (wy * wy + wz * wz), B * wx * wy - A * wz,        B * wx * wz + A * wy,
+                      B * wx * wy + A * wz,        1.0f - B * (wx * wx + wz * wz), B * wy * wz - A * wx,
+                      B * wx * wz - A * wy,        B * wy * wz + A * wx,        1.0f - B * (wx * wx + wy * wy)};
+  float Rn[9];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) Rn[a * 3 + b] = E[a * 3] * M[b] + E[a * 3 + 1] * M[4 + b] + E[a * 3 + 2] * M[8 + b];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) M[a * 4 + b] = Rn[a * 3 + b];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Adam: f32 master parameters + moments, f16 working copy refreshed (tiny-cuda-nn semantics:
 // entries with a zero gradient and no weight decay are skipped so untouched hash cells keep their
 // moments).  One streaming pass, float4-vectorised.
@@ -306,6 +437,7 @@ struct SampleRaysArgs {
   int n, H, W, R;
   uint32_t seed;
   float *rays_o, *rays_d, *t_range, *gt_rgb, *gt_depth, *gt_cov;
+  int* ray_img;  // optional [R]: image index of every ray (camera-pose refinement)
 };
 
 __global__ __launch_bounds__(256) void ngp_sample_rays_kernel(SampleRaysArgs a) {
@@ -347,6 +479,7 @@ __global__ __launch_bounds__(256) void ngp_sample_rays_kernel(SampleRaysArgs a) 
   a.gt_rgb[r * 3 + 2] = a.images[pix * 4 + 2];
   a.gt_depth[r] = a.depths[pix];
   a.gt_cov[r] = fmaxf(a.covs[pix], 1e-6f);
+  if (a.ray_img != nullptr) a.ray_img[r] = img;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -786,17 +919,58 @@ extern "C" int ns_ngp_adam(float* master, void* half_params, float* grad, float*
   return NS_OK;
 }
 
+extern "C" int ns_ngp_encode_backward_input(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                            float per_level_scale, const float* positions, const void* params,
+                                            const void* dLdoutT, float* dLdpos, long N, void* stream) {
+  NS_REQUIRE(positions && params && dLdoutT && dLdpos, "ns_ngp_encode_backward_input: null pointer");
+  GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
+  GridLayout g;
+  if (grid_layout_host(c, g) != NS_OK) {
+    ns_set_error("ns_ngp_encode_backward_input: need 1..16 levels and 2 features per level");
+    return NS_ENOSUP;
+  }
+  if (N <= 0) return NS_OK;
+  hipLaunchKernelGGL(ngp_encode_bwd_input_kernel, dim3(ns_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, g, positions,
+                     (const h2_t*)params, (const _Float16*)dLdoutT, dLdpos, N, n_levels);
+  NS_CHECK_LAUNCH("ngp_encode_bwd_input_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_ngp_camera_gradient(const float* dLdpos, const float* tmid, const float* rays_d, const int* ray_start,
+                                      const int* ray_n, const int* ray_img, float pos_inv, float* cam_grad, int R,
+                                      void* stream) {
+  NS_REQUIRE(dLdpos && tmid && rays_d && ray_start && ray_n && ray_img && cam_grad, "ns_ngp_camera_gradient: null pointer");
+  if (R <= 0) return NS_OK;
+  hipLaunchKernelGGL(ngp_camera_grad_kernel, dim3(ns_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, dLdpos, tmid, rays_d,
+                     ray_start, ray_n, ray_img, pos_inv, cam_grad, R);
+  NS_CHECK_LAUNCH("ngp_camera_grad_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_ngp_camera_step(float* c2w, float* cam_grad, float* m1, float* m2, int n_images, int step, float lr_pos,
+                                  float lr_rot, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  NS_REQUIRE(c2w && cam_grad && m1 && m2, "ns_ngp_camera_step: null pointer");
+  NS_REQUIRE(step >= 1 && grad_scale > 0.0f, "ns_ngp_camera_step: step must be >= 1 and grad_scale > 0");
+  if (n_images <= 0) return NS_OK;
+  const float c1 = 1.0f - powf(beta1, (float)step), c2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(ngp_camera_step_kernel, dim3(ns_cdiv(n_images, 64)), dim3(64), 0, (hipStream_t)stream, c2w, cam_grad,
+                     m1, m2, n_images, c1, c2, lr_pos, lr_rot, beta1, beta2, eps, 1.0f / grad_scale);
+  NS_CHECK_LAUNCH("ngp_camera_step_kernel");
+  return NS_OK;
+}
+
 extern "C" int ns_ngp_sample_rays(const float* images, const float* depths, const float* depth_covs, const float* c2w,
                                   int n_images, int H, int W, float fx, float fy, float cx, float cy, float box_lo,
                                   float box_hi, float near, unsigned seed, int R, float* rays_o, float* rays_d,
-                                  float* t_range, float* gt_rgb, float* gt_depth, float* gt_depth_cov, void* stream) {
+                                  float* t_range, float* gt_rgb, float* gt_depth, float* gt_depth_cov, int* ray_img,
+                                  void* stream) {
   NS_REQUIRE(images && depths && depth_covs && c2w && rays_o && rays_d && t_range && gt_rgb && gt_depth && gt_depth_cov,
              "ns_ngp_sample_rays: null pointer");
   NS_REQUIRE(n_images > 0 && H > 0 && W > 0 && fx != 0.0f && fy != 0.0f && box_hi > box_lo,
              "ns_ngp_sample_rays: bad image set / intrinsics / box");
   if (R <= 0) return NS_OK;
   SampleRaysArgs a{images, depths, depth_covs, c2w, fx, fy, cx, cy, box_lo, box_hi, near, n_images, H, W, R, seed,
-                   rays_o, rays_d, t_range, gt_rgb, gt_depth, gt_depth_cov};
+                   rays_o, rays_d, t_range, gt_rgb, gt_depth, gt_depth_cov, ray_img};
   hipLaunchKernelGGL(ngp_sample_rays_kernel, dim3(ns_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, a);
   NS_CHECK_LAUNCH("ngp_sample_rays_kernel");
   return NS_OK;

@@ -50,6 +50,9 @@ class NgpConfig:
     min_optical_thickness: float = 0.01
     near: float = 0.05
     wgrad_ksplit: int = 256
+    optimize_extrinsics: bool = False    # nerf_fusion.py:99 sets it; refine c2w of the training views
+    extrinsic_lr_pos: float = 1e-4       # scene units per step (Adam)
+    extrinsic_lr_rot: float = 1e-4       # radians per step (Adam)
     grad_fixed_scale: float = 262144.0   # hash-grid gradients accumulate as packed Q18 fixed point (0: f32 atomics)
 
     @property
@@ -193,6 +196,7 @@ class NgpNerf:
             f = dict(dtype=torch.float32, device=dev)
             o, d, tr = torch.empty((R, 3), **f), torch.empty((R, 3), **f), torch.empty((R, 2), **f)
             gt_rgb, gt_depth, gt_cov = torch.empty((R, 3), **f), torch.empty(R, **f), torch.empty(R, **f)
+            ray_img = torch.empty(R, dtype=torch.int32, device=dev) if c.optimize_extrinsics else None
             s = float(c.aabb_scale)
             fx, fy, cx, cy = self.intr
             seed = (self.seed * 0x9E3779B1 + self.step * 0x85EBCA77) & 0xFFFFFFFF
@@ -200,7 +204,7 @@ class NgpNerf:
                                            C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
                                            C.c_float(0.5 - 0.5 * s), C.c_float(0.5 + 0.5 * s), C.c_float(c.near),
                                            C.c_uint32(seed), R, ptr(o), ptr(d), ptr(tr), ptr(gt_rgb), ptr(gt_depth),
-                                           ptr(gt_cov), stream_ptr()), "ngp_sample_rays")
+                                           ptr(gt_cov), ptr(ray_img), stream_ptr()), "ngp_sample_rays")
             N = self.march(o, d, tr, unit=True)   # positions come back in unit-cube coordinates
             # keep the sample budget filled without refusing rays (instant-ngp adapts its rays per batch likewise)
             want = R * 0.9 * c.max_samples / max(self.samples_requested, 1)
@@ -238,6 +242,8 @@ class NgpNerf:
             check(lib().ns_ngp_encode_backward(*self._grid_args(), ptr(pos_unit), ptr(dfeatT), 1,
                                                ptr(self.grid_grad), ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(N8),
                                                stream_ptr()), "ngp_encode_backward")
+            if c.optimize_extrinsics:
+                self._camera_backward(pos_unit, dfeatT, d, ray_img, N8, R)
             # optimiser
             self.step += 1
             for (m, hp, g, m1, m2, l2, fx) in (
@@ -251,6 +257,24 @@ class NgpNerf:
             self.loss_tensor = loss / (self.ray_n >= 0).sum().clamp(min=1)
             self.last_samples, self.last_rays = N, R
         return self.loss_tensor
+
+    def _camera_backward(self, pos_unit, dfeatT, rays_d, ray_img, N, R):
+        """pose refinement: sample-position gradients through the encoding -> per-image 6-dof gradient -> Adam on c2w"""
+        c, dev = self.cfg, self.device
+        n = self.n_images
+        if getattr(self, "cam_grad", None) is None or self.cam_grad.shape[0] != n:
+            f = dict(dtype=torch.float32, device=dev)
+            self.cam_grad, self.cam_m1, self.cam_m2 = torch.zeros((n, 6), **f), torch.zeros((n, 6), **f), torch.zeros((n, 6), **f)
+        dpos = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        check(lib().ns_ngp_encode_backward_input(*self._grid_args(), ptr(pos_unit), ptr(self.grid_half), ptr(dfeatT), ptr(dpos),
+                                                 C.c_long(N), stream_ptr()), "ngp_encode_backward_input")
+        check(lib().ns_ngp_camera_gradient(ptr(dpos), ptr(self.s_t), ptr(rays_d), ptr(self.ray_start), ptr(self.ray_n),
+                                           ptr(ray_img), C.c_float(1.0 / float(c.aabb_scale)), ptr(self.cam_grad), R,
+                                           stream_ptr()), "ngp_camera_gradient")
+        check(lib().ns_ngp_camera_step(ptr(self.c2w), ptr(self.cam_grad), ptr(self.cam_m1), ptr(self.cam_m2), n, self.step + 1,
+                                       C.c_float(c.extrinsic_lr_pos), C.c_float(c.extrinsic_lr_rot), C.c_float(c.beta1),
+                                       C.c_float(c.beta2), C.c_float(c.eps), C.c_float(c.loss_scale), stream_ptr()),
+              "ngp_camera_step")
 
     # ------------------------------------------------------------------------------------------
     def density_at(self, pos_scene):

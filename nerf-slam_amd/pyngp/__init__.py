@@ -54,11 +54,20 @@ class _Training:
     def __init__(self, owner):
         self._o = owner
         self.n_images_for_training = 0
-        self.optimize_extrinsics = False   # accepted; pose refinement is not implemented
+        self.extrinsic_learning_rate = 1e-4
         self.depth_loss_type = LossType.L2
         self.near_distance = 0.05
         self.density_grid_decay = 0.95
         self.dataset = _Dataset()
+
+    @property
+    def optimize_extrinsics(self):
+        """camera-pose refinement of the training views (nerf_fusion.py:99,123)"""
+        return self._o._cfg.optimize_extrinsics
+
+    @optimize_extrinsics.setter
+    def optimize_extrinsics(self, v):
+        self._o._cfg.optimize_extrinsics = bool(v)
 
     @property
     def depth_supervision_lambda(self):

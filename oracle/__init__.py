@@ -366,6 +366,30 @@ def ngp_march_ray(bits, G, ncasc, o, d, cone, min_step, max_step, t0, t1, max_n)
     return pos[:n], dts[:n], ts[:n]
 
 
+def ngp_encode_bwd_input(cfg, pos, params, dLdout):
+    pos = _f32(pos)
+    params = np.ascontiguousarray(params, np.float16)
+    dLdout = np.ascontiguousarray(dLdout, np.float16)
+    out = np.zeros((pos.shape[0], 3), np.float32)
+    lib().orc_ngp_encode_bwd_input(C.byref(cfg), _p(pos), _p(params), _p(dLdout), _p(out), C.c_long(pos.shape[0]))
+    return out
+
+
+def ngp_camera_gradient(dLdpos, tmid, rays_d, ray_start, ray_n, ray_img, pos_inv, n_images):
+    g = np.zeros((n_images, 6), np.float64)
+    a = [np.ascontiguousarray(x, np.int32) for x in (ray_start, ray_n, ray_img)]
+    lib().orc_ngp_camera_gradient(_p(_f32(dLdpos)), _p(_f32(tmid)), _p(_f32(rays_d)), _p(a[0]), _p(a[1]), _p(a[2]),
+                                  C.c_float(pos_inv), _p(g), len(a[0]))
+    return g
+
+
+def ngp_camera_step(c2w, cam_grad, m1, m2, step, lr_pos, lr_rot, beta1=0.9, beta2=0.99, eps=1e-15, grad_scale=1.0):
+    c2w, m1, m2 = _f32(c2w).copy(), _f32(m1).copy(), _f32(m2).copy()
+    lib().orc_ngp_camera_step(_p(c2w), _p(_f32(cam_grad)), _p(m1), _p(m2), c2w.shape[0], step, C.c_float(lr_pos),
+                              C.c_float(lr_rot), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(grad_scale))
+    return c2w, m1, m2
+
+
 def ngp_sample_rays(images, depths, covs, c2w, intr, box_lo, box_hi, near, seed, R):
     images, depths, covs, c2w = _f32(images), _f32(depths), _f32(covs), _f32(c2w)
     n, H, W = depths.shape

@@ -396,3 +396,96 @@ void orc_ngp_sample_rays(const float* images, const float* depths, const float* 
     gt_cov[r] = fmaxf(covs[pix], 1e-6f);
   }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* camera-pose refinement (restates csrc/ngp.hip: ngp_encode_bwd_input_kernel, ngp_camera_grad_kernel,      */
+/* ngp_camera_step_kernel).  dLdout [N, L*F] f16 row-major here.                                           */
+/* ------------------------------------------------------------------------------------------ */
+void orc_ngp_encode_bwd_input(const orc_grid_cfg* c, const float* pos, const uint16_t* params, const uint16_t* dLdout,
+                              float* dLdpos, long N) {
+  float scale[32];
+  int res[32];
+  uint32_t off[33];
+  orc_ngp_grid_layout(c, scale, res, off);
+  const int L = c->n_levels;
+  for (long i = 0; i < N; i++) {
+    float g3[3] = {0, 0, 0};
+    for (int l = 0; l < L; l++) {
+      const float d0 = H2F(dLdout[i * (long)(L * 2) + l * 2]), d1 = H2F(dLdout[i * (long)(L * 2) + l * 2 + 1]);
+      if (d0 == 0.0f && d1 == 0.0f) continue;
+      const uint32_t hs = off[l + 1] - off[l];
+      float w[3];
+      uint32_t g[3];
+      for (int d = 0; d < 3; d++) {
+        float p = fmaf(scale[l], pos[i * 3 + d], 0.5f);
+        float fl = floorf(p);
+        g[d] = (uint32_t)(int)fl;
+        w[d] = p - fl;
+      }
+      float s[8];
+      for (int corner = 0; corner < 8; corner++) {
+        const uint32_t idx = grid_index(hs, (uint32_t)res[l], g[0] + (corner & 1), g[1] + ((corner >> 1) & 1), g[2] + (corner >> 2));
+        s[corner] = d0 * H2F(params[((long)off[l] + idx) * 2]) + d1 * H2F(params[((long)off[l] + idx) * 2 + 1]);
+      }
+      const float wx0 = 1.0f - w[0], wx1 = w[0], wy0 = 1.0f - w[1], wy1 = w[1], wz0 = 1.0f - w[2], wz1 = w[2];
+      g3[0] += scale[l] * (wy0 * wz0 * (s[1] - s[0]) + wy1 * wz0 * (s[3] - s[2]) + wy0 * wz1 * (s[5] - s[4]) + wy1 * wz1 * (s[7] - s[6]));
+      g3[1] += scale[l] * (wx0 * wz0 * (s[2] - s[0]) + wx1 * wz0 * (s[3] - s[1]) + wx0 * wz1 * (s[6] - s[4]) + wx1 * wz1 * (s[7] - s[5]));
+      g3[2] += scale[l] * (wx0 * wy0 * (s[4] - s[0]) + wx1 * wy0 * (s[5] - s[1]) + wx0 * wy1 * (s[6] - s[2]) + wx1 * wy1 * (s[7] - s[3]));
+    }
+    dLdpos[i * 3] = g3[0]; dLdpos[i * 3 + 1] = g3[1]; dLdpos[i * 3 + 2] = g3[2];
+  }
+}
+
+void orc_ngp_camera_gradient(const float* dLdpos, const float* tmid, const float* rays_d, const int32_t* ray_start,
+                             const int32_t* ray_n, const int32_t* ray_img, float pos_inv, double* cam_grad, int R) {
+  for (int r = 0; r < R; r++) {
+    double o[3] = {0, 0, 0}, d[3] = {0, 0, 0};
+    for (int k = 0; k < ray_n[r]; k++) {
+      const long s = (long)ray_start[r] + k;
+      for (int a = 0; a < 3; a++) {
+        const double gpa = (double)(dLdpos[s * 3 + a] * pos_inv);
+        o[a] += gpa;
+        d[a] += (double)tmid[s] * gpa;
+      }
+    }
+    if (ray_n[r] <= 0) continue;
+    const double x = rays_d[r * 3], y = rays_d[r * 3 + 1], z = rays_d[r * 3 + 2];
+    double* gp = cam_grad + (long)ray_img[r] * 6;
+    gp[0] += o[0]; gp[1] += o[1]; gp[2] += o[2];
+    gp[3] += y * d[2] - z * d[1]; gp[4] += z * d[0] - x * d[2]; gp[5] += x * d[1] - y * d[0];
+  }
+}
+
+void orc_ngp_camera_step(float* c2w, const float* cam_grad, float* m1, float* m2, int n, int step, float lr_pos,
+                         float lr_rot, float beta1, float beta2, float eps, float grad_scale) {
+  const float c1 = 1.0f - powf(beta1, (float)step), c2 = 1.0f - powf(beta2, (float)step);
+  for (int i = 0; i < n; i++) {
+    float st[6];
+    int any = 0;
+    for (int k = 0; k < 6; k++) {
+      const float gk = cam_grad[i * 6 + k] * (1.0f / grad_scale);
+      st[k] = 0.0f;
+      if (gk != 0.0f) {
+        any = 1;
+        const float a = beta1 * m1[i * 6 + k] + (1.0f - beta1) * gk, b = beta2 * m2[i * 6 + k] + (1.0f - beta2) * gk * gk;
+        m1[i * 6 + k] = a; m2[i * 6 + k] = b;
+        st[k] = -(k < 3 ? lr_pos : lr_rot) * (a / c1) / (sqrtf(b / c2) + eps);
+      }
+    }
+    if (!any) continue;
+    float* M = c2w + (long)i * 12;
+    M[3] += st[0]; M[7] += st[1]; M[11] += st[2];
+    const float wx = st[3], wy = st[4], wz = st[5];
+    const float th2 = wx * wx + wy * wy + wz * wz, th = sqrtf(th2);
+    const float A = th < 1e-6f ? 1.0f - th2 / 6.0f : sinf(th) / th;
+    const float B = th < 1e-6f ? 0.5f - th2 / 24.0f : (1.0f - cosf(th)) / th2;
+    const float E[9] = {1.0f - B * (wy * wy + wz * wz), B * wx * wy - A * wz, B * wx * wz + A * wy,
+                        B * wx * wy + A * wz, 1.0f - B * (wx * wx + wz * wz), B * wy * wz - A * wx,
+                        B * wx * wz - A * wy, B * wy * wz + A * wx, 1.0f - B * (wx * wx + wy * wy)};
+    float Rn[9];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) Rn[a * 3 + b] = E[a * 3] * M[b] + E[a * 3 + 1] * M[4 + b] + E[a * 3 + 2] * M[8 + b];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) M[a * 4 + b] = Rn[a * 3 + b];
+  }
+}

@@ -278,9 +278,11 @@ def test_sample_rays(oracle_mod, dev):
     f = dict(dtype=torch.float32, device=dev)
     out = [torch.empty((R, 3), **f), torch.empty((R, 3), **f), torch.empty((R, 2), **f), torch.empty((R, 3), **f),
            torch.empty(R, **f), torch.empty(R, **f)]
+    img_idx = torch.empty(R, dtype=torch.int32, device=dev)
     check(lib().ns_ngp_sample_rays(*[ptr(k) for k in keep], n, H, W, *[C.c_float(v) for v in intr], C.c_float(-1.5),
                                    C.c_float(2.5), C.c_float(0.05), C.c_uint32(12345), R, *[ptr(t) for t in out],
-                                   stream_ptr()), "sample_rays")
+                                   ptr(img_idx), stream_ptr()), "sample_rays")
+    assert np.array_equal(img_idx.cpu().numpy(), ref["picks"][:, 0])
     for t, k in zip(out, ("rays_o", "rays_d", "t_range", "gt_rgb", "gt_depth", "gt_cov")):
         tol = dict(rtol=0, atol=0) if k.startswith("gt") or k == "rays_o" else dict(rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(t.cpu().numpy(), ref[k], err_msg=k, **tol)
@@ -383,3 +385,112 @@ def test_nerf_fusion_consumes_slam_packet(dev):
     for _ in range(8):
         fusion.fuse(False)
     assert s0 > 0 and fusion.total_iters > s0 and np.isfinite(fusion.ngp.loss) and fusion.ngp.loss < l0
+
+
+def test_camera_refinement_kernels(oracle_mod, dev):
+    """optimize_extrinsics path: encoding input gradient, per-image 6-dof gradient, Adam + retraction -- each against the C
+    restatement, and the input gradient against central differences of a float64 trilinear interpolation"""
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    cfg = oracle_mod.ngp_cfg(n_levels=6, log2_hashmap=12, base_res=4, per_level_scale=1.6)
+    _, res, off = oracle_mod.ngp_grid_layout(cfg)
+    L, n_par = cfg.n_levels, int(off[-1]) * 2
+    rng = np.random.default_rng(11)
+    params = rng.uniform(-0.5, 0.5, n_par).astype(np.float16)
+    N = 2000
+    pos = rng.uniform(0.02, 0.98, (N, 3)).astype(np.float32)
+    dL = (rng.standard_normal((N, 2 * L)) * 1e-1).astype(np.float16)
+    dL[rng.uniform(size=N) < 0.2] = 0
+    ref = oracle_mod.ngp_encode_bwd_input(cfg, pos, params, dL)
+    args = (L, 2, cfg.log2_hashmap, cfg.base_res, C.c_float(cfg.per_level_scale))
+    d_pos, d_par, d_dLT = T(pos, dev), T(params, dev), T(np.ascontiguousarray(dL.T), dev)
+    out = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    check(lib().ns_ngp_encode_backward_input(*args, ptr(d_pos), ptr(d_par), ptr(d_dLT), ptr(out), C.c_long(N), stream_ptr()), "bwd_in")
+    got = out.cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    # finite differences (float64) of  sum_lf dL[l,f] * feat_lf(pos)  on the dense levels (0, 1: res^3 <= table)
+    scale = [float(np.exp2(l * np.log2(cfg.per_level_scale)) * cfg.base_res - 1.0) for l in range(L)]
+    dense = [l for l in range(L) if res[l] ** 3 <= (1 << cfg.log2_hashmap)]
+    assert len(dense) >= 2
+    P64 = params.astype(np.float64).reshape(-1, 2)
+
+    def energy(p, i):
+        e = 0.0
+        for l in dense:
+            q = scale[l] * p + 0.5
+            g = np.floor(q).astype(int); w = q - g
+            for corner in range(8):
+                c = [(corner >> d) & 1 for d in range(3)]
+                wt = np.prod([w[d] if c[d] else 1 - w[d] for d in range(3)])
+                idx = ((g[0] + c[0]) + (g[1] + c[1]) * int(res[l]) + (g[2] + c[2]) * int(res[l]) ** 2) % (int(off[l + 1]) - int(off[l]))
+                v = P64[int(off[l]) + idx]
+                e += wt * (float(dL[i, 2 * l]) * v[0] + float(dL[i, 2 * l + 1]) * v[1])
+        return e
+    dl_dense = dL.copy()
+    for l in range(L):
+        if l not in dense:
+            dl_dense[:, 2 * l:2 * l + 2] = 0
+    ref_dense = oracle_mod.ngp_encode_bwd_input(cfg, pos, params, dl_dense)
+    h = 1e-5
+    for i in range(0, 40):
+        qs = [scale[l] * pos[i].astype(np.float64) + 0.5 for l in dense]
+        if min(np.min(np.minimum(q - np.floor(q), np.ceil(q) - q)) for q in qs) < 1e-3:
+            continue     # too close to a cell face (of some level) for a central difference
+        fd = [(energy(pos[i].astype(np.float64) + h * np.eye(3)[d], i) - energy(pos[i].astype(np.float64) - h * np.eye(3)[d], i)) / (2 * h)
+              for d in range(3)]
+        assert np.abs(np.array(fd) - ref_dense[i]).max() <= 2e-3 * max(1.0, np.abs(ref_dense[i]).max()), i
+    # per-image gradient
+    R, n_img = 300, 7
+    ray_n = rng.integers(-1, 30, R).astype(np.int32)
+    ray_start = np.concatenate([[0], np.cumsum(np.maximum(ray_n, 0))[:-1]]).astype(np.int32)
+    S = int(np.maximum(ray_n, 0).sum())
+    dpos = rng.standard_normal((S, 3)).astype(np.float32)
+    tm = rng.uniform(0.1, 4, S).astype(np.float32)
+    rd = rng.standard_normal((R, 3)).astype(np.float32); rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    ri = rng.integers(0, n_img, R).astype(np.int32)
+    gref = oracle_mod.ngp_camera_gradient(dpos, tm, rd, ray_start, ray_n, ri, 0.25, n_img)
+    keep = [T(x, dev) for x in (dpos, tm, rd, ray_start, ray_n, ri)]
+    cg = torch.zeros((n_img, 6), dtype=torch.float32, device=dev)
+    check(lib().ns_ngp_camera_gradient(*[ptr(k) for k in keep], C.c_float(0.25), ptr(cg), R, stream_ptr()), "cam_grad")
+    assert np.abs(cg.cpu().numpy() - gref).max() <= 1e-4 * np.abs(gref).max()
+    # Adam + retraction
+    c2w = np.zeros((n_img, 3, 4), np.float32)
+    for k in range(n_img):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        c2w[k, :, :3], c2w[k, :, 3] = q * np.sign(np.linalg.det(q)), rng.uniform(-1, 1, 3)
+    g6 = gref.astype(np.float32) * 128
+    g6[2] = 0                                                   # an image no ray hit: untouched
+    m1 = (rng.standard_normal((n_img, 6)) * 0.1).astype(np.float32); m2 = rng.uniform(0, 0.1, (n_img, 6)).astype(np.float32)
+    rc, r1, r2 = oracle_mod.ngp_camera_step(c2w, g6, m1, m2, step=5, lr_pos=1e-2, lr_rot=2e-2, grad_scale=128.0)
+    dc, dg, d1, d2 = T(c2w, dev), T(g6, dev), T(m1, dev), T(m2, dev)
+    check(lib().ns_ngp_camera_step(ptr(dc), ptr(dg), ptr(d1), ptr(d2), n_img, 5, C.c_float(1e-2), C.c_float(2e-2), C.c_float(0.9),
+                                   C.c_float(0.99), C.c_float(1e-15), C.c_float(128.0), stream_ptr()), "cam_step")
+    np.testing.assert_allclose(dc.cpu().numpy(), rc, atol=2e-6)
+    np.testing.assert_allclose(d1.cpu().numpy(), r1, rtol=1e-5, atol=1e-8)
+    assert not dg.any() and np.array_equal(dc.cpu().numpy()[2], c2w[2])
+    Rn = dc.cpu().numpy()[:, :, :3]
+    assert np.abs(Rn @ Rn.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5        # still rotations
+
+
+def test_pose_refinement_pulls_a_perturbed_camera_back(dev):
+    """end to end: train on the true poses, freeze the field, move one view 3.7 cm off and let optimize_extrinsics
+    (translation only) pull it back through the rendering loss"""
+    import importlib.util
+    import os
+    from nerfslam.ngp import NgpConfig, NgpNerf
+    spec = importlib.util.spec_from_file_location("ngp_scene", os.path.join(os.path.dirname(__file__), "..", "tools", "ngp_scene.py"))
+    sc = importlib.util.module_from_spec(spec); spec.loader.exec_module(sc)
+    imgs, deps, covs, poses, intr = sc.sphere_scene(n=8, H=60, W=80, f=75.0)
+    net = NgpNerf(NgpConfig(), dev, seed=0)
+    net.set_images(imgs, deps, covs, poses.clone(), intr)
+    for _ in range(500):
+        net.train_step()
+    delta = torch.tensor([0.03, -0.02, 0.01])
+    net.c2w[0, :, 3] += delta.to(dev)
+    net.cfg.lr, net.cfg.optimize_extrinsics, net.cfg.extrinsic_lr_pos, net.cfg.extrinsic_lr_rot = 0.0, True, 3e-4, 0.0
+    errs = []
+    for k in range(500):
+        net.train_step()
+        if k % 100 == 99:
+            errs.append((net.c2w[0, :, 3].cpu() - poses[0, :, 3]).norm().item())
+    others = (net.c2w[1:, :, 3].cpu() - poses[1:, :, 3]).norm(dim=-1).max().item()
+    assert errs[-1] < 0.5 * float(delta.norm()) and others < 0.01, (errs, others)

@@ -12,27 +12,10 @@ warm = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 dev = torch.device("cuda:0")
 cfg = NgpConfig()
 net = NgpNerf(cfg, dev, seed=0)
-H, W, f = 120, 160, 150.0
-imgs, deps, covs, poses = [], [], [], []
-centre = np.array([0.5, 0.5, 0.5])
-for k in range(8):
-    a = 2 * np.pi * k / 8
-    eye = centre + 1.2 * np.array([np.cos(a), 0.3, np.sin(a)])
-    fwd = centre - eye; fwd /= np.linalg.norm(fwd)
-    right = np.cross(fwd, [0, 1, 0]); right /= np.linalg.norm(right)
-    up = np.cross(right, fwd)
-    c2w = np.stack([right, -up, fwd, eye], 1)
-    vv, uu = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
-    d = np.stack([(uu + 0.5 - W / 2) / f, (vv + 0.5 - H / 2) / f, np.ones_like(uu, float)], -1) @ c2w[:, :3].T
-    d /= np.linalg.norm(d, axis=-1, keepdims=True)
-    oc = eye - centre
-    b = (d * oc).sum(-1); disc = b * b - ((oc * oc).sum() - 0.25 ** 2)
-    hit = disc > 0
-    t = np.where(hit, -b - np.sqrt(np.maximum(disc, 0)), -1.0)
-    pts = eye + t[..., None] * d
-    col = np.where(hit[..., None], 0.5 + 0.5 * (pts - centre) / 0.25, 0.0)
-    imgs.append(np.concatenate([col, hit[..., None].astype(float)], -1)); deps.append(t); covs.append(np.full((H, W), 0.05)); poses.append(c2w)
-net.set_images(torch.tensor(np.array(imgs)), torch.tensor(np.array(deps)), torch.tensor(np.array(covs)), torch.tensor(np.array(poses)), (f, f, W / 2, H / 2))
+import importlib.util
+spec = importlib.util.spec_from_file_location("ngp_scene", os.path.join(root, "tools", "ngp_scene.py"))
+sc = importlib.util.module_from_spec(spec); spec.loader.exec_module(sc)
+net.set_images(*sc.sphere_scene())
 for _ in range(warm):
     net.train_step()
 torch.cuda.synchronize()
