@@ -82,6 +82,31 @@ class NerfFusion:
             self.fit_volume()
         return True
 
+    def evaluate(self, stride=2):
+        """PSNR / depth-L1 of the rendered training views against what the tracker uploaded (nerf_fusion.py:388-470 does this
+        against ground-truth frames it never stores -- `ref_frames` stays empty there)"""
+        import pyngp as ngp
+        from . import eval as ev
+        n = self.ngp.nerf.training.n_images_for_training
+        train, mode = self.ngp.shall_train, self.ngp.render_mode
+        self.ngp.shall_train = False
+        ps, l1 = [], []
+        for i in range(0, n, stride):
+            ref_rgb, ref_depth = self.ngp.training_view(i)
+            H, W = ref_depth.shape
+            self.ngp.set_camera_to_training_view(i)
+            self.ngp.render_mode = ngp.Shade
+            est = self.ngp.render(W, H, 1, True)[..., :3]
+            self.ngp.render_mode = ngp.Depth
+            dep = self.ngp.render(W, H, 1, True)[..., 0]
+            ps.append(ev.psnr(est, ref_rgb))
+            m = ref_depth > 0
+            if m.any() and dep[m].mean() > 0:
+                l1.append(ev.depth_l1_cm(dep[m], ref_depth[m]))
+        self.ngp.shall_train, self.ngp.render_mode = train, mode
+        return {"psnr": float(np.mean(ps)) if ps else float("nan"), "depth_l1_cm": float(np.mean(l1)) if l1 else float("nan"),
+                "views": len(ps)}
+
     def stop_condition(self):
         return self.total_iters > self.stop_iters
 

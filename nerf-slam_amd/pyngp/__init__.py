@@ -189,6 +189,10 @@ class Testbed:
             self.elapsed_training_time += time.time() - t0
         return True
 
+    def training_view(self, i):
+        """(linear rgb [H,W,3], depth [H,W]) of training slot i as uploaded (numpy) -- evaluation reference"""
+        return self._imgs[int(i), ..., :3].cpu().numpy(), self._deps[int(i)].cpu().numpy()
+
     def apply_camera_smoothing(self, *a, **k):
         pass
 

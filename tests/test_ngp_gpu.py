@@ -385,6 +385,8 @@ def test_nerf_fusion_consumes_slam_packet(dev):
     for _ in range(8):
         fusion.fuse(False)
     assert s0 > 0 and fusion.total_iters > s0 and np.isfinite(fusion.ngp.loss) and fusion.ngp.loss < l0
+    m = fusion.evaluate(stride=2)
+    assert m["views"] == 2 and np.isfinite(m["psnr"]) and m["psnr"] > 5.0 and np.isfinite(m["depth_l1_cm"])
 
 
 def test_camera_refinement_kernels(oracle_mod, dev):
