@@ -323,7 +323,19 @@ def main():
     kern = {k: 1e3 * float(np.mean([s.elapsed_time(e) for s, e in v])) for k, v in hp.ev.items()}  # us / call
     per_step = {k: kern[k] * len(hp.ev[k]) / args.steps for k in kern}
     dom = max(ALG_BYTES, key=lambda k: per_step.get(k, 0.0))
-    achieved = ALG_BYTES[dom] / (kern[dom] * 1e-6) / 1e9
+    # average launch duration of the dominant kernel: HIP events (torch.cuda.Event on the launch stream) around a train of
+    # back-to-back launches, so that the host's launch latency (GPU idle between the events of pass A) is not counted
+    run_dom = {"lookup48": hp.op_lookup48, "build10": lambda: hp.op_build(hp.new_i, hp.new_j)}[dom]
+    hp.ev = None
+    run_dom(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run_dom()
+    e1.record(); torch.cuda.synchronize()
+    dom_us = 1e3 * e0.elapsed_time(e1) / 20
+    hp.ev = ev
+    achieved = ALG_BYTES[dom] / (dom_us * 1e-6) / 1e9
     ms_per_step = 1e3 * dt / args.steps
     out = {
         "metric": "frames/s tracked+mapped on Replica office0 640x480; PSNR + ATE-RMSE vs ref",
@@ -346,7 +358,8 @@ def main():
                    "launch": launch, "eager_ms_per_step": 1e3 * dt_eager / args.steps},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": ALG_BYTES[dom], "avg_launch_us": kern[dom]},
+                     "algorithmic_bytes_per_launch": ALG_BYTES[dom], "avg_launch_us": dom_us,
+                     "avg_launch_us_eager_pass": kern[dom]},
         "us_per_call": {k: round(v, 2) for k, v in sorted(kern.items())},
         "us_per_step": {k: round(v, 1) for k, v in sorted(per_step.items())},
     }
