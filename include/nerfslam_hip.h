@@ -60,7 +60,7 @@ int ns_corr_index_backward(const float* coords, const float* corr_grad, float* v
  * native [E,h1,w1,2] layout when coords_interleaved=1, else [E,2,h1,w1]; it is divided by 2^l
  * inside the kernel (corr.py:47).  out [E, num_levels*49, h1, w1] f16 == torch.cat(out_pyramid,2). */
 int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_levels, const float* coords,
-                           int coords_interleaved, void* out, int E, int h1, int w1, void* stream);
+                           int coords_interleaved, void* out, int E, int h1, int w1, int tiled, void* stream);
 
 /* CorrBlock.__init__ pyramid (corr.py:23-38): one 2x2 average-pool step over the last two dims,
  * f16 in/out, f32 accumulate, one rounding.  in [nslices,h,w] -> out [nslices,h/2,w/2].       */
@@ -69,9 +69,12 @@ int ns_corr_pool2x2(const void* in, void* out, long nslices, int h, int w, void*
 /* CorrBlock.corr + pyramid fused (corr.py:63-72 + :35-38), f16 MFMA, every output byte written once.
  *   fmap1 [n1,HW,C], fmap2 [n2,HW,C] f16 CHANNELS-LAST and already divided by 4 (corr.py:67-68);
  *   ii,jj [E] i64 frame ids into fmap1/fmap2 (both NULL: edge e uses row e of each);
- *   writes pyr_host[l] = [E,ht,wd,ht>>l,wd>>l] f16 for l < num_levels.  C must be 128.          */
+ *   writes pyr_host[l] = [E,ht,wd,ht>>l,wd>>l] f16 for l < num_levels.  C must be 128.
+ *   tiled = 1: levels 0 and 1 are written as 8x8-tiled slices, pyr_host[l] = [E, ht*wd, ceil(h_l/8), ceil(w_l/8), 8, 8]
+ *   (one 128-byte line per tile; border tiles are padded, padding content unspecified) -- a private layout that
+ *   ns_corr_lookup_pyramid reads with tiled = 1: the 8x8 tap window touches <= 4 lines instead of 8-9.          */
 int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, const int64_t* ii, const int64_t* jj,
-                           void* const* pyr_host, int num_levels, int E, int C, int ht, int wd, void* stream);
+                           void* const* pyr_host, int num_levels, int E, int C, int ht, int wd, int tiled, void* stream);
 
 /* altcorr_forward (src/droid.cpp:303-313 -> src/altcorr_kernel.cu:290-319, kernel :28-149)
  *   fmap1 [B,H1,W1,C] f32, fmap2 [B,H2,W2,C] f32 (channels-last), coords [B,N,H1,W1,2] f32,

@@ -37,6 +37,7 @@ struct LookupLevels {
   float scale[4];
   long slice_elems[4];  // h2*w2
   long total_elems[4];  // E*HW1*h2*w2
+  int ntx[4];           // > 0: the level is stored as 8x8 tiles, ntx tiles per tile row (slice_elems = nty*ntx*64)
   int num_levels;
 };
 
@@ -45,7 +46,7 @@ __device__ __forceinline__ uint32_t as_u32(h2_t h) { return __builtin_bit_cast(u
 
 // One (edge,pixel,level).  out points at channel 0 of this pixel; channel stride = HW1 elements.
 __device__ __forceinline__ void lookup_r3_f16(const _Float16* __restrict__ vol, long slice_off, long total,
-                                              int h2, int w2, float x0, float y0,
+                                              int h2, int w2, int ntx, float x0, float y0,
                                               _Float16* __restrict__ out, long HW1) {
   const float fx0 = floorf(x0), fy0 = floorf(y0);
   // non-finite or far-away coordinates: every tap is outside -> zeros
@@ -63,9 +64,44 @@ __device__ __forceinline__ void lookup_r3_f16(const _Float16* __restrict__ vol, 
   }
   const bool any_col = (xb > -8) && (xb < w2);
 
+  uint32_t row[8][4];
+  if (ntx > 0) {
+    // TILED slice (corr_volume.hip): row y1 of the window lives in tile row y1 >> 3; its 8 taps straddle the two
+    // tiles tx0, tx0 + 1 -> two ALIGNED 16-byte loads (both inside the slice or replaced by a safe address and
+    // zeroed) and a funnel shift by (xb & 7) halves.  The window touches <= 2 x 2 cache lines instead of 8-9.
+    const int tx0 = xb >> 3, c0 = xb & 7;
+    const bool okA = tx0 >= 0 && tx0 < ntx, okB = tx0 + 1 >= 0 && tx0 + 1 < ntx;
+    const uint32_t sel1 = (c0 & 2) ? ~0u : 0u, sel2 = (c0 & 4) ? ~0u : 0u, sh16 = (c0 & 1) ? 16u : 0u;
+    u32x4 A[8], B[8];
+    bool rvt[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int y1 = yb + j;
+      rvt[j] = any_col && y1 >= 0 && y1 < h2;
+      const long base = slice_off + ((long)(y1 >> 3) * ntx + tx0) * 64 + (y1 & 7) * 8;
+      A[j] = *reinterpret_cast<const u32x4*>(vol + ((rvt[j] && okA) ? base : slice_off));
+      B[j] = *reinterpret_cast<const u32x4*>(vol + ((rvt[j] && okB) ? base + 64 : slice_off));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      uint32_t D[9];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        D[k] = (rvt[j] && okA) ? A[j][k] : 0u;
+        D[4 + k] = (rvt[j] && okB) ? B[j][k] : 0u;
+      }
+      D[8] = 0u;
+      uint32_t Es[7], F[5];
+#pragma unroll
+      for (int i = 0; i < 7; i++) Es[i] = (D[i + 1] & sel1) | (D[i] & ~sel1);      // shift by one dword  (c0 & 2)
+#pragma unroll
+      for (int i = 0; i < 5; i++) F[i] = (Es[i + 2] & sel2) | (Es[i] & ~sel2);     // shift by two dwords (c0 & 4)
+#pragma unroll
+      for (int k = 0; k < 4; k++) row[j][k] = __builtin_amdgcn_alignbit(F[k + 1], F[k], sh16) & cm[k];  // one half (c0 & 1)
+    }
+  } else {
   // Issue all eight row loads unconditionally (no per-row branches, 8 x 16 B in flight per lane):
   // rows that are not real taps read the start of the pixel's own slice and are zeroed afterwards.
-  uint32_t row[8][4];
   bool rv[8];
   bool need_slow = false;
 #pragma unroll
@@ -112,6 +148,7 @@ __device__ __forceinline__ void lookup_r3_f16(const _Float16* __restrict__ vol, 
           }
       }
     }
+  }
   }
 
   // weights, rounded to half exactly as `scalar_t(dx*dy)` etc. (correlation_kernels.cu:56-65)
@@ -170,8 +207,8 @@ __global__ __launch_bounds__(256) void corr_lookup_pyramid_kernel(LookupLevels L
   }
   const float s = L.scale[lvl];
   _Float16* o = out + ((long)n * (L.num_levels * 49) + lvl * 49) * HW1 + p;
-  lookup_r3_f16(L.vol[lvl], idx * L.slice_elems[lvl], L.total_elems[lvl], L.h2[lvl], L.w2[lvl], cx * s, cy * s, o,
-                HW1);
+  lookup_r3_f16(L.vol[lvl], idx * L.slice_elems[lvl], L.total_elems[lvl], L.h2[lvl], L.w2[lvl], L.ntx[lvl], cx * s, cy * s,
+                o, HW1);
 }
 
 // Generic single-level kernel (any radius, f16 or f32): one lane per pixel, scalar taps.
@@ -256,7 +293,8 @@ __global__ __launch_bounds__(256) void corr_index_backward_kernel(const float* _
 }
 
 extern "C" int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_levels, const float* coords,
-                                      int coords_interleaved, void* out, int E, int h1, int w1, void* stream) {
+                                      int coords_interleaved, void* out, int E, int h1, int w1, int tiled,
+                                      void* stream) {
   NS_REQUIRE(pyr_host && coords && out, "ns_corr_lookup_pyramid: null pointer");
   NS_REQUIRE(num_levels >= 1 && num_levels <= 4, "ns_corr_lookup_pyramid: num_levels=%d not in 1..4", num_levels);
   NS_REQUIRE(E >= 0 && h1 > 0 && w1 > 0, "ns_corr_lookup_pyramid: bad shape E=%d h1=%d w1=%d", E, h1, w1);
@@ -271,7 +309,8 @@ extern "C" int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_level
     L.h2[l] = h1 >> ll;
     L.w2[l] = w1 >> ll;
     L.scale[l] = 1.0f / (float)(1 << ll);
-    L.slice_elems[l] = (long)L.h2[l] * L.w2[l];
+    L.ntx[l] = (tiled && ll < 2) ? (L.w2[l] + 7) / 8 : 0;
+    L.slice_elems[l] = L.ntx[l] ? (long)((L.h2[l] + 7) / 8) * L.ntx[l] * 64 : (long)L.h2[l] * L.w2[l];
     L.total_elems[l] = (long)E * HW1 * L.slice_elems[l];
     NS_REQUIRE(L.h2[l] > 0 && L.w2[l] > 0, "ns_corr_lookup_pyramid: level %d is empty", ll);
   }
@@ -298,6 +337,7 @@ extern "C" int ns_corr_index_forward(const void* volume, const float* coords, vo
       L.h2[l] = h2;
       L.w2[l] = w2;
       L.scale[l] = 1.0f;
+      L.ntx[l] = 0;
       L.slice_elems[l] = (long)h2 * w2;
       L.total_elems[l] = (long)B * HW1 * h2 * w2;
     }

@@ -36,6 +36,7 @@ struct VolArgs {
   const int64_t* jj;
   _Float16* pyr[4];    // level l: [E][HW][h>>l][w>>l]
   int E, ht, wd, num_levels;
+  int tiled;  // levels 0 and 1 in 8x8-tiled slices (see corr_volume_tiled_kernel)
 };
 
 __device__ __forceinline__ _Float16 pool4(_Float16 a, _Float16 b, _Float16 c, _Float16 d) {
@@ -272,9 +273,167 @@ __global__ __launch_bounds__(256) void corr_volume_pyramid_kernel(VolArgs a) {
   for (; x0 < a.wd; x0 += 32) rows_chunk<C, 1>(a, F2, src, lds, r0, r1, x0, col, half, pok, o0, o1, o2, o3);
 }
 
+// ---------------------------------------------------------------------------------------------
+// TILED variant.  Levels 0 and 1 are stored as 8x8 tiles of 128 bytes (one cache line):
+//     slice(e, p, l) = [ceil(h_l/8)][ceil(w_l/8)][8][8] f16         (levels 2, 3 stay row-major: they are 1-5 lines)
+// Why: (1) the lookup's 8x8 tap window then touches <= 2x2 lines instead of 8-9 (row pitch 160 B), which is what
+// its HBM traffic is made of; (2) this kernel can walk the target image TILE BY TILE: the 64 target pixels of a
+// tile are the 64 A-operand rows of two MFMAs, lane (p, half) ends up with rows 4*half..4*half+3 of the tile =
+// 64 contiguous bytes of the output line (the lane pair writes the whole line), and ALL pooling for the tile
+// (4x4 level-1, 2x2 level-2, 1 level-3 value) happens in the lane's registers at once -- no carries across rows,
+// a third fewer registers, and no row-parity control flow.  Tiles are visited in 2x2 groups so that the 8-byte
+// level-1 pieces of one level-1 line are written within four consecutive iterations (they merge in L2).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_tile_load(const _Float16* __restrict__ F2, int ty, int tx, int ht, int wd, int tid,
+                                                uint4* regs) {
+  // 64 pixels x 16 pieces of 16 B; LDS row o = 8 * (row in tile) + (column in tile)
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int piece = tid + 256 * k;
+    const int o = piece >> 4, sl = piece & 15;
+    const int y = 8 * ty + (o >> 3), x = 8 * tx + (o & 7);
+    regs[k] = (y < ht && x < wd) ? *reinterpret_cast<const uint4*>(F2 + ((long)y * wd + x) * 128 + sl * 8)
+                                 : make_uint4(0, 0, 0, 0);
+  }
+}
+
+struct TileWalk {  // tiles of a z-slice in 2x2-group order, skipping the ones outside the tile grid
+  int t, t_end, ngx, nty, ntx;
+  __device__ __forceinline__ bool decode(int tt, int& ty, int& tx) const {
+    const int g = tt >> 2, sub = tt & 3;
+    ty = 2 * (g / ngx) + (sub >> 1);
+    tx = 2 * (g % ngx) + (sub & 1);
+    return ty < nty && tx < ntx;
+  }
+  __device__ __forceinline__ bool next(int& ty, int& tx) {  // advances to the next valid tile; false at the end
+    while (t < t_end) {
+      const bool ok = decode(t, ty, tx);
+      t++;
+      if (ok) return true;
+    }
+    return false;
+  }
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
+  static_assert(C == 128, "staging assumes 128 channels");
+  constexpr int KS = C / 16;
+  constexpr int TILEB = 64 * ROWB;
+  __shared__ __attribute__((aligned(16))) char lds[3 * TILEB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int ht = a.ht, wd = a.wd, HW = ht * wd;
+  const int e = blockIdx.y;
+  const int p0 = (blockIdx.x * 4 + wave) * 32;
+  const long fi = a.ii ? a.ii[e] : e, fj = a.jj ? a.jj[e] : e;
+  const _Float16* __restrict__ F1 = a.f1 + fi * (long)HW * C;
+  const _Float16* __restrict__ F2 = a.f2 + fj * (long)HW * C;
+  const int p = p0 + col;
+  const bool pok = p < HW;
+  f16x8 src[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) {
+    src[kk] = *reinterpret_cast<const f16x8*>(F1 + (long)(pok ? p : 0) * C + kk * 16 + half * 8);
+    if (!pok) src[kk] = (f16x8)(_Float16)0;
+  }
+  const int h1 = ht >> 1, w1 = wd >> 1, h2 = ht >> 2, w2 = wd >> 2, h3 = ht >> 3, w3 = wd >> 3;
+  const int nty0 = (ht + 7) >> 3, ntx0 = (wd + 7) >> 3, nty1 = (h1 + 7) >> 3, ntx1 = (w1 + 7) >> 3;
+  const long pp = (long)e * HW + (pok ? p : 0);
+  _Float16* o0 = a.pyr[0] + pp * ((long)nty0 * ntx0 * 64);
+  _Float16* o1 = a.num_levels > 1 ? a.pyr[1] + pp * ((long)nty1 * ntx1 * 64) : nullptr;
+  _Float16* o2 = a.num_levels > 2 ? a.pyr[2] + pp * (long)h2 * w2 : nullptr;
+  _Float16* o3 = a.num_levels > 3 ? a.pyr[3] + pp * (long)h3 * w3 : nullptr;
+
+  TileWalk ld;   // walks ahead of the compute: issues the global loads
+  ld.ngx = (ntx0 + 1) >> 1; ld.nty = nty0; ld.ntx = ntx0;
+  const int ngroups = ((nty0 + 1) >> 1) * ld.ngx;
+  ld.t = 4 * (int)((long)blockIdx.z * ngroups / gridDim.z);
+  ld.t_end = 4 * (int)((long)(blockIdx.z + 1) * ngroups / gridDim.z);
+  TileWalk cp = ld;  // compute cursor
+  uint4 regs[4];
+  int lty, ltx, ty, tx;
+  if (!ld.next(lty, ltx)) return;  // workgroup-uniform: empty slice
+  stage_tile_load(F2, lty, ltx, ht, wd, tid, regs);
+  stage_store<2>(lds, tid, regs);
+  bool have_next = ld.next(lty, ltx);
+  if (have_next) stage_tile_load(F2, lty, ltx, ht, wd, tid, regs);
+  __syncthreads();
+  int buf = 0;
+  while (cp.next(ty, tx)) {
+    const char* cur = lds + buf * TILEB;
+    const int nb = buf == 2 ? 0 : buf + 1;
+    if (have_next) {
+      stage_store<2>(lds + nb * TILEB, tid, regs);            // tile t+1 -> LDS
+      have_next = ld.next(lty, ltx);
+      if (have_next) stage_tile_load(F2, lty, ltx, ht, wd, tid, regs);  // tile t+2 in flight
+    }
+    buf = nb;
+    f16x2 v[16];  // v[k] = tile-local offsets 32*half + 2k, +1  (rows 4*half .. 4*half+3, 8 columns each)
+    row_chunk<C, 2>(cur, src, col, half, v);
+    if (pok) {
+      // level 0: 64 contiguous bytes of the tile's line
+      uint4* d0 = reinterpret_cast<uint4*>(o0 + ((long)(ty * ntx0 + tx) * 64 + 32 * half));
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const f16x8 o = {v[4 * q][0], v[4 * q][1], v[4 * q + 1][0], v[4 * q + 1][1],
+                         v[4 * q + 2][0], v[4 * q + 2][1], v[4 * q + 3][0], v[4 * q + 3][1]};
+        d0[q] = __builtin_bit_cast(uint4, o);
+      }
+    }
+    if (a.num_levels > 1) {
+      // level 1: rows rr = 0,1 <- tile rows (4h + 2rr, 4h + 2rr + 1); v index of (row R, col c) = 4 (R - 4h) + c / 2
+      f16x2 l1[2][2];
+#pragma unroll
+      for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+          const f16x2 u0 = v[8 * rr + 2 * cc], u1 = v[8 * rr + 2 * cc + 1];          // upper row, columns 4cc..4cc+3
+          const f16x2 d0_ = v[8 * rr + 4 + 2 * cc], d1_ = v[8 * rr + 4 + 2 * cc + 1];  // lower row
+          l1[rr][cc] = mk2(pool4(u0[0], u0[1], d0_[0], d0_[1]), pool4(u1[0], u1[1], d1_[0], d1_[1]));
+        }
+      if (pok) {
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+          const int Y1 = 4 * ty + 2 * half + rr, X1 = 4 * tx;
+          if (Y1 < h1 && X1 < w1) {
+            _Float16* d1p = o1 + ((long)((Y1 >> 3) * ntx1 + (X1 >> 3)) * 64 + (Y1 & 7) * 8 + (X1 & 7));
+            if (X1 + 4 <= w1) {
+              const f16x4 o = {l1[rr][0][0], l1[rr][0][1], l1[rr][1][0], l1[rr][1][1]};
+              *reinterpret_cast<f16x4*>(d1p) = o;
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; c++)
+                if (X1 + c < w1) d1p[c] = l1[rr][c >> 1][c & 1];
+            }
+          }
+        }
+      }
+      if (a.num_levels > 2) {
+        // level 2: one row (Y2 = 2 ty + half), two columns
+        const f16x2 l2 = mk2(pool4(l1[0][0][0], l1[0][0][1], l1[1][0][0], l1[1][0][1]),
+                             pool4(l1[0][1][0], l1[0][1][1], l1[1][1][0], l1[1][1][1]));
+        const int Y2 = 2 * ty + half, X2 = 2 * tx;
+        if (pok && Y2 < h2) {
+          _Float16* d2p = o2 + (long)Y2 * w2 + X2;
+          if (X2 < w2) d2p[0] = l2[0];
+          if (X2 + 1 < w2) d2p[1] = l2[1];
+        }
+        if (a.num_levels > 3) {
+          // level 3: the tile's single value needs both halves' level-2 rows
+          const uint32_t mine = __builtin_bit_cast(uint32_t, l2);
+          const f16x2 other = __builtin_bit_cast(f16x2, (uint32_t)__shfl_xor((int)mine, 32));
+          if (half == 0 && pok && ty < h3 && tx < w3) o3[(long)ty * w3 + tx] = pool4(l2[0], l2[1], other[0], other[1]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, const int64_t* ii, const int64_t* jj,
                                       void* const* pyr_host, int num_levels, int E, int C, int ht, int wd,
-                                      void* stream) {
+                                      int tiled, void* stream) {
   NS_REQUIRE(fmap1 && fmap2 && pyr_host, "ns_corr_volume_pyramid: null pointer");
   NS_REQUIRE(num_levels >= 1 && num_levels <= 4, "ns_corr_volume_pyramid: num_levels=%d not in 1..4", num_levels);
   NS_REQUIRE(E >= 0 && ht > 0 && wd > 0, "ns_corr_volume_pyramid: bad shape");
@@ -298,6 +457,7 @@ extern "C" int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, cons
   a.ht = ht;
   a.wd = wd;
   a.num_levels = num_levels;
+  a.tiled = tiled;
   const int HW = ht * wd;
   // The sweep over the target image is latency bound per wave (16 dependent 16-byte loads per 8x8
   // block); split it over 8-row bands until ~4 workgroups per CU are in flight.
@@ -305,6 +465,15 @@ extern "C" int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, cons
   int zs = ns_cdiv(1024, (long)ns_cdiv(HW, 128) * E);
   if (zs > nby) zs = nby;
   if (zs < 1) zs = 1;
+  if (tiled) {
+    const int ngroups = ((nby + 1) / 2) * ((((wd + 7) / 8) + 1) / 2);
+    int zt = ns_cdiv(1024, (long)ns_cdiv(HW, 128) * E);
+    if (zt > ngroups) zt = ngroups;
+    if (zt < 1) zt = 1;
+    hipLaunchKernelGGL(corr_volume_tiled_kernel<128>, dim3(ns_cdiv(HW, 128), E, zt), dim3(256), 0, (hipStream_t)stream, a);
+    NS_CHECK_LAUNCH("corr_volume_tiled_kernel");
+    return NS_OK;
+  }
   dim3 grid(ns_cdiv(HW, 128), E, zs);
   static const int mode = getenv("NS_VOL_NT") ? atoi(getenv("NS_VOL_NT")) : 2;  // tuning switch: widest column chunk
   if (mode >= 3) {

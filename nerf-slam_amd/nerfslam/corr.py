@@ -19,8 +19,13 @@ from ._lib import NerfSlamHipError, check, lib, ptr, require_cuda, stream_ptr
 class CorrBlock:
     """networks/modules/corr.py:23-60."""
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=3, fused=None):
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3, fused=None, tiled=False):
         """fmap1, fmap2 [batch, num, 128, ht, wd] (reference layout, corr.py:23-38).
+
+        tiled=True (fused path only) keeps levels 0 and 1 in the private 8x8-tiled slice layout of
+        ns_corr_volume_pyramid: same values and the same lookups bit for bit, ~1.4x less lookup traffic, but
+        `corr_pyramid[0/1]` then have shape [E, HW, tiles, 64] instead of the reference's [E, ht, wd, h, w]
+        (`untiled()` converts).
 
         fused=None picks the single-launch MFMA kernel (ns_corr_volume_pyramid) whenever it applies
         (f16, 128 channels, <= 4 levels); fused=False forces the reference's own decomposition
@@ -28,6 +33,8 @@ class CorrBlock:
         self.num_levels = num_levels
         self.radius = radius
         self.corr_pyramid = []
+        self.tiled = False
+        self.hw = None
         if fmap1 is None:
             return
         require_cuda(fmap1, fmap2)
@@ -41,7 +48,8 @@ class CorrBlock:
             # channels-last, pre-divided by 4 exactly as corr.py:67-68 does (in half)
             f1 = (fmap1.reshape(batch * num, dim, ht * wd) / 4.0).transpose(1, 2).contiguous()
             f2 = (fmap2.reshape(batch * num, dim, ht * wd) / 4.0).transpose(1, 2).contiguous()
-            self.corr_pyramid = CorrBlock.build_pyramid(f1, f2, None, None, batch * num, ht, wd, num_levels)
+            self.corr_pyramid = CorrBlock.build_pyramid(f1, f2, None, None, batch * num, ht, wd, num_levels, tiled=tiled)
+            self.tiled, self.hw = bool(tiled), (ht, wd)
             return
         # all pairs correlation (corr.py:63-72): both operands / 4, matmul in the features' dtype
         corr = CorrBlock.corr(fmap1, fmap2)
@@ -61,22 +69,43 @@ class CorrBlock:
             h, w = h // 2, w // 2
 
     @staticmethod
-    def build_pyramid(f1, f2, ii, jj, E, ht, wd, num_levels=4):
+    def build_pyramid(f1, f2, ii, jj, E, ht, wd, num_levels=4, tiled=False):
         """f1, f2: channels-last feature banks [n, ht*wd, 128] f16 already divided by 4; ii, jj: optional
         int64 frame ids (None: edge e uses row e).  One launch, every output byte written once."""
         dev = f1.device
-        pyr = [torch.empty((E, ht, wd, ht >> l, wd >> l), dtype=torch.float16, device=dev) for l in range(num_levels)]
+        def level(l):
+            h, w = ht >> l, wd >> l
+            if tiled and l < 2:
+                return torch.empty((E, ht * wd, ((h + 7) // 8) * ((w + 7) // 8), 64), dtype=torch.float16, device=dev)
+            return torch.empty((E, ht, wd, h, w), dtype=torch.float16, device=dev)
+        pyr = [level(l) for l in range(num_levels)]
         arr = (C.c_void_p * 4)(*[pyr[min(l, num_levels - 1)].data_ptr() for l in range(4)])
         with torch.cuda.device(dev):
             check(lib().ns_corr_volume_pyramid(ptr(f1), ptr(f2), ptr(ii), ptr(jj), arr, num_levels, E, f1.shape[-1], ht,
-                                               wd, stream_ptr()), "corr_volume_pyramid")
+                                               wd, 1 if tiled else 0, stream_ptr()), "corr_volume_pyramid")
         return pyr
 
     @classmethod
-    def from_pyramid(cls, pyramid, radius=3):
+    def from_pyramid(cls, pyramid, radius=3, tiled=False, hw=None):
         blk = cls(None, None, num_levels=len(pyramid), radius=radius)
         blk.corr_pyramid = list(pyramid)
+        blk.tiled, blk.hw = bool(tiled), hw
         return blk
+
+    def untiled(self):
+        """the pyramid in the reference's layout [E, ht, wd, h, w] (copies levels 0 / 1 when they are tiled)"""
+        if not self.tiled:
+            return list(self.corr_pyramid)
+        ht, wd = self.hw
+        out = []
+        for l, p in enumerate(self.corr_pyramid):
+            h, w = ht >> l, wd >> l
+            if l < 2:
+                nty, ntx = (h + 7) // 8, (w + 7) // 8
+                p = p.view(-1, ht, wd, nty, ntx, 8, 8).permute(0, 1, 2, 3, 5, 4, 6).reshape(-1, ht, wd, nty * 8, ntx * 8)
+                p = p[..., :h, :w].contiguous()
+            out.append(p)
+        return out
 
     def __call__(self, coords):
         """coords [batch, num, ht, wd, 2] float -> [batch, num, num_levels*49, ht, wd] (corr.py:40-50)."""
@@ -85,6 +114,8 @@ class CorrBlock:
         p0 = self.corr_pyramid[0]
         require_cuda(coords)
         if self.radius != 3 or p0.dtype != torch.float16 or self.num_levels > 4:
+            if self.tiled:
+                raise NerfSlamHipError("CorrBlock: the tiled layout is read by the fused radius-3 lookup only")
             return self._call_per_level(coords)
         coords = coords.contiguous().float()
         out = torch.empty((batch, num, self.num_levels * 49, ht, wd), dtype=torch.float16, device=coords.device)
@@ -94,7 +125,7 @@ class CorrBlock:
         arr = (C.c_void_p * 4)(*[self.corr_pyramid[min(l, self.num_levels - 1)].data_ptr() for l in range(4)])
         with torch.cuda.device(coords.device):
             check(lib().ns_corr_lookup_pyramid(arr, self.num_levels, ptr(coords), 1, ptr(out), E, ht, wd,
-                                               stream_ptr()), "corr_lookup_pyramid")
+                                               1 if self.tiled else 0, stream_ptr()), "corr_lookup_pyramid")
         return out
 
     def _call_per_level(self, coords):
@@ -108,6 +139,8 @@ class CorrBlock:
         return torch.cat(outs, dim=2)
 
     def cat(self, other):  # corr.py:52-55
+        if self.tiled != other.tiled:
+            raise NerfSlamHipError("CorrBlock.cat: both blocks must use the same volume layout")
         for i in range(self.num_levels):
             self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], 0)
         return self

@@ -113,8 +113,8 @@ class TrackingFrontend:
         if ni.shape[0] == 0:
             return
         di, dj = torch.from_numpy(ni).to(self.device), torch.from_numpy(nj).to(self.device)
-        pyr = CorrBlock.build_pyramid(self.feat_bank, self.feat_bank, di, dj, ni.shape[0], self.ht, self.wd)
-        new = CorrBlock.from_pyramid(pyr)
+        pyr = CorrBlock.build_pyramid(self.feat_bank, self.feat_bank, di, dj, ni.shape[0], self.ht, self.wd, tiled=True)
+        new = CorrBlock.from_pyramid(pyr, tiled=True, hw=(self.ht, self.wd))
         self.corr = new if self.corr is None else self.corr.cat(new)
         tgt = self.reproject(di, dj)
         self.target = torch.cat([self.target, tgt], 0)

@@ -67,7 +67,8 @@ class TrackingSLAM:
         fe = self.fe
         f1 = fe.feat_bank[self.last_kf][None]                              # channels-last half, already / 4
         f2 = (fmap.to(self.device).half().reshape(128, fe.HW) / 4.0).t().contiguous()[None]
-        corr = CorrBlock.from_pyramid(CorrBlock.build_pyramid(f1, f2, None, None, 1, fe.ht, fe.wd))(fe.coords0[None, None])
+        pyr = CorrBlock.build_pyramid(f1, f2, None, None, 1, fe.ht, fe.wd, tiled=True)
+        corr = CorrBlock.from_pyramid(pyr, tiled=True, hw=(fe.ht, fe.wd))(fe.coords0[None, None])
         delta = self.net.motion(corr, self.last_kf)
         return float(delta.norm(dim=-1).mean()) > self.motion_filter_thresh
 

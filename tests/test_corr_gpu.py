@@ -166,3 +166,32 @@ def test_altcorr_block_fused_pyramid(oracle_mod, dev):
         g = got[0, :, 49 * l:49 * (l + 1)].cpu().numpy()
         np.testing.assert_allclose(g, ref, rtol=0, atol=1e-5 * np.abs(ref).max())
         lv = torch.nn.functional.avg_pool2d(lv, 2, stride=2)
+
+
+@pytest.mark.parametrize("shape", [(16, 24), (43, 77), (60, 80)])
+def test_tiled_layout_same_volume_and_same_lookup_bits(dev, shape):
+    """the private 8x8-tiled slice layout (levels 0 / 1): the volume values are those of the row-major build, and the
+    lookup through it is bit-identical, including windows that straddle tiles, borders, and odd image sizes"""
+    from nerfslam.corr import CorrBlock
+    ht, wd = shape
+    g = torch.Generator().manual_seed(ht * 100 + wd)
+    E = 3
+    f1 = torch.randn((1, E, 128, ht, wd), generator=g).half().to(dev)
+    f2 = torch.randn((1, E, 128, ht, wd), generator=g).half().to(dev)
+    a = CorrBlock(f1, f2, fused=True, tiled=False)
+    b = CorrBlock(f1, f2, fused=True, tiled=True)
+    for l, (x, y) in enumerate(zip(a.corr_pyramid, b.untiled())):
+        assert x.shape == y.shape and torch.equal(x, y), l
+    gy, gx = torch.meshgrid(torch.arange(ht), torch.arange(wd), indexing="ij")
+    base = torch.stack([gx, gy], -1).float()
+    for scale in (1.5, 12.0, 200.0):
+        coords = (base[None, None] + torch.randn((1, E, ht, wd, 2), generator=g) * scale).to(dev)
+        coords[0, 0, 0, 0] = float("nan")
+        coords[0, 1, 1, 1, 0] = -3.25
+        coords[0, 2, 2, 2] = torch.tensor([wd + 2.5, ht + 1.75])
+        ra, rb = a(coords), b(coords)
+        assert torch.equal(ra.view(torch.int16), rb.view(torch.int16)), scale
+    # payload operations of the frontend keep working on the tiled block
+    c = CorrBlock(f1, f2, fused=True, tiled=True)
+    c = c[torch.tensor([True, False, True], device=dev)]
+    assert c.corr_pyramid[0].shape[0] == 2 and torch.equal(c(coords[:, [0, 2]]), rb[:, [0, 2]])

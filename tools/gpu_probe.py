@@ -23,7 +23,7 @@ coords[0, 0, 0] = [-2.5, -2.25]; coords[-1, -1, -1] = [wd + 1.5, ht + 0.75]; coo
 cd = torch.from_numpy(coords).cuda()
 out = torch.empty((E, 196, ht, wd), dtype=torch.float16, device="cuda")
 arr = (C.c_void_p * 4)(*[p.data_ptr() for p in pyr])
-check(L.ns_corr_lookup_pyramid(arr, 4, ptr(cd), 1, ptr(out), E, ht, wd, stream_ptr()), "lookup")
+check(L.ns_corr_lookup_pyramid(arr, 4, ptr(cd), 1, ptr(out), E, ht, wd, 0, stream_ptr()), "lookup")
 torch.cuda.synchronize()
 got = out.cpu().numpy()
 ok = True
@@ -49,12 +49,12 @@ cd = (torch.stack([gx, gy], -1)[None].float() + torch.empty(E, ht, wd, 2, device
 out = torch.empty((E, 196, ht, wd), dtype=torch.float16, device="cuda")
 arr = (C.c_void_p * 4)(*[p.data_ptr() for p in pyr])
 for _ in range(5):
-    L.ns_corr_lookup_pyramid(arr, 4, ptr(cd), 1, ptr(out), E, ht, wd, stream_ptr())
+    L.ns_corr_lookup_pyramid(arr, 4, ptr(cd), 1, ptr(out), E, ht, wd, 0, stream_ptr())
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
 for _ in range(50):
-    L.ns_corr_lookup_pyramid(arr, 4, ptr(cd), 1, ptr(out), E, ht, wd, stream_ptr())
+    L.ns_corr_lookup_pyramid(arr, 4, ptr(cd), 1, ptr(out), E, ht, wd, 0, stream_ptr())
 e.record(); torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 50
 alg = E * 4 * ht * wd * 234

@@ -27,7 +27,7 @@ if which in ("volume", "all"):
     f2 = (hp.fmaps[hp.new_j].reshape(10, 128, -1) / 4.0).transpose(1, 2).contiguous()
     timeit("volume10 (kernel only)", lambda: CorrBlock.build_pyramid(f1, f2, None, None, 10, bench.HT, bench.WD))
     timeit("volume1  (kernel only)", lambda: CorrBlock.build_pyramid(f1[:1], f2[:1], None, None, 1, bench.HT, bench.WD))
-    timeit("build10 (torch prep + kernel)", lambda: hp.op_build(hp.new_i, hp.new_j))
+    timeit("build10 (from the feature bank)", lambda: hp.op_build(hp.new_i, hp.new_j))
     timeit("build10 unfused (matmul+pool)", lambda: CorrBlock(hp.fmaps[None, hp.new_i], hp.fmaps[None, hp.new_j], fused=False))
 if which in ("lookup", "all"):
     timeit("lookup48", hp.op_lookup48)
