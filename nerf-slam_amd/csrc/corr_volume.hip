@@ -281,8 +281,10 @@ __global__ __launch_bounds__(256) void corr_volume_pyramid_kernel(VolArgs a) {
 // tile are the 64 A-operand rows of two MFMAs, lane (p, half) ends up with rows 4*half..4*half+3 of the tile =
 // 64 contiguous bytes of the output line (the lane pair writes the whole line), and ALL pooling for the tile
 // (4x4 level-1, 2x2 level-2, 1 level-3 value) happens in the lane's registers at once -- no carries across rows,
-// a third fewer registers, and no row-parity control flow.  Tiles are visited in 2x2 groups so that the 8-byte
-// level-1 pieces of one level-1 line are written within four consecutive iterations (they merge in L2).
+// and no row-parity control flow.  Tiles are visited in 2x2 groups = one level-1 tile, one 4x4 level-2 block and one
+// 2x2 level-3 block per source pixel, and the OUTPUT is batched per tile / per group into whole 128-byte lines
+// (through a wave-private LDS transposition) because the kernel is bound by the number of L2 write requests, not
+// by bytes: 335 -> 230 us for 10 edges when the 16-byte-per-lane stores became 8-lanes-per-line stores.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void stage_tile_load(const _Float16* __restrict__ F2, int ty, int tx, int ht, int wd, int tid,
                                                 uint4* regs) {
@@ -320,7 +322,12 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
   static_assert(C == 128, "staging assumes 128 channels");
   constexpr int KS = C / 16;
   constexpr int TILEB = 64 * ROWB;
-  __shared__ __attribute__((aligned(16))) char lds[3 * TILEB];
+  constexpr int XPITCH = 144;  // 128-byte output line + 16: conflict-free 16-byte slots for both access patterns
+  // Two staging buffers are enough with one barrier per tile: iteration t fills the buffer that was read in
+  // iteration t-1 (all waves are past that barrier) and reads the one filled during t-1.
+  __shared__ __attribute__((aligned(16))) char lds[2 * TILEB];
+  // per wave: 32 level-0 lines of the current tile + 32 level-1 lines of the current 2x2 tile group
+  __shared__ __attribute__((aligned(16))) char xpose[4][2][32 * XPITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int ht = a.ht, wd = a.wd, HW = ht * wd;
@@ -339,11 +346,12 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
   }
   const int h1 = ht >> 1, w1 = wd >> 1, h2 = ht >> 2, w2 = wd >> 2, h3 = ht >> 3, w3 = wd >> 3;
   const int nty0 = (ht + 7) >> 3, ntx0 = (wd + 7) >> 3, nty1 = (h1 + 7) >> 3, ntx1 = (w1 + 7) >> 3;
+  const long slice0 = (long)nty0 * ntx0 * 64, slice1 = (long)nty1 * ntx1 * 64;
   const long pp = (long)e * HW + (pok ? p : 0);
-  _Float16* o0 = a.pyr[0] + pp * ((long)nty0 * ntx0 * 64);
-  _Float16* o1 = a.num_levels > 1 ? a.pyr[1] + pp * ((long)nty1 * ntx1 * 64) : nullptr;
   _Float16* o2 = a.num_levels > 2 ? a.pyr[2] + pp * (long)h2 * w2 : nullptr;
   _Float16* o3 = a.num_levels > 3 ? a.pyr[3] + pp * (long)h3 * w3 : nullptr;
+  char* xp0 = xpose[wave][0];
+  char* xp1 = xpose[wave][1];
 
   TileWalk ld;   // walks ahead of the compute: issues the global loads
   ld.ngx = (ntx0 + 1) >> 1; ld.nty = nty0; ld.ntx = ntx0;
@@ -360,30 +368,36 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
   if (have_next) stage_tile_load(F2, lty, ltx, ht, wd, tid, regs);
   __syncthreads();
   int buf = 0;
+  f16x4 l2g[2] = {(f16x4)(_Float16)0, (f16x4)(_Float16)0};  // level-2 rows (half, 2 + half) of the group, 4 columns
+  f16x2 l3g[2] = {(f16x2)(_Float16)0, (f16x2)(_Float16)0};  // level-3 rows 0, 1 of the group (held by half == 0)
   while (cp.next(ty, tx)) {
     const char* cur = lds + buf * TILEB;
-    const int nb = buf == 2 ? 0 : buf + 1;
     if (have_next) {
-      stage_store<2>(lds + nb * TILEB, tid, regs);            // tile t+1 -> LDS
+      stage_store<2>(lds + (buf ^ 1) * TILEB, tid, regs);           // tile t+1 -> LDS
       have_next = ld.next(lty, ltx);
       if (have_next) stage_tile_load(F2, lty, ltx, ht, wd, tid, regs);  // tile t+2 in flight
     }
-    buf = nb;
+    buf ^= 1;
     f16x2 v[16];  // v[k] = tile-local offsets 32*half + 2k, +1  (rows 4*half .. 4*half+3, 8 columns each)
     row_chunk<C, 2>(cur, src, col, half, v);
-    if (pok) {
-      // level 0: 64 contiguous bytes of the tile's line
-      uint4* d0 = reinterpret_cast<uint4*>(o0 + ((long)(ty * ntx0 + tx) * 64 + 32 * half));
+    const int dy = ty & 1, dx = tx & 1, gy = ty >> 1, gx = tx >> 1;
+    // last tile of its 2x2 group in walk order (the others are outside the tile grid)?
+    const bool last_in_group = !((dx == 0 && tx + 1 < ntx0) || (dy == 0 && ty + 1 < nty0));
+    {
+      // level 0.  The L2 takes ~190 G write requests/s and that, not bytes, bounds this kernel: a lane's 16-byte store
+      // is its own request (the lines of different source pixels are 10 KB apart).  So the wave's 32 lines (4 KB) go
+      // through a wave-private LDS area and leave as 4 stores in which 8 consecutive lanes cover one whole 128-byte
+      // line: 32 requests per tile instead of 256.
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const f16x8 o = {v[4 * q][0], v[4 * q][1], v[4 * q + 1][0], v[4 * q + 1][1],
                          v[4 * q + 2][0], v[4 * q + 2][1], v[4 * q + 3][0], v[4 * q + 3][1]};
-        d0[q] = __builtin_bit_cast(uint4, o);
+        *reinterpret_cast<f16x8*>(xp0 + col * XPITCH + 64 * half + 16 * q) = o;
       }
     }
+    f16x2 l1[2][2];
     if (a.num_levels > 1) {
       // level 1: rows rr = 0,1 <- tile rows (4h + 2rr, 4h + 2rr + 1); v index of (row R, col c) = 4 (R - 4h) + c / 2
-      f16x2 l1[2][2];
 #pragma unroll
       for (int rr = 0; rr < 2; rr++)
 #pragma unroll
@@ -392,38 +406,83 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
           const f16x2 d0_ = v[8 * rr + 4 + 2 * cc], d1_ = v[8 * rr + 4 + 2 * cc + 1];  // lower row
           l1[rr][cc] = mk2(pool4(u0[0], u0[1], d0_[0], d0_[1]), pool4(u1[0], u1[1], d1_[0], d1_[1]));
         }
-      if (pok) {
+      // into the group's level-1 line of this source pixel: row 4 dy + 2 half + rr, columns 4 dx .. 4 dx + 3
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-          const int Y1 = 4 * ty + 2 * half + rr, X1 = 4 * tx;
-          if (Y1 < h1 && X1 < w1) {
-            _Float16* d1p = o1 + ((long)((Y1 >> 3) * ntx1 + (X1 >> 3)) * 64 + (Y1 & 7) * 8 + (X1 & 7));
-            if (X1 + 4 <= w1) {
-              const f16x4 o = {l1[rr][0][0], l1[rr][0][1], l1[rr][1][0], l1[rr][1][1]};
-              *reinterpret_cast<f16x4*>(d1p) = o;
+      for (int rr = 0; rr < 2; rr++) {
+        const f16x4 o = {l1[rr][0][0], l1[rr][0][1], l1[rr][1][0], l1[rr][1][1]};
+        *reinterpret_cast<f16x4*>(xp1 + col * XPITCH + (4 * dy + 2 * half + rr) * 16 + 8 * dx) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private areas: LDS ops of one wave complete in order
+    {
+      const long tile_off = (long)(ty * ntx0 + tx) * 64;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int line = 8 * k + (lane >> 3), piece = lane & 7;
+        const uint4 d = *reinterpret_cast<const uint4*>(xp0 + line * XPITCH + 16 * piece);
+        const int pl = p0 + line;
+        if (pl < HW) *reinterpret_cast<uint4*>(a.pyr[0] + ((long)e * HW + pl) * slice0 + tile_off + 8 * piece) = d;
+      }
+    }
+    if (a.num_levels > 1 && last_in_group && gy < nty1 && gx < ntx1) {
+      // the group's level-1 tile of every source pixel is complete (parts from tiles outside the grid are padding)
+      const long tile_off = (long)(gy * ntx1 + gx) * 64;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int line = 8 * k + (lane >> 3), piece = lane & 7;
+        const uint4 d = *reinterpret_cast<const uint4*>(xp1 + line * XPITCH + 16 * piece);
+        const int pl = p0 + line;
+        if (pl < HW) *reinterpret_cast<uint4*>(a.pyr[1] + ((long)e * HW + pl) * slice1 + tile_off + 8 * piece) = d;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next tile overwrites the areas
+    if (a.num_levels > 2) {
+      // level 2: this tile gives one row (2 dy + half of the group's 4) and two columns (2 dx, 2 dx + 1); kept in
+      // registers until the group is complete, then two 8-byte stores per lane instead of four 4-byte ones
+      const f16x2 l2 = mk2(pool4(l1[0][0][0], l1[0][0][1], l1[1][0][0], l1[1][0][1]),
+                           pool4(l1[0][1][0], l1[0][1][1], l1[1][1][0], l1[1][1][1]));
+#pragma unroll
+      for (int ry = 0; ry < 2; ry++)
+        if (dy == ry) {
+          if (dx == 0) { l2g[ry][0] = l2[0]; l2g[ry][1] = l2[1]; }
+          else         { l2g[ry][2] = l2[0]; l2g[ry][3] = l2[1]; }
+        }
+      if (a.num_levels > 3) {
+        // level 3: the tile's single value needs both halves' level-2 rows
+        const uint32_t mine = __builtin_bit_cast(uint32_t, l2);
+        const f16x2 other = __builtin_bit_cast(f16x2, (uint32_t)__shfl_xor((int)mine, 32));
+        const _Float16 l3 = pool4(l2[0], l2[1], other[0], other[1]);  // meaningful on half == 0
+#pragma unroll
+        for (int ry = 0; ry < 2; ry++)
+          if (dy == ry) l3g[ry][dx] = l3;
+      }
+      if (last_in_group && pok) {
+        struct __attribute__((packed, aligned(2))) U4 { f16x4 v; };
+        struct __attribute__((packed, aligned(2))) U2 { f16x2 v; };
+#pragma unroll
+        for (int ry = 0; ry < 2; ry++) {
+          const int Y2 = 4 * gy + 2 * ry + half, X2 = 4 * gx;
+          if (Y2 < h2 && (2 * gy + ry) < nty0) {
+            _Float16* d2p = o2 + (long)Y2 * w2 + X2;
+            if (X2 + 4 <= w2) {
+              reinterpret_cast<U4*>(d2p)->v = l2g[ry];
             } else {
 #pragma unroll
               for (int c = 0; c < 4; c++)
-                if (X1 + c < w1) d1p[c] = l1[rr][c >> 1][c & 1];
+                if (X2 + c < w2) d2p[c] = l2g[ry][c];
             }
           }
-        }
-      }
-      if (a.num_levels > 2) {
-        // level 2: one row (Y2 = 2 ty + half), two columns
-        const f16x2 l2 = mk2(pool4(l1[0][0][0], l1[0][0][1], l1[1][0][0], l1[1][0][1]),
-                             pool4(l1[0][1][0], l1[0][1][1], l1[1][1][0], l1[1][1][1]));
-        const int Y2 = 2 * ty + half, X2 = 2 * tx;
-        if (pok && Y2 < h2) {
-          _Float16* d2p = o2 + (long)Y2 * w2 + X2;
-          if (X2 < w2) d2p[0] = l2[0];
-          if (X2 + 1 < w2) d2p[1] = l2[1];
-        }
-        if (a.num_levels > 3) {
-          // level 3: the tile's single value needs both halves' level-2 rows
-          const uint32_t mine = __builtin_bit_cast(uint32_t, l2);
-          const f16x2 other = __builtin_bit_cast(f16x2, (uint32_t)__shfl_xor((int)mine, 32));
-          if (half == 0 && pok && ty < h3 && tx < w3) o3[(long)ty * w3 + tx] = pool4(l2[0], l2[1], other[0], other[1]);
+          if (a.num_levels > 3 && half == 0) {
+            const int Y3 = 2 * gy + ry, X3 = 2 * gx;
+            if (Y3 < h3) {
+              _Float16* d3p = o3 + (long)Y3 * w3 + X3;
+              if (X3 + 2 <= w3) {
+                reinterpret_cast<U2*>(d3p)->v = l3g[ry];
+              } else if (X3 < w3) {
+                d3p[0] = l3g[ry][0];
+              }
+            }
+          }
         }
       }
     }
@@ -457,7 +516,7 @@ extern "C" int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, cons
   a.ht = ht;
   a.wd = wd;
   a.num_levels = num_levels;
-  a.tiled = tiled;
+  a.tiled = tiled ? 1 : 0;
   const int HW = ht * wd;
   // The sweep over the target image is latency bound per wave (16 dependent 16-byte loads per 8x8
   // block); split it over 8-row bands until ~4 workgroups per CU are in flight.
