@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void altcorr_pyramid_kernel(AltPyramid P, cons
 extern "C" int ns_altcorr_pyramid(const float* const* fmaps_host, int num_levels, const int64_t* ii,
                                   const int64_t* jj, const float* coords, float* out, int E, int H1, int W1, int C,
                                   void* stream) {
+  if (E == 0) return NS_OK;  // an empty set is a no-op whatever the pointers are
   NS_REQUIRE(fmaps_host && ii && jj && coords && out, "ns_altcorr_pyramid: null pointer");
   NS_REQUIRE(num_levels >= 1 && num_levels <= 4, "ns_altcorr_pyramid: num_levels=%d not in 1..4", num_levels);
   NS_REQUIRE(E >= 0 && H1 > 0 && W1 > 0 && C > 0 && C % 4 == 0, "ns_altcorr_pyramid: bad shape");

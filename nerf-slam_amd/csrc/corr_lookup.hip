@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256) void corr_index_backward_kernel(const float* _
 extern "C" int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_levels, const float* coords,
                                       int coords_interleaved, void* out, int E, int h1, int w1, int tiled,
                                       void* stream) {
+  if (E == 0) return NS_OK;  // an empty set is a no-op whatever the pointers are
   NS_REQUIRE(pyr_host && coords && out, "ns_corr_lookup_pyramid: null pointer");
   NS_REQUIRE(num_levels >= 1 && num_levels <= 4, "ns_corr_lookup_pyramid: num_levels=%d not in 1..4", num_levels);
   NS_REQUIRE(E >= 0 && h1 > 0 && w1 > 0, "ns_corr_lookup_pyramid: bad shape E=%d h1=%d w1=%d", E, h1, w1);
@@ -323,6 +324,7 @@ extern "C" int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_level
 
 extern "C" int ns_corr_index_forward(const void* volume, const float* coords, void* corr, int dtype, int B, int h1,
                                      int w1, int h2, int w2, int radius, void* stream) {
+  if (B == 0) return NS_OK;  // an empty set is a no-op whatever the pointers are
   NS_REQUIRE(volume && coords && corr, "ns_corr_index_forward: null pointer");
   NS_REQUIRE(dtype == NS_F16 || dtype == NS_F32, "ns_corr_index_forward: dtype %d unsupported", dtype);
   NS_REQUIRE(B >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0 && radius >= 0,
@@ -360,6 +362,7 @@ extern "C" int ns_corr_index_forward(const void* volume, const float* coords, vo
 
 extern "C" int ns_corr_index_backward(const float* coords, const float* corr_grad, float* volume_grad, int B, int h1,
                                       int w1, int h2, int w2, int radius, void* stream) {
+  if (B == 0) return NS_OK;  // an empty set is a no-op whatever the pointers are
   NS_REQUIRE(coords && corr_grad && volume_grad, "ns_corr_index_backward: null pointer");
   NS_REQUIRE(B >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0 && radius >= 0, "ns_corr_index_backward: bad shape");
   if (B == 0) return NS_OK;

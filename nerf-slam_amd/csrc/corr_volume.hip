@@ -493,6 +493,7 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
 extern "C" int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, const int64_t* ii, const int64_t* jj,
                                       void* const* pyr_host, int num_levels, int E, int C, int ht, int wd,
                                       int tiled, void* stream) {
+  if (E == 0) return NS_OK;  // an empty set is a no-op whatever the pointers are
   NS_REQUIRE(fmap1 && fmap2 && pyr_host, "ns_corr_volume_pyramid: null pointer");
   NS_REQUIRE(num_levels >= 1 && num_levels <= 4, "ns_corr_volume_pyramid: num_levels=%d not in 1..4", num_levels);
   NS_REQUIRE(E >= 0 && ht > 0 && wd > 0, "ns_corr_volume_pyramid: bad shape");

@@ -198,8 +198,8 @@ __global__ __launch_bounds__(256) void reproject_kernel(const float* __restrict_
 
 extern "C" int ns_reproject(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,
                             const int64_t* jj, float* coords, float* valid, int num, int ht, int wd, void* stream) {
+  if (num <= 0) return NS_OK;  // an empty set is a no-op whatever the pointers are
   NS_REQUIRE(poses && disps && intrinsics && coords, "ns_reproject: null pointer");
-  if (num <= 0) return NS_OK;
   NS_REQUIRE(ii && jj, "ns_reproject: null index");
   hipLaunchKernelGGL(reproject_kernel, dim3(num, ns_cdiv(ht * wd, 256)), dim3(256), 0, (hipStream_t)stream, poses, disps,
                      intrinsics, ii, jj, coords, valid, ht * wd, wd);
@@ -209,6 +209,7 @@ extern "C" int ns_reproject(const float* poses, const float* disps, const float*
 
 extern "C" int ns_frame_distance(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,
                                  const int64_t* jj, float* dist, int num, int ht, int wd, float beta, void* stream) {
+  if (num == 0) return NS_OK;  // an empty set is a no-op whatever the pointers are
   NS_REQUIRE(poses && disps && intrinsics && dist, "ns_frame_distance: null pointer");
   NS_REQUIRE(num >= 0 && ht > 0 && wd > 0, "ns_frame_distance: bad shape");
   if (num == 0) return NS_OK;

@@ -195,3 +195,51 @@ def test_tiled_layout_same_volume_and_same_lookup_bits(dev, shape):
     c = CorrBlock(f1, f2, fused=True, tiled=True)
     c = c[torch.tensor([True, False, True], device=dev)]
     assert c.corr_pyramid[0].shape[0] == 2 and torch.equal(c(coords[:, [0, 2]]), rb[:, [0, 2]])
+
+
+def test_full_size_c1280_properties(dev):
+    """BASELINE config #5 size (1280x720 -> 90x160 grid, one edge = 415 MB of volume): size-independent properties --
+    tiled build == row-major build bit for bit, lookups through both agree bit for bit, the identity lookup returns the
+    volume's own entries, and the on-the-fly (altcorr) path agrees with the volume lookup to f16 resolution"""
+    from nerfslam.corr import AltCorrBlock, CorrBlock
+    ht, wd = 90, 160
+    g = torch.Generator().manual_seed(7)
+    f1 = (torch.randn((1, 1, 128, ht, wd), generator=g) * 0.5).half().to(dev)
+    f2 = (torch.randn((1, 1, 128, ht, wd), generator=g) * 0.5).half().to(dev)
+    a = CorrBlock(f1, f2, fused=True, tiled=False)
+    b = CorrBlock(f1, f2, fused=True, tiled=True)
+    for l, (x, y) in enumerate(zip(a.corr_pyramid, b.untiled())):
+        assert torch.equal(x, y), l
+    gy, gx = torch.meshgrid(torch.arange(ht), torch.arange(wd), indexing="ij")
+    base = torch.stack([gx, gy], -1).float()[None, None].to(dev)
+    coords = base + torch.randn((1, 1, ht, wd, 2), generator=g).to(dev) * 20.0
+    ra, rb = a(coords), b(coords)
+    assert torch.equal(ra.view(torch.int16), rb.view(torch.int16))
+    # integer coordinates: the centre tap (channel 3*7+3 of level 0) is volume[p, y, x] itself
+    centre = a(base)[0, 0, 24]
+    vol = a.corr_pyramid[0][0]
+    own = vol.reshape(ht * wd, ht * wd).diagonal().view(ht, wd)
+    assert torch.equal(centre, own)
+    alt = AltCorrBlock(torch.cat([f1, f2], 1).float())
+    rc = alt(coords, torch.tensor([0], device=dev), torch.tensor([1], device=dev))
+    scale = ra.float().abs().max().item()
+    assert (rc[0, 0] - ra[0, 0].float()).abs().max().item() <= 4e-3 * scale     # f16 volume vs f32 on-the-fly
+
+
+def test_empty_edge_sets(dev):
+    """E = 0 everywhere an edge count appears: the entry points accept it and return empty results"""
+    from nerfslam.corr import AltCorrBlock, CorrBlock
+    import droid_backends
+    ht, wd = 12, 16
+    bank = torch.randn((4, ht * wd, 128), device=dev).half()
+    empty = torch.zeros(0, dtype=torch.long, device=dev)
+    for tiled in (False, True):
+        pyr = CorrBlock.build_pyramid(bank, bank, empty, empty, 0, ht, wd, tiled=tiled)
+        blk = CorrBlock.from_pyramid(pyr, tiled=tiled, hw=(ht, wd))
+        out = blk(torch.zeros((1, 0, ht, wd, 2), device=dev))
+        assert out.shape == (1, 0, 196, ht, wd)
+    d = droid_backends.frame_distance(torch.zeros((4, 7), device=dev), torch.ones((4, ht, wd), device=dev),
+                                      torch.tensor([10.0, 10.0, 8.0, 6.0], device=dev), empty, empty, 0.3)
+    assert d.shape == (0,)
+    alt = AltCorrBlock(torch.randn((1, 4, 128, ht, wd), device=dev))
+    assert alt(torch.zeros((1, 0, ht, wd, 2), device=dev), empty, empty).shape == (1, 0, 196, ht, wd)
