@@ -390,7 +390,11 @@ def main():
             out["roofline"]["traffic"] = tr["traffic_bytes"]
             out["roofline"]["traffic_note"] = tr["note"]
     if rank == 0 and world == 1:
-        out["mapping"] = mapping_rate(dev)
+        out["mapping"] = m = mapping_rate(dev)
+        # configs[2] on ONE GPU, sequential pipeline as the reference runs it: per input frame one tracking step, then one
+        # `frame()` of the mapper = 16 training steps (pyngp.Testbed.steps_per_frame)
+        m["tracked_plus_mapped_frames_per_s_single_gpu"] = 1.0 / (dt / args.steps + 16.0 / m["nerf_train_steps_per_s"])
+        m["assumption"] = "one tracking step + 16 NeRF training steps per frame, run back to back on the same GPU"
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(hp)
     elif rank == 0:
