@@ -536,6 +536,7 @@ struct MarchArgs {
 // ray reserves the range (same protocol as before: a ray that does not fit gets nothing).
 #define MARCH_SPL 64
 #define MARCH_ROUND (16 * MARCH_SPL)
+#define MARCH_WIN 256  // samples of one ray staged in LDS at a time (16 rays x 256 x 8 B = 32 KiB per workgroup)
 
 __device__ __forceinline__ float march_dt(float t, const MarchArgs& a) {
   return fminf(fmaxf(t * a.cone, a.min_step), a.max_step);
@@ -617,50 +618,89 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(MarchArgs a) {
     if (!more || total >= a.max_per_ray) break;
   }
   int n = min(total, a.max_per_ray);
-  int base = 0;
-  if (sub == 0) {
-    if (n > 0) {
-      base = atomicAdd(&a.counter[0], n);
-      if ((long)base + n > a.max_samples) n = -1;  // batch is full: the ray is refused (not part of this batch)
+  // One reservation per WORKGROUP (16 rays), not per ray: thousands of returning atomics on one address serialise at
+  // ~10 ns each, which was the whole run time of this kernel (143 us for ~5000 rays whatever the marching cost).
+  // Rays keep their order inside the block's range; a ray whose range would cross max_samples is refused, and so
+  // are all later ones (their bases are larger), so the accepted ranges still tile [0, counter[2]) without holes.
+  __shared__ int row_n[16], row_base[16];
+  const int row = threadIdx.x >> 4;
+  if (sub == 0) row_n[row] = live ? n : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) tot += row_n[k];
+    int b = tot > 0 ? atomicAdd(&a.counter[0], tot) : 0;
+    int accepted = 0, end = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int nk = row_n[k];
+      row_base[k] = b;
+      if (nk > 0) {
+        if ((long)b + nk > a.max_samples) {
+          row_n[k] = -1;  // batch is full: the ray is refused (not part of this batch)
+        } else {
+          accepted++;
+          end = b + nk;
+        }
+      }
+      b += nk;
     }
-    if (live) {
-      a.ray_start[r] = base;
-      a.ray_n[r] = n;
-    }
-    if (n > 0) {
-      atomicAdd(&a.counter[1], 1);
-      atomicMax(&a.counter[2], base + n);
+    if (accepted > 0) {
+      atomicAdd(&a.counter[1], accepted);
+      atomicMax(&a.counter[2], end);
     }
   }
-  base = __shfl(base, 0, 16);
-  n = __shfl(n, 0, 16);
+  __syncthreads();
+  n = row_n[row];
+  int base = row_base[row];
+  if (sub == 0 && live) {
+    a.ray_start[r] = base;
+    a.ray_n[r] = n;
+  }
   if (n <= 0) return;  // row-uniform
-  // pass 2: write
+  // pass 2: write.  A lane's samples are scattered over the ray's range, and 8 four-byte stores per sample with 64
+  // unrelated addresses per instruction kept the texture addresser busy (144 us for ~5000 rays).  So the (t, dt) of
+  // the row's samples are first compacted into an LDS window in ray order (same wave: no barrier needed), and the 16
+  // lanes of the row then write 16 CONSECUTIVE samples per instruction.
+  __shared__ float2 sbuf[16][MARCH_WIN];
+  float2* win = sbuf[threadIdx.x >> 4];
   int off = 0;
   tc = tb;
   for (int round = 0; round < rounds; round++) {
     const uint64_t m = round == 0 ? mask0 : march_scan(a, ry, tc);
     const int c = __popcll(m);
     const int incl = row_inclusive_sum(c, sub);
-    int k = off + incl - c;  // index of this lane's first sample within the ray
-    off += __shfl(incl, 15, 16);
-    float t = tc;
-    for (int q = 0; q < MARCH_SPL && k < n && (m >> q) != 0; q++) {
-      const float dt = march_dt(t, a);
-      if ((m >> q) & 1) {
-        const long s = (long)base + k;
-        a.pos[s * 3] = (__fmaf_rn(t, ry.dx, ry.ox) - a.pos_lo) * a.pos_inv;
-        a.pos[s * 3 + 1] = (__fmaf_rn(t, ry.dy, ry.oy) - a.pos_lo) * a.pos_inv;
-        a.pos[s * 3 + 2] = (__fmaf_rn(t, ry.dz, ry.oz) - a.pos_lo) * a.pos_inv;
+    const int k0 = off + incl - c;  // index of this lane's first sample within the ray
+    const int round_end = min(off + __shfl(incl, 15, 16), n);
+    for (int w0 = off; w0 < round_end; w0 += MARCH_WIN) {
+      float t = tc;
+      int k = k0;
+      for (int q = 0; q < MARCH_SPL && k < w0 + MARCH_WIN && k < n && (m >> q) != 0; q++) {
+        const float dt = march_dt(t, a);
+        if ((m >> q) & 1) {
+          if (k >= w0) win[k - w0] = make_float2(t, dt);
+          k++;
+        }
+        t += dt;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the row lives in one wave: its LDS writes are now visible
+      const int cnt = min(MARCH_WIN, round_end - w0);
+      for (int i = sub; i < cnt; i += 16) {
+        const float2 td = win[i];
+        const long s = (long)base + w0 + i;
+        a.pos[s * 3] = (__fmaf_rn(td.x, ry.dx, ry.ox) - a.pos_lo) * a.pos_inv;
+        a.pos[s * 3 + 1] = (__fmaf_rn(td.x, ry.dy, ry.oy) - a.pos_lo) * a.pos_inv;
+        a.pos[s * 3 + 2] = (__fmaf_rn(td.x, ry.dz, ry.oz) - a.pos_lo) * a.pos_inv;
         a.dirs[s * 3] = ry.dx;
         a.dirs[s * 3 + 1] = ry.dy;
         a.dirs[s * 3 + 2] = ry.dz;
-        a.dt[s] = dt;
-        a.tmid[s] = t;
-        k++;
+        a.dt[s] = td.y;
+        a.tmid[s] = td.x;
       }
-      t += dt;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // window consumed before it is refilled
     }
+    off += __shfl(incl, 15, 16);
     if (round + 1 < rounds) tc = march_advance(tc, MARCH_ROUND, ry.t1, a);
   }
 }
