@@ -93,6 +93,13 @@ int ns_altcorr_pyramid(const float* const* fmaps_host, int num_levels, const int
  * Geometry
  * ---------------------------------------------------------------------------------------- */
 
+/* cvx_upsample (utils/flow_viz.py:166-183; visual_frontend.py:445-446): convex 8x upsampling of n maps [n,ht,wd] f32 with
+ * the update operator's mask [n, 9*8*8, ht, wd] (f16 or f32 logits; plane index k*64 + sy*8 + sx, k = 3x3 neighbour in
+ * row-major order): out [n, 8ht, 8wd] = sum_k softmax_k(mask)^pow * data(neighbour k); neighbours outside the image are
+ * excluded from the softmax.                                                                                    */
+int ns_cvx_upsample(const float* data, const void* mask, int mask_dtype, float* out, int n, int ht, int wd, float pow_,
+                    void* stream);
+
 /* frame_distance (src/droid.cpp:230-246 -> src/droid_kernels.cu:1572-1594, kernel :630-769)
  *   poses [n,7] (t,q xyzw), disps [n,ht,wd], intrinsics [4], ii,jj [num] i64 -> dist [num].   */
 int ns_frame_distance(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,

@@ -196,6 +196,80 @@ __global__ __launch_bounds__(256) void reproject_kernel(const float* __restrict_
   if (valid) valid[(long)e * HW + k] = (Xj[2] > 0.2f) ? 1.0f : 0.0f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Convex 8x upsampling of a per-keyframe map with the update operator's mask (utils/flow_viz.py:166-183, used at
+// visual_frontend.py:445-446,513-514): out[8y+sy, 8x+sx] = sum_k softmax_k(mask[k, sy, sx, y, x])^pow * data[y+dy_k, x+dx_k]
+// over the 3x3 neighbourhood, neighbours outside the image excluded from the softmax (the reference sets their logits
+// to -inf).  One lane per coarse pixel: every mask plane is read with consecutive lanes on consecutive x, and the lane's
+// 8x8 output block leaves as 16-byte pieces of contiguous rows.
+// ---------------------------------------------------------------------------------------------
+template <typename MT>
+__global__ __launch_bounds__(256) void cvx_upsample_kernel(const float* __restrict__ data, const MT* __restrict__ mask,
+                                                           float* __restrict__ out, int n, int ht, int wd, float pw) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int f = blockIdx.z;
+  if (x >= wd || y >= ht) return;
+  const long HW = (long)ht * wd;
+  const float* d = data + f * HW;
+  const MT* m = mask + (long)f * 576 * HW + (long)y * wd + x;
+  float nb[9];
+  bool ok[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    ok[k] = yy >= 0 && yy < ht && xx >= 0 && xx < wd;
+    nb[k] = ok[k] ? d[(long)yy * wd + xx] : 0.0f;
+  }
+  float* o = out + (long)f * HW * 64 + ((long)(8 * y) * (8 * wd) + 8 * x);
+  for (int sy = 0; sy < 8; sy++) {
+    float row[8];
+#pragma unroll
+    for (int sx = 0; sx < 8; sx++) {
+      float lg[9], mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        lg[k] = ok[k] ? (float)m[(long)(k * 64 + sy * 8 + sx) * HW] : -INFINITY;
+        mx = fmaxf(mx, lg[k]);
+      }
+      float den = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        lg[k] = ok[k] ? __expf(lg[k] - mx) : 0.0f;
+        den += lg[k];
+      }
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        float w = lg[k] / den;
+        if (pw != 1.0f) w = __powf(w, pw);
+        acc = fmaf(w, nb[k], acc);
+      }
+      row[sx] = acc;
+    }
+    float4* dst = reinterpret_cast<float4*>(o + (long)sy * (8 * wd));
+    dst[0] = make_float4(row[0], row[1], row[2], row[3]);
+    dst[1] = make_float4(row[4], row[5], row[6], row[7]);
+  }
+}
+
+extern "C" int ns_cvx_upsample(const float* data, const void* mask, int mask_dtype, float* out, int n, int ht, int wd,
+                               float pow_, void* stream) {
+  if (n == 0) return NS_OK;
+  NS_REQUIRE(data && mask && out, "ns_cvx_upsample: null pointer");
+  NS_REQUIRE(n > 0 && ht > 0 && wd > 0, "ns_cvx_upsample: bad shape");
+  NS_REQUIRE(mask_dtype == NS_F16 || mask_dtype == NS_F32, "ns_cvx_upsample: mask dtype %d unsupported", mask_dtype);
+  dim3 grid(ns_cdiv(wd, 64), ns_cdiv(ht, 4), n);
+  if (mask_dtype == NS_F16)
+    hipLaunchKernelGGL(cvx_upsample_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, data, (const _Float16*)mask, out,
+                       n, ht, wd, pow_);
+  else
+    hipLaunchKernelGGL(cvx_upsample_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, data, (const float*)mask, out, n,
+                       ht, wd, pow_);
+  NS_CHECK_LAUNCH("cvx_upsample_kernel");
+  return NS_OK;
+}
+
 extern "C" int ns_reproject(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,
                             const int64_t* jj, float* coords, float* valid, int num, int ht, int wd, void* stream) {
   if (num <= 0) return NS_OK;  // an empty set is a no-op whatever the pointers are

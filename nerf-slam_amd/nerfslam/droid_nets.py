@@ -228,10 +228,10 @@ class DroidNetworks:
         net = torch.stack([self.hidden.get((i, j), self.ctx[i]) for i, j in zip(ih, jh)])[None]
         inp = torch.stack([self.inp[i] for i in ih])[None]
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda"):
-            net, delta, weight, eta, _ = self.net.update_net(net, inp, corr, motion, ii, jj)
+            net, delta, weight, eta, upmask = self.net.update_net(net, inp, corr, motion, ii, jj)
         for e, (i, j) in enumerate(zip(ih, jh)):
             self.hidden[(i, j)] = net[0, e]
         live = set(zip(ih, jh))
         if len(self.hidden) > 4 * max(len(live), 64):       # edges that left the graph
             self.hidden = {e: h for e, h in self.hidden.items() if e in live}
-        return delta.float(), weight.float(), eta[0].float()
+        return delta.float(), weight.float(), eta[0].float(), upmask[0]

@@ -15,7 +15,8 @@ networks/droid_net.py) are OUT of this project's hot-path scope (SURVEY.md 2A, 8
 weights (`droid.pth`) are missing from the reference tree; they are injected as callables:
     feature_fn(image [3,H,W] float) -> fmap [128, H/8, W/8]
     update_op(corr [1,E,196,ht,wd], motion [1,E,4,ht,wd], ii, jj) -> (delta [1,E,ht,wd,2], weight [1,E,ht,wd,2],
-                                                                          damping [n_unique_ii, ht, wd])
+                                                                          damping [n_unique_ii, ht, wd]
+                                                                          [, upmask [n_unique_ii, 576, ht, wd]])
 """
 import ctypes as C
 
@@ -50,6 +51,11 @@ class TrackingFrontend:
         self.intr8 = (torch.as_tensor(intrinsics, dtype=torch.float32) / 8.0).to(dev)   # :274
         self.feat_bank = torch.zeros((buffer, self.HW, 128), dtype=torch.float16, device=dev)  # channels-last, /4
         self.images = torch.zeros((buffer, 3, H, W), dtype=torch.uint8, device=dev)
+        # full-resolution inverse depth / depth covariance by convex upsampling with the update operator's mask (:191-192,
+        # :445-446); keyframes that never received a mask are upsampled bilinearly in get_viz_out
+        self.cam0_idepths_up = torch.zeros((buffer, H, W), **f)
+        self.cam0_depths_cov_up = torch.ones((buffer, H, W), **f)
+        self.has_up = torch.zeros(buffer, dtype=torch.bool, device=dev)
         self.viz_idx = torch.zeros(buffer, dtype=torch.bool, device=dev)
         gy, gx = torch.meshgrid(torch.arange(self.ht, device=dev), torch.arange(self.wd, device=dev), indexing="ij")
         self.coords0 = torch.stack([gx, gy], -1).float()        # [ht,wd,2]
@@ -158,7 +164,9 @@ class TrackingFrontend:
         coords1 = self.reproject(self.ii, self.jj)                                    # [E,ht,wd,2]
         motion = torch.cat([coords1 - self.coords0, self.target - coords1], -1).permute(0, 3, 1, 2).clamp(-64.0, 64.0)
         corr = self.corr(coords1[None])                                               # [1,E,196,ht,wd]
-        delta, weight, damping = self.update_op(corr, motion[None], self.ii, self.jj)
+        res = self.update_op(corr, motion[None], self.ii, self.jj)
+        delta, weight, damping = res[:3]
+        upmask = res[3] if len(res) > 3 else None
         self.target = coords1 + delta[0].float()
         self.weight = weight[0].float()
         kx = np.unique(self.graph.ii)
@@ -169,6 +177,8 @@ class TrackingFrontend:
         target = torch.cat([self.target_inactive[m_d], self.target], 0).permute(0, 3, 1, 2).contiguous()
         weight = torch.cat([self.weight_inactive[m_d], self.weight], 0).permute(0, 3, 1, 2).contiguous()
         out = self.ba(target, weight, ii_h, jj_h, kf0, itrs=itrs)
+        if upmask is not None:
+            self.upsample(torch.from_numpy(kx).to(self.device), upmask)
         self.graph.age += 1
         self.viz_idx[kf0:self.kf_idx + 1] = True
         return out
@@ -203,6 +213,21 @@ class TrackingFrontend:
             self.cam0_depths_cov[kx] = z / self.cam0_idepths[kx] ** 4                          # :1229
         return sol
 
+    def upsample(self, kx, upmask):
+        """convex 8x upsampling of the inverse depths and depth covariances of keyframes kx (:445-446)"""
+        n = kx.shape[0]
+        mask = upmask.reshape(n, 576, self.ht, self.wd).contiguous()
+        dt = 1 if mask.dtype == torch.float16 else 2
+        if mask.dtype not in (torch.float16, torch.float32):
+            mask, dt = mask.float(), 2
+        with torch.cuda.device(self.device):
+            for src, dst in ((self.cam0_idepths, self.cam0_idepths_up), (self.cam0_depths_cov, self.cam0_depths_cov_up)):
+                out = torch.empty((n, self.H, self.W), dtype=torch.float32, device=self.device)
+                check(lib().ns_cvx_upsample(ptr(src[kx].contiguous()), ptr(mask), dt, ptr(out), n, self.ht, self.wd,
+                                            C.c_float(1.0), stream_ptr()), "cvx_upsample")
+                dst[kx] = out
+        self.has_up[kx] = True
+
     # ---------------------------------------------------------------------------------------------
     def get_viz_out(self):
         """SLAM -> mapper packet (:1337-1391): the dirty keyframes, as DEVICE tensors (the reference moves them to
@@ -214,9 +239,12 @@ class TrackingFrontend:
                                                        align_corners=False)[:, 0]
         out = {"cam0_poses": self.cam0_T_world[idx], "world_T_body": self.world_T_body[idx],
                "world_T_body_cov": self.world_T_body_cov[idx], "cam0_idepths": self.cam0_idepths[idx],
-               "cam0_idepths_up": up(self.cam0_idepths[idx]), "cam0_idepths_sensed": self.cam0_idepths_sensed[idx],
+               "cam0_idepths_up": torch.where(self.has_up[idx, None, None], self.cam0_idepths_up[idx], up(self.cam0_idepths[idx])),
+               "cam0_idepths_sensed": self.cam0_idepths_sensed[idx],
                "cam0_idepths_cov": self.cam0_idepths_cov[idx], "cam0_depths_cov": self.cam0_depths_cov[idx],
-               "cam0_depths_cov_up": up(self.cam0_depths_cov[idx]), "cam0_images": self.images[idx],
+               "cam0_depths_cov_up": torch.where(self.has_up[idx, None, None], self.cam0_depths_cov_up[idx],
+                                                 up(self.cam0_depths_cov[idx])),
+               "cam0_images": self.images[idx],
                "cam0_intrinsics": (self.intr8 * 8.0)[None].repeat(idx.numel(), 1), "viz_idx": idx,
                "kf_idx": self.kf_idx, "is_last_frame": False}
         self.viz_idx[:] = False

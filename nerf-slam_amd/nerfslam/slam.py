@@ -171,7 +171,8 @@ class TrackingSLAM:
         """:530-574: slide frame k+1 over k in every buffer, drop / renumber the edges that touch it."""
         fe = self.fe
         for buf in (fe.images, fe.cam0_T_world, fe.world_T_body, fe.world_T_body_cov, fe.cam0_idepths, fe.cam0_idepths_cov,
-                    fe.cam0_depths_cov, fe.cam0_idepths_sensed, fe.feat_bank):
+                    fe.cam0_depths_cov, fe.cam0_idepths_sensed, fe.feat_bank, fe.cam0_idepths_up, fe.cam0_depths_cov_up,
+                    fe.has_up):
             buf[k] = buf[k + 1]
         if hasattr(self.net, "remove_keyframe"):
             self.net.remove_keyframe(k)
@@ -212,9 +213,12 @@ class TrackingSLAM:
                     if not bool(v.any()):
                         continue
                     corr = corr_op(coords1[None, v], ii[v], jj[v])
-                    delta, w, damping = self.net.update(corr, motion[None, v], ii[v], jj[v])
+                    res = self.net.update(corr, motion[None, v], ii[v], jj[v])
+                    delta, w, damping = res[:3]
                     target[v], weight[v] = coords1[v] + delta[0].float(), w[0].float()
                     fe.damping[torch.unique(ii[v])] = damping
+                    if len(res) > 3:
+                        fe.upsample(torch.unique(ii[v]), res[3])
                 fe.ba(target.permute(0, 3, 1, 2).contiguous(), weight.permute(0, 3, 1, 2).contiguous(), ii_h, jj_h,
                       kf0=0, itrs=2, compute_covariances=False)   # :523-526 (its lm / ep arguments are dead: ba() never reads them)
         g.__init__(max_factors=saved)

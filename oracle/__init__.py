@@ -403,6 +403,23 @@ def ngp_sample_rays(images, depths, covs, c2w, intr, box_lo, box_hi, near, seed,
     return out
 
 
+def cvx_upsample(data, mask, pow_=1.0):
+    """utils/flow_viz.py:166-183 restated in numpy: data [n,ht,wd], mask [n,576,ht,wd] -> [n,8ht,8wd]"""
+    data, mask = np.asarray(data, np.float64), np.asarray(mask, np.float64)
+    n, ht, wd = data.shape
+    m = mask.reshape(n, 9, 8, 8, ht, wd).copy()
+    pad = np.zeros((n, ht + 2, wd + 2)); pad[:, 1:-1, 1:-1] = data
+    nb = np.stack([pad[:, 1 + dy:1 + dy + ht, 1 + dx:1 + dx + wd] for dy in (-1, 0, 1) for dx in (-1, 0, 1)], 1)  # [n,9,ht,wd]
+    yy, xx = np.meshgrid(np.arange(ht), np.arange(wd), indexing="ij")
+    for k, (dy, dx) in enumerate([(a, b) for a in (-1, 0, 1) for b in (-1, 0, 1)]):
+        bad = (yy + dy < 0) | (yy + dy >= ht) | (xx + dx < 0) | (xx + dx >= wd)
+        m[:, k][:, :, :, bad] = -np.inf
+    m = np.exp(m - m.max(1, keepdims=True)); m /= m.sum(1, keepdims=True)
+    m = m ** pow_
+    up = (m * nb[:, :, None, None]).sum(1)                      # [n,8,8,ht,wd]
+    return up.transpose(0, 3, 1, 4, 2).reshape(n, 8 * ht, 8 * wd).astype(np.float32)
+
+
 # --------------------------------------------------------------------------- float64 SE3 (numpy)
 def _qmul(a, b):
     ax, ay, az, aw = a

@@ -86,3 +86,21 @@ def test_tracking_converges_to_ground_truth(oracle_mod, dev):
     assert fe.target.shape[0] == n == fe.corr.corr_pyramid[3].shape[0]
     fe.rm_factors(fe.graph.age > 5, store=True)
     assert fe.target_inactive.shape[0] == len(fe.graph.ii_inactive)
+
+
+def test_cvx_upsample_kernel(oracle_mod, dev):
+    """ns_cvx_upsample against the numpy restatement pinned to utils/flow_viz.py (f32 and f16 masks, pow, 1-pixel-wide maps)"""
+    import ctypes as C
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(0)
+    for (n, ht, wd, pw, dt) in ((3, 12, 16, 1.0, np.float32), (2, 43, 77, 1.0, np.float16), (1, 5, 1, 0.5, np.float32), (1, 1, 9, 1.0, np.float32)):
+        data = rng.uniform(0.1, 2.0, (n, ht, wd)).astype(np.float32)
+        mask = (rng.standard_normal((n, 576, ht, wd)) * 2).astype(dt)
+        ref = oracle_mod.cvx_upsample(data, mask.astype(np.float32), pw)
+        d, m = torch.from_numpy(data).to(dev), torch.from_numpy(mask).to(dev)
+        out = torch.empty((n, 8 * ht, 8 * wd), device=dev)
+        check(lib().ns_cvx_upsample(ptr(d), ptr(m), 1 if dt == np.float16 else 2, ptr(out), n, ht, wd, C.c_float(pw), stream_ptr()),
+              "cvx_upsample")
+        assert np.abs(out.cpu().numpy() - ref).max() <= 5e-6 * max(1.0, np.abs(ref).max()), (n, ht, wd)
+        # a convex combination never leaves the range of the data
+        assert out.min().item() >= data.min() - 1e-5 and (pw != 1.0 or out.max().item() <= data.max() + 1e-5)

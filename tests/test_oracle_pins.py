@@ -206,3 +206,12 @@ def test_golden_reproject(oracle_mod):
     coords, valid = oracle_mod.reproject(g["poses"], g["disps"], g["intr"], g["ii"], g["jj"])
     np.testing.assert_array_equal(valid, g["valid"][..., 0])
     assert np.abs(coords - g["coords"]).max() <= 2e-5 * np.abs(g["coords"]).max()
+
+
+def test_cvx_upsample_matches_reference_function(oracle_mod):
+    """utils/flow_viz.py:166-183 run on seeded inputs (tools/gen_golden.py section 5), incl. the pow variant"""
+    z = np.load(os.path.join(GOLD, "cvx_upsample.npz"))
+    up = oracle_mod.cvx_upsample(z["data"], z["mask"])
+    assert np.abs(up - z["up"]).max() <= 2e-6
+    up2 = oracle_mod.cvx_upsample(z["data"], z["mask"], 0.5)
+    assert np.abs(up2 - z["up_pow05"]).max() <= 2e-6

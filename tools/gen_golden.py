@@ -178,6 +178,19 @@ def main():
                         corr=corr.numpy(), flow=flow.numpy(), ii=ii.numpy(), jj=jj.numpy(), fmap=fm.numpy(), cmap=cm.numpy(),
                         h=h.numpy(), delta=delta.numpy(), weight=weight.numpy(), eta=eta.numpy(),
                         upmask=upmask.numpy()[:, :, ::16], delta_noflow=d0.numpy(), weight_noflow=w0.numpy())
+    # ---- (5) convex upsampling (utils/flow_viz.py:166-183) ----
+    class _AnyAttr(types.ModuleType):                      # import-time needs of flow_viz.py only (default arguments)
+        def __getattr__(self, name):
+            return 0
+    sys.modules.setdefault("cv2", _AnyAttr("cv2"))
+    from utils.flow_viz import cvx_upsample as ref_cvx      # REFERENCE code
+    g = torch.Generator().manual_seed(25)
+    d = torch.rand((2, 5, 7, 1), generator=g) + 0.2
+    mk = torch.randn((2, 576, 5, 7), generator=g) * 2.0
+    up1 = ref_cvx(d.clone(), mk.clone())
+    up2 = ref_cvx(d.clone(), mk.clone(), pow=0.5)
+    np.savez_compressed(os.path.join(out, "cvx_upsample.npz"), data=d[..., 0].numpy(), mask=mk.numpy(), up=up1[..., 0].numpy(),
+                        up_pow05=up2[..., 0].numpy())
     for f in sorted(os.listdir(out)):
         print(f, os.path.getsize(os.path.join(out, f)))
 
