@@ -72,10 +72,36 @@ class NgpConfig:
         return self.min_step * self.aabb_scale * 8.0
 
 
+def pack_fixed(g0, g1, scale):
+    """host-side twin of csrc/ngp.hip:pack_fixed (tests, diagnostics): int64 word = round(g0 S) + (round(g1 S) << 32)"""
+    import numpy as np
+    lo = np.rint(np.asarray(g0, np.float64) * scale).astype(np.int64)
+    hi = np.rint(np.asarray(g1, np.float64) * scale).astype(np.int64)
+    return lo + (hi << 32)
+
+
+def unpack_fixed(words, scale):
+    import numpy as np
+    w = np.asarray(words, np.int64)
+    lo = (w & 0xffffffff).astype(np.uint32).view(np.int32).astype(np.int64)
+    hi = (w - lo) >> 32
+    return lo / scale, hi / scale
+
+
 class NgpNerf:
-    def __init__(self, cfg=None, device="cuda:0", seed=1337):
+    def __init__(self, cfg=None, device="cuda:0", seed=1337, group=None, world=None, rank=None):
+        """group / world / rank: REPLICATED trainers: every replica holds the full model and the same image
+        set, samples its own rays (seed + rank) and the gradients are summed over the replicas before Adam -- one
+        all-reduce of the hash-grid gradient (packed fixed-point words add exactly as int64) and one of the MLP gradient."""
         self.cfg = cfg or NgpConfig()
         self.device = torch.device(device)
+        self.group = group
+        if world is None:
+            import torch.distributed as dist
+            on = dist.is_available() and dist.is_initialized() and group is not None
+            world, rank = (dist.get_world_size(group), dist.get_rank(group)) if on else (1, 0)
+        self.world, self.rank = int(world), int(rank or 0)
+        seed = int(seed) + self.rank
         c, dev = self.cfg, self.device
         off = (C.c_uint32 * (c.n_levels + 1))()
         check(lib().ns_ngp_grid_layout(c.n_levels, 2, c.log2_hashmap, c.base_res, C.c_float(c.per_level_scale), None,
@@ -244,6 +270,8 @@ class NgpNerf:
                                                stream_ptr()), "ngp_encode_backward")
             if c.optimize_extrinsics:
                 self._camera_backward(pos_unit, dfeatT, d, ray_img, N8, R)
+            if self.world > 1:
+                self._allreduce_gradients()
             # optimiser
             self.step += 1
             for (m, hp, g, m1, m2, l2, fx) in (
@@ -251,12 +279,20 @@ class NgpNerf:
                     (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0)):
                 check(lib().ns_ngp_adam(ptr(m), ptr(hp), ptr(g), ptr(m1), ptr(m2), C.c_long(m.numel()), self.step,
                                         C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
-                                        C.c_float(l2), C.c_float(c.loss_scale), C.c_float(fx), stream_ptr()), "ngp_adam")
+                                        C.c_float(l2), C.c_float(c.loss_scale * self.world), C.c_float(fx), stream_ptr()),
+                      "ngp_adam")
             if self.step % c.grid_update_every == 0:
                 self.update_density_grid()
             self.loss_tensor = loss / (self.ray_n >= 0).sum().clamp(min=1)
             self.last_samples, self.last_rays = N, R
         return self.loss_tensor
+
+    def _allreduce_gradients(self):
+        """sum over the replicas; Adam then divides by loss_scale * world (mean gradient)"""
+        import torch.distributed as dist
+        g = self.grid_grad.view(torch.int64) if self.cfg.grad_fixed_scale > 0 else self.grid_grad
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(self.mlp_grad, op=dist.ReduceOp.SUM, group=self.group)
 
     def _camera_backward(self, pos_unit, dfeatT, rays_d, ray_img, N, R):
         """pose refinement: sample-position gradients through the encoding -> per-image 6-dof gradient -> Adam on c2w"""

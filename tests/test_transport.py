@@ -35,6 +35,21 @@ def _worker(rank, world, port, q):
     g = [torch.full((1000,), float(rank + 1)), torch.full((10,), float(10 * (rank + 1)))]
     transport.allreduce_gradients(g)
     ok &= bool((g[0] == 1.5).all() and (g[1] == 15.0).all())
+    # replicated NeRF trainers: the packed fixed-point hash-grid gradient (two signed Q18 fields per int64 word) is summed
+    # as int64 and still decodes to the sum of the fields, negative values and cross-field borrows included
+    from nerfslam.ngp import pack_fixed, unpack_fixed
+    rng = np.random.default_rng(10 + rank)
+    a, b = rng.normal(0, 5, 4096), rng.normal(0, 5, 4096)
+    words = torch.from_numpy(pack_fixed(a, b, 262144.0))
+    dist.all_reduce(words)
+    tot = [np.zeros(4096), np.zeros(4096)]
+    for r in range(world):
+        rr = np.random.default_rng(10 + r)
+        x, y = rr.normal(0, 5, 4096), rr.normal(0, 5, 4096)
+        tot[0] += np.rint(x * 262144.0) / 262144.0
+        tot[1] += np.rint(y * 262144.0) / 262144.0
+    lo, hi = unpack_fixed(words.numpy(), 262144.0)
+    ok &= bool(np.array_equal(lo, tot[0]) and np.array_equal(hi, tot[1]))
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
