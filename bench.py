@@ -270,13 +270,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the HIP path")
+    # NS_BENCH_DIST_BACKEND=gloo + NS_BENCH_ONE_DEVICE=1: smoke-test the N > 1 control flow on a 1-GPU box (all ranks on
+    # device 0, timing collectives over gloo); the driver's runs use one GPU per rank over RCCL.
+    backend = os.environ.get("NS_BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("NS_BENCH_ONE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.set_grad_enabled(False)
 
     hp = HotPath(dev, seed=rank)
@@ -299,7 +307,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt
