@@ -222,10 +222,12 @@ def cpu_baseline(hp):
     oracle.solve_depth(dx, a[1], Q, E, w, hp.ii_h, hp.jj_h, KF0, KF1)
     t["ba_iteration"] = time.time() - t0
     step = (1 + E_NEW) * t["build_per_edge"] + (6 + 1.0 / E_ACTIVE) * t["lookup48"] + 12 * t["ba_iteration"]
-    return {"value": 1.0 / step, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "oracle (scalar C port, 1 thread): 1-edge pyramid build %.2fs, 48-edge 4-level lookup %.2fs, "
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"value": 1.0 / step, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle (C port, OpenMP over %d host cores for the volume build, the lookup and the per-edge linearisation; "
+                      "accumulation / Schur / depth update single-threaded): 1-edge pyramid build %.2fs, 48-edge 4-level lookup %.2fs, "
                       "one M=96 BA linearisation+Schur+depth %.2fs; extrapolated to one step = 11 builds, "
-                      "6 lookups, 12 BA iterations" % (t["build_per_edge"], t["lookup48"], t["ba_iteration"])}
+                      "6 lookups, 12 BA iterations" % (cores, t["build_per_edge"], t["lookup48"], t["ba_iteration"])}
 
 
 def mapping_rate(dev, steps=100, warmup=200):

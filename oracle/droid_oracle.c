@@ -104,6 +104,8 @@ void orc_corr_index_forward_f16(const uint16_t* volume, const float* coords, uin
   const int rd = 2 * r + 1;
   const long HW1 = (long)h1 * w1;
   memset(corr, 0, sizeof(uint16_t) * (size_t)B * rd * rd * HW1);
+  /* every (n, y, x) owns its outputs: threads change nothing in the arithmetic (bench.py times this on all host cores) */
+#pragma omp parallel for collapse(2) schedule(static)
   for (int n = 0; n < B; n++)
     for (int y = 0; y < h1; y++)
       for (int x = 0; x < w1; x++) {
@@ -176,6 +178,7 @@ void orc_corr_index_forward_f32(const float* volume, const float* coords, float*
 /* ------------------------------------------------------------------------- */
 void orc_corr_pool_f16(const uint16_t* in, uint16_t* out, long nslices, int h, int w) {
   int ho = h / 2, wo = w / 2;
+#pragma omp parallel for schedule(static)
   for (long s = 0; s < nslices; s++) {
     const uint16_t* I = in + s * (long)h * w;
     uint16_t* O = out + s * (long)ho * wo;
@@ -200,6 +203,7 @@ void orc_corr_volume_f16(const uint16_t* fmap1, const uint16_t* fmap2, uint16_t*
       a[k] = h2f(f2h(h2f(fmap1[(long)e * C * HW + k]) / 4.0f));
       b[k] = h2f(f2h(h2f(fmap2[(long)e * C * HW + k]) / 4.0f));
     }
+#pragma omp parallel for schedule(static)
     for (int p = 0; p < HW; p++)
       for (int q = 0; q < HW; q++) {
         double acc = 0.0;
@@ -440,6 +444,7 @@ void orc_projective_transform(const float* target, const float* weight, const fl
   const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
   const float* cTb_t = extr;
   const float* cTb_q = extr + 3;
+#pragma omp parallel for schedule(static) /* per-edge outputs are disjoint */
   for (int e = 0; e < M; e++) {
     const int ix = (int)ii[e], jx = (int)jj[e];
     float tij[3], qij[4];
