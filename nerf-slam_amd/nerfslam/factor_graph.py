@@ -30,6 +30,17 @@ class FactorGraph:
         self.ii_bad, self.jj_bad = z.copy(), z.copy()
         self.version = 0  # bumped on every change: consumers cache their BaPlan on it
 
+    def reset(self, max_factors=None):
+        """drop every edge list (global-BA passes, visual_frontend.py:1263-1283); the version keeps growing so that
+        plans cached on it can never be mistaken for the new graph's"""
+        z = np.zeros((0,), np.int64)
+        self.ii, self.jj, self.age = z.copy(), z.copy(), z.copy()
+        self.ii_inactive, self.jj_inactive = z.copy(), z.copy()
+        self.ii_bad, self.jj_bad = z.copy(), z.copy()
+        if max_factors is not None:
+            self.max_factors = max_factors
+        self.version += 1
+
     # ---------------------------------------------------------------------------------------------
     @staticmethod
     def neighborhood_edges(kf0, kf1, radius, stereo=False):

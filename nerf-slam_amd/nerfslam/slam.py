@@ -193,7 +193,7 @@ class TrackingSLAM:
             fe.cam0_T_world[:t, :3] *= s
         g = fe.graph
         saved = g.max_factors
-        g.__init__(max_factors=16 * t)
+        g.reset(max_factors=16 * t)
         fe.corr, fe.damping = None, 1e-6 * torch.ones_like(fe.cam0_idepths)
         fe.target = fe.weight = fe.target_inactive = fe.weight_inactive = torch.zeros((0, fe.ht, fe.wd, 2), device=self.device)
         I, J = np.meshgrid(np.arange(0, t + 1), np.arange(0, t + 1), indexing="ij")
@@ -221,7 +221,7 @@ class TrackingSLAM:
                         fe.upsample(torch.unique(ii[v]), res[3])
                 fe.ba(target.permute(0, 3, 1, 2).contiguous(), weight.permute(0, 3, 1, 2).contiguous(), ii_h, jj_h,
                       kf0=0, itrs=2, compute_covariances=False)   # :523-526 (its lm / ep arguments are dead: ba() never reads them)
-        g.__init__(max_factors=saved)
+        g.reset(max_factors=saved)
         fe._sync_edges()
         fe.viz_idx[:t] = True
 

@@ -102,3 +102,14 @@ def test_neighborhood_and_ba_edges():
     ii, jj, m = g.ba_edges(kf0=5)
     np.testing.assert_array_equal(m, [False, True, False, True])
     np.testing.assert_array_equal(ii, [2, 4, 5, 6, 7])
+
+
+def test_reset_keeps_the_version_monotonic():
+    from nerfslam.factor_graph import FactorGraph
+    g = FactorGraph(max_factors=10)
+    g.add([1, 2], [2, 1])
+    v = g.version
+    g.reset(max_factors=99)
+    assert g.version > v and len(g.ii) == 0 and len(g.ii_inactive) == 0 and g.max_factors == 99
+    g.add([1], [2])
+    assert g.version > v + 1
