@@ -18,6 +18,8 @@
 // out-of-image taps are skipped.  Adding a +0 product is the identity on every value the
 // accumulator can hold (it can never be -0), so masking taps to +0 reproduces the skip and the
 // result is bit-identical to the reference's arithmetic.  FP contraction is off in this file.
+#include <cstdlib>
+
 #include "common.h"
 #include <hip/hip_fp16.h>
 
@@ -211,6 +213,166 @@ __global__ __launch_bounds__(256) void corr_lookup_pyramid_kernel(LookupLevels L
                 o, HW1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cooperative variant of the fused pyramid lookup: EIGHT lanes per (edge, pixel, level), one per window row.
+//
+// The one-lane-per-pixel kernel above issues 8 (row-major) or 16 (tiled) 16-byte loads per lane, each its own L2
+// request because every lane reads its own slice: at ~15 M requests per launch it sits on the L2 request rate
+// (~140 G/s), not on bytes.  Here lane r of a pixel's 8-lane group owns ONE window row:
+//   tiled level   : tile row r of the window's tile column pair -- rows yb..yb+7 wrap around the tile height, so the
+//                   lanes r >= (yb & 7) read the upper tile pair and the others the lower one: 2 aligned loads per
+//                   lane, and the 8 lanes of a pixel together read whole tile lines (2-4 L2 requests per pixel);
+//   row-major level: window row r, one unaligned 16-byte load.
+// The neighbouring row for the bilinear blend comes from the next lane of the group (one ds_bpermute per dword),
+// every lane computes the 7 outputs of its row with the same packed-f16 operation order as above (bit-identical),
+// and the 49 x 64 outputs of the workgroup's 64 pixels are staged in LDS and written as whole 128-byte channel-plane
+// lines (8 lanes x 16 B), as before.
+// ---------------------------------------------------------------------------------------------
+#define COOP_PITCH 72  // halves per LDS plane row (64 pixels + pad; 144 B keeps 16-byte reads aligned)
+
+__global__ __launch_bounds__(512) void corr_lookup_coop_kernel(LookupLevels L, const float* __restrict__ coords,
+                                                               int interleaved, _Float16* __restrict__ out, int E,
+                                                               int HW1) {
+  __shared__ __attribute__((aligned(16))) uint16_t ob[49 * COOP_PITCH];
+  const int t = threadIdx.x, r = t & 7, pl = t >> 3;
+  const int lvl = blockIdx.y;
+  const long idx0 = (long)blockIdx.x * 64;
+  const long total_px = (long)E * HW1;
+  const long idx = idx0 + pl;
+  const bool live = idx < total_px;
+  const long idc = live ? idx : total_px - 1;
+  const int n = (int)(idc / HW1);
+  const int p = (int)(idc - (long)n * HW1);
+  float cx, cy;
+  if (interleaved) {
+    const float2 c = *reinterpret_cast<const float2*>(coords + 2 * idc);
+    cx = c.x;
+    cy = c.y;
+  } else {
+    cx = coords[((long)n * 2 + 0) * HW1 + p];
+    cy = coords[((long)n * 2 + 1) * HW1 + p];
+  }
+  const float sc = L.scale[lvl];
+  const float x0 = cx * sc, y0 = cy * sc;
+  const int h2 = L.h2[lvl], w2 = L.w2[lvl], ntx = L.ntx[lvl];
+  const _Float16* __restrict__ vol = L.vol[lvl];
+  const long slice_off = idc * L.slice_elems[lvl], total = L.total_elems[lvl];
+  const float fx0 = floorf(x0), fy0 = floorf(y0);
+  const bool sane = live && (fabsf(x0) < 1.0e6f) && (fabsf(y0) < 1.0e6f);
+  const float dx = sane ? x0 - fx0 : 0.0f, dy = sane ? y0 - fy0 : 0.0f;
+  const int xb = sane ? (int)fx0 - 3 : -100000;
+  const int yb = sane ? (int)fy0 - 3 : -100000;
+  uint32_t cm[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int xl = xb + 2 * k, xh = xl + 1;
+    cm[k] = ((xl >= 0 && xl < w2) ? 0x0000ffffu : 0u) | ((xh >= 0 && xh < w2) ? 0xffff0000u : 0u);
+  }
+  const bool any_col = (xb > -8) && (xb < w2);
+  // the window row this lane owns
+  const int j = ntx > 0 ? ((r - yb) & 7) : r;
+  const int y1 = yb + j;
+  const bool rowvalid = any_col && y1 >= 0 && y1 < h2;
+  uint32_t row[4];
+  if (ntx > 0) {
+    const int tx0 = xb >> 3, c0 = xb & 7;
+    const bool okA = rowvalid && tx0 >= 0 && tx0 < ntx, okB = rowvalid && tx0 + 1 >= 0 && tx0 + 1 < ntx;
+    const long base = slice_off + ((long)(y1 >> 3) * ntx + tx0) * 64 + (y1 & 7) * 8;
+    const u32x4 A = *reinterpret_cast<const u32x4*>(vol + (okA ? base : slice_off));
+    const u32x4 B = *reinterpret_cast<const u32x4*>(vol + (okB ? base + 64 : slice_off));
+    uint32_t D[9];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      D[k] = okA ? A[k] : 0u;
+      D[4 + k] = okB ? B[k] : 0u;
+    }
+    D[8] = 0u;
+    const uint32_t sel1 = (c0 & 2) ? ~0u : 0u, sel2 = (c0 & 4) ? ~0u : 0u, sh16 = (c0 & 1) ? 16u : 0u;
+    uint32_t Es[7], F[5];
+#pragma unroll
+    for (int i = 0; i < 7; i++) Es[i] = (D[i + 1] & sel1) | (D[i] & ~sel1);
+#pragma unroll
+    for (int i = 0; i < 5; i++) F[i] = (Es[i + 2] & sel2) | (Es[i] & ~sel2);
+#pragma unroll
+    for (int k = 0; k < 4; k++) row[k] = __builtin_amdgcn_alignbit(F[k + 1], F[k], sh16) & cm[k];
+  } else {
+    const long g0 = slice_off + (long)y1 * w2 + xb;
+    const bool inb = g0 >= 0 && g0 + 8 <= total;
+    if (rowvalid && inb) {
+      const Run16 rr = *reinterpret_cast<const Run16*>(vol + g0);
+#pragma unroll
+      for (int k = 0; k < 4; k++) row[k] = rr.d[k] & cm[k];
+    } else if (rowvalid) {  // the run pokes outside the tensor (first / last slice only): element-wise, bounds-checked
+      const uint16_t* v16 = reinterpret_cast<const uint16_t*>(vol);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int xl = xb + 2 * k;
+        const uint32_t lo = (xl >= 0 && xl < w2) ? v16[g0 + 2 * k] : 0u;
+        const uint32_t hi = (xl + 1 >= 0 && xl + 1 < w2) ? v16[g0 + 2 * k + 1] : 0u;
+        row[k] = lo | (hi << 16);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) row[k] = 0u;
+    }
+  }
+  // next window row from the next lane of the group
+  uint32_t nxt[4];
+  const int srcl = (t & 63 & ~7) | ((r + 1) & 7);
+#pragma unroll
+  for (int k = 0; k < 4; k++) nxt[k] = (uint32_t)__shfl((int)row[k], srcl);
+  float p00 = (1.0f - dx) * (1.0f - dy), p01 = (1.0f - dx) * dy, p10 = dx * (1.0f - dy), p11 = dx * dy;
+  asm volatile("" : "+v"(p00), "+v"(p01), "+v"(p10), "+v"(p11));  // no mul+cvt fusion (see lookup_r3_f16)
+  const _Float16 w00 = (_Float16)p00, w01 = (_Float16)p01, w10 = (_Float16)p10, w11 = (_Float16)p11;
+  const h2_t W00 = {w00, w00}, W01 = {w01, w01}, W10 = {w10, w10}, W11 = {w11, w11};
+  uint32_t sh[4], shn[4];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    sh[k] = __builtin_amdgcn_alignbit(row[k + 1], row[k], 16);
+    shn[k] = __builtin_amdgcn_alignbit(nxt[k + 1], nxt[k], 16);
+  }
+  sh[3] = row[3] >> 16;
+  shn[3] = nxt[3] >> 16;
+  if (j < 7) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      h2_t acc = as_h2(row[k]) * W00;        // tap (a  , b  )
+      acc = acc + as_h2(nxt[k]) * W01;       // tap (a  , b+1)
+      acc = acc + as_h2(sh[k]) * W10;        // tap (a+1, b  )
+      acc = acc + as_h2(shn[k]) * W11;       // tap (a+1, b+1)
+      const uint32_t u = as_u32(acc);
+      const int a0 = 2 * k;
+      ob[(a0 * 7 + j) * COOP_PITCH + pl] = (uint16_t)(u & 0xffffu);
+      if (a0 + 1 < 7) ob[((a0 + 1) * 7 + j) * COOP_PITCH + pl] = (uint16_t)(u >> 16);
+    }
+  }
+  __syncthreads();
+  // 49 channel planes x 64 pixels -> whole lines where the 8 pixels of a piece are consecutive in one plane
+  uint16_t* o16 = reinterpret_cast<uint16_t*>(out);
+  for (int q = t; q < 49 * 8; q += 512) {
+    const int ch = q >> 3, piece = q & 7;
+    const long i0 = idx0 + piece * 8;
+    if (i0 >= total_px) continue;
+    const int n0 = (int)(i0 / HW1);
+    const int q0 = (int)(i0 - (long)n0 * HW1);
+    const uint16_t* src = ob + ch * COOP_PITCH + piece * 8;
+    if (q0 + 8 <= HW1 && i0 + 8 <= total_px) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src);
+      Run16 w;
+      w.d[0] = v.x; w.d[1] = v.y; w.d[2] = v.z; w.d[3] = v.w;
+      *reinterpret_cast<Run16*>(o16 + ((long)n0 * (L.num_levels * 49) + lvl * 49 + ch) * HW1 + q0) = w;
+    } else {
+      for (int e = 0; e < 8; e++) {
+        const long ie = i0 + e;
+        if (ie >= total_px) break;
+        const int ne = (int)(ie / HW1);
+        const int pe = (int)(ie - (long)ne * HW1);
+        o16[((long)ne * (L.num_levels * 49) + lvl * 49 + ch) * HW1 + pe] = src[e];
+      }
+    }
+  }
+}
+
 // Generic single-level kernel (any radius, f16 or f32): one lane per pixel, scalar taps.
 // Same arithmetic order as the reference; used by the drop-in op when radius != 3 or dtype f32.
 template <typename T>
@@ -315,10 +477,18 @@ extern "C" int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_level
     L.total_elems[l] = (long)E * HW1 * L.slice_elems[l];
     NS_REQUIRE(L.h2[l] > 0 && L.w2[l] > 0, "ns_corr_lookup_pyramid: level %d is empty", ll);
   }
-  dim3 grid(ns_cdiv((long)E * HW1, 256), num_levels);
-  hipLaunchKernelGGL(corr_lookup_pyramid_kernel, grid, dim3(256), 0, (hipStream_t)stream, L, coords,
-                     coords_interleaved, (_Float16*)out, E, (int)HW1);
-  NS_CHECK_LAUNCH("corr_lookup_pyramid_kernel");
+  static const bool one_lane = getenv("NS_LOOKUP_ONE_LANE") != nullptr;  // comparison switch: one lane per pixel
+  if (one_lane) {
+    dim3 grid(ns_cdiv((long)E * HW1, 256), num_levels);
+    hipLaunchKernelGGL(corr_lookup_pyramid_kernel, grid, dim3(256), 0, (hipStream_t)stream, L, coords,
+                       coords_interleaved, (_Float16*)out, E, (int)HW1);
+    NS_CHECK_LAUNCH("corr_lookup_pyramid_kernel");
+  } else {
+    dim3 grid(ns_cdiv((long)E * HW1, 64), num_levels);
+    hipLaunchKernelGGL(corr_lookup_coop_kernel, grid, dim3(512), 0, (hipStream_t)stream, L, coords, coords_interleaved,
+                       (_Float16*)out, E, (int)HW1);
+    NS_CHECK_LAUNCH("corr_lookup_coop_kernel");
+  }
   return NS_OK;
 }
 
