@@ -67,12 +67,25 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(SolveArgs a) {
   if (tid == 0) fail = 0;
 
   // ---- load the upper triangle of H (what the HessianFactors keep) ----
-  for (int idx = tid; idx < n * n; idx += SOLVE_THREADS) {
-    const int r = idx / n, c = idx - r * n;
-    if (c <= r) {
-      double h = (double)a.H[(long)c * n + r];
-      if (c == r) h += (double)a.ep + (double)a.lm * h;
-      Lp[tri(r, c)] = h;
+  // eight independent global loads per thread in flight, then the LDS stores (a load -> store loop ran at one global
+  // round trip per 256 elements: 6 us for n = 60)
+  for (int base = 0; base < n * n; base += 8 * SOLVE_THREADS) {
+    float hv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int idx = base + tid + u * SOLVE_THREADS;
+      const int r = idx / n, c = idx - r * n;
+      hv[u] = (idx < n * n && c <= r) ? a.H[(long)c * n + r] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int idx = base + tid + u * SOLVE_THREADS;
+      const int r = idx / n, c = idx - r * n;
+      if (idx < n * n && c <= r) {
+        double h = (double)hv[u];
+        if (c == r) h += (double)a.ep + (double)a.lm * h;
+        Lp[tri(r, c)] = h;
+      }
     }
   }
   for (int r = tid; r < n; r += SOLVE_THREADS) yrow[r] = (double)a.v[r];
@@ -103,44 +116,49 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(SolveArgs a) {
     __syncthreads();
   }
 
-  // ---- blocked right-looking Cholesky of the bordered system, block = one pose (6) ----
+  // ---- blocked right-looking Cholesky of the bordered system, block = one pose (6), with LOOK-AHEAD ----
+  // The 6x6 diagonal factor is a serial fp64 chain on one lane (0.7 us per block: a quarter of the kernel when it sat
+  // between two barriers).  Wave 0 is the diagonal specialist: during the trailing update of block jb it first applies
+  // that update to the NEXT diagonal block (21 entries, all the trailing entries the next block's rows have), factors it,
+  // and the other three waves meanwhile do the rest of the trailing update.
+  auto factor_diag = [&](int j0) {  // lane 0 of wave 0
+    double D[21];
+    load_diag(Lp, j0, D);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      double s = D[j * (j + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= D[j * (j + 1) / 2 + k] * D[j * (j + 1) / 2 + k];
+      if (!(s > 0.0)) {
+        fail = j0 + j + 1;
+        s = 1.0;
+      }
+      // 1/sqrt(s) from the hardware estimate + two Newton steps (each squares the error: 2^-26 -> < 2^-100), then
+      // d = s * di: ~12 dependent ops on the critical path of every block column instead of the ~40 of an IEEE
+      // sqrt followed by an IEEE divide
+      double di = __builtin_amdgcn_rsq(s);
+      di = di * (1.5 - 0.5 * s * di * di);
+      di = di * (1.5 - 0.5 * s * di * di);
+      const double d = s * di;
+      D[j * (j + 1) / 2 + j] = d;
+      rd[j0 + j] = di;
+#pragma unroll
+      for (int i = j + 1; i < 6; i++) {
+        double t = D[i * (i + 1) / 2 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) t -= D[i * (i + 1) / 2 + k] * D[j * (j + 1) / 2 + k];
+        D[i * (i + 1) / 2 + j] = t * di;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c <= r; c++) Lp[tri(j0 + r, j0 + c)] = D[r * (r + 1) / 2 + c];
+  };
+  if (tid == 0) factor_diag(0);
+  __syncthreads();
   for (int jb = 0; jb < P; jb++) {
     const int j0 = 6 * jb;
-    if (tid == 0) {  // diagonal block in registers (one LDS round trip instead of ~100 dependent ones)
-      double D[21];
-      load_diag(Lp, j0, D);
-#pragma unroll
-      for (int j = 0; j < 6; j++) {
-        double s = D[j * (j + 1) / 2 + j];
-#pragma unroll
-        for (int k = 0; k < j; k++) s -= D[j * (j + 1) / 2 + k] * D[j * (j + 1) / 2 + k];
-        if (!(s > 0.0)) {
-          fail = j0 + j + 1;
-          s = 1.0;
-        }
-        // 1/sqrt(s) from the hardware estimate + two Newton steps (each squares the error: 2^-26 -> < 2^-100), then
-        // d = s * di: ~12 dependent ops on the critical path of every block column instead of the ~40 of an IEEE
-        // sqrt followed by an IEEE divide (this serial 6x6 factor was a third of the kernel)
-        double di = __builtin_amdgcn_rsq(s);
-        di = di * (1.5 - 0.5 * s * di * di);
-        di = di * (1.5 - 0.5 * s * di * di);
-        const double d = s * di;
-        D[j * (j + 1) / 2 + j] = d;
-        rd[j0 + j] = di;
-#pragma unroll
-        for (int i = j + 1; i < 6; i++) {
-          double t = D[i * (i + 1) / 2 + j];
-#pragma unroll
-          for (int k = 0; k < j; k++) t -= D[i * (i + 1) / 2 + k] * D[j * (j + 1) / 2 + k];
-          D[i * (i + 1) / 2 + j] = t * di;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int c = 0; c <= r; c++) Lp[tri(j0 + r, j0 + c)] = D[r * (r + 1) / 2 + c];
-    }
-    __syncthreads();
     // panel: rows below the diagonal block (row n = rhs),  X * Ljj^T = A_ij
     for (int i = j0 + 6 + tid; i < nrows; i += SOLVE_THREADS) {
       double D[21], X[6], R[6];
@@ -162,21 +180,41 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(SolveArgs a) {
       for (int c = 0; c < 6; c++) row[c] = X[c];
     }
     __syncthreads();
-    // trailing update on a 16x16 thread grid; the row's panel entries stay in registers
-    const int tx = tid & 15, ty = tid >> 4;
-    for (int i = j0 + 6 + ty; i < nrows; i += 16) {
-      double Ri[6];
-      const double* ri = rowp(i, j0);
+    const bool has_next = jb + 1 < P;
+    if (tid < 64) {
+      if (has_next) {
+        // the next diagonal block: lane l < 21 <-> entry (i, k), k <= i, of rows j0+6 .. j0+11
+        if (tid < 21) {
+          int li = 0;
+          while ((li + 1) * (li + 2) / 2 <= tid) li++;
+          const int lk = tid - li * (li + 1) / 2;
+          const double* ri = Lp + tri(j0 + 6 + li, j0);
+          const double* rk = Lp + tri(j0 + 6 + lk, j0);
+          double s = 0.0;
 #pragma unroll
-      for (int c = 0; c < 6; c++) Ri[c] = ri[c];
-      const int kmax = (i < n) ? i : n - 1;  // border rows have no diagonal entry
-      double* out = rowp(i, 0);
-      for (int k = j0 + 6 + tx; k <= kmax; k += 16) {
-        const double* rk = Lp + tri(k, j0);
-        double s = 0.0;
+          for (int c = 0; c < 6; c++) s += ri[c] * rk[c];
+          Lp[tri(j0 + 6 + li, j0 + 6 + lk)] -= s;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave: the 21 updates are in LDS before lane 0 reads them
+        if (tid == 0) factor_diag(j0 + 6);
+      }
+    } else {
+      // trailing update by the other three waves on a 16 x 12 thread grid; rows of the next block are wave 0's
+      const int t2 = tid - 64, tx = t2 & 15, ty = t2 >> 4;
+      for (int i = j0 + 12 + ty; i < nrows; i += 12) {
+        double Ri[6];
+        const double* ri = rowp(i, j0);
 #pragma unroll
-        for (int c = 0; c < 6; c++) s += Ri[c] * rk[c];
-        out[k] -= s;
+        for (int c = 0; c < 6; c++) Ri[c] = ri[c];
+        const int kmax = (i < n) ? i : n - 1;  // border rows have no diagonal entry
+        double* out = rowp(i, 0);
+        for (int k = j0 + 6 + tx; k <= kmax; k += 16) {
+          const double* rk = Lp + tri(k, j0);
+          double s = 0.0;
+#pragma unroll
+          for (int c = 0; c < 6; c++) s += Ri[c] * rk[c];
+          out[k] -= s;
+        }
       }
     }
     __syncthreads();
