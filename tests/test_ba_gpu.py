@@ -30,7 +30,8 @@ def close(got, ref, rel, what=""):
 PROBLEMS = [dict(ht=12, wd=16, P=5, M=24, seed=0),
             dict(ht=9, wd=13, P=4, M=14, seed=1, kf0=3, extra_fixed=2, sensed_frac=0.3),
             dict(ht=30, wd=40, P=8, M=60, seed=2, kf0=3, extra_fixed=3),
-            dict(ht=43, wd=77, P=6, M=30, seed=3, sensed_frac=0.5)]
+            dict(ht=43, wd=77, P=6, M=30, seed=3, sensed_frac=0.5),
+            dict(ht=60, wd=80, P=10, M=96, seed=4, kf0=6, extra_fixed=3, sensed_frac=0.1)]   # BASELINE C640: M=96, P=10
 
 
 @pytest.mark.parametrize("cfg", PROBLEMS)
