@@ -25,3 +25,14 @@ for _ in range(steps):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"steps/s {steps / dt:.1f}  ms/step {1e3 * dt / steps:.3f}  samples/step {ns / steps:.0f}  rays-with-samples/step {nr / steps:.0f}  Msamples/s {ns / dt / 1e6:.1f}  loss {float(net.loss_tensor):.4f}")
+
+# quality: render the training views at their poses and compare with the ground truth (linear rgb), PSNR in dB
+from nerfslam import eval as ev
+imgs, deps, covs, poses, intr = sc.sphere_scene()
+ps, l1 = [], []
+for k in (0, 3):
+    rgb, dep = net.render(poses[k], imgs.shape[1], imgs.shape[2])
+    ps.append(ev.psnr(rgb.cpu(), imgs[k, ..., :3]))
+    m = deps[k] > 0
+    l1.append(float((dep.cpu()[m] - deps[k][m]).abs().mean()))
+print(f"after {net.step} steps: PSNR {sum(ps) / len(ps):.1f} dB over 2 training views, mean |depth error| on the object {100 * sum(l1) / len(l1):.2f} cm")
