@@ -261,7 +261,7 @@ __device__ __forceinline__ void mask_tile(const f32x16& acc0, const f32x16& acc1
   }
 }
 
-__global__ __launch_bounds__(256) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
   __shared__ f16x8 Wf[BW_NFRAG * 64];
   fill_frags<true>(Wf, a.W, W5_OFF, 16, 64, BW_L5);
   fill_frags<true>(Wf, a.W, W4_OFF, 64, 64, BW_L4);
