@@ -92,7 +92,7 @@ __device__ __forceinline__ void altcorr_pixel(const float* __restrict__ f1, cons
 }
 
 // drop-in op: pre-gathered per-edge feature maps, one level, N coordinate sets
-__global__ __launch_bounds__(256) void altcorr_forward_kernel(const float* __restrict__ fmap1,
+__global__ __launch_bounds__(256, 4) void altcorr_forward_kernel(const float* __restrict__ fmap1,
                                                               const float* __restrict__ fmap2,
                                                               const float* __restrict__ coords,
                                                               float* __restrict__ corr, int B, int H1, int W1,
@@ -121,7 +121,7 @@ struct AltPyramid {
   int num_levels;
 };
 
-__global__ __launch_bounds__(256) void altcorr_pyramid_kernel(AltPyramid P, const int64_t* __restrict__ ii,
+__global__ __launch_bounds__(256, 4) void altcorr_pyramid_kernel(AltPyramid P, const int64_t* __restrict__ ii,
                                                               const int64_t* __restrict__ jj,
                                                               const float* __restrict__ coords,
                                                               float* __restrict__ out, int E, int H1, int W1, int C) {
