@@ -243,3 +243,28 @@ def test_empty_edge_sets(dev):
     assert d.shape == (0,)
     alt = AltCorrBlock(torch.randn((1, 4, 128, ht, wd), device=dev))
     assert alt(torch.zeros((1, 0, ht, wd, 2), device=dev), empty, empty).shape == (1, 0, 196, ht, wd)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 3, 5), (3, 8, 8), (2, 9, 17), (1, 24, 8), (5, 31, 33)])
+def test_lookup_small_and_odd_shapes_against_oracle(oracle_mod, dev, shape):
+    """the cooperative fused lookup on degenerate sizes (levels that shrink to 0-1 pixels are clamped by the reference's
+    own floor division), row-major and tiled volumes, against the oracle's per-level lookups bit for bit"""
+    from nerfslam.corr import CorrBlock
+    E, ht, wd = shape
+    g = torch.Generator().manual_seed(E * 1000 + ht * 10 + wd)
+    nl = 1
+    while nl < 4 and (ht >> nl) > 0 and (wd >> nl) > 0:
+        nl += 1
+    f1 = torch.randn((1, E, 128, ht, wd), generator=g).half().to(dev)
+    f2 = torch.randn((1, E, 128, ht, wd), generator=g).half().to(dev)
+    gy, gx = torch.meshgrid(torch.arange(ht), torch.arange(wd), indexing="ij")
+    coords = (torch.stack([gx, gy], -1).float()[None, None] + torch.randn((1, E, ht, wd, 2), generator=g) * 3.0).to(dev)
+    blocks = [CorrBlock(f1, f2, num_levels=nl, fused=True, tiled=t) for t in (False, True)]
+    outs = [b(coords) for b in blocks]
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    pyr = [p.cpu().numpy() for p in blocks[0].corr_pyramid]
+    cf = np.ascontiguousarray(coords[0].cpu().numpy().transpose(0, 3, 1, 2))
+    ref = np.concatenate([oracle_mod.corr_index_forward(pyr[l], cf / np.float32(2 ** l), 3).reshape(E, 49, ht, wd)
+                          for l in range(nl)], 1)
+    got = outs[0][0].cpu().numpy()
+    assert ((got.view(np.uint16) == ref.view(np.uint16)) | ((got == 0) & (ref == 0))).all()
