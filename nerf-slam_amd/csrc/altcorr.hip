@@ -14,6 +14,8 @@
 // No LDS, no barriers, no atomics, no zero-fill.  Arithmetic is f32 like the reference's float
 // dispatch (corr.py:121); summation order differs from the reference's 32-channel slabs, so the
 // parity tolerance is relative 1e-5 of max|corr| (tests/test_altcorr.py).
+#include <cstdlib>
+
 #include "common.h"
 
 #define ALT_PIX_PER_WAVE 8
@@ -145,6 +147,137 @@ __global__ __launch_bounds__(256, 4) void altcorr_pyramid_kernel(AltPyramid P, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tiled variant of the fused pyramid kernel.  The wave-per-pixel kernel above reads a private 8x8x128-channel window
+// (32 KiB) per (edge, pixel, level) through L1/L2: 30 GB per 48-edge call, i.e. it runs at the L2 bandwidth (~13 TB/s,
+// 2.3 ms).  Neighbouring pixels of a smooth flow field look at nearly the same target region, so here a workgroup owns
+// an 8x8 SOURCE-PIXEL TILE of one (edge, level): it stages the union of the tile's windows (bounding box, clipped to the
+// image) through LDS one 16-channel slab at a time, and thread (pixel p, quarter q) accumulates the 16 raw taps of window
+// rows 2q, 2q+1 of its pixel across the slabs.  The raw
+// 8x8 taps then meet in LDS for the bilinear blend.  Tiles whose bounding box does not fit (wild flow) fall back to the
+// wave-per-pixel routine inside the same launch.  L2 traffic drops ~10x; the kernel becomes LDS-read bound.
+// ---------------------------------------------------------------------------------------------
+#define AT_MAXR 640   // staged region, pixels (25 x 25; x 20 floats pitch = 50 KiB)
+#define AT_SLAB 16    // channels staged at a time
+#define AT_PITCH 20   // floats per staged pixel and slab (16-byte aligned rows)
+#define AT_TAPP 65    // pitch of the raw-tap table
+
+__global__ __launch_bounds__(256) void altcorr_tile_kernel(AltPyramid P, const int64_t* __restrict__ ii,
+                                                           const int64_t* __restrict__ jj,
+                                                           const float* __restrict__ coords, float* __restrict__ out,
+                                                           int E, int H1, int W1, int C) {
+  __shared__ __attribute__((aligned(16))) float region[AT_MAXR * AT_PITCH];
+  __shared__ int bbox[4];
+  float* taps = region;  // the raw-tap table reuses the staging buffer after the last slab (64 x 65 floats)
+  const int tid = threadIdx.x, p = tid >> 2, q = tid & 3;
+  const int lvl = blockIdx.y, e = blockIdx.z;
+  const int ntx = (W1 + 7) >> 3;
+  const int ty = blockIdx.x / ntx, tx = blockIdx.x - ty * ntx;
+  const long HW1 = (long)H1 * W1;
+  const int H2 = H1 >> lvl, W2 = W1 >> lvl;
+  const float scale = 1.0f / (float)(1 << lvl);
+  const long fi = ii[e], fj = jj[e];
+  const float* __restrict__ f2 = P.fmap[lvl] + fj * (long)H2 * W2 * C;
+  float* __restrict__ obase = out + ((long)e * P.num_levels * 49 + lvl * 49) * HW1;
+  const int py = 8 * ty + (p >> 3), px = 8 * tx + (p & 7);
+  const bool inimg = py < H1 && px < W1;
+  const long pix = inimg ? (long)py * W1 + px : 0;
+  float x2 = 0.0f, y2 = 0.0f;
+  if (inimg) {
+    const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + pix) * 2);
+    x2 = c.x * scale;
+    y2 = c.y * scale;
+  }
+  const bool sane = inimg && (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
+  const float fx0 = floorf(x2), fy0 = floorf(y2);
+  const float dx = sane ? x2 - fx0 : 0.0f, dy = sane ? y2 - fy0 : 0.0f;
+  const int xb = sane ? (int)fx0 - 3 : -100000;
+  const int yb = sane ? (int)fy0 - 3 : -100000;
+  // bounding box of the windows that touch the image at all
+  if (tid < 4) bbox[tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;
+  __syncthreads();
+  const bool touches = sane && xb > -8 && xb < W2 && yb > -8 && yb < H2;
+  if (q == 0 && touches) {
+    atomicMin(&bbox[0], max(xb, 0));
+    atomicMin(&bbox[1], max(yb, 0));
+    atomicMax(&bbox[2], min(xb + 8, W2));
+    atomicMax(&bbox[3], min(yb + 8, H2));
+  }
+  __syncthreads();
+  const int x0 = bbox[0], y0 = bbox[1], RW = bbox[2] - bbox[0], RH = bbox[3] - bbox[1];
+  if (RW <= 0 || RH <= 0) {  // nothing of this tile looks into the image: zeros
+    if (inimg && q == 0)
+      for (int ch = 0; ch < 49; ch++) obase[(long)ch * HW1 + pix] = 0.0f;
+    return;
+  }
+  if ((long)RW * RH > AT_MAXR || (C % AT_SLAB) != 0) {  // workgroup-uniform: the union does not fit -> wave per pixel
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int k = 0; k < 16; k++) {
+      const int pp = wave * 16 + k;
+      const int qy = 8 * ty + (pp >> 3), qx = 8 * tx + (pp & 7);
+      if (qy >= H1 || qx >= W1) continue;  // wave-uniform
+      const long qpix = (long)qy * W1 + qx;
+      const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + qpix) * 2);
+      altcorr_pixel(P.fmap[0] + (fi * HW1 + qpix) * C, f2, H2, W2, C, c.x * scale, c.y * scale, obase + qpix, HW1, lane);
+    }
+    return;
+  }
+  float acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; t++) acc[t] = 0.0f;
+  const float* __restrict__ f1 = P.fmap[0] + (fi * HW1 + pix) * C;
+  const int R4 = RW * RH * (AT_SLAB / 4);
+  // LDS offsets of this thread's 16 taps (window rows 2q, 2q+1), -1 when the tap is outside the image; computed once.
+  // (A double-buffered variant with the next slab's loads in flight was not faster: the kernel is bound by the LDS
+  // reads and the FMAs of the dot products, not by the staging latency.)
+  int toff[16];
+#pragma unroll
+  for (int t = 0; t < 16; t++) {
+    const int h2 = yb + 2 * q + (t >> 3), w2 = xb + (t & 7);
+    const bool ok = h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2;  // inside the image => inside the box
+    toff[t] = ok ? ((h2 - y0) * RW + (w2 - x0)) * AT_PITCH : -1;
+  }
+  for (int c0 = 0; c0 < C; c0 += AT_SLAB) {
+    __syncthreads();  // the previous slab has been consumed
+    for (int idx = tid; idx < R4; idx += 256) {
+      const int r = idx >> 2, c4 = idx & 3;
+      const int ry = r / RW, rx = r - ry * RW;
+      *reinterpret_cast<float4*>(region + r * AT_PITCH + 4 * c4) =
+          *reinterpret_cast<const float4*>(f2 + ((long)(y0 + ry) * W2 + (x0 + rx)) * C + c0 + 4 * c4);
+    }
+    float4 a[AT_SLAB / 4];
+#pragma unroll
+    for (int k = 0; k < AT_SLAB / 4; k++) a[k] = sane ? *reinterpret_cast<const float4*>(f1 + c0 + 4 * k) : make_float4(0, 0, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const float* __restrict__ rr = region + max(toff[t], 0);  // branch-free: a masked tap reads entry 0 and adds 0
+      float s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < AT_SLAB / 4; k++) s += dot4(a[k], *reinterpret_cast<const float4*>(rr + 4 * k));
+      acc[t] += toff[t] >= 0 ? s : 0.0f;
+    }
+  }
+  __syncthreads();  // all slabs consumed: the staging buffer becomes the raw-tap table
+#pragma unroll
+  for (int t = 0; t < 16; t++) taps[p * AT_TAPP + 16 * q + t] = acc[t];  // raw tap (row 2q + t/8, column t%8)
+  __syncthreads();
+  if (!inimg) return;
+  const float w00 = (1.0f - dy) * (1.0f - dx), w01 = (1.0f - dy) * dx, w10 = dy * (1.0f - dx), w11 = dy * dx;
+#pragma unroll
+  for (int r2 = 0; r2 < 2; r2++) {
+    const int oy = 2 * q + r2;
+    if (oy >= 7) continue;
+    const float* T0 = taps + p * AT_TAPP + oy * 8;
+#pragma unroll
+    for (int ox = 0; ox < 7; ox++) {
+      // reference weights (altcorr_kernel.cu:112-115), channel = iy + 7*ix (:102-105)
+      const float val = T0[ox] * w00 + T0[ox + 1] * w01 + T0[8 + ox] * w10 + T0[8 + ox + 1] * w11;
+      obase[(long)(oy + 7 * ox) * HW1 + pix] = val;
+    }
+  }
+}
+
 extern "C" int ns_altcorr_pyramid(const float* const* fmaps_host, int num_levels, const int64_t* ii,
                                   const int64_t* jj, const float* coords, float* out, int E, int H1, int W1, int C,
                                   void* stream) {
@@ -160,11 +293,19 @@ extern "C" int ns_altcorr_pyramid(const float* const* fmaps_host, int num_levels
     P.fmap[l] = fmaps_host[l < num_levels ? l : num_levels - 1];
     NS_REQUIRE(P.fmap[l] != nullptr, "ns_altcorr_pyramid: fmaps[%d] is null", l);
   }
-  const long ntask = (long)E * H1 * W1;
-  dim3 grid(ns_cdiv(ntask, 4 * ALT_PIX_PER_WAVE), num_levels);
-  hipLaunchKernelGGL(altcorr_pyramid_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, out, E, H1,
-                     W1, C);
-  NS_CHECK_LAUNCH("altcorr_pyramid_kernel");
+  static const bool per_pixel = getenv("NS_ALTCORR_PER_PIXEL") != nullptr;  // comparison switch: wave-per-pixel kernel
+  if (per_pixel || E > 65535) {
+    const long ntask = (long)E * H1 * W1;
+    dim3 grid(ns_cdiv(ntask, 4 * ALT_PIX_PER_WAVE), num_levels);
+    hipLaunchKernelGGL(altcorr_pyramid_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, out, E, H1,
+                       W1, C);
+    NS_CHECK_LAUNCH("altcorr_pyramid_kernel");
+  } else {
+    dim3 grid(((H1 + 7) / 8) * ((W1 + 7) / 8), num_levels, E);
+    hipLaunchKernelGGL(altcorr_tile_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, out, E, H1, W1,
+                       C);
+    NS_CHECK_LAUNCH("altcorr_tile_kernel");
+  }
   return NS_OK;
 }
 
