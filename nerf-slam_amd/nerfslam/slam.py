@@ -57,7 +57,8 @@ class TrackingSLAM:
         if hasattr(self.net, "begin_keyframe"):
             self.net.begin_keyframe(fe.kf_idx, data["image_u8"])
         depth = data.get("depth")
-        if depth is not None:                                              # sensed depth -> 1/8-res inverse depth (:297-305)
+        if depth is not None:   # EXTENSION: the reference allocates cam0_idepths_sensed (:190) but never fills it (monocular
+                                # only); a dataset that carries depth seeds the sensed-depth prior of the BA here
             d = torch.as_tensor(depth, dtype=torch.float32, device=self.device)[3::8, 3::8]
             fe.cam0_idepths_sensed[fe.kf_idx] = torch.where(d > 0, 1.0 / d, torch.zeros_like(d))
         self.kf_to_frame[fe.kf_idx] = k
