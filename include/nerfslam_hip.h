@@ -93,6 +93,10 @@ int ns_altcorr_pyramid(const float* const* fmaps_host, int num_levels, const int
  * Geometry
  * ---------------------------------------------------------------------------------------- */
 
+/* motion features of the update operator (visual_frontend.py:379-386): out [E,4,ht,wd] =
+ * clamp(cat(coords1 - pixel grid, target - coords1), -64, 64), channel-first, from interleaved [E,ht,wd,2] inputs. */
+int ns_motion_features(const float* coords1, const float* target, float* out, int E, int ht, int wd, void* stream);
+
 /* cvx_upsample (utils/flow_viz.py:166-183; visual_frontend.py:445-446): convex 8x upsampling of n maps [n,ht,wd] f32 with
  * the update operator's mask [n, 9*8*8, ht, wd] (f16 or f32 logits; plane index k*64 + sy*8 + sx, k = 3x3 neighbour in
  * row-major order): out [n, 8ht, 8wd] = sum_k softmax_k(mask)^pow * data(neighbour k); neighbours outside the image are

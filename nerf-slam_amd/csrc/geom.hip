@@ -270,6 +270,37 @@ extern "C" int ns_cvx_upsample(const float* data, const void* mask, int mask_dty
   return NS_OK;
 }
 
+// motion features of the update operator (visual_frontend.py:379-386): cat(coords1 - coords0, target - coords1) clamped to
+// +-64, channel-first [E,4,ht,wd], from the frontend's interleaved [E,ht,wd,2] tensors -- one launch instead of
+// sub, sub, cat, permute, clamp, contiguous.
+__global__ __launch_bounds__(256) void motion_features_kernel(const float* __restrict__ coords1,
+                                                              const float* __restrict__ target, float* __restrict__ out,
+                                                              int E, int HW, int wd) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)E * HW) return;
+  const int e = (int)(i / HW), p = (int)(i - (long)e * HW);
+  const float2 c = *reinterpret_cast<const float2*>(coords1 + 2 * i);
+  const float2 t = *reinterpret_cast<const float2*>(target + 2 * i);
+  const float gx = (float)(p % wd), gy = (float)(p / wd);
+  float* o = out + (long)e * 4 * HW + p;
+  o[0] = fminf(fmaxf(c.x - gx, -64.0f), 64.0f);
+  o[HW] = fminf(fmaxf(c.y - gy, -64.0f), 64.0f);
+  o[2L * HW] = fminf(fmaxf(t.x - c.x, -64.0f), 64.0f);
+  o[3L * HW] = fminf(fmaxf(t.y - c.y, -64.0f), 64.0f);
+}
+
+extern "C" int ns_motion_features(const float* coords1, const float* target, float* out, int E, int ht, int wd,
+                                  void* stream) {
+  if (E == 0) return NS_OK;
+  NS_REQUIRE(coords1 && target && out, "ns_motion_features: null pointer");
+  NS_REQUIRE(E > 0 && ht > 0 && wd > 0, "ns_motion_features: bad shape");
+  const long n = (long)E * ht * wd;
+  hipLaunchKernelGGL(motion_features_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, coords1, target, out,
+                     E, ht * wd, wd);
+  NS_CHECK_LAUNCH("motion_features_kernel");
+  return NS_OK;
+}
+
 extern "C" int ns_reproject(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,
                             const int64_t* jj, float* coords, float* valid, int num, int ht, int wd, void* stream) {
   if (num <= 0) return NS_OK;  // an empty set is a no-op whatever the pointers are

@@ -98,6 +98,15 @@ class TrackingFrontend:
                                      ptr(coords), None, E, self.ht, self.wd, stream_ptr()), "reproject")
         return coords
 
+    def motion_features(self, coords1, target):
+        """(:379-386) -> [E,4,ht,wd]"""
+        E = coords1.shape[0]
+        out = torch.empty((E, 4, self.ht, self.wd), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().ns_motion_features(ptr(coords1), ptr(target.contiguous()), ptr(out), E, self.ht, self.wd, stream_ptr()),
+                  "motion_features")
+        return out
+
     def distance(self, ii, jj, bidirectional=True):
         """(:778-799)"""
         import droid_backends
@@ -162,7 +171,7 @@ class TrackingFrontend:
         """one update-operator + dense-BA step (:370-470)."""
         E = self.ii.shape[0]
         coords1 = self.reproject(self.ii, self.jj)                                    # [E,ht,wd,2]
-        motion = torch.cat([coords1 - self.coords0, self.target - coords1], -1).permute(0, 3, 1, 2).clamp(-64.0, 64.0)
+        motion = self.motion_features(coords1, self.target)
         corr = self.corr(coords1[None])                                               # [1,E,196,ht,wd]
         res = self.update_op(corr, motion[None], self.ii, self.jj)
         delta, weight, damping = res[:3]

@@ -208,7 +208,7 @@ class TrackingSLAM:
             target, weight = fe.reproject(ii, jj), torch.zeros((ii.shape[0], fe.ht, fe.wd, 2), device=self.device)
             for _ in range(steps):
                 coords1 = fe.reproject(ii, jj)
-                motion = torch.cat([coords1 - fe.coords0, target - coords1], -1).permute(0, 3, 1, 2).clamp(-64.0, 64.0)
+                motion = fe.motion_features(coords1, target)
                 for lo in range(0, int(jj_h.max()) + 1, 8):                # windows of 8 source frames (:494-499)
                     v = torch.from_numpy((ii_h >= lo) & (ii_h < lo + 8)).to(self.device)
                     if not bool(v.any()):

@@ -104,3 +104,14 @@ def test_cvx_upsample_kernel(oracle_mod, dev):
         assert np.abs(out.cpu().numpy() - ref).max() <= 5e-6 * max(1.0, np.abs(ref).max()), (n, ht, wd)
         # a convex combination never leaves the range of the data
         assert out.min().item() >= data.min() - 1e-5 and (pw != 1.0 or out.max().item() <= data.max() + 1e-5)
+
+
+def test_motion_features_kernel(dev):
+    """one launch == sub, sub, cat, permute, clamp of visual_frontend.py:379-386"""
+    from nerfslam.frontend import TrackingFrontend
+    fe = TrackingFrontend(4, 96, 128, np.array([100.0, 100.0, 64.0, 48.0], np.float32), dev)
+    g = torch.Generator().manual_seed(0)
+    c1 = (fe.coords0[None] + torch.randn((5, 12, 16, 2), generator=g).to(dev) * 50).contiguous()
+    tg = (c1 + torch.randn((5, 12, 16, 2), generator=g).to(dev) * 50).contiguous()
+    ref = torch.cat([c1 - fe.coords0, tg - c1], -1).permute(0, 3, 1, 2).clamp(-64.0, 64.0)
+    assert torch.equal(fe.motion_features(c1, tg), ref.contiguous())
