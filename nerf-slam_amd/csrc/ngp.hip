@@ -118,9 +118,24 @@ __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const
   }
   const h2_t* __restrict__ tab = params + g.offset[l];
   h2_t v[8];
+  // The gather is bound by the number of L2 requests, not by bytes.  The two x-neighbours of a cell edge are adjacent
+  // table entries on every dense level (stride 1 in x) and, on the hashed levels, whenever x is even (x and x + 1 differ
+  // in bit 0 only, and x enters the hash with multiplier 1): one 8-byte load then serves both corners.
 #pragma unroll
-  for (int corner = 0; corner < 8; corner++)
-    v[corner] = tab[grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2))];
+  for (int yz = 0; yz < 4; yz++) {
+    const uint32_t i0 = grid_index(hs, res, c[0], c[1] + (yz & 1), c[2] + (yz >> 1));
+    const uint32_t i1 = grid_index(hs, res, c[0] + 1, c[1] + (yz & 1), c[2] + (yz >> 1));
+    const uint32_t lo = min(i0, i1);
+    if (max(i0, i1) - lo == 1u) {
+      struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
+      const Pair pr = *reinterpret_cast<const Pair*>(tab + lo);
+      v[2 * yz] = __builtin_bit_cast(h2_t, i0 == lo ? pr.a : pr.b);
+      v[2 * yz + 1] = __builtin_bit_cast(h2_t, i0 == lo ? pr.b : pr.a);
+    } else {
+      v[2 * yz] = tab[i0];
+      v[2 * yz + 1] = tab[i1];
+    }
+  }
   float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
   for (int corner = 0; corner < 8; corner++) {
