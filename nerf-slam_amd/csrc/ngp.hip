@@ -577,7 +577,8 @@ struct MarchRay {
 };
 
 // occupancy bits of the 64 steps that start at t
-__device__ __forceinline__ uint64_t march_scan(const MarchArgs& a, const MarchRay& ry, float t) {
+// (t is advanced to the end of the block, or to the first step at or beyond t1 where the block stops early)
+__device__ __forceinline__ uint64_t march_scan(const MarchArgs& a, const MarchRay& ry, float& t) {
   uint64_t mask = 0;
   for (int g = 0; g < MARCH_SPL; g += 8) {
     if (!(t < ry.t1)) break;
@@ -622,15 +623,16 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(MarchArgs a) {
   int total = 0, rounds = 0;
   float tc = tb;
   for (;;) {
-    const uint64_t m = march_scan(a, ry, tc);
+    float te = tc;
+    const uint64_t m = march_scan(a, ry, te);
     if (rounds == 0) mask0 = m;
     total += __shfl(row_inclusive_sum(__popcll(m), sub), 15, 16);
     rounds++;
-    tc = march_advance(tc, MARCH_ROUND, ry.t1, a);
-    int more = tc < ry.t1;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) more |= __shfl_xor(more, d, 16);
+    // another round only if the last lane's block ended before t1; only then is the next block start
+    // worth the 960-step replay (it used to be replayed unconditionally: a serial chain as long as the prologue's)
+    const int more = __shfl((int)(te < ry.t1), 15, 16);
     if (!more || total >= a.max_per_ray) break;
+    tc = march_advance(te, MARCH_ROUND - MARCH_SPL, ry.t1, a);
   }
   int n = min(total, a.max_per_ray);
   // One reservation per WORKGROUP (16 rays), not per ray: thousands of returning atomics on one address serialise at
@@ -683,7 +685,8 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(MarchArgs a) {
   int off = 0;
   tc = tb;
   for (int round = 0; round < rounds; round++) {
-    const uint64_t m = round == 0 ? mask0 : march_scan(a, ry, tc);
+    float tscan = tc;
+    const uint64_t m = round == 0 ? mask0 : march_scan(a, ry, tscan);
     const int c = __popcll(m);
     const int incl = row_inclusive_sum(c, sub);
     const int k0 = off + incl - c;  // index of this lane's first sample within the ray
