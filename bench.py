@@ -7,10 +7,11 @@ stream (1/8 grid 80x60), with every input already resident in HBM (SURVEY.md 8(d
   motion filter      1-edge correlation pyramid build + one 4-level lookup
   proximity factors  2 x frame_distance over 125 pairs + 2 x 1 pair
   new edges          correlation pyramid build for 10 new edges
-  6 x update()       4-level lookup for the 48 active edges, then BA itrs=2:
+  6 x update()       reprojection + motion features of the 48 active edges, their 4-level lookup, then BA itrs=2:
                        2 x [reduced camera matrix (M=96 edges, P=10 poses, K'=13 depth maps),
                             device Cholesky solve + pose retraction, depth back-substitution]
-                     and the depth/pose covariance block
+                     the depth/pose covariance block, and the convex 8x upsampling of the updated
+                     keyframes' inverse depths and depth covariances (one paired launch)
 
 The conv nets of the reference (encoders, ConvGRU) are outside SURVEY.md 8's hot-path rows
 ("next" row 2) and are NOT part of the step; `config.workload` says so.  Counting every frame as a
@@ -118,6 +119,17 @@ class HotPath:
         self.fd_i = torch.from_numpy(pi.reshape(-1).astype(np.int64)).to(dev)
         self.fd_j = torch.from_numpy(pj.reshape(-1).astype(np.int64)).to(dev)
         self.fd1_i = torch.tensor([KF1 - 3], device=dev)
+        # update-operator glue of every update() (visual_frontend.py:379-386, 445-446, 909-918): reprojection of the active
+        # edges, motion features, convex upsampling of the updated keyframes' inverse depths and depth covariances
+        self.ai, self.aj = ai.contiguous(), aj.contiguous()
+        self.kx = torch.unique(self.ai)
+        self.target_a = self.targets[E_INACTIVE:].permute(0, 2, 3, 1).contiguous()   # the frontend's [E,ht,wd,2]
+        self.coords_a = torch.empty((E_ACTIVE, HT, WD, 2), device=dev)
+        self.motion = torch.empty((E_ACTIVE, 4, HT, WD), device=dev)
+        self.upmask = torch.randn((self.kx.shape[0], 576, HT, WD), generator=g).half().to(dev)  # the GRU head's f16 logits
+        self.depth_cov = torch.rand((NBUF, HT, WD), generator=g).to(dev)
+        self.disps_up = torch.zeros((NBUF, 8 * HT, 8 * WD), device=dev)
+        self.depth_cov_up = torch.zeros((NBUF, 8 * HT, 8 * WD), device=dev)
         self.fd1_j = torch.tensor([KF1 - 2], device=dev)
         self.CorrBlock, self.ba_plan = CorrBlock, ba_plan
         self.ev = None  # optional per-op event recorder
@@ -159,6 +171,21 @@ class HotPath:
     def op_lookup48(self):
         return self.corr48(self.coords48)
 
+    def op_update_glue_pre(self):
+        from nerfslam._lib import check, lib, ptr, stream_ptr
+        L = lib()
+        check(L.ns_reproject(ptr(self.cTw), ptr(self.disps), ptr(self.intr), ptr(self.ai), ptr(self.aj), ptr(self.coords_a),
+                             None, E_ACTIVE, HT, WD, stream_ptr()), "reproject")
+        check(L.ns_motion_features(ptr(self.coords_a), ptr(self.target_a), ptr(self.motion), E_ACTIVE, HT, WD,
+                                   stream_ptr()), "motion_features")
+
+    def op_upsample(self):
+        import ctypes as C
+        from nerfslam._lib import check, lib, ptr, stream_ptr
+        check(lib().ns_cvx_upsample_keyframes(ptr(self.disps), ptr(self.depth_cov), ptr(self.kx), ptr(self.upmask), 1,
+                                              ptr(self.disps_up), ptr(self.depth_cov_up), self.kx.shape[0], HT, WD,
+                                              C.c_float(1.0), stream_ptr()), "cvx_upsample_keyframes")
+
     def op_ba_iteration(self, want_cov):
         import droid_backends
         bp = self.ba_plan
@@ -186,10 +213,12 @@ class HotPath:
         self._t("build10", lambda: self.op_build(self.new_i, self.new_j))
         # iters1 + iters2 updates (visual_frontend.py:607-621)
         for _ in range(6):
+            self._t("reproject+motion", self.op_update_glue_pre)
             self._t("lookup48", self.op_lookup48)
             self.op_ba_iteration(False)
             sol, Q, E = self.op_ba_iteration(True)
             self._t("cov", lambda: self.ba_plan.depth_cov(self.plan, sol["Linv"], Q, E, HW))
+            self._t("upsample", self.op_upsample)
 
 
 ALG_BYTES = {
@@ -380,7 +409,8 @@ def main():
         "config": {"workload": "configs[1]: --slam only, 640x480 (80x60 grid), tracking hot path of one keyframe per "
                                "step: 11 corr-pyramid builds, 7 four-level lookups (E=48), 12 BA iterations "
                                "(M=96,P=10,K'=13) incl. device solve/retraction/depth update, 6 covariance blocks, "
-                               "252 frame distances; conv nets (encoders/ConvGRU) and NeRF fusion NOT included",
+                               "6 x (reprojection + motion features of the 48 edges, paired convex 8x upsampling of the "
+                               "updated keyframes), 252 frame distances; conv nets (encoders/ConvGRU) and NeRF fusion NOT included",
                    "replicas": world, "parallelism": "independent streams, one per GPU" if world > 1 else "single GPU",
                    "launch": launch, "eager_ms_per_step": 1e3 * dt_eager / args.steps,
                    "corr_volume_layout": hp.corr_layout},

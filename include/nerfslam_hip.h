@@ -104,6 +104,13 @@ int ns_motion_features(const float* coords1, const float* target, float* out, in
 int ns_cvx_upsample(const float* data, const void* mask, int mask_dtype, float* out, int n, int ht, int wd, float pow_,
                     void* stream);
 
+/* The frontend's use of it (visual_frontend.py:445-446: inverse depths AND depth covariances of the updated keyframes kx,
+ * same mask) as ONE launch on the keyframe buffers: data_a/data_b [buffer,ht,wd], out_a/out_b [buffer,8ht,8wd], kx [n] i64
+ * (distinct), mask [n,576,ht,wd]; frame kx[f] of each output is overwritten.  data_b/out_b may both be NULL.  The mask
+ * (98 % of the bytes) is read and soft-maxed once for both maps, and no gather / scatter copies are made.          */
+int ns_cvx_upsample_keyframes(const float* data_a, const float* data_b, const int64_t* kx, const void* mask, int mask_dtype,
+                              float* out_a, float* out_b, int n, int ht, int wd, float pow_, void* stream);
+
 /* frame_distance (src/droid.cpp:230-246 -> src/droid_kernels.cu:1572-1594, kernel :630-769)
  *   poses [n,7] (t,q xyzw), disps [n,ht,wd], intrinsics [4], ii,jj [num] i64 -> dist [num].   */
 int ns_frame_distance(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,

@@ -200,57 +200,182 @@ __global__ __launch_bounds__(256) void reproject_kernel(const float* __restrict_
 // Convex 8x upsampling of a per-keyframe map with the update operator's mask (utils/flow_viz.py:166-183, used at
 // visual_frontend.py:445-446,513-514): out[8y+sy, 8x+sx] = sum_k softmax_k(mask[k, sy, sx, y, x])^pow * data[y+dy_k, x+dx_k]
 // over the 3x3 neighbourhood, neighbours outside the image excluded from the softmax (the reference sets their logits
-// to -inf).  One lane per coarse pixel: every mask plane is read with consecutive lanes on consecutive x, and the lane's
-// 8x8 output block leaves as 16-byte pieces of contiguous rows.
+// to -inf).  One lane per (coarse pixel, output row): every mask plane is read with consecutive lanes on consecutive x, and
+// the lane's 8 outputs leave as two 16-byte pieces of a contiguous row (a wave writes 2 KB contiguous).
 // ---------------------------------------------------------------------------------------------
-template <typename MT>
-__global__ __launch_bounds__(256) void cvx_upsample_kernel(const float* __restrict__ data, const MT* __restrict__ mask,
-                                                           float* __restrict__ out, int n, int ht, int wd, float pw) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const int f = blockIdx.z;
-  if (x >= wd || y >= ht) return;
+// With kx != nullptr the maps are gathered from / scattered to whole keyframe buffers (frame kx[f] of data_* [buffer,ht,wd]
+// and out_* [buffer,8ht,8wd]); data_b / out_b (optional) is a second map upsampled with the SAME weights in the same pass
+// (the frontend upsamples inverse depth and depth covariance with one mask, visual_frontend.py:445-446), so the 576-channel
+// mask -- 98 % of the bytes -- is read and soft-maxed once instead of twice.
+template <typename MT, bool PAIR>
+__global__ __launch_bounds__(256) void cvx_upsample_kernel(const float* __restrict__ data_a, const float* __restrict__ data_b,
+                                                           const int64_t* __restrict__ kx, const MT* __restrict__ mask,
+                                                           float* __restrict__ out_a, float* __restrict__ out_b, int n,
+                                                           int ht, int wd, float pw) {
+  // one lane per (coarse pixel, output row sy): 8x the lanes of a lane-per-pixel mapping.  With ~10 keyframes of 4800
+  // pixels a lane per pixel is < 1 wave per SIMD, each walking 576 dependent strided loads (540 us measured).
+  // Lanes run over the LINEAR pixel index (rows of 80 pixels would leave a 64-wide x tiling 62 % full and every
+  // 160-byte mask row straddling two cache lines).
   const long HW = (long)ht * wd;
-  const float* d = data + f * HW;
+  const int p = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int f = blockIdx.z;
+  if (p >= HW) return;
+  const int y = p / wd, x = p - y * wd;
+  const long fs = kx ? (long)kx[f] : (long)f;
+  const float* da = data_a + fs * HW;
+  const float* db = PAIR ? data_b + fs * HW : nullptr;
   const MT* m = mask + (long)f * 576 * HW + (long)y * wd + x;
-  float nb[9];
+  float na[9], nb[9];
   bool ok[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) {
     const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
     ok[k] = yy >= 0 && yy < ht && xx >= 0 && xx < wd;
-    nb[k] = ok[k] ? d[(long)yy * wd + xx] : 0.0f;
+    na[k] = ok[k] ? da[(long)yy * wd + xx] : 0.0f;
+    nb[k] = (PAIR && ok[k]) ? db[(long)yy * wd + xx] : 0.0f;
   }
-  float* o = out + (long)f * HW * 64 + ((long)(8 * y) * (8 * wd) + 8 * x);
-  for (int sy = 0; sy < 8; sy++) {
-    float row[8];
+  float lg[8][9];
 #pragma unroll
-    for (int sx = 0; sx < 8; sx++) {
-      float lg[9], mx = -INFINITY;
+  for (int sx = 0; sx < 8; sx++)
+#pragma unroll
+    for (int k = 0; k < 9; k++) lg[sx][k] = ok[k] ? (float)m[(long)(k * 64 + sy * 8 + sx) * HW] : -INFINITY;
+  float ra[8], rb[8];
+#pragma unroll
+  for (int sx = 0; sx < 8; sx++) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; k++) mx = fmaxf(mx, lg[sx][k]);
+    float den = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      lg[sx][k] = ok[k] ? __expf(lg[sx][k] - mx) : 0.0f;
+      den += lg[sx][k];
+    }
+    const float inv = 1.0f / den;
+    float acca = 0.0f, accb = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      float w = lg[sx][k] * inv;
+      if (pw != 1.0f) w = __powf(w, pw);
+      acca = fmaf(w, na[k], acca);
+      if (PAIR) accb = fmaf(w, nb[k], accb);
+    }
+    ra[sx] = acca;
+    rb[sx] = accb;
+  }
+  const long o = fs * HW * 64 + ((long)(8 * y + sy) * (8 * wd) + 8 * x);
+  float4* dst = reinterpret_cast<float4*>(out_a + o);
+  dst[0] = make_float4(ra[0], ra[1], ra[2], ra[3]);
+  dst[1] = make_float4(ra[4], ra[5], ra[6], ra[7]);
+  if (PAIR) {
+    float4* dsb = reinterpret_cast<float4*>(out_b + o);
+    dsb[0] = make_float4(rb[0], rb[1], rb[2], rb[3]);
+    dsb[1] = make_float4(rb[4], rb[5], rb[6], rb[7]);
+  }
+}
+
+// f16 masks, even wd: one lane per (PAIR of x-adjacent coarse pixels, output row sy, half of the 8 sub-columns).  The logits
+// of the two pixels are one aligned dword, so a wave instruction fetches 256 contiguous bytes of a mask plane instead of
+// 128: measured 22 us (L2/MALL-warm mask) / 51 us (cold) for 10 keyframes of 80x60 against 58 / 91 us with one pixel per
+// lane (fetching the pixel's own dword and selecting the half in registers did not help: it is the bytes per wave
+// instruction, not the 2-byte load type).
+template <bool PAIR>
+__global__ __launch_bounds__(256) void cvx_upsample_h2_kernel(const float* __restrict__ data_a, const float* __restrict__ data_b,
+                                                              const int64_t* __restrict__ kx,
+                                                              const _Float16* __restrict__ mask, float* __restrict__ out_a,
+                                                              float* __restrict__ out_b, int n, int ht, int wd, float pw) {
+  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  const long HW = (long)ht * wd;
+  const int pp = blockIdx.x * 64 + (threadIdx.x & 63);  // pixel pair: pixels 2pp, 2pp+1 (same row: wd is even)
+  const int sub = blockIdx.y * 4 + (threadIdx.x >> 6);   // 0..15
+  const int sy = sub >> 1, sx0 = (sub & 1) * 4;
+  const int f = blockIdx.z;
+  if (2L * pp >= HW) return;
+  const int y = (2 * pp) / wd, x = 2 * pp - y * wd;
+  const long fs = kx ? (long)kx[f] : (long)f;
+  const float* da = data_a + fs * HW;
+  const float* db = PAIR ? data_b + fs * HW : nullptr;
+  // 3 x 4 window of the data around the pair
+  float wa[3][4], wb[3][4];
+  bool okr[3], okc[4];
+#pragma unroll
+  for (int r = 0; r < 3; r++) okr[r] = (y + r - 1) >= 0 && (y + r - 1) < ht;
+#pragma unroll
+  for (int c = 0; c < 4; c++) okc[c] = (x + c - 1) >= 0 && (x + c - 1) < wd;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const bool o = okr[r] && okc[c];
+      wa[r][c] = o ? da[(long)(y + r - 1) * wd + (x + c - 1)] : 0.0f;
+      wb[r][c] = (PAIR && o) ? db[(long)(y + r - 1) * wd + (x + c - 1)] : 0.0f;
+    }
+  const half2_t* m2 = reinterpret_cast<const half2_t*>(mask + (long)f * 576 * HW) + pp;
+  half2_t lg[4][9];
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int k = 0; k < 9; k++) lg[s][k] = m2[((long)(k * 64 + sy * 8 + sx0 + s) * HW) >> 1];
+  float ra[2][4], rb[2][4];
+#pragma unroll
+  for (int q = 0; q < 2; q++)   // pixel of the pair
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      float e[9], mx = -INFINITY;
 #pragma unroll
       for (int k = 0; k < 9; k++) {
-        lg[k] = ok[k] ? (float)m[(long)(k * 64 + sy * 8 + sx) * HW] : -INFINITY;
-        mx = fmaxf(mx, lg[k]);
+        const bool o = okr[k / 3] && okc[k % 3 + q];
+        e[k] = o ? (float)lg[s][k][q] : -INFINITY;
+        mx = fmaxf(mx, e[k]);
       }
       float den = 0.0f;
 #pragma unroll
       for (int k = 0; k < 9; k++) {
-        lg[k] = ok[k] ? __expf(lg[k] - mx) : 0.0f;
-        den += lg[k];
+        const bool o = okr[k / 3] && okc[k % 3 + q];
+        e[k] = o ? __expf(e[k] - mx) : 0.0f;
+        den += e[k];
       }
-      float acc = 0.0f;
+      const float inv = 1.0f / den;
+      float acca = 0.0f, accb = 0.0f;
 #pragma unroll
       for (int k = 0; k < 9; k++) {
-        float w = lg[k] / den;
+        float w = e[k] * inv;
         if (pw != 1.0f) w = __powf(w, pw);
-        acc = fmaf(w, nb[k], acc);
+        acca = fmaf(w, wa[k / 3][k % 3 + q], acca);
+        if (PAIR) accb = fmaf(w, wb[k / 3][k % 3 + q], accb);
       }
-      row[sx] = acc;
+      ra[q][s] = acca;
+      rb[q][s] = accb;
     }
-    float4* dst = reinterpret_cast<float4*>(o + (long)sy * (8 * wd));
-    dst[0] = make_float4(row[0], row[1], row[2], row[3]);
-    dst[1] = make_float4(row[4], row[5], row[6], row[7]);
+  const long o = fs * HW * 64 + ((long)(8 * y + sy) * (8 * wd) + 8 * x + sx0);
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    *reinterpret_cast<float4*>(out_a + o + 8 * q) = make_float4(ra[q][0], ra[q][1], ra[q][2], ra[q][3]);
+    if (PAIR) *reinterpret_cast<float4*>(out_b + o + 8 * q) = make_float4(rb[q][0], rb[q][1], rb[q][2], rb[q][3]);
   }
+}
+
+template <typename MT>
+static void cvx_launch(const float* data_a, const float* data_b, const int64_t* kx, const void* mask, float* out_a, float* out_b,
+                       int n, int ht, int wd, float pow_, void* stream) {
+  if (sizeof(MT) == 2 && wd % 2 == 0 && getenv("NS_CVX_ONE_PIXEL") == nullptr) {
+    dim3 g2(ns_cdiv((long)ht * wd / 2, 64), 4, n);
+    if (data_b)
+      hipLaunchKernelGGL((cvx_upsample_h2_kernel<true>), g2, dim3(256), 0, (hipStream_t)stream, data_a, data_b, kx,
+                         (const _Float16*)mask, out_a, out_b, n, ht, wd, pow_);
+    else
+      hipLaunchKernelGGL((cvx_upsample_h2_kernel<false>), g2, dim3(256), 0, (hipStream_t)stream, data_a, data_b, kx,
+                         (const _Float16*)mask, out_a, out_b, n, ht, wd, pow_);
+    return;
+  }
+  dim3 grid(ns_cdiv((long)ht * wd, 64), 2, n);
+  if (data_b)
+    hipLaunchKernelGGL((cvx_upsample_kernel<MT, true>), grid, dim3(256), 0, (hipStream_t)stream, data_a, data_b, kx,
+                       (const MT*)mask, out_a, out_b, n, ht, wd, pow_);
+  else
+    hipLaunchKernelGGL((cvx_upsample_kernel<MT, false>), grid, dim3(256), 0, (hipStream_t)stream, data_a, data_b, kx,
+                       (const MT*)mask, out_a, out_b, n, ht, wd, pow_);
 }
 
 extern "C" int ns_cvx_upsample(const float* data, const void* mask, int mask_dtype, float* out, int n, int ht, int wd,
@@ -259,13 +384,26 @@ extern "C" int ns_cvx_upsample(const float* data, const void* mask, int mask_dty
   NS_REQUIRE(data && mask && out, "ns_cvx_upsample: null pointer");
   NS_REQUIRE(n > 0 && ht > 0 && wd > 0, "ns_cvx_upsample: bad shape");
   NS_REQUIRE(mask_dtype == NS_F16 || mask_dtype == NS_F32, "ns_cvx_upsample: mask dtype %d unsupported", mask_dtype);
-  dim3 grid(ns_cdiv(wd, 64), ns_cdiv(ht, 4), n);
   if (mask_dtype == NS_F16)
-    hipLaunchKernelGGL(cvx_upsample_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, data, (const _Float16*)mask, out,
-                       n, ht, wd, pow_);
+    cvx_launch<_Float16>(data, nullptr, nullptr, mask, out, nullptr, n, ht, wd, pow_, stream);
   else
-    hipLaunchKernelGGL(cvx_upsample_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, data, (const float*)mask, out, n,
-                       ht, wd, pow_);
+    cvx_launch<float>(data, nullptr, nullptr, mask, out, nullptr, n, ht, wd, pow_, stream);
+  NS_CHECK_LAUNCH("cvx_upsample_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_cvx_upsample_keyframes(const float* data_a, const float* data_b, const int64_t* kx, const void* mask,
+                                         int mask_dtype, float* out_a, float* out_b, int n, int ht, int wd, float pow_,
+                                         void* stream) {
+  if (n == 0) return NS_OK;
+  NS_REQUIRE(data_a && mask && out_a && kx, "ns_cvx_upsample_keyframes: null pointer");
+  NS_REQUIRE((data_b == nullptr) == (out_b == nullptr), "ns_cvx_upsample_keyframes: data_b and out_b go together");
+  NS_REQUIRE(n > 0 && ht > 0 && wd > 0, "ns_cvx_upsample_keyframes: bad shape");
+  NS_REQUIRE(mask_dtype == NS_F16 || mask_dtype == NS_F32, "ns_cvx_upsample_keyframes: mask dtype %d unsupported", mask_dtype);
+  if (mask_dtype == NS_F16)
+    cvx_launch<_Float16>(data_a, data_b, kx, mask, out_a, out_b, n, ht, wd, pow_, stream);
+  else
+    cvx_launch<float>(data_a, data_b, kx, mask, out_a, out_b, n, ht, wd, pow_, stream);
   NS_CHECK_LAUNCH("cvx_upsample_kernel");
   return NS_OK;
 }

@@ -229,12 +229,11 @@ class TrackingFrontend:
         dt = 1 if mask.dtype == torch.float16 else 2
         if mask.dtype not in (torch.float16, torch.float32):
             mask, dt = mask.float(), 2
-        with torch.cuda.device(self.device):
-            for src, dst in ((self.cam0_idepths, self.cam0_idepths_up), (self.cam0_depths_cov, self.cam0_depths_cov_up)):
-                out = torch.empty((n, self.H, self.W), dtype=torch.float32, device=self.device)
-                check(lib().ns_cvx_upsample(ptr(src[kx].contiguous()), ptr(mask), dt, ptr(out), n, self.ht, self.wd,
-                                            C.c_float(1.0), stream_ptr()), "cvx_upsample")
-                dst[kx] = out
+        kx = kx.to(torch.int64).contiguous()
+        with torch.cuda.device(self.device):  # both maps, in place in the keyframe buffers, one pass over the mask
+            check(lib().ns_cvx_upsample_keyframes(ptr(self.cam0_idepths), ptr(self.cam0_depths_cov), ptr(kx), ptr(mask), dt,
+                                                  ptr(self.cam0_idepths_up), ptr(self.cam0_depths_cov_up), n, self.ht,
+                                                  self.wd, C.c_float(1.0), stream_ptr()), "cvx_upsample_keyframes")
         self.has_up[kx] = True
 
     # ---------------------------------------------------------------------------------------------

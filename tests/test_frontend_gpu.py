@@ -93,7 +93,8 @@ def test_cvx_upsample_kernel(oracle_mod, dev):
     import ctypes as C
     from nerfslam._lib import check, lib, ptr, stream_ptr
     rng = np.random.default_rng(0)
-    for (n, ht, wd, pw, dt) in ((3, 12, 16, 1.0, np.float32), (2, 43, 77, 1.0, np.float16), (1, 5, 1, 0.5, np.float32), (1, 1, 9, 1.0, np.float32)):
+    for (n, ht, wd, pw, dt) in ((3, 12, 16, 1.0, np.float32), (2, 43, 77, 1.0, np.float16), (2, 13, 22, 1.0, np.float16), (1, 60, 80, 0.5, np.float16), (1, 3, 2, 1.0, np.float16),
+                               (1, 5, 1, 0.5, np.float32), (1, 1, 9, 1.0, np.float32)):
         data = rng.uniform(0.1, 2.0, (n, ht, wd)).astype(np.float32)
         mask = (rng.standard_normal((n, 576, ht, wd)) * 2).astype(dt)
         ref = oracle_mod.cvx_upsample(data, mask.astype(np.float32), pw)
@@ -104,6 +105,37 @@ def test_cvx_upsample_kernel(oracle_mod, dev):
         assert np.abs(out.cpu().numpy() - ref).max() <= 5e-6 * max(1.0, np.abs(ref).max()), (n, ht, wd)
         # a convex combination never leaves the range of the data
         assert out.min().item() >= data.min() - 1e-5 and (pw != 1.0 or out.max().item() <= data.max() + 1e-5)
+
+
+def test_cvx_upsample_keyframes_kernel(oracle_mod, dev):
+    """the frontend's one-launch form: two maps, one mask, gathered from / scattered into the keyframe buffers by index"""
+    import ctypes as C
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(1)
+    kx = np.array([5, 0, 3], np.int64)
+    for (nbuf, ht, wd, dt) in ((7, 11, 19, np.float16), (7, 11, 19, np.float32), (6, 9, 20, np.float16), (6, 9, 20, np.float32)):
+        a = rng.uniform(0.1, 2.0, (nbuf, ht, wd)).astype(np.float32)
+        b = rng.uniform(0.0, 9.0, (nbuf, ht, wd)).astype(np.float32)
+        mask = (rng.standard_normal((3, 576, ht, wd)) * 2).astype(dt)
+        ta, tb, tm, tk = (torch.from_numpy(v).to(dev) for v in (a, b, mask, kx))
+        oa = torch.full((nbuf, 8 * ht, 8 * wd), -7.0, device=dev)
+        ob = torch.full((nbuf, 8 * ht, 8 * wd), -9.0, device=dev)
+        check(lib().ns_cvx_upsample_keyframes(ptr(ta), ptr(tb), ptr(tk), ptr(tm), 1 if dt == np.float16 else 2, ptr(oa), ptr(ob),
+                                              3, ht, wd, C.c_float(1.0), stream_ptr()), "cvx_upsample_keyframes")
+        ra = oracle_mod.cvx_upsample(a[kx], mask.astype(np.float32))
+        rb = oracle_mod.cvx_upsample(b[kx], mask.astype(np.float32))
+        assert np.abs(oa[tk].cpu().numpy() - ra).max() <= 5e-6 * np.abs(ra).max()
+        assert np.abs(ob[tk].cpu().numpy() - rb).max() <= 5e-6 * np.abs(rb).max()
+        rest = [k for k in range(nbuf) if k not in kx]
+        assert (oa[rest] == -7.0).all() and (ob[rest] == -9.0).all()       # other keyframes untouched
+        # single-map form of the same entry point == ns_cvx_upsample bit for bit
+        o1 = torch.zeros((nbuf, 8 * ht, 8 * wd), device=dev)
+        check(lib().ns_cvx_upsample_keyframes(ptr(ta), None, ptr(tk), ptr(tm), 1 if dt == np.float16 else 2, ptr(o1), None,
+                                              3, ht, wd, C.c_float(1.0), stream_ptr()), "cvx_upsample_keyframes")
+        o2 = torch.empty((3, 8 * ht, 8 * wd), device=dev)
+        check(lib().ns_cvx_upsample(ptr(ta[tk].contiguous()), ptr(tm), 1 if dt == np.float16 else 2, ptr(o2), 3, ht, wd,
+                                    C.c_float(1.0), stream_ptr()), "cvx_upsample")
+        assert torch.equal(o1[tk], o2) and torch.equal(o1[tk], oa[tk])
 
 
 def test_motion_features_kernel(dev):
