@@ -36,6 +36,11 @@ extern "C" {
 #define NS_F16 1
 #define NS_F32 2
 
+#define NS_ACT_NONE 0
+#define NS_ACT_RELU 1
+#define NS_ACT_SIGMOID 2
+#define NS_ACT_TANH 3
+
 const char* ns_last_error(void);
 int ns_version(void);          /* ABI version of this header: 1                          */
 const char* ns_arch(void);     /* "gfx950"                                               */
@@ -328,6 +333,26 @@ int ns_ngp_composite(const void* net_out, const float* dt, const float* tmid, co
                      const int* ray_n, int R, const float* gt_rgb, const float* gt_depth, const float* gt_depth_cov,
                      float depth_lambda, float loss_scale, float* out_rgb, float* out_depth, float* loss,
                      void* dLdout, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Update operator of the tracker: channels-last f16 convolution on the MFMA units
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces the nn.Conv2d (3x3 pad 1 / 1x1, stride 1) + bias + activation (+ the torch.cat in front of it) calls of
+ * networks/droid_net.py:78-150 (UpdateModule, GraphAgg) and networks/modules/gru.py:5-34 (ConvGRU):
+ *   out[n,y,x, out_offset + co] = act( bias[n*bias_nstride + co] + sum_{dy,dx,ci} w[co][ci][dy][dx] * in[n, y+dy, x+dx, ci] )
+ * in  = the channel concatenation of nsrc (1..4) channels-last f16 tensors src_host[s] = [N,H,W,src_channels_host[s]]
+ *       (device pointers in a HOST array; each channel count a multiple of 16), zero padding outside the image;
+ * w   = weights packed by fragment: f16 [CI/16][ksize^2][COP/32][2 (h)][32 (i)][8 (e)] holding
+ *       w[co = 32 ct + i][ci = 16 c + 8 h + e][tap], COP = ns_conv_packed_cout(cout), zero for co >= cout;
+ * bias = f32 or NULL; bias_nstride = 0 for one bias vector, cout-or-more for a bias per image (the ConvGRU's global-context
+ *       terms convz_glo(glo) etc. are exactly that);  act = NS_ACT_*;
+ * out = channels-last f16 [N,H,W,out_stride], the result occupies channels [out_offset, out_offset + cout) (8-byte stores
+ *       when stride and offset are multiples of 4 channels, scalar ones otherwise).                                 */
+int ns_conv_packed_cout(int cout);
+int ns_conv_nhwc_f16(const void* const* src_host, const int* src_channels_host, int nsrc, int N, int H, int W,
+                     const void* wpacked, int ksize, int cout, const float* bias, long bias_nstride, int act, void* out,
+                     int out_stride, int out_offset, void* stream);
 
 #ifdef __cplusplus
 }

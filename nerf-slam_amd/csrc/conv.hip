@@ -1,0 +1,374 @@
+// conv.hip -- channels-last f16 convolution (3x3 pad 1, or 1x1) as an implicit GEMM on the MFMA units, for the update
+// operator of the tracker (networks/droid_net.py:78-150, networks/modules/gru.py:5-34 -- ConvGRU gates,
+// correlation / flow encoders, the delta / weight heads and GraphAgg are all 3x3 or 1x1 convolutions over [E, 128..448, 60, 80]).
+// torch + MIOpen run that operator at ~260 TFLOP/s (tools/nets_bench.py: 4.1 ms for E=48) with a dozen cat / bias /
+// activation / layout kernels in between; this kernel takes the concatenation as a LIST of source tensors, adds a
+// (per-image) bias, applies the activation and writes f16 straight into a channel slice of a channels-last tensor.
+//
+// GEMM view: out^T[cout][pixel] = sum over (tap, cin) of W[cout][tap, cin] * in[pixel + tap][cin], computed with
+// v_mfma_f32_32x32x16_f16 (A = 32 couts x 16 cin, B = 16 cin x 32 pixels); the accumulator layout then gives every lane 4
+// CONSECUTIVE couts of one pixel, i.e. 8-byte channels-last stores.
+//
+// Workgroup = 4 waves = a tile of (8 UT) rows x 16 columns of one image x (32 MT) couts.  Per 16-channel chunk of the
+// input the workgroup stages into LDS (double buffered, one barrier per chunk)
+//   * the input slab: tile + halo, 48-byte pixel stride (16 channels + pad: the 16 lanes of a b128 read group are 16
+//     adjacent pixels, 48 B apart = 12 banks, which tiles the 64 banks without conflicts), zero-filled outside the image;
+//   * the chunk's weights for all taps, pre-packed on the host in fragment order (a wave's A fragment is 1 KB contiguous).
+// A wave owns 2 UT rows (UT column tiles of 2 rows x 16 pixels) x all 32 MT couts: per tap it reads UT B fragments and MT A
+// fragments (ds_read_b128) for UT*MT MFMAs.
+#include "common.h"
+
+typedef _Float16 cv_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cv_f16x4 __attribute__((ext_vector_type(4)));
+typedef float cv_f32x16 __attribute__((ext_vector_type(16)));
+
+#define CV_TC 16       // tile columns
+#define CV_SP 24       // slab pixel stride in halves (48 B)
+#define CV_MAXSRC 4
+
+struct ConvArgs {
+  const _Float16* src[CV_MAXSRC];  // virtual concatenation along channels, each [N,H,W,src_ch[s]]
+  int src_ch[CV_MAXSRC];
+  int src_start[CV_MAXSRC + 1];    // cumulative channel offsets
+  int nsrc;
+  int N, H, W, CI, CO, COP;        // COP = CO rounded up to the workgroup's cout tile (the packed weights are padded)
+  const cv_f16x8* wp;              // [CI/16][taps][COP/32][64 lanes] fragments
+  const float* bias;               // bias[n * bias_nstride + co], or nullptr
+  long bias_nstride;
+  _Float16* out;                   // out[((n H + y) W + x) * ostride + ooff + co]
+  int ostride, ooff;
+  int act;                         // NS_ACT_*
+  int vec;                         // output slice 4-channel aligned: 8-byte stores
+  int tiles_y;
+};
+
+__device__ __forceinline__ float cv_act(float v, int act) {
+  switch (act) {
+    case NS_ACT_RELU: return fmaxf(v, 0.0f);
+    case NS_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+    case NS_ACT_TANH: return 2.0f / (1.0f + __expf(-2.0f * v)) - 1.0f;
+    default: return v;
+  }
+}
+
+template <bool B>
+struct cv_bool { static constexpr bool value = B; };
+
+template <int KS, int MT>
+__global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
+  constexpr int UT = 2;                          // column tiles (2 rows x 16 pixels) per wave
+  constexpr int HALO = KS / 2, T = KS * KS;
+  constexpr int TR = 8 * UT;
+  constexpr int SR = TR + 2 * HALO, SC = CV_TC + 2 * HALO, SPIX = SR * SC;
+  constexpr int NPS = (SPIX * 2 + 255) / 256;    // 16-byte slab pieces per thread
+  constexpr int WV = T * MT * 64;                // weight fragments (16 B) per stage
+  constexpr int NPW = (WV + 255) / 256;          // LDS-DMA instructions per thread and chunk
+  constexpr int ERS = MT * 32 + 4;               // epilogue row stride in halves (+8 B: conflict-free ds_write_b64)
+  // two stages as SEPARATE LDS objects, selected statically (the chunk loop is unrolled by two): the waitcnt pass tells an
+  // in-flight LDS-DMA apart from the ds_reads of the other stage only by LDS object; with one array indexed [c & 1] it
+  // inserts vmcnt(0) in front of the first fragment read and the prefetch is serialised again.
+  __shared__ __attribute__((aligned(16))) _Float16 slabA[SPIX * CV_SP], slabB[SPIX * CV_SP];
+  __shared__ cv_f16x8 wlA[WV], wlB[WV];
+  __shared__ __attribute__((aligned(16))) _Float16 epi[4][32 * ERS];   // per wave: 32 pixels x (32 MT) couts
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int n = blockIdx.y / a.tiles_y;
+  const int y0 = (blockIdx.y - n * a.tiles_y) * TR, x0 = blockIdx.x * CV_TC;
+  const int cz = blockIdx.z;
+  const int nchunk = a.CI >> 4;
+  const int ctiles = a.COP >> 5;
+
+  cv_f32x16 acc[MT][UT];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int u = 0; u < UT; u++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][u][r] = 0.0f;
+
+  // ---- staging ----
+  // slab: this thread's 16-byte pieces go through registers (the padded pixel stride rules out an LDS-DMA image);
+  // weights: global -> LDS directly (global_load_lds_dwordx4: LDS address = wave-uniform base + 16 lane, which is exactly
+  // the fragment order they are packed in), no registers, no ds_write pass.
+  uint4 ps[NPS];
+  int s_off[NPS];        // slab offset (halves) of piece q, or -1
+  long g_pix[NPS];       // pixel index (n H + yy) W + xx of the piece; outside the image: pixel 0 (loaded, then zeroed)
+  bool g_ok[NPS];
+#pragma clang loop unroll(full)
+  for (int q = 0; q < NPS; q++) {
+    const int p = tid + q * 256;
+    const int sp = p >> 1;
+    s_off[q] = -1;
+    g_pix[q] = 0;
+    g_ok[q] = false;
+    if (sp < SPIX) {
+      const int sr = sp / SC, sc = sp - sr * SC;
+      const int yy = y0 + sr - HALO, xx = x0 + sc - HALO;
+      s_off[q] = sp * CV_SP + (p & 1) * 8;
+      if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+        g_pix[q] = ((long)n * a.H + yy) * a.W + xx;
+        g_ok[q] = true;
+      }
+    }
+  }
+  const int e8 = (tid & 1) * 8;
+  // source tensor / channel offset of chunk c
+  const _Float16* cbase = nullptr;
+  int csch = 0, ccoff = 0;
+  const cv_f16x8* cwsrc = nullptr;
+  auto chunk_source = [&](int c) __attribute__((always_inline)) {
+    const int cb = c << 4;
+    int s = 0;
+    while (s + 1 < a.nsrc && cb >= a.src_start[s + 1]) s++;
+    cbase = a.src[s];
+    csch = a.src_ch[s];
+    ccoff = cb - a.src_start[s] + e8;
+    cwsrc = a.wp + ((long)c * T * ctiles + cz * MT) * 64;
+  };
+  auto load_slab_piece = [&](int q) __attribute__((always_inline)) {   // unconditional: no branch inside the MFMA stream
+    ps[q] = *reinterpret_cast<const uint4*>(cbase + g_pix[q] * csch + ccoff);
+  };
+  auto load_weight_piece = [&](int q, cv_f16x8* wdst) __attribute__((always_inline)) {
+    const int v = tid + q * 256;                   // (v < WV is wave-uniform: WV is a multiple of 64)
+    if (WV % 256 == 0 || v < WV) {
+      const int t = v / (MT * 64), rem = v - t * (MT * 64);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cwsrc + (long)t * ctiles * 64 + rem),
+                                       (__attribute__((address_space(3))) void*)(wdst + q * 256 + wv * 64), 16, 0, 0);
+    }
+  };
+  auto store_chunk = [&](_Float16* sdst) __attribute__((always_inline)) {
+#pragma clang loop unroll(full)
+    for (int q = 0; q < NPS; q++)
+      if (s_off[q] >= 0) *reinterpret_cast<uint4*>(sdst + s_off[q]) = g_ok[q] ? ps[q] : make_uint4(0, 0, 0, 0);
+  };
+
+  // B-fragment base offsets (halves) of this lane's pixels for tap (0,0)
+  int boff[UT];
+#pragma unroll
+  for (int u = 0; u < UT; u++) {
+    const int row = 2 * UT * wv + 2 * u + (j >> 4), col = j & 15;
+    boff[u] = (row * SC + col) * CV_SP + 8 * h;
+  }
+  // One chunk: 9 taps x (UT B fragments + MT A fragments -> UT MT MFMAs), software-pipelined by one tap, with the NEXT
+  // chunk's loads (LDS-DMA of the weights, slab pieces into registers) issued one per MFMA in the same stream: with one
+  // wave per SIMD nothing else hides an instruction's issue or latency, so everything rides in the shadow of the MFMAs.
+  auto compute = [&](const _Float16* sl, const cv_f16x8* w, auto more, cv_f16x8* wdst) __attribute__((always_inline)) {
+    constexpr bool MORE = decltype(more)::value;
+    cv_f16x8 bf[2][UT], af[2][MT];
+#pragma unroll
+    for (int u = 0; u < UT; u++) bf[0][u] = *reinterpret_cast<const cv_f16x8*>(sl + boff[u]);
+#pragma unroll
+    for (int m = 0; m < MT; m++) af[0][m] = w[m * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      const int cur = t & 1, nxt = cur ^ 1;
+      if (t + 1 < T) {
+        const int toff = (((t + 1) / KS) * SC + ((t + 1) % KS)) * CV_SP;
+#pragma unroll
+        for (int u = 0; u < UT; u++) bf[nxt][u] = *reinterpret_cast<const cv_f16x8*>(sl + boff[u] + toff);
+#pragma unroll
+        for (int m = 0; m < MT; m++) af[nxt][m] = w[((t + 1) * MT + m) * 64 + lane];
+      }
+      // this tap's share of the next chunk's loads
+      const int w0 = t * NPW / T, w1 = (t + 1) * NPW / T;                       // weights: spread over the taps
+      const int s0 = t < NPS ? t : NPS, s1 = (T == 1) ? NPS : (t + 1 < NPS ? t + 1 : NPS);   // slab: first taps (longest time to land)
+      if (MORE) {
+#pragma unroll
+        for (int q = w0; q < w1; q++) load_weight_piece(q, wdst);
+#pragma unroll
+        for (int q = s0; q < s1; q++) load_slab_piece(q);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int u = 0; u < UT; u++)
+          acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][m], bf[cur][u], acc[m][u], 0, 0, 0);
+      // issue order inside the tap: MFMA, one memory instruction, MFMA, ...
+      const int nds = (t + 1 < T) ? UT + MT : 0, nvm = MORE ? (w1 - w0) + (s1 - s0) : 0;
+#pragma unroll
+      for (int i = 0; i < MT * UT; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // 1 MFMA
+        if (i < nds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+        if (i < nvm) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 VMEM
+      }
+    }
+  };
+#define CV_STEP(c_, SCUR, WCUR, SNXT, WNXT)                                   \
+  {                                                                           \
+    if ((c_) + 1 < nchunk) {                                                  \
+      chunk_source((c_) + 1);                                                 \
+      compute(SCUR, WCUR, cv_bool<true>(), WNXT);                             \
+      __builtin_amdgcn_sched_barrier(0);                                      \
+      store_chunk(SNXT);                                                      \
+    } else {                                                                  \
+      compute(SCUR, WCUR, cv_bool<false>(), WNXT);                            \
+    }                                                                         \
+    __syncthreads(); /* (drains the LDS-DMA too: vmcnt(0)) */                 \
+  }
+
+  chunk_source(0);
+#pragma clang loop unroll(full)
+  for (int q = 0; q < NPW; q++) load_weight_piece(q, wlA);
+#pragma clang loop unroll(full)
+  for (int q = 0; q < NPS; q++) load_slab_piece(q);
+  store_chunk(slabA);
+  __syncthreads();
+  for (int c = 0; c < nchunk; c += 2) {
+    CV_STEP(c, slabA, wlA, slabB, wlB)
+    if (c + 1 >= nchunk) break;
+    CV_STEP(c + 1, slabB, wlB, slabA, wlA)
+  }
+#undef CV_STEP
+
+  // ---- epilogue: bias + activation in registers, then through a wave-private LDS tile so that the global stores are
+  // whole rows of the tile's couts (64 MT contiguous bytes per pixel) instead of 8-byte pieces 2 couts-rows apart: the
+  // direct stores were 28 % of the kernel's time (32 store instructions of 64 scattered pieces per wave) ----
+  const float* bp = a.bias ? a.bias + (long)n * a.bias_nstride : nullptr;
+  const bool full = a.vec && (cz * MT + MT) * 32 <= a.CO;        // workgroup-uniform
+  if (full) {
+    _Float16* et = epi[wv];
+    float bv[MT][4][4];
+#pragma clang loop unroll(full)
+    for (int m = 0; m < MT; m++)
+#pragma clang loop unroll(full)
+      for (int g = 0; g < 4; g++)
+#pragma clang loop unroll(full)
+        for (int e = 0; e < 4; e++) bv[m][g][e] = 0.0f;
+    if (bp && (reinterpret_cast<uintptr_t>(bp) & 15) == 0) {
+#pragma clang loop unroll(full)
+      for (int m = 0; m < MT; m++)
+#pragma clang loop unroll(full)
+        for (int g = 0; g < 4; g++) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bp + (cz * MT + m) * 32 + 8 * g + 4 * h);
+          bv[m][g][0] = b4.x; bv[m][g][1] = b4.y; bv[m][g][2] = b4.z; bv[m][g][3] = b4.w;
+        }
+    } else if (bp) {
+#pragma clang loop unroll(full)
+      for (int m = 0; m < MT; m++)
+#pragma clang loop unroll(full)
+        for (int g = 0; g < 4; g++)
+#pragma clang loop unroll(full)
+          for (int e = 0; e < 4; e++) bv[m][g][e] = bp[(cz * MT + m) * 32 + 8 * g + 4 * h + e];
+    }
+#pragma clang loop unroll(full)
+    for (int u = 0; u < UT; u++) {
+#pragma clang loop unroll(full)
+      for (int m = 0; m < MT; m++)
+#pragma clang loop unroll(full)
+        for (int g = 0; g < 4; g++) {
+          cv_f16x4 o = {(_Float16)cv_act(acc[m][u][4 * g] + bv[m][g][0], a.act), (_Float16)cv_act(acc[m][u][4 * g + 1] + bv[m][g][1], a.act),
+                        (_Float16)cv_act(acc[m][u][4 * g + 2] + bv[m][g][2], a.act), (_Float16)cv_act(acc[m][u][4 * g + 3] + bv[m][g][3], a.act)};
+          *reinterpret_cast<cv_f16x4*>(et + j * ERS + m * 32 + 8 * g + 4 * h) = o;
+        }
+      // read back: MT 8 lanes per pixel row (8 bytes each), 64 / (8 MT) pixels per instruction
+      constexpr int LPR = MT * 8, PPI = 64 / LPR;
+#pragma clang loop unroll(full)
+      for (int i = 0; i < 32 / PPI; i++) {
+        const int pj = i * PPI + lane / LPR, l = lane % LPR;
+        const cv_f16x4 v = *reinterpret_cast<const cv_f16x4*>(et + pj * ERS + 4 * l);
+        const int y = y0 + 2 * UT * wv + 2 * u + (pj >> 4), x = x0 + (pj & 15);
+        if (y < a.H && x < a.W)
+          *reinterpret_cast<cv_f16x4*>(a.out + (((long)n * a.H + y) * a.W + x) * a.ostride + a.ooff + cz * MT * 32 + 4 * l) = v;
+      }
+    }
+    return;
+  }
+  // ragged cout tile or unaligned slice: direct stores
+#pragma clang loop unroll(full)
+  for (int u = 0; u < UT; u++) {
+    const int y = y0 + 2 * UT * wv + 2 * u + (j >> 4), x = x0 + (j & 15);
+    const bool pv = y < a.H && x < a.W;
+    _Float16* op = a.out + (((long)n * a.H + y) * a.W + x) * a.ostride + a.ooff;
+#pragma clang loop unroll(full)
+    for (int m = 0; m < MT; m++) {
+#pragma clang loop unroll(full)
+      for (int g = 0; g < 4; g++) {
+        const int co = (cz * MT + m) * 32 + 8 * g + 4 * h;
+        float v0 = acc[m][u][4 * g], v1 = acc[m][u][4 * g + 1], v2 = acc[m][u][4 * g + 2], v3 = acc[m][u][4 * g + 3];
+        if (pv && co + 3 < a.CO && a.vec) {
+          if (bp) {
+            v0 += bp[co]; v1 += bp[co + 1]; v2 += bp[co + 2]; v3 += bp[co + 3];
+          }
+          cv_f16x4 o = {(_Float16)cv_act(v0, a.act), (_Float16)cv_act(v1, a.act), (_Float16)cv_act(v2, a.act),
+                        (_Float16)cv_act(v3, a.act)};
+          *reinterpret_cast<cv_f16x4*>(op + co) = o;
+        } else if (pv && co < a.CO) {  // ragged tail of a cout count that is not a multiple of 4, or unaligned slice
+          op[co] = (_Float16)cv_act(v0 + (bp ? bp[co] : 0.0f), a.act);
+          if (co + 1 < a.CO) op[co + 1] = (_Float16)cv_act(v1 + (bp ? bp[co + 1] : 0.0f), a.act);
+          if (co + 2 < a.CO) op[co + 2] = (_Float16)cv_act(v2 + (bp ? bp[co + 2] : 0.0f), a.act);
+          if (co + 3 < a.CO) op[co + 3] = (_Float16)cv_act(v3 + (bp ? bp[co + 3] : 0.0f), a.act);
+        }
+      }
+    }
+  }
+}
+
+// cout tile of the workgroup that ns_conv_nhwc_f16 uses for `cout` output channels
+static int cv_cout_tile(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
+
+extern "C" int ns_conv_packed_cout(int cout) {
+  const int t = cv_cout_tile(cout);
+  return (cout + t - 1) / t * t;
+}
+
+template <int KS, int MT>
+static void cv_launch(const ConvArgs& a, hipStream_t st) {
+  dim3 grid(ns_cdiv(a.W, CV_TC), a.N * a.tiles_y, a.COP / (32 * MT));
+  hipLaunchKernelGGL((conv_nhwc_kernel<KS, MT>), grid, dim3(256), 0, st, a);
+}
+
+extern "C" int ns_conv_nhwc_f16(const void* const* src_host, const int* src_channels_host, int nsrc, int N, int H, int W,
+                                const void* wpacked, int ksize, int cout, const float* bias, long bias_nstride, int act,
+                                void* out, int out_stride, int out_offset, void* stream) {
+  if (N == 0) return NS_OK;
+  NS_REQUIRE(src_host && src_channels_host && wpacked && out, "ns_conv_nhwc_f16: null pointer");
+  NS_REQUIRE(nsrc >= 1 && nsrc <= CV_MAXSRC, "ns_conv_nhwc_f16: %d sources (1..%d)", nsrc, CV_MAXSRC);
+  NS_REQUIRE(N > 0 && H > 0 && W > 0 && cout > 0, "ns_conv_nhwc_f16: bad shape");
+  NS_REQUIRE(ksize == 1 || ksize == 3, "ns_conv_nhwc_f16: kernel size %d unsupported (1 or 3)", ksize);
+  NS_REQUIRE(act >= NS_ACT_NONE && act <= NS_ACT_TANH, "ns_conv_nhwc_f16: activation %d unknown", act);
+  NS_REQUIRE(out_offset >= 0 && out_offset + cout <= out_stride, "ns_conv_nhwc_f16: output slice [%d, %d) leaves the row of %d",
+             out_offset, out_offset + cout, out_stride);
+  ConvArgs a;
+  a.nsrc = nsrc;
+  a.src_start[0] = 0;
+  for (int s = 0; s < CV_MAXSRC; s++) {
+    a.src[s] = nullptr;
+    a.src_ch[s] = 0;
+    a.src_start[s + 1] = a.src_start[s];
+    if (s < nsrc) {
+      NS_REQUIRE(src_host[s] && src_channels_host[s] > 0 && src_channels_host[s] % 16 == 0,
+                 "ns_conv_nhwc_f16: source %d needs a multiple of 16 channels (got %d)", s, src_channels_host[s]);
+      a.src[s] = (const _Float16*)src_host[s];
+      a.src_ch[s] = src_channels_host[s];
+      a.src_start[s + 1] = a.src_start[s] + src_channels_host[s];
+    }
+  }
+  a.N = N; a.H = H; a.W = W;
+  a.CI = a.src_start[nsrc];
+  a.CO = cout;
+  a.COP = ns_conv_packed_cout(cout);
+  a.wp = (const cv_f16x8*)wpacked;
+  a.bias = bias;
+  a.bias_nstride = bias_nstride;
+  a.out = (_Float16*)out;
+  a.ostride = out_stride;
+  a.ooff = out_offset;
+  a.act = act;
+  a.vec = (out_stride % 4 == 0 && out_offset % 4 == 0 && ((uintptr_t)out % 8) == 0) ? 1 : 0;
+  a.tiles_y = ns_cdiv(H, 16);
+  const int mt = cv_cout_tile(cout) / 32;
+  NS_REQUIRE((long)N * a.tiles_y <= 65535, "ns_conv_nhwc_f16: too many row tiles");
+  hipStream_t st = (hipStream_t)stream;
+  if (ksize == 3) {
+    if (mt == 4) cv_launch<3, 4>(a, st);
+    else if (mt == 2) cv_launch<3, 2>(a, st);
+    else cv_launch<3, 1>(a, st);
+  } else {
+    if (mt == 4) cv_launch<1, 4>(a, st);
+    else if (mt == 2) cv_launch<1, 2>(a, st);
+    else cv_launch<1, 1>(a, st);
+  }
+  NS_CHECK_LAUNCH("conv_nhwc_kernel");
+  return NS_OK;
+}

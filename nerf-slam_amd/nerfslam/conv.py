@@ -1,0 +1,88 @@
+"""Host side of the MFMA convolution (`csrc/conv.hip`, `ns_conv_nhwc_f16`): weight packing and the launch wrapper.
+
+Everything here is channels-last: an activation is a contiguous f16 tensor [N, H, W, C].  A convolution reads the channel
+concatenation of up to 4 such tensors (the `torch.cat` of networks/modules/gru.py:24-25 never materialises) and writes a
+channel slice of its output tensor, so the encoders can write straight into the buffers the ConvGRU reads.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import check, lib, ptr, require_cuda, stream_ptr
+
+ACT = {None: 0, "none": 0, "relu": 1, "sigmoid": 2, "tanh": 3}
+
+
+def packed_cout(cout):
+    L = lib()
+    return int(L.ns_conv_packed_cout(int(cout)))
+
+
+def pack_weights(weight, pad_cin_to=None):
+    """nn.Conv2d weight [CO, CI, k, k] (k = 1 or 3) -> f16 fragments [CI/16][k*k][COP/32][2][32][8] holding
+    w[co = 32 ct + i][ci = 16 c + 8 h + e][tap] (include/nerfslam_hip.h); CI is zero-padded to a multiple of 16 (or to
+    `pad_cin_to`), CO to ns_conv_packed_cout(CO)."""
+    co, ci, kh, kw = weight.shape
+    assert kh == kw and kh in (1, 3)
+    cip = pad_cin_to if pad_cin_to is not None else (ci + 15) // 16 * 16
+    assert cip % 16 == 0 and cip >= ci
+    cop = packed_cout(co)
+    w = torch.zeros((cop, cip, kh * kw), dtype=torch.float32, device=weight.device)
+    w[:co, :ci] = weight.detach().float().reshape(co, ci, kh * kw)
+    w = w.reshape(cop // 32, 32, cip // 16, 2, 8, kh * kw)          # ct, i, c, h, e, t
+    return w.permute(2, 5, 0, 3, 1, 4).contiguous().half()          # c, t, ct, h, i, e
+
+
+class PackedConv:
+    """one convolution layer: packed weights + f32 bias, ready to launch"""
+
+    def __init__(self, weight, bias=None, pad_cin_to=None):
+        self.cout, self.cin = int(weight.shape[0]), int(weight.shape[1])
+        self.ksize = int(weight.shape[2])
+        self.w = pack_weights(weight, pad_cin_to)
+        self.cin_padded = self.w.shape[0] * 16
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+
+    @classmethod
+    def from_modules(cls, *convs, pad_cin_to=None):
+        """several nn.Conv2d with the same input, fused along the output channels (e.g. convz | convr)"""
+        w = torch.cat([c.weight for c in convs], 0)
+        b = torch.cat([c.bias for c in convs], 0) if convs[0].bias is not None else None
+        return cls(w, b, pad_cin_to)
+
+    def __call__(self, srcs, act=None, out=None, out_offset=0, bias=None):
+        return conv_nhwc(srcs, self, act=act, out=out, out_offset=out_offset, bias=bias)
+
+
+def conv_nhwc(srcs, layer, act=None, out=None, out_offset=0, bias=None):
+    """srcs: list of channels-last f16 tensors [N,H,W,C_s] whose channel counts add up to layer.cin_padded.
+    bias: None (the layer's own), or a per-image f32 tensor [N, cout] (the layer's bias must then be folded in by the caller).
+    out: None (a fresh [N,H,W,cout]) or a channels-last f16 tensor whose channels [out_offset, out_offset+cout) are written."""
+    if not isinstance(srcs, (list, tuple)):
+        srcs = [srcs]
+    require_cuda(*srcs)
+    N, H, W = srcs[0].shape[:3]
+    chans = []
+    for s in srcs:
+        if s.dtype != torch.float16 or not s.is_contiguous() or s.dim() != 4 or tuple(s.shape[:3]) != (N, H, W):
+            raise RuntimeError("conv_nhwc: sources must be contiguous f16 [N,H,W,C] tensors of one spatial shape")
+        chans.append(int(s.shape[3]))
+    if sum(chans) != layer.cin_padded:
+        raise RuntimeError(f"conv_nhwc: sources carry {sum(chans)} channels, the layer was packed for {layer.cin_padded}")
+    if out is None:
+        out = torch.empty((N, H, W, layer.cout), dtype=torch.float16, device=srcs[0].device)
+    elif out.dtype != torch.float16 or not out.is_contiguous() or tuple(out.shape[:3]) != (N, H, W):
+        raise RuntimeError("conv_nhwc: out must be a contiguous f16 [N,H,W,C] tensor")
+    b, bstride = layer.bias, 0
+    if bias is not None:
+        if bias.dtype != torch.float32 or not bias.is_contiguous() or tuple(bias.shape) != (N, layer.cout):
+            raise RuntimeError("conv_nhwc: a per-image bias is a contiguous f32 [N, cout] tensor")
+        b, bstride = bias, layer.cout
+    n = len(srcs)
+    src_arr = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    ch_arr = (C.c_int * n)(*chans)
+    with torch.cuda.device(out.device):
+        check(lib().ns_conv_nhwc_f16(src_arr, ch_arr, n, N, H, W, ptr(layer.w), layer.ksize, layer.cout, ptr(b),
+                                     C.c_long(bstride), ACT[act], ptr(out), int(out.shape[3]), int(out_offset), stream_ptr()),
+              "conv_nhwc_f16")
+    return out

@@ -1,0 +1,81 @@
+"""ns_conv_nhwc_f16 (csrc/conv.hip) against torch's fp32 conv2d on the same f16-rounded inputs: the convolutions of the
+tracker's update operator (networks/droid_net.py:78-150, networks/modules/gru.py:5-34) at its shapes and at awkward ones."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ACTS = {None: lambda x: x, "relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}
+
+
+def _case(dev, N, H, W, chans, cout, k, act, per_image_bias=False, out_stride=None, out_offset=0, seed=0):
+    from nerfslam.conv import PackedConv, conv_nhwc
+    g = torch.Generator().manual_seed(seed)
+    cin = sum(chans)
+    srcs = [torch.randn((N, H, W, c), generator=g).half().to(dev) for c in chans]
+    w = (torch.randn((cout, cin, k, k), generator=g) / np.sqrt(cin * k * k)).half().float().to(dev)
+    b = torch.randn((cout,), generator=g).to(dev)
+    layer = PackedConv(w, b)
+    bias = torch.randn((N, cout), generator=g).to(dev) if per_image_bias else None
+    out = None
+    if out_stride is not None:
+        out = torch.full((N, H, W, out_stride), 7.0, dtype=torch.float16, device=dev)
+    res = conv_nhwc(srcs, layer, act=act, out=out, out_offset=out_offset, bias=bias)
+    x = torch.cat(srcs, -1).float().permute(0, 3, 1, 2)
+    ref = F.conv2d(x, w, None, padding=k // 2)
+    ref = ref + (bias[:, :, None, None] if per_image_bias else b[None, :, None, None])
+    ref = ACTS[act](ref).permute(0, 2, 3, 1)
+    got = res[..., out_offset:out_offset + cout].float()
+    tol = 2.5e-3 * max(1.0, ref.abs().max().item())
+    err = (got - ref).abs().max().item()
+    assert err <= tol, (N, H, W, chans, cout, k, act, err, tol)
+    if out_stride is not None:   # the rest of the output row is untouched
+        mask = torch.ones(out_stride, dtype=torch.bool, device=dev)
+        mask[out_offset:out_offset + cout] = False
+        assert (res[..., mask] == 7.0).all()
+    return err
+
+
+def test_gru_gate_shapes(dev):
+    # convz|convr fused: [h, inp, corr, flow] -> 256, sigmoid, per-edge global-context bias (gru.py:28-29)
+    _case(dev, 3, 60, 80, (128, 128, 128, 64), 256, 3, "sigmoid", per_image_bias=True)
+    # convq: -> 128, tanh
+    _case(dev, 2, 60, 80, (128, 128, 128, 64), 128, 3, "tanh", per_image_bias=True, seed=1)
+
+
+def test_encoders_heads_and_slices(dev):
+    # corr encoder: 1x1 over 196 channels padded to 208, relu; then 3x3 into a slice of the GRU input buffer
+    _case(dev, 2, 60, 80, (208,), 128, 1, "relu")
+    _case(dev, 2, 60, 80, (128,), 128, 3, "relu", out_stride=448, out_offset=256, seed=2)
+    # flow encoder's second conv (-> 64), heads (-> 2, ragged cout), eta (-> 1), upmask (1x1 -> 576)
+    _case(dev, 2, 60, 80, (128,), 64, 3, "relu", out_stride=448, out_offset=384, seed=3)
+    _case(dev, 2, 60, 80, (128,), 2, 3, None, seed=4)
+    _case(dev, 2, 60, 80, (128,), 1, 3, None, out_stride=4, out_offset=0, seed=5)
+    _case(dev, 2, 60, 80, (128,), 576, 1, None, seed=6)
+    _case(dev, 1, 60, 80, (128,), 384, 3, "relu", seed=7)
+
+
+def test_odd_and_tiny_images(dev):
+    _case(dev, 2, 43, 77, (32, 16), 40, 3, "relu")              # the real Replica grid, ragged everything
+    _case(dev, 1, 5, 3, (16,), 6, 3, None, seed=1)
+    _case(dev, 2, 9, 11, (16,), 7, 3, "relu", out_stride=13, out_offset=3, seed=5)   # unaligned slice: scalar stores
+    _case(dev, 1, 1, 1, (16,), 130, 3, "tanh", seed=2)           # only the centre tap sees data
+    _case(dev, 3, 17, 33, (48,), 128, 1, "sigmoid", per_image_bias=True, seed=3)
+    _case(dev, 1, 33, 16, (16, 16, 16, 16), 96, 3, None, seed=4)
+
+
+def test_rejects_bad_arguments(dev):
+    from nerfslam._lib import NerfSlamHipError
+    from nerfslam.conv import PackedConv, conv_nhwc
+    layer = PackedConv(torch.zeros((8, 32, 3, 3), device=dev))
+    x = torch.zeros((1, 4, 4, 32), dtype=torch.float16, device=dev)
+    with pytest.raises(RuntimeError):
+        conv_nhwc([x[..., :16].contiguous()], layer)                    # channel count does not match the packing
+    with pytest.raises(RuntimeError):
+        conv_nhwc([x.float()], layer)
+    out = torch.zeros((1, 4, 4, 10), dtype=torch.float16, device=dev)
+    with pytest.raises(NerfSlamHipError):
+        conv_nhwc([x], layer, out=out, out_offset=4)                    # slice [4, 12) leaves the 10-channel row
+    assert conv_nhwc([x[:0]], layer).shape == (0, 4, 4, 8)             # empty batch is a no-op
