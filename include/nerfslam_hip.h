@@ -343,6 +343,8 @@ int ns_ngp_composite(const void* net_out, const float* dt, const float* tmid, co
  *   out[n,y,x, out_offset + co] = act( bias[n*bias_nstride + co] + sum_{dy,dx,ci} w[co][ci][dy][dx] * in[n, y+dy, x+dx, ci] )
  * in  = the channel concatenation of nsrc (1..4) channels-last f16 tensors src_host[s] = [N,H,W,src_channels_host[s]]
  *       (device pointers in a HOST array; each channel count a multiple of 16), zero padding outside the image;
+ *       src_strides_host[s] = pixel stride in elements when source s is a channel slice of a wider tensor (NULL: dense;
+ *       stride a multiple of 8 and the slice's first element 16-byte aligned);
  * w   = weights packed by fragment: f16 [CI/16][ksize^2][COP/32][2 (h)][32 (i)][8 (e)] holding
  *       w[co = 32 ct + i][ci = 16 c + 8 h + e][tap], COP = ns_conv_packed_cout(cout), zero for co >= cout;
  * bias = f32 or NULL; bias_nstride = 0 for one bias vector, cout-or-more for a bias per image (the ConvGRU's global-context
@@ -350,7 +352,8 @@ int ns_ngp_composite(const void* net_out, const float* dt, const float* tmid, co
  * out = channels-last f16 [N,H,W,out_stride], the result occupies channels [out_offset, out_offset + cout) (8-byte stores
  *       when stride and offset are multiples of 4 channels, scalar ones otherwise).                                 */
 int ns_conv_packed_cout(int cout);
-int ns_conv_nhwc_f16(const void* const* src_host, const int* src_channels_host, int nsrc, int N, int H, int W,
+int ns_conv_nhwc_f16(const void* const* src_host, const int* src_channels_host, const int* src_strides_host, int nsrc,
+                     int N, int H, int W,
                      const void* wpacked, int ksize, int cout, const float* bias, long bias_nstride, int act, void* out,
                      int out_stride, int out_offset, void* stream);
 

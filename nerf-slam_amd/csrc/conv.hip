@@ -29,6 +29,7 @@ typedef float cv_f32x16 __attribute__((ext_vector_type(16)));
 struct ConvArgs {
   const _Float16* src[CV_MAXSRC];  // virtual concatenation along channels, each [N,H,W,src_ch[s]]
   int src_ch[CV_MAXSRC];
+  int src_stride[CV_MAXSRC];       // pixel stride in halves (>= src_ch: a source may be a channel slice of a wider tensor)
   int src_start[CV_MAXSRC + 1];    // cumulative channel offsets
   int nsrc;
   int N, H, W, CI, CO, COP;        // COP = CO rounded up to the workgroup's cout tile (the packed weights are padded)
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
     int s = 0;
     while (s + 1 < a.nsrc && cb >= a.src_start[s + 1]) s++;
     cbase = a.src[s];
-    csch = a.src_ch[s];
+    csch = a.src_stride[s];
     ccoff = cb - a.src_start[s] + e8;
     cwsrc = a.wp + ((long)c * T * ctiles + cz * MT) * 64;
   };
@@ -318,7 +319,8 @@ static void cv_launch(const ConvArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((conv_nhwc_kernel<KS, MT>), grid, dim3(256), 0, st, a);
 }
 
-extern "C" int ns_conv_nhwc_f16(const void* const* src_host, const int* src_channels_host, int nsrc, int N, int H, int W,
+extern "C" int ns_conv_nhwc_f16(const void* const* src_host, const int* src_channels_host, const int* src_strides_host, int nsrc,
+                                int N, int H, int W,
                                 const void* wpacked, int ksize, int cout, const float* bias, long bias_nstride, int act,
                                 void* out, int out_stride, int out_offset, void* stream) {
   if (N == 0) return NS_OK;
@@ -335,12 +337,17 @@ extern "C" int ns_conv_nhwc_f16(const void* const* src_host, const int* src_chan
   for (int s = 0; s < CV_MAXSRC; s++) {
     a.src[s] = nullptr;
     a.src_ch[s] = 0;
+    a.src_stride[s] = 0;
     a.src_start[s + 1] = a.src_start[s];
     if (s < nsrc) {
       NS_REQUIRE(src_host[s] && src_channels_host[s] > 0 && src_channels_host[s] % 16 == 0,
                  "ns_conv_nhwc_f16: source %d needs a multiple of 16 channels (got %d)", s, src_channels_host[s]);
+      const int stride = src_strides_host ? src_strides_host[s] : src_channels_host[s];
+      NS_REQUIRE(stride >= src_channels_host[s] && stride % 8 == 0 && ((uintptr_t)src_host[s] % 16) == 0,
+                 "ns_conv_nhwc_f16: source %d: pixel stride %d / base address must keep 16-byte alignment", s, stride);
       a.src[s] = (const _Float16*)src_host[s];
       a.src_ch[s] = src_channels_host[s];
+      a.src_stride[s] = stride;
       a.src_start[s + 1] = a.src_start[s] + src_channels_host[s];
     }
   }

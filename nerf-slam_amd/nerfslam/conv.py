@@ -62,11 +62,15 @@ def conv_nhwc(srcs, layer, act=None, out=None, out_offset=0, bias=None):
         srcs = [srcs]
     require_cuda(*srcs)
     N, H, W = srcs[0].shape[:3]
-    chans = []
+    chans, strides = [], []
     for s in srcs:
-        if s.dtype != torch.float16 or not s.is_contiguous() or s.dim() != 4 or tuple(s.shape[:3]) != (N, H, W):
-            raise RuntimeError("conv_nhwc: sources must be contiguous f16 [N,H,W,C] tensors of one spatial shape")
+        if s.dtype != torch.float16 or s.dim() != 4 or tuple(s.shape[:3]) != (N, H, W):
+            raise RuntimeError("conv_nhwc: sources must be f16 [N,H,W,C] tensors of one spatial shape")
+        ps = s.stride(2)                                 # pixel stride: C, or more for a channel slice of a wider tensor
+        if N * H * W > 0 and (s.stride(3) != 1 or s.stride(1) != W * ps or s.stride(0) != H * W * ps):
+            raise RuntimeError("conv_nhwc: sources must be channels-last (dense, or a channel slice of a dense tensor)")
         chans.append(int(s.shape[3]))
+        strides.append(int(ps) if N * H * W > 0 else int(s.shape[3]))
     if sum(chans) != layer.cin_padded:
         raise RuntimeError(f"conv_nhwc: sources carry {sum(chans)} channels, the layer was packed for {layer.cin_padded}")
     if out is None:
@@ -81,8 +85,9 @@ def conv_nhwc(srcs, layer, act=None, out=None, out_offset=0, bias=None):
     n = len(srcs)
     src_arr = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
     ch_arr = (C.c_int * n)(*chans)
+    st_arr = (C.c_int * n)(*strides)
     with torch.cuda.device(out.device):
-        check(lib().ns_conv_nhwc_f16(src_arr, ch_arr, n, N, H, W, ptr(layer.w), layer.ksize, layer.cout, ptr(b),
+        check(lib().ns_conv_nhwc_f16(src_arr, ch_arr, st_arr, n, N, H, W, ptr(layer.w), layer.ksize, layer.cout, ptr(b),
                                      C.c_long(bstride), ACT[act], ptr(out), int(out.shape[3]), int(out_offset), stream_ptr()),
               "conv_nhwc_f16")
     return out

@@ -174,7 +174,7 @@ class DroidNetworks:
     MEAN = (0.485, 0.456, 0.406)
     STD = (0.229, 0.224, 0.225)
 
-    def __init__(self, device, weights=None, buffer=512, seed=0):
+    def __init__(self, device, weights=None, buffer=512, seed=0, hip_update=None):
         self.device = torch.device(device)
         torch.manual_seed(seed)
         self.net = DroidNet()
@@ -184,6 +184,14 @@ class DroidNetworks:
         self.ctx, self.inp = {}, {}          # per keyframe: tanh / relu halves of the context encoder
         self.hidden = {}                     # per edge (i, j): ConvGRU hidden state [128, ht, wd]
         self._pending = None
+        # update operator on the MFMA convolution kernel (nerfslam/update_op.py); hidden / context states are then kept
+        # channels-last [ht, wd, 128].  Default: on whenever the HIP device is there.
+        self.hip_update = (self.device.type == "cuda") if hip_update is None else bool(hip_update)
+        self.update_op = None
+        if self.hip_update:
+            from .update_op import HipUpdateOperator
+            self.update_op = HipUpdateOperator(self.net.update_net)
+            self.ctx_cl, self.inp_cl = {}, {}
 
     def _normalize(self, img_u8):
         x = img_u8.to(self.device).float()[:3] / 255.0
@@ -206,10 +214,13 @@ class DroidNetworks:
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda"):
             c = self.net.context_net(x)[0, 0]
         self.ctx[k], self.inp[k] = torch.tanh(c[:128]), torch.relu(c[128:])
+        if self.hip_update:
+            self.ctx_cl[k] = self.ctx[k].permute(1, 2, 0).contiguous().half()
+            self.inp_cl[k] = self.inp[k].permute(1, 2, 0).contiguous().half()
 
     def remove_keyframe(self, k):
         """hook of TrackingSLAM.rm_keyframe: keyframe k+1 slides onto k, edges touching k disappear"""
-        for d in (self.ctx, self.inp):
+        for d in (self.ctx, self.inp) + ((self.ctx_cl, self.inp_cl) if self.hip_update else ()):
             if k + 1 in d:
                 d[k] = d.pop(k + 1)
         sh = lambda a: a - (a >= k)
@@ -225,6 +236,17 @@ class DroidNetworks:
     @torch.no_grad()
     def update(self, corr, motion, ii, jj):
         ih, jh = ii.tolist(), jj.tolist()
+        if self.hip_update:
+            net = torch.stack([self.hidden.get((i, j), self.ctx_cl[i]) for i, j in zip(ih, jh)])
+            inp = torch.stack([self.inp_cl[i] for i in ih])
+            c = corr[0] if corr.dim() == 5 else corr
+            net, delta, weight, eta, upmask = self.update_op(net, inp, c.half(), motion.reshape(-1, 4, *motion.shape[-2:]).float(), ih)
+            for e, (i, j) in enumerate(zip(ih, jh)):
+                self.hidden[(i, j)] = net[e]
+            live = set(zip(ih, jh))
+            if len(self.hidden) > 4 * max(len(live), 64):
+                self.hidden = {e: h for e, h in self.hidden.items() if e in live}
+            return delta[None], weight[None], eta, upmask
         net = torch.stack([self.hidden.get((i, j), self.ctx[i]) for i, j in zip(ih, jh)])[None]
         inp = torch.stack([self.inp[i] for i in ih])[None]
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda"):

@@ -1,0 +1,80 @@
+"""The tracker's update operator (networks/droid_net.py:78-150 `UpdateModule`, networks/modules/gru.py:5-34 `ConvGRU`,
+`GraphAgg`) on the MFMA convolution of `csrc/conv.hip`, channels-last end to end.
+
+Same arithmetic as `nerfslam.droid_nets.UpdateModule` (whose weights it is built from), different plumbing:
+  * every 3x3 / 1x1 convolution is one `ns_conv_nhwc_f16` launch with bias and activation fused;
+  * no `torch.cat`: the ConvGRU reads [net | inp | corr features | flow features] as a list of tensors, and the encoders
+    write their halves of one [E,ht,wd,192] buffer;
+  * convz | convr are one 448 -> 256 convolution; the global-context terms conv*_glo(glo) are 1x1 convolutions of a
+    per-edge vector, i.e. a per-image bias of that launch (one small matmul for all three);
+  * the first convolutions of the delta head, the weight head and GraphAgg share their input: one 128 -> 384 launch,
+    whose channel slices feed the second convolutions directly.
+The 7x7 convolution of the flow encoder (4 input channels, 1 % of the FLOPs) stays with torch/MIOpen.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .conv import PackedConv
+
+
+class HipUpdateOperator:
+    def __init__(self, um):
+        P = PackedConv
+        ce, fe, g, a = um.corr_encoder, um.flow_encoder, um.gru, um.agg
+        self.corr1 = P(ce[0].weight, ce[0].bias, pad_cin_to=208)      # 196 lookup channels, padded to 13 chunks of 16
+        self.corr2 = P(ce[2].weight, ce[2].bias)
+        self.flow1_w = fe[0].weight.detach().half().contiguous(memory_format=torch.channels_last)
+        self.flow1_b = fe[0].bias.detach().half()
+        self.flow2 = P(fe[2].weight, fe[2].bias)
+        self.gw = P(g.w.weight, g.w.bias)
+        self.zr = P.from_modules(g.convz, g.convr)
+        self.q = P(g.convq.weight, g.convq.bias)
+        # conv*_glo on the [E,128,1,1] context vector = one [E,128] x [128,384] product; the convolutions' own biases folded in
+        self.glo_w = torch.cat([m.weight.detach().float().reshape(128, 128) for m in (g.convz_glo, g.convr_glo, g.convq_glo)], 0).t().contiguous()
+        self.glo_b = torch.cat([g.convz_glo.bias + g.convz.bias, g.convr_glo.bias + g.convr.bias,
+                                g.convq_glo.bias + g.convq.bias]).detach().float()
+        self.heads = P.from_modules(um.delta[0], um.weight[0], a.conv1)
+        self.delta2 = P(um.delta[2].weight, um.delta[2].bias)
+        self.weight2 = P(um.weight[2].weight, um.weight[2].bias)
+        self.agg2 = P(a.conv2.weight, a.conv2.bias)
+        self.eta = P(a.eta[0].weight, a.eta[0].bias)
+        self.upmask = P(a.upmask[0].weight, a.upmask[0].bias)
+
+    @torch.no_grad()
+    def __call__(self, net, inp, corr, flow, ii_host):
+        """net, inp [E,ht,wd,128] f16 channels-last; corr [E,196,ht,wd] f16 (the lookup's layout); flow [E,4,ht,wd] f32;
+        ii_host: source keyframe of every edge (host ints).
+        -> net' [E,ht,wd,128] f16, delta [E,ht,wd,2] f32, weight [E,ht,wd,2] f32, eta [k,ht,wd] f32, upmask [k,576,ht,wd] f16"""
+        E, ht, wd, _ = net.shape
+        dev = net.device
+        # ---- encoders: X = [corr features 128 | flow features 64] ----
+        c208 = F.pad(corr.permute(0, 2, 3, 1), (0, 12)).contiguous()
+        c1 = self.corr1([c208], act="relu")
+        X = torch.empty((E, ht, wd, 192), dtype=torch.float16, device=dev)
+        self.corr2([c1], act="relu", out=X, out_offset=0)
+        f1 = torch.relu(F.conv2d(flow.half().contiguous(memory_format=torch.channels_last), self.flow1_w, self.flow1_b, padding=3))
+        self.flow2([f1.permute(0, 2, 3, 1).contiguous()], act="relu", out=X, out_offset=128)   # (already dense: f1 is channels-last)
+        # ---- ConvGRU ----
+        wg = self.gw([net], act="sigmoid")
+        glo = (wg * net).float().mean((1, 2))                               # [E,128]
+        gb = torch.addmm(self.glo_b, glo, self.glo_w)                         # [E,384] per-edge biases of z | r | q
+        zr = self.zr([net, inp, X], act="sigmoid", bias=gb[:, :256].contiguous())
+        rh = zr[..., 128:] * net
+        q = self.q([rh, inp, X], act="tanh", bias=gb[:, 256:].contiguous())
+        z = zr[..., :128]
+        net2 = torch.addcmul(net, z, q - net)                                 # (1 - z) net + z q
+        # ---- heads ----
+        hd = self.heads([net2], act="relu")                                   # [delta | weight | agg] x 128
+        delta = self.delta2([hd[..., :128]]).float()
+        weight = self.weight2([hd[..., 128:256]], act="sigmoid").float()
+        # ---- GraphAgg: mean over the edges of each source keyframe, conv, eta + upsampling mask ----
+        uniq, ix = np.unique(np.asarray(ii_host), return_inverse=True)
+        k = len(uniq)
+        ixd = torch.from_numpy(ix.astype(np.int64)).to(dev)
+        s = torch.zeros((k, ht, wd, 128), dtype=torch.float32, device=dev).index_add_(0, ixd, hd[..., 256:].float())
+        cnt = torch.from_numpy(np.bincount(ix, minlength=k).astype(np.float32)).to(dev)
+        x2 = self.agg2([(s / cnt.view(k, 1, 1, 1)).half()], act="relu")
+        eta = 0.01 * F.softplus(self.eta([x2]).float())[..., 0]
+        upmask = self.upmask([x2]).permute(0, 3, 1, 2).contiguous()
+        return net2, delta, weight, eta, upmask

@@ -66,6 +66,22 @@ def test_odd_and_tiny_images(dev):
     _case(dev, 1, 33, 16, (16, 16, 16, 16), 96, 3, None, seed=4)
 
 
+def test_channel_slices_as_sources(dev):
+    """a source may be a channel slice of a wider channels-last tensor (the heads read slices of one fused 384-channel conv)"""
+    from nerfslam.conv import PackedConv, conv_nhwc
+    g = torch.Generator().manual_seed(0)
+    wide = torch.randn((2, 21, 37, 384), generator=g).half().to(dev)
+    other = torch.randn((2, 21, 37, 32), generator=g).half().to(dev)
+    w = (torch.randn((48, 160, 3, 3), generator=g) / 38.0).half().float().to(dev)
+    b = torch.randn((48,), generator=g).to(dev)
+    got = conv_nhwc([wide[..., 128:256], other], PackedConv(w, b), act="relu").float()
+    x = torch.cat([wide[..., 128:256], other], -1).float().permute(0, 3, 1, 2)
+    ref = torch.relu(F.conv2d(x, w, b, padding=1)).permute(0, 2, 3, 1)
+    assert (got - ref).abs().max().item() <= 2.5e-3 * max(1.0, ref.abs().max().item())
+    with pytest.raises(RuntimeError):
+        conv_nhwc([wide.permute(0, 2, 1, 3)[..., :160]], PackedConv(w, b))      # not channels-last
+
+
 def test_rejects_bad_arguments(dev):
     from nerfslam._lib import NerfSlamHipError
     from nerfslam.conv import PackedConv, conv_nhwc

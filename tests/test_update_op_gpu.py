@@ -1,0 +1,59 @@
+"""HipUpdateOperator (MFMA convolutions, channels-last) against the torch UpdateModule it is built from
+(networks/droid_net.py:78-150 restated in nerfslam/droid_nets.py, itself pinned to the reference modules by
+tests/golden/droid_nets_forward.npz): same weights, same inputs, f16 autocast on the torch side."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+
+
+@pytest.mark.parametrize("E,ht,wd", [(12, 60, 80), (5, 43, 77)])
+def test_update_operator_matches_torch_module(dev, E, ht, wd):
+    from nerfslam.droid_nets import UpdateModule
+    from nerfslam.update_op import HipUpdateOperator
+    torch.manual_seed(0)
+    um = UpdateModule().to(dev).eval()
+    op = HipUpdateOperator(um)
+    g = torch.Generator().manual_seed(1)
+    net = torch.tanh(torch.randn((E, 128, ht, wd), generator=g)).to(dev)
+    inp = torch.relu(torch.randn((E, 128, ht, wd), generator=g)).to(dev)
+    corr = (torch.randn((E, 196, ht, wd), generator=g) * 2).half().to(dev)
+    flow = (torch.randn((E, 4, ht, wd), generator=g) * 4).to(dev)
+    ii = torch.tensor([3, 3, 4, 9, 4, 3, 7, 7, 9, 9, 9, 4][:E], device=dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        h_ref, d_ref, w_ref, eta_ref, up_ref = um(net[None].half(), inp[None].half(), corr[None], flow[None], ii, ii)
+    cl = lambda t: t.permute(0, 2, 3, 1).contiguous().half()
+    h, d, w, eta, up = op(cl(net), cl(inp), corr, flow, ii.tolist())
+    assert h.shape == (E, ht, wd, 128) and d.shape == (E, ht, wd, 2) and up.shape == (up_ref.shape[1], 576, ht, wd)
+    # both sides round to f16 between layers, at different points: agreement to a few 1e-3 of the signal
+    assert _rel(h.permute(0, 3, 1, 2), h_ref[0]) < 4e-3
+    assert _rel(d, d_ref[0]) < 1e-2 and (d - d_ref[0].float()).abs().max().item() < 2e-2 * d_ref.abs().max().item() + 1e-3
+    assert _rel(w, w_ref[0]) < 4e-3
+    assert _rel(eta, eta_ref[0]) < 1e-2
+    assert _rel(up, up_ref[0]) < 1e-2
+
+
+def test_droid_networks_adapter_uses_the_hip_operator(dev):
+    """DroidNetworks.update through the HIP operator == through torch, incl. the hidden-state carry-over between calls"""
+    from nerfslam.droid_nets import DroidNetworks
+    ht, wd = 24, 32
+    a = DroidNetworks(dev, seed=3, hip_update=True)
+    b = DroidNetworks(dev, seed=3, hip_update=False)
+    assert a.update_op is not None and b.update_op is None
+    g = torch.Generator().manual_seed(0)
+    for k in range(3):
+        img = torch.randint(0, 255, (3, 8 * ht, 8 * wd), generator=g, dtype=torch.uint8)
+        for n in (a, b):
+            n.features(img); n.begin_keyframe(k, img)
+    ii = torch.tensor([0, 1, 1, 2], device=dev); jj = torch.tensor([1, 0, 2, 1], device=dev)
+    for it in range(2):
+        corr = torch.randn((1, 4, 196, ht, wd), generator=g).half().to(dev)
+        motion = torch.randn((4, 4, ht, wd), generator=g).to(dev)
+        ra, rb = a.update(corr, motion, ii, jj), b.update(corr, motion, ii, jj)
+        for x, y, tol in zip(ra, rb, (2e-2, 1e-2, 2e-2, 2e-2)):
+            assert x.shape == y.shape and _rel(x, y) < tol, (it, x.shape, _rel(x, y))
