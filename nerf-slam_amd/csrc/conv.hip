@@ -65,11 +65,8 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
   constexpr int WV = T * MT * 64;                // weight fragments (16 B) per stage
   constexpr int NPW = (WV + 255) / 256;          // LDS-DMA instructions per thread and chunk
   constexpr int ERS = MT * 32 + 4;               // epilogue row stride in halves (+8 B: conflict-free ds_write_b64)
-  // two stages as SEPARATE LDS objects, selected statically (the chunk loop is unrolled by two): the waitcnt pass tells an
-  // in-flight LDS-DMA apart from the ds_reads of the other stage only by LDS object; with one array indexed [c & 1] it
-  // inserts vmcnt(0) in front of the first fragment read and the prefetch is serialised again.
-  __shared__ __attribute__((aligned(16))) _Float16 slabA[SPIX * CV_SP], slabB[SPIX * CV_SP];
-  __shared__ cv_f16x8 wlA[WV], wlB[WV];
+  __shared__ __attribute__((aligned(16))) _Float16 slab[2][SPIX * CV_SP];
+  __shared__ cv_f16x8 wl[2][WV];
   __shared__ __attribute__((aligned(16))) _Float16 epi[4][32 * ERS];   // per wave: 32 pixels x (32 MT) couts
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -130,12 +127,20 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
   auto load_slab_piece = [&](int q) __attribute__((always_inline)) {   // unconditional: no branch inside the MFMA stream
     ps[q] = *reinterpret_cast<const uint4*>(cbase + g_pix[q] * csch + ccoff);
   };
-  auto load_weight_piece = [&](int q, cv_f16x8* wdst) __attribute__((always_inline)) {
+  // The LDS-DMA is issued from inline asm, invisible to the compiler: as a builtin it is a pending LDS write that the
+  // waitcnt pass cannot tell apart from the other stage (one array, dynamic index), so every fragment read waited for
+  // vmcnt(0); with two statically selected LDS objects (loop unrolled by two) that went away, but the two copies of the
+  // MFMA stream got two accumulator register sets and 256 v_accvgpr moves per chunk.  Hidden, it costs nothing: the
+  // explicit vmcnt(0) in front of the barrier that publishes the stage is the only wait it needs.
+  auto load_weight_piece = [&](int q, uint32_t wdst_lds) __attribute__((always_inline)) {
     const int v = tid + q * 256;                   // (v < WV is wave-uniform: WV is a multiple of 64)
     if (WV % 256 == 0 || v < WV) {
       const int t = v / (MT * 64), rem = v - t * (MT * 64);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cwsrc + (long)t * ctiles * 64 + rem),
-                                       (__attribute__((address_space(3))) void*)(wdst + q * 256 + wv * 64), 16, 0, 0);
+      const cv_f16x8* g = cwsrc + (long)t * ctiles * 64 + rem;
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(wdst_lds + (uint32_t)(q * 256 + wv * 64) * 16u);
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
     }
   };
   auto store_chunk = [&](_Float16* sdst) __attribute__((always_inline)) {
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
   // One chunk: 9 taps x (UT B fragments + MT A fragments -> UT MT MFMAs), software-pipelined by one tap, with the NEXT
   // chunk's loads (LDS-DMA of the weights, slab pieces into registers) issued one per MFMA in the same stream: with one
   // wave per SIMD nothing else hides an instruction's issue or latency, so everything rides in the shadow of the MFMAs.
-  auto compute = [&](const _Float16* sl, const cv_f16x8* w, auto more, cv_f16x8* wdst) __attribute__((always_inline)) {
+  auto compute = [&](const _Float16* sl, const cv_f16x8* w, auto more, uint32_t wdst) __attribute__((always_inline)) {
     constexpr bool MORE = decltype(more)::value;
     cv_f16x8 bf[2][UT], af[2][MT];
 #pragma unroll
@@ -195,32 +200,25 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
       }
     }
   };
-#define CV_STEP(c_, SCUR, WCUR, SNXT, WNXT)                                   \
-  {                                                                           \
-    if ((c_) + 1 < nchunk) {                                                  \
-      chunk_source((c_) + 1);                                                 \
-      compute(SCUR, WCUR, cv_bool<true>(), WNXT);                             \
-      __builtin_amdgcn_sched_barrier(0);                                      \
-      store_chunk(SNXT);                                                      \
-    } else {                                                                  \
-      compute(SCUR, WCUR, cv_bool<false>(), WNXT);                            \
-    }                                                                         \
-    __syncthreads(); /* (drains the LDS-DMA too: vmcnt(0)) */                 \
-  }
-
+  const uint32_t wl_lds[2] = {(uint32_t)(uintptr_t)&wl[0][0], (uint32_t)(uintptr_t)&wl[1][0]};
   chunk_source(0);
 #pragma clang loop unroll(full)
-  for (int q = 0; q < NPW; q++) load_weight_piece(q, wlA);
+  for (int q = 0; q < NPW; q++) load_weight_piece(q, wl_lds[0]);
 #pragma clang loop unroll(full)
   for (int q = 0; q < NPS; q++) load_slab_piece(q);
-  store_chunk(slabA);
+  store_chunk(slab[0]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int c = 0; c < nchunk; c += 2) {
-    CV_STEP(c, slabA, wlA, slabB, wlB)
-    if (c + 1 >= nchunk) break;
-    CV_STEP(c + 1, slabB, wlB, slabA, wlA)
+  for (int c = 0; c < nchunk; c++) {
+    const int b = c & 1;
+    // (the last chunk prefetches itself again into the idle stage instead of branching around the loads)
+    chunk_source(c + 1 < nchunk ? c + 1 : c);
+    compute(slab[b], wl[b], cv_bool<true>(), wl_lds[b ^ 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    store_chunk(slab[b ^ 1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the next stage has landed
+    __syncthreads();
   }
-#undef CV_STEP
 
   // ---- epilogue: bias + activation in registers, then through a wave-private LDS tile so that the global stores are
   // whole rows of the tile's couts (64 MT contiguous bytes per pixel) instead of 8-byte pieces 2 couts-rows apart: the

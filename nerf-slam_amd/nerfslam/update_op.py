@@ -46,6 +46,10 @@ class HipUpdateOperator:
         """net, inp [E,ht,wd,128] f16 channels-last; corr [E,196,ht,wd] f16 (the lookup's layout); flow [E,4,ht,wd] f32;
         ii_host: source keyframe of every edge (host ints).
         -> net' [E,ht,wd,128] f16, delta [E,ht,wd,2] f32, weight [E,ht,wd,2] f32, eta [k,ht,wd] f32, upmask [k,576,ht,wd] f16"""
+        with torch.autocast("cuda", enabled=False):     # dtypes are explicit here; an enclosing autocast would only add casts
+            return self._forward(net, inp, corr, flow, ii_host)
+
+    def _forward(self, net, inp, corr, flow, ii_host):
         E, ht, wd, _ = net.shape
         dev = net.device
         # ---- encoders: X = [corr features 128 | flow features 64] ----

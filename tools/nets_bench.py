@@ -44,6 +44,12 @@ def timed(name, fn):
 f = timed("feature_net (1 frame)", lambda: net.feature_net(img))
 c = timed("context_net (1 frame)", lambda: net.context_net(img))
 u = timed("update_net (E=48)", lambda: net.update_net(hid, inp, corr, flow, ii, jj))
+from nerfslam.update_op import HipUpdateOperator
+op = HipUpdateOperator(net.update_net)
+cl = lambda t: t[0].permute(0, 2, 3, 1).contiguous().half()
+hid_cl, inp_cl, ih = cl(hid), cl(inp), ii.tolist()
+uh = timed("update operator, HIP (E=48)", lambda: op(hid_cl, inp_cl, corr[0], flow[0], ih))
 u1 = timed("update_net (E=1, motion)", lambda: net.update_net(hid[:, :1], inp[:, :1], corr[:, :1], flow[:, :1], ii[:1], jj[:1]))
 step = f + c + u1 + 6 * u
-print(f"conv nets per keyframe step: {step:.2f} ms  (feature + context + motion filter + 6 updates)")
+print(f"conv nets per keyframe step: {step:.2f} ms  (feature + context + motion filter + 6 updates), "
+      f"{f + c + u1 + 6 * uh:.2f} ms with the HIP update operator")
