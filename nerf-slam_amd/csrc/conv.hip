@@ -55,9 +55,8 @@ __device__ __forceinline__ float cv_act(float v, int act) {
 template <bool B>
 struct cv_bool { static constexpr bool value = B; };
 
-template <int KS, int MT>
+template <int KS, int MT, int UT>                // UT = column tiles (2 rows x 16 pixels) per wave
 __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
-  constexpr int UT = 2;                          // column tiles (2 rows x 16 pixels) per wave
   constexpr int HALO = KS / 2, T = KS * KS;
   constexpr int TR = 8 * UT;
   constexpr int SR = TR + 2 * HALO, SC = CV_TC + 2 * HALO, SPIX = SR * SC;
@@ -65,9 +64,13 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
   constexpr int WV = T * MT * 64;                // weight fragments (16 B) per stage
   constexpr int NPW = (WV + 255) / 256;          // LDS-DMA instructions per thread and chunk
   constexpr int ERS = MT * 32 + 4;               // epilogue row stride in halves (+8 B: conflict-free ds_write_b64)
-  __shared__ __attribute__((aligned(16))) _Float16 slab[2][SPIX * CV_SP];
-  __shared__ cv_f16x8 wl[2][WV];
-  __shared__ __attribute__((aligned(16))) _Float16 epi[4][32 * ERS];   // per wave: 32 pixels x (32 MT) couts
+  // one LDS block: [slab stage 0 | slab stage 1 | weight stage 0 | weight stage 1]; the epilogue's transposition tiles
+  // (per wave 32 pixels x 32 MT couts) reuse it from offset 0 once the last chunk is done
+  constexpr int SLAB_H = SPIX * CV_SP;                         // halves per slab stage
+  constexpr int MAIN_BYTES = 2 * SLAB_H * 2 + 2 * WV * 16, EPI_BYTES = 4 * 32 * ERS * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
+  _Float16* const slab0 = reinterpret_cast<_Float16*>(lds_raw);
+  cv_f16x8* const wl0 = reinterpret_cast<cv_f16x8*>(lds_raw + 2 * SLAB_H * 2);
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -200,22 +203,22 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
       }
     }
   };
-  const uint32_t wl_lds[2] = {(uint32_t)(uintptr_t)&wl[0][0], (uint32_t)(uintptr_t)&wl[1][0]};
+  const uint32_t wl_lds0 = (uint32_t)(uintptr_t)wl0;
   chunk_source(0);
 #pragma clang loop unroll(full)
-  for (int q = 0; q < NPW; q++) load_weight_piece(q, wl_lds[0]);
+  for (int q = 0; q < NPW; q++) load_weight_piece(q, wl_lds0);
 #pragma clang loop unroll(full)
   for (int q = 0; q < NPS; q++) load_slab_piece(q);
-  store_chunk(slab[0]);
+  store_chunk(slab0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int c = 0; c < nchunk; c++) {
     const int b = c & 1;
     // (the last chunk prefetches itself again into the idle stage instead of branching around the loads)
     chunk_source(c + 1 < nchunk ? c + 1 : c);
-    compute(slab[b], wl[b], cv_bool<true>(), wl_lds[b ^ 1]);
+    compute(slab0 + b * SLAB_H, wl0 + b * WV, cv_bool<true>(), wl_lds0 + (uint32_t)((b ^ 1) * WV * 16));
     __builtin_amdgcn_sched_barrier(0);
-    store_chunk(slab[b ^ 1]);
+    store_chunk(slab0 + (b ^ 1) * SLAB_H);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the next stage has landed
     __syncthreads();
   }
@@ -226,40 +229,24 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
   const float* bp = a.bias ? a.bias + (long)n * a.bias_nstride : nullptr;
   const bool full = a.vec && (cz * MT + MT) * 32 <= a.CO;        // workgroup-uniform
   if (full) {
-    _Float16* et = epi[wv];
-    float bv[MT][4][4];
-#pragma clang loop unroll(full)
-    for (int m = 0; m < MT; m++)
-#pragma clang loop unroll(full)
-      for (int g = 0; g < 4; g++)
-#pragma clang loop unroll(full)
-        for (int e = 0; e < 4; e++) bv[m][g][e] = 0.0f;
-    if (bp && (reinterpret_cast<uintptr_t>(bp) & 15) == 0) {
-#pragma clang loop unroll(full)
-      for (int m = 0; m < MT; m++)
-#pragma clang loop unroll(full)
-        for (int g = 0; g < 4; g++) {
-          const float4 b4 = *reinterpret_cast<const float4*>(bp + (cz * MT + m) * 32 + 8 * g + 4 * h);
-          bv[m][g][0] = b4.x; bv[m][g][1] = b4.y; bv[m][g][2] = b4.z; bv[m][g][3] = b4.w;
-        }
-    } else if (bp) {
-#pragma clang loop unroll(full)
-      for (int m = 0; m < MT; m++)
-#pragma clang loop unroll(full)
-        for (int g = 0; g < 4; g++)
-#pragma clang loop unroll(full)
-          for (int e = 0; e < 4; e++) bv[m][g][e] = bp[(cz * MT + m) * 32 + 8 * g + 4 * h + e];
-    }
+    _Float16* et = reinterpret_cast<_Float16*>(lds_raw) + wv * 32 * ERS;
+    const bool bvec = bp && (reinterpret_cast<uintptr_t>(bp) & 15) == 0;
 #pragma clang loop unroll(full)
     for (int u = 0; u < UT; u++) {
 #pragma clang loop unroll(full)
-      for (int m = 0; m < MT; m++)
+      for (int m = 0; m < MT; m++) {
 #pragma clang loop unroll(full)
         for (int g = 0; g < 4; g++) {
-          cv_f16x4 o = {(_Float16)cv_act(acc[m][u][4 * g] + bv[m][g][0], a.act), (_Float16)cv_act(acc[m][u][4 * g + 1] + bv[m][g][1], a.act),
-                        (_Float16)cv_act(acc[m][u][4 * g + 2] + bv[m][g][2], a.act), (_Float16)cv_act(acc[m][u][4 * g + 3] + bv[m][g][3], a.act)};
+          const int co = (cz * MT + m) * 32 + 8 * g + 4 * h;
+          float4 b4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (bvec) b4 = *reinterpret_cast<const float4*>(bp + co);
+          else if (bp) b4 = make_float4(bp[co], bp[co + 1], bp[co + 2], bp[co + 3]);
+          cv_f16x4 o = {(_Float16)cv_act(acc[m][u][4 * g] + b4.x, a.act), (_Float16)cv_act(acc[m][u][4 * g + 1] + b4.y, a.act),
+                        (_Float16)cv_act(acc[m][u][4 * g + 2] + b4.z, a.act), (_Float16)cv_act(acc[m][u][4 * g + 3] + b4.w, a.act)};
           *reinterpret_cast<cv_f16x4*>(et + j * ERS + m * 32 + 8 * g + 4 * h) = o;
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the accumulator reads of later tiles from being hoisted (spills)
+      }
       // read back: MT 8 lanes per pixel row (8 bytes each), 64 / (8 MT) pixels per instruction
       constexpr int LPR = MT * 8, PPI = 64 / LPR;
 #pragma clang loop unroll(full)
@@ -270,6 +257,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
         if (y < a.H && x < a.W)
           *reinterpret_cast<cv_f16x4*>(a.out + (((long)n * a.H + y) * a.W + x) * a.ostride + a.ooff + cz * MT * 32 + 4 * l) = v;
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     return;
   }
@@ -299,6 +287,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
           if (co + 3 < a.CO) op[co + 3] = (_Float16)cv_act(v3 + (bp ? bp[co + 3] : 0.0f), a.act);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -311,10 +300,11 @@ extern "C" int ns_conv_packed_cout(int cout) {
   return (cout + t - 1) / t * t;
 }
 
-template <int KS, int MT>
-static void cv_launch(const ConvArgs& a, hipStream_t st) {
+template <int KS, int MT, int UT>
+static void cv_launch(ConvArgs a, hipStream_t st) {
+  a.tiles_y = ns_cdiv(a.H, 8 * UT);
   dim3 grid(ns_cdiv(a.W, CV_TC), a.N * a.tiles_y, a.COP / (32 * MT));
-  hipLaunchKernelGGL((conv_nhwc_kernel<KS, MT>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_nhwc_kernel<KS, MT, UT>), grid, dim3(256), 0, st, a);
 }
 
 extern "C" int ns_conv_nhwc_f16(const void* const* src_host, const int* src_channels_host, const int* src_strides_host, int nsrc,
@@ -361,18 +351,20 @@ extern "C" int ns_conv_nhwc_f16(const void* const* src_host, const int* src_chan
   a.ooff = out_offset;
   a.act = act;
   a.vec = (out_stride % 4 == 0 && out_offset % 4 == 0 && ((uintptr_t)out % 8) == 0) ? 1 : 0;
-  a.tiles_y = ns_cdiv(H, 16);
+  a.tiles_y = 0;
   const int mt = cv_cout_tile(cout) / 32;
-  NS_REQUIRE((long)N * a.tiles_y <= 65535, "ns_conv_nhwc_f16: too many row tiles");
+  // (UT = 4, 32-row tiles with 256 accumulator registers, measured 814 vs 749 TF/s on 448 -> 256 but 25 % slower on the
+  // 128-channel convolutions -- its epilogue spills -- so only the 16-row tile is instantiated)
+  NS_REQUIRE((long)N * ns_cdiv(H, 16) <= 65535, "ns_conv_nhwc_f16: too many row tiles");
   hipStream_t st = (hipStream_t)stream;
   if (ksize == 3) {
-    if (mt == 4) cv_launch<3, 4>(a, st);
-    else if (mt == 2) cv_launch<3, 2>(a, st);
-    else cv_launch<3, 1>(a, st);
+    if (mt == 4) cv_launch<3, 4, 2>(a, st);
+    else if (mt == 2) cv_launch<3, 2, 2>(a, st);
+    else cv_launch<3, 1, 2>(a, st);
   } else {
-    if (mt == 4) cv_launch<1, 4>(a, st);
-    else if (mt == 2) cv_launch<1, 2>(a, st);
-    else cv_launch<1, 1>(a, st);
+    if (mt == 4) cv_launch<1, 4, 2>(a, st);
+    else if (mt == 2) cv_launch<1, 2, 2>(a, st);
+    else cv_launch<1, 1, 2>(a, st);
   }
   NS_CHECK_LAUNCH("conv_nhwc_kernel");
   return NS_OK;
