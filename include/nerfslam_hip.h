@@ -41,6 +41,10 @@ extern "C" {
 #define NS_ACT_SIGMOID 2
 #define NS_ACT_TANH 3
 
+#define NS_CONV_FUSE_NONE 0
+#define NS_CONV_FUSE_MUL_HI 1 /* out[co] *= e0[pixel][co - cout/2] for co >= cout/2       (r * h, gru.py:29-30)  */
+#define NS_CONV_FUSE_GRU 2    /* out = e1 + e0 * (act(conv) - e1), e0 = z, e1 = h          (gru.py:31-33)        */
+
 const char* ns_last_error(void);
 int ns_version(void);          /* ABI version of this header: 1                          */
 const char* ns_arch(void);     /* "gfx950"                                               */
@@ -356,6 +360,16 @@ int ns_conv_nhwc_f16(const void* const* src_host, const int* src_channels_host, 
                      int N, int H, int W,
                      const void* wpacked, int ksize, int cout, const float* bias, long bias_nstride, int act, void* out,
                      int out_stride, int out_offset, void* stream);
+
+/* The same convolution with one elementwise step of the ConvGRU (networks/modules/gru.py:28-33) folded into its epilogue
+ * (fuse = NS_CONV_FUSE_*): e0 / e1 are channels-last f16 tensors with pixel strides e0_stride / e1_stride (elements,
+ * multiples of 4; a channel slice of a wider tensor is fine).  MUL_HI: the convz|convr launch writes [z | r * h] (e0 = h);
+ * GRU: the convq launch writes the new hidden state (e0 = z, e1 = h).  Needs cout a multiple of the cout tile and a
+ * 4-channel-aligned output slice.                                                                                  */
+int ns_conv_nhwc_f16_fused(const void* const* src_host, const int* src_channels_host, const int* src_strides_host, int nsrc,
+                           int N, int H, int W, const void* wpacked, int ksize, int cout, const float* bias, long bias_nstride,
+                           int act, void* out, int out_stride, int out_offset, int fuse, const void* e0, int e0_stride,
+                           const void* e1, int e1_stride, void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,10 @@ struct ConvArgs {
   int ostride, ooff;
   int act;                         // NS_ACT_*
   int vec;                         // output slice 4-channel aligned: 8-byte stores
+  int fuse;                        // NS_CONV_FUSE_*: extra elementwise step of the ConvGRU in the epilogue
+  const _Float16* e0;              // MUL_HI: the factor [N,H,W,e0s] for the upper half of the couts; GRU: z
+  const _Float16* e1;              // GRU: h
+  int e0s, e1s;                    // pixel strides (elements)
   int tiles_y;
 };
 
@@ -252,10 +256,25 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
 #pragma clang loop unroll(full)
       for (int i = 0; i < 32 / PPI; i++) {
         const int pj = i * PPI + lane / LPR, l = lane % LPR;
-        const cv_f16x4 v = *reinterpret_cast<const cv_f16x4*>(et + pj * ERS + 4 * l);
+        cv_f16x4 v = *reinterpret_cast<const cv_f16x4*>(et + pj * ERS + 4 * l);
         const int y = y0 + 2 * UT * wv + 2 * u + (pj >> 4), x = x0 + (pj & 15);
-        if (y < a.H && x < a.W)
-          *reinterpret_cast<cv_f16x4*>(a.out + (((long)n * a.H + y) * a.W + x) * a.ostride + a.ooff + cz * MT * 32 + 4 * l) = v;
+        if (y < a.H && x < a.W) {
+          const long pix = ((long)n * a.H + y) * a.W + x;
+          const int co = cz * MT * 32 + 4 * l;
+          if (a.fuse == NS_CONV_FUSE_MUL_HI) {          // r * h next to z (gru.py:29-30): couts >= CO/2 are multiplied
+            if (co >= (a.CO >> 1)) {
+              const cv_f16x4 f = *reinterpret_cast<const cv_f16x4*>(a.e0 + pix * a.e0s + co - (a.CO >> 1));
+#pragma unroll
+              for (int e = 0; e < 4; e++) v[e] = (_Float16)((float)v[e] * (float)f[e]);
+            }
+          } else if (a.fuse == NS_CONV_FUSE_GRU) {      // (1 - z) h + z q (gru.py:31-33)
+            const cv_f16x4 z = *reinterpret_cast<const cv_f16x4*>(a.e0 + pix * a.e0s + co);
+            const cv_f16x4 hh = *reinterpret_cast<const cv_f16x4*>(a.e1 + pix * a.e1s + co);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = (_Float16)((float)hh[e] + (float)z[e] * ((float)v[e] - (float)hh[e]));
+          }
+          *reinterpret_cast<cv_f16x4*>(a.out + pix * a.ostride + a.ooff + co) = v;
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -307,10 +326,10 @@ static void cv_launch(ConvArgs a, hipStream_t st) {
   hipLaunchKernelGGL((conv_nhwc_kernel<KS, MT, UT>), grid, dim3(256), 0, st, a);
 }
 
-extern "C" int ns_conv_nhwc_f16(const void* const* src_host, const int* src_channels_host, const int* src_strides_host, int nsrc,
-                                int N, int H, int W,
-                                const void* wpacked, int ksize, int cout, const float* bias, long bias_nstride, int act,
-                                void* out, int out_stride, int out_offset, void* stream) {
+static int cv_run(const void* const* src_host, const int* src_channels_host, const int* src_strides_host, int nsrc, int N, int H,
+                  int W, const void* wpacked, int ksize, int cout, const float* bias, long bias_nstride, int act, void* out,
+                  int out_stride, int out_offset, int fuse, const void* e0, int e0_stride, const void* e1, int e1_stride,
+                  void* stream) {
   if (N == 0) return NS_OK;
   NS_REQUIRE(src_host && src_channels_host && wpacked && out, "ns_conv_nhwc_f16: null pointer");
   NS_REQUIRE(nsrc >= 1 && nsrc <= CV_MAXSRC, "ns_conv_nhwc_f16: %d sources (1..%d)", nsrc, CV_MAXSRC);
@@ -351,6 +370,22 @@ extern "C" int ns_conv_nhwc_f16(const void* const* src_host, const int* src_chan
   a.ooff = out_offset;
   a.act = act;
   a.vec = (out_stride % 4 == 0 && out_offset % 4 == 0 && ((uintptr_t)out % 8) == 0) ? 1 : 0;
+  a.fuse = fuse;
+  a.e0 = (const _Float16*)e0;
+  a.e1 = (const _Float16*)e1;
+  a.e0s = e0_stride;
+  a.e1s = e1_stride;
+  if (fuse != NS_CONV_FUSE_NONE) {
+    NS_REQUIRE(fuse == NS_CONV_FUSE_MUL_HI || fuse == NS_CONV_FUSE_GRU, "ns_conv_nhwc_f16_fused: mode %d unknown", fuse);
+    // the fused step lives on the whole-row store path: full 4-aligned cout tiles only
+    NS_REQUIRE(a.vec && cout % cv_cout_tile(cout) == 0, "ns_conv_nhwc_f16_fused: needs an aligned output slice and cout a multiple of %d",
+               cv_cout_tile(cout));
+    NS_REQUIRE(e0 && e0_stride % 4 == 0 && ((uintptr_t)e0 % 8) == 0, "ns_conv_nhwc_f16_fused: operand 0 missing or misaligned");
+    if (fuse == NS_CONV_FUSE_GRU)
+      NS_REQUIRE(e1 && e1_stride % 4 == 0 && ((uintptr_t)e1 % 8) == 0, "ns_conv_nhwc_f16_fused: operand 1 missing or misaligned");
+    else
+      NS_REQUIRE((cout / 2) % 4 == 0, "ns_conv_nhwc_f16_fused: cout/2 must be a multiple of 4");
+  }
   a.tiles_y = 0;
   const int mt = cv_cout_tile(cout) / 32;
   // (UT = 4, 32-row tiles with 256 accumulator registers, measured 814 vs 749 TF/s on 448 -> 256 but 25 % slower on the
@@ -368,4 +403,19 @@ extern "C" int ns_conv_nhwc_f16(const void* const* src_host, const int* src_chan
   }
   NS_CHECK_LAUNCH("conv_nhwc_kernel");
   return NS_OK;
+}
+
+extern "C" int ns_conv_nhwc_f16(const void* const* src_host, const int* src_channels_host, const int* src_strides_host, int nsrc,
+                                int N, int H, int W, const void* wpacked, int ksize, int cout, const float* bias,
+                                long bias_nstride, int act, void* out, int out_stride, int out_offset, void* stream) {
+  return cv_run(src_host, src_channels_host, src_strides_host, nsrc, N, H, W, wpacked, ksize, cout, bias, bias_nstride, act, out,
+                out_stride, out_offset, NS_CONV_FUSE_NONE, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int ns_conv_nhwc_f16_fused(const void* const* src_host, const int* src_channels_host, const int* src_strides_host,
+                                      int nsrc, int N, int H, int W, const void* wpacked, int ksize, int cout, const float* bias,
+                                      long bias_nstride, int act, void* out, int out_stride, int out_offset, int fuse,
+                                      const void* e0, int e0_stride, const void* e1, int e1_stride, void* stream) {
+  return cv_run(src_host, src_channels_host, src_strides_host, nsrc, N, H, W, wpacked, ksize, cout, bias, bias_nstride, act, out,
+                out_stride, out_offset, fuse, e0, e0_stride, e1, e1_stride, stream);
 }

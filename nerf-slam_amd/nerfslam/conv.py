@@ -50,14 +50,24 @@ class PackedConv:
         b = torch.cat([c.bias for c in convs], 0) if convs[0].bias is not None else None
         return cls(w, b, pad_cin_to)
 
-    def __call__(self, srcs, act=None, out=None, out_offset=0, bias=None):
-        return conv_nhwc(srcs, self, act=act, out=out, out_offset=out_offset, bias=bias)
+    def __call__(self, srcs, act=None, out=None, out_offset=0, bias=None, fuse=None):
+        return conv_nhwc(srcs, self, act=act, out=out, out_offset=out_offset, bias=bias, fuse=fuse)
 
 
-def conv_nhwc(srcs, layer, act=None, out=None, out_offset=0, bias=None):
+def _slice_operand(t, N, H, W):
+    """(tensor, pixel stride) of a channels-last f16 operand that may be a channel slice of a wider tensor"""
+    if t.dtype != torch.float16 or t.dim() != 4 or tuple(t.shape[:3]) != (N, H, W) or t.stride(3) != 1 or \
+            t.stride(1) != W * t.stride(2) or t.stride(0) != H * W * t.stride(2):
+        raise RuntimeError("conv_nhwc: fused operands must be channels-last f16 [N,H,W,C] (dense or a channel slice)")
+    return t, int(t.stride(2))
+
+
+def conv_nhwc(srcs, layer, act=None, out=None, out_offset=0, bias=None, fuse=None):
     """srcs: list of channels-last f16 tensors [N,H,W,C_s] whose channel counts add up to layer.cin_padded.
     bias: None (the layer's own), or a per-image f32 tensor [N, cout] (the layer's bias must then be folded in by the caller).
-    out: None (a fresh [N,H,W,cout]) or a channels-last f16 tensor whose channels [out_offset, out_offset+cout) are written."""
+    out: None (a fresh [N,H,W,cout]) or a channels-last f16 tensor whose channels [out_offset, out_offset+cout) are written.
+    fuse: None, ("mul_hi", h): the upper half of the couts is multiplied by h after the activation (z | r*h of the ConvGRU),
+          or ("gru", z, h): the output is h + z * (act(conv) - h)."""
     if not isinstance(srcs, (list, tuple)):
         srcs = [srcs]
     require_cuda(*srcs)
@@ -86,8 +96,16 @@ def conv_nhwc(srcs, layer, act=None, out=None, out_offset=0, bias=None):
     src_arr = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
     ch_arr = (C.c_int * n)(*chans)
     st_arr = (C.c_int * n)(*strides)
+    mode, e0, e0s, e1, e1s = 0, None, 0, None, 0
+    if fuse is not None and N * H * W > 0:
+        if fuse[0] == "mul_hi":
+            mode, (e0, e0s) = 1, _slice_operand(fuse[1], N, H, W)
+        elif fuse[0] == "gru":
+            mode, (e0, e0s), (e1, e1s) = 2, _slice_operand(fuse[1], N, H, W), _slice_operand(fuse[2], N, H, W)
+        else:
+            raise RuntimeError(f"conv_nhwc: unknown fusion {fuse[0]!r}")
     with torch.cuda.device(out.device):
-        check(lib().ns_conv_nhwc_f16(src_arr, ch_arr, st_arr, n, N, H, W, ptr(layer.w), layer.ksize, layer.cout, ptr(b),
-                                     C.c_long(bstride), ACT[act], ptr(out), int(out.shape[3]), int(out_offset), stream_ptr()),
-              "conv_nhwc_f16")
+        check(lib().ns_conv_nhwc_f16_fused(src_arr, ch_arr, st_arr, n, N, H, W, ptr(layer.w), layer.ksize, layer.cout, ptr(b),
+                                           C.c_long(bstride), ACT[act], ptr(out), int(out.shape[3]), int(out_offset), mode,
+                                           ptr(e0), e0s, ptr(e1), e1s, stream_ptr()), "conv_nhwc_f16")
     return out

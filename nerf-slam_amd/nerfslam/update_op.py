@@ -5,7 +5,8 @@ Same arithmetic as `nerfslam.droid_nets.UpdateModule` (whose weights it is built
   * every 3x3 / 1x1 convolution is one `ns_conv_nhwc_f16` launch with bias and activation fused;
   * no `torch.cat`: the ConvGRU reads [net | inp | corr features | flow features] as a list of tensors, and the encoders
     write their halves of one [E,ht,wd,192] buffer;
-  * convz | convr are one 448 -> 256 convolution; the global-context terms conv*_glo(glo) are 1x1 convolutions of a
+  * convz | convr are one 448 -> 256 convolution whose epilogue also forms r * net, and the convq launch's epilogue is
+    the GRU blend (1 - z) net + z q: no elementwise kernels between the gates; the global-context terms conv*_glo(glo) are 1x1 convolutions of a
     per-edge vector, i.e. a per-image bias of that launch (one small matmul for all three);
   * the first convolutions of the delta head, the weight head and GraphAgg share their input: one 128 -> 384 launch,
     whose channel slices feed the second convolutions directly.
@@ -61,13 +62,11 @@ class HipUpdateOperator:
         self.flow2([f1.permute(0, 2, 3, 1).contiguous()], act="relu", out=X, out_offset=128)   # (already dense: f1 is channels-last)
         # ---- ConvGRU ----
         wg = self.gw([net], act="sigmoid")
-        glo = (wg * net).float().mean((1, 2))                               # [E,128]
+        glo = (wg * net).sum((1, 2), dtype=torch.float32) / float(ht * wd)    # [E,128]
         gb = torch.addmm(self.glo_b, glo, self.glo_w)                         # [E,384] per-edge biases of z | r | q
-        zr = self.zr([net, inp, X], act="sigmoid", bias=gb[:, :256].contiguous())
-        rh = zr[..., 128:] * net
-        q = self.q([rh, inp, X], act="tanh", bias=gb[:, 256:].contiguous())
-        z = zr[..., :128]
-        net2 = torch.addcmul(net, z, q - net)                                 # (1 - z) net + z q
+        zrh = self.zr([net, inp, X], act="sigmoid", bias=gb[:, :256].contiguous(), fuse=("mul_hi", net))   # [z | r * net]
+        net2 = self.q([zrh[..., 128:], inp, X], act="tanh", bias=gb[:, 256:].contiguous(),
+                      fuse=("gru", zrh[..., :128], net))                      # (1 - z) net + z q
         # ---- heads ----
         hd = self.heads([net2], act="relu")                                   # [delta | weight | agg] x 128
         delta = self.delta2([hd[..., :128]]).float()
@@ -76,9 +75,9 @@ class HipUpdateOperator:
         uniq, ix = np.unique(np.asarray(ii_host), return_inverse=True)
         k = len(uniq)
         ixd = torch.from_numpy(ix.astype(np.int64)).to(dev)
-        s = torch.zeros((k, ht, wd, 128), dtype=torch.float32, device=dev).index_add_(0, ixd, hd[..., 256:].float())
-        cnt = torch.from_numpy(np.bincount(ix, minlength=k).astype(np.float32)).to(dev)
-        x2 = self.agg2([(s / cnt.view(k, 1, 1, 1)).half()], act="relu")
+        s = torch.zeros((k, ht, wd, 128), dtype=torch.float16, device=dev).index_add_(0, ixd, hd[..., 256:])   # f16 as the reference
+        cnt = torch.from_numpy(np.bincount(ix, minlength=k).astype(np.float16)).to(dev)
+        x2 = self.agg2([s / cnt.view(k, 1, 1, 1)], act="relu")
         eta = 0.01 * F.softplus(self.eta([x2]).float())[..., 0]
         upmask = self.upmask([x2]).permute(0, 3, 1, 2).contiguous()
         return net2, delta, weight, eta, upmask

@@ -82,6 +82,29 @@ def test_channel_slices_as_sources(dev):
         conv_nhwc([wide.permute(0, 2, 1, 3)[..., :160]], PackedConv(w, b))      # not channels-last
 
 
+def test_fused_gru_epilogues(dev):
+    """the two ConvGRU steps folded into the epilogue == conv followed by the torch elementwise ops (gru.py:28-33)"""
+    from nerfslam.conv import PackedConv, conv_nhwc
+    g = torch.Generator().manual_seed(0)
+    N, H, W = 2, 23, 37
+    h = torch.tanh(torch.randn((N, H, W, 128), generator=g)).half().to(dev)
+    x = torch.randn((N, H, W, 64), generator=g).half().to(dev)
+    wzr = (torch.randn((256, 192, 3, 3), generator=g) / 41.0).to(dev)
+    wq = (torch.randn((128, 192, 3, 3), generator=g) / 41.0).to(dev)
+    bzr, bq = torch.randn((N, 256), generator=g).to(dev), torch.randn((N, 128), generator=g).to(dev)
+    Lzr, Lq = PackedConv(wzr), PackedConv(wq)
+    zr = conv_nhwc([h, x], Lzr, act="sigmoid", bias=bzr)
+    zrh = conv_nhwc([h, x], Lzr, act="sigmoid", bias=bzr, fuse=("mul_hi", h))
+    assert torch.equal(zrh[..., :128], zr[..., :128])
+    assert (zrh[..., 128:].float() - zr[..., 128:].float() * h.float()).abs().max().item() <= 1e-3
+    q = conv_nhwc([zrh[..., 128:], x], Lq, act="tanh", bias=bq)
+    h2 = conv_nhwc([zrh[..., 128:], x], Lq, act="tanh", bias=bq, fuse=("gru", zrh[..., :128], h))
+    ref = h.float() + zrh[..., :128].float() * (q.float() - h.float())
+    assert (h2.float() - ref).abs().max().item() <= 2e-3
+    with pytest.raises(RuntimeError):
+        conv_nhwc([h, x], PackedConv(wzr[:100]), fuse=("mul_hi", h))          # ragged cout tile: not on the fused path
+
+
 def test_rejects_bad_arguments(dev):
     from nerfslam._lib import NerfSlamHipError
     from nerfslam.conv import PackedConv, conv_nhwc
