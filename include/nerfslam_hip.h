@@ -371,6 +371,11 @@ int ns_conv_nhwc_f16_fused(const void* const* src_host, const int* src_channels_
                            int act, void* out, int out_stride, int out_offset, int fuse, const void* e0, int e0_stride,
                            const void* e1, int e1_stride, void* stream);
 
+/* im2col of the flow encoder's first layer (networks/droid_net.py:96, Conv2d(4,128,7,padding=3) on the motion features):
+ * flow [E,4,ht,wd] f32 -> out [E,ht,wd,208] f16 with out[..., (ci*7+ky)*7+kx] = flow[e,ci,y+ky-3,x+kx-3] (0 outside the
+ * image; channels 196..207 zero), so that the layer is a 1x1 ns_conv_nhwc_f16 with weight.reshape(128,196).       */
+int ns_flow_im2col(const float* flow, void* out, int E, int ht, int wd, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

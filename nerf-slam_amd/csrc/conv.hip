@@ -419,3 +419,43 @@ extern "C" int ns_conv_nhwc_f16_fused(const void* const* src_host, const int* sr
   return cv_run(src_host, src_channels_host, src_strides_host, nsrc, N, H, W, wpacked, ksize, cout, bias, bias_nstride, act, out,
                 out_stride, out_offset, fuse, e0, e0_stride, e1, e1_stride, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// im2col of the flow encoder's 7x7 convolution (networks/droid_net.py:96: Conv2d(4, 128, 7, padding=3) over the motion
+// features [E,4,ht,wd] f32): out[e,y,x, k] = flow[e, ci, y+ky-3, x+kx-3] for k = (ci*7 + ky)*7 + kx < 196 (the order of
+// weight.reshape(128, 196)), zero outside the image and for the 12 pad channels -> the convolution becomes a 1x1
+// ns_conv_nhwc_f16 over 208 channels on the MFMA units.  (MIOpen's immediate mode picks a naive kernel for this shape in
+// channels-last: 10.8 ms per call at E=48.)  One thread per 16-byte piece: 26 pieces per pixel, stores fully coalesced.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flow_im2col_kernel(const float* __restrict__ flow, _Float16* __restrict__ out, long npix,
+                                                          int ht, int wd) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix * 26) return;
+  const long pix = i / 26;
+  const int piece = (int)(i - pix * 26);
+  const int hw = ht * wd;
+  const long e = pix / hw;
+  const int p = (int)(pix - e * hw), y = p / wd, x = p - y * wd;
+  const float* f = flow + e * 4 * hw;
+  cv_f16x8 v;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int k = piece * 8 + q;
+    const int ci = k / 49, r = k - ci * 49, ky = r / 7, kx = r - ky * 7;
+    const int yy = y + ky - 3, xx = x + kx - 3;
+    const bool ok = k < 196 && yy >= 0 && yy < ht && xx >= 0 && xx < wd;
+    v[q] = ok ? (_Float16)f[ci * hw + yy * wd + xx] : (_Float16)0.0f;
+  }
+  *reinterpret_cast<cv_f16x8*>(out + pix * 208 + piece * 8) = v;
+}
+
+extern "C" int ns_flow_im2col(const float* flow, void* out, int E, int ht, int wd, void* stream) {
+  if (E == 0) return NS_OK;
+  NS_REQUIRE(flow && out, "ns_flow_im2col: null pointer");
+  NS_REQUIRE(E > 0 && ht > 0 && wd > 0, "ns_flow_im2col: bad shape");
+  const long npix = (long)E * ht * wd;
+  hipLaunchKernelGGL(flow_im2col_kernel, dim3(ns_cdiv(npix * 26, 256)), dim3(256), 0, (hipStream_t)stream, flow, (_Float16*)out,
+                     npix, ht, wd);
+  NS_CHECK_LAUNCH("flow_im2col_kernel");
+  return NS_OK;
+}

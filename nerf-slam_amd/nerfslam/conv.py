@@ -109,3 +109,15 @@ def conv_nhwc(srcs, layer, act=None, out=None, out_offset=0, bias=None, fuse=Non
                                            C.c_long(bstride), ACT[act], ptr(out), int(out.shape[3]), int(out_offset), mode,
                                            ptr(e0), e0s, ptr(e1), e1s, stream_ptr()), "conv_nhwc_f16")
     return out
+
+
+def flow_im2col(flow):
+    """[E,4,ht,wd] f32 motion features -> [E,ht,wd,208] f16 patches of the flow encoder's 7x7 convolution (ns_flow_im2col)"""
+    require_cuda(flow)
+    if flow.dtype != torch.float32 or flow.dim() != 4 or flow.shape[1] != 4 or not flow.is_contiguous():
+        raise RuntimeError("flow_im2col: expects a contiguous f32 [E,4,ht,wd] tensor")
+    E, _, ht, wd = flow.shape
+    out = torch.empty((E, ht, wd, 208), dtype=torch.float16, device=flow.device)
+    with torch.cuda.device(flow.device):
+        check(lib().ns_flow_im2col(ptr(flow), ptr(out), E, ht, wd, stream_ptr()), "flow_im2col")
+    return out

@@ -229,6 +229,11 @@ class DroidNetworks:
 
     @torch.no_grad()
     def motion(self, corr, last_kf):
+        if self.hip_update:
+            c = corr[0] if corr.dim() == 5 else corr
+            flow = torch.zeros((1, 4) + tuple(c.shape[-2:]), device=self.device)
+            _, delta, _, _, _ = self.update_op(self.ctx_cl[last_kf][None], self.inp_cl[last_kf][None], c.half(), flow, [0])
+            return delta[None]
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda"):
             _, delta, _ = self.net.update_net(self.ctx[last_kf][None, None], self.inp[last_kf][None, None], corr)
         return delta.float()

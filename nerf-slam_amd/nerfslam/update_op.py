@@ -10,13 +10,13 @@ Same arithmetic as `nerfslam.droid_nets.UpdateModule` (whose weights it is built
     per-edge vector, i.e. a per-image bias of that launch (one small matmul for all three);
   * the first convolutions of the delta head, the weight head and GraphAgg share their input: one 128 -> 384 launch,
     whose channel slices feed the second convolutions directly.
-The 7x7 convolution of the flow encoder (4 input channels, 1 % of the FLOPs) stays with torch/MIOpen.
+The 7x7 convolution of the flow encoder (4 input channels) is an im2col kernel + a 1x1 launch over 208 channels.
 """
 import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .conv import PackedConv
+from .conv import PackedConv, flow_im2col
 
 
 class HipUpdateOperator:
@@ -25,8 +25,7 @@ class HipUpdateOperator:
         ce, fe, g, a = um.corr_encoder, um.flow_encoder, um.gru, um.agg
         self.corr1 = P(ce[0].weight, ce[0].bias, pad_cin_to=208)      # 196 lookup channels, padded to 13 chunks of 16
         self.corr2 = P(ce[2].weight, ce[2].bias)
-        self.flow1_w = fe[0].weight.detach().half().contiguous(memory_format=torch.channels_last)
-        self.flow1_b = fe[0].bias.detach().half()
+        self.flow1 = P(fe[0].weight.reshape(128, 196, 1, 1), fe[0].bias, pad_cin_to=208)   # 7x7 as a 1x1 over im2col patches
         self.flow2 = P(fe[2].weight, fe[2].bias)
         self.gw = P(g.w.weight, g.w.bias)
         self.zr = P.from_modules(g.convz, g.convr)
@@ -58,8 +57,8 @@ class HipUpdateOperator:
         c1 = self.corr1([c208], act="relu")
         X = torch.empty((E, ht, wd, 192), dtype=torch.float16, device=dev)
         self.corr2([c1], act="relu", out=X, out_offset=0)
-        f1 = torch.relu(F.conv2d(flow.half().contiguous(memory_format=torch.channels_last), self.flow1_w, self.flow1_b, padding=3))
-        self.flow2([f1.permute(0, 2, 3, 1).contiguous()], act="relu", out=X, out_offset=128)   # (already dense: f1 is channels-last)
+        f1 = self.flow1([flow_im2col(flow.float().contiguous())], act="relu")
+        self.flow2([f1], act="relu", out=X, out_offset=128)
         # ---- ConvGRU ----
         wg = self.gw([net], act="sigmoid")
         glo = (wg * net).sum((1, 2), dtype=torch.float32) / float(ht * wd)    # [E,128]

@@ -105,6 +105,21 @@ def test_fused_gru_epilogues(dev):
         conv_nhwc([h, x], PackedConv(wzr[:100]), fuse=("mul_hi", h))          # ragged cout tile: not on the fused path
 
 
+def test_flow_im2col_makes_the_7x7_conv_a_1x1(dev):
+    from nerfslam.conv import PackedConv, conv_nhwc, flow_im2col
+    g = torch.Generator().manual_seed(0)
+    for (E, ht, wd) in ((3, 60, 80), (2, 5, 3), (1, 1, 1)):
+        flow = (torch.randn((E, 4, ht, wd), generator=g) * 3).to(dev)
+        col = flow_im2col(flow)
+        ref = F.unfold(flow.half().float(), 7, padding=3).reshape(E, 196, ht, wd).permute(0, 2, 3, 1)
+        assert torch.equal(col[..., :196].float(), ref) and (col[..., 196:] == 0).all()
+        w = (torch.randn((128, 4, 7, 7), generator=g) / 14.0).half().float().to(dev)
+        b = torch.randn((128,), generator=g).to(dev)
+        got = conv_nhwc([col], PackedConv(w.reshape(128, 196, 1, 1), b, pad_cin_to=208), act="relu").float()
+        want = torch.relu(F.conv2d(flow.half().float(), w, b, padding=3)).permute(0, 2, 3, 1)
+        assert (got - want).abs().max().item() <= 2.5e-3 * max(1.0, want.abs().max().item())
+
+
 def test_rejects_bad_arguments(dev):
     from nerfslam._lib import NerfSlamHipError
     from nerfslam.conv import PackedConv, conv_nhwc
