@@ -288,6 +288,44 @@ def mapping_rate(dev, steps=100, warmup=200):
             "note": "instant-ngp style trainer on the HIP kernels (hash encode, MFMA MLPs, ray marching), not part of `value`"}
 
 
+def conv_nets_rate(dev, iters=10):
+    """The tracker's conv nets at the step's shapes (NOT part of `value`): encoders through torch/MIOpen,
+    the update operator through nerfslam.update_op (MFMA convolutions of csrc/conv.hip); random-init weights."""
+    from nerfslam.droid_nets import DroidNet
+    from nerfslam.update_op import HipUpdateOperator
+    torch.manual_seed(0)
+    net = DroidNet().to(dev).eval()
+    op = HipUpdateOperator(net.update_net)
+    img = torch.randn((1, 1, 3, 8 * HT, 8 * WD), device=dev)
+    E = E_ACTIVE
+    hid = torch.randn((E, HT, WD, 128), device=dev).half(); inp = torch.randn((E, HT, WD, 128), device=dev).half()
+    corr = torch.randn((E, 196, HT, WD), device=dev).half(); flow = torch.randn((E, 4, HT, WD), device=dev)
+    ii = [KF0 + k % (KF1 - KF0) for k in range(E)]
+
+    def timed(fn):
+        with torch.no_grad():
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / iters
+
+    def enc(m):
+        with torch.autocast("cuda", dtype=torch.float16):
+            return m(img)
+    f = timed(lambda: enc(net.feature_net))
+    c = timed(lambda: enc(net.context_net))
+    u = timed(lambda: op(hid, inp, corr, flow, ii))
+    u1 = timed(lambda: op(hid[:1], inp[:1], corr[:1], flow[:1], ii[:1]))
+    return {"feature_net_ms": f, "context_net_ms": c, "update_operator_E48_ms": u, "update_operator_E1_ms": u1,
+            "ms_per_keyframe_step": f + c + u1 + 6 * u,
+            "note": "feature + context encoders (torch/MIOpen f16) + motion-filter update + 6 updates over 48 edges with the "
+                    "HIP update operator; random-init weights; not part of `value`"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -435,6 +473,12 @@ def main():
         # `frame()` of the mapper = 16 training steps (pyngp.Testbed.steps_per_frame)
         m["tracked_plus_mapped_frames_per_s_single_gpu"] = 1.0 / (dt / args.steps + 16.0 / m["nerf_train_steps_per_s"])
         m["assumption"] = "one tracking step + 16 NeRF training steps per frame, run back to back on the same GPU"
+    if rank == 0 and world == 1:
+        try:
+            out["conv_nets"] = cn = conv_nets_rate(dev)
+            cn["tracked_frames_per_s_incl_conv_nets"] = 1.0 / (dt / args.steps + 1e-3 * cn["ms_per_keyframe_step"])
+        except Exception as e:           # informational only
+            out["conv_nets"] = {"error": str(e)[:200]}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(hp)
     elif rank == 0:
