@@ -59,24 +59,29 @@ __device__ __forceinline__ float cv_act(float v, int act) {
 template <bool B>
 struct cv_bool { static constexpr bool value = B; };
 
-template <int KS, int MT, int UT>                // UT = column tiles (2 rows x 16 pixels) per wave
-__global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
+// UT = column tiles (2 rows x 16 pixels) per wave; CG = cout groups: the workgroup is 4 CG waves, wave w owns pixel rows
+// 2 UT (w % 4) .. and the couts of A tiles [MTW (w / 4), MTW (w / 4 + 1)), MTW = MT / CG.  CG = 2 puts two waves on every
+// SIMD (64 accumulator registers each): one's waits (fragment reads, LDS-DMA issue) are the other's MFMA time.
+template <int KS, int MT, int UT, int CG>
+__global__ __launch_bounds__(256 * CG) void conv_nhwc_kernel(ConvArgs a) {
+  constexpr int NT = 256 * CG, MTW = MT / CG;
   constexpr int HALO = KS / 2, T = KS * KS;
   constexpr int TR = 8 * UT;
   constexpr int SR = TR + 2 * HALO, SC = CV_TC + 2 * HALO, SPIX = SR * SC;
-  constexpr int NPS = (SPIX * 2 + 255) / 256;    // 16-byte slab pieces per thread
+  constexpr int NPS = (SPIX * 2 + NT - 1) / NT;  // 16-byte slab pieces per thread
   constexpr int WV = T * MT * 64;                // weight fragments (16 B) per stage
-  constexpr int NPW = (WV + 255) / 256;          // LDS-DMA instructions per thread and chunk
-  constexpr int ERS = MT * 32 + 4;               // epilogue row stride in halves (+8 B: conflict-free ds_write_b64)
+  constexpr int NPW = (WV + NT - 1) / NT;        // LDS-DMA instructions per thread and chunk
+  constexpr int ERS = MTW * 32 + 4;              // epilogue row stride in halves (+8 B: conflict-free ds_write_b64)
   // one LDS block: [slab stage 0 | slab stage 1 | weight stage 0 | weight stage 1]; the epilogue's transposition tiles
   // (per wave 32 pixels x 32 MT couts) reuse it from offset 0 once the last chunk is done
   constexpr int SLAB_H = SPIX * CV_SP;                         // halves per slab stage
-  constexpr int MAIN_BYTES = 2 * SLAB_H * 2 + 2 * WV * 16, EPI_BYTES = 4 * 32 * ERS * 2;
+  constexpr int MAIN_BYTES = 2 * SLAB_H * 2 + 2 * WV * 16, EPI_BYTES = 4 * CG * 32 * ERS * 2;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
   _Float16* const slab0 = reinterpret_cast<_Float16*>(lds_raw);
   cv_f16x8* const wl0 = reinterpret_cast<cv_f16x8*>(lds_raw + 2 * SLAB_H * 2);
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int pg = wv & 3, cg = wv >> 2;              // pixel-row group / cout group of this wave
   const int j = lane & 31, h = lane >> 5;
   const int n = blockIdx.y / a.tiles_y;
   const int y0 = (blockIdx.y - n * a.tiles_y) * TR, x0 = blockIdx.x * CV_TC;
@@ -84,9 +89,9 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
   const int nchunk = a.CI >> 4;
   const int ctiles = a.COP >> 5;
 
-  cv_f32x16 acc[MT][UT];
+  cv_f32x16 acc[MTW][UT];
 #pragma unroll
-  for (int m = 0; m < MT; m++)
+  for (int m = 0; m < MTW; m++)
 #pragma unroll
     for (int u = 0; u < UT; u++)
 #pragma unroll
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
   bool g_ok[NPS];
 #pragma clang loop unroll(full)
   for (int q = 0; q < NPS; q++) {
-    const int p = tid + q * 256;
+    const int p = tid + q * NT;
     const int sp = p >> 1;
     s_off[q] = -1;
     g_pix[q] = 0;
@@ -140,11 +145,11 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
   // MFMA stream got two accumulator register sets and 256 v_accvgpr moves per chunk.  Hidden, it costs nothing: the
   // explicit vmcnt(0) in front of the barrier that publishes the stage is the only wait it needs.
   auto load_weight_piece = [&](int q, uint32_t wdst_lds) __attribute__((always_inline)) {
-    const int v = tid + q * 256;                   // (v < WV is wave-uniform: WV is a multiple of 64)
-    if (WV % 256 == 0 || v < WV) {
+    const int v = tid + q * NT;                    // (v < WV is wave-uniform: WV is a multiple of 64)
+    if (WV % NT == 0 || v < WV) {
       const int t = v / (MT * 64), rem = v - t * (MT * 64);
       const cv_f16x8* g = cwsrc + (long)t * ctiles * 64 + rem;
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(wdst_lds + (uint32_t)(q * 256 + wv * 64) * 16u);
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(wdst_lds + (uint32_t)(q * NT + wv * 64) * 16u);
       uint32_t keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
   int boff[UT];
 #pragma unroll
   for (int u = 0; u < UT; u++) {
-    const int row = 2 * UT * wv + 2 * u + (j >> 4), col = j & 15;
+    const int row = 2 * UT * pg + 2 * u + (j >> 4), col = j & 15;
     boff[u] = (row * SC + col) * CV_SP + 8 * h;
   }
   // One chunk: 9 taps x (UT B fragments + MT A fragments -> UT MT MFMAs), software-pipelined by one tap, with the NEXT
@@ -168,11 +173,11 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
   // wave per SIMD nothing else hides an instruction's issue or latency, so everything rides in the shadow of the MFMAs.
   auto compute = [&](const _Float16* sl, const cv_f16x8* w, auto more, uint32_t wdst) __attribute__((always_inline)) {
     constexpr bool MORE = decltype(more)::value;
-    cv_f16x8 bf[2][UT], af[2][MT];
+    cv_f16x8 bf[2][UT], af[2][MTW];
 #pragma unroll
     for (int u = 0; u < UT; u++) bf[0][u] = *reinterpret_cast<const cv_f16x8*>(sl + boff[u]);
 #pragma unroll
-    for (int m = 0; m < MT; m++) af[0][m] = w[m * 64 + lane];
+    for (int m = 0; m < MTW; m++) af[0][m] = w[(cg * MTW + m) * 64 + lane];
 #pragma unroll
     for (int t = 0; t < T; t++) {
       const int cur = t & 1, nxt = cur ^ 1;
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
 #pragma unroll
         for (int u = 0; u < UT; u++) bf[nxt][u] = *reinterpret_cast<const cv_f16x8*>(sl + boff[u] + toff);
 #pragma unroll
-        for (int m = 0; m < MT; m++) af[nxt][m] = w[((t + 1) * MT + m) * 64 + lane];
+        for (int m = 0; m < MTW; m++) af[nxt][m] = w[((t + 1) * MT + cg * MTW + m) * 64 + lane];
       }
       // this tap's share of the next chunk's loads
       const int w0 = t * NPW / T, w1 = (t + 1) * NPW / T;                       // weights: spread over the taps
@@ -193,16 +198,17 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
         for (int q = s0; q < s1; q++) load_slab_piece(q);
       }
 #pragma unroll
-      for (int m = 0; m < MT; m++)
+      for (int m = 0; m < MTW; m++)
 #pragma unroll
         for (int u = 0; u < UT; u++)
           acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][m], bf[cur][u], acc[m][u], 0, 0, 0);
       // issue order inside the tap: MFMA, one memory instruction, MFMA, ...
-      const int nds = (t + 1 < T) ? UT + MT : 0, nvm = MORE ? (w1 - w0) + (s1 - s0) : 0;
+      const int nds = (t + 1 < T) ? UT + MTW : 0, nvm = MORE ? (w1 - w0) + (s1 - s0) : 0;
 #pragma unroll
-      for (int i = 0; i < MT * UT; i++) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // 1 MFMA
-        if (i < nds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+      for (int i = 0; i < MTW * UT; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // 1 MFMA
+        if (2 * i < nds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS reads (up to 2 per MFMA)
+        if (2 * i + 1 < nds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         if (i < nvm) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 VMEM
       }
     }
@@ -234,14 +240,15 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
   const bool full = a.vec && (cz * MT + MT) * 32 <= a.CO;        // workgroup-uniform
   if (full) {
     _Float16* et = reinterpret_cast<_Float16*>(lds_raw) + wv * 32 * ERS;
+    const int cobase = (cz * MT + cg * MTW) * 32;       // first cout of this wave
     const bool bvec = bp && (reinterpret_cast<uintptr_t>(bp) & 15) == 0;
 #pragma clang loop unroll(full)
     for (int u = 0; u < UT; u++) {
 #pragma clang loop unroll(full)
-      for (int m = 0; m < MT; m++) {
+      for (int m = 0; m < MTW; m++) {
 #pragma clang loop unroll(full)
         for (int g = 0; g < 4; g++) {
-          const int co = (cz * MT + m) * 32 + 8 * g + 4 * h;
+          const int co = cobase + m * 32 + 8 * g + 4 * h;
           float4 b4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
           if (bvec) b4 = *reinterpret_cast<const float4*>(bp + co);
           else if (bp) b4 = make_float4(bp[co], bp[co + 1], bp[co + 2], bp[co + 3]);
@@ -251,16 +258,16 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the accumulator reads of later tiles from being hoisted (spills)
       }
-      // read back: MT 8 lanes per pixel row (8 bytes each), 64 / (8 MT) pixels per instruction
-      constexpr int LPR = MT * 8, PPI = 64 / LPR;
+      // read back: MTW 8 lanes per pixel row (8 bytes each), 64 / (8 MTW) pixels per instruction
+      constexpr int LPR = MTW * 8, PPI = 64 / LPR;
 #pragma clang loop unroll(full)
       for (int i = 0; i < 32 / PPI; i++) {
         const int pj = i * PPI + lane / LPR, l = lane % LPR;
         cv_f16x4 v = *reinterpret_cast<const cv_f16x4*>(et + pj * ERS + 4 * l);
-        const int y = y0 + 2 * UT * wv + 2 * u + (pj >> 4), x = x0 + (pj & 15);
+        const int y = y0 + 2 * UT * pg + 2 * u + (pj >> 4), x = x0 + (pj & 15);
         if (y < a.H && x < a.W) {
           const long pix = ((long)n * a.H + y) * a.W + x;
-          const int co = cz * MT * 32 + 4 * l;
+          const int co = cobase + 4 * l;
           if (a.fuse == NS_CONV_FUSE_MUL_HI) {          // r * h next to z (gru.py:29-30): couts >= CO/2 are multiplied
             if (co >= (a.CO >> 1)) {
               const cv_f16x4 f = *reinterpret_cast<const cv_f16x4*>(a.e0 + pix * a.e0s + co - (a.CO >> 1));
@@ -283,14 +290,14 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
   // ragged cout tile or unaligned slice: direct stores
 #pragma clang loop unroll(full)
   for (int u = 0; u < UT; u++) {
-    const int y = y0 + 2 * UT * wv + 2 * u + (j >> 4), x = x0 + (j & 15);
+    const int y = y0 + 2 * UT * pg + 2 * u + (j >> 4), x = x0 + (j & 15);
     const bool pv = y < a.H && x < a.W;
     _Float16* op = a.out + (((long)n * a.H + y) * a.W + x) * a.ostride + a.ooff;
 #pragma clang loop unroll(full)
-    for (int m = 0; m < MT; m++) {
+    for (int m = 0; m < MTW; m++) {
 #pragma clang loop unroll(full)
       for (int g = 0; g < 4; g++) {
-        const int co = (cz * MT + m) * 32 + 8 * g + 4 * h;
+        const int co = (cz * MT + cg * MTW + m) * 32 + 8 * g + 4 * h;
         float v0 = acc[m][u][4 * g], v1 = acc[m][u][4 * g + 1], v2 = acc[m][u][4 * g + 2], v3 = acc[m][u][4 * g + 3];
         if (pv && co + 3 < a.CO && a.vec) {
           if (bp) {
@@ -319,11 +326,11 @@ extern "C" int ns_conv_packed_cout(int cout) {
   return (cout + t - 1) / t * t;
 }
 
-template <int KS, int MT, int UT>
+template <int KS, int MT, int UT, int CG>
 static void cv_launch(ConvArgs a, hipStream_t st) {
   a.tiles_y = ns_cdiv(a.H, 8 * UT);
   dim3 grid(ns_cdiv(a.W, CV_TC), a.N * a.tiles_y, a.COP / (32 * MT));
-  hipLaunchKernelGGL((conv_nhwc_kernel<KS, MT, UT>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_nhwc_kernel<KS, MT, UT, CG>), grid, dim3(256 * CG), 0, st, a);
 }
 
 static int cv_run(const void* const* src_host, const int* src_channels_host, const int* src_strides_host, int nsrc, int N, int H,
@@ -392,14 +399,18 @@ static int cv_run(const void* const* src_host, const int* src_channels_host, con
   // 128-channel convolutions -- its epilogue spills -- so only the 16-row tile is instantiated)
   NS_REQUIRE((long)N * ns_cdiv(H, 16) <= 65535, "ns_conv_nhwc_f16: too many row tiles");
   hipStream_t st = (hipStream_t)stream;
+  const char* cg_env = getenv("NS_CONV_CG");        // 1 | 2 waves per SIMD for the 128-cout tile (experiments)
+  const bool two = cg_env ? atoi(cg_env) == 2 : true;
   if (ksize == 3) {
-    if (mt == 4) cv_launch<3, 4, 2>(a, st);
-    else if (mt == 2) cv_launch<3, 2, 2>(a, st);
-    else cv_launch<3, 1, 2>(a, st);
+    if (mt == 4 && two) cv_launch<3, 4, 2, 2>(a, st);
+    else if (mt == 4) cv_launch<3, 4, 2, 1>(a, st);
+    else if (mt == 2) cv_launch<3, 2, 2, 1>(a, st);
+    else cv_launch<3, 1, 2, 1>(a, st);
   } else {
-    if (mt == 4) cv_launch<1, 4, 2>(a, st);
-    else if (mt == 2) cv_launch<1, 2, 2>(a, st);
-    else cv_launch<1, 1, 2>(a, st);
+    if (mt == 4 && two) cv_launch<1, 4, 2, 2>(a, st);
+    else if (mt == 4) cv_launch<1, 4, 2, 1>(a, st);
+    else if (mt == 2) cv_launch<1, 2, 2, 1>(a, st);
+    else cv_launch<1, 1, 2, 1>(a, st);
   }
   NS_CHECK_LAUNCH("conv_nhwc_kernel");
   return NS_OK;
