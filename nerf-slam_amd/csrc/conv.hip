@@ -44,7 +44,7 @@ struct ConvArgs {
   const _Float16* e0;              // MUL_HI: the factor [N,H,W,e0s] for the upper half of the couts; GRU: z
   const _Float16* e1;              // GRU: h
   int e0s, e1s;                    // pixel strides (elements)
-  int tiles_y;
+  int tiles_y, tiles_x;
 };
 
 __device__ __forceinline__ float cv_act(float v, int act) {
@@ -83,9 +83,16 @@ __global__ __launch_bounds__(256 * CG) void conv_nhwc_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int pg = wv & 3, cg = wv >> 2;              // pixel-row group / cout group of this wave
   const int j = lane & 31, h = lane >> 5;
-  const int n = blockIdx.y / a.tiles_y;
-  const int y0 = (blockIdx.y - n * a.tiles_y) * TR, x0 = blockIdx.x * CV_TC;
-  const int cz = blockIdx.z;
+  // 1-D grid.  Workgroup ids are dealt round-robin to the 8 XCDs, so the cout tiles of one pixel tile get ids 8 apart:
+  // same XCD (same L2), dispatched back to back -- the second one finds the input slab in L2 instead of fetching it again
+  // (448 -> 256: two cout tiles, 2 x 262 MB of input otherwise).
+  const int L = blockIdx.x, nz = a.COP / (32 * MT);
+  const int cz = (L >> 3) % nz;
+  const int tile = (L / (8 * nz)) * 8 + (L & 7);
+  if (tile >= a.tiles_x * a.tiles_y * a.N) return;          // (workgroup-uniform: before any barrier)
+  const int bx = tile % a.tiles_x, by = tile / a.tiles_x;
+  const int n = by / a.tiles_y;
+  const int y0 = (by - n * a.tiles_y) * TR, x0 = bx * CV_TC;
   const int nchunk = a.CI >> 4;
   const int ctiles = a.COP >> 5;
 
@@ -329,7 +336,9 @@ extern "C" int ns_conv_packed_cout(int cout) {
 template <int KS, int MT, int UT, int CG>
 static void cv_launch(ConvArgs a, hipStream_t st) {
   a.tiles_y = ns_cdiv(a.H, 8 * UT);
-  dim3 grid(ns_cdiv(a.W, CV_TC), a.N * a.tiles_y, a.COP / (32 * MT));
+  a.tiles_x = ns_cdiv(a.W, CV_TC);
+  const long tiles = (long)a.tiles_x * a.tiles_y * a.N, nz = a.COP / (32 * MT);
+  dim3 grid((unsigned)((tiles + 7) / 8 * 8 * nz));
   hipLaunchKernelGGL((conv_nhwc_kernel<KS, MT, UT, CG>), grid, dim3(256 * CG), 0, st, a);
 }
 
@@ -397,7 +406,7 @@ static int cv_run(const void* const* src_host, const int* src_channels_host, con
   const int mt = cv_cout_tile(cout) / 32;
   // (UT = 4, 32-row tiles with 256 accumulator registers, measured 814 vs 749 TF/s on 448 -> 256 but 25 % slower on the
   // 128-channel convolutions -- its epilogue spills -- so only the 16-row tile is instantiated)
-  NS_REQUIRE((long)N * ns_cdiv(H, 16) <= 65535, "ns_conv_nhwc_f16: too many row tiles");
+  NS_REQUIRE((long)N * ns_cdiv(H, 16) * ns_cdiv(W, 16) * (ns_conv_packed_cout(cout) / 32) < (1L << 31), "ns_conv_nhwc_f16: too many tiles");
   hipStream_t st = (hipStream_t)stream;
   const char* cg_env = getenv("NS_CONV_CG");        // 1 | 2 waves per SIMD for the 128-cout tile (experiments)
   const bool two = cg_env ? atoi(cg_env) == 2 : true;

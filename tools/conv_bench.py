@@ -24,8 +24,10 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters
 
 
-for chans, cout, k in (((128, 128, 128, 64), 256, 3), ((128, 128, 128, 64), 128, 3), ((128,), 128, 3), ((128,), 384, 3),
-                       ((128,), 64, 3), ((208,), 128, 1), ((128,), 576, 1)):
+CASES = (((128, 128, 128, 64), 256, 3), ((128, 128, 128, 64), 128, 3), ((128,), 128, 3), ((128,), 384, 3),
+         ((128,), 64, 3), ((208,), 128, 1), ((128,), 576, 1))
+WITH_TORCH = os.environ.get("NS_CONV_BENCH_TORCH", "1") == "1"
+for chans, cout, k in CASES:
     cin = sum(chans)
     srcs = [torch.randn((N, H, W, c), device=dev).half() for c in chans]
     w = (torch.randn((cout, cin, k, k), device=dev) / (cin * k * k) ** 0.5)
@@ -36,6 +38,9 @@ for chans, cout, k in (((128, 128, 128, 64), 256, 3), ((128, 128, 128, 64), 128,
     line = f"{k}x{k} {cin:4d}->{cout:4d}: "
     ms = timeit(lambda: conv_nhwc(srcs, layer, act="relu", out=out))
     line += f"hip {ms*1e3:7.1f} us {flops/ms/1e9:6.0f} TF/s | "
+    if not WITH_TORCH:
+        print(line, flush=True)
+        continue
     x = torch.cat(srcs, -1).permute(0, 3, 1, 2)             # channels-last strides
     xc = x.contiguous()                                      # NCHW
     wh, bh = w.half(), b.half()
