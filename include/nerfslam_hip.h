@@ -119,6 +119,9 @@ int ns_cvx_upsample(const float* data, const void* mask, int mask_dtype, float* 
  * (98 % of the bytes) is read and soft-maxed once for both maps, and no gather / scatter copies are made.          */
 int ns_cvx_upsample_keyframes(const float* data_a, const float* data_b, const int64_t* kx, const void* mask, int mask_dtype,
                               float* out_a, float* out_b, int n, int ht, int wd, float pow_, void* stream);
+/* the same with a channels-last f16 mask [n,ht,wd,576] (what the update operator's 1x1 convolution writes) */
+int ns_cvx_upsample_keyframes_nhwc(const float* data_a, const float* data_b, const int64_t* kx, const void* mask, float* out_a,
+                                   float* out_b, int n, int ht, int wd, float pow_, void* stream);
 
 /* frame_distance (src/droid.cpp:230-246 -> src/droid_kernels.cu:1572-1594, kernel :630-769)
  *   poses [n,7] (t,q xyzw), disps [n,ht,wd], intrinsics [4], ii,jj [num] i64 -> dist [num].   */
@@ -375,6 +378,16 @@ int ns_conv_nhwc_f16_fused(const void* const* src_host, const int* src_channels_
  * flow [E,4,ht,wd] f32 -> out [E,ht,wd,208] f16 with out[..., (ci*7+ky)*7+kx] = flow[e,ci,y+ky-3,x+kx-3] (0 outside the
  * image; channels 196..207 zero), so that the layer is a 1x1 ns_conv_nhwc_f16 with weight.reshape(128,196).       */
 int ns_flow_im2col(const float* flow, void* out, int E, int ht, int wd, void* stream);
+
+/* layout glue of the update operator: the lookup's [E,C,HW] f16 planes (networks/modules/corr.py:52-57 output, C = 196) ->
+ * channels-last [E,HW,CP] with channels C..CP-1 zero (CP = 208: 13 chunks of 16 for ns_conv_nhwc_f16), one pass.   */
+int ns_planes_to_nhwc_f16(const void* src, void* dst, int E, int C, int CP, int HW, void* stream);
+
+/* GraphAgg's scatter_mean over the source keyframe of every edge (networks/droid_net.py:64-70):
+ * out[k,p,c] = mean_{m in [starts[k],starts[k+1])} src[members[m], p, c]; src [E,HW,src_stride] f16 (a channel slice is
+ * fine), starts [K+1] / members [E] i32 on the device, out [K,HW,channels] f16, f32 accumulation.                  */
+int ns_group_mean_nhwc_f16(const void* src, int src_stride, const int* starts, const int* members, void* out, int K, int HW,
+                           int channels, void* stream);
 
 #ifdef __cplusplus
 }

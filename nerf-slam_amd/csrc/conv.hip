@@ -479,3 +479,92 @@ extern "C" int ns_flow_im2col(const float* flow, void* out, int E, int ht, int w
   NS_CHECK_LAUNCH("flow_im2col_kernel");
   return NS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Layout glue of the update operator.
+//
+// planes_to_nhwc: the lookup's output [E, C, HW] f16 (C = 196) -> channels-last [E, HW, CP] (CP = 208, pad channels zero)
+// through an LDS tile of 64 pixels: global reads are 128-byte runs of one channel plane (two pixels per lane), global
+// writes 16-byte pieces of 416-byte pixel rows.  (torch: permute + pad = two passes, 128 us for E=48; here one.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void planes_to_nhwc_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst, int C,
+                                                             int CP, int HW) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 tile[];   // [64][CP + 8]
+  const int RS = CP + 8;
+  const int e = blockIdx.y, p0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const _Float16* sp = src + (long)e * C * HW;
+  // zero the pad channels
+  for (int i = tid; i < 64 * (CP - C); i += 256) tile[(i / (CP - C)) * RS + C + i % (CP - C)] = (_Float16)0.0f;
+  if ((HW & 1) == 0) {           // two pixels per lane: a wave instruction covers two channel rows of 64 pixels
+    const int half = lane >> 5, px = (lane & 31) * 2;
+    for (int c = wv * 2 + half; c < C; c += 8) {
+      uint32_t w = 0;
+      if (p0 + px < HW) w = *reinterpret_cast<const uint32_t*>(sp + (long)c * HW + p0 + px);
+      tile[px * RS + c] = __builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
+      tile[(px + 1) * RS + c] = __builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+    }
+  } else {
+    for (int c = wv; c < C; c += 4) tile[lane * RS + c] = (p0 + lane < HW) ? sp[(long)c * HW + p0 + lane] : (_Float16)0.0f;
+  }
+  __syncthreads();
+  const int ppr = CP / 8;        // 16-byte pieces per pixel row
+  for (int i = tid; i < 64 * ppr; i += 256) {
+    const int px = i / ppr, piece = i - px * ppr;
+    if (p0 + px < HW)
+      *reinterpret_cast<uint4*>(dst + ((long)e * HW + p0 + px) * CP + piece * 8) = *reinterpret_cast<const uint4*>(tile + px * RS + piece * 8);
+  }
+}
+
+extern "C" int ns_planes_to_nhwc_f16(const void* src, void* dst, int E, int C, int CP, int HW, void* stream) {
+  if (E == 0) return NS_OK;
+  NS_REQUIRE(src && dst, "ns_planes_to_nhwc_f16: null pointer");
+  NS_REQUIRE(E > 0 && C > 0 && HW > 0 && CP >= C && CP % 8 == 0 && CP <= 1024, "ns_planes_to_nhwc_f16: bad shape (C %d, CP %d)", C, CP);
+  NS_REQUIRE(E <= 65535, "ns_planes_to_nhwc_f16: too many images");
+  hipLaunchKernelGGL(planes_to_nhwc_kernel, dim3(ns_cdiv(HW, 64), E), dim3(256), 64 * (CP + 8) * sizeof(_Float16), (hipStream_t)stream,
+                     (const _Float16*)src, (_Float16*)dst, C, CP, HW);
+  NS_CHECK_LAUNCH("planes_to_nhwc_kernel");
+  return NS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GraphAgg's scatter-mean (networks/droid_net.py:64-70: torch_scatter.scatter_mean over the source keyframe of every edge):
+// out[k, p, c] = mean over the edges e in group k of src[e, p, c].  Groups as CSR (starts [K+1], members [E], built on
+// the host from the edge list).  One thread per (group, pixel, 8-channel piece): every input element is read once, f32 sums.
+// (torch: zeros + index_add_ + divide = 125 us + 2 passes for E=48.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_mean_kernel(const _Float16* __restrict__ src, int sstride, const int* __restrict__ starts,
+                                                         const int* __restrict__ members, _Float16* __restrict__ out, int K, long HW,
+                                                         int C8) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)K * HW * C8) return;
+  const int piece = (int)(i % C8);
+  const long kp = i / C8, p = kp % HW;
+  const int k = (int)(kp / HW);
+  const int e0 = starts[k], e1 = starts[k + 1];
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int m = e0; m < e1; m++) {
+    const cv_f16x8 v = *reinterpret_cast<const cv_f16x8*>(src + ((long)members[m] * HW + p) * sstride + piece * 8);
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc[q] += (float)v[q];
+  }
+  const float inv = e1 > e0 ? 1.0f / (float)(e1 - e0) : 0.0f;
+  cv_f16x8 o;
+#pragma unroll
+  for (int q = 0; q < 8; q++) o[q] = (_Float16)(acc[q] * inv);
+  *reinterpret_cast<cv_f16x8*>(out + kp * (C8 * 8) + piece * 8) = o;
+}
+
+extern "C" int ns_group_mean_nhwc_f16(const void* src, int src_stride, const int* starts, const int* members, void* out, int K,
+                                      int HW, int channels, void* stream) {
+  if (K == 0) return NS_OK;
+  NS_REQUIRE(src && starts && members && out, "ns_group_mean_nhwc_f16: null pointer");
+  NS_REQUIRE(K > 0 && HW > 0 && channels > 0 && channels % 8 == 0 && src_stride >= channels && src_stride % 8 == 0 &&
+                 ((uintptr_t)src % 16) == 0,
+             "ns_group_mean_nhwc_f16: bad shape / alignment (channels %d, stride %d)", channels, src_stride);
+  const long total = (long)K * HW * (channels / 8);
+  hipLaunchKernelGGL(group_mean_kernel, dim3(ns_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, src_stride,
+                     starts, members, (_Float16*)out, K, (long)HW, channels / 8);
+  NS_CHECK_LAUNCH("group_mean_kernel");
+  return NS_OK;
+}

@@ -356,6 +356,94 @@ __global__ __launch_bounds__(256) void cvx_upsample_h2_kernel(const float* __res
   }
 }
 
+// Channels-last mask [n, ht, wd, 576] f16 (what the update operator's 1x1 convolution writes): one lane per (pixel, output
+// row sy), the 8 lanes of a pixel side by side -- for each neighbour k they fetch the 8 logits of row sy as one 16-byte
+// piece, 128 contiguous bytes per pixel and k -- and a wave's 8 pixels are x-adjacent, so every output row segment it
+// stores is 256 contiguous bytes.
+template <bool PAIR>
+__global__ __launch_bounds__(256) void cvx_upsample_cl_kernel(const float* __restrict__ data_a, const float* __restrict__ data_b,
+                                                              const int64_t* __restrict__ kx,
+                                                              const _Float16* __restrict__ mask, float* __restrict__ out_a,
+                                                              float* __restrict__ out_b, int n, int ht, int wd, float pw) {
+  typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+  const long HW = (long)ht * wd;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int f = blockIdx.y;
+  const long p = t >> 3;
+  const int sy = (int)(t & 7);
+  if (p >= HW) return;
+  const int y = (int)(p / wd), x = (int)(p - (long)y * wd);
+  const long fs = kx ? (long)kx[f] : (long)f;
+  const float* da = data_a + fs * HW;
+  const float* db = PAIR ? data_b + fs * HW : nullptr;
+  const _Float16* m = mask + ((long)f * HW + p) * 576 + sy * 8;
+  float na[9], nb[9];
+  bool ok[9];
+  half8_t lg[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    ok[k] = yy >= 0 && yy < ht && xx >= 0 && xx < wd;
+    na[k] = ok[k] ? da[(long)yy * wd + xx] : 0.0f;
+    nb[k] = (PAIR && ok[k]) ? db[(long)yy * wd + xx] : 0.0f;
+    lg[k] = *reinterpret_cast<const half8_t*>(m + k * 64);
+  }
+  float ra[8], rb[8];
+#pragma unroll
+  for (int sx = 0; sx < 8; sx++) {
+    float e[9], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      e[k] = ok[k] ? (float)lg[k][sx] : -INFINITY;
+      mx = fmaxf(mx, e[k]);
+    }
+    float den = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      e[k] = ok[k] ? __expf(e[k] - mx) : 0.0f;
+      den += e[k];
+    }
+    const float inv = 1.0f / den;
+    float acca = 0.0f, accb = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      float w = e[k] * inv;
+      if (pw != 1.0f) w = __powf(w, pw);
+      acca = fmaf(w, na[k], acca);
+      if (PAIR) accb = fmaf(w, nb[k], accb);
+    }
+    ra[sx] = acca;
+    rb[sx] = accb;
+  }
+  const long o = fs * HW * 64 + ((long)(8 * y + sy) * (8 * wd) + 8 * x);
+  float4* dst = reinterpret_cast<float4*>(out_a + o);
+  dst[0] = make_float4(ra[0], ra[1], ra[2], ra[3]);
+  dst[1] = make_float4(ra[4], ra[5], ra[6], ra[7]);
+  if (PAIR) {
+    float4* dsb = reinterpret_cast<float4*>(out_b + o);
+    dsb[0] = make_float4(rb[0], rb[1], rb[2], rb[3]);
+    dsb[1] = make_float4(rb[4], rb[5], rb[6], rb[7]);
+  }
+}
+
+extern "C" int ns_cvx_upsample_keyframes_nhwc(const float* data_a, const float* data_b, const int64_t* kx, const void* mask,
+                                              float* out_a, float* out_b, int n, int ht, int wd, float pow_, void* stream) {
+  if (n == 0) return NS_OK;
+  NS_REQUIRE(data_a && mask && out_a && kx, "ns_cvx_upsample_keyframes_nhwc: null pointer");
+  NS_REQUIRE((data_b == nullptr) == (out_b == nullptr), "ns_cvx_upsample_keyframes_nhwc: data_b and out_b go together");
+  NS_REQUIRE(n > 0 && n <= 65535 && ht > 0 && wd > 0, "ns_cvx_upsample_keyframes_nhwc: bad shape");
+  NS_REQUIRE(((uintptr_t)mask % 16) == 0, "ns_cvx_upsample_keyframes_nhwc: mask must be 16-byte aligned");
+  dim3 grid(ns_cdiv((long)ht * wd * 8, 256), n);
+  if (data_b)
+    hipLaunchKernelGGL((cvx_upsample_cl_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, data_a, data_b, kx,
+                       (const _Float16*)mask, out_a, out_b, n, ht, wd, pow_);
+  else
+    hipLaunchKernelGGL((cvx_upsample_cl_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, data_a, data_b, kx,
+                       (const _Float16*)mask, out_a, out_b, n, ht, wd, pow_);
+  NS_CHECK_LAUNCH("cvx_upsample_cl_kernel");
+  return NS_OK;
+}
+
 template <typename MT>
 static void cvx_launch(const float* data_a, const float* data_b, const int64_t* kx, const void* mask, float* out_a, float* out_b,
                        int n, int ht, int wd, float pow_, void* stream) {

@@ -6,6 +6,7 @@ channel slice of its output tensor, so the encoders can write straight into the 
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from ._lib import check, lib, ptr, require_cuda, stream_ptr
@@ -121,3 +122,32 @@ def flow_im2col(flow):
     with torch.cuda.device(flow.device):
         check(lib().ns_flow_im2col(ptr(flow), ptr(out), E, ht, wd, stream_ptr()), "flow_im2col")
     return out
+
+
+def planes_to_nhwc(x, cp):
+    """[E,C,ht,wd] f16 planes (the lookup's layout) -> channels-last [E,ht,wd,cp], channels C..cp-1 zero (ns_planes_to_nhwc_f16)"""
+    require_cuda(x)
+    if x.dtype != torch.float16 or x.dim() != 4 or not x.is_contiguous():
+        raise RuntimeError("planes_to_nhwc: expects a contiguous f16 [E,C,ht,wd] tensor")
+    E, Cc, ht, wd = x.shape
+    out = torch.empty((E, ht, wd, cp), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().ns_planes_to_nhwc_f16(ptr(x), ptr(out), E, Cc, cp, ht * wd, stream_ptr()), "planes_to_nhwc_f16")
+    return out
+
+
+def group_mean(src, groups_host):
+    """src: channels-last f16 [E,ht,wd,C] (dense or a channel slice); groups_host: the group id of every row of src (host
+    ints, e.g. the source keyframe of every edge) -> ([K,ht,wd,C] f16 means in the order of np.unique(groups), K)"""
+    src, stride = _slice_operand(src, *src.shape[:3])
+    E, ht, wd, Cc = src.shape
+    uniq, ix = np.unique(np.asarray(groups_host), return_inverse=True)
+    K = len(uniq)
+    order = np.argsort(ix, kind="stable").astype(np.int32)
+    starts = np.concatenate([[0], np.cumsum(np.bincount(ix, minlength=K))]).astype(np.int32)
+    csr = torch.from_numpy(np.concatenate([starts, order])).to(src.device)
+    out = torch.empty((K, ht, wd, Cc), dtype=torch.float16, device=src.device)
+    with torch.cuda.device(src.device):
+        check(lib().ns_group_mean_nhwc_f16(ptr(src), stride, ptr(csr), C.c_void_p(csr.data_ptr() + 4 * (K + 1)), ptr(out), K,
+                                           ht * wd, Cc, stream_ptr()), "group_mean_nhwc_f16")
+    return out, K

@@ -16,7 +16,7 @@ weights (`droid.pth`) are missing from the reference tree; they are injected as 
     feature_fn(image [3,H,W] float) -> fmap [128, H/8, W/8]
     update_op(corr [1,E,196,ht,wd], motion [1,E,4,ht,wd], ii, jj) -> (delta [1,E,ht,wd,2], weight [1,E,ht,wd,2],
                                                                           damping [n_unique_ii, ht, wd]
-                                                                          [, upmask [n_unique_ii, 576, ht, wd]])
+                                                                          [, upmask [n_unique_ii, 576, ht, wd] or channels-last [n_unique_ii, ht, wd, 576] f16])
 """
 import ctypes as C
 
@@ -225,11 +225,20 @@ class TrackingFrontend:
     def upsample(self, kx, upmask):
         """convex 8x upsampling of the inverse depths and depth covariances of keyframes kx (:445-446)"""
         n = kx.shape[0]
+        kx = kx.to(torch.int64).contiguous()
+        if upmask.dim() == 4 and tuple(upmask.shape) == (n, self.ht, self.wd, 576) and upmask.dtype == torch.float16:
+            # channels-last logits, as nerfslam.update_op writes them: no transposition
+            with torch.cuda.device(self.device):
+                check(lib().ns_cvx_upsample_keyframes_nhwc(ptr(self.cam0_idepths), ptr(self.cam0_depths_cov), ptr(kx),
+                                                           ptr(upmask.contiguous()), ptr(self.cam0_idepths_up),
+                                                           ptr(self.cam0_depths_cov_up), n, self.ht, self.wd, C.c_float(1.0),
+                                                           stream_ptr()), "cvx_upsample_keyframes_nhwc")
+            self.has_up[kx] = True
+            return
         mask = upmask.reshape(n, 576, self.ht, self.wd).contiguous()
         dt = 1 if mask.dtype == torch.float16 else 2
         if mask.dtype not in (torch.float16, torch.float32):
             mask, dt = mask.float(), 2
-        kx = kx.to(torch.int64).contiguous()
         with torch.cuda.device(self.device):  # both maps, in place in the keyframe buffers, one pass over the mask
             check(lib().ns_cvx_upsample_keyframes(ptr(self.cam0_idepths), ptr(self.cam0_depths_cov), ptr(kx), ptr(mask), dt,
                                                   ptr(self.cam0_idepths_up), ptr(self.cam0_depths_cov_up), n, self.ht,

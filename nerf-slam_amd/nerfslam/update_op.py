@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .conv import PackedConv, flow_im2col
+from .conv import PackedConv, flow_im2col, group_mean, planes_to_nhwc
 
 
 class HipUpdateOperator:
@@ -45,7 +45,8 @@ class HipUpdateOperator:
     def __call__(self, net, inp, corr, flow, ii_host):
         """net, inp [E,ht,wd,128] f16 channels-last; corr [E,196,ht,wd] f16 (the lookup's layout); flow [E,4,ht,wd] f32;
         ii_host: source keyframe of every edge (host ints).
-        -> net' [E,ht,wd,128] f16, delta [E,ht,wd,2] f32, weight [E,ht,wd,2] f32, eta [k,ht,wd] f32, upmask [k,576,ht,wd] f16"""
+        -> net' [E,ht,wd,128] f16, delta [E,ht,wd,2] f32, weight [E,ht,wd,2] f32, eta [k,ht,wd] f32, upmask [k,ht,wd,576] f16
+        (channels-last; k = number of distinct source keyframes, in sorted order)"""
         with torch.autocast("cuda", enabled=False):     # dtypes are explicit here; an enclosing autocast would only add casts
             return self._forward(net, inp, corr, flow, ii_host)
 
@@ -53,8 +54,7 @@ class HipUpdateOperator:
         E, ht, wd, _ = net.shape
         dev = net.device
         # ---- encoders: X = [corr features 128 | flow features 64] ----
-        c208 = F.pad(corr.permute(0, 2, 3, 1), (0, 12)).contiguous()
-        c1 = self.corr1([c208], act="relu")
+        c1 = self.corr1([planes_to_nhwc(corr.contiguous(), 208)], act="relu")
         X = torch.empty((E, ht, wd, 192), dtype=torch.float16, device=dev)
         self.corr2([c1], act="relu", out=X, out_offset=0)
         f1 = self.flow1([flow_im2col(flow.float().contiguous())], act="relu")
@@ -71,12 +71,8 @@ class HipUpdateOperator:
         delta = self.delta2([hd[..., :128]]).float()
         weight = self.weight2([hd[..., 128:256]], act="sigmoid").float()
         # ---- GraphAgg: mean over the edges of each source keyframe, conv, eta + upsampling mask ----
-        uniq, ix = np.unique(np.asarray(ii_host), return_inverse=True)
-        k = len(uniq)
-        ixd = torch.from_numpy(ix.astype(np.int64)).to(dev)
-        s = torch.zeros((k, ht, wd, 128), dtype=torch.float16, device=dev).index_add_(0, ixd, hd[..., 256:])   # f16 as the reference
-        cnt = torch.from_numpy(np.bincount(ix, minlength=k).astype(np.float16)).to(dev)
-        x2 = self.agg2([s / cnt.view(k, 1, 1, 1)], act="relu")
+        mean, k = group_mean(hd[..., 256:], ii_host)
+        x2 = self.agg2([mean], act="relu")
         eta = 0.01 * F.softplus(self.eta([x2]).float())[..., 0]
-        upmask = self.upmask([x2]).permute(0, 3, 1, 2).contiguous()
+        upmask = self.upmask([x2])                                            # channels-last: ns_cvx_upsample_keyframes_nhwc reads it as is
         return net2, delta, weight, eta, upmask

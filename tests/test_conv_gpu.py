@@ -120,6 +120,24 @@ def test_flow_im2col_makes_the_7x7_conv_a_1x1(dev):
         assert (got - want).abs().max().item() <= 2.5e-3 * max(1.0, want.abs().max().item())
 
 
+def test_layout_glue_kernels(dev):
+    """planes -> channels-last with zero pad channels (bit-exact), and GraphAgg's scatter-mean"""
+    from nerfslam.conv import group_mean, planes_to_nhwc
+    g = torch.Generator().manual_seed(0)
+    for (E, Cc, ht, wd) in ((3, 196, 60, 80), (2, 196, 43, 77), (1, 5, 3, 3)):
+        x = torch.randn((E, Cc, ht, wd), generator=g).half().to(dev)
+        cp = (Cc + 15) // 16 * 16
+        y = planes_to_nhwc(x, cp)
+        assert torch.equal(y[..., :Cc], x.permute(0, 2, 3, 1)) and (y[..., Cc:] == 0).all()
+    wide = torch.randn((7, 9, 11, 384), generator=g).half().to(dev)
+    groups = [5, 2, 5, 9, 2, 5, 9]
+    mean, k = group_mean(wide[..., 256:], groups)
+    assert k == 3 and mean.shape == (3, 9, 11, 128)
+    for row, gid in enumerate((2, 5, 9)):
+        ref = torch.stack([wide[e, ..., 256:].float() for e in range(7) if groups[e] == gid]).mean(0)
+        assert (mean[row].float() - ref).abs().max().item() <= 2e-3
+
+
 def test_rejects_bad_arguments(dev):
     from nerfslam._lib import NerfSlamHipError
     from nerfslam.conv import PackedConv, conv_nhwc

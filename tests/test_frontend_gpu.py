@@ -136,6 +136,11 @@ def test_cvx_upsample_keyframes_kernel(oracle_mod, dev):
         check(lib().ns_cvx_upsample(ptr(ta[tk].contiguous()), ptr(tm), 1 if dt == np.float16 else 2, ptr(o2), 3, ht, wd,
                                     C.c_float(1.0), stream_ptr()), "cvx_upsample")
         assert torch.equal(o1[tk], o2) and torch.equal(o1[tk], oa[tk])
+        if dt == np.float16:      # channels-last mask variant == plane-major one (same arithmetic, other addressing)
+            oc, od = torch.zeros_like(oa), torch.zeros_like(ob)
+            check(lib().ns_cvx_upsample_keyframes_nhwc(ptr(ta), ptr(tb), ptr(tk), ptr(tm.permute(0, 2, 3, 1).contiguous()), ptr(oc),
+                                                       ptr(od), 3, ht, wd, C.c_float(1.0), stream_ptr()), "cvx_upsample_keyframes_nhwc")
+            assert torch.equal(oc[tk], oa[tk]) and torch.equal(od[tk], ob[tk])
 
 
 def test_motion_features_kernel(dev):
