@@ -126,7 +126,7 @@ class HotPath:
         self.target_a = self.targets[E_INACTIVE:].permute(0, 2, 3, 1).contiguous()   # the frontend's [E,ht,wd,2]
         self.coords_a = torch.empty((E_ACTIVE, HT, WD, 2), device=dev)
         self.motion = torch.empty((E_ACTIVE, 4, HT, WD), device=dev)
-        self.upmask = torch.randn((self.kx.shape[0], 576, HT, WD), generator=g).half().to(dev)  # the GRU head's f16 logits
+        self.upmask = torch.randn((self.kx.shape[0], HT, WD, 576), generator=g).half().to(dev)  # the mask head's f16 logits, channels-last as nerfslam.update_op writes them
         self.depth_cov = torch.rand((NBUF, HT, WD), generator=g).to(dev)
         self.disps_up = torch.zeros((NBUF, 8 * HT, 8 * WD), device=dev)
         self.depth_cov_up = torch.zeros((NBUF, 8 * HT, 8 * WD), device=dev)
@@ -182,9 +182,9 @@ class HotPath:
     def op_upsample(self):
         import ctypes as C
         from nerfslam._lib import check, lib, ptr, stream_ptr
-        check(lib().ns_cvx_upsample_keyframes(ptr(self.disps), ptr(self.depth_cov), ptr(self.kx), ptr(self.upmask), 1,
-                                              ptr(self.disps_up), ptr(self.depth_cov_up), self.kx.shape[0], HT, WD,
-                                              C.c_float(1.0), stream_ptr()), "cvx_upsample_keyframes")
+        check(lib().ns_cvx_upsample_keyframes_nhwc(ptr(self.disps), ptr(self.depth_cov), ptr(self.kx), ptr(self.upmask),
+                                                   ptr(self.disps_up), ptr(self.depth_cov_up), self.kx.shape[0], HT, WD,
+                                                   C.c_float(1.0), stream_ptr()), "cvx_upsample_keyframes_nhwc")
 
     def op_ba_iteration(self, want_cov):
         import droid_backends
