@@ -404,13 +404,19 @@ static int cv_run(const void* const* src_host, const int* src_channels_host, con
   }
   a.tiles_y = 0;
   const int mt = cv_cout_tile(cout) / 32;
-  // (UT = 4, 32-row tiles with 256 accumulator registers, measured 814 vs 749 TF/s on 448 -> 256 but 25 % slower on the
-  // 128-channel convolutions -- its epilogue spills -- so only the 16-row tile is instantiated)
   NS_REQUIRE((long)N * ns_cdiv(H, 16) * ns_cdiv(W, 16) * (ns_conv_packed_cout(cout) / 32) < (1L << 31), "ns_conv_nhwc_f16: too many tiles");
   hipStream_t st = (hipStream_t)stream;
   const char* cg_env = getenv("NS_CONV_CG");        // 1 | 2 waves per SIMD for the 128-cout tile (experiments)
   const bool two = cg_env ? atoi(cg_env) == 2 : true;
-  if (ksize == 3) {
+  // 3x3, 128-cout tile, images taller than one 16-row tile: 32-row tiles (4 column tiles per wave, 128 accumulator
+  // registers, still 2 waves per SIMD) -- twice the MFMAs per barrier and per LDS-DMA: 865 / 968 vs 791 / 872 TFLOP/s on
+  // the two ConvGRU gates; the 1x1 launches are load-bound and lose (61 vs 49 us).  NS_CONV_UT=2|4 overrides (tests).
+  const char* ut_env = getenv("NS_CONV_UT");
+  const bool tall = H > 16 && (ut_env ? atoi(ut_env) == 4 : ksize == 3);
+  if (mt == 4 && two && tall) {
+    if (ksize == 3) cv_launch<3, 4, 4, 2>(a, st);
+    else cv_launch<1, 4, 4, 2>(a, st);
+  } else if (ksize == 3) {
     if (mt == 4 && two) cv_launch<3, 4, 2, 2>(a, st);
     else if (mt == 4) cv_launch<3, 4, 2, 1>(a, st);
     else if (mt == 2) cv_launch<3, 2, 2, 1>(a, st);

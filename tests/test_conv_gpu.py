@@ -1,5 +1,7 @@
 """ns_conv_nhwc_f16 (csrc/conv.hip) against torch's fp32 conv2d on the same f16-rounded inputs: the convolutions of the
 tracker's update operator (networks/droid_net.py:78-150, networks/modules/gru.py:5-34) at its shapes and at awkward ones."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -38,14 +40,22 @@ def _case(dev, N, H, W, chans, cout, k, act, per_image_bias=False, out_stride=No
     return err
 
 
-def test_gru_gate_shapes(dev):
+@pytest.fixture(params=[2, 4])
+def ut(request):
+    """both pixel-tile variants of the 128-cout kernels (16- and 32-row tiles; NS_CONV_UT is read at every launch)"""
+    os.environ["NS_CONV_UT"] = str(request.param)
+    yield request.param
+    os.environ.pop("NS_CONV_UT", None)
+
+
+def test_gru_gate_shapes(dev, ut):
     # convz|convr fused: [h, inp, corr, flow] -> 256, sigmoid, per-edge global-context bias (gru.py:28-29)
     _case(dev, 3, 60, 80, (128, 128, 128, 64), 256, 3, "sigmoid", per_image_bias=True)
     # convq: -> 128, tanh
     _case(dev, 2, 60, 80, (128, 128, 128, 64), 128, 3, "tanh", per_image_bias=True, seed=1)
 
 
-def test_encoders_heads_and_slices(dev):
+def test_encoders_heads_and_slices(dev, ut):
     # corr encoder: 1x1 over 196 channels padded to 208, relu; then 3x3 into a slice of the GRU input buffer
     _case(dev, 2, 60, 80, (208,), 128, 1, "relu")
     _case(dev, 2, 60, 80, (128,), 128, 3, "relu", out_stride=448, out_offset=256, seed=2)
@@ -57,7 +67,7 @@ def test_encoders_heads_and_slices(dev):
     _case(dev, 1, 60, 80, (128,), 384, 3, "relu", seed=7)
 
 
-def test_odd_and_tiny_images(dev):
+def test_odd_and_tiny_images(dev, ut):
     _case(dev, 2, 43, 77, (32, 16), 40, 3, "relu")              # the real Replica grid, ragged everything
     _case(dev, 1, 5, 3, (16,), 6, 3, None, seed=1)
     _case(dev, 2, 9, 11, (16,), 7, 3, "relu", out_stride=13, out_offset=3, seed=5)   # unaligned slice: scalar stores
@@ -82,7 +92,7 @@ def test_channel_slices_as_sources(dev):
         conv_nhwc([wide.permute(0, 2, 1, 3)[..., :160]], PackedConv(w, b))      # not channels-last
 
 
-def test_fused_gru_epilogues(dev):
+def test_fused_gru_epilogues(dev, ut):
     """the two ConvGRU steps folded into the epilogue == conv followed by the torch elementwise ops (gru.py:28-33)"""
     from nerfslam.conv import PackedConv, conv_nhwc
     g = torch.Generator().manual_seed(0)
