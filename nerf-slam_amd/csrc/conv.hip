@@ -9,13 +9,16 @@
 // v_mfma_f32_32x32x16_f16 (A = 32 couts x 16 cin, B = 16 cin x 32 pixels); the accumulator layout then gives every lane 4
 // CONSECUTIVE couts of one pixel, i.e. 8-byte channels-last stores.
 //
-// Workgroup = 4 waves = a tile of (8 UT) rows x 16 columns of one image x (32 MT) couts.  Per 16-channel chunk of the
-// input the workgroup stages into LDS (double buffered, one barrier per chunk)
-//   * the input slab: tile + halo, 48-byte pixel stride (16 channels + pad: the 16 lanes of a b128 read group are 16
-//     adjacent pixels, 48 B apart = 12 banks, which tiles the 64 banks without conflicts), zero-filled outside the image;
-//   * the chunk's weights for all taps, pre-packed on the host in fragment order (a wave's A fragment is 1 KB contiguous).
-// A wave owns 2 UT rows (UT column tiles of 2 rows x 16 pixels) x all 32 MT couts: per tap it reads UT B fragments and MT A
-// fragments (ds_read_b128) for UT*MT MFMAs.
+// Workgroup = 4 CG waves = a tile of (8 UT) rows x 16 columns of one image x (32 MT) couts.  Per 16-channel chunk of the
+// input the workgroup stages into LDS (two stages, one barrier per chunk)
+//   * the input slab: tile + halo, 48-byte pixel stride (16 channels + pad: the lanes of a b128 read group are adjacent
+//     pixels, 48 B = 12 banks apart), zero-filled outside the image -- global -> registers -> LDS;
+//   * the chunk's weights for all taps, pre-packed on the host in fragment order (a wave's A fragment is 1 KB contiguous)
+//     -- global -> LDS directly (LDS-DMA).
+// Wave w owns pixel rows 2 UT (w % 4).. (UT column tiles of 2 rows x 16 pixels) and the couts of A tiles
+// [MT/CG (w / 4), MT/CG (w / 4 + 1)): per tap it reads UT B fragments and MT/CG A fragments (ds_read_b128) for UT MT/CG MFMAs.
+// Instantiated: 128-cout tile with 8 waves (CG = 2, two waves per SIMD) and 16- or 32-row tiles (UT = 2 for 1x1, 4 for 3x3);
+// 64- and 32-cout tiles with 4 waves for the small layers.  DESIGN.md section 8 has the measurements behind each choice.
 #include "common.h"
 
 typedef _Float16 cv_f16x8 __attribute__((ext_vector_type(8)));
