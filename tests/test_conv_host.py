@@ -38,3 +38,27 @@ def test_fused_layers_and_cpu_tensors_are_refused():
     assert torch.equal(layer.bias, torch.cat([a.bias, b.bias]).detach().float())
     with pytest.raises(NerfSlamHipError):      # no CPU fallback
         conv_nhwc([torch.zeros((1, 4, 4, 32), dtype=torch.float16)], layer)
+
+
+def test_update_operator_packs_the_torch_modules_weights():
+    """HipUpdateOperator construction is host work: fused layers carry the right weights, biases and channel padding"""
+    from nerfslam.droid_nets import UpdateModule
+    from nerfslam.update_op import HipUpdateOperator
+    torch.manual_seed(0)
+    um = UpdateModule().eval()
+    op = HipUpdateOperator(um)
+    g = um.gru
+    assert (op.zr.cout, op.zr.cin_padded, op.zr.ksize) == (256, 448, 3) and (op.q.cout, op.q.cin_padded) == (128, 448)
+    assert (op.corr1.cin, op.corr1.cin_padded, op.corr1.ksize) == (196, 208, 1)
+    assert (op.flow1.cin, op.flow1.cin_padded, op.flow1.cout, op.flow1.ksize) == (196, 208, 128, 1)      # 7x7x4 as im2col
+    assert (op.heads.cout, op.delta2.cout, op.weight2.cout, op.eta.cout, op.upmask.cout) == (384, 2, 2, 1, 576)
+    # convz | convr fused along the couts: fragment (c=0, tap 4 = centre, ct, h, i, e) of the second half is convr's weight
+    w = op.zr.w.float()
+    assert w[0, 4, 4, 1, 3, 5].item() == pytest.approx(g.convr.weight[3, 13, 1, 1].half().float().item())
+    assert w[0, 4, 0, 1, 3, 5].item() == pytest.approx(g.convz.weight[3, 13, 1, 1].half().float().item())
+    # the three global-context 1x1 convolutions as one [128, 384] matrix with the gate biases folded in
+    glo = torch.randn((5, 128))
+    ref = torch.cat([g.convz_glo(glo[:, :, None, None])[:, :, 0, 0] + g.convz.bias,
+                     g.convr_glo(glo[:, :, None, None])[:, :, 0, 0] + g.convr.bias,
+                     g.convq_glo(glo[:, :, None, None])[:, :, 0, 0] + g.convq.bias], 1)
+    assert torch.allclose(torch.addmm(op.glo_b, glo, op.glo_w), ref.detach(), atol=1e-5)
