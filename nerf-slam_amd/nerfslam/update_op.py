@@ -35,6 +35,7 @@ class HipUpdateOperator:
         self.glo_b = torch.cat([g.convz_glo.bias + g.convz.bias, g.convr_glo.bias + g.convr.bias,
                                 g.convq_glo.bias + g.convq.bias]).detach().float()
         self.heads = P.from_modules(um.delta[0], um.weight[0], a.conv1)
+        self.delta1 = P(um.delta[0].weight, um.delta[0].bias)            # delta head alone (motion filter: delta_only)
         self.delta2 = P(um.delta[2].weight, um.delta[2].bias)
         self.weight2 = P(um.weight[2].weight, um.weight[2].bias)
         self.agg2 = P(a.conv2.weight, a.conv2.bias)
@@ -50,7 +51,31 @@ class HipUpdateOperator:
         with torch.autocast("cuda", enabled=False):     # dtypes are explicit here; an enclosing autocast would only add casts
             return self._forward(net, inp, corr, flow, ii_host)
 
+    @torch.no_grad()
+    def delta_only(self, net, inp, corr, flow=None):
+        """The motion filter's use of the operator (visual_frontend.py:976-1007: only the flow correction of one edge is
+        looked at): encoders + ConvGRU + delta head.  No host work and no host-device copies, so the call can be captured in
+        a HIP graph (nerfslam.droid_nets.DroidNetworks.motion does).  flow None = zero motion features."""
+        with torch.autocast("cuda", enabled=False):
+            if flow is None:
+                flow = torch.zeros((net.shape[0], 4, net.shape[1], net.shape[2]), dtype=torch.float32, device=net.device)
+            net2 = self._gru(net, inp, corr, flow)
+            return self.delta2([self.delta1([net2], act="relu")]).float()
+
     def _forward(self, net, inp, corr, flow, ii_host):
+        net2 = self._gru(net, inp, corr, flow)
+        # ---- heads ----
+        hd = self.heads([net2], act="relu")                                   # [delta | weight | agg] x 128
+        delta = self.delta2([hd[..., :128]]).float()
+        weight = self.weight2([hd[..., 128:256]], act="sigmoid").float()
+        # ---- GraphAgg: mean over the edges of each source keyframe, conv, eta + upsampling mask ----
+        mean, k = group_mean(hd[..., 256:], ii_host)
+        x2 = self.agg2([mean], act="relu")
+        eta = 0.01 * F.softplus(self.eta([x2]).float())[..., 0]
+        upmask = self.upmask([x2])                                            # channels-last: ns_cvx_upsample_keyframes_nhwc reads it as is
+        return net2, delta, weight, eta, upmask
+
+    def _gru(self, net, inp, corr, flow):
         E, ht, wd, _ = net.shape
         dev = net.device
         # ---- encoders: X = [corr features 128 | flow features 64] ----
@@ -66,13 +91,4 @@ class HipUpdateOperator:
         zrh = self.zr([net, inp, X], act="sigmoid", bias=gb[:, :256].contiguous(), fuse=("mul_hi", net))   # [z | r * net]
         net2 = self.q([zrh[..., 128:], inp, X], act="tanh", bias=gb[:, 256:].contiguous(),
                       fuse=("gru", zrh[..., :128], net))                      # (1 - z) net + z q
-        # ---- heads ----
-        hd = self.heads([net2], act="relu")                                   # [delta | weight | agg] x 128
-        delta = self.delta2([hd[..., :128]]).float()
-        weight = self.weight2([hd[..., 128:256]], act="sigmoid").float()
-        # ---- GraphAgg: mean over the edges of each source keyframe, conv, eta + upsampling mask ----
-        mean, k = group_mean(hd[..., 256:], ii_host)
-        x2 = self.agg2([mean], act="relu")
-        eta = 0.01 * F.softplus(self.eta([x2]).float())[..., 0]
-        upmask = self.upmask([x2])                                            # channels-last: ns_cvx_upsample_keyframes_nhwc reads it as is
-        return net2, delta, weight, eta, upmask
+        return net2

@@ -58,3 +58,22 @@ def test_droid_networks_adapter_uses_the_hip_operator(dev):
         ra = ra[:3] + (ra[3].permute(0, 3, 1, 2),)      # the HIP operator's mask is channels-last
         for x, y, tol in zip(ra, rb, (2e-2, 1e-2, 2e-2, 2e-2)):
             assert x.shape == y.shape and _rel(x, y) < tol, (it, x.shape, _rel(x, y))
+
+
+def test_motion_filter_graph_replay_equals_direct_call(dev):
+    """DroidNetworks.motion (one edge, zero motion features, HIP-graph replay) == the operator called directly, call after call"""
+    from nerfslam.droid_nets import DroidNetworks
+    ht, wd = 24, 32
+    n = DroidNetworks(dev, seed=1, hip_update=True)
+    g = torch.Generator().manual_seed(0)
+    for k in range(2):
+        img = torch.randint(0, 255, (3, 8 * ht, 8 * wd), generator=g, dtype=torch.uint8)
+        n.features(img); n.begin_keyframe(k, img)
+    for it in range(3):
+        corr = torch.randn((1, 1, 196, ht, wd), generator=g).half().to(dev)
+        kf = it % 2
+        d = n.motion(corr, kf)
+        _, ref, _, _, _ = n.update_op(n.ctx_cl[kf][None], n.inp_cl[kf][None], corr[0], torch.zeros((1, 4, ht, wd), device=dev), [0])
+        assert d.shape == (1, 1, ht, wd, 2) and torch.equal(d[0], ref)       # same kernels, same inputs: bit-identical
+    assert len(n._motion_graphs) == 1
+
