@@ -54,8 +54,7 @@ class HipUpdateOperator:
     @torch.no_grad()
     def delta_only(self, net, inp, corr, flow=None):
         """The motion filter's use of the operator (visual_frontend.py:976-1007: only the flow correction of one edge is
-        looked at): encoders + ConvGRU + delta head.  No host work and no host-device copies, so the call can be captured in
-        a HIP graph (nerfslam.droid_nets.DroidNetworks.motion does).  flow None = zero motion features."""
+        looked at): encoders + ConvGRU + delta head, no weight head / GraphAgg, no host work.  flow None = zero motion features."""
         with torch.autocast("cuda", enabled=False):
             if flow is None:
                 flow = torch.zeros((net.shape[0], 4, net.shape[1], net.shape[2]), dtype=torch.float32, device=net.device)
