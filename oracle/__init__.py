@@ -517,10 +517,17 @@ def ba_solve_retract(H, v, world_T_body, cam_T_body, kf0, kf1, prior_pose=None, 
     return delta, wTb, cTw, Hd
 
 
-def ba_covariances(Hfull, E, Q, ii, jj, kf0, kf1, HW):
+def ba_covariances(Hfull, E, Q, ii, jj, kf0, kf1, HW, marginal_form=False):
     """visual_frontend.py:1164-1230 restated (float64): pose marginals = 6x6 diagonal blocks of
     H^-1; z_cov = Q + sum((Q*E^T) @ L^-1)^2 exactly as the reference composes it (:1215-1218, i.e.
-    right-multiplying by L^-1, not L^-T).  Returns (sigma_g[P,6,6], z_cov[K,HW], kx[K])."""
+    right-multiplying by L^-1, not L^-T).  Returns (sigma_g[P,6,6], z_cov[K,HW], kx[K]).
+
+    PIN (tests/test_oracle_pins.py::test_covariance_block_*): with `marginal_form=True` the ONE operand
+    `L^-1` of :1215 is replaced by `L^-T`; z_cov is then the diagonal of the depth block of the inverse
+    of the full (pose + depth) normal equations -- an identity that is checked in float64 against a
+    system assembled independently from K1's raw per-edge blocks and that pins everything else in this
+    function (the E scatter with fixed frames :1204-1211, the Ei diagonal :1211, the Q scaling, the
+    index bookkeeping).  The reference's own form (default) differs from it by exactly that transposition."""
     P = kf1 - kf0
     ii = np.asarray(ii)
     jj = np.asarray(jj)
@@ -542,6 +549,6 @@ def ba_covariances(Hfull, E, Q, ii, jj, kf0, kf1, HW):
         Ej[p, kf0 - mn + p] = E[p]
     Es = Ej.transpose(0, 2, 1, 3).reshape(P * 6, K * HW)
     Q_ = np.asarray(Q, np.float64).reshape(K * HW, 1)
-    F = (Q_ * Es.T) @ Linv
+    F = (Q_ * Es.T) @ (Linv.T if marginal_form else Linv)
     z = Q_[:, 0] + (F ** 2).sum(-1)
     return sigma_g, z.reshape(K, HW), kx

@@ -215,3 +215,63 @@ def test_cvx_upsample_matches_reference_function(oracle_mod):
     assert np.abs(up - z["up"]).max() <= 2e-6
     up2 = oracle_mod.cvx_upsample(z["data"], z["mask"], 0.5)
     assert np.abs(up2 - z["up_pow05"]).max() <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# (c) covariance block (visual_frontend.py:1164-1230): identity pin of oracle.ba_covariances
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [dict(P=3, M=6, kf0=0, extra_fixed=0), dict(P=3, M=20, kf0=2, extra_fixed=2)])
+def test_covariance_block_equals_full_inverse(oracle_mod, cfg):
+    """The full normal equations [[A, X],[X^T, C]] over (window poses, every depth map with outgoing edges) are
+    assembled here from K1's raw per-edge blocks in float64 and inverted: the pose block of the inverse must equal
+    sigma_g, the diagonal of its depth block must equal z_cov of oracle.ba_covariances(marginal_form=True).  The
+    reference's own composition (:1215 multiplies by L^-1 where the marginal needs L^-T) is the same code with that
+    one operand transposed; the two forms are checked to differ (so the switch is live) and to share the Q term."""
+    p = synth.make_problem(ht=4, wd=5, seed=21, **cfg)
+    kf0, kf1, HW, P = p["kf0"], p["kf1"], p["HW"], cfg["P"]
+    k1 = oracle_mod.projective_transform(p["targets"], p["weights"], p["poses"], p["disps"], p["intr"], p["extr"],
+                                         p["ii"], p["jj"])
+    H, v, Q, E, w, kx = oracle_mod.reduced_camera_matrix(p["poses"], p["disps"], p["intr"], p["extr"], p["disps_sens"],
+                                                         p["targets"], p["weights"], p["eta"], p["ii"], p["jj"], kf0, kf1)
+    K = len(kx)
+    kk = np.searchsorted(kx, p["ii"])
+    n = 6 * P
+    A = np.zeros((n, n)); X = np.zeros((n, K * HW)); Cd = np.zeros(K * HW)
+    for e in range(len(p["ii"])):
+        i, j, k = int(p["ii"][e]) - kf0, int(p["jj"][e]) - kf0, kk[e]
+        for (r, c, blk) in ((i, i, 0), (i, j, 1), (j, i, 2), (j, j, 3)):
+            if 0 <= r < P and 0 <= c < P:
+                A[6 * r:6 * r + 6, 6 * c:6 * c + 6] += k1["Hs"][blk, e]
+        if 0 <= i < P:
+            X[6 * i:6 * i + 6, k * HW:(k + 1) * HW] += k1["Eiz"][e]
+        if 0 <= j < P:
+            X[6 * j:6 * j + 6, k * HW:(k + 1) * HW] += k1["Ejz"][e]
+        Cd[k * HW:(k + 1) * HW] += k1["Cii"][e]
+    Cd += p["eta"].reshape(-1)[:K * HW].astype(np.float64)
+    lam = 1e-2 * np.abs(np.diag(A)).max()                    # gauge fixing (the frontend's prior plays this role)
+    A += lam * np.eye(n)
+    full = np.block([[A, X], [X.T, np.diag(Cd)]])
+    inv = np.linalg.inv(full)
+    Hred = H.astype(np.float64) + lam * np.eye(n)
+    assert np.abs(Hred - (A - (X / Cd) @ X.T)).max() <= 2e-4 * np.abs(Hred).max()       # same system
+    sig, z, kx2 = oracle_mod.ba_covariances(Hred, E, Q, p["ii"], p["jj"], kf0, kf1, HW, marginal_form=True)
+    np.testing.assert_array_equal(kx2, kx)
+    want_sig = np.stack([inv[6 * i:6 * i + 6, 6 * i:6 * i + 6] for i in range(P)])
+    assert np.abs(sig - want_sig).max() <= 2e-3 * np.abs(want_sig).max()
+    want_z = np.diag(inv)[n:].reshape(K, HW)
+    assert np.abs(z - want_z).max() <= 2e-3 * np.abs(want_z).max(), np.abs(z / want_z - 1).max()
+    # the reference's form: same Q term, different (L^-1 instead of L^-T) correction
+    sig_r, z_r, _ = oracle_mod.ba_covariances(Hred, E, Q, p["ii"], p["jj"], kf0, kf1, HW)
+    np.testing.assert_array_equal(sig_r, sig)
+    assert (z_r >= Q - 1e-12).all() and np.abs(z_r - z).max() > 1e-6 * np.abs(z).max()
+    L = np.linalg.cholesky(Hred.astype(np.float32).astype(np.float64))
+    Es = np.zeros((n, K * HW))                               # E of the reduced system laid out like X (independent scatter)
+    for pi in range(P):
+        Es[6 * pi:6 * pi + 6, np.searchsorted(kx, kf0 + pi) * HW:][:, :HW] += E[pi]
+    for e in range(len(p["ii"])):
+        j = int(p["jj"][e]) - kf0
+        if 0 <= j < P:
+            Es[6 * j:6 * j + 6, kk[e] * HW:(kk[e] + 1) * HW] += E[P + e]
+    assert np.abs(Es - X).max() <= 1e-5 * np.abs(X).max()
+    Fr = (Es.T * Q.reshape(-1, 1).astype(np.float64)) @ np.linalg.inv(L)
+    assert np.abs(z_r.reshape(-1) - (Q.reshape(-1) + (Fr ** 2).sum(-1))).max() <= 1e-9 * np.abs(z_r).max()
