@@ -18,8 +18,13 @@ _lock = threading.Lock()
 _lib = None
 
 
+NS_OK, NS_EINVAL, NS_ELAUNCH, NS_ENOSUP = 0, -1, -2, -3   # status codes of include/nerfslam_hip.h
+
+
 class NerfSlamHipError(RuntimeError):
-    pass
+    def __init__(self, msg, status=None):
+        super().__init__(msg)
+        self.status = status
 
 
 def lib():
@@ -44,7 +49,7 @@ def lib():
 def check(status, what):
     if status != 0:
         msg = lib().ns_last_error().decode("utf-8", "replace")
-        raise NerfSlamHipError(f"{what} failed ({status}): {msg}")
+        raise NerfSlamHipError(f"{what} failed ({status}): {msg}", status)
 
 
 def ptr(t):

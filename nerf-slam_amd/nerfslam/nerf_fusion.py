@@ -37,7 +37,10 @@ class NerfFusion:
         self.fit_volume_once()
 
     def process_slam(self, packet):
-        """:140-235.  Returns False after ingesting (the reference then skips training on this spin)."""
+        """:140-235.  Returns False after ingesting (the reference then skips training on this spin).
+        Intentional difference: the reference drops the packet flagged `is_last_frame` (:143-147) although it carries the
+        poses / depths refined by the final global BA; here it is ingested like any other (the mapper ends on the
+        globally optimised trajectory)."""
         if packet is None or "cam0_poses" not in packet:
             return True
         dev = self.device
@@ -53,7 +56,12 @@ class NerfFusion:
         elif self.mask_type == "no_depth":
             idepths_up = -torch.ones_like(idepths_up)
         elif self.mask_type == "ours_w_thresh":
-            idepths_up = torch.where(depths_cov_up.sqrt() > 1.0, -torch.ones_like(idepths_up), idepths_up)
+            # :177-179: threshold = depths_cov_up.quantile(0.50) (linear interpolation between the two middle order
+            # statistics; computed from a sort because torch.quantile refuses more than 2^24 elements)
+            flat = depths_cov_up.flatten().float().sort().values
+            m = flat.numel()
+            thr = 0.5 * (flat[(m - 1) // 2] + flat[m // 2])
+            idepths_up = torch.where(depths_cov_up.sqrt() > thr, -torch.ones_like(idepths_up), idepths_up)
         c2w = se3.matrix(se3.inv(poses.float()))[:, :3, :4].contiguous()  # :198-203 (inverse of cam_T_world)
         rgb = srgb_to_linear(images.float().permute(0, 2, 3, 1) / 255.0)
         rgba = torch.cat([rgb, torch.ones((n, H, W, 1), device=dev)], -1).contiguous()   # alpha 1: premultiplied == rgb

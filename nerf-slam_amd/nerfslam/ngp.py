@@ -272,6 +272,8 @@ class NgpNerf:
                 self._camera_backward(pos_unit, dfeatT, d, ray_img, N8, R)
             if self.world > 1:
                 self._allreduce_gradients()
+            if c.optimize_extrinsics:
+                self._camera_step()     # after the all-reduce: every replica applies the SAME pose update
             # optimiser
             self.step += 1
             for (m, hp, g, m1, m2, l2, fx) in (
@@ -293,23 +295,43 @@ class NgpNerf:
         g = self.grid_grad.view(torch.int64) if self.cfg.grad_fixed_scale > 0 else self.grid_grad
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
         dist.all_reduce(self.mlp_grad, op=dist.ReduceOp.SUM, group=self.group)
+        if self.cfg.optimize_extrinsics and getattr(self, "cam_grad", None) is not None:
+            dist.all_reduce(self.cam_grad, op=dist.ReduceOp.SUM, group=self.group)   # 24 B per training view
+        self.bytes_allreduced = getattr(self, "bytes_allreduced", 0) + g.numel() * g.element_size() + self.mlp_grad.numel() * 4
 
     def _camera_backward(self, pos_unit, dfeatT, rays_d, ray_img, N, R):
         """pose refinement: sample-position gradients through the encoding -> per-image 6-dof gradient -> Adam on c2w"""
         c, dev = self.cfg, self.device
         n = self.n_images
-        if getattr(self, "cam_grad", None) is None or self.cam_grad.shape[0] != n:
-            f = dict(dtype=torch.float32, device=dev)
-            self.cam_grad, self.cam_m1, self.cam_m2 = torch.zeros((n, 6), **f), torch.zeros((n, 6), **f), torch.zeros((n, 6), **f)
+        self._grow_camera_state(n)
         dpos = torch.empty((N, 3), dtype=torch.float32, device=dev)
         check(lib().ns_ngp_encode_backward_input(*self._grid_args(), ptr(pos_unit), ptr(self.grid_half), ptr(dfeatT), ptr(dpos),
                                                  C.c_long(N), stream_ptr()), "ngp_encode_backward_input")
         check(lib().ns_ngp_camera_gradient(ptr(dpos), ptr(self.s_t), ptr(rays_d), ptr(self.ray_start), ptr(self.ray_n),
                                            ptr(ray_img), C.c_float(1.0 / float(c.aabb_scale)), ptr(self.cam_grad), R,
                                            stream_ptr()), "ngp_camera_gradient")
+
+    def _grow_camera_state(self, n):
+        """per-view Adam moments of the pose refinement: GROWN when keyframes are added (a reset would restart the bias
+        correction of every existing view each time the tracker sends a keyframe)"""
+        f = dict(dtype=torch.float32, device=self.device)
+        if getattr(self, "cam_grad", None) is None:
+            self.cam_grad, self.cam_m1, self.cam_m2 = torch.zeros((n, 6), **f), torch.zeros((n, 6), **f), torch.zeros((n, 6), **f)
+        elif self.cam_grad.shape[0] < n:
+            k = n - self.cam_grad.shape[0]
+            self.cam_grad = torch.cat([self.cam_grad, torch.zeros((k, 6), **f)])
+            self.cam_m1 = torch.cat([self.cam_m1, torch.zeros((k, 6), **f)])
+            self.cam_m2 = torch.cat([self.cam_m2, torch.zeros((k, 6), **f)])
+        elif self.cam_grad.shape[0] > n:
+            self.cam_grad, self.cam_m1, self.cam_m2 = self.cam_grad[:n].contiguous(), self.cam_m1[:n].contiguous(), self.cam_m2[:n].contiguous()
+
+    def _camera_step(self):
+        """Adam + Rodrigues retraction of every training view's c2w from cam_grad (summed over the replicas when world > 1:
+        the gradient scale loss_scale * world makes it the mean, like the model gradients)"""
+        c, n = self.cfg, self.n_images
         check(lib().ns_ngp_camera_step(ptr(self.c2w), ptr(self.cam_grad), ptr(self.cam_m1), ptr(self.cam_m2), n, self.step + 1,
                                        C.c_float(c.extrinsic_lr_pos), C.c_float(c.extrinsic_lr_rot), C.c_float(c.beta1),
-                                       C.c_float(c.beta2), C.c_float(c.eps), C.c_float(c.loss_scale), stream_ptr()),
+                                       C.c_float(c.beta2), C.c_float(c.eps), C.c_float(c.loss_scale * self.world), stream_ptr()),
               "ngp_camera_step")
 
     # ------------------------------------------------------------------------------------------

@@ -70,11 +70,18 @@ class ShardedBA:
         self.ii = torch.from_numpy(ii_host[self.mine]).to(device)
         self.jj = torch.from_numpy(jj_host[self.mine]).to(device)
         self._sel = torch.from_numpy(self.mine).to(device)
+        own = np.unique(ii_host[self.mine])
+        if self.rank == 0:
+            own = np.union1d(own, np.setdiff1d(np.arange(kf0, kf1), np.unique(ii_host)))
+        self._owned = own
+        self._kx_all_d = torch.from_numpy(self.kx_all).to(device)
+        self._own_mask = torch.from_numpy(np.isin(self.kx_all, own).astype(np.float32)).to(device)[:, None, None]
 
     def iteration(self, poses, disps, intrinsics, extrinsics, disps_sens, targets, weights, eta, world_T_body,
-                  prior_pose=None, clamp_min=0.001, reduce=True):
+                  prior_pose=None, clamp_min=0.001, reduce=True, sync_depths=True):
         """targets / weights [M,2,ht,wd] and eta [K',HW] are the GLOBAL tensors (replicated inputs); poses / disps are
-        updated in place: poses identically on every rank, disps only for the depth maps this rank owns."""
+        updated in place, identically on every rank (sync_depths=False: disps only for the maps this rank owns, the
+        others keep their previous values)."""
         from . import ba_plan
         H, v, Q, E, w = ba_plan.reduced_camera_matrix(self.plan, poses, disps, intrinsics, extrinsics, disps_sens,
                                                       targets[self._sel].contiguous(), weights[self._sel].contiguous(),
@@ -82,9 +89,19 @@ class ShardedBA:
         if reduce and self.world > 1:
             allreduce_reduced_system(H, v, self.group)
         sol = ba_plan.ba_solve(H, v, self.kf0, self.kf1, world_T_body, poses, extrinsics, prior_pose=prior_pose)
+        # depth back-substitution: the plan carries every window frame, but only the maps this rank OWNS see all of their
+        # edges here -- on the others Q / w hold the damping / sensed-depth prior alone and the update would be wrong
+        # (ADVICE r01).  Update a copy, keep the owned rows' change, and sum the changes over the ranks: every map is
+        # owned by exactly one rank, so the sum IS the exchange (one all-reduce of |kx_all| maps).
+        before = disps[self._kx_all_d]
         ba_plan.solve_depth(self.plan, sol["dx"], disps, Q, E, w, clamp_min=clamp_min)
+        dz = (disps[self._kx_all_d] - before) * self._own_mask
+        if sync_depths and self.world > 1:
+            dist.all_reduce(dz, op=dist.ReduceOp.SUM, group=self.group)
+        disps[self._kx_all_d] = before + dz
         return sol
 
     def owned_depth_maps(self):
-        """depth maps whose update on this rank is the real one (sources of this rank's edges)"""
-        return np.unique(self.plan.ii_host)
+        """depth maps whose update on this rank is the real one: the sources of this rank's edges, plus (rank 0) the
+        window frames that are nobody's source (their update is the prior-only one on every rank)"""
+        return self._owned

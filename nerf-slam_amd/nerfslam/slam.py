@@ -59,7 +59,7 @@ class TrackingSLAM:
         depth = data.get("depth")
         if depth is not None:   # EXTENSION: the reference allocates cam0_idepths_sensed (:190) but never fills it (monocular
                                 # only); a dataset that carries depth seeds the sensed-depth prior of the BA here
-            d = torch.as_tensor(depth, dtype=torch.float32, device=self.device)[3::8, 3::8]
+            d = torch.as_tensor(depth, dtype=torch.float32, device=self.device)[3::8, 3::8] * float(data.get("depth_scale", 1.0))
             fe.cam0_idepths_sensed[fe.kf_idx] = torch.where(d > 0, 1.0 / d, torch.zeros_like(d))
         self.kf_to_frame[fe.kf_idx] = k
 
@@ -76,7 +76,10 @@ class TrackingSLAM:
     def _frontend(self, data):
         k = int(data["k"][0])
         img = torch.as_tensor(data["images"][0], device=self.device)[..., :3].permute(2, 0, 1).contiguous()
-        data = dict(data, image_u8=img, depth=(data.get("depths") or [None])[0])
+        depths = data.get("depths")
+        calib0 = data["calibs"][0] if "calibs" in data else None
+        data = dict(data, image_u8=img, depth=depths[0] if depths is not None and len(depths) > 0 else None,
+                    depth_scale=float(getattr(calib0, "depth_scale", 1.0) or 1.0))     # vio_slam.py: gt_depths * calib.depth_scale
         last_frame = bool(data.get("is_last_frame", False))
         if self.fe is None:
             assert k == 0

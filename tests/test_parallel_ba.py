@@ -113,3 +113,28 @@ def test_hip_shards_sum_to_the_full_system_and_update(dev, world):
         d_sh[own] = d_r[own]
     touched = torch.from_numpy(np.unique(ii)).to(dev)
     assert (d_sh[touched] - d_full[touched]).abs().max().item() <= 1e-5 * d_full.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_sharded_iteration_touches_only_owned_depth_maps(dev):
+    """ShardedBA.iteration: a rank changes only the depth maps it owns; the ownership sets of the ranks
+    partition the depth rows of the problem, so the summed change is the exchange."""
+    from nerfslam.parallel import ShardedBA
+    pr, ii, jj = _problem()
+    kf0, kf1 = 3, 9
+    targets, weights, eta, kx = _inputs(pr, ii, jj, kf0, kf1)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    owned = []
+    for r in range(2):
+        poses, disps, intr, extr, sens = (t(pr[k]) for k in ("poses", "disps", "intr", "extr", "disps_sens"))
+        sh = ShardedBA(ii, jj, kf0, kf1, dev, rank=r, world=2)
+        before = disps.clone()
+        sol = sh.iteration(poses, disps, intr, extr, sens, t(targets), t(weights), t(eta), poses.clone(), reduce=False,
+                           sync_depths=False)
+        assert sol["info"].item() == 0
+        changed = torch.nonzero((disps != before).flatten(1).any(1)).flatten().cpu().numpy()
+        assert set(changed.tolist()) <= set(sh.owned_depth_maps().tolist())
+        assert len(changed) > 0
+        owned.append(sh.owned_depth_maps())
+    assert len(np.intersect1d(owned[0], owned[1])) == 0
+    assert np.array_equal(np.union1d(owned[0], owned[1]), kx)
