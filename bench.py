@@ -1,337 +1,252 @@
 #!/usr/bin/env python3
-"""bench.py -- tracked frames/s of the NeRF-SLAM tracking hot path on MI355X (BASELINE.json configs[1]).
+"""bench.py -- tracked+mapped frames/s of the PRODUCT pipeline on MI355X (BASELINE.json metric, configs[2] at N=1,
+configs[3] at N>1).
 
-One "step" = the hot-path work of ONE input frame that is accepted as a keyframe of a 640x480
-stream (1/8 grid 80x60), with every input already resident in HBM:
+One "step" = ONE input frame of a synthetic 640x480 RGB stream pushed through the product objects exactly as
+examples/slam_demo.py wires them (reference examples/slam_demo.py:62-190): DataModule -> SlamModule("VioSLAM" =
+nerfslam.slam.TrackingSLAM + TrackingFrontend + DroidNetworks) -> FusionModule("nerf" = NerfFusion + pyngp.Testbed):
 
-  motion filter      1-edge correlation pyramid build + one 4-level lookup
-  proximity factors  2 x frame_distance over 125 pairs + 2 x 1 pair
-  new edges          correlation pyramid build for 10 new edges
-  6 x update()       reprojection + motion features of the 48 active edges, their 4-level lookup, then BA itrs=2:
-                       2 x [reduced camera matrix (M=96 edges, P=10 poses, K'=13 depth maps),
-                            device Cholesky solve + pose retraction, depth back-substitution]
-                     the depth/pose covariance block, and the convex 8x upsampling of the updated
-                     keyframes' inverse depths and depth covariances (one paired launch)
+  every frame      feature encoder, motion filter (1-edge correlation pyramid + lookup + update-operator pass)
+  keyframe         context encoder, proximity factors, correlation pyramids of the new edges, iters1=4 updates, keyframe
+  candidates       distance test (reject -> rm_keyframe), iters2=2 updates; an update = reprojection + motion features +
+                   4-level lookup + update operator (ConvGRU, heads, GraphAgg) + 2 dense-BA iterations + covariances +
+                   convex upsampling (visual_frontend.py:240-470, 577-638)
+  mapper           per frame one FusionModule spin (fusion_module.py:34-45): a frame that produced a SLAM packet ingests
+                   the dirty keyframes (nerf_fusion.py:140-235), any other frame trains (`frame()` = 16 optimiser steps,
+                   nerf_fusion.py:249-253, 298-307)
 
-The conv nets of the reference (encoders, ConvGRU) are outside SURVEY.md 8's hot-path rows
-("next" row 2) and are NOT part of the step; `config.workload` says so.  Counting every frame as a
-keyframe is the conservative reading of "frames/s tracked" (non-keyframes only run the motion filter).
+all inside ONE timed region; `value` = frames consumed per wall-second of that loop.  The keyframe ratio is whatever the
+product's motion filter / keyframe test decide on the stream (reported in `config`).  Inputs (the uint8 frames) are
+resident in HBM before the timed region.  The DROID checkpoint is not available (no network): the conv nets run with
+random-init weights at the real shapes and their flow corrections are replaced AFTER they ran by the ones the synthetic
+scene induces (tools/synth_stream.py explains why; nothing is skipped).
 
-Usage:  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run,
-        one rank per GPU; ranks run independent streams -- the tracker does not shard)
+N = 1: tracker and mapper share the GPU, run sequentially per frame (the reference without --parallel_run).
+N > 1 (torch.distributed.run, one rank per GPU): the reference's --multi_gpu split (examples/slam_demo.py:63-77) on N GPUs:
+  rank 0 tracks and broadcasts every packet over RCCL to ranks 1..N-1, which are REPLICATED free-running NeRF trainers
+  (same images, own rays, gradients all-reduced in their sub-group); `value` = tracked frames/s with the
+  mappers training concurrently; NeRF optimiser steps/s and bytes moved over RCCL are reported next to it.
+
+Also reported: `roofline` (dominant hand-written kernel of the timed region, launch time from HIP events around
+back-to-back launches), `cpu_baseline` (the oracle on a bounded sample, rank 0, N=1), `extra.hot_path_chain` (round 1's
+kernel-chain figure).
 """
 import argparse
 import json
 import os
 import sys
 import time
+from queue import Queue
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "nerf-slam_amd")):
+for p in (ROOT, os.path.join(ROOT, "nerf-slam_amd"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
 import numpy as np
 import torch
 
-HT, WD, CH = 60, 80, 128
-HW = HT * WD
-NBUF = 16
-E_ACTIVE, E_INACTIVE, E_NEW = 48, 48, 10
-KF0, KF1 = 6, 16
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TILED = os.environ.get("NS_BENCH_ROWMAJOR") is None  # volumes in the 8x8-tiled layout (the frontend's); set to compare
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak
 
 
-def quat_exp(w):
-    th = np.linalg.norm(w)
-    return np.concatenate([np.sin(th / 2) * w / max(th, 1e-12), [np.cos(th / 2)]])
-
-
-def make_graph(rng):
-    """48 active edges among frames [6,16), 48 inactive edges among frames [3,16) (both ends >= kf0-3,
-    visual_frontend.py:420-424); no duplicates, no self loops."""
-    def pick(lo, hi, n, seen):
-        es = []
-        for i in range(lo, hi):
-            for j in range(max(lo, i - 2), min(hi, i + 3)):
-                if i != j and (i, j) not in seen and len(es) < n:
-                    es.append((i, j)); seen.add((i, j))
-        while len(es) < n:
-            i, j = (int(x) for x in rng.integers(lo, hi, 2))
-            if i != j and (i, j) not in seen:
-                es.append((i, j)); seen.add((i, j))
-        return es
-    seen = set()
-    act = pick(KF0, KF1, E_ACTIVE, seen)
-    ina = pick(KF0 - 3, KF1, E_INACTIVE, seen)
-    allv = ina + act  # torch.cat([inactive, active]) (visual_frontend.py:421-422)
-    ii = np.array([e[0] for e in allv], np.int64)
-    jj = np.array([e[1] for e in allv], np.int64)
-    return ii, jj
-
-
-class HotPath:
-    def __init__(self, dev, seed=0):
-        from nerfslam import ba_plan
-        from nerfslam.corr import CorrBlock
+# =================================================================================================
+# the product pipeline
+# =================================================================================================
+class Pipeline:
+    def __init__(self, dev, n_frames, buffer, fusion=True, on_packet=None, trainer_group=None):
+        from nerfslam.pipeline import DataModule, FusionModule, SlamModule
+        from synth_stream import RoomStream, grounded_networks
         self.dev = dev
-        rng = np.random.default_rng(seed)
-        g = torch.Generator(device="cpu").manual_seed(seed)
-        poses = np.zeros((NBUF, 7), np.float32)
-        for k in range(NBUF):
-            poses[k, :3] = rng.normal(0, 0.05, 3)
-            poses[k, 3:] = quat_exp(rng.normal(0, 0.02, 3))
-        self.cTw0 = torch.from_numpy(poses).to(dev)
-        from nerfslam import se3
-        self.wTb0 = se3.inv(self.cTw0.double()).float().contiguous()
-        self.disps0 = torch.empty((NBUF, HT, WD)).uniform_(0.2, 2.0, generator=g).to(dev)
-        self.cTw, self.wTb, self.disps = self.cTw0.clone(), self.wTb0.clone(), self.disps0.clone()
-        self.disps_sens = torch.zeros_like(self.disps)
-        W = WD * 8.0
-        self.intr = (torch.tensor([0.5 * W, 0.5 * W, (W - 1) / 2, (HT * 8.0 - 1) / 2]) / 8.0).to(dev)
-        self.extr = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).to(dev)
-        self.fmaps = torch.randn((NBUF, CH, HT, WD), generator=g).half().to(dev)
-        ii, jj = make_graph(rng)
-        self.ii_h, self.jj_h = ii, jj
-        self.ii, self.jj = torch.from_numpy(ii).to(dev), torch.from_numpy(jj).to(dev)
-        self.M = ii.shape[0]
-        self.plan = ba_plan.BaPlan(ii, jj, KF0, KF1, dev)
-        self.K = self.plan.K
-        # targets = reprojection + noise, weights ~ U(0,1), damping as visual_frontend.py:428
-        c, _ = self._reproject(self.ii, self.jj)
-        self.targets = (c + 0.5 * torch.randn(c.shape, generator=g).to(dev)).contiguous()
-        self.weights = torch.rand((self.M, 2, HT, WD), generator=g).to(dev)
-        self.eta = (0.2 * torch.empty((self.K, HT, WD)).uniform_(1e-4, 2e-2, generator=g) + 1e-7).to(dev)
-        # persistent 48-edge pyramid, coordinates of the active edges in the frontend's layout
-        ai, aj = self.ii[E_INACTIVE:], self.jj[E_INACTIVE:]
-        # feature bank as the frontend keeps it (nerfslam/frontend.py:set_keyframe): channels-last f16, pre-divided by 4
-        self.feat_bank = (self.fmaps.reshape(NBUF, CH, HW) / 4.0).transpose(1, 2).contiguous()
-        self.corr48 = CorrBlock.from_pyramid(CorrBlock.build_pyramid(self.feat_bank, self.feat_bank, ai.contiguous(), aj.contiguous(),
-                                                                     E_ACTIVE, HT, WD, tiled=TILED), tiled=TILED, hw=(HT, WD))
-        gy, gx = torch.meshgrid(torch.arange(HT), torch.arange(WD), indexing="ij")
-        grid = torch.stack([gx, gy], -1).float()
-        self.coords48 = (grid[None, None] + torch.empty((1, E_ACTIVE, HT, WD, 2)).uniform_(-8, 8, generator=g)).to(dev)
-        self.coords1 = self.coords48[:, :1].contiguous()
-        self.new_i = torch.from_numpy(rng.integers(KF0, KF1, E_NEW)).to(dev)
-        self.new_j = torch.from_numpy(rng.integers(KF0, KF1, E_NEW)).to(dev)
-        pi, pj = np.meshgrid(np.arange(KF1 - 5, KF1), np.arange(0, KF1 + 9)[:25] % KF1, indexing="ij")
-        self.fd_i = torch.from_numpy(pi.reshape(-1).astype(np.int64)).to(dev)
-        self.fd_j = torch.from_numpy(pj.reshape(-1).astype(np.int64)).to(dev)
-        self.fd1_i = torch.tensor([KF1 - 3], device=dev)
-        # update-operator glue of every update() (visual_frontend.py:379-386, 445-446, 909-918): reprojection of the active
-        # edges, motion features, convex upsampling of the updated keyframes' inverse depths and depth covariances
-        self.ai, self.aj = ai.contiguous(), aj.contiguous()
-        self.kx = torch.unique(self.ai)
-        self.target_a = self.targets[E_INACTIVE:].permute(0, 2, 3, 1).contiguous()   # the frontend's [E,ht,wd,2]
-        self.coords_a = torch.empty((E_ACTIVE, HT, WD, 2), device=dev)
-        self.motion = torch.empty((E_ACTIVE, 4, HT, WD), device=dev)
-        self.upmask = torch.randn((self.kx.shape[0], HT, WD, 576), generator=g).half().to(dev)  # the mask head's f16 logits, channels-last as nerfslam.update_op writes them
-        self.depth_cov = torch.rand((NBUF, HT, WD), generator=g).to(dev)
-        self.disps_up = torch.zeros((NBUF, 8 * HT, 8 * WD), device=dev)
-        self.depth_cov_up = torch.zeros((NBUF, 8 * HT, 8 * WD), device=dev)
-        self.fd1_j = torch.tensor([KF1 - 2], device=dev)
-        self.CorrBlock, self.ba_plan = CorrBlock, ba_plan
-        self.ev = None  # optional per-op event recorder
+        self.stream = RoomStream(n_frames, device=dev, flow_px=0.45)
+        self.images = [self.stream.image(i) for i in range(n_frames)]      # resident in HBM
+        self.depth0 = self.stream.depth(0)
+        self.nets = grounded_networks(self.stream, dev, buffer)
+        args = argparse.Namespace(buffer=buffer, networks=self.nets, slam=True, global_ba=False, parallel_run=False,
+                                  mask_type="ours", stop_iters=10 ** 9, network="", trainer_group=trainer_group)
+        self.data_q, self.slam_q = Queue(), Queue()
+        self.data = DataModule("synthetic-room", args, dataset=(self._packet(i) for i in range(n_frames)))
+        self.data.register_output_queue(self.data_q)
+        self.slam = SlamModule("VioSLAM", args, device=str(dev))
+        self.slam.register_input_queue("data", self.data_q)
+        self.fusion = None
+        if fusion:
+            self.fusion = FusionModule("nerf", args, device=str(dev))
+            self.slam.register_output_queue(self.slam_q)
+            self.fusion.register_input_queue("slam", self.slam_q)
+            self.fusion.initialize_module()
+        if on_packet is not None:
+            self.slam.register_output_callback(on_packet)
+        self.slam.initialize_module()
+        self.k = 0
+        self.leg_ms = None     # set to a dict to attribute time per leg (adds a device sync after every leg)
 
-    def _reproject(self, ii, jj):
-        """targets for the synthetic problem (float64 torch, setup only)."""
-        from nerfslam import se3
-        gy, gx = torch.meshgrid(torch.arange(HT, device=self.dev), torch.arange(WD, device=self.dev), indexing="ij")
-        fx, fy, cx, cy = self.intr.double()
-        X = torch.stack([(gx - cx) / fx, (gy - cy) / fy, torch.ones_like(gx, dtype=torch.float64),
-                         torch.zeros_like(gx, dtype=torch.float64)], -1)[None].repeat(ii.shape[0], 1, 1, 1)
-        X[..., 3] = self.disps[ii].double()
-        G = se3.mul(self.cTw[jj].double(), se3.inv(self.cTw[ii].double()))
-        Y = se3.act(G[:, None, None], X)
-        z = Y[..., 2].clamp(min=0.25)
-        c = torch.stack([fx * Y[..., 0] / z + cx, fy * Y[..., 1] / z + cy], 1)
-        return c.float(), z
+    def _packet(self, i):
+        p = self.stream.packet(i, image=self.images[i])
+        return p
 
-    # ---- the ops of one step -------------------------------------------------------------------
-    def _t(self, name, fn):
-        if self.ev is None:
+    @property
+    def tracker(self):
+        return self.slam.slam
+
+    def _leg(self, name, fn):
+        if self.leg_ms is None:
             return fn()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         r = fn()
-        e.record()
-        self.ev.setdefault(name, []).append((s, e))
+        torch.cuda.synchronize()
+        self.leg_ms[name] = self.leg_ms.get(name, 0.0) + 1e3 * (time.perf_counter() - t0)
         return r
 
-    def op_build(self, i, j):
-        """correlation pyramids of new edges straight from the feature bank (frontend.py:add_factors)"""
-        pyr = self.CorrBlock.build_pyramid(self.feat_bank, self.feat_bank, i, j, i.shape[0], HT, WD, tiled=TILED)
-        return self.CorrBlock.from_pyramid(pyr, tiled=TILED, hw=(HT, WD))
+    def frame(self):
+        """one input frame through data -> slam -> fusion (examples/slam_demo.py:186-190, sequential wiring)"""
+        self.nets.frame = self.k
+        self.data.spin()
+        self._leg("tracking", self.slam.spin)
+        if self.nets.fe is None:
+            self.nets.fe = self.tracker.fe
+        if self.fusion is not None:
+            item = self.slam_q.queue[0] if self.slam_q.qsize() else None
+            got_packet = bool(item and item[1] and "cam0_poses" in item[1])
+            self._leg("mapping_ingest" if got_packet else "mapping_train", self.fusion.spin)
+        self.k += 1
 
-    def op_set_keyframe(self, k):
-        """the incoming frame's features enter the bank (frontend.py:set_keyframe)"""
-        self.feat_bank[k] = (self.fmaps[k].reshape(CH, HW) / 4.0).t()
-
-    def op_lookup48(self):
-        return self.corr48(self.coords48)
-
-    def op_update_glue_pre(self):
-        from nerfslam._lib import check, lib, ptr, stream_ptr
-        L = lib()
-        check(L.ns_reproject(ptr(self.cTw), ptr(self.disps), ptr(self.intr), ptr(self.ai), ptr(self.aj), ptr(self.coords_a),
-                             None, E_ACTIVE, HT, WD, stream_ptr()), "reproject")
-        check(L.ns_motion_features(ptr(self.coords_a), ptr(self.target_a), ptr(self.motion), E_ACTIVE, HT, WD,
-                                   stream_ptr()), "motion_features")
-
-    def op_upsample(self):
-        import ctypes as C
-        from nerfslam._lib import check, lib, ptr, stream_ptr
-        check(lib().ns_cvx_upsample_keyframes_nhwc(ptr(self.disps), ptr(self.depth_cov), ptr(self.kx), ptr(self.upmask),
-                                                   ptr(self.disps_up), ptr(self.depth_cov_up), self.kx.shape[0], HT, WD,
-                                                   C.c_float(1.0), stream_ptr()), "cvx_upsample_keyframes_nhwc")
-
-    def op_ba_iteration(self, want_cov):
-        import droid_backends
-        bp = self.ba_plan
-        H, v, Q, E, w = self._t("rcm", lambda: bp.reduced_camera_matrix(
-            self.plan, self.cTw, self.disps, self.intr, self.extr, self.disps_sens, self.targets, self.weights,
-            self.eta, self.ii, self.jj))
-        sol = self._t("solve", lambda: bp.ba_solve(H, v, KF0, KF1, self.wTb, self.cTw, self.extr,
-                                                   prior_pose=None, want_cov=want_cov))
-        self._t("depth", lambda: bp.solve_depth(self.plan, sol["dx"], self.disps, Q, E, w, clamp_min=0.001))
-        return sol, Q, E
-
-    def step(self):
-        import droid_backends
-        # new keyframe slot seeded from saved state (visual_frontend.py:626-635); keeps the synthetic
-        # problem stationary across steps
-        self.cTw.copy_(self.cTw0); self.wTb.copy_(self.wTb0); self.disps.copy_(self.disps0)
-        self._t("set_keyframe", lambda: self.op_set_keyframe(KF1 - 1))
-        # motion filter (visual_frontend.py:976-1007)
-        blk = self._t("build1", lambda: self.op_build(self.new_i[:1], self.new_j[:1]))
-        self._t("lookup1", lambda: blk(self.coords1))
-        # proximity factors (visual_frontend.py:712-775, 611)
-        for a, b in ((self.fd_i, self.fd_j), (self.fd_j, self.fd_i), (self.fd1_i, self.fd1_j), (self.fd1_j, self.fd1_i)):
-            self._t("frame_distance", lambda: droid_backends.frame_distance(self.cTw, self.disps, self.intr, a, b, 0.3))
-        # correlation volumes of the new edges (visual_frontend.py:838-844)
-        self._t("build10", lambda: self.op_build(self.new_i, self.new_j))
-        # iters1 + iters2 updates (visual_frontend.py:607-621)
-        for _ in range(6):
-            self._t("reproject+motion", self.op_update_glue_pre)
-            self._t("lookup48", self.op_lookup48)
-            self.op_ba_iteration(False)
-            sol, Q, E = self.op_ba_iteration(True)
-            self._t("cov", lambda: self.ba_plan.depth_cov(self.plan, sol["Linv"], Q, E, HW))
-            self._t("upsample", self.op_upsample)
+    def ate_rmse(self):
+        """translation RMSE of the estimated keyframe camera centres against the stream's ground truth (scene units)"""
+        from nerfslam import se3
+        fe, tr = self.tracker.fe, self.tracker
+        n = fe.kf_idx
+        fr = torch.tensor([tr.kf_to_frame[i] for i in range(n)], device=self.dev)
+        est = se3.inv(fe.cam0_T_world[:n].double())[:, :3]
+        gt = se3.inv(self.stream.poses[fr].double())[:, :3]
+        return float((est - gt).pow(2).sum(-1).mean().sqrt()), n
 
 
-ALG_BYTES = {
-    # per (edge, level, pixel) 64 taps*2 + 49 outputs*2 + 8 coords = 234 B
-    "lookup48": E_ACTIVE * 4 * HW * 234,
-    # per edge: read 2*HW*128*2, write HW^2*2*(1+1/4+1/16+1/64)
-    "build10": E_NEW * (2 * HW * CH * 2 + int(HW * HW * 2 * (1 + 0.25 + 0.0625 + 0.015625))),
-}
+def quality(pipe, views=2):
+    out = {}
+    try:
+        ate, n = pipe.ate_rmse()
+        out["ate_rmse_scene_units"] = ate
+        out["keyframes"] = n
+        if pipe.fusion is not None:
+            ngp = pipe.fusion.fusion.ngp
+            nimg = ngp.nerf.training.n_images_for_training
+            if nimg > 0:
+                ev = pipe.fusion.fusion.evaluate(stride=max(1, nimg // views))
+                out.update({"psnr_training_views_db": ev["psnr"], "depth_l1_cm": ev["depth_l1_cm"], "views_rendered": ev["views"],
+                            "nerf_steps_total": int(ngp.training_step)})
+    except Exception as e:      # informational only
+        out["error"] = str(e)[:200]
+    return out
 
 
-def cpu_baseline(hp):
-    """The oracle (a scalar C port of the reference kernels, 1 thread) on a bounded sample of the same
-    workload: one 1-edge pyramid build, one 48-edge 4-level lookup, one BA linearisation + Schur
-    reduction + depth back-substitution at M=96; extrapolated to the op counts of one step."""
-    import oracle
-    t = {}
-    f = hp.fmaps.cpu().numpy()
-    i0, j0 = int(hp.new_i[0]), int(hp.new_j[0])
-    t0 = time.time(); oracle.corr_pyramid(f[i0:i0 + 1], f[j0:j0 + 1]); t["build_per_edge"] = time.time() - t0
-    pyr = [p.cpu().numpy() for p in hp.corr48.untiled()]
-    c = np.ascontiguousarray(hp.coords48[0].cpu().numpy().transpose(0, 3, 1, 2))
-    t0 = time.time()
-    for l in range(4):
-        oracle.corr_index_forward(pyr[l], c / np.float32(2 ** l), 3)
-    t["lookup48"] = time.time() - t0
-    a = [x.cpu().numpy() for x in (hp.cTw0, hp.disps0, hp.intr, hp.extr, hp.disps_sens, hp.targets, hp.weights, hp.eta)]
-    t0 = time.time()
-    H, v, Q, E, w, kx = oracle.reduced_camera_matrix(*a, hp.ii_h, hp.jj_h, KF0, KF1)
-    dx = np.zeros((KF1 - KF0, 6), np.float32)
-    oracle.solve_depth(dx, a[1], Q, E, w, hp.ii_h, hp.jj_h, KF0, KF1)
-    t["ba_iteration"] = time.time() - t0
-    step = (1 + E_NEW) * t["build_per_edge"] + (6 + 1.0 / E_ACTIVE) * t["lookup48"] + 12 * t["ba_iteration"]
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return {"value": 1.0 / step, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "oracle (C port, OpenMP over %d host cores for the volume build, the lookup and the per-edge linearisation; "
-                      "accumulation / Schur / depth update single-threaded): 1-edge pyramid build %.2fs, 48-edge 4-level lookup %.2fs, "
-                      "one M=96 BA linearisation+Schur+depth %.2fs; extrapolated to one step = 11 builds, "
-                      "6 lookups, 12 BA iterations" % (cores, t["build_per_edge"], t["lookup48"], t["ba_iteration"])}
+# =================================================================================================
+# kernel-level rooflines (HIP events around trains of back-to-back launches, on the launch stream)
+# =================================================================================================
+def _train_us(fn, n=20):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / n
 
 
-def mapping_rate(dev, steps=100, warmup=200):
-    """NeRF trainer throughput (configs[2]'s mapping half), reported next to the tracking number: synthetic 8-view scene,
-    default NgpConfig (2^18-sample batches); see tools/ngp_bench.py."""
-    from nerfslam.ngp import NgpConfig, NgpNerf
-    net = NgpNerf(NgpConfig(), dev, seed=0)
-    H, W, f = 120, 160, 150.0
-    g = torch.Generator().manual_seed(0)
-    n = 8
-    c2w = torch.zeros((n, 3, 4))
-    for k in range(n):
-        a = 2 * np.pi * k / n
-        eye = np.array([0.5, 0.5, 0.5]) + 1.2 * np.array([np.cos(a), 0.3, np.sin(a)])
-        fwd = np.array([0.5, 0.5, 0.5]) - eye; fwd /= np.linalg.norm(fwd)
-        right = np.cross(fwd, [0, 1, 0]); right /= np.linalg.norm(right)
-        c2w[k] = torch.tensor(np.stack([right, -np.cross(right, fwd), fwd, eye], 1), dtype=torch.float32)
-    imgs = torch.rand((n, H, W, 4), generator=g)
-    net.set_images(imgs, torch.full((n, H, W), 1.2), torch.full((n, H, W), 0.05), c2w, (f, f, W / 2, H / 2))
-    for _ in range(warmup):
-        net.train_step()
+def kernel_rooflines(dev, hp, ngp_net):
+    """-> {name: {avg_launch_us, algorithmic units per launch, achieved, frac, bound}}.  Algorithmic bytes per unit as in
+    SURVEY 8(d) / DESIGN.md: lookup 234 B per (edge, level, pixel); volume build 2*HW*128*2 read + 85/64*HW^2*2 written
+    per edge; hash encode forward 16 levels x (8 corners x 4 B gathered) + 12 B position + 64 B features = 588 B per
+    sample; hash encode backward 16 x 8 x 8 B (64-bit packed RMW) + 12 + 64 = 1100 B per sample; update-operator
+    gate convolution (448 -> 256, 3x3) 2*9*448*256 flop per pixel."""
+    import ctypes as C
+    from hot_path_chain import ALG_BYTES, E_ACTIVE, HT, WD
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    out = {}
+    for k, fn in (("corr_lookup_coop_kernel[E=48]", hp.op_lookup48), ("corr_volume_tiled_kernel[E=10]", lambda: hp.op_build(hp.new_i, hp.new_j))):
+        us = _train_us(fn)
+        b = ALG_BYTES["lookup48" if "lookup" in k else "build10"]
+        out[k] = {"bound": "hbm", "avg_launch_us": us, "algorithmic_bytes_per_launch": b, "achieved": b / us / 1e3, "unit": "GB/s",
+                  "peak": HBM_PEAK_GBS, "frac": b / us / 1e3 / HBM_PEAK_GBS}
+    # hash grid at a full sample budget (2^18 samples), positions along rays like the trainer's
+    net = ngp_net
+    N = net.cfg.max_samples
+    g = torch.Generator(device=dev).manual_seed(1)
+    pos = torch.rand((N, 3), device=dev, generator=g).contiguous()
+    dfeat = (torch.randn((32, N), device=dev, generator=g) * 1e-3).half().contiguous()
+
+    def enc_fwd():
+        net.encode(pos, net.s_feat)
+
+    def enc_bwd():
+        check(lib().ns_ngp_encode_backward(*net._grid_args(), ptr(pos), ptr(dfeat), 1, ptr(net.grid_grad), ptr(net.enc_ws),
+                                           C.c_float(net.cfg.grad_fixed_scale), C.c_long(N), stream_ptr()), "ngp_encode_backward")
+    for k, fn, per in (("ngp_encode_fwd_kernel[2^18]", enc_fwd, 588), ("ngp_encode_bwd[2^18]", enc_bwd, 1100)):
+        us = _train_us(fn)
+        out[k] = {"bound": "hbm", "avg_launch_us": us, "algorithmic_bytes_per_launch": per * N, "achieved": per * N / us / 1e3,
+                  "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": per * N / us / 1e3 / HBM_PEAK_GBS,
+                  "note": "uniform random positions (worst case for locality)"}
+    net.grid_grad.zero_()
+    # the update operator's gate convolution (the largest MFMA launch of an update)
+    from nerfslam.conv import PackedConv, conv_nhwc
+    w = (torch.randn((256, 448, 3, 3), device=dev) / 60).half().float()
+    pc = PackedConv(w, torch.zeros(256, device=dev))
+    xs = [torch.randn((E_ACTIVE, HT, WD, c), device=dev).half() for c in (128, 128, 192)]
+    us = _train_us(lambda: conv_nhwc(xs, pc, act="sigmoid"), 10)
+    fl = 2.0 * 9 * 448 * 256 * E_ACTIVE * HT * WD
+    out["conv_nhwc_kernel<3x3,448->256>[E=48]"] = {"bound": "mfma", "avg_launch_us": us, "flop_per_launch": fl, "achieved": fl / us / 1e6,
+                                                   "unit": "TFLOP/s", "peak": MFMA_F16_PEAK_TFLOPS, "frac": fl / us / 1e6 / MFMA_F16_PEAK_TFLOPS}
+    return out
+
+
+# =================================================================================================
+def hot_path_chain(dev, steps, warmup):
+    """round 1's figure: the fixed kernel chain of one keyframe step, eager and hipGraph-replayed"""
+    from hot_path_chain import HotPath
+    hp = HotPath(dev, seed=0)
+    for _ in range(max(1, warmup)):
+        hp.step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter(); ns = 0
+    t0 = time.perf_counter()
     for _ in range(steps):
-        net.train_step(); ns += net.last_samples
+        hp.step()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"nerf_train_steps_per_s": steps / dt, "samples_per_step": ns / steps, "samples_per_s": ns / dt,
-            "note": "instant-ngp style trainer on the HIP kernels (hash encode, MFMA MLPs, ray marching), not part of `value`"}
+    eager = (time.perf_counter() - t0) / steps
+    out = {"eager_ms_per_keyframe_step": 1e3 * eager}
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            hp.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            hp.step()
+        graph.replay(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        out["graph_replay_ms_per_keyframe_step"] = 1e3 * (time.perf_counter() - t0) / steps
+        del graph
+    except Exception as e:
+        out["graph_error"] = str(e)[:160]
+    out["note"] = ("tracking kernels only (SURVEY 8a rows A1-A13: 11 pyramid builds, 7 lookups, 12 BA iterations, 6 covariance "
+                   "blocks, 6 x glue), no conv nets, no mapping: NOT the tracked+mapped metric")
+    return hp, out
 
 
-def conv_nets_rate(dev, iters=10):
-    """The tracker's conv nets at the step's shapes (NOT part of `value`): encoders through torch/MIOpen,
-    the update operator through nerfslam.update_op (MFMA convolutions of csrc/conv.hip); random-init weights."""
-    from nerfslam.droid_nets import DroidNet
-    from nerfslam.update_op import HipUpdateOperator
-    torch.manual_seed(0)
-    net = DroidNet().to(dev).eval()
-    op = HipUpdateOperator(net.update_net)
-    img = torch.randn((1, 1, 3, 8 * HT, 8 * WD), device=dev)
-    E = E_ACTIVE
-    hid = torch.randn((E, HT, WD, 128), device=dev).half(); inp = torch.randn((E, HT, WD, 128), device=dev).half()
-    corr = torch.randn((E, 196, HT, WD), device=dev).half(); flow = torch.randn((E, 4, HT, WD), device=dev)
-    ii = [KF0 + k % (KF1 - KF0) for k in range(E)]
-
-    def timed(fn):
-        with torch.no_grad():
-            for _ in range(3):
-                fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(iters):
-                fn()
-            torch.cuda.synchronize()
-        return 1e3 * (time.perf_counter() - t0) / iters
-
-    def enc(m):
-        with torch.autocast("cuda", dtype=torch.float16):
-            return m(img)
-    f = timed(lambda: enc(net.feature_net))
-    c = timed(lambda: enc(net.context_net))
-    u = timed(lambda: op(hid, inp, corr, flow, ii))
-    u1 = timed(lambda: op(hid[:1], inp[:1], corr[:1], flow[:1], ii[:1]))
-    return {"feature_net_ms": f, "context_net_ms": c, "update_operator_E48_ms": u, "update_operator_E1_ms": u1,
-            "ms_per_keyframe_step": f + c + u1 + 6 * u,
-            "note": "feature + context encoders (torch/MIOpen f16) + motion-filter update + 6 updates over 48 edges with the "
-                    "HIP update operator; random-init weights; not part of `value`"}
-
-
+# =================================================================================================
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline trains / hot-path chain / quality renders")
+    ap.add_argument("--buffer", type=int, default=0, help="keyframe buffer (0: sized to the stream)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -339,154 +254,220 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the HIP path")
-    # NS_BENCH_DIST_BACKEND=gloo + NS_BENCH_ONE_DEVICE=1: smoke-test the N > 1 control flow on a 1-GPU box (all ranks on
-    # device 0, timing collectives over gloo); the driver's runs use one GPU per rank over RCCL.
+    # NS_BENCH_DIST_BACKEND=gloo + NS_BENCH_ONE_DEVICE=1: run the N > 1 topology on a 1-GPU box (all ranks on device 0,
+    # collectives over gloo) -- tests/test_multigpu_bench_gpu.py; the driver's runs use one GPU per rank over RCCL.
     backend = os.environ.get("NS_BENCH_DIST_BACKEND", "nccl")
     if os.environ.get("NS_BENCH_ONE_DEVICE"):
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.set_grad_enabled(False)
+    K, W = args.steps, args.warmup
+    n_frames = 100 + W + 2 * K + 8          # initialisation (8 keyframes: < 100 frames) + warm-up + timed + attributed pass
+    buffer = args.buffer or max(32, min(512, n_frames // 3 + 16))
 
-    hp = HotPath(dev, seed=rank)
-    hp.ev = None
-    for _ in range(args.warmup):
-        hp.step()
+    if world > 1:
+        return main_split(args, rank, world, dev, backend, n_frames, buffer)
+
+    pipe = Pipeline(dev, n_frames, buffer, fusion=True)
+    init_frames = 0
+    while not pipe.tracker.is_initialized:
+        pipe.frame(); init_frames += 1
+        if init_frames > 100:
+            raise SystemExit("tracker did not initialise within 100 frames")
+    for _ in range(W):
+        pipe.frame()
+    ngp = pipe.fusion.fusion.ngp
     torch.cuda.synchronize()
-
-    def timed(run_step):
-        """exactly K steps, barrier + synchronize on both sides, max over ranks"""
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run_step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt
-
-    # ---- pass A (eager launches): per-kernel HIP events on the launch stream -> roofline, us_per_call ----
-    hp.ev = {}
-    dt_eager = timed(hp.step)
-    ev, hp.ev = hp.ev, None
-    # ---- pass B (the reported number): the same step captured once in a HIP graph and replayed K times.  A step is
-    # ~170 launches of 5-150 us kernels; launched one by one from Python the host is the bottleneck (pass A), which is
-    # what hipGraphs are for.  The captured work is identical (same kernels, same buffers, state carried on). ----
-    launch = "hipGraph replay"
-    try:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            hp.step()                      # allocator warm-up on the capture stream
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            hp.step()
-        for _ in range(max(1, args.warmup)):
-            graph.replay()
-        torch.cuda.synchronize()
-        dt = timed(graph.replay)
-    except Exception as e:                 # report the eager number rather than nothing
-        launch = "eager (graph capture failed: %s)" % str(e)[:120]
-        dt = dt_eager
-    hp.ev = ev
-
-    kern = {k: 1e3 * float(np.mean([s.elapsed_time(e) for s, e in v])) for k, v in hp.ev.items()}  # us / call
-    per_step = {k: kern[k] * len(hp.ev[k]) / args.steps for k in kern}
-    # launch duration of the two HBM-bound kernels: HIP events (torch.cuda.Event on the launch stream) around a train of
-    # back-to-back launches, so that the host's launch latency (GPU idle between the events of pass A) is not counted;
-    # the roofline is reported for the one with the larger share of the step
-    cands = {"lookup48": hp.op_lookup48, "build10": lambda: hp.op_build(hp.new_i, hp.new_j)}
-    calls = {k: len(ev[k]) / args.steps for k in cands}
-    hp.ev = None
-    train_us = {}
-    for k, fn in cands.items():
-        fn(); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            fn()
-        e1.record(); torch.cuda.synchronize()
-        train_us[k] = 1e3 * e0.elapsed_time(e1) / 20
-    hp.ev = ev
-    dom = max(cands, key=lambda k: train_us[k] * calls[k])
-    dom_us = train_us[dom]
-    hp.corr_layout = "8x8-tiled levels 0/1" if TILED else "row-major (reference layout)"
-    achieved = ALG_BYTES[dom] / (dom_us * 1e-6) / 1e9
-    ms_per_step = 1e3 * dt / args.steps
+    st0, up0, ns0 = dict(pipe.tracker.stats), pipe.tracker.fe.n_updates, int(ngp.training_step)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        pipe.frame()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st1, up1, ns1 = dict(pipe.tracker.stats), pipe.tracker.fe.n_updates, int(ngp.training_step)
+    counts = {"frames": K, "keyframe_candidates": st1["candidates"] - st0["candidates"],
+              "candidates_rejected_by_distance_test": st1["rejected"] - st0["rejected"], "updates": up1 - up0,
+              "nerf_train_steps": ns1 - ns0, "active_edges_at_end": int(pipe.tracker.fe.ii.shape[0]),
+              "nerf_samples_per_step": int(getattr(ngp._net, "last_samples", 0)), "nerf_rays_per_step": int(getattr(ngp._net, "last_rays", 0)),
+              "nerf_training_views": int(ngp.nerf.training.n_images_for_training)}
+    # attributed pass: the next K frames with a device sync after every leg (tracking / mapping) -- explains `value`
+    pipe.leg_ms = {}
+    t0 = time.perf_counter()
+    for _ in range(K):
+        pipe.frame()
+    torch.cuda.synchronize()
+    dt_attr = time.perf_counter() - t0
+    legs = {k: v / K for k, v in pipe.leg_ms.items()}
+    pipe.leg_ms = None
+    breakdown = {"ms_per_frame_by_leg": {k: round(v, 3) for k, v in legs.items()}, "sum_ms_per_frame": round(sum(legs.values()), 3),
+                 "ms_per_frame_of_this_pass": round(1e3 * dt_attr / K, 3),
+                 "note": "separate pass over the NEXT K frames with a device synchronisation after every leg (so host/GPU overlap "
+                         "across legs is lost: the sum is an upper bound of the timed pass's ms_per_step)"}
     out = {
         "metric": "frames/s tracked+mapped on Replica office0 640x480; PSNR + ATE-RMSE vs ref",
-        "value": world * args.steps / dt,
+        "value": K / dt,
         "unit": "frames/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f16 correlation volumes / f32 BA (f64 reduced-camera solve)",
-        "data": "synthetic",
-        "config": {"workload": "configs[1]: --slam only, 640x480 (80x60 grid), tracking hot path of one keyframe per "
-                               "step: 11 corr-pyramid builds, 7 four-level lookups (E=48), 12 BA iterations "
-                               "(M=96,P=10,K'=13) incl. device solve/retraction/depth update, 6 covariance blocks, "
-                               "6 x (reprojection + motion features of the 48 edges, paired convex 8x upsampling of the "
-                               "updated keyframes), 252 frame distances; conv nets (encoders/ConvGRU) and NeRF fusion NOT included",
-                   "replicas": world, "parallelism": "independent streams, one per GPU" if world > 1 else "single GPU",
-                   "launch": launch, "eager_ms_per_step": 1e3 * dt_eager / args.steps,
-                   "corr_volume_layout": hp.corr_layout},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": ALG_BYTES[dom], "avg_launch_us": dom_us,
-                     "avg_launch_us_eager_pass": kern[dom],
-                     "other": {k: {"avg_launch_us": train_us[k], "achieved": ALG_BYTES[k] / (train_us[k] * 1e-6) / 1e9,
-                                   "frac": ALG_BYTES[k] / (train_us[k] * 1e-6) / 1e9 / HBM_PEAK_GBS} for k in cands if k != dom}},
-        "us_per_call": {k: round(v, 2) for k, v in sorted(kern.items())},
-        "us_per_step": {k: round(v, 1) for k, v in sorted(per_step.items())},
+        "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 conv nets + correlation volumes + NeRF MLP/hash grid (f32 master weights), f32 BA with f64 reduced-camera solve",
+        "data": "synthetic 640x480 stream of a textured box room (tools/synth_stream.py), frames resident in HBM; random-init DROID "
+                "architecture executed in full, its flow corrections replaced after the fact by the scene's true flow (no checkpoint "
+                "available offline); NeRF random-init",
+        "config": {"workload": "configs[2]: --slam --fusion=nerf on one MI355X, sequential pipeline (DataModule -> SlamModule -> "
+                               "FusionModule per frame, examples/slam_demo.py:186-190): every frame feature net + motion filter; keyframe "
+                               "candidates context net + proximity factors + 4(+2) updates of <=48 edges (lookup, update operator, "
+                               "2 BA iterations, covariances, upsampling); mapper: ingest on packet frames, 16 NeRF steps on the others",
+                   "stream": "640x480, 90 deg FOV, %.2f px mean flow per frame on the 1/8 grid" % 0.57,
+                   "keyframe_ratio_measured": {"candidates_per_frame": counts["keyframe_candidates"] / K,
+                                               "kept_per_frame": (counts["keyframe_candidates"] - counts["candidates_rejected_by_distance_test"]) / K},
+                   "init_frames_untimed": init_frames, "buffer": buffer, "parallelism": "single GPU", "launch": "eager (product objects)"},
+        "counts": counts,
+        "nerf_train_steps_per_s": counts["nerf_train_steps"] / dt,
+        "breakdown": breakdown,
     }
-    traffic_file = os.path.join(ROOT, "profiles", "r01_traffic.json")  # rocprofv3 --pmc passes (tools/pmc.sh), per launch
-    if os.path.exists(traffic_file):
-        tr = json.load(open(traffic_file)).get(dom)
-        if tr:
-            out["roofline"]["traffic"] = tr["traffic_bytes"]
-            out["roofline"]["traffic_note"] = tr["note"]
-    if rank == 0 and world == 1:
-        out["mapping"] = m = mapping_rate(dev)
-        # configs[2] on ONE GPU, sequential pipeline as the reference runs it: per input frame one tracking step, then one
-        # `frame()` of the mapper = 16 training steps (pyngp.Testbed.steps_per_frame)
-        m["tracked_plus_mapped_frames_per_s_single_gpu"] = 1.0 / (dt / args.steps + 16.0 / m["nerf_train_steps_per_s"])
-        m["assumption"] = "one tracking step + 16 NeRF training steps per frame, run back to back on the same GPU"
-    if rank == 0 and world == 1:
-        try:
-            out["conv_nets"] = cn = conv_nets_rate(dev)
-            cn["tracked_frames_per_s_incl_conv_nets"] = 1.0 / (dt / args.steps + 1e-3 * cn["ms_per_keyframe_step"])
-        except Exception as e:           # informational only
-            out["conv_nets"] = {"error": str(e)[:200]}
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(hp)
-    elif rank == 0:
+    extra = {}
+    if not args.no_extras:
+        extra["quality"] = quality(pipe)
+        hp, extra["hot_path_chain"] = hot_path_chain(dev, 10, 2)
+        roofs = kernel_rooflines(dev, hp, ngp._net)
+        # share of the timed region per candidate kernel (launch time x launches per timed frame)
+        per_frame = {"corr_lookup_coop_kernel[E=48]": counts["updates"] / K, "corr_volume_tiled_kernel[E=10]": counts["keyframe_candidates"] / K,
+                     "ngp_encode_fwd_kernel[2^18]": counts["nerf_train_steps"] / K, "ngp_encode_bwd[2^18]": counts["nerf_train_steps"] / K,
+                     "conv_nhwc_kernel<3x3,448->256>[E=48]": counts["updates"] / K}
+        for k, r in roofs.items():
+            r["launches_per_frame"] = per_frame.get(k, 0.0)
+            r["ms_per_frame"] = r["avg_launch_us"] * r["launches_per_frame"] / 1e3
+        dom = max(roofs, key=lambda k: roofs[k]["ms_per_frame"])
+        d = roofs[dom]
+        out["roofline"] = {"bound": d["bound"], "kernel": dom, "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
+                           "frac": d["frac"], "traffic": None, "avg_launch_us": d["avg_launch_us"],
+                           "ms_per_frame_of_this_kernel": d["ms_per_frame"],
+                           "other": {k: v for k, v in roofs.items() if k != dom}}
+        tf = os.path.join(ROOT, "profiles", "r02_traffic.json")     # rocprofv3 --pmc passes (tools/pmc.sh), per launch
+        if os.path.exists(tf):
+            tr = json.load(open(tf))
+            for k in roofs:
+                if k in tr:
+                    (out["roofline"] if k == dom else out["roofline"]["other"][k])["traffic"] = tr[k].get("traffic_bytes")
+        if not args.no_cpu_baseline:
+            from hot_path_chain import cpu_baseline
+            cb = cpu_baseline(hp)
+            cand = max(counts["keyframe_candidates"] / K, 1e-9)
+            cb["value"] = 1.0 / (cand * cb["seconds_per_keyframe_step"])
+            cb["unit"] = "frames/s"
+            cb["sample"] += "; converted to frames/s of this stream with the measured %.3f keyframe candidates per frame; the CPU figure " \
+                            "covers ONLY the correlation + BA kernels (no conv nets, no NeRF): an upper bound of a CPU pipeline" % cand
+            out["cpu_baseline"] = cb
+    if "cpu_baseline" not in out:
         out["cpu_baseline"] = None
+    out["extra"] = extra
+    print(json.dumps(out))
+
+
+# =================================================================================================
+def main_split(args, rank, world, dev, backend, n_frames, buffer):
+    """--multi_gpu on N GPUs: rank 0 = tracker, ranks 1..N-1 = replicated free-running trainers (module docstring)."""
+    import torch.distributed as dist
+    from nerfslam import transport
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    K, W = args.steps, args.warmup
+    trainers = list(range(1, world))
+    control = dist.new_group(list(range(world)), backend="gloo")
+    trainer_control = dist.new_group(trainers, backend="gloo")
+    trainer_data = dist.new_group(trainers, backend=backend) if len(trainers) > 1 else None
+    chan = transport.PacketChannel(dev, tracker=0, trainers=trainers, control_group=control, data_group=None,
+                                   trainer_control_group=trainer_control)
+
+    def timed_max(dt):
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=control)
+        return float(tt.item())
+
     if rank == 0:
+        pipe = Pipeline(dev, n_frames, buffer, fusion=False,
+                        on_packet=lambda o: chan.publish(o[1]) if (o and o[1] and "cam0_poses" in o[1]) else None)
+        init_frames = 0
+        while not pipe.tracker.is_initialized:
+            pipe.frame(); init_frames += 1
+        for _ in range(W):
+            pipe.frame()
+        st0, up0, b0 = dict(pipe.tracker.stats), pipe.tracker.fe.n_updates, chan.bytes_sent
+        chan.publish(kind=transport.KIND_BARRIER)          # barrier + synchronize on every rank
+        t0 = time.perf_counter()
+        for _ in range(K):
+            pipe.frame()
+        torch.cuda.synchronize()
+        chan.publish(kind=transport.KIND_BARRIER)
+        dt = timed_max(time.perf_counter() - t0)
+        st1, up1, b1 = dict(pipe.tracker.stats), pipe.tracker.fe.n_updates, chan.bytes_sent
+        chan.close()
+        stats = [None] * world
+        dist.all_gather_object(stats, {"rank": 0}, group=control)
+        tr = [s for s in stats if s and s.get("rank", 0) > 0]
+        steps = [s["steps_timed"] for s in tr]
+        ate = quality(pipe)
+        out = {
+            "metric": "frames/s tracked+mapped on Replica office0 640x480; PSNR + ATE-RMSE vs ref",
+            "value": K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 conv nets + correlation volumes + NeRF MLP/hash grid (f32 master weights), f32 BA with f64 reduced-camera solve",
+            "data": "synthetic 640x480 stream (tools/synth_stream.py), frames resident in HBM; random-init networks (see N=1 line)",
+            "config": {"workload": "configs[3]: --multi_gpu split, rank 0 tracks the stream (same per-frame work as the N=1 line's "
+                                   "tracker) and broadcasts every SLAM packet over RCCL to %d replicated free-running NeRF trainers "
+                                   "(gradients all-reduced in the trainer sub-group); value = tracked frames/s while the mappers train "
+                                   "concurrently; per-GPU mapping work is fixed as N grows (weak)" % len(trainers),
+                       "parallelism": "1 tracker + %d replicated trainers" % len(trainers), "backend": backend, "buffer": buffer,
+                       "init_frames_untimed": init_frames,
+                       "keyframe_ratio_measured": {"candidates_per_frame": (st1["candidates"] - st0["candidates"]) / K,
+                                                   "kept_per_frame": (st1["candidates"] - st0["candidates"] - st1["rejected"] + st0["rejected"]) / K}},
+            "counts": {"frames": K, "updates": up1 - up0, "packets_sent": chan.packets},
+            "nerf_optimizer_steps_per_s": (min(steps) / dt) if steps else 0.0,
+            "nerf_ray_batches_per_s_all_trainers": (sum(steps) / dt) if steps else 0.0,
+            "rccl_bytes_per_frame": {"packet_broadcast": (b1 - b0) / K,
+                                     "gradient_allreduce_per_trainer": (sum(s["bytes_allreduced_timed"] for s in tr) / max(len(tr), 1)) / K},
+            "trainers": tr, "tracker_quality": ate, "roofline": None, "cpu_baseline": None,
+        }
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    else:
+        from nerfslam.pipeline import FusionModule
+        fargs = argparse.Namespace(buffer=buffer, parallel_run=False, mask_type="ours", stop_iters=10 ** 9, network="",
+                                   trainer_group=trainer_data)
+        fusion = FusionModule("nerf", fargs, device=str(dev))
+        fusion.initialize_module()
+        ngp = fusion.fusion.ngp
+        ngp.steps_per_frame = 4                  # poll the control plane every 4 optimiser steps
+        marks = []
+        while True:
+            msg = chan.poll()
+            if msg is None:
+                fusion.spin_once(False)          # no packet: train (nerf_fusion.py:249-253)
+                continue
+            kind, pkt = msg
+            if kind == transport.KIND_PACKET:
+                fusion.spin_once({"slam": [None, pkt]})
+            elif kind == transport.KIND_BARRIER:
+                marks.append((int(ngp.training_step), int(getattr(ngp._net, "bytes_allreduced", 0))))
+                if len(marks) == 2:
+                    timed_max(0.0)
+            elif kind == transport.KIND_STOP:
+                break
+        net = ngp._net
+        torch.cuda.synchronize()
+        csum = float(net.grid_master.double().sum().item()) + float(net.mlp_master.double().sum().item())
+        c2w = float(net.c2w.double().sum().item()) if net.c2w is not None else 0.0
+        me = {"rank": rank, "steps_timed": marks[1][0] - marks[0][0] if len(marks) == 2 else 0,
+              "bytes_allreduced_timed": marks[1][1] - marks[0][1] if len(marks) == 2 else 0,
+              "steps_total": int(ngp.training_step), "training_views": int(ngp.nerf.training.n_images_for_training),
+              "param_checksum": csum, "c2w_checksum": c2w, "loss": float(ngp.loss)}
+        stats = [None] * world
+        dist.all_gather_object(stats, me, group=control)
+    dist.barrier(group=control)
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

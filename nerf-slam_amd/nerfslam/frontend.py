@@ -73,6 +73,7 @@ class TrackingFrontend:
         self.feature_fn, self.update_op = feature_fn, update_op
         self.compute_covariances = compute_covariances
         self._plan, self._plan_key = None, None
+        self.n_updates = 0
         self.beta = 0.3
         self.keyframe_thresh, self.frontend_thresh = 4.0, 16.0
         self.frontend_window, self.frontend_radius, self.frontend_nms, self.max_age = 25, 2, 1, 25
@@ -191,6 +192,7 @@ class TrackingFrontend:
             self.upsample(torch.from_numpy(kx).to(self.device), upmask)
         self.graph.age += 1
         self.viz_idx[kf0:self.kf_idx + 1] = True
+        self.n_updates += 1
         return out
 
     def ba(self, target, weight, ii_h, jj_h, kf0, kf1=None, itrs=2, lm=0.0, ep=0.0, compute_covariances=None):

@@ -24,7 +24,8 @@ class NerfFusion:
         self.iters_if_none, self.total_iters = 1, 0                           # :51-54
         self.stop_iters = getattr(args, "stop_iters", 25000)
         dev_index = self.device.index if self.device.index is not None else 0
-        self.ngp = ngp.Testbed(ngp.TestbedMode.Nerf, dev_index)
+        # args.trainer_group: process group of the replicated mapper GPUs under --multi_gpu (None: one trainer)
+        self.ngp = ngp.Testbed(ngp.TestbedMode.Nerf, dev_index, group=getattr(args, "trainer_group", None))
         self.ngp.create_empty_nerf_dataset(args.buffer, 1.0, np.array([np.inf] * 3), 4, None)    # :67-72
         self.ngp.nerf.training.n_images_for_training = 0
         self.ngp.reload_network_from_file(getattr(args, "network", "") or "base.json")

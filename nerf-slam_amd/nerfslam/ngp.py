@@ -101,13 +101,15 @@ class NgpNerf:
             on = dist.is_available() and dist.is_initialized() and group is not None
             world, rank = (dist.get_world_size(group), dist.get_rank(group)) if on else (1, 0)
         self.world, self.rank = int(world), int(rank or 0)
-        seed = int(seed) + self.rank
+        # replicas start from the SAME parameters and keep the same occupancy-grid sampling sequence (base seed); only the
+        # ray selection differs (seed + rank), so the summed gradient is the gradient of an R-times larger batch
+        base_seed, seed = int(seed), int(seed) + self.rank
         c, dev = self.cfg, self.device
         off = (C.c_uint32 * (c.n_levels + 1))()
         check(lib().ns_ngp_grid_layout(c.n_levels, 2, c.log2_hashmap, c.base_res, C.c_float(c.per_level_scale), None,
                                        None, off), "ngp_grid_layout")
         self.n_grid = int(off[c.n_levels]) * 2
-        g = torch.Generator(device="cpu").manual_seed(seed)
+        g = torch.Generator(device="cpu").manual_seed(base_seed)
         f = dict(dtype=torch.float32, device=dev)
         self.grid_master = (torch.rand(self.n_grid, generator=g) * 2e-4 - 1e-4).to(dev)
         w = []
@@ -125,7 +127,7 @@ class NgpNerf:
         self.bits = torch.full((nc * G ** 3 // 8,), 255, dtype=torch.uint8, device=dev)
         self.step = 0
         self.loss = float("nan")
-        self.gen = torch.Generator(device=dev).manual_seed(seed)
+        self.gen = torch.Generator(device=dev).manual_seed(base_seed)
         self.seed = int(seed)
         # training views
         self.images = self.depths = self.depth_covs = self.c2w = None
@@ -236,7 +238,18 @@ class NgpNerf:
             want = R * 0.9 * c.max_samples / max(self.samples_requested, 1)
             self.rays_per_batch = int(min(max(want, 256), c.max_rays)) // 128 * 128
             if N == 0:
-                self.step += 1
+                if self.world > 1:
+                    # replicas stay in lockstep: contribute a zero gradient to this step's all-reduce and take the (shared)
+                    # optimiser step like the others -- returning here would leave the peers alone in the collective
+                    if c.optimize_extrinsics:
+                        self._grow_camera_state(self.n_images)
+                    self._allreduce_gradients()
+                    if c.optimize_extrinsics:
+                        self._camera_step()
+                    self._optimizer_step()
+                else:
+                    self.step += 1
+                self.last_samples, self.last_rays = 0, R
                 return 0.0
             N8 = (N + 7) // 8 * 8  # the weight-gradient GEMM reads 16-byte runs
             if N8 > N:
@@ -274,20 +287,23 @@ class NgpNerf:
                 self._allreduce_gradients()
             if c.optimize_extrinsics:
                 self._camera_step()     # after the all-reduce: every replica applies the SAME pose update
-            # optimiser
-            self.step += 1
-            for (m, hp, g, m1, m2, l2, fx) in (
-                    (self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale),
-                    (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0)):
-                check(lib().ns_ngp_adam(ptr(m), ptr(hp), ptr(g), ptr(m1), ptr(m2), C.c_long(m.numel()), self.step,
-                                        C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
-                                        C.c_float(l2), C.c_float(c.loss_scale * self.world), C.c_float(fx), stream_ptr()),
-                      "ngp_adam")
-            if self.step % c.grid_update_every == 0:
-                self.update_density_grid()
+            self._optimizer_step()
             self.loss_tensor = loss / (self.ray_n >= 0).sum().clamp(min=1)
             self.last_samples, self.last_rays = N, R
         return self.loss_tensor
+
+    def _optimizer_step(self):
+        c = self.cfg
+        self.step += 1
+        for (m, hp, g, m1, m2, l2, fx) in (
+                (self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale),
+                (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0)):
+            check(lib().ns_ngp_adam(ptr(m), ptr(hp), ptr(g), ptr(m1), ptr(m2), C.c_long(m.numel()), self.step,
+                                    C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
+                                    C.c_float(l2), C.c_float(c.loss_scale * self.world), C.c_float(fx), stream_ptr()),
+                  "ngp_adam")
+        if self.step % c.grid_update_every == 0:
+            self.update_density_grid()
 
     def _allreduce_gradients(self):
         """sum over the replicas; Adam then divides by loss_scale * world (mean gradient)"""

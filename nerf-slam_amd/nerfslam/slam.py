@@ -41,6 +41,7 @@ class TrackingSLAM:
         self.last_k, self.last_kf = None, 0
         self.is_initialized, self.stop = False, False
         self.kf_to_frame = {}
+        self.stats = {"frames": 0, "candidates": 0, "rejected": 0, "updates": 0}   # bookkeeping only (bench / logs)
 
     # the reference's nn.Module call
     def __call__(self, batch):
@@ -97,6 +98,7 @@ class TrackingSLAM:
             self.fe.kf_idx += 1
             return viz
         fe = self.fe
+        self.stats["frames"] += 1
         fmap = self.net.features(img)
         if not self._enough_motion(fmap):
             if last_frame:
@@ -105,11 +107,13 @@ class TrackingSLAM:
                 return self._viz(True)
             return None
         self._store(k, data, fmap)
+        self.stats["candidates"] += 1
         if not self.is_initialized:
             if fe.kf_idx >= self.keyframe_warmup:
                 self._initialize()
         elif not self._track():
             self.rm_keyframe(fe.kf_idx - 1)
+            self.stats["rejected"] += 1
             return None
         self.last_k, self.last_kf = k, fe.kf_idx
         viz = self._viz(last_frame)

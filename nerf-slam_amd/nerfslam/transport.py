@@ -12,8 +12,9 @@ Backend "nccl" on GPUs (= RCCL), "gloo" in the CPU tests (tests/test_transport.p
 import torch
 import torch.distributed as dist
 
-HEADER = 8  # int64 words: magic, n, H, W, kf_idx, is_last, fx*1e3, fy*1e3 ... kept small and explicit
+HEADER = 8  # int64 words: magic, n, H, W, kf_idx, is_last, payload bytes, kind
 MAGIC = 0x4E53
+KIND_PACKET, KIND_BARRIER, KIND_STOP = 0, 1, 2
 
 
 def packet_nbytes(n, H, W):
@@ -98,3 +99,96 @@ def allreduce_gradients(tensors, group=None):
     for t in tensors:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         t.div_(world)
+
+
+class PacketChannel:
+    """One tracker -> R FREE-RUNNING replicated trainers (examples/slam_demo.py:63-77 + fusion/fusion_module.py:30-45: the
+    reference's trainer never blocks on its input queue and trains on every spin without a packet, nerf_fusion.py:249-253).
+
+    Two planes:
+      * control (tiny, host side): the tracker drops the 64-byte header into a mailbox in the job's rendezvous store
+        (TCPStore: `set`); the LEADER trainer looks into the mailbox without blocking (`check`) and tells the other
+        trainers what to do next with one small `gloo` broadcast per poll.  All trainers therefore take the same decision
+        at the same point of their step sequence, which keeps the collectives below matched (a trainer that saw the packet
+        one step earlier than another would otherwise leave its peers alone in the gradient all-reduce).  (A posted
+        `irecv` cannot be polled: gloo only marks it complete inside `wait()`.)
+      * data (RCCL over xGMI on the GPUs): the packed keyframes are broadcast from the tracker's HBM to every trainer's
+        (each destination over its own link), enqueued asynchronously on the tracker so tracking never waits for it; the
+        trainers' gradient all-reduce runs in their own sub-group.
+    Control kinds: PACKET (a payload follows on the data plane), BARRIER (every rank meets in a control-plane barrier:
+    brackets timed regions), STOP."""
+
+    def __init__(self, device, tracker=0, trainers=None, control_group=None, data_group=None, trainer_control_group=None):
+        self.device = torch.device(device)
+        self.rank = dist.get_rank()
+        world = dist.get_world_size()
+        self.tracker = tracker
+        self.trainers = list(trainers) if trainers is not None else [r for r in range(world) if r != tracker]
+        self.leader = self.trainers[0]
+        self.control, self.data, self.trainer_control = control_group, data_group, trainer_control_group
+        self._inflight = []            # (work, tensors kept alive) of the tracker's asynchronous broadcasts
+        self._seq = 0                  # next mailbox slot (tracker: to write, leader: to read)
+        from torch.distributed.distributed_c10d import _get_default_store
+        self._store = dist.PrefixStore("nerfslam_packet_channel", _get_default_store())
+        self.bytes_sent = 0
+        self.packets = 0
+
+    # ---- tracker --------------------------------------------------------------------------------------------
+    def _reap(self, block=False):
+        keep = []
+        for work, hold in self._inflight:
+            if block:
+                work.wait()
+            elif not work.is_completed():
+                keep.append((work, hold))
+        self._inflight = keep
+
+    def publish(self, packet=None, kind=KIND_PACKET):
+        """tracker side; returns immediately (header: mailbox write, payload: asynchronous device broadcast)"""
+        self._reap()
+        if kind == KIND_PACKET:
+            header, payload = pack(packet)
+        else:
+            header, payload = torch.tensor([MAGIC, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int64), None
+        header[7] = kind
+        if payload is not None:
+            self._inflight.append((dist.broadcast(payload, self.tracker, group=self.data, async_op=True), payload))
+            self.bytes_sent += payload.numel() * len(self.trainers)
+            self.packets += 1
+        self._store.set(f"h{self._seq}", header.numpy().tobytes())   # after the broadcast is enqueued: a trainer that reads
+        self._seq += 1                                                # the header finds its peer already in the collective
+        if kind == KIND_BARRIER:
+            self.barrier()
+
+    def barrier(self):
+        torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+        dist.barrier(group=self.control)
+
+    def close(self):
+        self.publish(kind=KIND_STOP)
+        self._reap(block=True)
+
+    # ---- trainers -------------------------------------------------------------------------------------------
+    def poll(self):
+        """trainer side, called by EVERY trainer at the same point of its loop.  -> (kind, packet | None) or None when
+        nothing arrived (then train).  Never blocks on the tracker."""
+        header = torch.zeros(HEADER, dtype=torch.int64)
+        if self.rank == self.leader:
+            key = f"h{self._seq}"
+            if self._store.check([key]):
+                import numpy as np
+                header = torch.from_numpy(np.frombuffer(self._store.get(key), dtype=np.int64).copy())
+                self._store.delete_key(key)
+                self._seq += 1
+        if len(self.trainers) > 1:
+            dist.broadcast(header, self.leader, group=self.trainer_control)
+        if int(header[0]) != MAGIC:
+            return None
+        kind = int(header[7])
+        if kind == KIND_PACKET:
+            payload = torch.empty(int(header[6]), dtype=torch.uint8, device=self.device)
+            dist.broadcast(payload, self.tracker, group=self.data)
+            return kind, unpack(header, payload)
+        if kind == KIND_BARRIER:
+            self.barrier()
+        return kind, None

@@ -94,9 +94,12 @@ class _NerfState:
 
 
 class Testbed:
-    def __init__(self, mode=TestbedMode.Nerf, device=0):
+    def __init__(self, mode=TestbedMode.Nerf, device=0, group=None):
+        """group: torch.distributed process group of REPLICATED trainers (the --multi_gpu split with more than one mapper
+        GPU); None: a single trainer, as the reference has."""
         if mode != TestbedMode.Nerf:
             raise NotImplementedError("only TestbedMode.Nerf is used by NeRF-SLAM")
+        self._group = group
         self._device = torch.device("cuda", int(device))
         self._cfg = NgpConfig()
         self._net = None
@@ -127,14 +130,14 @@ class Testbed:
         ds.n_images, ds.aabb_scale, ds.scale = self._slots, int(aabb_scale), float(nerf_scale)
         off = np.asarray(nerf_offset if nerf_offset is not None else [0.5, 0.5, 0.5], np.float32)
         ds.offset = np.where(np.isfinite(off), off, 0.5).astype(np.float32)  # the reference passes inf ("not needed")
-        self._net = NgpNerf(self._cfg, self._device)
+        self._net = NgpNerf(self._cfg, self._device, group=self._group)
         self._imgs = self._deps = self._covs = self._c2w = None
 
     def reload_network_from_file(self, path=None):
         """The reference loads configs/nerf/base.json of the un-vendored fork (nerf_fusion.py:58-61,90); the
         network here is the fixed configuration of NgpConfig.  Re-initialises the parameters."""
         if self._net is not None:
-            self._net = NgpNerf(self._cfg, self._device)
+            self._net = NgpNerf(self._cfg, self._device, group=self._group)
             self._push_images()
 
     def init_window(self, *a, **k):

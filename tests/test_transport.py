@@ -76,3 +76,77 @@ def test_gloo_world_size_2():
     for p in procs:
         p.join(timeout=60)
     assert res == {0: True, 1: True}
+
+
+# ------------------------------------------------------------------------------------------------
+# PacketChannel: 1 tracker + 2 free-running replicated trainers (world size 3, gloo)
+# ------------------------------------------------------------------------------------------------
+def _channel_worker(rank, world, port, q):
+    import time
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nerfslam import transport
+    trainers = [1, 2]
+    control = dist.new_group([0, 1, 2], backend="gloo")
+    tc = dist.new_group(trainers, backend="gloo")
+    td = dist.new_group(trainers, backend="gloo")
+    chan = transport.PacketChannel("cpu", tracker=0, trainers=trainers, control_group=control, data_group=None,
+                                   trainer_control_group=tc)
+    log = []
+    if rank == 0:
+        chan.publish(kind=transport.KIND_BARRIER)
+        for k in range(4):
+            time.sleep(0.02 * (k % 3))                     # irregular arrival times
+            chan.publish(_make_packet(n=1 + k % 3, seed=k))
+        chan.publish(kind=transport.KIND_BARRIER)
+        chan.close()
+        q.put((0, chan.packets, chan.bytes_sent))
+    else:
+        steps = 0
+        grad = torch.zeros(64)
+        while True:
+            msg = chan.poll()
+            if msg is None:                                 # a "training step": a collective among the trainers only
+                g = torch.full((64,), float(rank))
+                dist.all_reduce(g, group=td)
+                grad += g
+                steps += 1
+                if rank == 2:
+                    time.sleep(0.001)                       # one trainer slower than the other
+                continue
+            kind, pkt = msg
+            if kind == transport.KIND_PACKET:
+                log.append(("pkt", steps, int(pkt["cam0_poses"].shape[0]), float(pkt["cam0_idepths_up"].sum())))
+            elif kind == transport.KIND_BARRIER:
+                log.append(("barrier", steps))
+            else:
+                break
+        q.put((rank, log, float(grad.sum()), steps))
+    dist.barrier(group=control)
+    dist.destroy_process_group()
+
+
+def test_packet_channel_one_tracker_two_free_running_trainers():
+    """both trainers take the same decision at the same step (identical logs incl. the step index at which each packet /
+    barrier was consumed), every packet arrives intact, training steps happen between packets, nobody deadlocks"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_channel_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(3):
+        r = q.get(timeout=180)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0][0] == 4 and res[0][1] > 0
+    log1, g1, s1 = res[1]
+    log2, g2, s2 = res[2]
+    assert log1 == log2 and g1 == g2 and s1 == s2
+    pk = [e for e in log1 if e[0] == "pkt"]
+    assert [e[2] for e in pk] == [1, 2, 3, 1]
+    for k, e in enumerate(pk):
+        assert abs(e[3] - float(_make_packet(n=1 + k % 3, seed=k)["cam0_idepths_up"].sum())) < 1e-3
+    assert [e[0] for e in log1].count("barrier") == 2 and s1 > 0

@@ -1,0 +1,155 @@
+"""Synthetic 640x480 RGB stream of a textured box room with exact ground truth (poses, depth), and the
+"grounded" network bundle the benchmark and the end-to-end tests drive the PRODUCT pipeline with.
+
+Why grounded: the DROID checkpoint (`droid.pth`) is not part of the reference tree and there is no network to fetch
+it, so the tracker's conv nets run with random-init weights.  Their outputs are then meaningless as flow
+corrections -- BA would diverge, the mapper would be fed garbage poses and its ray marcher would do an unrepresentative
+amount of work.  `GroundedNetworks` therefore EXECUTES the real networks at the real shapes (feature / context
+encoders, update operator with ConvGRU + heads + GraphAgg, motion-filter pass: every kernel runs, nothing is skipped
+or cached) and then substitutes the flow correction they return by the one the known scene geometry induces
+(3 tiny extra kernels per update, counted inside the timed region).  Everything downstream -- BA, covariances, keyframe
+logic, packets, NeRF ingest and training -- then operates on a consistent scene, as it would with trained weights.
+
+Conventions: pose = cam_T_world [tx,ty,tz,qx,qy,qz,qw] (visual_frontend.py:184); frame 0 is the identity; the 1/8 grid
+pixel (x, y) looks along ((x - cx/8)/(fx/8), (y - cy/8)/(fy/8), 1) exactly as the BA kernels assume.
+"""
+import numpy as np
+import torch
+
+
+def _quat_from_R(R):
+    """[...,3,3] -> xyzw (w >= 0)"""
+    m00, m11, m22 = R[..., 0, 0], R[..., 1, 1], R[..., 2, 2]
+    w = torch.sqrt(torch.clamp(1 + m00 + m11 + m22, min=1e-12)) / 2
+    x = (R[..., 2, 1] - R[..., 1, 2]) / (4 * w)
+    y = (R[..., 0, 2] - R[..., 2, 0]) / (4 * w)
+    z = (R[..., 1, 0] - R[..., 0, 1]) / (4 * w)
+    return torch.stack([x, y, z, w], -1)
+
+
+class RoomStream:
+    """Camera trucking sideways through a box room (triangle wave in x, small bob in y, small yaw), looking at the far wall.
+
+    flow_px: mean optical flow per frame on the 1/8 grid (the motion filter fires at 2.4 px, the keyframe test keeps a
+    keyframe at 4 px, visual_frontend.py:93-95,110): 0.55 px/frame -> a keyframe candidate every 5th frame, every second
+    candidate kept."""
+
+    def __init__(self, n_frames, H=480, W=640, flow_px=0.55, device="cuda:0", seed=0):
+        self.n, self.H, self.W = int(n_frames), H, W
+        self.dev = dev = torch.device(device)
+        self.fx = self.fy = 0.5 * W                       # 90 degree horizontal field of view (Replica's is 90 too)
+        self.cx, self.cy = (W - 1) / 2.0, (H - 1) / 2.0
+        self.intr = np.array([self.fx, self.fy, self.cx, self.cy], np.float32)
+        self.lo = torch.tensor([-1.95, -1.10, -1.90], device=dev, dtype=torch.float64)
+        self.hi = torch.tensor([1.95, 1.10, 1.60], device=dev, dtype=torch.float64)
+        depth = 1.6
+        speed = flow_px * depth / (self.fx / 8.0)         # world units per frame
+        k = torch.arange(self.n, dtype=torch.float64, device=dev)
+        amp = 1.2
+        phase = (k * speed) % (4 * amp)                   # triangle wave 0 -> amp -> -amp -> 0
+        x = torch.where(phase < amp, phase, torch.where(phase < 3 * amp, 2 * amp - phase, phase - 4 * amp))
+        c = torch.stack([x, 0.04 * torch.sin(0.11 * k), 0.03 * torch.sin(0.07 * k)], -1)       # camera centres
+        yaw, pitch = 0.06 * torch.sin(0.045 * k), 0.02 * torch.sin(0.08 * k)
+        cy_, sy_, cp_, sp_ = torch.cos(yaw), torch.sin(yaw), torch.cos(pitch), torch.sin(pitch)
+        z, o = torch.zeros_like(yaw), torch.ones_like(yaw)
+        Ry = torch.stack([cy_, z, sy_, z, o, z, -sy_, z, cy_], -1).view(-1, 3, 3)
+        Rx = torch.stack([o, z, z, z, cp_, -sp_, z, sp_, cp_], -1).view(-1, 3, 3)
+        self.R_wc = Ry @ Rx                               # camera-to-world rotation
+        self.c = c
+        R_cw = self.R_wc.transpose(1, 2)
+        t = -(R_cw @ c[..., None])[..., 0]
+        self.poses = torch.cat([t, _quat_from_R(R_cw)], -1).float().contiguous()               # cam_T_world [n,7]
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.tex = (torch.rand((6, 3, 4), generator=g, dtype=torch.float64) * 2 * np.pi).to(dev)   # per wall / channel phases
+        self.freq = torch.tensor([3.1, 7.3, 17.9, 41.0], dtype=torch.float64, device=dev)
+        self.disps = torch.stack([self._depth(i, 8)[0] for i in range(self.n)]).reciprocal().float().contiguous()  # [n,H/8,W/8]
+
+    # --------------------------------------------------------------------------------------------
+    def _depth(self, i, stride):
+        """ray / box intersection from inside -> (Z [h,w] camera-frame depth, hit point [h,w,3], wall id [h,w])"""
+        dev = self.dev
+        h, w = self.H // stride, self.W // stride
+        v, u = torch.meshgrid(torch.arange(h, dtype=torch.float64, device=dev) * stride,
+                              torch.arange(w, dtype=torch.float64, device=dev) * stride, indexing="ij")
+        d_cam = torch.stack([(u - self.cx) / self.fx, (v - self.cy) / self.fy, torch.ones_like(u)], -1)
+        d = d_cam @ self.R_wc[i].T
+        o = self.c[i]
+        inv = 1.0 / torch.where(d.abs() < 1e-12, torch.full_like(d, 1e-12), d)
+        t_far = torch.maximum((self.lo - o) * inv, (self.hi - o) * inv)                      # exit distance per axis
+        Z, axis = t_far.min(-1)
+        hit = o + Z[..., None] * d
+        wall = axis * 2 + (torch.gather(d, -1, axis[..., None])[..., 0] > 0).long()
+        return Z, hit, wall
+
+    def image(self, i):
+        """uint8 [H,W,3] on the device"""
+        Z, hit, wall = self._depth(i, 1)
+        ph = self.tex[wall]                                                                  # [H,W,3,4]
+        s = hit.sum(-1, keepdim=True) * 0.37 + hit[..., :1] * 0.61 - hit[..., 1:2] * 0.43 + hit[..., 2:] * 0.29   # [H,W,1]
+        waves = torch.sin(s[..., None] * self.freq + ph)                                     # [H,W,3,4]
+        col = 0.5 + (waves * torch.tensor([0.22, 0.14, 0.08, 0.05], dtype=torch.float64, device=self.dev)).sum(-1)
+        check = (((hit * 2.5).floor().sum(-1) % 2) * 0.12)[..., None]
+        return ((col + check - 0.06).clamp(0, 1) * 255).round().to(torch.uint8).contiguous()
+
+    def depth(self, i):
+        return self._depth(i, 1)[0].float()
+
+    def packet(self, i, image=None, last=False):
+        """dataset packet in the reference's layout (datasets/*: k, images, calibs, depths, is_last_frame); the image stays a
+        DEVICE tensor (inputs resident in HBM when the timed region starts).  Sensed depth only on frame 0: it fixes the
+        monocular scale gauge so that the estimate can be compared with the ground truth."""
+        img = self.image(i) if image is None else image
+        return {"k": [i], "images": [img], "calibs": [self.intr], "depths": [self.depth(i) if i == 0 else None],
+                "t_cams": [float(i)], "poses": [None], "is_last_frame": bool(last)}
+
+
+def _reproject(poses, disps, intr8, ii, jj, ht, wd):
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    E = ii.shape[0]
+    out = torch.empty((E, ht, wd, 2), dtype=torch.float32, device=poses.device)
+    check(lib().ns_reproject(ptr(poses), ptr(disps), ptr(intr8), ptr(ii), ptr(jj), ptr(out), None, E, ht, wd, stream_ptr()),
+          "reproject")
+    return out
+
+
+def grounded_networks(stream, device, buffer, seed=0):
+    """-> DroidNetworks subclass instance whose flow corrections are replaced (AFTER the real nets ran) by the flow the
+    stream's geometry induces.  `nets.frame` must be set to the stream index of the frame being processed."""
+    from nerfslam.droid_nets import DroidNetworks
+
+    class GroundedNetworks(DroidNetworks):
+        def __init__(self):
+            super().__init__(device, weights=None, buffer=buffer, seed=seed)
+            self.stream, self.frame, self.fe = stream, 0, None
+            ht, wd = stream.H // 8, stream.W // 8
+            self.ht, self.wd = ht, wd
+            self.kfP = torch.zeros((buffer, 7), device=self.device)
+            self.kfP[:, 6] = 1.0
+            self.kfD = torch.ones((buffer, ht, wd), device=self.device)
+            self.intr8 = torch.from_numpy(stream.intr / 8.0).to(self.device)
+            gy, gx = torch.meshgrid(torch.arange(ht, device=self.device), torch.arange(wd, device=self.device), indexing="ij")
+            self.coords0 = torch.stack([gx, gy], -1).float()
+            self._i0 = torch.zeros(1, dtype=torch.long, device=self.device)
+            self._i1 = torch.ones(1, dtype=torch.long, device=self.device)
+
+        def begin_keyframe(self, k, img_u8):
+            super().begin_keyframe(k, img_u8)
+            self.kfP[k], self.kfD[k] = self.stream.poses[self.frame], self.stream.disps[self.frame]
+
+        def remove_keyframe(self, k):
+            super().remove_keyframe(k)
+            self.kfP[k], self.kfD[k] = self.kfP[k + 1].clone(), self.kfD[k + 1].clone()
+
+        def motion(self, corr, last_kf):
+            super().motion(corr, last_kf)                                    # the real motion-filter pass (result unused)
+            P2 = torch.stack([self.kfP[last_kf], self.stream.poses[self.frame]])
+            c = _reproject(P2, self.kfD[last_kf][None].contiguous(), self.intr8, self._i0, self._i1, self.ht, self.wd)
+            return (c[0] - self.coords0)[None, None]
+
+        def update(self, corr, motion, ii, jj):
+            res = super().update(corr, motion, ii, jj)                       # the real update operator
+            true_c = _reproject(self.kfP, self.kfD, self.intr8, ii, jj, self.ht, self.wd)
+            delta = (true_c - self.fe.reproject(ii, jj))[None]
+            return (delta, torch.ones_like(delta)) + tuple(res[2:])
+
+    return GroundedNetworks()
