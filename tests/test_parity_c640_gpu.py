@@ -31,8 +31,8 @@ def _reproject_hip(dev, poses, disps, intr, ii, jj):
     n, (_, ht, wd) = ii.shape[0], disps.shape
     coords = torch.full((n, ht, wd, 2), float("nan"), device=dev)
     valid = torch.full((n, ht, wd), float("nan"), device=dev)
-    check(lib().ns_reproject(ptr(T(poses, dev)), ptr(T(disps, dev)), ptr(T(intr, dev)), ptr(T(ii, dev)), ptr(T(jj, dev)),
-                             ptr(coords), ptr(valid), n, ht, wd, stream_ptr()), "reproject")
+    a = [T(x, dev) for x in (poses, disps, intr, ii, jj)]     # named: a temporary would be freed (and its block reused) before the launch
+    check(lib().ns_reproject(*[ptr(x) for x in a], ptr(coords), ptr(valid), n, ht, wd, stream_ptr()), "reproject")
     return coords.cpu().numpy(), valid.cpu().numpy()
 
 
