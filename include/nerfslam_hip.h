@@ -71,6 +71,16 @@ int ns_corr_index_backward(const float* coords, const float* corr_grad, float* v
 int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_levels, const float* coords,
                            int coords_interleaved, void* out, int E, int h1, int w1, int tiled, void* stream);
 
+/* Slot-addressed forms (this project's frontend, nerfslam/corr.py:CorrPool): the per-edge volumes live in a pool of
+ * `capacity` slots and edge e uses volume index slot[e] (int32, device), so that edges enter / leave the factor graph
+ * (visual_frontend.py:806-892: `torch.cat` / boolean-mask copies of ~61 MB per edge there) without moving a byte of
+ * volume.  slot == NULL: identical to the plain entry points. */
+int ns_corr_lookup_pyramid_slots(const void* const* pyr_host, int num_levels, const float* coords, int coords_interleaved,
+                                 void* out, int E, int h1, int w1, int tiled, const int* slot, int capacity, void* stream);
+int ns_corr_volume_pyramid_slots(const void* fmap1, const void* fmap2, const int64_t* ii, const int64_t* jj,
+                                 void* const* pyr_host, int num_levels, int E, int C, int ht, int wd, int tiled,
+                                 const int* slot, void* stream);
+
 /* CorrBlock.__init__ pyramid (corr.py:23-38): one 2x2 average-pool step over the last two dims,
  * f16 in/out, f32 accumulate, one rounding.  in [nslices,h,w] -> out [nslices,h/2,w/2].       */
 int ns_corr_pool2x2(const void* in, void* out, long nslices, int h, int w, void* stream);
@@ -263,16 +273,20 @@ int ns_ngp_encode_forward(int n_levels, int n_features, int log2_hashmap, int ba
                           const float* positions, const void* params, void* out, int unit_major, long N, void* stream);
 
 /* grad_params f32 [entries*2] += trilinear weights * dLdout f16 ([N, n_levels*2], or [n_levels*2, N] with
- * unit_major = 1) (atomic scatter).
- * workspace: NULL, or ns_ngp_encode_backward_workspace_bytes(...) bytes, ZERO-FILLED once by the caller
- * (left zeroed by every call): private accumulation tables for the coarse levels, where all samples of a
- * scene hit a few hundred entries and same-address atomics would serialise.
+ * unit_major = 1).  No global atomics on table entries (csrc/ngp.hip: on this 8-XCD part they execute at the memory side):
+ *   workspace == NULL   owner-computes kernel on every level: a workgroup owns a 16384-entry table slice in LDS and scans
+ *                       all samples of the level for corners that fall into it;
+ *   workspace != NULL   (ns_ngp_encode_backward_workspace_bytes(..., max_samples >= N) bytes, zero-filled once by the
+ *                       caller; packed fixed-point mode only) the hashed levels are BINNED instead -- count / scatter /
+ *                       accumulate passes over 64-bit (slice index, 2 x 25-bit Q(S) gradient) records, 8 B written + 8 B read
+ *                       per (sample, corner); the dense coarse levels keep the owner-computes kernel.
+ * All three paths (NS_ENC_BWD_ATOMIC=1 selects round 1's atomic scatter) produce the same integer sums bit for bit.
  * fixed_scale: 0 -> grad_params holds f32 pairs.  S > 0 -> PACKED fixed point: one 64-bit word per table
- * entry, word = round(g0*S) + (round(g1*S) << 32) (two signed Q(S) 32-bit fields): one integer atomic per
- * corner instead of two float atomics, and an order-independent (bit-reproducible) sum.  ns_ngp_adam
+ * entry, word = round(g0*S) + (round(g1*S) << 32) (two signed Q(S) 32-bit fields): an order-independent
+ * (bit-reproducible) sum; contributions saturate at |g| >= 2^24 / S in the binned path.  ns_ngp_adam
  * decodes the same format when given the same fixed_scale.                                             */
 long ns_ngp_encode_backward_workspace_bytes(int n_levels, int n_features, int log2_hashmap, int base_res,
-                                            float per_level_scale);
+                                            float per_level_scale, long max_samples);
 int ns_ngp_encode_backward(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
                            const float* positions, const void* dLdout, int unit_major, float* grad_params,
                            float* workspace, float fixed_scale, long N, void* stream);
@@ -388,6 +402,38 @@ int ns_planes_to_nhwc_f16(const void* src, void* dst, int E, int C, int CP, int 
  * fine), starts [K+1] / members [E] i32 on the device, out [K,HW,channels] f16, f32 accumulation.                  */
 int ns_group_mean_nhwc_f16(const void* src, int src_stride, const int* starts, const int* members, void* out, int K, int HW,
                            int channels, void* stream);
+
+/* ---- graph-captured training step (nerfslam/ngp.py): the `_ctl` forms read the per-step scalars from a device
+ * control block instead of by-value arguments, so that a whole optimiser step is a fixed launch sequence:
+ *   ctl[0] optimiser steps completed, ctl[1] rays of the current batch, ctl[2] ray-sampling seed, ctl[3] training views,
+ *   ctl[4], ctl[5] float bits of Adam's bias corrections 1 - beta^(ctl[0] + 1) (maintained by ns_ngp_step_advance; the caller
+ *   initialises them).
+ * With ctl != NULL the by-value R / n_images are CAPACITIES (grid sizes), `step` and `seed` are ignored
+ * (seed = ctl[2] * 0x9E3779B1 + ctl[0] * 0x85EBCA77, bias corrections from ctl[0] + 1).  ctl == NULL: identical to the
+ * plain entry points.  ns_ngp_step_advance ends a step: last[0..3] = march counters + ray count of this step,
+ * ctl[1] = clamp(R * fill * max_samples / requested, min_rays, max_rays) rounded down to 128, ctl[0] += 1,
+ * counter[0..2] = 0.  [no reference counterpart: the fork's trainer reads its counters back on the host] */
+int ns_ngp_sample_rays_ctl(const float* images, const float* depths, const float* depth_covs, const float* c2w, int n_images,
+                           int H, int W, float fx, float fy, float cx, float cy, float box_lo, float box_hi, float near,
+                           unsigned seed, int R, float* rays_o, float* rays_d, float* t_range, float* gt_rgb, float* gt_depth,
+                           float* gt_depth_cov, int* ray_img, const int* ctl, void* stream);
+int ns_ngp_march_ctl(const uint8_t* bits, int G, int ncasc, const float* rays_o, const float* rays_d, const float* t_range,
+                     int R, float cone, float min_step, float max_step, float pos_lo, float pos_inv, int max_per_ray,
+                     long max_samples, int* counter, int* ray_start, int* ray_n, float* pos, float* dirs, float* dt, float* tmid,
+                     const int* ctl, void* stream);
+int ns_ngp_composite_ctl(const void* net_out, const float* dt, const float* tmid, const int* ray_start, const int* ray_n, int R,
+                         const float* gt_rgb, const float* gt_depth, const float* gt_depth_cov, float depth_lambda,
+                         float loss_scale, float* out_rgb, float* out_depth, float* loss, void* dLdout, const int* ctl,
+                         void* stream);
+int ns_ngp_camera_gradient_ctl(const float* dLdpos, const float* tmid, const float* rays_d, const int* ray_start,
+                               const int* ray_n, const int* ray_img, float pos_inv, float* cam_grad, int R, const int* ctl,
+                               void* stream);
+int ns_ngp_camera_step_ctl(float* c2w, float* cam_grad, float* m1, float* m2, int n_images, int step, float lr_pos, float lr_rot,
+                           float beta1, float beta2, float eps, float grad_scale, const int* ctl, void* stream);
+int ns_ngp_adam_ctl(float* master, void* half_params, float* grad, float* m1, float* m2, long n, int step, float lr, float beta1,
+                    float beta2, float eps, float l2, float grad_scale, float fixed_scale, const int* ctl, void* stream);
+int ns_ngp_step_advance(int* ctl, int* counter, int* last, float fill, long max_samples, int min_rays, int max_rays,
+                        float beta1, float beta2, void* stream);
 
 #ifdef __cplusplus
 }

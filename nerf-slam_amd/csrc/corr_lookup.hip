@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void corr_lookup_pyramid_kernel(LookupLevels L
 
 __global__ __launch_bounds__(512) void corr_lookup_coop_kernel(LookupLevels L, const float* __restrict__ coords,
                                                                int interleaved, _Float16* __restrict__ out, int E,
-                                                               int HW1) {
+                                                               int HW1, const int* __restrict__ slot) {
   __shared__ __attribute__((aligned(16))) uint16_t ob[49 * COOP_PITCH];
   const int t = threadIdx.x, r = t & 7, pl = t >> 3;
   const int lvl = blockIdx.y;
@@ -256,7 +256,9 @@ __global__ __launch_bounds__(512) void corr_lookup_coop_kernel(LookupLevels L, c
   const float x0 = cx * sc, y0 = cy * sc;
   const int h2 = L.h2[lvl], w2 = L.w2[lvl], ntx = L.ntx[lvl];
   const _Float16* __restrict__ vol = L.vol[lvl];
-  const long slice_off = idc * L.slice_elems[lvl], total = L.total_elems[lvl];
+  // slot-addressed pools: edge n reads volume index slot[n] (the edge list is reordered / shrunk without moving volumes)
+  const long vidx = slot ? (long)slot[n] * HW1 + p : idc;
+  const long slice_off = vidx * L.slice_elems[lvl], total = L.total_elems[lvl];
   const float fx0 = floorf(x0), fy0 = floorf(y0);
   const bool sane = live && (fabsf(x0) < 1.0e6f) && (fabsf(y0) < 1.0e6f);
   const float dx = sane ? x0 - fx0 : 0.0f, dy = sane ? y0 - fy0 : 0.0f;
@@ -457,7 +459,15 @@ __global__ __launch_bounds__(256) void corr_index_backward_kernel(const float* _
 extern "C" int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_levels, const float* coords,
                                       int coords_interleaved, void* out, int E, int h1, int w1, int tiled,
                                       void* stream) {
+  return ns_corr_lookup_pyramid_slots(pyr_host, num_levels, coords, coords_interleaved, out, E, h1, w1, tiled, nullptr, E,
+                                      stream);
+}
+
+extern "C" int ns_corr_lookup_pyramid_slots(const void* const* pyr_host, int num_levels, const float* coords,
+                                            int coords_interleaved, void* out, int E, int h1, int w1, int tiled,
+                                            const int* slot, int capacity, void* stream) {
   if (E == 0) return NS_OK;  // an empty set is a no-op whatever the pointers are
+  NS_REQUIRE(slot == nullptr || capacity >= 1, "ns_corr_lookup_pyramid_slots: capacity of the volume pool must be given");
   NS_REQUIRE(pyr_host && coords && out, "ns_corr_lookup_pyramid: null pointer");
   NS_REQUIRE(num_levels >= 1 && num_levels <= 4, "ns_corr_lookup_pyramid: num_levels=%d not in 1..4", num_levels);
   NS_REQUIRE(E >= 0 && h1 > 0 && w1 > 0, "ns_corr_lookup_pyramid: bad shape E=%d h1=%d w1=%d", E, h1, w1);
@@ -474,11 +484,11 @@ extern "C" int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_level
     L.scale[l] = 1.0f / (float)(1 << ll);
     L.ntx[l] = (tiled && ll < 2) ? (L.w2[l] + 7) / 8 : 0;
     L.slice_elems[l] = L.ntx[l] ? (long)((L.h2[l] + 7) / 8) * L.ntx[l] * 64 : (long)L.h2[l] * L.w2[l];
-    L.total_elems[l] = (long)E * HW1 * L.slice_elems[l];
+    L.total_elems[l] = (long)(slot ? capacity : E) * HW1 * L.slice_elems[l];
     NS_REQUIRE(L.h2[l] > 0 && L.w2[l] > 0, "ns_corr_lookup_pyramid: level %d is empty", ll);
   }
   static const bool one_lane = getenv("NS_LOOKUP_ONE_LANE") != nullptr;  // comparison switch: one lane per pixel
-  if (one_lane) {
+  if (one_lane && slot == nullptr) {
     dim3 grid(ns_cdiv((long)E * HW1, 256), num_levels);
     hipLaunchKernelGGL(corr_lookup_pyramid_kernel, grid, dim3(256), 0, (hipStream_t)stream, L, coords,
                        coords_interleaved, (_Float16*)out, E, (int)HW1);
@@ -486,7 +496,7 @@ extern "C" int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_level
   } else {
     dim3 grid(ns_cdiv((long)E * HW1, 64), num_levels);
     hipLaunchKernelGGL(corr_lookup_coop_kernel, grid, dim3(512), 0, (hipStream_t)stream, L, coords, coords_interleaved,
-                       (_Float16*)out, E, (int)HW1);
+                       (_Float16*)out, E, (int)HW1, slot);
     NS_CHECK_LAUNCH("corr_lookup_coop_kernel");
   }
   return NS_OK;

@@ -37,6 +37,7 @@ struct VolArgs {
   _Float16* pyr[4];    // level l: [E][HW][h>>l][w>>l]
   int E, ht, wd, num_levels;
   int tiled;  // levels 0 and 1 in 8x8-tiled slices (see corr_volume_tiled_kernel)
+  const int* slot;  // optional: edge e is written to volume index slot[e] of pyr[*] (slot-addressed pools; null: e)
 };
 
 __device__ __forceinline__ _Float16 pool4(_Float16 a, _Float16 b, _Float16 c, _Float16 d) {
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(256) void corr_volume_pyramid_kernel(VolArgs a) {
   const int e = blockIdx.y;
   const int p0 = (blockIdx.x * 4 + wave) * 32;
   const long fi = a.ii ? a.ii[e] : e, fj = a.jj ? a.jj[e] : e;
+  const int eo = a.slot ? a.slot[e] : e;  // output volume index
   const _Float16* __restrict__ F1 = a.f1 + fi * (long)HW * C;
   const _Float16* __restrict__ F2 = a.f2 + fj * (long)HW * C;
 
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void corr_volume_pyramid_kernel(VolArgs a) {
     src[kk] = *reinterpret_cast<const f16x8*>(F1 + (long)(pok ? p : 0) * C + kk * 16 + half * 8);
     if (!pok) src[kk] = (f16x8)(_Float16)0;
   }
-  const long pp = (long)e * HW + (pok ? p : 0);
+  const long pp = (long)eo * HW + (pok ? p : 0);
   _Float16* o0 = a.pyr[0] + pp * (long)HW;
   _Float16* o1 = a.num_levels > 1 ? a.pyr[1] + pp * (long)(a.ht >> 1) * (a.wd >> 1) : nullptr;
   _Float16* o2 = a.num_levels > 2 ? a.pyr[2] + pp * (long)(a.ht >> 2) * (a.wd >> 2) : nullptr;
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
   const int e = blockIdx.y;
   const int p0 = (blockIdx.x * 4 + wave) * 32;
   const long fi = a.ii ? a.ii[e] : e, fj = a.jj ? a.jj[e] : e;
+  const int eo = a.slot ? a.slot[e] : e;  // output volume index
   const _Float16* __restrict__ F1 = a.f1 + fi * (long)HW * C;
   const _Float16* __restrict__ F2 = a.f2 + fj * (long)HW * C;
   const int p = p0 + col;
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
   const int h1 = ht >> 1, w1 = wd >> 1, h2 = ht >> 2, w2 = wd >> 2, h3 = ht >> 3, w3 = wd >> 3;
   const int nty0 = (ht + 7) >> 3, ntx0 = (wd + 7) >> 3, nty1 = (h1 + 7) >> 3, ntx1 = (w1 + 7) >> 3;
   const long slice0 = (long)nty0 * ntx0 * 64, slice1 = (long)nty1 * ntx1 * 64;
-  const long pp = (long)e * HW + (pok ? p : 0);
+  const long pp = (long)eo * HW + (pok ? p : 0);
   _Float16* o2 = a.num_levels > 2 ? a.pyr[2] + pp * (long)h2 * w2 : nullptr;
   _Float16* o3 = a.num_levels > 3 ? a.pyr[3] + pp * (long)h3 * w3 : nullptr;
   char* xp0 = xpose[wave][0];
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
         const int line = 8 * k + (lane >> 3), piece = lane & 7;
         const uint4 d = *reinterpret_cast<const uint4*>(xp0 + line * XPITCH + 16 * piece);
         const int pl = p0 + line;
-        if (pl < HW) *reinterpret_cast<uint4*>(a.pyr[0] + ((long)e * HW + pl) * slice0 + tile_off + 8 * piece) = d;
+        if (pl < HW) *reinterpret_cast<uint4*>(a.pyr[0] + ((long)eo * HW + pl) * slice0 + tile_off + 8 * piece) = d;
       }
     }
     if (a.num_levels > 1 && last_in_group && gy < nty1 && gx < ntx1) {
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
         const int line = 8 * k + (lane >> 3), piece = lane & 7;
         const uint4 d = *reinterpret_cast<const uint4*>(xp1 + line * XPITCH + 16 * piece);
         const int pl = p0 + line;
-        if (pl < HW) *reinterpret_cast<uint4*>(a.pyr[1] + ((long)e * HW + pl) * slice1 + tile_off + 8 * piece) = d;
+        if (pl < HW) *reinterpret_cast<uint4*>(a.pyr[1] + ((long)eo * HW + pl) * slice1 + tile_off + 8 * piece) = d;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next tile overwrites the areas
@@ -493,6 +496,12 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
 extern "C" int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, const int64_t* ii, const int64_t* jj,
                                       void* const* pyr_host, int num_levels, int E, int C, int ht, int wd,
                                       int tiled, void* stream) {
+  return ns_corr_volume_pyramid_slots(fmap1, fmap2, ii, jj, pyr_host, num_levels, E, C, ht, wd, tiled, nullptr, stream);
+}
+
+extern "C" int ns_corr_volume_pyramid_slots(const void* fmap1, const void* fmap2, const int64_t* ii, const int64_t* jj,
+                                            void* const* pyr_host, int num_levels, int E, int C, int ht, int wd,
+                                            int tiled, const int* slot, void* stream) {
   if (E == 0) return NS_OK;  // an empty set is a no-op whatever the pointers are
   NS_REQUIRE(fmap1 && fmap2 && pyr_host, "ns_corr_volume_pyramid: null pointer");
   NS_REQUIRE(num_levels >= 1 && num_levels <= 4, "ns_corr_volume_pyramid: num_levels=%d not in 1..4", num_levels);
@@ -518,6 +527,7 @@ extern "C" int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, cons
   a.wd = wd;
   a.num_levels = num_levels;
   a.tiled = tiled ? 1 : 0;
+  a.slot = slot;
   const int HW = ht * wd;
   // The sweep over the target image is latency bound per wave (16 dependent 16-byte loads per 8x8
   // block); split it over 8-row bands until ~4 workgroups per CU are in flight.

@@ -14,6 +14,18 @@
 
 #include "common.h"
 
+// Device control block of the graph-captured training step (nerfslam/ngp.py): the values a step needs from the
+// previous one live in device memory, so that a step is a fixed sequence of launches with fixed arguments.
+//   ctl[0] optimiser steps completed   ctl[1] rays of the current batch   ctl[2] ray-sampling seed   ctl[3] training views
+// A kernel given `ctl` reads its ray count / step / view count from it (bounded by the by-value argument, which then
+// is the CAPACITY its grid was sized for); ctl == nullptr keeps the by-value behaviour.
+#define NS_CTL_STEP 0
+#define NS_CTL_RAYS 1
+#define NS_CTL_SEED 2
+#define NS_CTL_VIEWS 3
+#define NS_CTL_C1 4  // float bits: 1 - beta1^(ctl[0] + 1), 1 - beta2^(ctl[0] + 1) of the model's Adam (written by ns_ngp_step_advance)
+#define NS_CTL_C2 5
+
 struct GridCfg {
   int n_levels, n_features, log2_hashmap, base_res;
   float per_level_scale;
@@ -266,6 +278,447 @@ __global__ __launch_bounds__(256) void ngp_encode_bwd_kernel(GridLayout g, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Encode backward WITHOUT global atomics (round 2; what ns_ngp_encode_backward launches).
+//
+// Why: on this 8-XCD part a global atomic is executed at the memory side (the per-XCD L2s are not coherent: an atomic
+// drops the line from L2 and travels the fabric), so the scatter above is bound by the fabric's atomic rate -- 0.35-0.75 ms
+// per 2^18 samples and scene dependent (hot cells serialise).  Here every table entry is OWNED by exactly one workgroup:
+// a task = (level, slice of <= 16384 consecutive entries = 128 KB of LDS); the workgroup scans ALL samples of the level,
+// recomputes the 8 corner indices (a dozen integer ops each), and accumulates the corners that fall into its slice with
+// LDS atomics (ds_add_u64 on the packed fixed-point word / ds_add_f32 pairs); at the end the slice leaves with plain
+// coalesced read-modify-writes of its non-zero entries.  32 slices per hashed level -> the index arithmetic is done
+// 32x redundantly (~0.1 us of VALU per sample and level), which is cheaper than one fabric atomic per corner; the samples
+// (12 B position + 4 B gradient per level) are re-read from L2.  Time is independent of how the samples cluster.
+// Dense (coarse) levels have few slices but every sample hits them 8 times, so their tasks are split over NS_ENC_PARTS
+// sample ranges, each with a private LDS slice, merged by (few) global atomics on the non-zero entries; the wave-level
+// run-length reduction of the atomic kernel is kept for them (long runs of lanes in the same cell).
+// Task order: block b serves virtual task (b & 7) * (grid / 8) + (b >> 3): the blocks of one XCD (b % 8, observed
+// placement -- speed only, any placement is correct) work on the same one or two levels, whose gradient rows stay in
+// that XCD's L2.
+// ---------------------------------------------------------------------------------------------
+#define NS_ENC_SLICE 16384
+#define NS_ENC_PARTS 4
+#define NS_ENC_PARTS_BINNED 16
+struct EncBwdPlan {
+  int first[17];   // first virtual task of the k-th level in task order; first[n_levels] = number of tasks
+  int level[16];   // k -> level
+  int slices[16];  // per LEVEL
+  int parts[16];   // per LEVEL
+};
+
+static bool level_is_hashed(const GridLayout& g, int l) {
+  return (uint64_t)g.res[l] * g.res[l] * g.res[l] > (uint64_t)(g.offset[l + 1] - g.offset[l]);
+}
+
+// dense_only: the hashed levels are handled by the binned path below; the dense levels then get more (smaller) parts
+static int enc_bwd_plan_host(const GridLayout& g, int n_levels, EncBwdPlan& p, bool dense_only) {
+  int k = 0, t = 0;
+  for (int l = 0; l < 16; l++) p.slices[l] = p.parts[l] = 0;
+  for (int pass = dense_only ? 1 : 0; pass < 2; pass++)  // hashed (1 part) levels first, then the dense ones
+    for (int l = 0; l < n_levels; l++) {
+      const uint32_t hs = g.offset[l + 1] - g.offset[l];
+      const bool hashed = level_is_hashed(g, l);
+      if (hashed != (pass == 0)) continue;
+      p.slices[l] = (int)((hs + NS_ENC_SLICE - 1) / NS_ENC_SLICE);
+      p.parts[l] = hashed ? 1 : (dense_only ? NS_ENC_PARTS_BINNED : NS_ENC_PARTS);
+      p.level[k] = l;
+      p.first[k] = t;
+      t += p.slices[l] * p.parts[l];
+      k++;
+    }
+  for (; k <= 16; k++) {
+    p.first[k] = t;
+    if (k < 16) p.level[k] = 0;
+  }
+  return t;
+}
+
+template <bool FIXED>
+__global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, EncBwdPlan plan, const float* __restrict__ pos,
+                                                                  const h2_t* __restrict__ dLdout, float* __restrict__ grad,
+                                                                  long N, int L, int n_levels, int unit_major,
+                                                                  float fixed_scale) {
+  __shared__ unsigned long long tab[NS_ENC_SLICE];  // packed fixed-point words, or float2 bit patterns
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = gridDim.x >> 3;
+  const int v = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (v >= plan.first[16]) return;   // first[k] = number of tasks for every k past the planned levels
+  int k = 0;
+  while (v >= plan.first[k + 1]) k++;
+  const int l = plan.level[k];
+  const int local = v - plan.first[k];
+  const int nparts = plan.parts[l];
+  const int slice = local / nparts, part = local - slice * nparts;
+  const uint32_t hs = g.offset[l + 1] - g.offset[l];
+  const uint32_t lo = (uint32_t)slice * NS_ENC_SLICE;
+  const uint32_t cnt = min((uint32_t)NS_ENC_SLICE, hs - lo);
+  const float scale = g.scale[l];
+  const uint32_t res = (uint32_t)g.res[l];
+  const bool hashed = (uint64_t)res * res * res > hs;
+  for (uint32_t e = tid; e < cnt; e += 1024) tab[e] = 0ull;
+  __syncthreads();
+  // sample range of this part, in units of 64-sample wave chunks
+  const long chunks = (N + 63) >> 6;
+  const long c_lo = chunks * part / nparts, c_hi = chunks * (part + 1) / nparts;
+  const _Float16* dpu = reinterpret_cast<const _Float16*>(dLdout);
+  float* tabf = reinterpret_cast<float*>(tab);
+  for (long ch = c_lo + wave; ch < c_hi; ch += 16) {
+    const long i = (ch << 6) + lane;
+    float d0 = 0.0f, d1 = 0.0f;
+    if (i < N) {
+      if (unit_major) {
+        d0 = (float)dpu[(long)(2 * l) * N + i];
+        d1 = (float)dpu[(long)(2 * l + 1) * N + i];
+      } else {
+        const h2_t d = dLdout[i * L + l];
+        d0 = (float)d[0];
+        d1 = (float)d[1];
+      }
+    }
+    const bool valid = d0 != 0.0f || d1 != 0.0f;
+    if (__ballot(valid) == 0ull) continue;
+    float w[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t c[3] = {0u, 0u, 0u};
+    if (valid) {
+#pragma unroll
+      for (int dd = 0; dd < 3; dd++) {
+        const float p = fmaf(scale, pos[i * 3 + dd], 0.5f);
+        const float fl = floorf(p);
+        c[dd] = (uint32_t)(int)fl;
+        w[dd] = p - fl;
+      }
+    }
+    if (hashed) {
+      // idx = (x ^ y P1 ^ z P2) & (hs - 1): the 8 corners share the six partial products
+      const uint32_t hx[2] = {c[0], c[0] + 1u};
+      const uint32_t hy0 = c[1] * 2654435761u, hz0 = c[2] * 805459861u;
+      const uint32_t hy[2] = {hy0, hy0 + 2654435761u};
+      const uint32_t hz[2] = {hz0, hz0 + 805459861u};
+      const float wx[2] = {1.0f - w[0], w[0]}, wy[2] = {1.0f - w[1], w[1]}, wz[2] = {1.0f - w[2], w[2]};
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) {
+        const uint32_t idx = (hx[corner & 1] ^ hy[(corner >> 1) & 1] ^ hz[corner >> 2]) & (hs - 1u);
+        const uint32_t rel = idx - lo;
+        if (valid && rel < cnt) {
+          const float wt = wx[corner & 1] * wy[(corner >> 1) & 1] * wz[corner >> 2];
+          if (FIXED) {
+            atomicAdd(&tab[rel], pack_fixed(wt * d0, wt * d1, fixed_scale));
+          } else {
+            atomicAdd(&tabf[2 * rel], wt * d0);
+            atomicAdd(&tabf[2 * rel + 1], wt * d1);
+          }
+        }
+      }
+      continue;
+    }
+    // dense level: run-length reduction over lanes in the same cell, then the run's last lane adds
+    float val[16];
+#pragma unroll
+    for (int corner = 0; corner < 8; corner++) {
+      float wt = 1.0f;
+      wt *= (corner & 1) ? w[0] : 1.0f - w[0];
+      wt *= (corner & 2) ? w[1] : 1.0f - w[1];
+      wt *= (corner & 4) ? w[2] : 1.0f - w[2];
+      val[corner * 2] = wt * d0;
+      val[corner * 2 + 1] = wt * d1;
+    }
+    const uint32_t p0 = __shfl_up(c[0], 1), p1 = __shfl_up(c[1], 1), p2 = __shfl_up(c[2], 1);
+    const int pv = __shfl_up((int)valid, 1);
+    const bool head = lane == 0 || !valid || !pv || p0 != c[0] || p1 != c[1] || p2 != c[2];
+    const uint64_t hm = __ballot(head);
+    bool issue = valid;
+    if (__popcll(hm) <= 40) {
+      const int start = 63 - __clzll(hm & (~0ull >> (63 - lane)));
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const bool take = lane - d >= start;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const float u = __shfl_up(val[q], d);
+          if (take) val[q] += u;
+        }
+      }
+      issue = valid && (lane == 63 || ((hm >> (lane + 1)) & 1ull));
+    }
+    if (issue) {
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) {
+        const uint32_t idx = grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2));
+        const uint32_t rel = idx - lo;
+        if (rel < cnt) {
+          if (FIXED) {
+            atomicAdd(&tab[rel], pack_fixed(val[corner * 2], val[corner * 2 + 1], fixed_scale));
+          } else {
+            atomicAdd(&tabf[2 * rel], val[corner * 2]);
+            atomicAdd(&tabf[2 * rel + 1], val[corner * 2 + 1]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // flush: this workgroup is the only writer of its entries (nparts == 1) -> plain read-modify-write of the non-zero ones
+  unsigned long long* __restrict__ g64 = reinterpret_cast<unsigned long long*>(grad) + g.offset[l] + lo;
+  for (uint32_t e = tid; e < cnt; e += 1024) {
+    const unsigned long long word = tab[e];
+    if (word == 0ull) continue;
+    if (FIXED) {
+      if (nparts == 1) g64[e] += word; else atomicAdd(&g64[e], word);
+    } else {
+      float* gp = reinterpret_cast<float*>(g64 + e);
+      const float a = __builtin_bit_cast(float, (uint32_t)(word & 0xffffffffull));
+      const float b = __builtin_bit_cast(float, (uint32_t)(word >> 32));
+      if (nparts == 1) {
+        gp[0] += a;
+        gp[1] += b;
+      } else {
+        atomicAdd(&gp[0], a);
+        atomicAdd(&gp[1], b);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encode backward, hashed levels, BINNED (what ns_ngp_encode_backward launches when it is given a workspace).
+//
+// The owner-computes kernel above re-derives the corner indices of every sample in each of the 32 slice owners of a level:
+// ~0.5 ms of integer VALU per step on the twelve hashed levels.  Binning does that arithmetic twice instead of 32 times:
+//   count    a workgroup takes a tile of 1024 samples of one level, histograms the 8 x 1024 corner indices over the level's
+//            bins (bin = index >> 14 = the 16384-entry table slice), and reserves the tile's range in every bin with ONE
+//            returning atomic per bin (tile offsets in arrival order: the sums below are integer, hence order independent);
+//   scatter  the same tile again: every (sample, corner) becomes a 64-bit record [14-bit index in the slice | two 25-bit
+//            Q18 gradient fields], ranked inside its bin through LDS, staged bin-sorted in LDS and written out as contiguous
+//            runs (whole 128-byte lines);
+//   accum    one workgroup per (level, bin) streams its records, accumulates them in its 128-KB LDS slice (ds_add_u64) and
+//            flushes the non-zero entries with plain read-modify-writes (it is the only writer of its slice).
+// Traffic: 8 B written + 8 B read per (sample, corner) on the hashed levels (~0.4 GB per 2^18 samples), all of it
+// coalesced streams; no global atomics on table entries; bit-identical to the atomic and the owner-computes kernels
+// (same per-contribution rounding; the 25-bit fields saturate at |g| >= 64 gradient units, loss_scale included).
+// ---------------------------------------------------------------------------------------------
+#define NS_BIN_TILE 1024
+#define NS_BIN_MAX 32
+struct BinPlan {
+  int nh;            // hashed levels
+  int level[16];     // k -> level
+  int nbins[16];     // k -> bins of the level (table entries / 16384, at least 1)
+  int ntiles;        // ceil(N / 1024)
+};
+
+static void bin_plan_host(const GridLayout& g, int n_levels, long N, BinPlan& b) {
+  b.nh = 0;
+  for (int l = 0; l < n_levels; l++) {
+    if (!level_is_hashed(g, l)) continue;
+    const uint32_t hs = g.offset[l + 1] - g.offset[l];
+    b.level[b.nh] = l;
+    b.nbins[b.nh] = (int)((hs + NS_ENC_SLICE - 1) / NS_ENC_SLICE);
+    b.nh++;
+  }
+  for (int k = b.nh; k < 16; k++) b.level[k] = b.nbins[k] = 0;
+  b.ntiles = (int)((N + NS_BIN_TILE - 1) / NS_BIN_TILE);
+}
+
+static bool bin_plan_ok(const BinPlan& b) {
+  if (b.nh == 0) return false;
+  for (int k = 0; k < b.nh; k++)
+    if (b.nbins[k] > NS_BIN_MAX) return false;
+  return true;
+}
+
+// workspace layout (bytes): [tot: nh*32 int32 (kept zero between calls)] [cnt: nh*ntiles*32 int2 {count, offset}] [queue]
+static size_t bin_ws_tot_bytes(const BinPlan& b) { return ((size_t)b.nh * NS_BIN_MAX * 4 + 255) / 256 * 256; }
+static size_t bin_ws_cnt_bytes(const BinPlan& b) { return ((size_t)b.nh * b.ntiles * NS_BIN_MAX * 8 + 255) / 256 * 256; }
+static size_t bin_ws_bytes(const BinPlan& b, long N) {
+  return bin_ws_tot_bytes(b) + bin_ws_cnt_bytes(b) + (size_t)b.nh * 8 * (size_t)(b.ntiles * (long)NS_BIN_TILE) * 8;
+}
+
+struct BinSample {
+  bool valid;
+  uint32_t idx[8];
+  float wx[2], wy[2], wz[2], d0, d1;
+};
+
+__device__ __forceinline__ BinSample bin_sample(const GridLayout& g, int l, uint32_t hs, const float* __restrict__ pos,
+                                                const h2_t* __restrict__ dLdout, long i, long N, int L, int unit_major) {
+  BinSample s;
+  s.d0 = s.d1 = 0.0f;
+  if (i < N) {
+    if (unit_major) {
+      const _Float16* dp = reinterpret_cast<const _Float16*>(dLdout);
+      s.d0 = (float)dp[(long)(2 * l) * N + i];
+      s.d1 = (float)dp[(long)(2 * l + 1) * N + i];
+    } else {
+      const h2_t d = dLdout[i * L + l];
+      s.d0 = (float)d[0];
+      s.d1 = (float)d[1];
+    }
+  }
+  s.valid = s.d0 != 0.0f || s.d1 != 0.0f;
+  if (!s.valid) return s;
+  const float scale = g.scale[l];
+  uint32_t c[3];
+  float w[3];
+#pragma unroll
+  for (int dd = 0; dd < 3; dd++) {
+    const float p = fmaf(scale, pos[i * 3 + dd], 0.5f);
+    const float fl = floorf(p);
+    c[dd] = (uint32_t)(int)fl;
+    w[dd] = p - fl;
+  }
+  s.wx[0] = 1.0f - w[0]; s.wx[1] = w[0];
+  s.wy[0] = 1.0f - w[1]; s.wy[1] = w[1];
+  s.wz[0] = 1.0f - w[2]; s.wz[1] = w[2];
+  const uint32_t hx[2] = {c[0], c[0] + 1u};
+  const uint32_t hy0 = c[1] * 2654435761u, hz0 = c[2] * 805459861u;
+  const uint32_t hy[2] = {hy0, hy0 + 2654435761u};
+  const uint32_t hz[2] = {hz0, hz0 + 805459861u};
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++)
+    s.idx[corner] = (hx[corner & 1] ^ hy[(corner >> 1) & 1] ^ hz[corner >> 2]) % hs;
+  return s;
+}
+
+__global__ __launch_bounds__(256) void ngp_enc_bin_count_kernel(GridLayout g, BinPlan bp, const float* __restrict__ pos,
+                                                                const h2_t* __restrict__ dLdout, long N, int L, int unit_major,
+                                                                int* __restrict__ tot, int2* __restrict__ cnt) {
+  __shared__ int hist[NS_BIN_MAX];
+  const int k = blockIdx.y, l = bp.level[k], tile = blockIdx.x, tid = threadIdx.x;
+  const uint32_t hs = g.offset[l + 1] - g.offset[l];
+  if (tid < NS_BIN_MAX) hist[tid] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NS_BIN_TILE / 256; j++) {
+    const long i = (long)tile * NS_BIN_TILE + j * 256 + tid;
+    const BinSample s = bin_sample(g, l, hs, pos, dLdout, i, N, L, unit_major);
+    if (s.valid) {
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) atomicAdd(&hist[s.idx[corner] >> 14], 1);
+    }
+  }
+  __syncthreads();
+  if (tid < NS_BIN_MAX) {
+    const int c = hist[tid];
+    const int off = c > 0 ? atomicAdd(&tot[k * NS_BIN_MAX + tid], c) : 0;   // the tile's range in the bin (arrival order)
+    cnt[((long)k * bp.ntiles + tile) * NS_BIN_MAX + tid] = make_int2(c, off);
+  }
+}
+
+__device__ __forceinline__ unsigned long long bin_record(uint32_t rel, float g0, float g1, float S) {
+  const float lim = 16777215.0f;   // 25-bit signed fields
+  const int a = (int)__float2int_rn(fminf(fmaxf(g0 * S, -lim), lim));
+  const int b = (int)__float2int_rn(fminf(fmaxf(g1 * S, -lim), lim));
+  return ((unsigned long long)rel << 50) | ((unsigned long long)((uint32_t)b & 0x1ffffffu) << 25) |
+         (unsigned long long)((uint32_t)a & 0x1ffffffu);
+}
+
+__global__ __launch_bounds__(256) void ngp_enc_bin_scatter_kernel(GridLayout g, BinPlan bp, const float* __restrict__ pos,
+                                                                  const h2_t* __restrict__ dLdout, long N, int L, int unit_major,
+                                                                  float fixed_scale, const int* __restrict__ tot,
+                                                                  const int2* __restrict__ cnt,
+                                                                  unsigned long long* __restrict__ queue) {
+  __shared__ unsigned long long rec[8 * NS_BIN_TILE];   // 64 KB: the tile's records, bin-sorted
+  __shared__ int lbase[NS_BIN_MAX + 1], lcnt[NS_BIN_MAX], gdst[NS_BIN_MAX];
+  const int k = blockIdx.y, l = bp.level[k], tile = blockIdx.x, tid = threadIdx.x;
+  const uint32_t hs = g.offset[l + 1] - g.offset[l];
+  if (tid < 64) {  // one wave: prefix sums over the 32 bins (tile counts -> LDS bases, bin totals -> queue bases)
+    const int b = tid & 31;
+    const int2 co = cnt[((long)k * bp.ntiles + tile) * NS_BIN_MAX + b];
+    int c = co.x, t = tot[k * NS_BIN_MAX + b];
+    int ci = c, ti = t;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const int uc = __shfl_up(ci, d, 32), ut = __shfl_up(ti, d, 32);
+      if (b >= d) { ci += uc; ti += ut; }
+    }
+    if (tid < 32) {
+      lbase[b] = ci - c;
+      if (b == 31) lbase[32] = ci;
+      lcnt[b] = 0;
+      gdst[b] = (ti - t) + co.y;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NS_BIN_TILE / 256; j++) {
+    const long i = (long)tile * NS_BIN_TILE + j * 256 + tid;
+    const BinSample s = bin_sample(g, l, hs, pos, dLdout, i, N, L, unit_major);
+    if (s.valid) {
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) {
+        const uint32_t idx = s.idx[corner];
+        const int b = (int)(idx >> 14);
+        const int r = atomicAdd(&lcnt[b], 1);
+        const float wt = s.wx[corner & 1] * s.wy[(corner >> 1) & 1] * s.wz[corner >> 2];
+        rec[lbase[b] + r] = bin_record(idx & 16383u, wt * s.d0, wt * s.d1, fixed_scale);
+      }
+    }
+  }
+  __syncthreads();
+  const int total = lbase[32];
+  unsigned long long* __restrict__ q = queue + (long)k * 8 * ((long)bp.ntiles * NS_BIN_TILE);
+  for (int e = tid; e < total; e += 256) {
+    int b = 0;  // bin of staged record e: largest b with lbase[b] <= e (5-step binary search over the LDS table)
+#pragma unroll
+    for (int step = 16; step >= 1; step >>= 1)
+      if (b + step < NS_BIN_MAX && lbase[b + step] <= e) b += step;
+    q[(long)gdst[b] + (e - lbase[b])] = rec[e];
+  }
+}
+
+__global__ __launch_bounds__(1024) void ngp_enc_bin_accum_kernel(GridLayout g, BinPlan bp, const int* __restrict__ tot,
+                                                                 const unsigned long long* __restrict__ queue,
+                                                                 float* __restrict__ grad) {
+  __shared__ unsigned long long tab[NS_ENC_SLICE];
+  __shared__ int s_base, s_tot;
+  const int k = blockIdx.y, l = bp.level[k], b = blockIdx.x, tid = threadIdx.x;
+  if (b >= bp.nbins[k]) return;
+  const uint32_t hs = g.offset[l + 1] - g.offset[l];
+  const uint32_t lo = (uint32_t)b * NS_ENC_SLICE;
+  const uint32_t n_e = min((uint32_t)NS_ENC_SLICE, hs - lo);
+  for (uint32_t e = tid; e < NS_ENC_SLICE; e += 1024) tab[e] = 0ull;
+  if (tid < 64) {
+    const int bb = tid & 31;
+    const int t = tot[k * NS_BIN_MAX + bb];
+    int ti = t;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const int ut = __shfl_up(ti, d, 32);
+      if (bb >= d) ti += ut;
+    }
+    if (tid == b) {
+      s_base = ti - t;
+      s_tot = t;
+    }
+  }
+  __syncthreads();
+  const unsigned long long* __restrict__ q = queue + (long)k * 8 * ((long)bp.ntiles * NS_BIN_TILE) + s_base;
+  const int n = s_tot;
+  for (int e0 = 0; e0 < n; e0 += 4 * 1024) {
+    unsigned long long r[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * 1024 + tid;
+      r[u] = e < n ? q[e] : ~0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (e0 + u * 1024 + tid < n) {
+        const uint32_t rel = (uint32_t)(r[u] >> 50);
+        const long long a = ((long long)(r[u] << 39)) >> 39;          // sign-extended 25-bit fields
+        const long long c = ((long long)(r[u] << 14)) >> 39;
+        atomicAdd(&tab[rel], (unsigned long long)(a + (c << 32)));
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long* __restrict__ g64 = reinterpret_cast<unsigned long long*>(grad) + g.offset[l] + lo;
+  for (uint32_t e = tid; e < n_e; e += 1024) {
+    const unsigned long long word = tab[e];
+    if (word != 0ull) g64[e] += word;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Camera-pose refinement (`optimize_extrinsics`, nerf_fusion.py:99,123 [EXTERNAL arithmetic: instant-ngp]).
 //   dL/dpos of every sample  = the encoding's input gradient (trilinear weights differentiated),
 //   per ray:  g_o = sum dL/dpos,   g_d = sum t * dL/dpos            (pos = o + t d)
@@ -321,9 +774,11 @@ __global__ __launch_bounds__(256) void ngp_camera_grad_kernel(const float* __res
                                                               const float* __restrict__ rays_d,
                                                               const int* __restrict__ ray_start, const int* __restrict__ ray_n,
                                                               const int* __restrict__ ray_img, float pos_inv,
-                                                              float* __restrict__ cam_grad, int R) {
+                                                              float* __restrict__ cam_grad, int Rcap,
+                                                              const int* __restrict__ ctl) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int R = ctl ? min(ctl[NS_CTL_RAYS], Rcap) : Rcap;
   if (r >= R) return;
   const int s0 = ray_start[r], n = ray_n[r];
   if (n <= 0) return;
@@ -353,8 +808,14 @@ __global__ __launch_bounds__(256) void ngp_camera_grad_kernel(const float* __res
 __global__ __launch_bounds__(64) void ngp_camera_step_kernel(float* __restrict__ c2w, float* __restrict__ cam_grad,
                                                              float* __restrict__ m1, float* __restrict__ m2, int n, float c1,
                                                              float c2, float lr_pos, float lr_rot, float beta1, float beta2,
-                                                             float eps, float inv_grad_scale) {
+                                                             float eps, float inv_grad_scale, const int* __restrict__ ctl) {
   const int i = blockIdx.x * 64 + threadIdx.x;
+  if (ctl) {  // graph-captured step: view count and bias corrections from the device control block
+    n = min(n, ctl[NS_CTL_VIEWS]);
+    const float st = (float)(ctl[NS_CTL_STEP] + 1);
+    c1 = 1.0f - powf(beta1, st);
+    c2 = 1.0f - powf(beta2, st);
+  }
   if (i >= n) return;
   float step[6];
   bool any = false;
@@ -405,9 +866,14 @@ __global__ __launch_bounds__(256) void ngp_adam_kernel(float* __restrict__ maste
                                                        float* __restrict__ grad, float* __restrict__ m1,
                                                        float* __restrict__ m2, long n, float c1, float c2, float lr,
                                                        float beta1, float beta2, float eps, float l2,
-                                                       float inv_grad_scale, float inv_fixed_scale) {
+                                                       float inv_grad_scale, float inv_fixed_scale,
+                                                       const int* __restrict__ ctl) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  if (ctl) {  // graph-captured step: bias corrections of step ctl[0] + 1, precomputed by ns_ngp_step_advance
+    c1 = __int_as_float(ctl[NS_CTL_C1]);
+    c2 = __int_as_float(ctl[NS_CTL_C2]);
+  }
   float g;
   if (inv_fixed_scale > 0.0f) {  // packed fixed-point pairs (see pack_fixed): both lanes of a pair read the word
     float g0, g1;
@@ -453,13 +919,18 @@ struct SampleRaysArgs {
   uint32_t seed;
   float *rays_o, *rays_d, *t_range, *gt_rgb, *gt_depth, *gt_cov;
   int* ray_img;  // optional [R]: image index of every ray (camera-pose refinement)
+  const int* ctl;
 };
 
 __global__ __launch_bounds__(256) void ngp_sample_rays_kernel(SampleRaysArgs a) {
   const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= a.R) return;
-  const uint32_t base = a.seed + (uint32_t)r * 3u;
-  const int img = (int)(ns_pcg(base) % (uint32_t)a.n);
+  const int R = a.ctl ? min(a.ctl[NS_CTL_RAYS], a.R) : a.R;
+  if (r >= R) return;
+  // same seed schedule as the host path (nerfslam/ngp.py): seed * 0x9E3779B1 + step * 0x85EBCA77
+  const uint32_t seed = a.ctl ? (uint32_t)a.ctl[NS_CTL_SEED] * 0x9E3779B1u + (uint32_t)a.ctl[NS_CTL_STEP] * 0x85EBCA77u : a.seed;
+  const int nimg = a.ctl ? a.ctl[NS_CTL_VIEWS] : a.n;
+  const uint32_t base = seed + (uint32_t)r * 3u;
+  const int img = (int)(ns_pcg(base) % (uint32_t)nimg);
   const int u = (int)(ns_pcg(base + 1u) % (uint32_t)a.W);
   const int v = (int)(ns_pcg(base + 2u) % (uint32_t)a.H);
   const float* M = a.c2w + (long)img * 12;
@@ -537,6 +1008,7 @@ struct MarchArgs {
   float* dt;             // [max_samples]
   float* tmid;           // [max_samples]
   int R;
+  const int* ctl;
 };
 
 // Ray marching, 16 lanes per ray (one DPP row), 4 rays per wave.
@@ -611,8 +1083,10 @@ __device__ __forceinline__ int row_inclusive_sum(int v, int sub) {  // over the 
 __global__ __launch_bounds__(256) void ngp_march_kernel(MarchArgs a) {
   const int sub = threadIdx.x & 15;
   const int r = blockIdx.x * 16 + (threadIdx.x >> 4);
-  const bool live = r < a.R;          // row-uniform; dead rows run with an empty interval
-  const int rr = live ? r : a.R - 1;
+  const int R = a.ctl ? min(a.ctl[NS_CTL_RAYS], a.R) : a.R;
+  if ((int)blockIdx.x * 16 >= R) return;  // workgroup-uniform: the grid is sized for the capacity
+  const bool live = r < R;            // row-uniform; dead rows run with an empty interval
+  const int rr = live ? r : R - 1;
   MarchRay ry{a.rays_o[rr * 3], a.rays_o[rr * 3 + 1], a.rays_o[rr * 3 + 2],
               a.rays_d[rr * 3], a.rays_d[rr * 3 + 1], a.rays_d[rr * 3 + 2], 0.0f};
   const float t0 = a.t_range[rr * 2];
@@ -743,6 +1217,7 @@ struct CompositeArgs {
   float* loss;       // [1] accumulated sum over rays of the per-ray loss (caller zeroes, divides by R)
   _Float16* dLdout;  // [S,4] or null (inference)
   int R;
+  const int* ctl;
 };
 
 __device__ __forceinline__ float wave_incl_sum(float v, int lane) {
@@ -789,7 +1264,8 @@ __device__ __forceinline__ CompSample comp_load(const CompositeArgs& a, long s, 
 __global__ __launch_bounds__(256) void ngp_composite_kernel(CompositeArgs a) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= a.R) return;  // wave-uniform
+  const int R = a.ctl ? min(a.ctl[NS_CTL_RAYS], a.R) : a.R;
+  if (r >= R) return;  // wave-uniform
   const int s0 = a.ray_start[r], n = a.ray_n[r];
   float Tin = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, D = 0.0f;
   for (int k0 = 0; k0 < n; k0 += 64) {
@@ -823,7 +1299,7 @@ __global__ __launch_bounds__(256) void ngp_composite_kernel(CompositeArgs a) {
     dD = a.depth_lambda * 2.0f * ed * icov;
   }
   if (lane == 0) atomicAdd(a.loss, l);
-  const float sc = a.loss_scale / (float)a.R;
+  const float sc = a.loss_scale / (float)R;
   Tin = 1.0f;
   float P0 = 0.0f, P1 = 0.0f, P2 = 0.0f, PD = 0.0f;  // prefix sums carried across rounds
   for (int k0 = 0; k0 < n; k0 += 64) {
@@ -921,13 +1397,17 @@ __global__ __launch_bounds__(256) void ngp_encode_bwd_reduce_kernel(GridLayout g
 }
 
 extern "C" long ns_ngp_encode_backward_workspace_bytes(int n_levels, int n_features, int log2_hashmap, int base_res,
-                                                       float per_level_scale) {
+                                                       float per_level_scale, long max_samples) {
   GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
   GridLayout g;
   if (grid_layout_host(c, g) != NS_OK) return -1;
   ReplicaPlan rp;
   replica_plan_host(g, n_levels, rp);
-  return (long)(rp.total_floats * sizeof(float));
+  BinPlan bp;
+  bin_plan_host(g, n_levels, max_samples > 0 ? max_samples : 1, bp);
+  const size_t bin = bin_plan_ok(bp) ? bin_ws_bytes(bp, max_samples) : 0;
+  const size_t rep_b = rp.total_floats * sizeof(float);   // (round-1 atomic path, NS_ENC_BWD_ATOMIC)
+  return (long)(bin > rep_b ? bin : rep_b);
 }
 
 extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_hashmap, int base_res,
@@ -942,17 +1422,48 @@ extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_has
     return NS_ENOSUP;
   }
   if (N <= 0) return NS_OK;
+  static const bool atomic_path = getenv("NS_ENC_BWD_ATOMIC") != nullptr;  // round-1 kernel, kept for A/B profiling
+  if (!atomic_path) {
+    static const bool no_bins = getenv("NS_ENC_BWD_NO_BINS") != nullptr;   // A/B switch: owner-computes kernel on every level
+    BinPlan bp;
+    bin_plan_host(g, n_levels, N, bp);
+    const bool binned = workspace != nullptr && fixed_scale > 0.0f && bin_plan_ok(bp) && !no_bins;
+    EncBwdPlan plan;
+    const int tasks = enc_bwd_plan_host(g, n_levels, plan, binned);
+    const int blocks = (tasks + 7) / 8 * 8;
+    if (binned) {
+      int* tot = reinterpret_cast<int*>(workspace);
+      int2* cnt = reinterpret_cast<int2*>(reinterpret_cast<char*>(workspace) + bin_ws_tot_bytes(bp));
+      unsigned long long* queue = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) +
+                                                                        bin_ws_tot_bytes(bp) + bin_ws_cnt_bytes(bp));
+      if (hipMemsetAsync(tot, 0, bin_ws_tot_bytes(bp), (hipStream_t)stream) != hipSuccess) {
+        ns_set_error("ns_ngp_encode_backward: clearing the bin counters failed");
+        return NS_ELAUNCH;
+      }
+      hipLaunchKernelGGL(ngp_enc_bin_count_kernel, dim3(bp.ntiles, bp.nh), dim3(256), 0, (hipStream_t)stream, g, bp, positions,
+                         (const h2_t*)dLdout, N, n_levels, unit_major, tot, cnt);
+      NS_CHECK_LAUNCH("ngp_enc_bin_count_kernel");
+      hipLaunchKernelGGL(ngp_enc_bin_scatter_kernel, dim3(bp.ntiles, bp.nh), dim3(256), 0, (hipStream_t)stream, g, bp, positions,
+                         (const h2_t*)dLdout, N, n_levels, unit_major, fixed_scale, tot, cnt, queue);
+      NS_CHECK_LAUNCH("ngp_enc_bin_scatter_kernel");
+      hipLaunchKernelGGL(ngp_enc_bin_accum_kernel, dim3(NS_BIN_MAX, bp.nh), dim3(1024), 0, (hipStream_t)stream, g, bp, tot, queue,
+                         grad_params);
+      NS_CHECK_LAUNCH("ngp_enc_bin_accum_kernel");
+      if (tasks == 0) return NS_OK;
+    }
+    if (fixed_scale > 0.0f)
+      hipLaunchKernelGGL(ngp_encode_bwd_lds_kernel<true>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
+                         (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale);
+    else
+      hipLaunchKernelGGL(ngp_encode_bwd_lds_kernel<false>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
+                         (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale);
+    NS_CHECK_LAUNCH("ngp_encode_bwd_lds_kernel");
+    return NS_OK;
+  }
   ReplicaPlan rp;
   replica_plan_host(g, n_levels, rp);
-  static const bool per_level = getenv("NS_PROFILE_PER_LEVEL") != nullptr;  // one launch per level, for rocprof only
-  if (per_level) {
-    for (int l = 0; l < n_levels; l++)
-      hipLaunchKernelGGL(ngp_encode_bwd_kernel, dim3(ns_cdiv(N, 256), 1), dim3(256), 0, (hipStream_t)stream, g,
-                         positions, (const h2_t*)dLdout, grad_params, N, n_levels, l, rp, workspace, unit_major, fixed_scale);
-  } else {
-    hipLaunchKernelGGL(ngp_encode_bwd_kernel, dim3(ns_cdiv(N, 256), n_levels), dim3(256), 0, (hipStream_t)stream, g,
-                       positions, (const h2_t*)dLdout, grad_params, N, n_levels, 0, rp, workspace, unit_major, fixed_scale);
-  }
+  hipLaunchKernelGGL(ngp_encode_bwd_kernel, dim3(ns_cdiv(N, 256), n_levels), dim3(256), 0, (hipStream_t)stream, g,
+                     positions, (const h2_t*)dLdout, grad_params, N, n_levels, 0, rp, workspace, unit_major, fixed_scale);
   NS_CHECK_LAUNCH("ngp_encode_bwd_kernel");
   if (workspace != nullptr && rp.total_floats > 0) {
     hipLaunchKernelGGL(ngp_encode_bwd_reduce_kernel, dim3(256, n_levels), dim3(256), 0, (hipStream_t)stream, g, rp,
@@ -965,14 +1476,21 @@ extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_has
 extern "C" int ns_ngp_adam(float* master, void* half_params, float* grad, float* m1, float* m2, long n, int step,
                            float lr, float beta1, float beta2, float eps, float l2, float grad_scale,
                            float fixed_scale, void* stream) {
+  return ns_ngp_adam_ctl(master, half_params, grad, m1, m2, n, step, lr, beta1, beta2, eps, l2, grad_scale, fixed_scale,
+                         nullptr, stream);
+}
+
+extern "C" int ns_ngp_adam_ctl(float* master, void* half_params, float* grad, float* m1, float* m2, long n, int step,
+                               float lr, float beta1, float beta2, float eps, float l2, float grad_scale,
+                               float fixed_scale, const int* ctl, void* stream) {
   NS_REQUIRE(master && half_params && grad && m1 && m2, "ns_ngp_adam: null pointer");
-  NS_REQUIRE(step >= 1 && grad_scale > 0.0f, "ns_ngp_adam: step must be >= 1 and grad_scale > 0");
+  NS_REQUIRE((ctl || step >= 1) && grad_scale > 0.0f, "ns_ngp_adam: step must be >= 1 and grad_scale > 0");
   NS_REQUIRE(fixed_scale == 0.0f || n % 2 == 0, "ns_ngp_adam: packed gradients come in pairs");
   if (n <= 0) return NS_OK;
-  const float c1 = 1.0f - powf(beta1, (float)step), c2 = 1.0f - powf(beta2, (float)step);
+  const float c1 = 1.0f - powf(beta1, (float)(step < 1 ? 1 : step)), c2 = 1.0f - powf(beta2, (float)(step < 1 ? 1 : step));
   hipLaunchKernelGGL(ngp_adam_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, master,
                      (_Float16*)half_params, grad, m1, m2, n, c1, c2, lr, beta1, beta2, eps, l2, 1.0f / grad_scale,
-                     fixed_scale > 0.0f ? 1.0f / fixed_scale : 0.0f);
+                     fixed_scale > 0.0f ? 1.0f / fixed_scale : 0.0f, ctl);
   NS_CHECK_LAUNCH("ngp_adam_kernel");
   return NS_OK;
 }
@@ -997,22 +1515,36 @@ extern "C" int ns_ngp_encode_backward_input(int n_levels, int n_features, int lo
 extern "C" int ns_ngp_camera_gradient(const float* dLdpos, const float* tmid, const float* rays_d, const int* ray_start,
                                       const int* ray_n, const int* ray_img, float pos_inv, float* cam_grad, int R,
                                       void* stream) {
+  return ns_ngp_camera_gradient_ctl(dLdpos, tmid, rays_d, ray_start, ray_n, ray_img, pos_inv, cam_grad, R, nullptr, stream);
+}
+
+extern "C" int ns_ngp_camera_gradient_ctl(const float* dLdpos, const float* tmid, const float* rays_d, const int* ray_start,
+                                          const int* ray_n, const int* ray_img, float pos_inv, float* cam_grad, int R,
+                                          const int* ctl, void* stream) {
   NS_REQUIRE(dLdpos && tmid && rays_d && ray_start && ray_n && ray_img && cam_grad, "ns_ngp_camera_gradient: null pointer");
   if (R <= 0) return NS_OK;
   hipLaunchKernelGGL(ngp_camera_grad_kernel, dim3(ns_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, dLdpos, tmid, rays_d,
-                     ray_start, ray_n, ray_img, pos_inv, cam_grad, R);
+                     ray_start, ray_n, ray_img, pos_inv, cam_grad, R, ctl);
   NS_CHECK_LAUNCH("ngp_camera_grad_kernel");
   return NS_OK;
 }
 
 extern "C" int ns_ngp_camera_step(float* c2w, float* cam_grad, float* m1, float* m2, int n_images, int step, float lr_pos,
                                   float lr_rot, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  return ns_ngp_camera_step_ctl(c2w, cam_grad, m1, m2, n_images, step, lr_pos, lr_rot, beta1, beta2, eps, grad_scale, nullptr,
+                                stream);
+}
+
+extern "C" int ns_ngp_camera_step_ctl(float* c2w, float* cam_grad, float* m1, float* m2, int n_images, int step, float lr_pos,
+                                      float lr_rot, float beta1, float beta2, float eps, float grad_scale, const int* ctl,
+                                      void* stream) {
   NS_REQUIRE(c2w && cam_grad && m1 && m2, "ns_ngp_camera_step: null pointer");
-  NS_REQUIRE(step >= 1 && grad_scale > 0.0f, "ns_ngp_camera_step: step must be >= 1 and grad_scale > 0");
+  NS_REQUIRE((ctl || step >= 1) && grad_scale > 0.0f, "ns_ngp_camera_step: step must be >= 1 and grad_scale > 0");
   if (n_images <= 0) return NS_OK;
-  const float c1 = 1.0f - powf(beta1, (float)step), c2 = 1.0f - powf(beta2, (float)step);
+  const float st = (float)(step < 1 ? 1 : step);
+  const float c1 = 1.0f - powf(beta1, st), c2 = 1.0f - powf(beta2, st);
   hipLaunchKernelGGL(ngp_camera_step_kernel, dim3(ns_cdiv(n_images, 64)), dim3(64), 0, (hipStream_t)stream, c2w, cam_grad,
-                     m1, m2, n_images, c1, c2, lr_pos, lr_rot, beta1, beta2, eps, 1.0f / grad_scale);
+                     m1, m2, n_images, c1, c2, lr_pos, lr_rot, beta1, beta2, eps, 1.0f / grad_scale, ctl);
   NS_CHECK_LAUNCH("ngp_camera_step_kernel");
   return NS_OK;
 }
@@ -1022,13 +1554,22 @@ extern "C" int ns_ngp_sample_rays(const float* images, const float* depths, cons
                                   float box_hi, float near, unsigned seed, int R, float* rays_o, float* rays_d,
                                   float* t_range, float* gt_rgb, float* gt_depth, float* gt_depth_cov, int* ray_img,
                                   void* stream) {
+  return ns_ngp_sample_rays_ctl(images, depths, depth_covs, c2w, n_images, H, W, fx, fy, cx, cy, box_lo, box_hi, near, seed, R,
+                                rays_o, rays_d, t_range, gt_rgb, gt_depth, gt_depth_cov, ray_img, nullptr, stream);
+}
+
+extern "C" int ns_ngp_sample_rays_ctl(const float* images, const float* depths, const float* depth_covs, const float* c2w,
+                                      int n_images, int H, int W, float fx, float fy, float cx, float cy, float box_lo,
+                                      float box_hi, float near, unsigned seed, int R, float* rays_o, float* rays_d,
+                                      float* t_range, float* gt_rgb, float* gt_depth, float* gt_depth_cov, int* ray_img,
+                                      const int* ctl, void* stream) {
   NS_REQUIRE(images && depths && depth_covs && c2w && rays_o && rays_d && t_range && gt_rgb && gt_depth && gt_depth_cov,
              "ns_ngp_sample_rays: null pointer");
   NS_REQUIRE(n_images > 0 && H > 0 && W > 0 && fx != 0.0f && fy != 0.0f && box_hi > box_lo,
              "ns_ngp_sample_rays: bad image set / intrinsics / box");
   if (R <= 0) return NS_OK;
   SampleRaysArgs a{images, depths, depth_covs, c2w, fx, fy, cx, cy, box_lo, box_hi, near, n_images, H, W, R, seed,
-                   rays_o, rays_d, t_range, gt_rgb, gt_depth, gt_depth_cov, ray_img};
+                   rays_o, rays_d, t_range, gt_rgb, gt_depth, gt_depth_cov, ray_img, ctl};
   hipLaunchKernelGGL(ngp_sample_rays_kernel, dim3(ns_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, a);
   NS_CHECK_LAUNCH("ngp_sample_rays_kernel");
   return NS_OK;
@@ -1038,12 +1579,20 @@ extern "C" int ns_ngp_march(const uint8_t* bits, int G, int ncasc, const float* 
                             const float* t_range, int R, float cone, float min_step, float max_step, float pos_lo,
                             float pos_inv, int max_per_ray, long max_samples, int* counter, int* ray_start, int* ray_n, float* pos, float* dirs,
                             float* dt, float* tmid, void* stream) {
+  return ns_ngp_march_ctl(bits, G, ncasc, rays_o, rays_d, t_range, R, cone, min_step, max_step, pos_lo, pos_inv, max_per_ray,
+                          max_samples, counter, ray_start, ray_n, pos, dirs, dt, tmid, nullptr, stream);
+}
+
+extern "C" int ns_ngp_march_ctl(const uint8_t* bits, int G, int ncasc, const float* rays_o, const float* rays_d,
+                                const float* t_range, int R, float cone, float min_step, float max_step, float pos_lo,
+                                float pos_inv, int max_per_ray, long max_samples, int* counter, int* ray_start, int* ray_n,
+                                float* pos, float* dirs, float* dt, float* tmid, const int* ctl, void* stream) {
   NS_REQUIRE(bits && rays_o && rays_d && t_range && counter && ray_start && ray_n && pos && dirs && dt && tmid,
              "ns_ngp_march: null pointer");
   NS_REQUIRE(G > 0 && ncasc >= 1 && ncasc <= 8 && min_step > 0.0f, "ns_ngp_march: bad grid");
   if (R <= 0) return NS_OK;
   MarchArgs a{bits, rays_o, rays_d, t_range, cone, min_step, max_step, pos_lo, pos_inv, G, ncasc, max_per_ray, max_samples, counter,
-              ray_start, ray_n, pos, dirs, dt, tmid, R};
+              ray_start, ray_n, pos, dirs, dt, tmid, R, ctl};
   hipLaunchKernelGGL(ngp_march_kernel, dim3(ns_cdiv(R, 16)), dim3(256), 0, (hipStream_t)stream, a);
   NS_CHECK_LAUNCH("ngp_march_kernel");
   return NS_OK;
@@ -1053,13 +1602,53 @@ extern "C" int ns_ngp_composite(const void* net_out, const float* dt, const floa
                                 const int* ray_n, int R, const float* gt_rgb, const float* gt_depth,
                                 const float* gt_depth_cov, float depth_lambda, float loss_scale, float* out_rgb,
                                 float* out_depth, float* loss, void* dLdout, void* stream) {
+  return ns_ngp_composite_ctl(net_out, dt, tmid, ray_start, ray_n, R, gt_rgb, gt_depth, gt_depth_cov, depth_lambda, loss_scale,
+                              out_rgb, out_depth, loss, dLdout, nullptr, stream);
+}
+
+extern "C" int ns_ngp_composite_ctl(const void* net_out, const float* dt, const float* tmid, const int* ray_start,
+                                    const int* ray_n, int R, const float* gt_rgb, const float* gt_depth,
+                                    const float* gt_depth_cov, float depth_lambda, float loss_scale, float* out_rgb,
+                                    float* out_depth, float* loss, void* dLdout, const int* ctl, void* stream) {
   NS_REQUIRE(net_out && dt && tmid && ray_start && ray_n && out_rgb && out_depth, "ns_ngp_composite: null pointer");
   NS_REQUIRE(dLdout == nullptr || (gt_rgb && gt_depth && gt_depth_cov && loss),
              "ns_ngp_composite: training mode needs the ground truth and the loss pointer");
   if (R <= 0) return NS_OK;
   CompositeArgs a{(const _Float16*)net_out, dt, tmid, ray_start, ray_n, gt_rgb, gt_depth, gt_depth_cov,
-                  depth_lambda, loss_scale, out_rgb, out_depth, loss, (_Float16*)dLdout, R};
+                  depth_lambda, loss_scale, out_rgb, out_depth, loss, (_Float16*)dLdout, R, ctl};
   hipLaunchKernelGGL(ngp_composite_kernel, dim3(ns_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, a);
   NS_CHECK_LAUNCH("ngp_composite_kernel");
+  return NS_OK;
+}
+
+// End of a graph-captured training step: count the step, adapt the ray count of the next batch so that the sample budget
+// stays ~90 % full without refusing rays (the rule of nerfslam/ngp.py, instant-ngp adapts its batch likewise), keep a copy
+// of this step's march counters for (lazy) host reads, and clear them for the next march.
+__global__ void ngp_step_advance_kernel(int* __restrict__ ctl, int* __restrict__ counter, int* __restrict__ last, float fill,
+                                        long max_samples, int min_rays, int max_rays, float beta1, float beta2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int requested = counter[0], R = ctl[NS_CTL_RAYS];
+  last[0] = requested;
+  last[1] = counter[1];
+  last[2] = counter[2];
+  last[3] = R;
+  const float want = (float)R * fill * (float)max_samples / (float)max(requested, 1);
+  int Rn = (int)fminf(fmaxf(want, (float)min_rays), (float)max_rays);
+  Rn = Rn / 128 * 128;
+  ctl[NS_CTL_RAYS] = max(Rn, 128);
+  const int done = ctl[NS_CTL_STEP] + 1;
+  ctl[NS_CTL_STEP] = done;
+  ctl[NS_CTL_C1] = __float_as_int(1.0f - powf(beta1, (float)(done + 1)));
+  ctl[NS_CTL_C2] = __float_as_int(1.0f - powf(beta2, (float)(done + 1)));
+  counter[0] = counter[1] = counter[2] = 0;
+}
+
+extern "C" int ns_ngp_step_advance(int* ctl, int* counter, int* last, float fill, long max_samples, int min_rays, int max_rays,
+                                   float beta1, float beta2, void* stream) {
+  NS_REQUIRE(ctl && counter && last, "ns_ngp_step_advance: null pointer");
+  NS_REQUIRE(fill > 0.0f && max_samples > 0 && min_rays >= 128 && max_rays >= min_rays, "ns_ngp_step_advance: bad limits");
+  hipLaunchKernelGGL(ngp_step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, counter, last, fill, max_samples,
+                     min_rays, max_rays, beta1, beta2);
+  NS_CHECK_LAUNCH("ngp_step_advance_kernel");
   return NS_OK;
 }

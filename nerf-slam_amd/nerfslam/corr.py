@@ -160,6 +160,70 @@ class CorrBlock:
         return corr.view(batch, num, ht, wd, ht, wd)
 
 
+class CorrPool:
+    """Slot-addressed store of per-edge correlation pyramids (8x8-tiled levels 0 / 1): what TrackingFrontend keeps instead of
+    one growing / shrinking CorrBlock.
+
+    The reference appends the volumes of new edges with `torch.cat` and drops those of removed edges with a boolean-mask
+    copy (networks/modules/corr.py:52-60 called from visual_frontend.py:838-844, 868-892): at 640x480 every such call
+    copies the whole active set (48 edges x 61 MB = 2.9 GB).  Here a volume is written once, into a free slot of a
+    preallocated pool, and never moves: edges are (re)ordered by an int32 slot table that the build / lookup kernels read
+    (ns_corr_volume_pyramid_slots, ns_corr_lookup_pyramid_slots).  Same values, same lookups bit for bit."""
+
+    def __init__(self, ht, wd, capacity, device, num_levels=4):
+        self.ht, self.wd, self.num_levels, self.device = ht, wd, num_levels, torch.device(device)
+        self.capacity = 0
+        self.levels = None
+        self.grow(capacity)
+
+    def _alloc(self, cap):
+        out = []
+        for l in range(self.num_levels):
+            h, w = self.ht >> l, self.wd >> l
+            shape = (cap, self.ht * self.wd, ((h + 7) // 8) * ((w + 7) // 8), 64) if l < 2 else (cap, self.ht, self.wd, h, w)
+            out.append(torch.empty(shape, dtype=torch.float16, device=self.device))
+        return out
+
+    def grow(self, capacity):
+        if capacity <= self.capacity:
+            return
+        new = self._alloc(capacity)
+        if self.levels is not None:
+            for a, b in zip(new, self.levels):
+                a[:self.capacity] = b
+        self.levels, self.capacity = new, capacity
+
+    def _ptrs(self):
+        return (C.c_void_p * 4)(*[self.levels[min(l, self.num_levels - 1)].data_ptr() for l in range(4)])
+
+    def build(self, bank1, bank2, ii, jj, slots):
+        """volumes of edges (ii[e], jj[e]) from the channels-last f16 feature banks (already / 4) into slots[e] (int32, device)"""
+        E = int(slots.shape[0])
+        if E == 0:
+            return
+        with torch.cuda.device(self.device):
+            check(lib().ns_corr_volume_pyramid_slots(ptr(bank1), ptr(bank2), ptr(ii), ptr(jj), self._ptrs(), self.num_levels, E,
+                                                     bank1.shape[-1], self.ht, self.wd, 1, ptr(slots), stream_ptr()),
+                  "corr_volume_pyramid_slots")
+
+    def lookup(self, coords, slots, out=None):
+        """coords [1, E, ht, wd, 2] f32, slots [E] int32 (device) -> [1, E, 196, ht, wd] f16 (corr.py:40-50 on the pooled volumes)"""
+        batch, E, ht, wd, _ = coords.shape
+        coords = coords.contiguous().float()
+        if out is None:
+            out = torch.empty((batch, E, self.num_levels * 49, ht, wd), dtype=torch.float16, device=coords.device)
+        with torch.cuda.device(self.device):
+            check(lib().ns_corr_lookup_pyramid_slots(self._ptrs(), self.num_levels, ptr(coords), 1, ptr(out), batch * E, ht, wd, 1,
+                                                     ptr(slots), self.capacity, stream_ptr()), "corr_lookup_pyramid_slots")
+        return out
+
+    def block(self, slots):
+        """the volumes of `slots` as a CorrBlock in the reference's layout (copies; tests / debugging)"""
+        idx = slots.long()
+        blk = CorrBlock.from_pyramid([lv[idx] for lv in self.levels], tiled=True, hw=(self.ht, self.wd))
+        return CorrBlock.from_pyramid(blk.untiled())
+
+
 class AltCorrBlock:
     """On-the-fly correlation for the global BA (reference: networks/modules/corr.py:92-140).
 

@@ -239,8 +239,10 @@ class DroidNetworks:
         return delta.float()
 
     @torch.no_grad()
-    def update(self, corr, motion, ii, jj):
-        ih, jh = ii.tolist(), jj.tolist()
+    def update(self, corr, motion, ii, jj, ii_host=None, jj_host=None):
+        """ii_host / jj_host: the edge lists as host ints (TrackingFrontend keeps them on the host and passes them when the
+        callable advertises `host_indices`): without them ii.tolist() is a device read-back, i.e. a synchronisation per update"""
+        ih, jh = (ii.tolist(), jj.tolist()) if ii_host is None else (list(ii_host), list(jj_host))
         if self.hip_update:
             net = torch.stack([self.hidden.get((i, j), self.ctx_cl[i]) for i, j in zip(ih, jh)])
             inp = torch.stack([self.inp_cl[i] for i in ih])
@@ -262,3 +264,5 @@ class DroidNetworks:
         if len(self.hidden) > 4 * max(len(live), 64):       # edges that left the graph
             self.hidden = {e: h for e, h in self.hidden.items() if e in live}
         return delta.float(), weight.float(), eta[0].float(), upmask[0]
+
+    update.host_indices = True

@@ -26,7 +26,7 @@ import torch
 
 from . import ba_plan, se3
 from ._lib import NS_ENOSUP, NerfSlamHipError, check, lib, ptr, stream_ptr
-from .corr import CorrBlock
+from .corr import CorrPool
 from .factor_graph import FactorGraph
 
 
@@ -63,7 +63,12 @@ class TrackingFrontend:
         # graph + per-edge payloads
         self.graph = FactorGraph(max_factors=max_factors)
         self.ii = self.jj = torch.zeros(0, dtype=torch.long, device=dev)
+        # correlation volumes: a slot-addressed pool (nerfslam.corr.CorrPool); `corr` is None until the first edge has one
         self.corr = None
+        self.slots = np.zeros(0, np.int32)           # pool slot of every active edge, in the graph's edge order
+        self.slots_dev = torch.zeros(0, dtype=torch.int32, device=dev)
+        self._free_slots = []
+        self._edge_cache = None
         self.target = torch.zeros((0, self.ht, self.wd, 2), **f)
         self.weight = torch.zeros((0, self.ht, self.wd, 2), **f)
         self.target_inactive = torch.zeros((0, self.ht, self.wd, 2), **f)
@@ -90,6 +95,18 @@ class TrackingFrontend:
     def _sync_edges(self):
         self.ii = torch.from_numpy(self.graph.ii).to(self.device)
         self.jj = torch.from_numpy(self.graph.jj).to(self.device)
+        self.slots_dev = torch.from_numpy(np.ascontiguousarray(self.slots, np.int32)).to(self.device)
+        self._edge_cache = None      # device-side index tensors derived from the edge list (rebuilt lazily in update())
+
+    def _take_slots(self, n):
+        if self.corr is None:
+            self.corr = CorrPool(self.ht, self.wd, max(self.graph.max_factors + 16, 2 * n), self.device)
+            self._free_slots = list(range(self.corr.capacity - 1, -1, -1))
+        if len(self._free_slots) < n:        # init / global passes may exceed max_factors: grow (copies the live volumes once)
+            old = self.corr.capacity
+            self.corr.grow(max(2 * old, old + n))
+            self._free_slots = list(range(self.corr.capacity - 1, old - 1, -1)) + self._free_slots
+        return np.asarray([self._free_slots.pop() for _ in range(n)], np.int32)
 
     def reproject(self, ii, jj):
         """(:909-918) -> coords [E,ht,wd,2]."""
@@ -126,33 +143,37 @@ class TrackingFrontend:
         edges straight from the feature bank (one fused launch), initialise targets with the reprojection."""
         ni, nj, removed = self.graph.add(ii, jj, remove=remove, have_volumes=self.corr is not None)
         if removed is not None:
-            self._drop_payload(torch.from_numpy(removed).to(self.device), store=True)
+            self._drop_payload(removed, store=True)
         if ni.shape[0] == 0:
             return
         di, dj = torch.from_numpy(ni).to(self.device), torch.from_numpy(nj).to(self.device)
-        pyr = CorrBlock.build_pyramid(self.feat_bank, self.feat_bank, di, dj, ni.shape[0], self.ht, self.wd, tiled=True)
-        new = CorrBlock.from_pyramid(pyr, tiled=True, hw=(self.ht, self.wd))
-        self.corr = new if self.corr is None else self.corr.cat(new)
+        new_slots = self._take_slots(ni.shape[0])
+        self.corr.build(self.feat_bank, self.feat_bank, di, dj, torch.from_numpy(new_slots).to(self.device))
+        self.slots = np.concatenate([self.slots, new_slots])
         tgt = self.reproject(di, dj)
         self.target = torch.cat([self.target, tgt], 0)
         self.weight = torch.cat([self.weight, torch.zeros_like(tgt)], 0)
         self._sync_edges()
 
-    def _drop_payload(self, mask, store):
+    def _drop_payload(self, mask_h, store):
+        """mask_h: HOST bool array over the active edges (the edge lists live on the host: no read-back)"""
+        mh = np.asarray(mask_h, bool)
+        mask = torch.from_numpy(mh).to(self.device)
         if store:
             self.target_inactive = torch.cat([self.target_inactive, self.target[mask]], 0)
             self.weight_inactive = torch.cat([self.weight_inactive, self.weight[mask]], 0)
         keep = ~mask
         self.target, self.weight = self.target[keep], self.weight[keep]
-        if self.corr is not None:
-            self.corr = self.corr[keep]
+        if self.slots.shape[0] == mh.shape[0]:       # volumes stay where they are: the slots return to the free list
+            self._free_slots.extend(int(v) for v in self.slots[mh])
+            self.slots = self.slots[~mh]
         self._sync_edges()
 
     def rm_factors(self, mask, store=False):
         """(:868-892); mask: host bool array over the active edges."""
         mask = np.asarray(mask, bool)
         self.graph.remove(mask, store=store)
-        self._drop_payload(torch.from_numpy(mask).to(self.device), store)
+        self._drop_payload(mask, store)
 
     def add_neighborhood_factors(self, kf0, kf1, radius=3):
         ii, jj = FactorGraph.neighborhood_edges(kf0, kf1, radius)
@@ -169,29 +190,50 @@ class TrackingFrontend:
             self.add_factors(e[:, 0], e[:, 1], remove)
 
     # ---------------------------------------------------------------------------------------------
+    def _edges(self):
+        """host + device index tensors derived from the current edge lists, built once per graph change"""
+        c = self._edge_cache
+        if c is None:
+            g, dev = self.graph, self.device
+            kx = np.unique(g.ii)
+            kf0 = max(0, int(g.ii.min()))
+            ii_h, jj_h, m = g.ba_edges(kf0)
+            m_d = torch.from_numpy(m).to(dev)
+            Mi, E = int(m.sum()), int(g.ii.shape[0])
+            # BA inputs [M,2,ht,wd]: inactive edges first (visual_frontend.py:420-424); their part is filled once here
+            tgt = torch.empty((Mi + E, 2, self.ht, self.wd), dtype=torch.float32, device=dev)
+            wgt = torch.empty_like(tgt)
+            if Mi:
+                tgt[:Mi] = self.target_inactive[m_d].permute(0, 3, 1, 2)
+                wgt[:Mi] = self.weight_inactive[m_d].permute(0, 3, 1, 2)
+            c = self._edge_cache = dict(kx=kx, kx_d=torch.from_numpy(kx).to(dev), kf0=kf0, ii_h=ii_h, jj_h=jj_h, Mi=Mi,
+                                        tgt=tgt, wgt=wgt, ii_list=g.ii.tolist(), jj_list=g.jj.tolist())
+        return c
+
     def update(self, itrs=2):
-        """one update-operator + dense-BA step (:370-470)."""
-        E = self.ii.shape[0]
+        """one update-operator + dense-BA step (:370-470).  No host synchronisation: the edge lists are host arrays, every
+        index tensor the step needs is cached per graph change, and the update operator gets the host copies of (ii, jj)."""
+        c = self._edges()
         coords1 = self.reproject(self.ii, self.jj)                                    # [E,ht,wd,2]
         motion = self.motion_features(coords1, self.target)
-        corr = self.corr(coords1[None])                                               # [1,E,196,ht,wd]
-        res = self.update_op(corr, motion[None], self.ii, self.jj)
+        corr = self.corr.lookup(coords1[None], self.slots_dev)                        # [1,E,196,ht,wd]
+        if getattr(self.update_op, "host_indices", False):
+            res = self.update_op(corr, motion[None], self.ii, self.jj, ii_host=c["ii_list"], jj_host=c["jj_list"])
+        else:
+            res = self.update_op(corr, motion[None], self.ii, self.jj)
         delta, weight, damping = res[:3]
         upmask = res[3] if len(res) > 3 else None
         self.target = coords1 + delta[0].float()
         self.weight = weight[0].float()
-        kx = np.unique(self.graph.ii)
-        self.damping[torch.from_numpy(kx).to(self.device)] = damping
-        kf0 = max(0, int(self.graph.ii.min()))
-        ii_h, jj_h, m = self.graph.ba_edges(kf0)
-        m_d = torch.from_numpy(m).to(self.device)
-        target = torch.cat([self.target_inactive[m_d], self.target], 0).permute(0, 3, 1, 2).contiguous()
-        weight = torch.cat([self.weight_inactive[m_d], self.weight], 0).permute(0, 3, 1, 2).contiguous()
-        out = self.ba(target, weight, ii_h, jj_h, kf0, itrs=itrs)
+        self.damping[c["kx_d"]] = damping
+        Mi = c["Mi"]
+        c["tgt"][Mi:] = self.target.permute(0, 3, 1, 2)
+        c["wgt"][Mi:] = self.weight.permute(0, 3, 1, 2)
+        out = self.ba(c["tgt"], c["wgt"], c["ii_h"], c["jj_h"], c["kf0"], itrs=itrs)
         if upmask is not None:
-            self.upsample(torch.from_numpy(kx).to(self.device), upmask)
+            self.upsample(c["kx_d"], upmask)
         self.graph.age += 1
-        self.viz_idx[kf0:self.kf_idx + 1] = True
+        self.viz_idx[c["kf0"]:self.kf_idx + 1] = True
         self.n_updates += 1
         return out
 
@@ -204,8 +246,9 @@ class TrackingFrontend:
             self._plan, self._plan_key = ba_plan.BaPlan(ii_h, jj_h, kf0, kf1, self.device), key
             self._ii_ba = torch.from_numpy(ii_h).to(self.device)
             self._jj_ba = torch.from_numpy(jj_h).to(self.device)
+            self._kx_ba = torch.from_numpy(self._plan.kx_host).to(self.device)
         plan = self._plan
-        kx = torch.from_numpy(plan.kx_host).to(self.device)
+        kx = self._kx_ba
         damping = (0.2 * self.damping[kx] + 1e-7).contiguous()                        # :428
         prior = self.prior_pose if (kf0 == 0 and self.prior_pose is not None) else None
         sol = None

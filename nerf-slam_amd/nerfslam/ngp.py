@@ -54,6 +54,7 @@ class NgpConfig:
     extrinsic_lr_pos: float = 1e-4       # scene units per step (Adam)
     extrinsic_lr_rot: float = 1e-4       # radians per step (Adam)
     grad_fixed_scale: float = 262144.0   # hash-grid gradients accumulate as packed Q18 fixed point (0: f32 atomics)
+    use_graph: bool = True               # replay the training step from a HIP graph (False: same launch sequence, eager)
 
     @property
     def per_level_scale(self):
@@ -127,6 +128,7 @@ class NgpNerf:
         self.bits = torch.full((nc * G ** 3 // 8,), 255, dtype=torch.uint8, device=dev)
         self.step = 0
         self.loss = float("nan")
+        self._static = False
         self.gen = torch.Generator(device=dev).manual_seed(base_seed)
         self.seed = int(seed)
         # training views
@@ -144,8 +146,8 @@ class NgpNerf:
         self.dact = [torch.empty((u, S), **h) for u in (16, 64, 64, 16, 64)]    # d5T d4T d3T ddT d1T
         self.partial = torch.zeros((c.wgrad_ksplit, MLP_TOTAL), **f)
         self.counter = torch.zeros(3, dtype=torch.int32, device=dev)
-        ws_bytes = lib().ns_ngp_encode_backward_workspace_bytes(*self._grid_args())
-        self.enc_ws = torch.zeros(max(ws_bytes // 4, 1), **f)   # replicated coarse-level gradient tables (kept zeroed)
+        ws_bytes = lib().ns_ngp_encode_backward_workspace_bytes(*self._grid_args(), C.c_long(c.max_samples))
+        self.enc_ws = torch.zeros(max(ws_bytes // 4, 1), **f)   # record queues / counters of the binned encode backward
         self.rays_per_batch = c.n_rays
         self.samples_requested = 0
 
@@ -168,16 +170,20 @@ class NgpNerf:
         return out
 
     # ------------------------------------------------------------------------------------------
-    def set_images(self, images, depths, depth_covs, c2w, intr):
+    def set_images(self, images, depths, depth_covs, c2w, intr, n_images=None):
         """images [n,H,W,4] f32 linear premultiplied RGBA, depths / depth_covs [n,H,W] f32 (depth <= 0:
-        unsupervised pixel), c2w [n,3,4] f32 (camera-to-world in NGP scene coordinates), intr (fx,fy,cx,cy)."""
+        unsupervised pixel), c2w [n,3,4] f32 (camera-to-world in NGP scene coordinates), intr (fx,fy,cx,cy).
+        n_images: number of VALID leading views when the tensors are whole pre-allocated slot arrays (their addresses then
+        never change as keyframes arrive, and the captured training step stays valid)."""
         dev = self.device
         self.images = images.to(dev, torch.float32).contiguous()
         self.depths = depths.to(dev, torch.float32).contiguous()
         self.depth_covs = depth_covs.to(dev, torch.float32).contiguous()
         self.c2w = c2w.to(dev, torch.float32).contiguous()
         self.intr = [float(v) for v in intr]
-        self.n_images = self.images.shape[0]
+        self.n_images = self.images.shape[0] if n_images is None else int(n_images)
+        if getattr(self, "_static", False):
+            self.ctl[3] = max(self.n_images, 1)
 
     def _rays(self, img_idx, u, v):
         fx, fy, cx, cy = self.intr
@@ -201,109 +207,159 @@ class NgpNerf:
         s = float(c.aabb_scale)
         lo, inv = (0.5 - 0.5 * s, 1.0 / s) if unit else (0.0, 1.0)
         R = o.shape[0]
-        self.counter.zero_()
-        self.ray_start = torch.empty(R, dtype=torch.int32, device=self.device)
-        self.ray_n = torch.empty(R, dtype=torch.int32, device=self.device)
+        # (rendering path: its own counters / ray tables -- the training step's are part of a captured graph)
+        self.rm_counter = torch.zeros(3, dtype=torch.int32, device=self.device)
+        self.rm_start = torch.empty(R, dtype=torch.int32, device=self.device)
+        self.rm_n = torch.empty(R, dtype=torch.int32, device=self.device)
         check(lib().ns_ngp_march(ptr(self.bits), c.grid_size, c.n_cascades, ptr(o), ptr(d), ptr(tr), R,
                                  C.c_float(c.cone_angle), C.c_float(c.min_step), C.c_float(c.max_step),
-                                 C.c_float(lo), C.c_float(inv), c.max_steps_per_ray, C.c_long(c.max_samples), ptr(self.counter), ptr(self.ray_start),
-                                 ptr(self.ray_n), ptr(self.s_pos), ptr(self.s_dir), ptr(self.s_dt), ptr(self.s_t),
+                                 C.c_float(lo), C.c_float(inv), c.max_steps_per_ray, C.c_long(c.max_samples), ptr(self.rm_counter), ptr(self.rm_start),
+                                 ptr(self.rm_n), ptr(self.s_pos), ptr(self.s_dir), ptr(self.s_dt), ptr(self.s_t),
                                  stream_ptr()), "ngp_march")
-        # the one host read-back of a step (instant-ngp reads its ray counter too): end of the reserved ranges
-        cnt = self.counter.tolist()
+        cnt = self.rm_counter.tolist()      # host read-back: rendering sizes its launches by the sample count
         self.samples_requested = cnt[0]     # > max_samples: some rays of this batch received no samples
         return cnt[2]
 
-    def train_step(self):
+    # ------------------------------------------------------------------------------------------
+    # Training step = a FIXED launch sequence with fixed arguments: the per-step scalars (ray count, seed,
+    # step number, number of training views) live in the device control block `ctl`, every per-sample kernel runs over the
+    # whole sample budget (slots the marcher did not fill carry a zero upstream gradient), and nothing is read back.  The
+    # sequence is therefore captured ONCE in a HIP graph and replayed -- the eager form of the same sequence is what the
+    # replicated-trainer mode runs (its all-reduces sit between the backward pass and the optimiser).
+    def _alloc_static(self):
+        c, dev = self.cfg, self.device
+        f = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        Rc = self.ray_cap = int(min(c.max_rays, 16384))
+        self.r_o, self.r_d, self.r_tr = torch.zeros((Rc, 3), **f), torch.zeros((Rc, 3), **f), torch.zeros((Rc, 2), **f)
+        self.r_rgb, self.r_depth, self.r_cov = torch.zeros((Rc, 3), **f), torch.zeros(Rc, **f), torch.ones(Rc, **f)
+        self.r_img = torch.zeros(Rc, **i32)
+        self.ray_start, self.ray_n = torch.zeros(Rc, **i32), torch.full((Rc,), -1, **i32)
+        self.out_rgb, self.out_depth = torch.zeros((Rc, 3), **f), torch.zeros(Rc, **f)
+        self.loss_acc = torch.zeros(1, **f)
+        self.dpos = torch.zeros((c.max_samples, 3), **f)
+        import struct
+        fbits = lambda x: struct.unpack("<i", struct.pack("<f", x))[0]
+        self.ctl = torch.tensor([self.step, min(self.rays_per_batch, Rc), self.seed & 0x7FFFFFFF, max(self.n_images, 1),
+                                 fbits(1.0 - c.beta1 ** (self.step + 1)), fbits(1.0 - c.beta2 ** (self.step + 1)), 0, 0], **i32)
+        self.last = torch.zeros(4, **i32)
+        self.counter.zero_()
+        # unused sample slots must hold finite inputs: the per-sample kernels run over all of them
+        self.s_pos.fill_(0.5); self.s_dir.zero_(); self.s_dt.zero_(); self.s_t.zero_(); self.s_dout.zero_()
+        self._graph, self._graph_key = None, None
+        self._static = True
+
+    def _step_key(self):
+        c = self.cfg
+        return (self.images.data_ptr(), self.depths.data_ptr(), self.depth_covs.data_ptr(), self.c2w.data_ptr(),
+                tuple(self.images.shape[1:3]), tuple(self.intr), c.depth_lambda, c.optimize_extrinsics,
+                None if getattr(self, "cam_grad", None) is None else self.cam_grad.data_ptr(), self.bits.data_ptr())
+
+    def _enqueue_step(self):
+        """one optimiser step on the current stream; no host synchronisation, no allocation"""
+        c, dev = self.cfg, self.device
+        L = lib()
+        S, Rc = c.max_samples, self.ray_cap
+        n_cap, H, W = self.images.shape[:3]
+        s = float(c.aabb_scale)
+        fx, fy, cx, cy = self.intr
+        st = stream_ptr()
+        ctl = ptr(self.ctl)
+        self.ray_n.fill_(-1)
+        self.s_dout.zero_()
+        self.loss_acc.zero_()
+        check(L.ns_ngp_sample_rays_ctl(ptr(self.images), ptr(self.depths), ptr(self.depth_covs), ptr(self.c2w), n_cap, H, W,
+                                       C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                                       C.c_float(0.5 - 0.5 * s), C.c_float(0.5 + 0.5 * s), C.c_float(c.near), C.c_uint32(0), Rc,
+                                       ptr(self.r_o), ptr(self.r_d), ptr(self.r_tr), ptr(self.r_rgb), ptr(self.r_depth),
+                                       ptr(self.r_cov), ptr(self.r_img), ctl, st), "ngp_sample_rays")
+        check(L.ns_ngp_march_ctl(ptr(self.bits), c.grid_size, c.n_cascades, ptr(self.r_o), ptr(self.r_d), ptr(self.r_tr), Rc,
+                                 C.c_float(c.cone_angle), C.c_float(c.min_step), C.c_float(c.max_step),
+                                 C.c_float(0.5 - 0.5 * s), C.c_float(1.0 / s), c.max_steps_per_ray, C.c_long(S), ptr(self.counter),
+                                 ptr(self.ray_start), ptr(self.ray_n), ptr(self.s_pos), ptr(self.s_dir), ptr(self.s_dt),
+                                 ptr(self.s_t), ctl, st), "ngp_march")
+        featT = self.encode(self.s_pos, self.s_feat)
+        acts, dacts = self.act, self.dact
+        check(L.ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(featT), ptr(self.s_dir), ptr(self.s_out),
+                                   *[ptr(a) for a in acts], C.c_long(S), st), "ngp_mlp_forward")
+        check(L.ns_ngp_composite_ctl(ptr(self.s_out), ptr(self.s_dt), ptr(self.s_t), ptr(self.ray_start), ptr(self.ray_n), Rc,
+                                     ptr(self.r_rgb), ptr(self.r_depth), ptr(self.r_cov), C.c_float(c.depth_lambda),
+                                     C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), ptr(self.loss_acc),
+                                     ptr(self.s_dout), ctl, st), "ngp_composite")
+        check(L.ns_ngp_mlp_backward(ptr(self.mlp_half), ptr(self.s_dout), ptr(featT), *[ptr(a) for a in acts],
+                                    ptr(self.s_dfeat), *[ptr(a) for a in dacts], ptr(self.partial), c.wgrad_ksplit,
+                                    ptr(self.mlp_grad), C.c_long(S), st), "ngp_mlp_backward")
+        check(L.ns_ngp_encode_backward(*self._grid_args(), ptr(self.s_pos), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
+                                       ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(S), st), "ngp_encode_backward")
+        if c.optimize_extrinsics:
+            check(L.ns_ngp_encode_backward_input(*self._grid_args(), ptr(self.s_pos), ptr(self.grid_half), ptr(self.s_dfeat),
+                                                 ptr(self.dpos), C.c_long(S), st), "ngp_encode_backward_input")
+            check(L.ns_ngp_camera_gradient_ctl(ptr(self.dpos), ptr(self.s_t), ptr(self.r_d), ptr(self.ray_start), ptr(self.ray_n),
+                                               ptr(self.r_img), C.c_float(1.0 / s), ptr(self.cam_grad), Rc, ctl, st),
+                  "ngp_camera_gradient")
+        if self.world > 1:
+            self._allreduce_gradients()
+        if c.optimize_extrinsics:   # after the all-reduce: every replica applies the SAME pose update (ADVICE r01)
+            check(L.ns_ngp_camera_step_ctl(ptr(self.c2w), ptr(self.cam_grad), ptr(self.cam_m1), ptr(self.cam_m2),
+                                           self.cam_grad.shape[0], 0, C.c_float(c.extrinsic_lr_pos), C.c_float(c.extrinsic_lr_rot),
+                                           C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
+                                           C.c_float(c.loss_scale * self.world), ctl, st), "ngp_camera_step")
+        for (m, hp, g, m1, m2, l2, fxs) in (
+                (self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale),
+                (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0)):
+            check(L.ns_ngp_adam_ctl(ptr(m), ptr(hp), ptr(g), ptr(m1), ptr(m2), C.c_long(m.numel()), 0, C.c_float(c.lr),
+                                    C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps), C.c_float(l2),
+                                    C.c_float(c.loss_scale * self.world), C.c_float(fxs), ctl, st), "ngp_adam")
+        check(L.ns_ngp_step_advance(ptr(self.ctl), ptr(self.counter), ptr(self.last), C.c_float(0.9), C.c_long(S), 256,
+                                    Rc, C.c_float(c.beta1), C.c_float(c.beta2), st), "ngp_step_advance")
+
+    def train_step(self, return_loss=True):
         if self.n_images == 0:
             return None
         c, dev = self.cfg, self.device
         with torch.cuda.device(dev):
-            n, H, W = self.images.shape[:3]
-            R = self.rays_per_batch
-            f = dict(dtype=torch.float32, device=dev)
-            o, d, tr = torch.empty((R, 3), **f), torch.empty((R, 3), **f), torch.empty((R, 2), **f)
-            gt_rgb, gt_depth, gt_cov = torch.empty((R, 3), **f), torch.empty(R, **f), torch.empty(R, **f)
-            ray_img = torch.empty(R, dtype=torch.int32, device=dev) if c.optimize_extrinsics else None
-            s = float(c.aabb_scale)
-            fx, fy, cx, cy = self.intr
-            seed = (self.seed * 0x9E3779B1 + self.step * 0x85EBCA77) & 0xFFFFFFFF
-            check(lib().ns_ngp_sample_rays(ptr(self.images), ptr(self.depths), ptr(self.depth_covs), ptr(self.c2w), n, H, W,
-                                           C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
-                                           C.c_float(0.5 - 0.5 * s), C.c_float(0.5 + 0.5 * s), C.c_float(c.near),
-                                           C.c_uint32(seed), R, ptr(o), ptr(d), ptr(tr), ptr(gt_rgb), ptr(gt_depth),
-                                           ptr(gt_cov), ptr(ray_img), stream_ptr()), "ngp_sample_rays")
-            N = self.march(o, d, tr, unit=True)   # positions come back in unit-cube coordinates
-            # keep the sample budget filled without refusing rays (instant-ngp adapts its rays per batch likewise)
-            want = R * 0.9 * c.max_samples / max(self.samples_requested, 1)
-            self.rays_per_batch = int(min(max(want, 256), c.max_rays)) // 128 * 128
-            if N == 0:
-                if self.world > 1:
-                    # replicas stay in lockstep: contribute a zero gradient to this step's all-reduce and take the (shared)
-                    # optimiser step like the others -- returning here would leave the peers alone in the collective
-                    if c.optimize_extrinsics:
-                        self._grow_camera_state(self.n_images)
-                    self._allreduce_gradients()
-                    if c.optimize_extrinsics:
-                        self._camera_step()
-                    self._optimizer_step()
+            if not getattr(self, "_static", False):
+                self._alloc_static()
+            if c.optimize_extrinsics:
+                self._grow_camera_state(self.images.shape[0])
+            if self.world > 1 or not c.use_graph:
+                self._enqueue_step()
+            else:
+                key = self._step_key()
+                if self._graph_key != key:
+                    # (re)capture: the first step after a (re)allocation runs eagerly -- it is also the warm-up
+                    self._graph, self._graph_key = None, key
+                    self._enqueue_step()
+                elif self._graph is None:
+                    torch.cuda.synchronize(dev)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._enqueue_step()
+                    self._graph = g             # (capturing does not execute: the step runs with the first replay)
+                    g.replay()
                 else:
-                    self.step += 1
-                self.last_samples, self.last_rays = 0, R
-                return 0.0
-            N8 = (N + 7) // 8 * 8  # the weight-gradient GEMM reads 16-byte runs
-            if N8 > N:
-                self.s_pos[N:N8] = 0.5
-                self.s_dir[N:N8] = 0.0
-                self.s_dt[N:N8] = 0.0
-            pos_unit = self.s_pos[:N8]
-            # forward
-            featT = self.encode(pos_unit, self.s_feat)
-            acts = [a.view(-1)[:a.shape[0] * N8].view(a.shape[0], N8) for a in self.act]
-            dacts = [a.view(-1)[:a.shape[0] * N8].view(a.shape[0], N8) for a in self.dact]
-            dfeatT = self.s_dfeat.view(-1)[:32 * N8].view(32, N8)
-            check(lib().ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(featT), ptr(self.s_dir), ptr(self.s_out),
-                                           *[ptr(a) for a in acts], C.c_long(N8), stream_ptr()), "ngp_mlp_forward")
-            out_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
-            out_depth = torch.empty(R, dtype=torch.float32, device=dev)
-            loss = torch.zeros(1, dtype=torch.float32, device=dev)
-            if N8 > N:
-                self.s_dout[N:N8] = 0
-            check(lib().ns_ngp_composite(ptr(self.s_out), ptr(self.s_dt), ptr(self.s_t), ptr(self.ray_start),
-                                         ptr(self.ray_n), R, ptr(gt_rgb), ptr(gt_depth), ptr(gt_cov),
-                                         C.c_float(c.depth_lambda), C.c_float(c.loss_scale), ptr(out_rgb),
-                                         ptr(out_depth), ptr(loss), ptr(self.s_dout), stream_ptr()), "ngp_composite")
-            # backward
-            check(lib().ns_ngp_mlp_backward(ptr(self.mlp_half), ptr(self.s_dout), ptr(featT), *[ptr(a) for a in acts],
-                                            ptr(dfeatT), *[ptr(a) for a in dacts], ptr(self.partial),
-                                            c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(N8), stream_ptr()),
-                  "ngp_mlp_backward")
-            check(lib().ns_ngp_encode_backward(*self._grid_args(), ptr(pos_unit), ptr(dfeatT), 1,
-                                               ptr(self.grid_grad), ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(N8),
-                                               stream_ptr()), "ngp_encode_backward")
-            if c.optimize_extrinsics:
-                self._camera_backward(pos_unit, dfeatT, d, ray_img, N8, R)
-            if self.world > 1:
-                self._allreduce_gradients()
-            if c.optimize_extrinsics:
-                self._camera_step()     # after the all-reduce: every replica applies the SAME pose update
-            self._optimizer_step()
-            self.loss_tensor = loss / (self.ray_n >= 0).sum().clamp(min=1)
-            self.last_samples, self.last_rays = N, R
-        return self.loss_tensor
+                    self._graph.replay()
+            self.step += 1
+            if self.step % c.grid_update_every == 0:
+                self.update_density_grid()
+        return self.loss_tensor if return_loss else None
 
-    def _optimizer_step(self):
-        c = self.cfg
-        self.step += 1
-        for (m, hp, g, m1, m2, l2, fx) in (
-                (self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale),
-                (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0)):
-            check(lib().ns_ngp_adam(ptr(m), ptr(hp), ptr(g), ptr(m1), ptr(m2), C.c_long(m.numel()), self.step,
-                                    C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
-                                    C.c_float(l2), C.c_float(c.loss_scale * self.world), C.c_float(fx), stream_ptr()),
-                  "ngp_adam")
-        if self.step % c.grid_update_every == 0:
-            self.update_density_grid()
+    @property
+    def loss_tensor(self):
+        """mean per-ray loss of the last step (device scalar; rays the marcher refused are not part of the batch)"""
+        return self.loss_acc / (self.ray_n >= 0).sum().clamp(min=1)
+
+    @property
+    def last_samples(self):
+        return int(self.last[2].item()) if getattr(self, "_static", False) else 0
+
+    @property
+    def last_rays(self):
+        return int(self.last[3].item()) if getattr(self, "_static", False) else 0
+
+    @property
+    def samples_requested_last(self):
+        return int(self.last[0].item()) if getattr(self, "_static", False) else 0
 
     def _allreduce_gradients(self):
         """sum over the replicas; Adam then divides by loss_scale * world (mean gradient)"""
@@ -314,18 +370,6 @@ class NgpNerf:
         if self.cfg.optimize_extrinsics and getattr(self, "cam_grad", None) is not None:
             dist.all_reduce(self.cam_grad, op=dist.ReduceOp.SUM, group=self.group)   # 24 B per training view
         self.bytes_allreduced = getattr(self, "bytes_allreduced", 0) + g.numel() * g.element_size() + self.mlp_grad.numel() * 4
-
-    def _camera_backward(self, pos_unit, dfeatT, rays_d, ray_img, N, R):
-        """pose refinement: sample-position gradients through the encoding -> per-image 6-dof gradient -> Adam on c2w"""
-        c, dev = self.cfg, self.device
-        n = self.n_images
-        self._grow_camera_state(n)
-        dpos = torch.empty((N, 3), dtype=torch.float32, device=dev)
-        check(lib().ns_ngp_encode_backward_input(*self._grid_args(), ptr(pos_unit), ptr(self.grid_half), ptr(dfeatT), ptr(dpos),
-                                                 C.c_long(N), stream_ptr()), "ngp_encode_backward_input")
-        check(lib().ns_ngp_camera_gradient(ptr(dpos), ptr(self.s_t), ptr(rays_d), ptr(self.ray_start), ptr(self.ray_n),
-                                           ptr(ray_img), C.c_float(1.0 / float(c.aabb_scale)), ptr(self.cam_grad), R,
-                                           stream_ptr()), "ngp_camera_gradient")
 
     def _grow_camera_state(self, n):
         """per-view Adam moments of the pose refinement: GROWN when keyframes are added (a reset would restart the bias
@@ -340,15 +384,6 @@ class NgpNerf:
             self.cam_m2 = torch.cat([self.cam_m2, torch.zeros((k, 6), **f)])
         elif self.cam_grad.shape[0] > n:
             self.cam_grad, self.cam_m1, self.cam_m2 = self.cam_grad[:n].contiguous(), self.cam_m1[:n].contiguous(), self.cam_m2[:n].contiguous()
-
-    def _camera_step(self):
-        """Adam + Rodrigues retraction of every training view's c2w from cam_grad (summed over the replicas when world > 1:
-        the gradient scale loss_scale * world makes it the mean, like the model gradients)"""
-        c, n = self.cfg, self.n_images
-        check(lib().ns_ngp_camera_step(ptr(self.c2w), ptr(self.cam_grad), ptr(self.cam_m1), ptr(self.cam_m2), n, self.step + 1,
-                                       C.c_float(c.extrinsic_lr_pos), C.c_float(c.extrinsic_lr_rot), C.c_float(c.beta1),
-                                       C.c_float(c.beta2), C.c_float(c.eps), C.c_float(c.loss_scale * self.world), stream_ptr()),
-              "ngp_camera_step")
 
     # ------------------------------------------------------------------------------------------
     def density_at(self, pos_scene):
@@ -380,10 +415,10 @@ class NgpNerf:
         dens = self.density_at(pos.contiguous()) * c.min_step
         self.density_grid.mul_(c.grid_decay)
         self.density_grid[cells] = torch.maximum(self.density_grid[cells], dens)
-        thr = min(float(self.density_grid.mean()), c.min_optical_thickness)
+        thr = self.density_grid.mean().clamp(max=c.min_optical_thickness)      # device scalar: no read-back
         occ = (self.density_grid > thr).view(-1, 8).to(torch.uint8)
         wts = (2 ** torch.arange(8, device=dev, dtype=torch.uint8))
-        self.bits = (occ * wts).sum(-1).to(torch.uint8).contiguous()
+        self.bits.copy_((occ * wts).sum(-1).to(torch.uint8))                   # in place: the captured step reads this buffer
 
     @torch.no_grad()
     def render(self, c2w, H, W, intr=None, chunk=4096):
@@ -418,8 +453,8 @@ class NgpNerf:
                     featT = self.encode(self.to_unit(self.s_pos[:Ne]), self.s_feat)
                     check(lib().ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(featT), ptr(self.s_dir), ptr(self.s_out),
                                                    nul, nul, nul, nul, C.c_long(Ne), stream_ptr()), "ngp_mlp_forward")
-                    check(lib().ns_ngp_composite(ptr(self.s_out), ptr(self.s_dt), ptr(self.s_t), ptr(self.ray_start),
-                                                 ptr(self.ray_n), R, nul, nul, nul, C.c_float(0), C.c_float(1), ptr(orgb),
+                    check(lib().ns_ngp_composite(ptr(self.s_out), ptr(self.s_dt), ptr(self.s_t), ptr(self.rm_start),
+                                                 ptr(self.rm_n), R, nul, nul, nul, C.c_float(0), C.c_float(1), ptr(orgb),
                                                  ptr(odep), nul, nul, stream_ptr()), "ngp_composite")
                 rgb[s:s + R], dep[s:s + R] = orgb, odep
                 s += R

@@ -189,7 +189,7 @@ class TrackingSLAM:
         keep_inactive, drop_active = fe.graph.remove_keyframe(k)
         ki = torch.from_numpy(keep_inactive).to(self.device)
         fe.target_inactive, fe.weight_inactive = fe.target_inactive[ki], fe.weight_inactive[ki]
-        fe._drop_payload(torch.from_numpy(drop_active).to(self.device), store=False)
+        fe._drop_payload(drop_active, store=False)
 
     # ---------------------------------------------------------------------------------------------
     def backend(self, steps):
@@ -202,7 +202,8 @@ class TrackingSLAM:
         g = fe.graph
         saved = g.max_factors
         g.reset(max_factors=16 * t)
-        fe.corr, fe.damping = None, 1e-6 * torch.ones_like(fe.cam0_idepths)
+        fe.corr, fe.damping = None, 1e-6 * torch.ones_like(fe.cam0_idepths)      # (drops the volume pool: the global
+        fe.slots, fe._free_slots = np.zeros(0, np.int32), []                       #  passes correlate on the fly)
         fe.target = fe.weight = fe.target_inactive = fe.weight_inactive = torch.zeros((0, fe.ht, fe.wd, 2), device=self.device)
         I, J = np.meshgrid(np.arange(0, t + 1), np.arange(0, t + 1), indexing="ij")
         d = fe.distance(I.reshape(-1), J.reshape(-1)).cpu().numpy()

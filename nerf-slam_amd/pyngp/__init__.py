@@ -117,9 +117,13 @@ class Testbed:
         self.camera_matrix = np.eye(4, dtype=np.float32)[:3]
         self.elapsed_training_time = 0.0
         self.training_step = 0
-        self.loss = float("nan")
+        self._loss_t = None
         self.steps_per_frame = 16
         self._t0 = time.time()
+
+    @property
+    def loss(self):
+        return float("nan") if self._loss_t is None else float(self._loss_t)
 
     # -- dataset -------------------------------------------------------------------------------
     def create_empty_nerf_dataset(self, n_images, nerf_scale=1.0, nerf_offset=None, aabb_scale=4, render_aabb=None):
@@ -176,7 +180,8 @@ class Testbed:
     def _push_images(self):
         n = self.nerf.training.n_images_for_training
         if self._net is not None and self._imgs is not None and n > 0:
-            self._net.set_images(self._imgs[:n], self._deps[:n], self._covs[:n], self._c2w[:n], self._intr)
+            # whole slot arrays + the number of valid views: addresses stay put as keyframes arrive (captured training step)
+            self._net.set_images(self._imgs, self._deps, self._covs, self._c2w, self._intr, n_images=n)
 
     # -- training / rendering ----------------------------------------------------------------------
     def frame(self):
@@ -184,10 +189,10 @@ class Testbed:
         if self.shall_train and self._net is not None and self._net.n_images > 0:
             t0 = time.time()
             loss = None
-            for _ in range(self.steps_per_frame):
-                loss = self._net.train_step()
+            for i in range(self.steps_per_frame):
+                loss = self._net.train_step(return_loss=(i == self.steps_per_frame - 1))
             if loss is not None:
-                self.loss = float(loss)
+                self._loss_t = loss                      # device scalar; converted when `loss` is read (no per-frame sync)
             self.training_step = self._net.step
             self.elapsed_training_time += time.time() - t0
         return True

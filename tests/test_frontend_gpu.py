@@ -57,7 +57,7 @@ def test_tracking_converges_to_ground_truth(oracle_mod, dev):
     fe.cam0_idepths_sensed[0] = gtD[0]
     fe.cam0_idepths[0] = gtD[0]
     fe.add_neighborhood_factors(0, nkf - 1, radius=3)
-    assert fe.ii.shape[0] == len(fe.graph.ii) == 24 and fe.corr.corr_pyramid[0].shape[0] == 24
+    assert fe.ii.shape[0] == len(fe.graph.ii) == 24 and len(fe.slots) == 24 and len(set(fe.slots.tolist())) == 24
 
     def err():
         c = fe.reproject(fe.ii, fe.jj)
@@ -83,7 +83,7 @@ def test_tracking_converges_to_ground_truth(oracle_mod, dev):
     # graph maintenance on the device payloads
     fe.add_proximity_factors(kf0=0, kf1=0, rad=2, nms=2, thresh=1e9)
     n = fe.ii.shape[0]
-    assert fe.target.shape[0] == n == fe.corr.corr_pyramid[3].shape[0]
+    assert fe.target.shape[0] == n == len(fe.slots) == fe.slots_dev.shape[0]
     fe.rm_factors(fe.graph.age > 5, store=True)
     assert fe.target_inactive.shape[0] == len(fe.graph.ii_inactive)
 

@@ -17,13 +17,14 @@ spec = importlib.util.spec_from_file_location("ngp_scene", os.path.join(root, "t
 sc = importlib.util.module_from_spec(spec); spec.loader.exec_module(sc)
 net.set_images(*sc.sphere_scene())
 for _ in range(warm):
-    net.train_step()
+    net.train_step(return_loss=False)
 torch.cuda.synchronize()
 t0 = time.perf_counter(); ns = 0; nr = 0
 for _ in range(steps):
-    net.train_step(); ns += net.last_samples; nr += net.counter[1].item()
+    net.train_step(return_loss=False)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+ns, nr = steps * net.last_samples, steps * int(net.last[1].item())   # (read once, after the timed loop: no per-step sync)
 print(f"steps/s {steps / dt:.1f}  ms/step {1e3 * dt / steps:.3f}  samples/step {ns / steps:.0f}  rays-with-samples/step {nr / steps:.0f}  Msamples/s {ns / dt / 1e6:.1f}  loss {float(net.loss_tensor):.4f}")
 
 # quality: render the training views at their poses and compare with the ground truth (linear rgb), PSNR in dB

@@ -146,10 +146,12 @@ def grounded_networks(stream, device, buffer, seed=0):
             c = _reproject(P2, self.kfD[last_kf][None].contiguous(), self.intr8, self._i0, self._i1, self.ht, self.wd)
             return (c[0] - self.coords0)[None, None]
 
-        def update(self, corr, motion, ii, jj):
-            res = super().update(corr, motion, ii, jj)                       # the real update operator
+        def update(self, corr, motion, ii, jj, ii_host=None, jj_host=None):
+            res = super().update(corr, motion, ii, jj, ii_host, jj_host)     # the real update operator
             true_c = _reproject(self.kfP, self.kfD, self.intr8, ii, jj, self.ht, self.wd)
             delta = (true_c - self.fe.reproject(ii, jj))[None]
             return (delta, torch.ones_like(delta)) + tuple(res[2:])
+
+        update.host_indices = True
 
     return GroundedNetworks()
