@@ -783,12 +783,25 @@ __global__ __launch_bounds__(256) void ngp_camera_grad_kernel(const float* __res
   const int s0 = ray_start[r], n = ray_n[r];
   if (n <= 0) return;
   float o0 = 0, o1 = 0, o2 = 0, d0 = 0, d1 = 0, d2 = 0;
-  for (int k = lane; k < n; k += 64) {
-    const long s = (long)s0 + k;
-    const float t = tmid[s];
-    const float a = dLdpos[s * 3] * pos_inv, b = dLdpos[s * 3 + 1] * pos_inv, c = dLdpos[s * 3 + 2] * pos_inv;
-    o0 += a; o1 += b; o2 += c;
-    d0 += t * a; d1 += t * b; d2 += t * c;
+  // four independent 64-sample chunks per round: the walk along a ray is a chain of dependent round trips otherwise
+  // (a 1024-sample ray: 16 of them; measured 114 us per step for ~2000 rays, the slowest wave's chain)
+  for (int k0 = 0; k0 < n; k0 += 256) {
+    float t[4], a[4], b[4], c[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + u * 64 + lane;
+      const long s = (long)s0 + (k < n ? k : 0);
+      const float m = k < n ? pos_inv : 0.0f;
+      t[u] = tmid[s];
+      a[u] = dLdpos[s * 3] * m;
+      b[u] = dLdpos[s * 3 + 1] * m;
+      c[u] = dLdpos[s * 3 + 2] * m;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      o0 += a[u]; o1 += b[u]; o2 += c[u];
+      d0 += t[u] * a[u]; d1 += t[u] * b[u]; d2 += t[u] * c[u];
+    }
   }
   o0 = wave_sum(o0); o1 = wave_sum(o1); o2 = wave_sum(o2);
   d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
