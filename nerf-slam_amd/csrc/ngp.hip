@@ -578,6 +578,11 @@ __device__ __forceinline__ BinSample bin_sample(const GridLayout& g, int l, uint
   return s;
 }
 
+__global__ void ngp_zero_ints_kernel(int* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void ngp_enc_bin_count_kernel(GridLayout g, BinPlan bp, const float* __restrict__ pos,
                                                                 const h2_t* __restrict__ dLdout, long N, int L, int unit_major,
                                                                 int* __restrict__ tot, int2* __restrict__ cnt) {
@@ -1449,10 +1454,10 @@ extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_has
       int2* cnt = reinterpret_cast<int2*>(reinterpret_cast<char*>(workspace) + bin_ws_tot_bytes(bp));
       unsigned long long* queue = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) +
                                                                         bin_ws_tot_bytes(bp) + bin_ws_cnt_bytes(bp));
-      if (hipMemsetAsync(tot, 0, bin_ws_tot_bytes(bp), (hipStream_t)stream) != hipSuccess) {
-        ns_set_error("ns_ngp_encode_backward: clearing the bin counters failed");
-        return NS_ELAUNCH;
-      }
+      // (a kernel, not hipMemsetAsync: a memset node in the captured training step faulted on its second replay, ROCm 7.2)
+      hipLaunchKernelGGL(ngp_zero_ints_kernel, dim3(ns_cdiv(bp.nh * NS_BIN_MAX, 256)), dim3(256), 0, (hipStream_t)stream, tot,
+                         bp.nh * NS_BIN_MAX);
+      NS_CHECK_LAUNCH("ngp_zero_ints_kernel");
       hipLaunchKernelGGL(ngp_enc_bin_count_kernel, dim3(bp.ntiles, bp.nh), dim3(256), 0, (hipStream_t)stream, g, bp, positions,
                          (const h2_t*)dLdout, N, n_levels, unit_major, tot, cnt);
       NS_CHECK_LAUNCH("ngp_enc_bin_count_kernel");
