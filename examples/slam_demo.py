@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "nerf-slam_amd"))
-from nerfslam.pipeline import DataModule, FusionModule, SlamModule  # noqa: E402
+from nerfslam.pipeline import DataModule, FusionModule, SlamModule, StreamQueue, spin_in_thread  # noqa: E402
 
 
 def parse_args(argv=None):
@@ -92,14 +92,32 @@ def run(args, return_modules=False, tweak=None):
         slam.register_input_queue("data", data_q)
         if split:
             slam.register_output_callback(lambda out: transport.broadcast_packet(out[1], 0, dev) if out[1] else None)
+    threaded = bool(args.parallel_run and args.fusion and not split and slam is not None)
     if args.fusion and not split:
-        fusion = FusionModule(args.fusion, args_seq, device=dev)
+        if threaded:
+            # --parallel_run on one GPU: the mapper spins in its own host thread on its own HIP stream and never blocks on
+            # its input (it trains on every spin without a packet, fusion_module.py:30-45); the tracker stays on this thread
+            args_par = argparse.Namespace(**{**vars(args_seq), "parallel_run": True})
+            fusion = FusionModule(args.fusion, args_par, device=dev)
+            slam_q = StreamQueue(maxsize=8)
+        else:
+            fusion = FusionModule(args.fusion, args_seq, device=dev)
         if slam:
             slam.register_output_queue(slam_q)
             fusion.register_input_queue("slam", slam_q)
     if slam is not None and tweak is not None:
         slam.initialize_module()
         tweak(slam)
+    if threaded:
+        fusion.initialize_module()
+        worker = spin_in_thread(fusion, dev)
+        while data.spin() and slam.spin() and not fusion.shutdown:
+            pass
+        while worker.is_alive() and not fusion.shutdown:      # the data ran out: let the mapper reach its stop condition
+            worker.join(timeout=0.05)
+        if return_modules:
+            return {"data": data, "slam": slam, "fusion": fusion}
+        return
     while data.spin() and (slam is None or slam.spin()) and (fusion is None or fusion.spin()):
         pass
     while fusion is not None and not fusion.shutdown and fusion.spin():

@@ -428,6 +428,11 @@ int ns_ngp_composite_ctl(const void* net_out, const float* dt, const float* tmid
 int ns_ngp_camera_gradient_ctl(const float* dLdpos, const float* tmid, const float* rays_d, const int* ray_start,
                                const int* ray_n, const int* ray_img, float pos_inv, float* cam_grad, int R, const int* ctl,
                                void* stream);
+/* two-stage camera gradient: per-ray 6-vectors into ray_scratch [R,6] f32, then one workgroup sums them per image in LDS and
+ * adds the sums to cam_grad [n_images,6] (no global atomics; n_images <= 4096).  ray_scratch == NULL: the atomic form. */
+int ns_ngp_camera_gradient_2stage(const float* dLdpos, const float* tmid, const float* rays_d, const int* ray_start,
+                                  const int* ray_n, const int* ray_img, float pos_inv, float* cam_grad, int R, const int* ctl,
+                                  float* ray_scratch, int n_images, void* stream);
 int ns_ngp_camera_step_ctl(float* c2w, float* cam_grad, float* m1, float* m2, int n_images, int step, float lr_pos, float lr_rot,
                            float beta1, float beta2, float eps, float grad_scale, const int* ctl, void* stream);
 int ns_ngp_adam_ctl(float* master, void* half_params, float* grad, float* m1, float* m2, long n, int step, float lr, float beta1,

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void ngp_encode_bwd_kernel(GridLayout g, const
 // ---------------------------------------------------------------------------------------------
 #define NS_ENC_SLICE 16384
 #define NS_ENC_PARTS 4
-#define NS_ENC_PARTS_BINNED 16
+#define NS_ENC_PARTS_BINNED 15   // 17 dense slices x 15 parts = 255 workgroups: one round on 256 CUs
 struct EncBwdPlan {
   int first[17];   // first virtual task of the k-th level in task order; first[n_levels] = number of tasks
   int level[16];   // k -> level
@@ -411,46 +411,22 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
       }
       continue;
     }
-    // dense level: run-length reduction over lanes in the same cell, then the run's last lane adds
-    float val[16];
-#pragma unroll
-    for (int corner = 0; corner < 8; corner++) {
-      float wt = 1.0f;
-      wt *= (corner & 1) ? w[0] : 1.0f - w[0];
-      wt *= (corner & 2) ? w[1] : 1.0f - w[1];
-      wt *= (corner & 4) ? w[2] : 1.0f - w[2];
-      val[corner * 2] = wt * d0;
-      val[corner * 2 + 1] = wt * d1;
-    }
-    const uint32_t p0 = __shfl_up(c[0], 1), p1 = __shfl_up(c[1], 1), p2 = __shfl_up(c[2], 1);
-    const int pv = __shfl_up((int)valid, 1);
-    const bool head = lane == 0 || !valid || !pv || p0 != c[0] || p1 != c[1] || p2 != c[2];
-    const uint64_t hm = __ballot(head);
-    bool issue = valid;
-    if (__popcll(hm) <= 40) {
-      const int start = 63 - __clzll(hm & (~0ull >> (63 - lane)));
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const bool take = lane - d >= start;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-          const float u = __shfl_up(val[q], d);
-          if (take) val[q] += u;
-        }
-      }
-      issue = valid && (lane == 63 || ((hm >> (lane + 1)) & 1ull));
-    }
-    if (issue) {
+    // dense level: every lane adds its 8 corners.  (The run-length reduction of the atomic kernel does not pay here: lanes
+    // of a wave that hit the same LDS address serialise at ~1 per cycle, the 96 ds_bpermute of a 16-value segmented scan
+    // cost several thousand cycles -- 130 -> ~30 us for the four dense levels of the default grid.)
+    if (valid) {
+      const float wx[2] = {1.0f - w[0], w[0]}, wy[2] = {1.0f - w[1], w[1]}, wz[2] = {1.0f - w[2], w[2]};
 #pragma unroll
       for (int corner = 0; corner < 8; corner++) {
         const uint32_t idx = grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2));
         const uint32_t rel = idx - lo;
         if (rel < cnt) {
+          const float wt = wx[corner & 1] * wy[(corner >> 1) & 1] * wz[corner >> 2];
           if (FIXED) {
-            atomicAdd(&tab[rel], pack_fixed(val[corner * 2], val[corner * 2 + 1], fixed_scale));
+            atomicAdd(&tab[rel], pack_fixed(wt * d0, wt * d1, fixed_scale));
           } else {
-            atomicAdd(&tabf[2 * rel], val[corner * 2]);
-            atomicAdd(&tabf[2 * rel + 1], val[corner * 2 + 1]);
+            atomicAdd(&tabf[2 * rel], wt * d0);
+            atomicAdd(&tabf[2 * rel + 1], wt * d1);
           }
         }
       }
@@ -648,13 +624,16 @@ __global__ __launch_bounds__(256) void ngp_enc_bin_scatter_kernel(GridLayout g, 
     const long i = (long)tile * NS_BIN_TILE + j * 256 + tid;
     const BinSample s = bin_sample(g, l, hs, pos, dLdout, i, N, L, unit_major);
     if (s.valid) {
+      int slot[8];   // the eight returning LDS atomics and base reads are issued back to back; the records follow
 #pragma unroll
       for (int corner = 0; corner < 8; corner++) {
-        const uint32_t idx = s.idx[corner];
-        const int b = (int)(idx >> 14);
-        const int r = atomicAdd(&lcnt[b], 1);
+        const int b = (int)(s.idx[corner] >> 14);
+        slot[corner] = atomicAdd(&lcnt[b], 1) + lbase[b];
+      }
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) {
         const float wt = s.wx[corner & 1] * s.wy[(corner >> 1) & 1] * s.wz[corner >> 2];
-        rec[lbase[b] + r] = bin_record(idx & 16383u, wt * s.d0, wt * s.d1, fixed_scale);
+        rec[slot[corner]] = bin_record(s.idx[corner] & 16383u, wt * s.d0, wt * s.d1, fixed_scale);
       }
     }
   }
@@ -780,7 +759,7 @@ __global__ __launch_bounds__(256) void ngp_camera_grad_kernel(const float* __res
                                                               const int* __restrict__ ray_start, const int* __restrict__ ray_n,
                                                               const int* __restrict__ ray_img, float pos_inv,
                                                               float* __restrict__ cam_grad, int Rcap,
-                                                              const int* __restrict__ ctl) {
+                                                              const int* __restrict__ ctl, float* __restrict__ ray_g) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int R = ctl ? min(ctl[NS_CTL_RAYS], Rcap) : Rcap;
@@ -812,6 +791,12 @@ __global__ __launch_bounds__(256) void ngp_camera_grad_kernel(const float* __res
   d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
   if (lane == 0) {
     const float x = rays_d[r * 3], y = rays_d[r * 3 + 1], z = rays_d[r * 3 + 2];
+    if (ray_g != nullptr) {   // two-stage form: the per-image sums are formed by ngp_camera_grad_reduce_kernel
+      float* gp = ray_g + (long)r * 6;
+      gp[0] = o0; gp[1] = o1; gp[2] = o2;
+      gp[3] = y * d2 - z * d1; gp[4] = z * d0 - x * d2; gp[5] = x * d1 - y * d0;
+      return;
+    }
     float* gp = cam_grad + (long)ray_img[r] * 6;
     atomicAdd(gp + 0, o0);
     atomicAdd(gp + 1, o1);
@@ -819,6 +804,32 @@ __global__ __launch_bounds__(256) void ngp_camera_grad_kernel(const float* __res
     atomicAdd(gp + 3, y * d2 - z * d1);  // d x g_d
     atomicAdd(gp + 4, z * d0 - x * d2);
     atomicAdd(gp + 5, x * d1 - y * d0);
+  }
+}
+
+// Second stage of the camera gradient: ONE workgroup adds the per-ray vectors into a per-image table in LDS and adds the
+// table to cam_grad.  (Thousands of rays share a few dozen images: as global atomics those are same-address atomics,
+// which this part executes at the memory side one after the other -- 113 us per step for ~2000 rays.)
+#define NS_CAM_LDS_IMAGES 4096
+__global__ __launch_bounds__(1024) void ngp_camera_grad_reduce_kernel(const float* __restrict__ ray_g, const int* __restrict__ ray_n,
+                                                                      const int* __restrict__ ray_img, float* __restrict__ cam_grad,
+                                                                      int Rcap, int n_images, const int* __restrict__ ctl) {
+  __shared__ float tab[NS_CAM_LDS_IMAGES * 6];
+  const int R = ctl ? min(ctl[NS_CTL_RAYS], Rcap) : Rcap;
+  const int nimg = min(n_images, NS_CAM_LDS_IMAGES);
+  for (int e = threadIdx.x; e < nimg * 6; e += 1024) tab[e] = 0.0f;
+  __syncthreads();
+  for (int r = threadIdx.x; r < R; r += 1024) {
+    if (ray_n[r] <= 0) continue;
+    const int img = ray_img[r];
+    if (img < 0 || img >= nimg) continue;
+#pragma unroll
+    for (int k = 0; k < 6; k++) atomicAdd(&tab[img * 6 + k], ray_g[(long)r * 6 + k]);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nimg * 6; e += 1024) {
+    const float v = tab[e];
+    if (v != 0.0f) cam_grad[e] += v;
   }
 }
 
@@ -1539,11 +1550,25 @@ extern "C" int ns_ngp_camera_gradient(const float* dLdpos, const float* tmid, co
 extern "C" int ns_ngp_camera_gradient_ctl(const float* dLdpos, const float* tmid, const float* rays_d, const int* ray_start,
                                           const int* ray_n, const int* ray_img, float pos_inv, float* cam_grad, int R,
                                           const int* ctl, void* stream) {
+  return ns_ngp_camera_gradient_2stage(dLdpos, tmid, rays_d, ray_start, ray_n, ray_img, pos_inv, cam_grad, R, ctl, nullptr, 0,
+                                       stream);
+}
+
+extern "C" int ns_ngp_camera_gradient_2stage(const float* dLdpos, const float* tmid, const float* rays_d, const int* ray_start,
+                                             const int* ray_n, const int* ray_img, float pos_inv, float* cam_grad, int R,
+                                             const int* ctl, float* ray_scratch, int n_images, void* stream) {
+  NS_REQUIRE(ray_scratch == nullptr || (n_images >= 1 && n_images <= NS_CAM_LDS_IMAGES),
+             "ns_ngp_camera_gradient_2stage: 1..%d images", NS_CAM_LDS_IMAGES);
   NS_REQUIRE(dLdpos && tmid && rays_d && ray_start && ray_n && ray_img && cam_grad, "ns_ngp_camera_gradient: null pointer");
   if (R <= 0) return NS_OK;
   hipLaunchKernelGGL(ngp_camera_grad_kernel, dim3(ns_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, dLdpos, tmid, rays_d,
-                     ray_start, ray_n, ray_img, pos_inv, cam_grad, R, ctl);
+                     ray_start, ray_n, ray_img, pos_inv, cam_grad, R, ctl, ray_scratch);
   NS_CHECK_LAUNCH("ngp_camera_grad_kernel");
+  if (ray_scratch != nullptr) {
+    hipLaunchKernelGGL(ngp_camera_grad_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ray_scratch, ray_n, ray_img,
+                       cam_grad, R, n_images, ctl);
+    NS_CHECK_LAUNCH("ngp_camera_grad_reduce_kernel");
+  }
   return NS_OK;
 }
 

@@ -238,6 +238,7 @@ class NgpNerf:
         self.out_rgb, self.out_depth = torch.zeros((Rc, 3), **f), torch.zeros(Rc, **f)
         self.loss_acc = torch.zeros(1, **f)
         self.dpos = torch.zeros((c.max_samples, 3), **f)
+        self.ray_g = torch.zeros((Rc, 6), **f)
         import struct
         fbits = lambda x: struct.unpack("<i", struct.pack("<f", x))[0]
         self.ctl = torch.tensor([self.step, min(self.rays_per_batch, Rc), self.seed & 0x7FFFFFFF, max(self.n_images, 1),
@@ -294,9 +295,10 @@ class NgpNerf:
         if c.optimize_extrinsics:
             check(L.ns_ngp_encode_backward_input(*self._grid_args(), ptr(self.s_pos), ptr(self.grid_half), ptr(self.s_dfeat),
                                                  ptr(self.dpos), C.c_long(S), st), "ngp_encode_backward_input")
-            check(L.ns_ngp_camera_gradient_ctl(ptr(self.dpos), ptr(self.s_t), ptr(self.r_d), ptr(self.ray_start), ptr(self.ray_n),
-                                               ptr(self.r_img), C.c_float(1.0 / s), ptr(self.cam_grad), Rc, ctl, st),
-                  "ngp_camera_gradient")
+            n_cam = self.cam_grad.shape[0]
+            check(L.ns_ngp_camera_gradient_2stage(ptr(self.dpos), ptr(self.s_t), ptr(self.r_d), ptr(self.ray_start), ptr(self.ray_n),
+                                                  ptr(self.r_img), C.c_float(1.0 / s), ptr(self.cam_grad), Rc, ctl,
+                                                  ptr(self.ray_g) if n_cam <= 4096 else None, n_cam, st), "ngp_camera_gradient")
         if self.world > 1:
             self._allreduce_gradients()
         if c.optimize_extrinsics:   # after the all-reduce: every replica applies the SAME pose update
@@ -333,8 +335,8 @@ class NgpNerf:
                 elif self._graph is None:
                     torch.cuda.synchronize(dev)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        self._enqueue_step()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other host threads (the tracker under
+                        self._enqueue_step()                                        # --parallel_run) keep launching meanwhile
                     self._graph = g             # (capturing does not execute: the step runs with the first replay)
                     g.replay()
                 else:

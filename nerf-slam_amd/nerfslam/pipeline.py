@@ -11,8 +11,67 @@ over RCCL (nerfslam.transport) instead of being moved to the CPU and pickled
 """
 import logging
 import queue as _queue
+import threading
 
 log = logging.getLogger("nerfslam.pipeline")
+
+
+def _walk_tensors(obj):
+    import torch
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _walk_tensors(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _walk_tensors(v)
+
+
+class StreamQueue(_queue.Queue):
+    """Queue between two modules that run in different host threads on different HIP streams of ONE process -- the
+    single-GPU form of the reference's --parallel_run (one process per module and a torch.multiprocessing queue,
+    examples/slam_demo.py:100-160).  put() records an event on the producer's current stream; get() makes the consumer's
+    current stream wait for it and tells the caching allocator that the packet's tensors are in use there."""
+
+    def put(self, item, block=True, timeout=None):
+        import torch
+        ev = None
+        if item is not None and torch.cuda.is_available():
+            ev = torch.cuda.Event()
+            ev.record()
+        super().put((item, ev), block, timeout)
+
+    def get(self, block=True, timeout=None):
+        import torch
+        item, ev = super().get(block, timeout)
+        if ev is not None:
+            s = torch.cuda.current_stream()
+            s.wait_event(ev)
+            for t in _walk_tensors(item):
+                if t.is_cuda:
+                    t.record_stream(s)
+        return item
+
+
+def spin_in_thread(module, device, stream=None):
+    """run `module.spin()` (its parallel_run loop) in a host thread under its own HIP stream; returns the thread"""
+    import torch
+    stream = stream or torch.cuda.Stream(device=device)
+
+    def work():
+        torch.cuda.set_device(device)
+        torch.set_grad_enabled(False)
+        with torch.cuda.stream(stream):
+            try:
+                module.spin()
+            except BaseException as e:       # noqa: BLE001 -- surfaced through the module's failure callbacks
+                log.error("module %s died: %s", module.name, e)
+                module.error = e
+                module.notify_on_failure()
+    t = threading.Thread(target=work, name=f"nerfslam-{module.name}", daemon=True)
+    t.start()
+    return t
 
 
 class PipelineModuleBase:
