@@ -337,7 +337,8 @@ template <bool FIXED>
 __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, EncBwdPlan plan, const float* __restrict__ pos,
                                                                   const h2_t* __restrict__ dLdout, float* __restrict__ grad,
                                                                   long N, int L, int n_levels, int unit_major,
-                                                                  float fixed_scale) {
+                                                                  float fixed_scale, unsigned long long* __restrict__ partial,
+                                                                  long partial_stride) {
   __shared__ unsigned long long tab[NS_ENC_SLICE];  // packed fixed-point words, or float2 bit patterns
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = gridDim.x >> 3;
@@ -435,6 +436,14 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
   __syncthreads();
   // flush: this workgroup is the only writer of its entries (nparts == 1) -> plain read-modify-write of the non-zero ones
   unsigned long long* __restrict__ g64 = reinterpret_cast<unsigned long long*>(grad) + g.offset[l] + lo;
+  if (FIXED && partial != nullptr && nparts > 1) {
+    // multi-part (dense) slices with a workspace: every part stores its whole slice (zeros included) in its own plane and
+    // ngp_enc_dense_reduce_kernel adds the planes -- the merge by global atomics cost more than the accumulation itself
+    // (up to 15 same-address memory-side atomics per touched entry)
+    unsigned long long* __restrict__ dst = partial + (long)part * partial_stride + g.offset[l] + lo;
+    for (uint32_t e = tid; e < cnt; e += 1024) dst[e] = tab[e];
+    return;
+  }
   for (uint32_t e = tid; e < cnt; e += 1024) {
     const unsigned long long word = tab[e];
     if (word == 0ull) continue;
@@ -453,6 +462,16 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
       }
     }
   }
+}
+
+// sum of the NS_ENC_PARTS_BINNED partial planes of the dense levels (entries [0, n_dense) of the grid) into the gradient
+__global__ __launch_bounds__(256) void ngp_enc_dense_reduce_kernel(const unsigned long long* __restrict__ partial, long stride,
+                                                                   int nparts, long n_dense, float* __restrict__ grad) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_dense) return;
+  unsigned long long sum = 0ull;
+  for (int p = 0; p < nparts; p++) sum += partial[(long)p * stride + e];
+  if (sum != 0ull) reinterpret_cast<unsigned long long*>(grad)[e] += sum;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -504,8 +523,19 @@ static bool bin_plan_ok(const BinPlan& b) {
 // workspace layout (bytes): [tot: nh*32 int32 (kept zero between calls)] [cnt: nh*ntiles*32 int2 {count, offset}] [queue]
 static size_t bin_ws_tot_bytes(const BinPlan& b) { return ((size_t)b.nh * NS_BIN_MAX * 4 + 255) / 256 * 256; }
 static size_t bin_ws_cnt_bytes(const BinPlan& b) { return ((size_t)b.nh * b.ntiles * NS_BIN_MAX * 8 + 255) / 256 * 256; }
-static size_t bin_ws_bytes(const BinPlan& b, long N) {
-  return bin_ws_tot_bytes(b) + bin_ws_cnt_bytes(b) + (size_t)b.nh * 8 * (size_t)(b.ntiles * (long)NS_BIN_TILE) * 8;
+static size_t bin_ws_queue_bytes(const BinPlan& b) { return (size_t)b.nh * 8 * (size_t)(b.ntiles * (long)NS_BIN_TILE) * 8; }
+// dense levels = the leading (coarsest) levels of the grid: entries [0, n_dense); one partial plane per sample part
+static long dense_prefix_entries(const GridLayout& g, int n_levels) {
+  int l = 0;
+  while (l < n_levels && !level_is_hashed(g, l)) l++;
+  for (int m = l; m < n_levels; m++)
+    if (!level_is_hashed(g, m)) return -1;   // a dense level above a hashed one: not a prefix (not produced by grid_layout_host)
+  return (long)g.offset[l];
+}
+static size_t bin_ws_bytes(const BinPlan& b, const GridLayout& g, int n_levels) {
+  const long nd = dense_prefix_entries(g, n_levels);
+  return bin_ws_tot_bytes(b) + bin_ws_cnt_bytes(b) + bin_ws_queue_bytes(b) +
+         (nd > 0 ? (size_t)NS_ENC_PARTS_BINNED * (size_t)nd * 8 : 0);
 }
 
 struct BinSample {
@@ -638,14 +668,13 @@ __global__ __launch_bounds__(256) void ngp_enc_bin_scatter_kernel(GridLayout g, 
     }
   }
   __syncthreads();
-  const int total = lbase[32];
   unsigned long long* __restrict__ q = queue + (long)k * 8 * ((long)bp.ntiles * NS_BIN_TILE);
-  for (int e = tid; e < total; e += 256) {
-    int b = 0;  // bin of staged record e: largest b with lbase[b] <= e (5-step binary search over the LDS table)
-#pragma unroll
-    for (int step = 16; step >= 1; step >>= 1)
-      if (b + step < NS_BIN_MAX && lbase[b + step] <= e) b += step;
-    q[(long)gdst[b] + (e - lbase[b])] = rec[e];
+  // copy-out: a wave takes every fourth bin and streams its staged run (consecutive lanes -> consecutive records)
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int b = wave; b < NS_BIN_MAX; b += 4) {
+    const int b0 = lbase[b], n = lbase[b + 1] - b0;
+    unsigned long long* __restrict__ dst = q + gdst[b];
+    for (int e = lane; e < n; e += 64) dst[e] = rec[b0 + e];
   }
 }
 
@@ -1434,7 +1463,7 @@ extern "C" long ns_ngp_encode_backward_workspace_bytes(int n_levels, int n_featu
   replica_plan_host(g, n_levels, rp);
   BinPlan bp;
   bin_plan_host(g, n_levels, max_samples > 0 ? max_samples : 1, bp);
-  const size_t bin = bin_plan_ok(bp) ? bin_ws_bytes(bp, max_samples) : 0;
+  const size_t bin = bin_plan_ok(bp) ? bin_ws_bytes(bp, g, n_levels) : 0;
   const size_t rep_b = rp.total_floats * sizeof(float);   // (round-1 atomic path, NS_ENC_BWD_ATOMIC)
   return (long)(bin > rep_b ? bin : rep_b);
 }
@@ -1479,13 +1508,26 @@ extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_has
                          grad_params);
       NS_CHECK_LAUNCH("ngp_enc_bin_accum_kernel");
       if (tasks == 0) return NS_OK;
+      const long nd = dense_prefix_entries(g, n_levels);
+      if (nd > 0) {
+        unsigned long long* partial = queue + bin_ws_queue_bytes(bp) / 8;
+        hipLaunchKernelGGL(ngp_encode_bwd_lds_kernel<true>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
+                           (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale, partial, nd);
+        NS_CHECK_LAUNCH("ngp_encode_bwd_lds_kernel");
+        hipLaunchKernelGGL(ngp_enc_dense_reduce_kernel, dim3(ns_cdiv(nd, 256)), dim3(256), 0, (hipStream_t)stream, partial, nd,
+                           NS_ENC_PARTS_BINNED, nd, grad_params);
+        NS_CHECK_LAUNCH("ngp_enc_dense_reduce_kernel");
+        return NS_OK;
+      }
     }
     if (fixed_scale > 0.0f)
       hipLaunchKernelGGL(ngp_encode_bwd_lds_kernel<true>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
-                         (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale);
+                         (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale,
+                         (unsigned long long*)nullptr, 0L);
     else
       hipLaunchKernelGGL(ngp_encode_bwd_lds_kernel<false>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
-                         (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale);
+                         (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale,
+                         (unsigned long long*)nullptr, 0L);
     NS_CHECK_LAUNCH("ngp_encode_bwd_lds_kernel");
     return NS_OK;
   }
