@@ -55,6 +55,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// integer form of wave_sum (same six DPP steps, v_add_u32): exact and order independent
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add_i(int v) {
+  return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
+}
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+  v = dpp_add_i<0xB1, 0xf>(v);
+  v = dpp_add_i<0x4E, 0xf>(v);
+  v = dpp_add_i<0x141, 0xf>(v);
+  v = dpp_add_i<0x140, 0xf>(v);
+  v = dpp_add_i<0x142, 0xa>(v);
+  v = dpp_add_i<0x143, 0xc>(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -412,22 +412,67 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
       }
       continue;
     }
-    // dense level: every lane adds its 8 corners.  (The run-length reduction of the atomic kernel does not pay here: lanes
-    // of a wave that hit the same LDS address serialise at ~1 per cycle, the 96 ds_bpermute of a 16-value segmented scan
-    // cost several thousand cycles -- 130 -> ~30 us for the four dense levels of the default grid.)
-    if (valid) {
-      const float wx[2] = {1.0f - w[0], w[0]}, wy[2] = {1.0f - w[1], w[1]}, wz[2] = {1.0f - w[2], w[2]};
+    // dense level.  Lanes of a wave that hit the SAME LDS address serialise as dependent read-modify-writes (measured: the
+    // four dense levels took 88 us with one ds_add per lane and corner -- along a ray 16-30 consecutive samples share a
+    // level-0 cell).  So the wave first reduces, cell by cell: the lowest pending lane's cell is broadcast, the lanes in
+    // that cell sum their 16 contributions with DPP row reductions (no LDS, no waits) and the leader adds the totals; after
+    // four such cells the remaining lanes (cells with few samples) add their own.  In the packed mode the contributions
+    // are rounded to Q(S) integers BEFORE the reduction, so the result is the same integer sum as in every other path.
+    const float wx[2] = {1.0f - w[0], w[0]}, wy[2] = {1.0f - w[1], w[1]}, wz[2] = {1.0f - w[2], w[2]};
+    float wt[8];
+#pragma unroll
+    for (int corner = 0; corner < 8; corner++) wt[corner] = valid ? wx[corner & 1] * wy[(corner >> 1) & 1] * wz[corner >> 2] : 0.0f;
+    const uint32_t key = c[0] | (c[1] << 10) | (c[2] << 20);   // dense levels: res^3 <= 2^19, i.e. res <= 80
+    uint64_t todo = __ballot(valid), direct = 0ull;
+    for (int it = 0; it < 4 && todo != 0ull; it++) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+      const bool mine = ((todo >> lane) & 1ull) && key == k0;
+      const uint64_t grp = __ballot(mine);
+      if (__popcll(grp) == 1) {       // a lone sample: nothing to reduce, its lane adds directly below
+        direct |= grp;
+        todo &= ~grp;
+        continue;
+      }
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) {
+        unsigned long long word = 0ull;
+        float f0 = 0.0f, f1 = 0.0f;
+        if (FIXED) {
+          const int a0 = wave_sum_i(mine ? __float2int_rn(wt[corner] * d0 * fixed_scale) : 0);
+          const int a1 = wave_sum_i(mine ? __float2int_rn(wt[corner] * d1 * fixed_scale) : 0);
+          word = (unsigned long long)((long long)a0 + ((long long)a1 << 32));
+        } else {
+          f0 = wave_sum(mine ? wt[corner] * d0 : 0.0f);
+          f1 = wave_sum(mine ? wt[corner] * d1 : 0.0f);
+        }
+        if (lane == leader) {
+          const uint32_t idx = grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2));
+          const uint32_t rel = idx - lo;
+          if (rel < cnt) {
+            if (FIXED) {
+              atomicAdd(&tab[rel], word);
+            } else {
+              atomicAdd(&tabf[2 * rel], f0);
+              atomicAdd(&tabf[2 * rel + 1], f1);
+            }
+          }
+        }
+      }
+      todo &= ~grp;
+    }
+    direct |= todo;
+    if ((direct >> lane) & 1ull) {
 #pragma unroll
       for (int corner = 0; corner < 8; corner++) {
         const uint32_t idx = grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2));
         const uint32_t rel = idx - lo;
         if (rel < cnt) {
-          const float wt = wx[corner & 1] * wy[(corner >> 1) & 1] * wz[corner >> 2];
           if (FIXED) {
-            atomicAdd(&tab[rel], pack_fixed(wt * d0, wt * d1, fixed_scale));
+            atomicAdd(&tab[rel], pack_fixed(wt[corner] * d0, wt[corner] * d1, fixed_scale));
           } else {
-            atomicAdd(&tabf[2 * rel], wt * d0);
-            atomicAdd(&tabf[2 * rel + 1], wt * d1);
+            atomicAdd(&tabf[2 * rel], wt[corner] * d0);
+            atomicAdd(&tabf[2 * rel + 1], wt[corner] * d1);
           }
         }
       }
