@@ -423,8 +423,11 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
 #pragma unroll
     for (int corner = 0; corner < 8; corner++) wt[corner] = valid ? wx[corner & 1] * wy[(corner >> 1) & 1] * wz[corner >> 2] : 0.0f;
     const uint32_t key = c[0] | (c[1] << 10) | (c[2] << 20);   // dense levels: res^3 <= 2^19, i.e. res <= 80
+    // (only on the coarsest levels, res <= 32, where a wave spans two to four cells: measured, the reduction loop costs the
+    // finer dense levels -- 7-12 cells per wave, few lanes each -- more than their 5-9-way LDS conflicts do)
     uint64_t todo = __ballot(valid), direct = 0ull;
-    for (int it = 0; it < 4 && todo != 0ull; it++) {
+    const int max_it = res <= 32u ? 6 : 0;
+    for (int it = 0; it < max_it && todo != 0ull; it++) {
       const int leader = __ffsll((long long)todo) - 1;
       const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
       const bool mine = ((todo >> lane) & 1ull) && key == k0;
