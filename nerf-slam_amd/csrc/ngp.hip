@@ -298,12 +298,14 @@ __global__ __launch_bounds__(256) void ngp_encode_bwd_kernel(GridLayout g, const
 // ---------------------------------------------------------------------------------------------
 #define NS_ENC_SLICE 16384
 #define NS_ENC_PARTS 4
-#define NS_ENC_PARTS_BINNED 15   // 17 dense slices x 15 parts = 255 workgroups: one round on 256 CUs
+#define NS_ENC_PARTS_BINNED 15   // dense levels of several slices
+#define NS_ENC_PARTS_COARSE 64   // single-slice (coarsest) dense levels: see the dense branch of the kernel
 struct EncBwdPlan {
   int first[17];   // first virtual task of the k-th level in task order; first[n_levels] = number of tasks
   int level[16];   // k -> level
   int slices[16];  // per LEVEL
   int parts[16];   // per LEVEL
+  long plane_base[16];  // per LEVEL: first entry of the level's partial planes (parts[l] planes of its table size each)
 };
 
 static bool level_is_hashed(const GridLayout& g, int l) {
@@ -314,13 +316,14 @@ static bool level_is_hashed(const GridLayout& g, int l) {
 static int enc_bwd_plan_host(const GridLayout& g, int n_levels, EncBwdPlan& p, bool dense_only) {
   int k = 0, t = 0;
   for (int l = 0; l < 16; l++) p.slices[l] = p.parts[l] = 0;
-  for (int pass = dense_only ? 1 : 0; pass < 2; pass++)  // hashed (1 part) levels first, then the dense ones
-    for (int l = 0; l < n_levels; l++) {
+  for (int pass = dense_only ? 1 : 0; pass < 2; pass++)  // hashed (1 part) levels first, then the dense ones, finest first
+    for (int li = 0; li < n_levels; li++) {                // (their tasks are the longest: they should start first)
+      const int l = pass == 0 ? li : n_levels - 1 - li;
       const uint32_t hs = g.offset[l + 1] - g.offset[l];
       const bool hashed = level_is_hashed(g, l);
       if (hashed != (pass == 0)) continue;
       p.slices[l] = (int)((hs + NS_ENC_SLICE - 1) / NS_ENC_SLICE);
-      p.parts[l] = hashed ? 1 : (dense_only ? NS_ENC_PARTS_BINNED : NS_ENC_PARTS);
+      p.parts[l] = hashed ? 1 : (!dense_only ? NS_ENC_PARTS : (p.slices[l] == 1 ? NS_ENC_PARTS_COARSE : NS_ENC_PARTS_BINNED));
       p.level[k] = l;
       p.first[k] = t;
       t += p.slices[l] * p.parts[l];
@@ -329,6 +332,11 @@ static int enc_bwd_plan_host(const GridLayout& g, int n_levels, EncBwdPlan& p, b
   for (; k <= 16; k++) {
     p.first[k] = t;
     if (k < 16) p.level[k] = 0;
+  }
+  long base = 0;
+  for (int l = 0; l < 16; l++) {
+    p.plane_base[l] = base;
+    if (l < n_levels && !level_is_hashed(g, l)) base += (long)p.parts[l] * (long)(g.offset[l + 1] - g.offset[l]);
   }
   return t;
 }
@@ -412,70 +420,25 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
       }
       continue;
     }
-    // dense level.  Lanes of a wave that hit the SAME LDS address serialise as dependent read-modify-writes (measured: the
-    // four dense levels took 88 us with one ds_add per lane and corner -- along a ray 16-30 consecutive samples share a
-    // level-0 cell).  So the wave first reduces, cell by cell: the lowest pending lane's cell is broadcast, the lanes in
-    // that cell sum their 16 contributions with DPP row reductions (no LDS, no waits) and the leader adds the totals; after
-    // four such cells the remaining lanes (cells with few samples) add their own.  In the packed mode the contributions
-    // are rounded to Q(S) integers BEFORE the reduction, so the result is the same integer sum as in every other path.
-    const float wx[2] = {1.0f - w[0], w[0]}, wy[2] = {1.0f - w[1], w[1]}, wz[2] = {1.0f - w[2], w[2]};
-    float wt[8];
-#pragma unroll
-    for (int corner = 0; corner < 8; corner++) wt[corner] = valid ? wx[corner & 1] * wy[(corner >> 1) & 1] * wz[corner >> 2] : 0.0f;
-    const uint32_t key = c[0] | (c[1] << 10) | (c[2] << 20);   // dense levels: res^3 <= 2^19, i.e. res <= 80
-    // (only on the coarsest levels, res <= 32, where a wave spans two to four cells: measured, the reduction loop costs the
-    // finer dense levels -- 7-12 cells per wave, few lanes each -- more than their 5-9-way LDS conflicts do)
-    uint64_t todo = __ballot(valid), direct = 0ull;
-    const int max_it = res <= 32u ? 6 : 0;
-    for (int it = 0; it < max_it && todo != 0ull; it++) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
-      const bool mine = ((todo >> lane) & 1ull) && key == k0;
-      const uint64_t grp = __ballot(mine);
-      if (__popcll(grp) == 1) {       // a lone sample: nothing to reduce, its lane adds directly below
-        direct |= grp;
-        todo &= ~grp;
-        continue;
-      }
-#pragma unroll
-      for (int corner = 0; corner < 8; corner++) {
-        unsigned long long word = 0ull;
-        float f0 = 0.0f, f1 = 0.0f;
-        if (FIXED) {
-          const int a0 = wave_sum_i(mine ? __float2int_rn(wt[corner] * d0 * fixed_scale) : 0);
-          const int a1 = wave_sum_i(mine ? __float2int_rn(wt[corner] * d1 * fixed_scale) : 0);
-          word = (unsigned long long)((long long)a0 + ((long long)a1 << 32));
-        } else {
-          f0 = wave_sum(mine ? wt[corner] * d0 : 0.0f);
-          f1 = wave_sum(mine ? wt[corner] * d1 : 0.0f);
-        }
-        if (lane == leader) {
-          const uint32_t idx = grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2));
-          const uint32_t rel = idx - lo;
-          if (rel < cnt) {
-            if (FIXED) {
-              atomicAdd(&tab[rel], word);
-            } else {
-              atomicAdd(&tabf[2 * rel], f0);
-              atomicAdd(&tabf[2 * rel + 1], f1);
-            }
-          }
-        }
-      }
-      todo &= ~grp;
-    }
-    direct |= todo;
-    if ((direct >> lane) & 1ull) {
+    // dense level: every lane adds its 8 corners.  Lanes of a wave that hit the SAME LDS address are served one per cycle
+    // (measured: ~85 cycles per 64-lane ds_add when a whole wave sits in one level-0 cell), so a task costs about one cycle
+    // per (sample, corner) it accumulates: the coarsest levels -- where every sample hits the single slice 8 times -- are
+    // therefore split over more sample parts (NS_ENC_PARTS_COARSE).  Tried and dropped: the run-length scan of the atomic
+    // kernel (96 ds_bpermute per wave) and a cell-by-cell DPP reduction (16 wave sums per distinct cell): both cost more
+    // VALU time at four waves per SIMD than the conflicts they remove.
+    if (valid) {
+      const float wx[2] = {1.0f - w[0], w[0]}, wy[2] = {1.0f - w[1], w[1]}, wz[2] = {1.0f - w[2], w[2]};
 #pragma unroll
       for (int corner = 0; corner < 8; corner++) {
         const uint32_t idx = grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2));
         const uint32_t rel = idx - lo;
         if (rel < cnt) {
+          const float wt = wx[corner & 1] * wy[(corner >> 1) & 1] * wz[corner >> 2];
           if (FIXED) {
-            atomicAdd(&tab[rel], pack_fixed(wt[corner] * d0, wt[corner] * d1, fixed_scale));
+            atomicAdd(&tab[rel], pack_fixed(wt * d0, wt * d1, fixed_scale));
           } else {
-            atomicAdd(&tabf[2 * rel], wt[corner] * d0);
-            atomicAdd(&tabf[2 * rel + 1], wt[corner] * d1);
+            atomicAdd(&tabf[2 * rel], wt * d0);
+            atomicAdd(&tabf[2 * rel + 1], wt * d1);
           }
         }
       }
@@ -488,7 +451,7 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
     // multi-part (dense) slices with a workspace: every part stores its whole slice (zeros included) in its own plane and
     // ngp_enc_dense_reduce_kernel adds the planes -- the merge by global atomics cost more than the accumulation itself
     // (up to 15 same-address memory-side atomics per touched entry)
-    unsigned long long* __restrict__ dst = partial + (long)part * partial_stride + g.offset[l] + lo;
+    unsigned long long* __restrict__ dst = partial + plan.plane_base[l] + (long)part * hs + lo;
     for (uint32_t e = tid; e < cnt; e += 1024) dst[e] = tab[e];
     return;
   }
@@ -512,13 +475,18 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
   }
 }
 
-// sum of the NS_ENC_PARTS_BINNED partial planes of the dense levels (entries [0, n_dense) of the grid) into the gradient
-__global__ __launch_bounds__(256) void ngp_enc_dense_reduce_kernel(const unsigned long long* __restrict__ partial, long stride,
-                                                                   int nparts, long n_dense, float* __restrict__ grad) {
+// sum of the partial planes of the dense levels (entries [0, n_dense) of the grid) into the gradient
+__global__ __launch_bounds__(256) void ngp_enc_dense_reduce_kernel(GridLayout g, EncBwdPlan plan, int n_levels,
+                                                                   const unsigned long long* __restrict__ partial, long n_dense,
+                                                                   float* __restrict__ grad) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= n_dense) return;
+  int l = 0;
+  while (l + 1 < n_levels && (long)g.offset[l + 1] <= e) l++;
+  const long hs = (long)(g.offset[l + 1] - g.offset[l]);
+  const unsigned long long* __restrict__ src = partial + plan.plane_base[l] + (e - (long)g.offset[l]);
   unsigned long long sum = 0ull;
-  for (int p = 0; p < nparts; p++) sum += partial[(long)p * stride + e];
+  for (int p = 0; p < plan.parts[l]; p++) sum += src[(long)p * hs];
   if (sum != 0ull) reinterpret_cast<unsigned long long*>(grad)[e] += sum;
 }
 
@@ -583,7 +551,7 @@ static long dense_prefix_entries(const GridLayout& g, int n_levels) {
 static size_t bin_ws_bytes(const BinPlan& b, const GridLayout& g, int n_levels) {
   const long nd = dense_prefix_entries(g, n_levels);
   return bin_ws_tot_bytes(b) + bin_ws_cnt_bytes(b) + bin_ws_queue_bytes(b) +
-         (nd > 0 ? (size_t)NS_ENC_PARTS_BINNED * (size_t)nd * 8 : 0);
+         (nd > 0 ? (size_t)NS_ENC_PARTS_COARSE * (size_t)nd * 8 : 0);   // upper bound of the per-level plane sets
 }
 
 struct BinSample {
@@ -1562,8 +1530,8 @@ extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_has
         hipLaunchKernelGGL(ngp_encode_bwd_lds_kernel<true>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
                            (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale, partial, nd);
         NS_CHECK_LAUNCH("ngp_encode_bwd_lds_kernel");
-        hipLaunchKernelGGL(ngp_enc_dense_reduce_kernel, dim3(ns_cdiv(nd, 256)), dim3(256), 0, (hipStream_t)stream, partial, nd,
-                           NS_ENC_PARTS_BINNED, nd, grad_params);
+        hipLaunchKernelGGL(ngp_enc_dense_reduce_kernel, dim3(ns_cdiv(nd, 256)), dim3(256), 0, (hipStream_t)stream, g, plan, n_levels,
+                           partial, nd, grad_params);
         NS_CHECK_LAUNCH("ngp_enc_dense_reduce_kernel");
         return NS_OK;
       }
