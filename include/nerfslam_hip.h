@@ -440,6 +440,25 @@ int ns_ngp_adam_ctl(float* master, void* half_params, float* grad, float* m1, fl
 int ns_ngp_step_advance(int* ctl, int* counter, int* last, float fill, long max_samples, int min_rays, int max_rays,
                         float beta1, float beta2, void* stream);
 
+/* `_n` forms of the per-sample NeRF kernels: N is the CAPACITY (grid size and row stride of the unit-major tensors), the
+ * number of samples actually processed is read from device memory (*n_dev, e.g. the marcher's counter; rounded up to 8 by
+ * the MLP kernels, whose tail slots must carry zero gradients).  n_dev == NULL: identical to the plain entry points.
+ * They let the graph-captured training step skip the unused tail of its fixed sample budget. */
+int ns_ngp_encode_forward_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                            const float* positions, const void* params, void* out, int unit_major, long N, const int* n_dev,
+                            void* stream);
+int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                             const float* positions, const void* dLdout, int unit_major, float* grad_params, float* workspace,
+                             float fixed_scale, long N, const int* n_dev, void* stream);
+int ns_ngp_encode_backward_input_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                                   const float* positions, const void* params, const void* dLdoutT, float* dLdpos, long N,
+                                   const int* n_dev, void* stream);
+int ns_ngp_mlp_forward_n(const void* weights, const void* featT, const float* dirs, void* out, void* h1T, void* cinT, void* h3T,
+                         void* h4T, long N, const int* n_dev, void* stream);
+int ns_ngp_mlp_backward_n(const void* weights, const void* dLdout, const void* featT, const void* h1T, const void* cinT,
+                          const void* h3T, const void* h4T, void* dLdfeatT, void* d5T, void* d4T, void* d3T, void* ddT, void* d1T,
+                          float* partial_ws, int ksplit, float* grad_weights, long N, const int* n_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

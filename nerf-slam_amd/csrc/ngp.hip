@@ -112,9 +112,10 @@ typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 // coarse (dense, small) levels stay in L1/L2 and only the hashed fine levels go to HBM.
 __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const float* __restrict__ pos,
                                                              const h2_t* __restrict__ params,
-                                                             h2_t* __restrict__ out, long N, int L, int unit_major) {
+                                                             h2_t* __restrict__ out, long N, int L, int unit_major,
+                                                             const int* __restrict__ n_dev) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
+  if (i >= N || (n_dev != nullptr && i >= (long)*n_dev)) return;   // N stays the row stride of the unit-major output
   const int l = blockIdx.y;
   const uint32_t hs = g.offset[l + 1] - g.offset[l];
   const float scale = g.scale[l];
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
                                                                   const h2_t* __restrict__ dLdout, float* __restrict__ grad,
                                                                   long N, int L, int n_levels, int unit_major,
                                                                   float fixed_scale, unsigned long long* __restrict__ partial,
-                                                                  long partial_stride) {
+                                                                  const int* __restrict__ n_dev) {
   __shared__ unsigned long long tab[NS_ENC_SLICE];  // packed fixed-point words, or float2 bit patterns
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = gridDim.x >> 3;
@@ -367,14 +368,15 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
   for (uint32_t e = tid; e < cnt; e += 1024) tab[e] = 0ull;
   __syncthreads();
   // sample range of this part, in units of 64-sample wave chunks
-  const long chunks = (N + 63) >> 6;
+  const long nvalid = n_dev ? min(N, (long)*n_dev) : N;   // N stays the row stride of a unit-major gradient
+  const long chunks = (nvalid + 63) >> 6;
   const long c_lo = chunks * part / nparts, c_hi = chunks * (part + 1) / nparts;
   const _Float16* dpu = reinterpret_cast<const _Float16*>(dLdout);
   float* tabf = reinterpret_cast<float*>(tab);
   for (long ch = c_lo + wave; ch < c_hi; ch += 16) {
     const long i = (ch << 6) + lane;
     float d0 = 0.0f, d1 = 0.0f;
-    if (i < N) {
+    if (i < nvalid) {
       if (unit_major) {
         d0 = (float)dpu[(long)(2 * l) * N + i];
         d1 = (float)dpu[(long)(2 * l + 1) * N + i];
@@ -428,9 +430,15 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
     // VALU time at four waves per SIMD than the conflicts they remove.
     if (valid) {
       const float wx[2] = {1.0f - w[0], w[0]}, wy[2] = {1.0f - w[1], w[1]}, wz[2] = {1.0f - w[2], w[2]};
+      // dense index x + y res + z res^2 of the 8 corners from one base (grid_index() re-derives it per corner and ends in
+      // an integer modulo: ~50 instructions per corner, which made THIS the cost of the dense levels).  A corner on the
+      // far border can reach res + res^2 + res^3 < 2 hs: one conditional subtraction is the modulo.
+      const uint32_t r2 = res * res;
+      const uint32_t base = c[0] + c[1] * res + c[2] * r2;
 #pragma unroll
       for (int corner = 0; corner < 8; corner++) {
-        const uint32_t idx = grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2));
+        uint32_t idx = base + (corner & 1) + ((corner >> 1) & 1) * res + (corner >> 2) * r2;
+        idx = idx >= hs ? idx - hs : idx;
         const uint32_t rel = idx - lo;
         if (rel < cnt) {
           const float wt = wx[corner & 1] * wy[(corner >> 1) & 1] * wz[corner >> 2];
@@ -561,10 +569,11 @@ struct BinSample {
 };
 
 __device__ __forceinline__ BinSample bin_sample(const GridLayout& g, int l, uint32_t hs, const float* __restrict__ pos,
-                                                const h2_t* __restrict__ dLdout, long i, long N, int L, int unit_major) {
+                                                const h2_t* __restrict__ dLdout, long i, long N, int L, int unit_major,
+                                                long cnt) {
   BinSample s;
   s.d0 = s.d1 = 0.0f;
-  if (i < N) {
+  if (i < cnt) {
     if (unit_major) {
       const _Float16* dp = reinterpret_cast<const _Float16*>(dLdout);
       s.d0 = (float)dp[(long)(2 * l) * N + i];
@@ -607,16 +616,18 @@ __global__ void ngp_zero_ints_kernel(int* __restrict__ p, int n) {
 
 __global__ __launch_bounds__(256) void ngp_enc_bin_count_kernel(GridLayout g, BinPlan bp, const float* __restrict__ pos,
                                                                 const h2_t* __restrict__ dLdout, long N, int L, int unit_major,
-                                                                int* __restrict__ tot, int2* __restrict__ cnt) {
+                                                                int* __restrict__ tot, int2* __restrict__ cnt,
+                                                                const int* __restrict__ n_dev) {
   __shared__ int hist[NS_BIN_MAX];
   const int k = blockIdx.y, l = bp.level[k], tile = blockIdx.x, tid = threadIdx.x;
+  const long nvalid = n_dev ? min(N, (long)*n_dev) : N;
   const uint32_t hs = g.offset[l + 1] - g.offset[l];
   if (tid < NS_BIN_MAX) hist[tid] = 0;
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < NS_BIN_TILE / 256; j++) {
     const long i = (long)tile * NS_BIN_TILE + j * 256 + tid;
-    const BinSample s = bin_sample(g, l, hs, pos, dLdout, i, N, L, unit_major);
+    const BinSample s = bin_sample(g, l, hs, pos, dLdout, i, N, L, unit_major, nvalid);
     if (s.valid) {
 #pragma unroll
       for (int corner = 0; corner < 8; corner++) atomicAdd(&hist[s.idx[corner] >> 14], 1);
@@ -642,11 +653,13 @@ __global__ __launch_bounds__(256) void ngp_enc_bin_scatter_kernel(GridLayout g, 
                                                                   const h2_t* __restrict__ dLdout, long N, int L, int unit_major,
                                                                   float fixed_scale, const int* __restrict__ tot,
                                                                   const int2* __restrict__ cnt,
-                                                                  unsigned long long* __restrict__ queue) {
+                                                                  unsigned long long* __restrict__ queue,
+                                                                  const int* __restrict__ n_dev) {
   __shared__ unsigned long long rec[8 * NS_BIN_TILE];   // 64 KB: the tile's records, bin-sorted
   __shared__ int lbase[NS_BIN_MAX + 1], lcnt[NS_BIN_MAX], gdst[NS_BIN_MAX];
   const int k = blockIdx.y, l = bp.level[k], tile = blockIdx.x, tid = threadIdx.x;
   const uint32_t hs = g.offset[l + 1] - g.offset[l];
+  const long nvalid = n_dev ? min(N, (long)*n_dev) : N;
   if (tid < 64) {  // one wave: prefix sums over the 32 bins (tile counts -> LDS bases, bin totals -> queue bases)
     const int b = tid & 31;
     const int2 co = cnt[((long)k * bp.ntiles + tile) * NS_BIN_MAX + b];
@@ -668,7 +681,7 @@ __global__ __launch_bounds__(256) void ngp_enc_bin_scatter_kernel(GridLayout g, 
 #pragma unroll
   for (int j = 0; j < NS_BIN_TILE / 256; j++) {
     const long i = (long)tile * NS_BIN_TILE + j * 256 + tid;
-    const BinSample s = bin_sample(g, l, hs, pos, dLdout, i, N, L, unit_major);
+    const BinSample s = bin_sample(g, l, hs, pos, dLdout, i, N, L, unit_major, nvalid);
     if (s.valid) {
       int slot[8];   // the eight returning LDS atomics and base reads are issued back to back; the records follow
 #pragma unroll
@@ -759,9 +772,10 @@ __global__ __launch_bounds__(1024) void ngp_enc_bin_accum_kernel(GridLayout g, B
 __global__ __launch_bounds__(256) void ngp_encode_bwd_input_kernel(GridLayout g, const float* __restrict__ pos,
                                                                    const h2_t* __restrict__ params,
                                                                    const _Float16* __restrict__ dLdfeatT,
-                                                                   float* __restrict__ dLdpos, long N, int L) {
+                                                                   float* __restrict__ dLdpos, long N, int L,
+                                                                   const int* __restrict__ n_dev) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
+  if (i >= N || (n_dev != nullptr && i >= (long)*n_dev)) return;
   const float px = pos[i * 3], py = pos[i * 3 + 1], pz = pos[i * 3 + 2];
   float gx = 0.0f, gy = 0.0f, gz = 0.0f;
   for (int l = 0; l < L; l++) {
@@ -1425,6 +1439,13 @@ extern "C" int ns_ngp_grid_layout(int n_levels, int n_features, int log2_hashmap
 extern "C" int ns_ngp_encode_forward(int n_levels, int n_features, int log2_hashmap, int base_res,
                                      float per_level_scale, const float* positions, const void* params, void* out,
                                      int unit_major, long N, void* stream) {
+  return ns_ngp_encode_forward_n(n_levels, n_features, log2_hashmap, base_res, per_level_scale, positions, params, out, unit_major,
+                                 N, nullptr, stream);
+}
+
+extern "C" int ns_ngp_encode_forward_n(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                     float per_level_scale, const float* positions, const void* params, void* out,
+                                     int unit_major, long N, const int* n_dev, void* stream) {
   NS_REQUIRE(positions && params && out, "ns_ngp_encode_forward: null pointer");
   GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
   GridLayout g;
@@ -1434,7 +1455,7 @@ extern "C" int ns_ngp_encode_forward(int n_levels, int n_features, int log2_hash
   }
   if (N <= 0) return NS_OK;
   hipLaunchKernelGGL(ngp_encode_fwd_kernel, dim3(ns_cdiv(N, 256), n_levels), dim3(256), 0, (hipStream_t)stream, g,
-                     positions, (const h2_t*)params, (h2_t*)out, N, n_levels, unit_major);
+                     positions, (const h2_t*)params, (h2_t*)out, N, n_levels, unit_major, n_dev);
   NS_CHECK_LAUNCH("ngp_encode_fwd_kernel");
   return NS_OK;
 }
@@ -1488,6 +1509,14 @@ extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_has
                                       float per_level_scale, const float* positions, const void* dLdout,
                                       int unit_major, float* grad_params, float* workspace, float fixed_scale, long N,
                                       void* stream) {
+  return ns_ngp_encode_backward_n(n_levels, n_features, log2_hashmap, base_res, per_level_scale, positions, dLdout, unit_major,
+                                  grad_params, workspace, fixed_scale, N, nullptr, stream);
+}
+
+extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                      float per_level_scale, const float* positions, const void* dLdout,
+                                      int unit_major, float* grad_params, float* workspace, float fixed_scale, long N,
+                                      const int* n_dev, void* stream) {
   NS_REQUIRE(positions && dLdout && grad_params, "ns_ngp_encode_backward: null pointer");
   GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
   GridLayout g;
@@ -1515,10 +1544,10 @@ extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_has
                          bp.nh * NS_BIN_MAX);
       NS_CHECK_LAUNCH("ngp_zero_ints_kernel");
       hipLaunchKernelGGL(ngp_enc_bin_count_kernel, dim3(bp.ntiles, bp.nh), dim3(256), 0, (hipStream_t)stream, g, bp, positions,
-                         (const h2_t*)dLdout, N, n_levels, unit_major, tot, cnt);
+                         (const h2_t*)dLdout, N, n_levels, unit_major, tot, cnt, n_dev);
       NS_CHECK_LAUNCH("ngp_enc_bin_count_kernel");
       hipLaunchKernelGGL(ngp_enc_bin_scatter_kernel, dim3(bp.ntiles, bp.nh), dim3(256), 0, (hipStream_t)stream, g, bp, positions,
-                         (const h2_t*)dLdout, N, n_levels, unit_major, fixed_scale, tot, cnt, queue);
+                         (const h2_t*)dLdout, N, n_levels, unit_major, fixed_scale, tot, cnt, queue, n_dev);
       NS_CHECK_LAUNCH("ngp_enc_bin_scatter_kernel");
       hipLaunchKernelGGL(ngp_enc_bin_accum_kernel, dim3(NS_BIN_MAX, bp.nh), dim3(1024), 0, (hipStream_t)stream, g, bp, tot, queue,
                          grad_params);
@@ -1528,7 +1557,7 @@ extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_has
       if (nd > 0) {
         unsigned long long* partial = queue + bin_ws_queue_bytes(bp) / 8;
         hipLaunchKernelGGL(ngp_encode_bwd_lds_kernel<true>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
-                           (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale, partial, nd);
+                           (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale, partial, n_dev);
         NS_CHECK_LAUNCH("ngp_encode_bwd_lds_kernel");
         hipLaunchKernelGGL(ngp_enc_dense_reduce_kernel, dim3(ns_cdiv(nd, 256)), dim3(256), 0, (hipStream_t)stream, g, plan, n_levels,
                            partial, nd, grad_params);
@@ -1539,11 +1568,11 @@ extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_has
     if (fixed_scale > 0.0f)
       hipLaunchKernelGGL(ngp_encode_bwd_lds_kernel<true>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
                          (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale,
-                         (unsigned long long*)nullptr, 0L);
+                         (unsigned long long*)nullptr, n_dev);
     else
       hipLaunchKernelGGL(ngp_encode_bwd_lds_kernel<false>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
                          (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale,
-                         (unsigned long long*)nullptr, 0L);
+                         (unsigned long long*)nullptr, n_dev);
     NS_CHECK_LAUNCH("ngp_encode_bwd_lds_kernel");
     return NS_OK;
   }
@@ -1585,6 +1614,13 @@ extern "C" int ns_ngp_adam_ctl(float* master, void* half_params, float* grad, fl
 extern "C" int ns_ngp_encode_backward_input(int n_levels, int n_features, int log2_hashmap, int base_res,
                                             float per_level_scale, const float* positions, const void* params,
                                             const void* dLdoutT, float* dLdpos, long N, void* stream) {
+  return ns_ngp_encode_backward_input_n(n_levels, n_features, log2_hashmap, base_res, per_level_scale, positions, params, dLdoutT,
+                                        dLdpos, N, nullptr, stream);
+}
+
+extern "C" int ns_ngp_encode_backward_input_n(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                            float per_level_scale, const float* positions, const void* params,
+                                            const void* dLdoutT, float* dLdpos, long N, const int* n_dev, void* stream) {
   NS_REQUIRE(positions && params && dLdoutT && dLdpos, "ns_ngp_encode_backward_input: null pointer");
   GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
   GridLayout g;
@@ -1594,7 +1630,7 @@ extern "C" int ns_ngp_encode_backward_input(int n_levels, int n_features, int lo
   }
   if (N <= 0) return NS_OK;
   hipLaunchKernelGGL(ngp_encode_bwd_input_kernel, dim3(ns_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, g, positions,
-                     (const h2_t*)params, (const _Float16*)dLdoutT, dLdpos, N, n_levels);
+                     (const h2_t*)params, (const _Float16*)dLdoutT, dLdpos, N, n_levels, n_dev);
   NS_CHECK_LAUNCH("ngp_encode_bwd_input_kernel");
   return NS_OK;
 }

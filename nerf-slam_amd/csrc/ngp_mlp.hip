@@ -141,7 +141,15 @@ struct MlpFwdArgs {
   _Float16* h3T;          // [64,N]
   _Float16* h4T;          // [64,N]
   long N;
+  const int* n_dev;       // optional: device sample count (<= N); N stays the row stride of the unit-major tensors
 };
+
+// samples to process: the by-value N, or the device count rounded up to 8 (the tail slots carry zero gradients)
+__device__ __forceinline__ long ngp_count(long N, const int* n_dev) {
+  if (n_dev == nullptr) return N;
+  const long c = ((long)*n_dev + 7) & ~7L;
+  return c < N ? c : N;
+}
 
 __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
   __shared__ f16x8 Wf[FW_NFRAG * 64];
@@ -152,12 +160,12 @@ __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
   fill_frags<false>(Wf, a.W, W5_OFF, 16, 64, FW_L5);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  const long N = a.N;
+  const long N = a.N, cnt = ngp_count(a.N, a.n_dev);
   const bool save = a.h1T != nullptr;
   for (int iter = 0; iter < MLP_ITERS; iter++) {
     const long n0 = (((long)blockIdx.x * MLP_ITERS + iter) * 4 + wave) * 64;
-    if (n0 >= N) return;  // wave-uniform
-    const bool ok = n0 + 2 * j < N;  // N is even: the pair (np, np + 1) is valid or not as a whole
+    if (n0 >= cnt) return;  // wave-uniform
+    const bool ok = n0 + 2 * j < cnt;  // cnt is even: the pair (np, np + 1) is valid or not as a whole
     const long np = ok ? n0 + 2 * j : 0;
     const long nq = np;
     // input: 2 chunks x 8 units, both tiles in one dword
@@ -243,6 +251,7 @@ struct MlpBwdArgs {
   _Float16* dLdfeatT;     // [32,N] unit-major
   _Float16 *d5T, *d4T, *d3T, *ddT, *d1T;  // [16,N] [64,N] [64,N] [16,N] [64,N] unit-major output gradients
   long N;
+  const int* n_dev;
 };
 
 // dy = relu'(h) * f16(acc) for one 32-unit tile of both sample tiles; returns the B chunks and stores unit-major
@@ -270,12 +279,12 @@ __global__ __launch_bounds__(256, 2) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
   fill_frags<true>(Wf, a.W, W1_OFF, 64, 32, BW_L1);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  const long N = a.N;
+  const long N = a.N, cnt = ngp_count(a.N, a.n_dev);
   for (int iter = 0; iter < MLP_ITERS; iter++) {
     const long n0 = (((long)blockIdx.x * MLP_ITERS + iter) * 4 + wave) * 64;
-    if (n0 >= N) return;
+    if (n0 >= cnt) return;
     // every lane runs every MFMA (lane i also supplies row i of A): out-of-range pairs read pair 0 and store nothing
-    const bool ok = n0 + 2 * j < N;
+    const bool ok = n0 + 2 * j < cnt;
     const long np = ok ? n0 + 2 * j : 0;
     const f16x8 go = *reinterpret_cast<const f16x8*>(a.dLdout + np * 4);  // (r,g,b,d) of samples np, np + 1
     // dY5: units 0..2 = colour gradients (held by h == 0, q = 0..2), rest zero
@@ -361,6 +370,7 @@ struct WgradArgs {
   float* partial;  // [ksplit][W_TOTAL]
   long N;
   int ksplit;
+  const int* n_dev;
 };
 
 #define WG_ROWB 144  // 64 samples * 2 B + 16 B pad: conflict-free 16-byte slots
@@ -376,8 +386,9 @@ __global__ __launch_bounds__(256) void ngp_mlp_wgrad_kernel(WgradArgs a) {
   const int to = wave / tiles_i, ti = wave % tiles_i;
   const bool active = wave < tiles_o * tiles_i;
   f32x16 acc = (f32x16)0.0f;
-  const long per = ((a.N + a.ksplit - 1) / a.ksplit + 63) / 64 * 64;
-  const long n0 = (long)blockIdx.x * per, n1 = min(a.N, n0 + per);
+  const long cnt = ngp_count(a.N, a.n_dev);
+  const long per = ((cnt + a.ksplit - 1) / a.ksplit + 63) / 64 * 64;
+  const long n0 = (long)blockIdx.x * per, n1 = min(cnt, n0 + per);
   for (long nb = n0; nb < n1; nb += 64) {
     __syncthreads();
     // stage: row r (0..nout-1: dYT, then XT) x 8 pieces of 16 B
@@ -385,11 +396,11 @@ __global__ __launch_bounds__(256) void ngp_mlp_wgrad_kernel(WgradArgs a) {
       const int r = piece >> 3, s = piece & 7;
       const _Float16* src = (r < L.nout ? L.dYT + (long)r * a.N : L.XT + (long)(r - L.nout) * a.N) + nb + s * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (nb + s * 8 + 8 <= a.N) {
+      if (nb + s * 8 + 8 <= cnt) {
         v = *reinterpret_cast<const uint4*>(src);
       } else {
         _Float16 t[8];
-        for (int q = 0; q < 8; q++) t[q] = (nb + s * 8 + q < a.N) ? src[q] : (_Float16)0;
+        for (int q = 0; q < 8; q++) t[q] = (nb + s * 8 + q < cnt) ? src[q] : (_Float16)0;
         v = *reinterpret_cast<const uint4*>(t);
       }
       *reinterpret_cast<uint4*>(tile + r * WG_ROWB + s * 16) = v;
@@ -439,6 +450,11 @@ __global__ __launch_bounds__(256) void ngp_mlp_wgrad_reduce_kernel(const float* 
 // ---------------------------------------------------------------------------------------------
 extern "C" int ns_ngp_mlp_forward(const void* weights, const void* featT, const float* dirs, void* out, void* h1T,
                                   void* cinT, void* h3T, void* h4T, long N, void* stream) {
+  return ns_ngp_mlp_forward_n(weights, featT, dirs, out, h1T, cinT, h3T, h4T, N, nullptr, stream);
+}
+
+extern "C" int ns_ngp_mlp_forward_n(const void* weights, const void* featT, const float* dirs, void* out, void* h1T,
+                                    void* cinT, void* h3T, void* h4T, long N, const int* n_dev, void* stream) {
   NS_REQUIRE(weights && featT && dirs && out, "ns_ngp_mlp_forward: null pointer");
   NS_REQUIRE((h1T == nullptr) == (cinT == nullptr) && (h1T == nullptr) == (h3T == nullptr) &&
                  (h1T == nullptr) == (h4T == nullptr),
@@ -446,7 +462,7 @@ extern "C" int ns_ngp_mlp_forward(const void* weights, const void* featT, const 
   NS_REQUIRE(N % 2 == 0, "ns_ngp_mlp_forward: N must be even (a lane owns two adjacent samples)");
   if (N <= 0) return NS_OK;
   MlpFwdArgs a{(const _Float16*)weights, (const _Float16*)featT, dirs, (_Float16*)out, (_Float16*)h1T,
-               (_Float16*)cinT, (_Float16*)h3T, (_Float16*)h4T, N};
+               (_Float16*)cinT, (_Float16*)h3T, (_Float16*)h4T, N, n_dev};
   hipLaunchKernelGGL(ngp_mlp_fwd_kernel, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, (hipStream_t)stream, a);
   NS_CHECK_LAUNCH("ngp_mlp_fwd_kernel");
   return NS_OK;
@@ -456,6 +472,14 @@ extern "C" int ns_ngp_mlp_backward(const void* weights, const void* dLdout, cons
                                    const void* cinT, const void* h3T, const void* h4T, void* dLdfeatT, void* d5T,
                                    void* d4T, void* d3T, void* ddT, void* d1T, float* partial_ws, int ksplit,
                                    float* grad_weights, long N, void* stream) {
+  return ns_ngp_mlp_backward_n(weights, dLdout, featT, h1T, cinT, h3T, h4T, dLdfeatT, d5T, d4T, d3T, ddT, d1T, partial_ws, ksplit,
+                               grad_weights, N, nullptr, stream);
+}
+
+extern "C" int ns_ngp_mlp_backward_n(const void* weights, const void* dLdout, const void* featT, const void* h1T,
+                                     const void* cinT, const void* h3T, const void* h4T, void* dLdfeatT, void* d5T,
+                                     void* d4T, void* d3T, void* ddT, void* d1T, float* partial_ws, int ksplit,
+                                     float* grad_weights, long N, const int* n_dev, void* stream) {
   NS_REQUIRE(weights && dLdout && featT && h1T && cinT && h3T && h4T && dLdfeatT && d5T && d4T && d3T && ddT && d1T &&
                  partial_ws && grad_weights,
              "ns_ngp_mlp_backward: null pointer");
@@ -464,7 +488,8 @@ extern "C" int ns_ngp_mlp_backward(const void* weights, const void* dLdout, cons
   hipStream_t st = (hipStream_t)stream;
   MlpBwdArgs b{(const _Float16*)weights, (const _Float16*)dLdout, (const _Float16*)h1T, (const _Float16*)h3T,
                (const _Float16*)h4T,     (_Float16*)dLdfeatT,     (_Float16*)d5T,       (_Float16*)d4T,
-               (_Float16*)d3T,           (_Float16*)ddT,          (_Float16*)d1T,       N};
+               (_Float16*)d3T,           (_Float16*)ddT,          (_Float16*)d1T,       N,
+               n_dev};
   hipLaunchKernelGGL(ngp_mlp_bwd_kernel, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, st, b);
   NS_CHECK_LAUNCH("ngp_mlp_bwd_kernel");
   WgradArgs w;
@@ -476,6 +501,7 @@ extern "C" int ns_ngp_mlp_backward(const void* weights, const void* dLdout, cons
   w.partial = partial_ws;
   w.N = N;
   w.ksplit = ksplit;
+  w.n_dev = n_dev;
   hipLaunchKernelGGL(ngp_mlp_wgrad_kernel, dim3(ksplit, 5), dim3(256), 0, st, w);
   NS_CHECK_LAUNCH("ngp_mlp_wgrad_kernel");
   hipLaunchKernelGGL(ngp_mlp_wgrad_reduce_kernel, dim3(W_TOTAL / 64), dim3(256), 0, st, partial_ws, ksplit,

@@ -279,22 +279,28 @@ class NgpNerf:
                                  C.c_float(0.5 - 0.5 * s), C.c_float(1.0 / s), c.max_steps_per_ray, C.c_long(S), ptr(self.counter),
                                  ptr(self.ray_start), ptr(self.ray_n), ptr(self.s_pos), ptr(self.s_dir), ptr(self.s_dt),
                                  ptr(self.s_t), ctl, st), "ngp_march")
-        featT = self.encode(self.s_pos, self.s_feat)
+        # sample count of THIS step = end of the marcher's reserved ranges (device memory): the per-sample kernels are launched
+        # over the whole budget S (fixed grids, fixed row strides) and skip the tail the marcher did not fill
+        n_dev = C.c_void_p(self.counter.data_ptr() + 8)
+        featT = self.s_feat.view(-1)[:32 * S].view(32, S)
+        check(L.ns_ngp_encode_forward_n(*self._grid_args(), ptr(self.s_pos), ptr(self.grid_half), ptr(featT), 1, C.c_long(S), n_dev,
+                                        st), "ngp_encode_forward")
         acts, dacts = self.act, self.dact
-        check(L.ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(featT), ptr(self.s_dir), ptr(self.s_out),
-                                   *[ptr(a) for a in acts], C.c_long(S), st), "ngp_mlp_forward")
+        check(L.ns_ngp_mlp_forward_n(ptr(self.mlp_half), ptr(featT), ptr(self.s_dir), ptr(self.s_out),
+                                     *[ptr(a) for a in acts], C.c_long(S), n_dev, st), "ngp_mlp_forward")
         check(L.ns_ngp_composite_ctl(ptr(self.s_out), ptr(self.s_dt), ptr(self.s_t), ptr(self.ray_start), ptr(self.ray_n), Rc,
                                      ptr(self.r_rgb), ptr(self.r_depth), ptr(self.r_cov), C.c_float(c.depth_lambda),
                                      C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), ptr(self.loss_acc),
                                      ptr(self.s_dout), ctl, st), "ngp_composite")
-        check(L.ns_ngp_mlp_backward(ptr(self.mlp_half), ptr(self.s_dout), ptr(featT), *[ptr(a) for a in acts],
-                                    ptr(self.s_dfeat), *[ptr(a) for a in dacts], ptr(self.partial), c.wgrad_ksplit,
-                                    ptr(self.mlp_grad), C.c_long(S), st), "ngp_mlp_backward")
-        check(L.ns_ngp_encode_backward(*self._grid_args(), ptr(self.s_pos), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
-                                       ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(S), st), "ngp_encode_backward")
+        check(L.ns_ngp_mlp_backward_n(ptr(self.mlp_half), ptr(self.s_dout), ptr(featT), *[ptr(a) for a in acts],
+                                      ptr(self.s_dfeat), *[ptr(a) for a in dacts], ptr(self.partial), c.wgrad_ksplit,
+                                      ptr(self.mlp_grad), C.c_long(S), n_dev, st), "ngp_mlp_backward")
+        check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(self.s_pos), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
+                                         ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev, st),
+              "ngp_encode_backward")
         if c.optimize_extrinsics:
-            check(L.ns_ngp_encode_backward_input(*self._grid_args(), ptr(self.s_pos), ptr(self.grid_half), ptr(self.s_dfeat),
-                                                 ptr(self.dpos), C.c_long(S), st), "ngp_encode_backward_input")
+            check(L.ns_ngp_encode_backward_input_n(*self._grid_args(), ptr(self.s_pos), ptr(self.grid_half), ptr(self.s_dfeat),
+                                                   ptr(self.dpos), C.c_long(S), n_dev, st), "ngp_encode_backward_input")
             n_cam = self.cam_grad.shape[0]
             check(L.ns_ngp_camera_gradient_2stage(ptr(self.dpos), ptr(self.s_t), ptr(self.r_d), ptr(self.ray_start), ptr(self.ray_n),
                                                   ptr(self.r_img), C.c_float(1.0 / s), ptr(self.cam_grad), Rc, ctl,
