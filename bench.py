@@ -247,6 +247,22 @@ def kernel_rooflines(dev, hp, ngp_net):
                   "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": per * N / us / 1e3 / HBM_PEAK_GBS,
                   "note": "uniform random positions (worst case for locality)"}
     net.grid_grad.zero_()
+    # Adam over the hash grid: 18 B read (master, gradient word, two moments, ...) + 14 B written per parameter
+    c = net.cfg
+    n_par = net.grid_master.numel()
+    tmp = [torch.zeros_like(net.grid_master) for _ in range(3)]
+    hp16 = torch.zeros(n_par, dtype=torch.float16, device=dev)
+    gq = torch.ones(n_par, dtype=torch.float32, device=dev)
+
+    def adam():
+        check(lib().ns_ngp_adam(ptr(tmp[0]), ptr(hp16), ptr(gq), ptr(tmp[1]), ptr(tmp[2]), C.c_long(n_par), 7, C.c_float(c.lr),
+                                C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps), C.c_float(0.0), C.c_float(c.loss_scale),
+                                C.c_float(0.0), stream_ptr()), "ngp_adam")
+    us = _train_us(adam)
+    out["ngp_adam_kernel[hash grid]"] = {"bound": "hbm", "avg_launch_us": us, "algorithmic_bytes_per_launch": 32 * n_par,
+                                         "achieved": 32 * n_par / us / 1e3, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                         "frac": 32 * n_par / us / 1e3 / HBM_PEAK_GBS}
+    del tmp, hp16, gq
     # the update operator's gate convolution (the largest MFMA launch of an update)
     from nerfslam.conv import PackedConv, conv_nhwc
     w = (torch.randn((256, 448, 3, 3), device=dev) / 60).half().float()
@@ -416,6 +432,7 @@ def main():
         # share of the timed region per candidate kernel (launch time x launches per timed frame)
         per_frame = {"corr_lookup_coop_kernel[E=48]": counts["updates"] / K, "corr_volume_tiled_kernel[E=10]": counts["keyframe_candidates"] / K,
                      "ngp_encode_fwd_kernel[2^18]": counts["nerf_train_steps"] / K, "ngp_encode_bwd[2^18]": counts["nerf_train_steps"] / K,
+                     "ngp_adam_kernel[hash grid]": counts["nerf_train_steps"] / K,
                      "conv_nhwc_kernel<3x3,448->256>[E=48]": counts["updates"] / K}
         for k, r in roofs.items():
             r["launches_per_frame"] = per_frame.get(k, 0.0)

@@ -106,6 +106,20 @@ __device__ __forceinline__ uint32_t grid_index(uint32_t hashmap_size, uint32_t r
   return index % hashmap_size;
 }
 
+// Same index as grid_index() at a fraction of its cost (the generic form ends in an integer modulo by a run-time value:
+// ~40 VALU instructions per corner, 8 corners x 16 levels per sample -- it, not the gathers, was most of the encode
+// kernels' time).  A level is either hashed -- its table size is then 2^log2_hashmap, the modulo is a mask -- or dense,
+// where x + y res + z res^2 < 2 * table size (a far-border corner can reach res + res^2 + res^3), so one conditional
+// subtraction is the modulo.  `hashed` is uniform per level.
+__device__ __forceinline__ uint32_t grid_index_lvl(bool hashed, uint32_t hs, uint32_t res, uint32_t x, uint32_t y, uint32_t z) {
+  if (hashed) return (x ^ (y * 2654435761u) ^ (z * 805459861u)) & (hs - 1u);
+  const uint32_t idx = x + (y + z * res) * res;
+  return idx >= hs ? idx - hs : idx;
+}
+__device__ __forceinline__ bool grid_level_hashed(uint32_t hs, uint32_t res) {
+  return (uint64_t)res * res * res > (uint64_t)hs;
+}
+
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 
 // grid (ceil(N/256), n_levels): all lanes of a workgroup gather from the same level's table, so the
@@ -115,11 +129,15 @@ __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const
                                                              h2_t* __restrict__ out, long N, int L, int unit_major,
                                                              const int* __restrict__ n_dev) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= N || (n_dev != nullptr && i >= (long)*n_dev)) return;   // N stays the row stride of the unit-major output
+  // N stays the row stride of the unit-major output.  The device count is rounded up to 8 like in the MLP kernels, which
+  // read the features of the (up to 7) tail slots: left unwritten they are whatever the allocation held -- NaN bits there
+  // turn the weight gradient into NaN even though the tail's upstream gradient is zero (0 x NaN).
+  if (i >= N || (n_dev != nullptr && i >= (((long)*n_dev + 7) & ~7L))) return;
   const int l = blockIdx.y;
   const uint32_t hs = g.offset[l + 1] - g.offset[l];
   const float scale = g.scale[l];
   const uint32_t res = (uint32_t)g.res[l];
+  const bool hashed = grid_level_hashed(hs, res);
   float w[3];
   uint32_t c[3];
 #pragma unroll
@@ -136,8 +154,8 @@ __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const
   // in bit 0 only, and x enters the hash with multiplier 1): one 8-byte load then serves both corners.
 #pragma unroll
   for (int yz = 0; yz < 4; yz++) {
-    const uint32_t i0 = grid_index(hs, res, c[0], c[1] + (yz & 1), c[2] + (yz >> 1));
-    const uint32_t i1 = grid_index(hs, res, c[0] + 1, c[1] + (yz & 1), c[2] + (yz >> 1));
+    const uint32_t i0 = grid_index_lvl(hashed, hs, res, c[0], c[1] + (yz & 1), c[2] + (yz >> 1));
+    const uint32_t i1 = grid_index_lvl(hashed, hs, res, c[0] + 1, c[1] + (yz & 1), c[2] + (yz >> 1));
     const uint32_t lo = min(i0, i1);
     if (max(i0, i1) - lo == 1u) {
       struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
@@ -605,7 +623,7 @@ __device__ __forceinline__ BinSample bin_sample(const GridLayout& g, int l, uint
   const uint32_t hz[2] = {hz0, hz0 + 805459861u};
 #pragma unroll
   for (int corner = 0; corner < 8; corner++)
-    s.idx[corner] = (hx[corner & 1] ^ hy[(corner >> 1) & 1] ^ hz[corner >> 2]) % hs;
+    s.idx[corner] = (hx[corner & 1] ^ hy[(corner >> 1) & 1] ^ hz[corner >> 2]) & (hs - 1u);   // hashed: hs = 2^log2_hashmap
   return s;
 }
 
@@ -784,6 +802,7 @@ __global__ __launch_bounds__(256) void ngp_encode_bwd_input_kernel(GridLayout g,
     const uint32_t hs = g.offset[l + 1] - g.offset[l];
     const float scale = g.scale[l];
     const uint32_t res = (uint32_t)g.res[l];
+    const bool hashed = grid_level_hashed(hs, res);
     float w[3];
     uint32_t c[3];
     const float pp[3] = {px, py, pz};
@@ -798,7 +817,7 @@ __global__ __launch_bounds__(256) void ngp_encode_bwd_input_kernel(GridLayout g,
     float s[8];  // dL/dfeat . value of corner
 #pragma unroll
     for (int corner = 0; corner < 8; corner++) {
-      const h2_t v = tab[grid_index(hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2))];
+      const h2_t v = tab[grid_index_lvl(hashed, hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2))];
       s[corner] = d0 * (float)v[0] + d1 * (float)v[1];
     }
     // d/dx of sum_c wx(c) wy(c) wz(c) s_c = sum over the 4 (y,z) edges of wy wz (s_{x=1} - s_{x=0}), times scale

@@ -140,10 +140,12 @@ class NgpNerf:
         h = dict(dtype=torch.float16, device=dev)
         self.s_pos, self.s_dir = torch.empty((S, 3), **f), torch.empty((S, 3), **f)
         self.s_dt, self.s_t = torch.empty(S, **f), torch.empty(S, **f)
-        self.s_feat, self.s_out, self.s_dout = torch.empty((S, 32), **h), torch.empty((S, 4), **h), torch.empty((S, 4), **h)
-        self.s_dfeat = torch.empty((S, 32), **h)
-        self.act = [torch.empty((u, S), **h) for u in (64, 32, 64, 64)]         # h1T cinT h3T h4T
-        self.dact = [torch.empty((u, S), **h) for u in (16, 64, 64, 16, 64)]    # d5T d4T d3T ddT d1T
+        # (zero-initialised, not torch.empty: the training step skips the unused tail of the budget, and what it skips must
+        # never hold NaN bits -- see csrc/ngp.hip:ngp_encode_fwd_kernel)
+        self.s_feat, self.s_out, self.s_dout = torch.zeros((S, 32), **h), torch.zeros((S, 4), **h), torch.zeros((S, 4), **h)
+        self.s_dfeat = torch.zeros((S, 32), **h)
+        self.act = [torch.zeros((u, S), **h) for u in (64, 32, 64, 64)]         # h1T cinT h3T h4T
+        self.dact = [torch.zeros((u, S), **h) for u in (16, 64, 64, 16, 64)]    # d5T d4T d3T ddT d1T
         self.partial = torch.zeros((c.wgrad_ksplit, MLP_TOTAL), **f)
         self.counter = torch.zeros(3, dtype=torch.int32, device=dev)
         ws_bytes = lib().ns_ngp_encode_backward_workspace_bytes(*self._grid_args(), C.c_long(c.max_samples))
