@@ -246,6 +246,8 @@ def kernel_rooflines(dev, hp, ngp_net):
         out[k] = {"bound": "hbm", "avg_launch_us": us, "algorithmic_bytes_per_launch": per * N, "achieved": per * N / us / 1e3,
                   "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": per * N / us / 1e3 / HBM_PEAK_GBS,
                   "note": "uniform random positions (worst case for locality)"}
+    out["ngp_encode_bwd[2^18]"]["note"] += ("; one call = 7 launches: ngp_zero_ints, ngp_enc_bin_count, ngp_enc_bin_scatter, "
+                                            "ngp_enc_bin_accum (hashed levels), ngp_encode_bwd_lds, ngp_enc_dense_reduce (dense levels)")
     net.grid_grad.zero_()
     # Adam over the hash grid: 18 B read (master, gradient word, two moments, ...) + 14 B written per parameter
     c = net.cfg
@@ -254,9 +256,9 @@ def kernel_rooflines(dev, hp, ngp_net):
     hp16 = torch.zeros(n_par, dtype=torch.float16, device=dev)
     gq = torch.ones(n_par, dtype=torch.float32, device=dev)
 
-    def adam():
+    def adam():   # (weight decay > 0: every entry takes the full update path although the kernel zeroes the gradient behind it)
         check(lib().ns_ngp_adam(ptr(tmp[0]), ptr(hp16), ptr(gq), ptr(tmp[1]), ptr(tmp[2]), C.c_long(n_par), 7, C.c_float(c.lr),
-                                C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps), C.c_float(0.0), C.c_float(c.loss_scale),
+                                C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps), C.c_float(1e-6), C.c_float(c.loss_scale),
                                 C.c_float(0.0), stream_ptr()), "ngp_adam")
     us = _train_us(adam)
     out["ngp_adam_kernel[hash grid]"] = {"bound": "hbm", "avg_launch_us": us, "algorithmic_bytes_per_launch": 32 * n_par,
