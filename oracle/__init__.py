@@ -552,3 +552,47 @@ def ba_covariances(Hfull, E, Q, ii, jj, kf0, kf1, HW, marginal_form=False):
     F = (Q_ * Es.T) @ (Linv.T if marginal_form else Linv)
     z = Q_[:, 0] + (F ** 2).sum(-1)
     return sigma_g, z.reshape(K, HW), kx
+
+
+# --------------------------------------------------------------------------- SLAM packet -> NeRF training images
+def srgb_to_linear(img):
+    """utils/utils.py:136-139 (float64 numpy)"""
+    img = np.asarray(img, np.float64)
+    return np.where(img > 0.04045, np.power((img + 0.055) / 1.055, 2.4), img / 12.92)
+
+
+def nerf_ingest(packet, mask_type="ours", scale=1.0, offset=(0.0, 0.0, 0.0)):
+    """fusion/nerf_fusion.py:158-226 restated in float64 numpy: what `process_slam` hands to
+    `update_training_images` for a SLAM packet (visual_frontend.py:1364-1382).
+    packet: cam0_poses [n,7] (cam_T_world, [t, q xyzw]), cam0_images [n,3,H,W] uint8, cam0_idepths_up / cam0_depths_cov_up [n,H,W].
+    -> dict(poses [n,3,4] camera-to-world with t * scale + offset (:198-203, utils.py:163-165), images [n,H,W,4] linear
+    premultiplied RGBA with alpha 1 (:194-196,204,209-213), depths [n,H,W,1] = 1 / idepth (:205), depths_cov [n,H,W,1] (:206)).
+    Mask policies (:173-183).  [The reference passes scale = 1, offset = 0 (:168-169); what the un-vendored fork then does
+    with the dataset's own offset inside update_training_images is not in the tree.]"""
+    poses = np.asarray(packet["cam0_poses"], np.float64)
+    images = np.asarray(packet["cam0_images"])
+    idepth = np.asarray(packet["cam0_idepths_up"], np.float64).copy()
+    cov = np.asarray(packet["cam0_depths_cov_up"], np.float64).copy()
+    if mask_type == "raw":
+        cov[...] = 1.0
+    elif mask_type == "ours_w_thresh":
+        idepth[np.sqrt(cov) > np.quantile(cov, 0.5)] = -1.0
+    elif mask_type == "no_depth":
+        idepth[...] = -1.0
+    elif mask_type != "ours":
+        raise NotImplementedError(mask_type)
+    n = poses.shape[0]
+    c2w = np.zeros((n, 3, 4))
+    for k in range(n):
+        inv = se3_inv64(poses[k])                                   # world_T_cam = cam_T_world^-1
+        x, y, z, w = inv[3:]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        c2w[k, :, :3] = R
+        c2w[k, :, 3] = inv[:3] * scale + np.asarray(offset, np.float64)
+    rgb = srgb_to_linear(images.transpose(0, 2, 3, 1).astype(np.float64) / 255.0)
+    rgba = np.concatenate([rgb, np.ones(rgb.shape[:3] + (1,))], -1)          # alpha 255 / 255; premultiplied == rgb
+    with np.errstate(divide="ignore"):
+        depths = 1.0 / idepth[..., None]
+    return dict(poses=c2w, images=rgba, depths=depths, depths_cov=cov[..., None])

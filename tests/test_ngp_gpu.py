@@ -390,6 +390,46 @@ def test_nerf_fusion_consumes_slam_packet(dev):
     assert m["views"] == 2 and np.isfinite(m["psnr"]) and m["psnr"] > 5.0 and np.isfinite(m["depth_l1_cm"])
 
 
+@pytest.mark.parametrize("mask_type", ["ours", "raw", "ours_w_thresh", "no_depth"])
+def test_ingest_arithmetic_matches_the_reference_restatement(oracle_mod, dev, mask_type):
+    """SLAM packet -> training images (fusion/nerf_fusion.py:158-226): what the device-side
+    `NerfFusion.process_slam` leaves in the trainer's slot arrays vs `oracle.nerf_ingest` -- camera-to-world from cam_T_world
+    (random rotations), sRGB -> linear, alpha, depth = 1 / idepth, covariance pass-through, the four mask policies, slots
+    selected by viz_idx.  The dataset offset 0.5 is this project's pyngp convention (the fork's is not in the tree)."""
+    import argparse
+    from nerfslam.nerf_fusion import NerfFusion
+    rng = np.random.default_rng(3)
+    n, H, W = 3, 24, 40
+    q = rng.standard_normal((n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    poses = np.concatenate([rng.normal(0, 0.3, (n, 3)), q], 1).astype(np.float32)
+    images = rng.integers(0, 256, (n, 3, H, W), dtype=np.uint8)
+    idepth = rng.uniform(0.2, 2.0, (n, H, W)).astype(np.float32)
+    cov = rng.uniform(0.001, 0.5, (n, H, W)).astype(np.float32)
+    viz = np.array([4, 1, 6])
+    pkt = {"cam0_poses": torch.from_numpy(poses), "cam0_images": torch.from_numpy(images), "cam0_idepths_up": torch.from_numpy(idepth),
+           "cam0_depths_cov_up": torch.from_numpy(cov), "cam0_intrinsics": torch.tensor([[30.0, 31.0, 20.0, 12.0]] * n),
+           "viz_idx": torch.from_numpy(viz), "kf_idx": 6, "is_last_frame": False}
+    fusion = NerfFusion("nerf", argparse.Namespace(buffer=8, mask_type=mask_type), dev)
+    assert fusion.process_slam(pkt) is False
+    tb = fusion.ngp
+    ref = oracle_mod.nerf_ingest({k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in pkt.items()}, mask_type=mask_type,
+                                 scale=1.0, offset=(0.5, 0.5, 0.5))
+    assert tb.nerf.training.n_images_for_training == 7 and tb._intr == (30.0, 31.0, 20.0, 12.0)
+    got_c2w = tb._c2w[torch.from_numpy(viz).to(dev)].cpu().numpy()
+    assert np.abs(got_c2w - ref["poses"]).max() <= 2e-6
+    got_img = tb._imgs[torch.from_numpy(viz).to(dev)].cpu().numpy()
+    assert np.abs(got_img - ref["images"]).max() <= 2e-6          # pow(x, 2.4) in f32 vs f64
+    got_dep = tb._deps[torch.from_numpy(viz).to(dev)].cpu().numpy()
+    assert np.array_equal(got_dep < 0, ref["depths"][..., 0] < 0)                      # masked pixels
+    assert np.abs(got_dep - ref["depths"][..., 0]).max() <= 1e-6 * np.abs(ref["depths"]).max()
+    got_cov = tb._covs[torch.from_numpy(viz).to(dev)].cpu().numpy()
+    assert np.abs(got_cov - ref["depths_cov"][..., 0]).max() <= 1e-7 * np.abs(ref["depths_cov"]).max()
+    if mask_type == "ours_w_thresh":   # the reference compares sqrt(cov) with the median of cov (:177-179): for cov < 1 most pixels go
+        assert 0.7 < (got_dep < 0).mean() < 0.95
+    untouched = [i for i in range(8) if i not in viz.tolist()]
+    assert not tb._imgs[torch.tensor(untouched, device=dev)].any()
+
+
 def test_camera_refinement_kernels(oracle_mod, dev):
     """optimize_extrinsics path: encoding input gradient, per-image 6-dof gradient, Adam + retraction -- each against the C
     restatement, and the input gradient against central differences of a float64 trilinear interpolation"""

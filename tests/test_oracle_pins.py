@@ -275,3 +275,18 @@ def test_covariance_block_equals_full_inverse(oracle_mod, cfg):
     assert np.abs(Es - X).max() <= 1e-5 * np.abs(X).max()
     Fr = (Es.T * Q.reshape(-1, 1).astype(np.float64)) @ np.linalg.inv(L)
     assert np.abs(z_r.reshape(-1) - (Q.reshape(-1) + (Fr ** 2).sum(-1))).max() <= 1e-9 * np.abs(z_r).max()
+
+
+def test_srgb_and_ingest_restatement_known_values(oracle_mod):
+    """utils/utils.py:136-139 is the standard sRGB decoding: known values (IEC 61966-2-1), continuity at the knee, and the
+    pose part of the ingest restatement: camera-to-world of the identity / of a pure translation"""
+    v = oracle_mod.srgb_to_linear([0.0, 0.04045, 0.5, 1.0])
+    assert abs(v[0]) == 0 and abs(v[1] - 0.04045 / 12.92) < 1e-15 and abs(v[2] - 0.21404114048223255) < 1e-12 and abs(v[3] - 1) < 1e-15
+    assert abs(oracle_mod.srgb_to_linear(0.04045 + 1e-9) - oracle_mod.srgb_to_linear(0.04045)) < 1e-7
+    pk = {"cam0_poses": np.array([[0, 0, 0, 0, 0, 0, 1.0], [0.3, -0.2, 0.1, 0, 0, 0, 1.0]]),
+          "cam0_images": np.full((2, 3, 2, 2), 128, np.uint8), "cam0_idepths_up": np.full((2, 2, 2), 0.5),
+          "cam0_depths_cov_up": np.full((2, 2, 2), 0.1)}
+    out = oracle_mod.nerf_ingest(pk)
+    assert np.allclose(out["poses"][0], np.eye(4)[:3]) and np.allclose(out["poses"][1, :, 3], [-0.3, 0.2, -0.1])
+    assert np.allclose(out["depths"], 2.0) and np.allclose(out["images"][..., 3], 1.0)
+    assert np.allclose(out["images"][..., :3], oracle_mod.srgb_to_linear(128 / 255.0))
