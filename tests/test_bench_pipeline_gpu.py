@@ -52,22 +52,25 @@ def test_product_pipeline_tracks_and_maps(dev):
     assert k_init < 60
 
 
-def test_bench_multi_gpu_topology_on_one_device():
-    """python -m torch.distributed.run --nproc-per-node 3 bench.py --gpus 3: rank 0 tracks, ranks 1-2 are replicated trainers.
+@pytest.mark.parametrize("nproc", [3, 2])
+def test_bench_multi_gpu_topology_on_one_device(nproc):
+    """python -m torch.distributed.run --nproc-per-node N bench.py --gpus N: rank 0 tracks, ranks 1.. are replicated trainers
+    (N = 2: the reference's own tracker | mapper split, one trainer, graph-replayed steps).
     Same code path as the driver's RCCL run except the backend name (gloo, all ranks on device 0)."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, NS_BENCH_DIST_BACKEND="gloo", NS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "12", "--warmup", "2"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "12", "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 3 and out["value"] > 0
+    assert out["n_gpus"] == nproc and out["value"] > 0
     tr = out["trainers"]
-    assert len(tr) == 2 and all(t["steps_total"] > 0 and t["training_views"] >= 8 for t in tr)
-    # replicated trainers: identical parameters and identical refined camera poses after the run
-    assert tr[0]["param_checksum"] == tr[1]["param_checksum"], tr
-    assert tr[0]["c2w_checksum"] == tr[1]["c2w_checksum"], tr
-    assert tr[0]["steps_total"] == tr[1]["steps_total"]
-    assert out["rccl_bytes_per_frame"]["packet_broadcast"] > 0 and out["rccl_bytes_per_frame"]["gradient_allreduce_per_trainer"] > 0
+    assert len(tr) == nproc - 1 and all(t["steps_total"] > 0 and t["training_views"] >= 8 for t in tr)
+    assert out["rccl_bytes_per_frame"]["packet_broadcast"] > 0 and out["nerf_optimizer_steps_per_s"] > 0
+    if nproc > 2:   # replicated trainers: identical parameters and identical refined camera poses after the run
+        assert tr[0]["param_checksum"] == tr[1]["param_checksum"], tr
+        assert tr[0]["c2w_checksum"] == tr[1]["c2w_checksum"], tr
+        assert tr[0]["steps_total"] == tr[1]["steps_total"]
+        assert out["rccl_bytes_per_frame"]["gradient_allreduce_per_trainer"] > 0
