@@ -391,19 +391,32 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
   const long c_lo = chunks * part / nparts, c_hi = chunks * (part + 1) / nparts;
   const _Float16* dpu = reinterpret_cast<const _Float16*>(dLdout);
   float* tabf = reinterpret_cast<float*>(tab);
-  for (long ch = c_lo + wave; ch < c_hi; ch += 16) {
-    const long i = (ch << 6) + lane;
-    float d0 = 0.0f, d1 = 0.0f;
-    if (i < nvalid) {
+  // software prefetch: the loads of the NEXT chunk are in flight while this one is accumulated (a wave otherwise waits a
+  // full L2 round trip per 64 samples: four waves per SIMD do not hide it)
+  _Float16 nd0 = (_Float16)0, nd1 = (_Float16)0;
+  float npos[3] = {0.0f, 0.0f, 0.0f};
+  auto fetch = [&](long chn) {
+    const long in = (chn << 6) + lane;
+    nd0 = nd1 = (_Float16)0;
+    if (chn < c_hi && in < nvalid) {
       if (unit_major) {
-        d0 = (float)dpu[(long)(2 * l) * N + i];
-        d1 = (float)dpu[(long)(2 * l + 1) * N + i];
+        nd0 = dpu[(long)(2 * l) * N + in];
+        nd1 = dpu[(long)(2 * l + 1) * N + in];
       } else {
-        const h2_t d = dLdout[i * L + l];
-        d0 = (float)d[0];
-        d1 = (float)d[1];
+        const h2_t d = dLdout[in * L + l];
+        nd0 = d[0];
+        nd1 = d[1];
       }
+      npos[0] = pos[in * 3];
+      npos[1] = pos[in * 3 + 1];
+      npos[2] = pos[in * 3 + 2];
     }
+  };
+  fetch(c_lo + wave);
+  for (long ch = c_lo + wave; ch < c_hi; ch += 16) {
+    const float d0 = (float)nd0, d1 = (float)nd1;
+    const float cpos[3] = {npos[0], npos[1], npos[2]};
+    fetch(ch + 16);
     const bool valid = d0 != 0.0f || d1 != 0.0f;
     if (__ballot(valid) == 0ull) continue;
     float w[3] = {0.0f, 0.0f, 0.0f};
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
     if (valid) {
 #pragma unroll
       for (int dd = 0; dd < 3; dd++) {
-        const float p = fmaf(scale, pos[i * 3 + dd], 0.5f);
+        const float p = fmaf(scale, cpos[dd], 0.5f);
         const float fl = floorf(p);
         c[dd] = (uint32_t)(int)fl;
         w[dd] = p - fl;
@@ -586,22 +599,37 @@ struct BinSample {
   float wx[2], wy[2], wz[2], d0, d1;
 };
 
-__device__ __forceinline__ BinSample bin_sample(const GridLayout& g, int l, uint32_t hs, const float* __restrict__ pos,
-                                                const h2_t* __restrict__ dLdout, long i, long N, int L, int unit_major,
-                                                long cnt) {
-  BinSample s;
-  s.d0 = s.d1 = 0.0f;
+struct BinRaw {
+  float d0, d1, p[3];
+};
+
+// loads only (issued for all of a thread's samples before any of them is processed)
+__device__ __forceinline__ BinRaw bin_load(int l, const float* __restrict__ pos, const h2_t* __restrict__ dLdout, long i, long N,
+                                           int L, int unit_major, long cnt) {
+  BinRaw r;
+  r.d0 = r.d1 = 0.0f;
+  r.p[0] = r.p[1] = r.p[2] = 0.0f;
   if (i < cnt) {
     if (unit_major) {
       const _Float16* dp = reinterpret_cast<const _Float16*>(dLdout);
-      s.d0 = (float)dp[(long)(2 * l) * N + i];
-      s.d1 = (float)dp[(long)(2 * l + 1) * N + i];
+      r.d0 = (float)dp[(long)(2 * l) * N + i];
+      r.d1 = (float)dp[(long)(2 * l + 1) * N + i];
     } else {
       const h2_t d = dLdout[i * L + l];
-      s.d0 = (float)d[0];
-      s.d1 = (float)d[1];
+      r.d0 = (float)d[0];
+      r.d1 = (float)d[1];
     }
+    r.p[0] = pos[i * 3];
+    r.p[1] = pos[i * 3 + 1];
+    r.p[2] = pos[i * 3 + 2];
   }
+  return r;
+}
+
+__device__ __forceinline__ BinSample bin_sample(const GridLayout& g, int l, uint32_t hs, const BinRaw& r) {
+  BinSample s;
+  s.d0 = r.d0;
+  s.d1 = r.d1;
   s.valid = s.d0 != 0.0f || s.d1 != 0.0f;
   if (!s.valid) return s;
   const float scale = g.scale[l];
@@ -609,7 +637,7 @@ __device__ __forceinline__ BinSample bin_sample(const GridLayout& g, int l, uint
   float w[3];
 #pragma unroll
   for (int dd = 0; dd < 3; dd++) {
-    const float p = fmaf(scale, pos[i * 3 + dd], 0.5f);
+    const float p = fmaf(scale, r.p[dd], 0.5f);
     const float fl = floorf(p);
     c[dd] = (uint32_t)(int)fl;
     w[dd] = p - fl;
@@ -642,10 +670,13 @@ __global__ __launch_bounds__(256) void ngp_enc_bin_count_kernel(GridLayout g, Bi
   const uint32_t hs = g.offset[l + 1] - g.offset[l];
   if (tid < NS_BIN_MAX) hist[tid] = 0;
   __syncthreads();
+  BinRaw raw[NS_BIN_TILE / 256];
+#pragma unroll
+  for (int j = 0; j < NS_BIN_TILE / 256; j++)
+    raw[j] = bin_load(l, pos, dLdout, (long)tile * NS_BIN_TILE + j * 256 + tid, N, L, unit_major, nvalid);
 #pragma unroll
   for (int j = 0; j < NS_BIN_TILE / 256; j++) {
-    const long i = (long)tile * NS_BIN_TILE + j * 256 + tid;
-    const BinSample s = bin_sample(g, l, hs, pos, dLdout, i, N, L, unit_major, nvalid);
+    const BinSample s = bin_sample(g, l, hs, raw[j]);
     if (s.valid) {
 #pragma unroll
       for (int corner = 0; corner < 8; corner++) atomicAdd(&hist[s.idx[corner] >> 14], 1);
@@ -695,11 +726,14 @@ __global__ __launch_bounds__(256) void ngp_enc_bin_scatter_kernel(GridLayout g, 
       gdst[b] = (ti - t) + co.y;
     }
   }
+  BinRaw raw[NS_BIN_TILE / 256];   // (loaded before the barrier: in flight while the prefix sums are formed)
+#pragma unroll
+  for (int j = 0; j < NS_BIN_TILE / 256; j++)
+    raw[j] = bin_load(l, pos, dLdout, (long)tile * NS_BIN_TILE + j * 256 + tid, N, L, unit_major, nvalid);
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < NS_BIN_TILE / 256; j++) {
-    const long i = (long)tile * NS_BIN_TILE + j * 256 + tid;
-    const BinSample s = bin_sample(g, l, hs, pos, dLdout, i, N, L, unit_major, nvalid);
+    const BinSample s = bin_sample(g, l, hs, raw[j]);
     if (s.valid) {
       int slot[8];   // the eight returning LDS atomics and base reads are issued back to back; the records follow
 #pragma unroll
