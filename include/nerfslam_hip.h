@@ -409,14 +409,14 @@ int ns_group_mean_nhwc_f16(const void* src, int src_stride, const int* starts, c
  *   ctl[4], ctl[5] float bits of Adam's bias corrections 1 - beta^(ctl[0] + 1) (maintained by ns_ngp_step_advance; the caller
  *   initialises them).
  * With ctl != NULL the by-value R / n_images are CAPACITIES (grid sizes), `step` and `seed` are ignored
- * (seed = ctl[2] * 0x9E3779B1 + ctl[0] * 0x85EBCA77, bias corrections from ctl[0] + 1).  ctl == NULL: identical to the
+ * (seed = ctl[2] * 0x9E3779B1 + (ctl[0] + step_offset) * 0x85EBCA77, bias corrections from ctl[0] + 1).  ctl == NULL: identical to the
  * plain entry points.  ns_ngp_step_advance ends a step: last[0..3] = march counters + ray count of this step,
  * ctl[1] = clamp(R * fill * max_samples / requested, min_rays, max_rays) rounded down to 128, ctl[0] += 1,
  * counter[0..2] = 0.  [no reference counterpart: the fork's trainer reads its counters back on the host] */
 int ns_ngp_sample_rays_ctl(const float* images, const float* depths, const float* depth_covs, const float* c2w, int n_images,
                            int H, int W, float fx, float fy, float cx, float cy, float box_lo, float box_hi, float near,
                            unsigned seed, int R, float* rays_o, float* rays_d, float* t_range, float* gt_rgb, float* gt_depth,
-                           float* gt_depth_cov, int* ray_img, const int* ctl, void* stream);
+                           float* gt_depth_cov, int* ray_img, const int* ctl, int step_offset, void* stream);
 int ns_ngp_march_ctl(const uint8_t* bits, int G, int ncasc, const float* rays_o, const float* rays_d, const float* t_range,
                      int R, float cone, float min_step, float max_step, float pos_lo, float pos_inv, int max_per_ray,
                      long max_samples, int* counter, int* ray_start, int* ray_n, float* pos, float* dirs, float* dt, float* tmid,
@@ -439,6 +439,11 @@ int ns_ngp_adam_ctl(float* master, void* half_params, float* grad, float* m1, fl
                     float beta2, float eps, float l2, float grad_scale, float fixed_scale, const int* ctl, void* stream);
 int ns_ngp_step_advance(int* ctl, int* counter, int* last, float fill, long max_samples, int min_rays, int max_rays,
                         float beta1, float beta2, void* stream);
+/* the two halves of ns_ngp_step_advance: `_rays` (counters -> last, next ray count, counters cleared) may run as soon as the
+ * backward pass is done, so that the next step's ns_ngp_sample_rays_ctl(step_offset = 1) + ns_ngp_march_ctl overlap this
+ * step's optimiser pass; `_count` (ctl[0] += 1, Adam's bias corrections) closes the step after both have finished. */
+int ns_ngp_step_rays(int* ctl, int* counter, int* last, float fill, long max_samples, int min_rays, int max_rays, void* stream);
+int ns_ngp_step_count(int* ctl, float beta1, float beta2, void* stream);
 
 /* `_n` forms of the per-sample NeRF kernels: N is the CAPACITY (grid size and row stride of the unit-major tensors), the
  * number of samples actually processed is read from device memory (*n_dev, e.g. the marcher's counter; rounded up to 8 by

@@ -1061,6 +1061,7 @@ struct SampleRaysArgs {
   float *rays_o, *rays_d, *t_range, *gt_rgb, *gt_depth, *gt_cov;
   int* ray_img;  // optional [R]: image index of every ray (camera-pose refinement)
   const int* ctl;
+  int step_offset;  // ctl mode: the rays are those of step ctl[0] + step_offset (1: sampled ahead, while step ctl[0] finishes)
 };
 
 __global__ __launch_bounds__(256) void ngp_sample_rays_kernel(SampleRaysArgs a) {
@@ -1068,7 +1069,9 @@ __global__ __launch_bounds__(256) void ngp_sample_rays_kernel(SampleRaysArgs a) 
   const int R = a.ctl ? min(a.ctl[NS_CTL_RAYS], a.R) : a.R;
   if (r >= R) return;
   // same seed schedule as the host path (nerfslam/ngp.py): seed * 0x9E3779B1 + step * 0x85EBCA77
-  const uint32_t seed = a.ctl ? (uint32_t)a.ctl[NS_CTL_SEED] * 0x9E3779B1u + (uint32_t)a.ctl[NS_CTL_STEP] * 0x85EBCA77u : a.seed;
+  const uint32_t seed = a.ctl ? (uint32_t)a.ctl[NS_CTL_SEED] * 0x9E3779B1u +
+                                    (uint32_t)(a.ctl[NS_CTL_STEP] + a.step_offset) * 0x85EBCA77u
+                              : a.seed;
   const int nimg = a.ctl ? a.ctl[NS_CTL_VIEWS] : a.n;
   const uint32_t base = seed + (uint32_t)r * 3u;
   const int img = (int)(ns_pcg(base) % (uint32_t)nimg);
@@ -1745,21 +1748,21 @@ extern "C" int ns_ngp_sample_rays(const float* images, const float* depths, cons
                                   float* t_range, float* gt_rgb, float* gt_depth, float* gt_depth_cov, int* ray_img,
                                   void* stream) {
   return ns_ngp_sample_rays_ctl(images, depths, depth_covs, c2w, n_images, H, W, fx, fy, cx, cy, box_lo, box_hi, near, seed, R,
-                                rays_o, rays_d, t_range, gt_rgb, gt_depth, gt_depth_cov, ray_img, nullptr, stream);
+                                rays_o, rays_d, t_range, gt_rgb, gt_depth, gt_depth_cov, ray_img, nullptr, 0, stream);
 }
 
 extern "C" int ns_ngp_sample_rays_ctl(const float* images, const float* depths, const float* depth_covs, const float* c2w,
                                       int n_images, int H, int W, float fx, float fy, float cx, float cy, float box_lo,
                                       float box_hi, float near, unsigned seed, int R, float* rays_o, float* rays_d,
                                       float* t_range, float* gt_rgb, float* gt_depth, float* gt_depth_cov, int* ray_img,
-                                      const int* ctl, void* stream) {
+                                      const int* ctl, int step_offset, void* stream) {
   NS_REQUIRE(images && depths && depth_covs && c2w && rays_o && rays_d && t_range && gt_rgb && gt_depth && gt_depth_cov,
              "ns_ngp_sample_rays: null pointer");
   NS_REQUIRE(n_images > 0 && H > 0 && W > 0 && fx != 0.0f && fy != 0.0f && box_hi > box_lo,
              "ns_ngp_sample_rays: bad image set / intrinsics / box");
   if (R <= 0) return NS_OK;
   SampleRaysArgs a{images, depths, depth_covs, c2w, fx, fy, cx, cy, box_lo, box_hi, near, n_images, H, W, R, seed,
-                   rays_o, rays_d, t_range, gt_rgb, gt_depth, gt_depth_cov, ray_img, ctl};
+                   rays_o, rays_d, t_range, gt_rgb, gt_depth, gt_depth_cov, ray_img, ctl, step_offset};
   hipLaunchKernelGGL(ngp_sample_rays_kernel, dim3(ns_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, a);
   NS_CHECK_LAUNCH("ngp_sample_rays_kernel");
   return NS_OK;
@@ -1811,11 +1814,15 @@ extern "C" int ns_ngp_composite_ctl(const void* net_out, const float* dt, const 
   return NS_OK;
 }
 
-// End of a graph-captured training step: count the step, adapt the ray count of the next batch so that the sample budget
-// stays ~90 % full without refusing rays (the rule of nerfslam/ngp.py, instant-ngp adapts its batch likewise), keep a copy
-// of this step's march counters for (lazy) host reads, and clear them for the next march.
-__global__ void ngp_step_advance_kernel(int* __restrict__ ctl, int* __restrict__ counter, int* __restrict__ last, float fill,
-                                        long max_samples, int min_rays, int max_rays, float beta1, float beta2) {
+// End of a graph-captured training step, in two halves so that the NEXT step's rays can be sampled and marched (side stream
+// of the graph) while this step's optimiser pass runs:
+//   ngp_step_rays_kernel   after the backward pass: keep a copy of this step's march counters for (lazy) host reads, adapt the
+//                          ray count of the next batch so that the sample budget stays ~`fill` full without refusing rays
+//                          (the rule of nerfslam/ngp.py; instant-ngp adapts its batch likewise), clear the counters;
+//   ngp_step_count_kernel  after the optimiser AND the next march have finished: count the step, Adam's bias corrections
+//                          for the next one.
+__global__ void ngp_step_rays_kernel(int* __restrict__ ctl, int* __restrict__ counter, int* __restrict__ last, float fill,
+                                     long max_samples, int min_rays, int max_rays) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int requested = counter[0], R = ctl[NS_CTL_RAYS];
   last[0] = requested;
@@ -1826,19 +1833,36 @@ __global__ void ngp_step_advance_kernel(int* __restrict__ ctl, int* __restrict__
   int Rn = (int)fminf(fmaxf(want, (float)min_rays), (float)max_rays);
   Rn = Rn / 128 * 128;
   ctl[NS_CTL_RAYS] = max(Rn, 128);
+  counter[0] = counter[1] = counter[2] = 0;
+}
+
+__global__ void ngp_step_count_kernel(int* __restrict__ ctl, float beta1, float beta2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int done = ctl[NS_CTL_STEP] + 1;
   ctl[NS_CTL_STEP] = done;
   ctl[NS_CTL_C1] = __float_as_int(1.0f - powf(beta1, (float)(done + 1)));
   ctl[NS_CTL_C2] = __float_as_int(1.0f - powf(beta2, (float)(done + 1)));
-  counter[0] = counter[1] = counter[2] = 0;
+}
+
+extern "C" int ns_ngp_step_rays(int* ctl, int* counter, int* last, float fill, long max_samples, int min_rays, int max_rays,
+                                void* stream) {
+  NS_REQUIRE(ctl && counter && last, "ns_ngp_step_rays: null pointer");
+  NS_REQUIRE(fill > 0.0f && max_samples > 0 && min_rays >= 128 && max_rays >= min_rays, "ns_ngp_step_rays: bad limits");
+  hipLaunchKernelGGL(ngp_step_rays_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, counter, last, fill, max_samples,
+                     min_rays, max_rays);
+  NS_CHECK_LAUNCH("ngp_step_rays_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_ngp_step_count(int* ctl, float beta1, float beta2, void* stream) {
+  NS_REQUIRE(ctl, "ns_ngp_step_count: null pointer");
+  hipLaunchKernelGGL(ngp_step_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, beta1, beta2);
+  NS_CHECK_LAUNCH("ngp_step_count_kernel");
+  return NS_OK;
 }
 
 extern "C" int ns_ngp_step_advance(int* ctl, int* counter, int* last, float fill, long max_samples, int min_rays, int max_rays,
                                    float beta1, float beta2, void* stream) {
-  NS_REQUIRE(ctl && counter && last, "ns_ngp_step_advance: null pointer");
-  NS_REQUIRE(fill > 0.0f && max_samples > 0 && min_rays >= 128 && max_rays >= min_rays, "ns_ngp_step_advance: bad limits");
-  hipLaunchKernelGGL(ngp_step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, counter, last, fill, max_samples,
-                     min_rays, max_rays, beta1, beta2);
-  NS_CHECK_LAUNCH("ngp_step_advance_kernel");
-  return NS_OK;
+  const int rc = ns_ngp_step_rays(ctl, counter, last, fill, max_samples, min_rays, max_rays, stream);
+  return rc != NS_OK ? rc : ns_ngp_step_count(ctl, beta1, beta2, stream);
 }

@@ -209,6 +209,7 @@ class NgpNerf:
         s = float(c.aabb_scale)
         lo, inv = (0.5 - 0.5 * s, 1.0 / s) if unit else (0.0, 1.0)
         R = o.shape[0]
+        self._primed = False       # the sample arrays are shared with training: the next training step re-marches its rays
         # (rendering path: its own counters / ray tables -- the training step's are part of a captured graph)
         self.rm_counter = torch.zeros(3, dtype=torch.int32, device=self.device)
         self.rm_start = torch.empty(R, dtype=torch.int32, device=self.device)
@@ -250,6 +251,8 @@ class NgpNerf:
         # unused sample slots must hold finite inputs: the per-sample kernels run over all of them
         self.s_pos.fill_(0.5); self.s_dir.zero_(); self.s_dt.zero_(); self.s_t.zero_(); self.s_dout.zero_()
         self._graph, self._graph_key = None, None
+        self._side = torch.cuda.Stream(device=dev)       # next step's ray marching overlaps this step's optimiser pass
+        self._primed = False
         self._static = True
 
     def _step_key(self):
@@ -258,29 +261,39 @@ class NgpNerf:
                 tuple(self.images.shape[1:3]), tuple(self.intr), c.depth_lambda, c.optimize_extrinsics,
                 None if getattr(self, "cam_grad", None) is None else self.cam_grad.data_ptr(), self.bits.data_ptr())
 
-    def _enqueue_step(self):
-        """one optimiser step on the current stream; no host synchronisation, no allocation"""
-        c, dev = self.cfg, self.device
-        L = lib()
+    def _enqueue_rays(self, step_offset):
+        """sample the rays of step ctl[0] + step_offset and march them (fills the sample arrays and the march counters)"""
+        c, L = self.cfg, lib()
         S, Rc = c.max_samples, self.ray_cap
         n_cap, H, W = self.images.shape[:3]
         s = float(c.aabb_scale)
         fx, fy, cx, cy = self.intr
-        st = stream_ptr()
-        ctl = ptr(self.ctl)
+        st, ctl = stream_ptr(), ptr(self.ctl)
         self.ray_n.fill_(-1)
-        self.s_dout.zero_()
-        self.loss_acc.zero_()
         check(L.ns_ngp_sample_rays_ctl(ptr(self.images), ptr(self.depths), ptr(self.depth_covs), ptr(self.c2w), n_cap, H, W,
                                        C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
                                        C.c_float(0.5 - 0.5 * s), C.c_float(0.5 + 0.5 * s), C.c_float(c.near), C.c_uint32(0), Rc,
                                        ptr(self.r_o), ptr(self.r_d), ptr(self.r_tr), ptr(self.r_rgb), ptr(self.r_depth),
-                                       ptr(self.r_cov), ptr(self.r_img), ctl, st), "ngp_sample_rays")
+                                       ptr(self.r_cov), ptr(self.r_img), ctl, int(step_offset), st), "ngp_sample_rays")
         check(L.ns_ngp_march_ctl(ptr(self.bits), c.grid_size, c.n_cascades, ptr(self.r_o), ptr(self.r_d), ptr(self.r_tr), Rc,
                                  C.c_float(c.cone_angle), C.c_float(c.min_step), C.c_float(c.max_step),
                                  C.c_float(0.5 - 0.5 * s), C.c_float(1.0 / s), c.max_steps_per_ray, C.c_long(S), ptr(self.counter),
                                  ptr(self.ray_start), ptr(self.ray_n), ptr(self.s_pos), ptr(self.s_dir), ptr(self.s_dt),
                                  ptr(self.s_t), ctl, st), "ngp_march")
+
+    def _enqueue_step(self):
+        """one optimiser step on the current stream (+ a side stream); no host synchronisation, no allocation.
+        The rays of a step are sampled and marched at the END of the previous step's launch sequence, on a side stream,
+        while that step's optimiser pass (a pure HBM stream over the 12.6 M grid parameters) runs: the marcher is latency
+        bound (84 us at low occupancy), Adam is bandwidth bound (94 us) -- together they take the time of one."""
+        c, dev = self.cfg, self.device
+        L = lib()
+        S, Rc = c.max_samples, self.ray_cap
+        s = float(c.aabb_scale)
+        st = stream_ptr()
+        ctl = ptr(self.ctl)
+        self.s_dout.zero_()
+        self.loss_acc.zero_()
         # sample count of THIS step = end of the marcher's reserved ranges (device memory): the per-sample kernels are launched
         # over the whole budget S (fixed grids, fixed row strides) and skip the tail the marcher did not fill
         n_dev = C.c_void_p(self.counter.data_ptr() + 8)
@@ -314,14 +327,21 @@ class NgpNerf:
                                            self.cam_grad.shape[0], 0, C.c_float(c.extrinsic_lr_pos), C.c_float(c.extrinsic_lr_rot),
                                            C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
                                            C.c_float(c.loss_scale * self.world), ctl, st), "ngp_camera_step")
+        # this step no longer needs its rays / samples: record the march counters, adapt the next batch, clear them
+        check(L.ns_ngp_step_rays(ptr(self.ctl), ptr(self.counter), ptr(self.last), C.c_float(0.9), C.c_long(S), 256, Rc, st),
+              "ngp_step_rays")
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):          # next step's rays, concurrently with this step's optimiser pass
+            self._enqueue_rays(1)
         for (m, hp, g, m1, m2, l2, fxs) in (
                 (self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale),
                 (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0)):
             check(L.ns_ngp_adam_ctl(ptr(m), ptr(hp), ptr(g), ptr(m1), ptr(m2), C.c_long(m.numel()), 0, C.c_float(c.lr),
                                     C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps), C.c_float(l2),
                                     C.c_float(c.loss_scale * self.world), C.c_float(fxs), ctl, st), "ngp_adam")
-        check(L.ns_ngp_step_advance(ptr(self.ctl), ptr(self.counter), ptr(self.last), C.c_float(0.9), C.c_long(S), 256,
-                                    Rc, C.c_float(c.beta1), C.c_float(c.beta2), st), "ngp_step_advance")
+        main.wait_stream(self._side)
+        check(L.ns_ngp_step_count(ptr(self.ctl), C.c_float(c.beta1), C.c_float(c.beta2), st), "ngp_step_count")
 
     def train_step(self, return_loss=True):
         if self.n_images == 0:
@@ -332,6 +352,11 @@ class NgpNerf:
                 self._alloc_static()
             if c.optimize_extrinsics:
                 self._grow_camera_state(self.images.shape[0])
+            if not self._primed:
+                # no predecessor step marched this step's rays (first step, or render() has used the sample arrays since)
+                self.counter.zero_()
+                self._enqueue_rays(0)
+                self._primed = True
             if self.world > 1 or not c.use_graph:
                 self._enqueue_step()
             else:
@@ -356,8 +381,9 @@ class NgpNerf:
 
     @property
     def loss_tensor(self):
-        """mean per-ray loss of the last step (device scalar; rays the marcher refused are not part of the batch)"""
-        return self.loss_acc / (self.ray_n >= 0).sum().clamp(min=1)
+        """mean per-ray loss of the last step (device scalar): loss sum over the step's rays / their number (the ray tables
+        themselves already belong to the NEXT step: its rays are marched while this step's optimiser pass runs)"""
+        return self.loss_acc / self.last[3].clamp(min=1).float()
 
     @property
     def last_samples(self):
