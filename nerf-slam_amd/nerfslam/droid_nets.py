@@ -181,6 +181,13 @@ class DroidNetworks:
         if weights:
             self.net.load_weights(weights)
         self.net = self.net.to(self.device).eval()
+        # f16 copies of the two encoders: under autocast the f32 weights are cast to f16 on EVERY call (~60 tiny cast kernels
+        # per encoder call); same arithmetic (f16 convolutions, instance-norm statistics in f32) without them
+        self.fnet_h = self.cnet_h = None
+        if self.device.type == "cuda":
+            import copy
+            self.fnet_h = copy.deepcopy(self.net.feature_net).half()
+            self.cnet_h = copy.deepcopy(self.net.context_net).half()
         self.ctx, self.inp = {}, {}          # per keyframe: tanh / relu halves of the context encoder
         self.hidden = {}                     # per edge (i, j): ConvGRU hidden state [128, ht, wd]
         self._pending = None
@@ -202,7 +209,9 @@ class DroidNetworks:
     @torch.no_grad()
     def features(self, img_u8):
         x = self._normalize(img_u8)
-        with torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda"):
+        if self.fnet_h is not None:
+            f = self.fnet_h(x.half())[0, 0]
+        else:
             f = self.net.feature_net(x)[0, 0]
         self._pending = x
         return f
@@ -211,8 +220,7 @@ class DroidNetworks:
     def begin_keyframe(self, k, img_u8):
         """hook of TrackingSLAM._store: context features of the frame that just became keyframe k"""
         x = self._pending if self._pending is not None else self._normalize(img_u8)
-        with torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda"):
-            c = self.net.context_net(x)[0, 0]
+        c = self.cnet_h(x.half())[0, 0] if self.cnet_h is not None else self.net.context_net(x)[0, 0]
         self.ctx[k], self.inp[k] = torch.tanh(c[:128]), torch.relu(c[128:])
         if self.hip_update:
             self.ctx_cl[k] = self.ctx[k].permute(1, 2, 0).contiguous().half()

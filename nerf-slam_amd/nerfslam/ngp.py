@@ -310,16 +310,25 @@ class NgpNerf:
         check(L.ns_ngp_mlp_backward_n(ptr(self.mlp_half), ptr(self.s_dout), ptr(featT), *[ptr(a) for a in acts],
                                       ptr(self.s_dfeat), *[ptr(a) for a in dacts], ptr(self.partial), c.wgrad_ksplit,
                                       ptr(self.mlp_grad), C.c_long(S), n_dev, st), "ngp_mlp_backward")
+        main = torch.cuda.current_stream()
+        if c.optimize_extrinsics:
+            # pose refinement (input gradient of the encoding: 8 gathers x 16 levels per sample, L2-request bound; per-ray and
+            # per-image reductions) on the side stream, concurrently with the table gradient (record streams + LDS): both
+            # only READ the feature gradient
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                st2 = stream_ptr()
+                check(L.ns_ngp_encode_backward_input_n(*self._grid_args(), ptr(self.s_pos), ptr(self.grid_half), ptr(self.s_dfeat),
+                                                       ptr(self.dpos), C.c_long(S), n_dev, st2), "ngp_encode_backward_input")
+                n_cam = self.cam_grad.shape[0]
+                check(L.ns_ngp_camera_gradient_2stage(ptr(self.dpos), ptr(self.s_t), ptr(self.r_d), ptr(self.ray_start),
+                                                      ptr(self.ray_n), ptr(self.r_img), C.c_float(1.0 / s), ptr(self.cam_grad), Rc, ctl,
+                                                      ptr(self.ray_g) if n_cam <= 4096 else None, n_cam, st2), "ngp_camera_gradient")
         check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(self.s_pos), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
                                          ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev, st),
               "ngp_encode_backward")
         if c.optimize_extrinsics:
-            check(L.ns_ngp_encode_backward_input_n(*self._grid_args(), ptr(self.s_pos), ptr(self.grid_half), ptr(self.s_dfeat),
-                                                   ptr(self.dpos), C.c_long(S), n_dev, st), "ngp_encode_backward_input")
-            n_cam = self.cam_grad.shape[0]
-            check(L.ns_ngp_camera_gradient_2stage(ptr(self.dpos), ptr(self.s_t), ptr(self.r_d), ptr(self.ray_start), ptr(self.ray_n),
-                                                  ptr(self.r_img), C.c_float(1.0 / s), ptr(self.cam_grad), Rc, ctl,
-                                                  ptr(self.ray_g) if n_cam <= 4096 else None, n_cam, st), "ngp_camera_gradient")
+            main.wait_stream(self._side)
         if self.world > 1:
             self._allreduce_gradients()
         if c.optimize_extrinsics:   # after the all-reduce: every replica applies the SAME pose update
@@ -330,7 +339,6 @@ class NgpNerf:
         # this step no longer needs its rays / samples: record the march counters, adapt the next batch, clear them
         check(L.ns_ngp_step_rays(ptr(self.ctl), ptr(self.counter), ptr(self.last), C.c_float(0.9), C.c_long(S), 256, Rc, st),
               "ngp_step_rays")
-        main = torch.cuda.current_stream()
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):          # next step's rays, concurrently with this step's optimiser pass
             self._enqueue_rays(1)
