@@ -210,6 +210,7 @@ class TrackingSLAM:
         es = np.asarray(g.proximity_edges(d, t, 0, 0, self.backend_radius, self.backend_nms, self.backend_thresh), np.int64)
         if steps and es.shape[0]:
             ii_h, jj_h, _ = g.add(es[:, 0], es[:, 1])
+            self.last_backend_edges = int(ii_h.shape[0])
             ii, jj = torch.from_numpy(ii_h).to(self.device), torch.from_numpy(jj_h).to(self.device)
             fmaps = (fe.feat_bank.float() * 4.0).transpose(1, 2).reshape(1, self.buffer, 128, fe.ht, fe.wd)
             corr_op = AltCorrBlock(fmaps)
@@ -218,16 +219,22 @@ class TrackingSLAM:
                 coords1 = fe.reproject(ii, jj)
                 motion = fe.motion_features(coords1, target)
                 for lo in range(0, int(jj_h.max()) + 1, 8):                # windows of 8 source frames (:494-499)
-                    v = torch.from_numpy((ii_h >= lo) & (ii_h < lo + 8)).to(self.device)
-                    if not bool(v.any()):
+                    vh = np.nonzero((ii_h >= lo) & (ii_h < lo + 8))[0]     # (the edge lists are host arrays: the window
+                    if vh.shape[0] == 0:                                   #  selection costs no device read-back)
                         continue
-                    corr = corr_op(coords1[None, v], ii[v], jj[v])
-                    res = self.net.update(corr, motion[None, v], ii[v], jj[v])
+                    v = torch.from_numpy(vh).to(self.device)
+                    iv, jv = ii[v], jj[v]
+                    corr = corr_op(coords1[None, v], iv, jv)
+                    if getattr(self.net.update, "host_indices", False):
+                        res = self.net.update(corr, motion[None, v], iv, jv, ii_host=ii_h[vh].tolist(), jj_host=jj_h[vh].tolist())
+                    else:
+                        res = self.net.update(corr, motion[None, v], iv, jv)
                     delta, w, damping = res[:3]
                     target[v], weight[v] = coords1[v] + delta[0].float(), w[0].float()
-                    fe.damping[torch.unique(ii[v])] = damping
+                    kxv = torch.from_numpy(np.unique(ii_h[vh])).to(self.device)
+                    fe.damping[kxv] = damping
                     if len(res) > 3:
-                        fe.upsample(torch.unique(ii[v]), res[3])
+                        fe.upsample(kxv, res[3])
                 fe.ba(target.permute(0, 3, 1, 2).contiguous(), weight.permute(0, 3, 1, 2).contiguous(), ii_h, jj_h,
                       kf0=0, itrs=2, compute_covariances=False)   # :523-526 (its lm / ep arguments are dead: ba() never reads them)
         g.reset(max_factors=saved)
