@@ -405,6 +405,8 @@ def bench_c1280(args, dev):
 
 # =================================================================================================
 def main():
+    import faulthandler
+    faulthandler.enable()      # a device fault aborts the process: leave the Python stack of the offending launch in stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)

@@ -204,7 +204,9 @@ __global__ __launch_bounds__(256) void altcorr_tile_kernel(AltPyramid P, const i
     atomicMax(&bbox[3], min(yb + 8, H2));
   }
   __syncthreads();
-  const int x0 = bbox[0], y0 = bbox[1], RW = bbox[2] - bbox[0], RH = bbox[3] - bbox[1];
+  // (an untouched box keeps its +/-INT_MAX sentinels, whose difference wraps to +2: test the sentinel, not the difference)
+  const bool empty = bbox[0] == 0x7fffffff || bbox[2] == -0x7fffffff;
+  const int x0 = bbox[0], y0 = bbox[1], RW = empty ? 0 : bbox[2] - bbox[0], RH = empty ? 0 : bbox[3] - bbox[1];
   if (RW <= 0 || RH <= 0) {  // nothing of this tile looks into the image: zeros
     if (inimg && q == 0)
       for (int ch = 0; ch < 49; ch++) obase[(long)ch * HW1 + pix] = 0.0f;

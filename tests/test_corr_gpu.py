@@ -168,6 +168,30 @@ def test_altcorr_block_fused_pyramid(oracle_mod, dev):
         lv = torch.nn.functional.avg_pool2d(lv, 2, stride=2)
 
 
+def test_altcorr_block_smooth_flow_and_tiles_that_leave_the_image(oracle_mod, dev):
+    """The staged (LDS) path of the tile kernel: a smooth flow keeps a tile's windows inside a small box.  Edge 1 is shifted
+    so far that whole 8x8 tiles look outside the image (their box stays empty -> exact zeros, altcorr_kernel.cu:63-66 `within`),
+    edge 2 leaves only on the right-hand side; H is not a multiple of 8 (the 1280x720 grid is 90 rows)."""
+    from nerfslam.corr import AltCorrBlock
+    rng = np.random.default_rng(17)
+    nfr, Cc, H, W, E = 3, 128, 26, 40, 3
+    fm = rng.standard_normal((1, nfr, Cc, H, W)).astype(np.float16)
+    ii, jj = np.array([0, 1, 2], np.int64), np.array([1, 2, 0], np.int64)
+    gy, gx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    base = np.stack([gx, gy], -1).astype(np.float32)
+    coords = np.stack([base + [1.3, -0.6], base + [3.0 * W, 0.4], base + [W - 20.25, 2.5]])[None].astype(np.float32)
+    blk = AltCorrBlock(torch.from_numpy(fm).to(dev))
+    got = blk(torch.from_numpy(coords).to(dev), torch.from_numpy(ii).to(dev), torch.from_numpy(jj).to(dev))[0].cpu().numpy()
+    assert np.all(got[1] == 0.0), "windows entirely outside the image correlate to exact zeros"
+    lv = torch.from_numpy(fm[0]).float() / 4.0
+    f0 = lv.permute(0, 2, 3, 1).contiguous().numpy()
+    for l in range(4):
+        f = lv.permute(0, 2, 3, 1).contiguous().numpy()
+        ref = oracle_mod.altcorr_forward(f0[ii], f[jj], coords[0][:, None] / np.float32(2 ** l), 3)[:, 0]
+        np.testing.assert_allclose(got[:, 49 * l:49 * (l + 1)], ref, rtol=0, atol=1e-5 * np.abs(ref).max())
+        lv = torch.nn.functional.avg_pool2d(lv, 2, stride=2)
+
+
 @pytest.mark.parametrize("shape", [(16, 24), (43, 77), (60, 80)])
 def test_tiled_layout_same_volume_and_same_lookup_bits(dev, shape):
     """the private 8x8-tiled slice layout (levels 0 / 1): the volume values are those of the row-major build, and the
