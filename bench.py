@@ -351,6 +351,10 @@ def bench_c1280(args, dev):
     fe.cam0_T_world[:NB, :3] += 0.01 * torch.randn((NB, 3), device=dev, generator=g)
     fe.cam0_idepths[:NB] = stream.disps[::stride][:NB] * (1.0 + 0.02 * torch.randn((NB, fe.ht, fe.wd), device=dev, generator=g))
     fe.cam0_idepths_sensed[0] = stream.disps[0]              # gauge (as in the c640 stream)
+    from nerfslam import se3 as _se3
+    # the BA retracts world_T_body and re-derives cam0_T_world = cam0_T_body * world_T_body^-1 from it
+    fe.world_T_body[:NB] = _se3.mul(_se3.inv(fe.cam0_T_world[:NB]), fe.cam0_T_body.reshape(1, 7).expand(NB, 7).contiguous())
+    fe.prior_pose = fe.world_T_body[0].clone()               # frame-0 prior, as TrackingSLAM sets it on the first frame
     fe.kf_idx = NB - 1
     torch.cuda.synchronize()
     fill_s = time.perf_counter() - t0

@@ -403,6 +403,29 @@ int ns_planes_to_nhwc_f16(const void* src, void* dst, int E, int C, int CP, int 
 int ns_group_mean_nhwc_f16(const void* src, int src_stride, const int* starts, const int* members, void* out, int K, int HW,
                            int channels, void* stream);
 
+/* ---- feature / context encoders on the MFMA convolution (networks/modules/extractor.py:118-198 `BasicEncoder`; host
+ * side nerfslam/encoder_op.py).  Activations are dense channels-last f16 [N,H,W,C]; Ho = (H-1)/2+1, Wo = (W-1)/2+1.
+ *
+ * ns_enc_stem_im2col: image [N,3,H,W] (u8 if img_is_u8, else f32 holding 0..255) -> out [N,Ho,Wo,160] f16 patches of the
+ *   7x7 / stride 2 / pad 3 stem over the NORMALISED image (x/255 - mean[c]) / std[c] (zero padded after normalisation):
+ *   out[..., (ky*7+kx)*3 + c], channels 147..159 zero -> the stem is a 1x1 ns_conv_nhwc_f16 with
+ *   weight.permute(0,2,3,1).reshape(32,147).  mean / std: 3 floats each in HOST memory.
+ * ns_enc_im2col_3x3s2: x [N,H,W,C] -> out [N,Ho,Wo,9C], out[..., (ky*3+kx)*C + c] = x[n, 2oy+ky-1, 2ox+kx-1, c] (0 outside):
+ *   a stride-2 3x3 convolution (extractor.py:16-17,158-159) becomes a 1x1 over 9C channels, and the block's stride-2 1x1
+ *   shortcut (extractor.py:46-47) a 1x1 over the centre-tap slice [4C, 5C) of the same buffer.
+ * ns_enc_in_stats: partial[n][p][0|1][c] = sum | sum of squares of x [N,HW,C] over part p of the pixels,
+ *   p < ns_enc_in_parts(HW); C in {32, 64, 128}.  partial: f32 [N, parts, 2, C].
+ * ns_enc_in_apply: out = relu(x' + relu(y')) with y' = (y - mean) / sqrt(var + eps) from ystats (nullptr: y' = y),
+ *   x' likewise from xstats without the relu (x nullptr: out = relu(y')); biased variance, statistics combined in f64:
+ *   InstanceNorm2d + relu, and the tail of a residual block (extractor.py:50-60), in one pass.                        */
+int ns_enc_stem_im2col(const void* img, int img_is_u8, void* out, int N, int H, int W, const float* mean, const float* std,
+                       void* stream);
+int ns_enc_im2col_3x3s2(const void* x, void* out, int N, int H, int W, int C, void* stream);
+int ns_enc_in_parts(int HW);
+int ns_enc_in_stats(const void* x, float* partial, int N, int HW, int C, void* stream);
+int ns_enc_in_apply(const void* y, const float* ystats, const void* x, const float* xstats, void* out, int N, int HW, int C,
+                    float eps, void* stream);
+
 /* ---- graph-captured training step (nerfslam/ngp.py): the `_ctl` forms read the per-step scalars from a device
  * control block instead of by-value arguments, so that a whole optimiser step is a fixed launch sequence:
  *   ctl[0] optimiser steps completed, ctl[1] rays of the current batch, ctl[2] ray-sampling seed, ctl[3] training views,
@@ -463,6 +486,14 @@ int ns_ngp_mlp_forward_n(const void* weights, const void* featT, const float* di
 int ns_ngp_mlp_backward_n(const void* weights, const void* dLdout, const void* featT, const void* h1T, const void* cinT,
                           const void* h3T, const void* h4T, void* dLdfeatT, void* d5T, void* d4T, void* d3T, void* ddT, void* d1T,
                           float* partial_ws, int ksplit, float* grad_weights, long N, const int* n_dev, void* stream);
+/* the two halves of ns_ngp_mlp_backward_n: activation gradients (writes dLdfeatT and the d*T buffers), then the weight
+ * gradients (reads them).  Separate entries so that the caller can put the second half on another stream, next to the
+ * hash-grid backward that consumes dLdfeatT (nerfslam/ngp.py).                                                       */
+int ns_ngp_mlp_dgrad_n(const void* weights, const void* dLdout, const void* h1T, const void* h3T, const void* h4T, void* dLdfeatT,
+                       void* d5T, void* d4T, void* d3T, void* ddT, void* d1T, long N, const int* n_dev, void* stream);
+int ns_ngp_mlp_wgrad_n(const void* featT, const void* h1T, const void* cinT, const void* h3T, const void* h4T, const void* d5T,
+                       const void* d4T, const void* d3T, const void* ddT, const void* d1T, float* partial_ws, int ksplit,
+                       float* grad_weights, long N, const int* n_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -476,22 +476,21 @@ extern "C" int ns_ngp_mlp_backward(const void* weights, const void* dLdout, cons
                                grad_weights, N, nullptr, stream);
 }
 
-extern "C" int ns_ngp_mlp_backward_n(const void* weights, const void* dLdout, const void* featT, const void* h1T,
-                                     const void* cinT, const void* h3T, const void* h4T, void* dLdfeatT, void* d5T,
-                                     void* d4T, void* d3T, void* ddT, void* d1T, float* partial_ws, int ksplit,
-                                     float* grad_weights, long N, const int* n_dev, void* stream) {
-  NS_REQUIRE(weights && dLdout && featT && h1T && cinT && h3T && h4T && dLdfeatT && d5T && d4T && d3T && ddT && d1T &&
-                 partial_ws && grad_weights,
-             "ns_ngp_mlp_backward: null pointer");
-  NS_REQUIRE(ksplit >= 1 && N % 8 == 0, "ns_ngp_mlp_backward: ksplit >= 1 and N a multiple of 8 are required");
-  if (N <= 0) return NS_OK;
-  hipStream_t st = (hipStream_t)stream;
+static int mlp_dgrad_launch(const void* weights, const void* dLdout, const void* h1T, const void* h3T, const void* h4T,
+                            void* dLdfeatT, void* d5T, void* d4T, void* d3T, void* ddT, void* d1T, long N, const int* n_dev,
+                            hipStream_t st) {
   MlpBwdArgs b{(const _Float16*)weights, (const _Float16*)dLdout, (const _Float16*)h1T, (const _Float16*)h3T,
                (const _Float16*)h4T,     (_Float16*)dLdfeatT,     (_Float16*)d5T,       (_Float16*)d4T,
                (_Float16*)d3T,           (_Float16*)ddT,          (_Float16*)d1T,       N,
                n_dev};
   hipLaunchKernelGGL(ngp_mlp_bwd_kernel, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, st, b);
   NS_CHECK_LAUNCH("ngp_mlp_bwd_kernel");
+  return NS_OK;
+}
+
+static int mlp_wgrad_launch(const void* featT, const void* h1T, const void* cinT, const void* h3T, const void* h4T, const void* d5T,
+                            const void* d4T, const void* d3T, const void* ddT, const void* d1T, float* partial_ws, int ksplit,
+                            float* grad_weights, long N, const int* n_dev, hipStream_t st) {
   WgradArgs w;
   w.layer[0] = WgradLayer{(const _Float16*)d1T, (const _Float16*)featT, 64, 32, W1_OFF};
   w.layer[1] = WgradLayer{(const _Float16*)ddT, (const _Float16*)h1T, 16, 64, W2_OFF};
@@ -508,4 +507,41 @@ extern "C" int ns_ngp_mlp_backward_n(const void* weights, const void* dLdout, co
                      grad_weights);
   NS_CHECK_LAUNCH("ngp_mlp_wgrad_reduce_kernel");
   return NS_OK;
+}
+
+extern "C" int ns_ngp_mlp_backward_n(const void* weights, const void* dLdout, const void* featT, const void* h1T,
+                                     const void* cinT, const void* h3T, const void* h4T, void* dLdfeatT, void* d5T,
+                                     void* d4T, void* d3T, void* ddT, void* d1T, float* partial_ws, int ksplit,
+                                     float* grad_weights, long N, const int* n_dev, void* stream) {
+  NS_REQUIRE(weights && dLdout && featT && h1T && cinT && h3T && h4T && dLdfeatT && d5T && d4T && d3T && ddT && d1T &&
+                 partial_ws && grad_weights,
+             "ns_ngp_mlp_backward: null pointer");
+  NS_REQUIRE(ksplit >= 1 && N % 8 == 0, "ns_ngp_mlp_backward: ksplit >= 1 and N a multiple of 8 are required");
+  if (N <= 0) return NS_OK;
+  const int rc = mlp_dgrad_launch(weights, dLdout, h1T, h3T, h4T, dLdfeatT, d5T, d4T, d3T, ddT, d1T, N, n_dev, (hipStream_t)stream);
+  if (rc != NS_OK) return rc;
+  return mlp_wgrad_launch(featT, h1T, cinT, h3T, h4T, d5T, d4T, d3T, ddT, d1T, partial_ws, ksplit, grad_weights, N, n_dev,
+                          (hipStream_t)stream);
+}
+
+// the two halves of ns_ngp_mlp_backward_n as separate entries: the weight gradients only READ what the activation backward
+// wrote, so a caller may run them on another stream, next to the hash-grid backward that consumes dLdfeatT
+extern "C" int ns_ngp_mlp_dgrad_n(const void* weights, const void* dLdout, const void* h1T, const void* h3T, const void* h4T,
+                                  void* dLdfeatT, void* d5T, void* d4T, void* d3T, void* ddT, void* d1T, long N, const int* n_dev,
+                                  void* stream) {
+  NS_REQUIRE(weights && dLdout && h1T && h3T && h4T && dLdfeatT && d5T && d4T && d3T && ddT && d1T, "ns_ngp_mlp_dgrad: null pointer");
+  NS_REQUIRE(N % 8 == 0, "ns_ngp_mlp_dgrad: N must be a multiple of 8");
+  if (N <= 0) return NS_OK;
+  return mlp_dgrad_launch(weights, dLdout, h1T, h3T, h4T, dLdfeatT, d5T, d4T, d3T, ddT, d1T, N, n_dev, (hipStream_t)stream);
+}
+
+extern "C" int ns_ngp_mlp_wgrad_n(const void* featT, const void* h1T, const void* cinT, const void* h3T, const void* h4T,
+                                  const void* d5T, const void* d4T, const void* d3T, const void* ddT, const void* d1T,
+                                  float* partial_ws, int ksplit, float* grad_weights, long N, const int* n_dev, void* stream) {
+  NS_REQUIRE(featT && h1T && cinT && h3T && h4T && d5T && d4T && d3T && ddT && d1T && partial_ws && grad_weights,
+             "ns_ngp_mlp_wgrad: null pointer");
+  NS_REQUIRE(ksplit >= 1 && N % 8 == 0, "ns_ngp_mlp_wgrad: ksplit >= 1 and N a multiple of 8 are required");
+  if (N <= 0) return NS_OK;
+  return mlp_wgrad_launch(featT, h1T, cinT, h3T, h4T, d5T, d4T, d3T, ddT, d1T, partial_ws, ksplit, grad_weights, N, n_dev,
+                          (hipStream_t)stream);
 }

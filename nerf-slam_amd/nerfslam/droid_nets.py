@@ -174,7 +174,7 @@ class DroidNetworks:
     MEAN = (0.485, 0.456, 0.406)
     STD = (0.229, 0.224, 0.225)
 
-    def __init__(self, device, weights=None, buffer=512, seed=0, hip_update=None):
+    def __init__(self, device, weights=None, buffer=512, seed=0, hip_update=None, hip_encoders=None):
         self.device = torch.device(device)
         torch.manual_seed(seed)
         self.net = DroidNet()
@@ -184,10 +184,17 @@ class DroidNetworks:
         # f16 copies of the two encoders: under autocast the f32 weights are cast to f16 on EVERY call (~60 tiny cast kernels
         # per encoder call); same arithmetic (f16 convolutions, instance-norm statistics in f32) without them
         self.fnet_h = self.cnet_h = None
+        self.fnet_hip = self.cnet_hip = None
         if self.device.type == "cuda":
             import copy
+            import os
             self.fnet_h = copy.deepcopy(self.net.feature_net).half()
             self.cnet_h = copy.deepcopy(self.net.context_net).half()
+            # both encoders on the MFMA convolution (nerfslam/encoder_op.py); NS_TORCH_ENCODERS=1 keeps the MIOpen path (A/B runs)
+            if (hip_encoders is None and not os.environ.get("NS_TORCH_ENCODERS")) or hip_encoders:
+                from .encoder_op import HipEncoder
+                self.fnet_hip = HipEncoder(self.net.feature_net, True, self.MEAN, self.STD)
+                self.cnet_hip = HipEncoder(self.net.context_net, False, self.MEAN, self.STD)
         self.ctx, self.inp = {}, {}          # per keyframe: tanh / relu halves of the context encoder
         self.hidden = {}                     # per edge (i, j): ConvGRU hidden state [128, ht, wd]
         self._pending = None
@@ -208,6 +215,11 @@ class DroidNetworks:
 
     @torch.no_grad()
     def features(self, img_u8):
+        if self.fnet_hip is not None:
+            img = img_u8.to(self.device)[:3]
+            img = (img if img.dtype == torch.uint8 else img.float())[None]
+            self._pending = img                                            # (the context encoder normalises it again itself)
+            return self.fnet_hip(img)[0].permute(2, 0, 1)                  # [128, ht, wd] view of the channels-last output
         x = self._normalize(img_u8)
         if self.fnet_h is not None:
             f = self.fnet_h(x.half())[0, 0]
@@ -219,6 +231,17 @@ class DroidNetworks:
     @torch.no_grad()
     def begin_keyframe(self, k, img_u8):
         """hook of TrackingSLAM._store: context features of the frame that just became keyframe k"""
+        if self.cnet_hip is not None:
+            img = self._pending
+            if img is None:
+                img = img_u8.to(self.device)[:3]
+                img = (img if img.dtype == torch.uint8 else img.float())[None]
+            c = self.cnet_hip(img)[0]                                      # [ht, wd, 256] channels-last f16
+            ctx, inp = torch.tanh(c[..., :128]).contiguous(), torch.relu(c[..., 128:]).contiguous()
+            self.ctx[k], self.inp[k] = ctx.permute(2, 0, 1), inp.permute(2, 0, 1)
+            if self.hip_update:
+                self.ctx_cl[k], self.inp_cl[k] = ctx, inp
+            return
         x = self._pending if self._pending is not None else self._normalize(img_u8)
         c = self.cnet_h(x.half())[0, 0] if self.cnet_h is not None else self.net.context_net(x)[0, 0]
         self.ctx[k], self.inp[k] = torch.tanh(c[:128]), torch.relu(c[128:])

@@ -12,6 +12,7 @@ per-sample / per-parameter pass runs in the HIP kernels.
 """
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 
 import torch
@@ -307,27 +308,43 @@ class NgpNerf:
                                      ptr(self.r_rgb), ptr(self.r_depth), ptr(self.r_cov), C.c_float(c.depth_lambda),
                                      C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), ptr(self.loss_acc),
                                      ptr(self.s_dout), ctl, st), "ngp_composite")
-        check(L.ns_ngp_mlp_backward_n(ptr(self.mlp_half), ptr(self.s_dout), ptr(featT), *[ptr(a) for a in acts],
-                                      ptr(self.s_dfeat), *[ptr(a) for a in dacts], ptr(self.partial), c.wgrad_ksplit,
-                                      ptr(self.mlp_grad), C.c_long(S), n_dev, st), "ngp_mlp_backward")
+        # activation gradients on this stream; the weight gradients (and the pose refinement's input gradient) only READ what
+        # they wrote, so they go to the side stream, next to the table gradient: that one is bound by LDS atomics and
+        # scattered records, they by streaming reads (NS_NGP_WGRAD_MAIN=1 keeps the weight gradients in line: A/B runs)
+        h1T, cinT, h3T, h4T = acts
+        d5T, d4T, d3T, ddT, d1T = dacts
+        check(L.ns_ngp_mlp_dgrad_n(ptr(self.mlp_half), ptr(self.s_dout), ptr(h1T), ptr(h3T), ptr(h4T), ptr(self.s_dfeat),
+                                   ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT), ptr(d1T), C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
+
+        def wgrad(stream):
+            check(L.ns_ngp_mlp_wgrad_n(ptr(featT), ptr(h1T), ptr(cinT), ptr(h3T), ptr(h4T), ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT),
+                                       ptr(d1T), ptr(self.partial), c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(S), n_dev, stream),
+                  "ngp_mlp_wgrad")
         main = torch.cuda.current_stream()
-        if c.optimize_extrinsics:
-            # pose refinement (input gradient of the encoding: 8 gathers x 16 levels per sample, L2-request bound; per-ray and
-            # per-image reductions) on the side stream, concurrently with the table gradient (record streams + LDS): both
-            # only READ the feature gradient
+        wgrad_side = not os.environ.get("NS_NGP_WGRAD_MAIN")
+        if not wgrad_side:
+            wgrad(st)
+        if c.optimize_extrinsics or wgrad_side:
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 st2 = stream_ptr()
-                check(L.ns_ngp_encode_backward_input_n(*self._grid_args(), ptr(self.s_pos), ptr(self.grid_half), ptr(self.s_dfeat),
-                                                       ptr(self.dpos), C.c_long(S), n_dev, st2), "ngp_encode_backward_input")
-                n_cam = self.cam_grad.shape[0]
-                check(L.ns_ngp_camera_gradient_2stage(ptr(self.dpos), ptr(self.s_t), ptr(self.r_d), ptr(self.ray_start),
-                                                      ptr(self.ray_n), ptr(self.r_img), C.c_float(1.0 / s), ptr(self.cam_grad), Rc, ctl,
-                                                      ptr(self.ray_g) if n_cam <= 4096 else None, n_cam, st2), "ngp_camera_gradient")
+                if wgrad_side:
+                    wgrad(st2)
+                if c.optimize_extrinsics:
+                    # pose refinement (input gradient of the encoding: 8 gathers x 16 levels per sample, L2-request bound;
+                    # per-ray and per-image reductions)
+                    check(L.ns_ngp_encode_backward_input_n(*self._grid_args(), ptr(self.s_pos), ptr(self.grid_half),
+                                                           ptr(self.s_dfeat), ptr(self.dpos), C.c_long(S), n_dev, st2),
+                          "ngp_encode_backward_input")
+                    n_cam = self.cam_grad.shape[0]
+                    check(L.ns_ngp_camera_gradient_2stage(ptr(self.dpos), ptr(self.s_t), ptr(self.r_d), ptr(self.ray_start),
+                                                          ptr(self.ray_n), ptr(self.r_img), C.c_float(1.0 / s), ptr(self.cam_grad), Rc,
+                                                          ctl, ptr(self.ray_g) if n_cam <= 4096 else None, n_cam, st2),
+                          "ngp_camera_gradient")
         check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(self.s_pos), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
                                          ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev, st),
               "ngp_encode_backward")
-        if c.optimize_extrinsics:
+        if c.optimize_extrinsics or wgrad_side:
             main.wait_stream(self._side)
         if self.world > 1:
             self._allreduce_gradients()

@@ -48,7 +48,26 @@ def ut(request):
     os.environ.pop("NS_CONV_UT", None)
 
 
-def test_gru_gate_shapes(dev, ut):
+@pytest.fixture(params=[None, 1, 2])
+def mt(request):
+    """the cout tile: None = the launch heuristic (128-cout tiles unless the launch would have < 200 workgroups), 1 | 2 = forced
+    32- / 64-cout tiles (what a single-edge launch gets)"""
+    if request.param is not None:
+        os.environ["NS_CONV_MT"] = str(request.param)
+    yield request.param
+    os.environ.pop("NS_CONV_MT", None)
+
+
+def test_single_image_launches(dev, mt):
+    # the motion filter's one edge and the encoders' N = 1: small tiles by the heuristic, same arithmetic
+    _case(dev, 1, 60, 80, (128, 128, 128, 64), 256, 3, "sigmoid", per_image_bias=True)
+    _case(dev, 1, 60, 80, (128,), 128, 3, "relu", seed=1)
+    _case(dev, 1, 120, 160, (64,), 64, 3, None, seed=2)
+    _case(dev, 1, 60, 80, (576,), 128, 1, None, seed=3)
+    _case(dev, 1, 60, 80, (128,), 576, 1, None, seed=4)
+
+
+def test_gru_gate_shapes(dev, ut, mt):
     # convz|convr fused: [h, inp, corr, flow] -> 256, sigmoid, per-edge global-context bias (gru.py:28-29)
     _case(dev, 3, 60, 80, (128, 128, 128, 64), 256, 3, "sigmoid", per_image_bias=True)
     # convq: -> 128, tanh
@@ -92,7 +111,7 @@ def test_channel_slices_as_sources(dev):
         conv_nhwc([wide.permute(0, 2, 1, 3)[..., :160]], PackedConv(w, b))      # not channels-last
 
 
-def test_fused_gru_epilogues(dev, ut):
+def test_fused_gru_epilogues(dev, ut, mt):
     """the two ConvGRU steps folded into the epilogue == conv followed by the torch elementwise ops (gru.py:28-33)"""
     from nerfslam.conv import PackedConv, conv_nhwc
     g = torch.Generator().manual_seed(0)
