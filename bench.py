@@ -348,7 +348,9 @@ def bench_c1280(args, dev):
         nets.begin_keyframe(k, img)
         slam.kf_to_frame[k] = f
     fe.cam0_T_world[:NB] = stream.poses[::stride][:NB]
-    fe.cam0_T_world[:NB, :3] += 0.01 * torch.randn((NB, 3), device=dev, generator=g)
+    noise = 0.01 * torch.randn((NB, 3), device=dev, generator=g)
+    noise[0] = 0.0                                            # frame 0 carries the prior: it is the gauge, not an unknown
+    fe.cam0_T_world[:NB, :3] += noise
     fe.cam0_idepths[:NB] = stream.disps[::stride][:NB] * (1.0 + 0.02 * torch.randn((NB, fe.ht, fe.wd), device=dev, generator=g))
     fe.cam0_idepths_sensed[0] = stream.disps[0]              # gauge (as in the c640 stream)
     from nerfslam import se3 as _se3

@@ -332,7 +332,8 @@ static bool level_is_hashed(const GridLayout& g, int l) {
 }
 
 // dense_only: the hashed levels are handled by the binned path below; the dense levels then get more (smaller) parts
-static int enc_bwd_plan_host(const GridLayout& g, int n_levels, EncBwdPlan& p, bool dense_only) {
+static int enc_bwd_plan_host(const GridLayout& g, int n_levels, EncBwdPlan& p, bool dense_only, int parts_coarse = NS_ENC_PARTS_COARSE,
+                             int parts_multi = NS_ENC_PARTS_BINNED) {
   int k = 0, t = 0;
   for (int l = 0; l < 16; l++) p.slices[l] = p.parts[l] = 0;
   for (int pass = dense_only ? 1 : 0; pass < 2; pass++)  // hashed (1 part) levels first, then the dense ones, finest first
@@ -342,7 +343,7 @@ static int enc_bwd_plan_host(const GridLayout& g, int n_levels, EncBwdPlan& p, b
       const bool hashed = level_is_hashed(g, l);
       if (hashed != (pass == 0)) continue;
       p.slices[l] = (int)((hs + NS_ENC_SLICE - 1) / NS_ENC_SLICE);
-      p.parts[l] = hashed ? 1 : (!dense_only ? NS_ENC_PARTS : (p.slices[l] == 1 ? NS_ENC_PARTS_COARSE : NS_ENC_PARTS_BINNED));
+      p.parts[l] = hashed ? 1 : (!dense_only ? NS_ENC_PARTS : (p.slices[l] == 1 ? parts_coarse : parts_multi));
       p.level[k] = l;
       p.first[k] = t;
       t += p.slices[l] * p.parts[l];
@@ -511,6 +512,133 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
         atomicAdd(&gp[1], b);
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense levels, RUN-LENGTH variant (packed fixed point, unit-major gradient): same tasks (level, slice, part) and the same
+// LDS slice as the kernel above, but a LANE owns a run of 8 CONSECUTIVE samples instead of one sample of 64 consecutive ones.
+// Consecutive samples are consecutive steps along one ray: on the coarse levels (cell = 1/16 .. 1/56 of the cube, a step
+// ~1/500) they stay in one cell for many steps, so the lane sums their packed contributions per corner in registers and
+// issues 8 LDS atomics per CELL CHANGE instead of 8 per sample; and the 64 lanes of a wave now sit on 64 different ray
+// segments, so the atomics that remain rarely meet on one address (the kernel above is bound by exactly that: ~1 cycle
+// per (sample, corner) when a wave sits in one level-0 cell).  Integer sums: bit-identical to every other path.
+// A run is 96 B of positions + 2 x 16 B of gradient per lane, loaded as 16-byte vectors one chunk ahead.
+// ---------------------------------------------------------------------------------------------
+#define NS_RL_K 8
+__global__ __launch_bounds__(1024) void ngp_encode_bwd_dense_rl_kernel(GridLayout g, EncBwdPlan plan, const float* __restrict__ pos,
+                                                                       const _Float16* __restrict__ dpu, float* __restrict__ grad,
+                                                                       long N, float fixed_scale,
+                                                                       unsigned long long* __restrict__ partial,
+                                                                       const int* __restrict__ n_dev) {
+  __shared__ unsigned long long tab[NS_ENC_SLICE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = gridDim.x >> 3;
+  const int v = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (v >= plan.first[16]) return;
+  int k = 0;
+  while (v >= plan.first[k + 1]) k++;
+  const int l = plan.level[k];
+  const int local = v - plan.first[k];
+  const int nparts = plan.parts[l];
+  const int slice = local / nparts, part = local - slice * nparts;
+  const uint32_t hs = g.offset[l + 1] - g.offset[l];
+  const uint32_t lo = (uint32_t)slice * NS_ENC_SLICE;
+  const uint32_t cnt = min((uint32_t)NS_ENC_SLICE, hs - lo);
+  const float scale = g.scale[l];
+  const uint32_t res = (uint32_t)g.res[l], r2 = res * res;
+  for (uint32_t e = tid; e < cnt; e += 1024) tab[e] = 0ull;
+  __syncthreads();
+  const long nvalid = n_dev ? min(N, (long)*n_dev) : N;
+  const long chunks = (nvalid + 64 * NS_RL_K - 1) / (64 * NS_RL_K);   // a wave chunk = 64 runs of 8 samples
+  const long c_lo = chunks * part / nparts, c_hi = chunks * (part + 1) / nparts;
+  const _Float16* __restrict__ d0p = dpu + (long)(2 * l) * N;
+  const _Float16* __restrict__ d1p = dpu + (long)(2 * l + 1) * N;
+  // cells whose 8 corners all lie outside [lo, lo + cnt) are skipped before any weight is formed (multi-slice levels: a
+  // slice is a few z layers of the level).  span = offset of the far corner; a wrapped corner (index >= hs) re-enters at 0.
+  const uint32_t span = 1u + res + r2;
+  float4 np[6];
+  uint4 ng0 = make_uint4(0, 0, 0, 0), ng1 = make_uint4(0, 0, 0, 0);
+  auto fetch = [&](long chn) {
+    const long i0 = (chn * 64 + lane) * NS_RL_K;
+    ng0 = ng1 = make_uint4(0, 0, 0, 0);
+    if (chn < c_hi && i0 < nvalid) {                   // (N is a multiple of 8: a run that starts below N ends below N)
+      const float4* __restrict__ pp = reinterpret_cast<const float4*>(pos + i0 * 3);
+#pragma unroll
+      for (int q = 0; q < 6; q++) np[q] = pp[q];
+      ng0 = *reinterpret_cast<const uint4*>(d0p + i0);
+      ng1 = *reinterpret_cast<const uint4*>(d1p + i0);
+    }
+  };
+  fetch(c_lo + wave);
+  for (long ch = c_lo + wave; ch < c_hi; ch += 16) {
+    float pf[24];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      pf[4 * q] = np[q].x; pf[4 * q + 1] = np[q].y; pf[4 * q + 2] = np[q].z; pf[4 * q + 3] = np[q].w;
+    }
+    const uint32_t gw0[4] = {ng0.x, ng0.y, ng0.z, ng0.w}, gw1[4] = {ng1.x, ng1.y, ng1.z, ng1.w};
+    const long i0 = (ch * 64 + lane) * NS_RL_K;
+    fetch(ch + 16);
+    uint32_t cur = 0xffffffffu;          // dense index of the current cell's (0,0,0) corner
+    unsigned long long acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) acc[c] = 0ull;
+    auto flush = [&]() {
+      if (cur == 0xffffffffu) return;
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) {
+        uint32_t idx = cur + (corner & 1) + ((corner >> 1) & 1) * res + (corner >> 2) * r2;
+        idx = idx >= hs ? idx - hs : idx;
+        const uint32_t rel = idx - lo;
+        if (rel < cnt && acc[corner] != 0ull) atomicAdd(&tab[rel], acc[corner]);
+        acc[corner] = 0ull;
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < NS_RL_K; j++) {
+      const uint32_t w0 = gw0[j >> 1], w1 = gw1[j >> 1];
+      const float d0 = (float)__builtin_bit_cast(_Float16, (uint16_t)((j & 1) ? (w0 >> 16) : (w0 & 0xffffu)));
+      const float d1 = (float)__builtin_bit_cast(_Float16, (uint16_t)((j & 1) ? (w1 >> 16) : (w1 & 0xffffu)));
+      if ((d0 == 0.0f && d1 == 0.0f) || i0 + j >= nvalid) continue;
+      float w[3];
+      uint32_t c[3];
+#pragma unroll
+      for (int dd = 0; dd < 3; dd++) {
+        const float p = fmaf(scale, pf[3 * j + dd], 0.5f);
+        const float fl = floorf(p);
+        c[dd] = (uint32_t)(int)fl;
+        w[dd] = p - fl;
+      }
+      const uint32_t base = c[0] + c[1] * res + c[2] * r2;
+      // any corner inside this slice?  (corner indices lie in [base, base + span], wrapped once at hs)
+      const bool touches = (base + span >= lo && base < lo + cnt) || (base + span >= hs && base + span - hs >= lo) ||
+                           (base + span >= hs && lo == 0u);
+      if (!touches) continue;
+      if (base != cur) {
+        flush();
+        cur = base;
+      }
+      const float wx[2] = {1.0f - w[0], w[0]}, wy[2] = {1.0f - w[1], w[1]}, wz[2] = {1.0f - w[2], w[2]};
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) {
+        const float wt = wx[corner & 1] * wy[(corner >> 1) & 1] * wz[corner >> 2];
+        acc[corner] += pack_fixed(wt * d0, wt * d1, fixed_scale);
+      }
+    }
+    flush();
+  }
+  __syncthreads();
+  unsigned long long* __restrict__ g64 = reinterpret_cast<unsigned long long*>(grad) + g.offset[l] + lo;
+  if (partial != nullptr && nparts > 1) {
+    unsigned long long* __restrict__ dst = partial + plan.plane_base[l] + (long)part * hs + lo;
+    for (uint32_t e = tid; e < cnt; e += 1024) dst[e] = tab[e];
+    return;
+  }
+  for (uint32_t e = tid; e < cnt; e += 1024) {
+    const unsigned long long word = tab[e];
+    if (word == 0ull) continue;
+    if (nparts == 1) g64[e] += word; else atomicAdd(&g64[e], word);
   }
 }
 
@@ -1588,7 +1716,22 @@ extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_h
     bin_plan_host(g, n_levels, N, bp);
     const bool binned = workspace != nullptr && fixed_scale > 0.0f && bin_plan_ok(bp) && !no_bins;
     EncBwdPlan plan;
-    const int tasks = enc_bwd_plan_host(g, n_levels, plan, binned);
+    // run-length kernel for the dense levels (NS_ENC_BWD_NO_RL=1: the one-sample-per-lane kernel, A/B runs); fewer, longer
+    // parts: its tasks are bound by the scan of the samples, not by LDS atomics (NS_ENC_RL_PARTS=coarse,multi overrides)
+    static const bool no_rl = getenv("NS_ENC_BWD_NO_RL") != nullptr;
+    static int rl_pc = 24, rl_pm = 12;
+    static const bool rl_env = [] {
+      const char* e = getenv("NS_ENC_RL_PARTS");
+      int a = 0, b = 0;
+      if (e && sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= NS_ENC_PARTS_COARSE && b >= 1 && b <= NS_ENC_PARTS_COARSE) {
+        rl_pc = a;
+        rl_pm = b;
+      }
+      return true;
+    }();
+    (void)rl_env;
+    const bool rl = binned && !no_rl && unit_major && N % 8 == 0 && ((uintptr_t)positions % 16) == 0 && ((uintptr_t)dLdout % 16) == 0;
+    const int tasks = rl ? enc_bwd_plan_host(g, n_levels, plan, true, rl_pc, rl_pm) : enc_bwd_plan_host(g, n_levels, plan, binned);
     const int blocks = (tasks + 7) / 8 * 8;
     if (binned) {
       int* tot = reinterpret_cast<int*>(workspace);
@@ -1612,9 +1755,15 @@ extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_h
       const long nd = dense_prefix_entries(g, n_levels);
       if (nd > 0) {
         unsigned long long* partial = queue + bin_ws_queue_bytes(bp) / 8;
-        hipLaunchKernelGGL(ngp_encode_bwd_lds_kernel<true>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
-                           (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale, partial, n_dev);
-        NS_CHECK_LAUNCH("ngp_encode_bwd_lds_kernel");
+        if (rl) {
+          hipLaunchKernelGGL(ngp_encode_bwd_dense_rl_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
+                             (const _Float16*)dLdout, grad_params, N, fixed_scale, partial, n_dev);
+          NS_CHECK_LAUNCH("ngp_encode_bwd_dense_rl_kernel");
+        } else {
+          hipLaunchKernelGGL(ngp_encode_bwd_lds_kernel<true>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
+                             (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale, partial, n_dev);
+          NS_CHECK_LAUNCH("ngp_encode_bwd_lds_kernel");
+        }
         hipLaunchKernelGGL(ngp_enc_dense_reduce_kernel, dim3(ns_cdiv(nd, 256)), dim3(256), 0, (hipStream_t)stream, g, plan, n_levels,
                            partial, nd, grad_params);
         NS_CHECK_LAUNCH("ngp_enc_dense_reduce_kernel");

@@ -606,6 +606,19 @@ def test_hash_encode_backward_full_budget_properties(oracle_mod, dev):
         check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(dl), um, ptr(gq), ptr(w), C.c_float(S), C.c_long(n_odd), stream_ptr()), "bwd")
         outs.append(gq.cpu().numpy())
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    # ... and for the training step's form: the full-budget buffers with the sample count in device memory (the tail of the
+    # gradient buffer then holds stale values that must not be read: poison it)
+    n_dev = torch.tensor([n_odd], dtype=torch.int32, device=dev)
+    poisoned = dLT.copy()
+    poisoned[:, n_odd:] = np.float16(3.0)
+    d_poison = T(poisoned, dev)
+    outs_n = []
+    for w in (None, ws):
+        gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
+        check(lib().ns_ngp_encode_backward_n(*args, ptr(d_pos), ptr(d_poison), 1, ptr(gq), ptr(w), C.c_float(S), C.c_long(N), ptr(n_dev),
+                                             stream_ptr()), "bwd_n")
+        outs_n.append(gq.cpu().numpy())
+    assert np.array_equal(outs_n[0], outs[0]) and np.array_equal(outs_n[1], outs[0])
     g0, g1 = unpack_fixed(runs[0], S)
     want = dLT.astype(np.float64).reshape(L, 2, N).sum(-1)
     for l in range(L):
