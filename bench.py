@@ -232,22 +232,33 @@ def kernel_rooflines(dev, hp, ngp_net):
     net = ngp_net
     N = net.cfg.max_samples
     g = torch.Generator(device=dev).manual_seed(1)
-    pos = torch.rand((N, 3), device=dev, generator=g).contiguous()
+    # samples in the order the marcher emits them: consecutive steps of one ray are consecutive samples (2048 rays x 128
+    # steps of ~1/600 of the cube); the uniform-random figure (no two consecutive samples share a cell on any level: the
+    # worst case for every cache and for the run-length accumulation of the dense levels) is reported next to it
+    R = 2048
+    o = torch.rand((R, 1, 3), device=dev, generator=g) * 0.4 + 0.3
+    d = torch.nn.functional.normalize(torch.randn((R, 1, 3), device=dev, generator=g), dim=-1)
+    t = (0.02 + 0.0017 * torch.arange(N // R, device=dev))[None, :, None]
+    pos_rays = (o + t * d).clamp(0.0, 1.0).reshape(N, 3).contiguous()
+    pos_unif = torch.rand((N, 3), device=dev, generator=g).contiguous()
     dfeat = (torch.randn((32, N), device=dev, generator=g) * 1e-3).half().contiguous()
 
-    def enc_fwd():
+    def enc_fwd(pos):
         net.encode(pos, net.s_feat)
 
-    def enc_bwd():
+    def enc_bwd(pos):
         check(lib().ns_ngp_encode_backward(*net._grid_args(), ptr(pos), ptr(dfeat), 1, ptr(net.grid_grad), ptr(net.enc_ws),
                                            C.c_float(net.cfg.grad_fixed_scale), C.c_long(N), stream_ptr()), "ngp_encode_backward")
     for k, fn, per in (("ngp_encode_fwd_kernel[2^18]", enc_fwd, 588), ("ngp_encode_bwd[2^18]", enc_bwd, 1100)):
-        us = _train_us(fn)
+        us = _train_us(lambda: fn(pos_rays))
+        us_u = _train_us(lambda: fn(pos_unif))
         out[k] = {"bound": "hbm", "avg_launch_us": us, "algorithmic_bytes_per_launch": per * N, "achieved": per * N / us / 1e3,
                   "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": per * N / us / 1e3 / HBM_PEAK_GBS,
-                  "note": "uniform random positions (worst case for locality)"}
+                  "avg_launch_us_uniform_random_positions": us_u,
+                  "note": "samples ordered along rays as the marcher emits them (2048 rays x 128 steps); uniform random positions "
+                          "(worst case for locality) in avg_launch_us_uniform_random_positions"}
     out["ngp_encode_bwd[2^18]"]["note"] += ("; one call = 7 launches: ngp_zero_ints, ngp_enc_bin_count, ngp_enc_bin_scatter, "
-                                            "ngp_enc_bin_accum (hashed levels), ngp_encode_bwd_lds, ngp_enc_dense_reduce (dense levels)")
+                                            "ngp_enc_bin_accum (hashed levels), ngp_encode_bwd_dense_rl, ngp_enc_dense_reduce (dense levels)")
     net.grid_grad.zero_()
     # Adam over the hash grid: 18 B read (master, gradient word, two moments, ...) + 14 B written per parameter
     c = net.cfg

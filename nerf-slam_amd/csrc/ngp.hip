@@ -1719,7 +1719,7 @@ extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_h
     // run-length kernel for the dense levels (NS_ENC_BWD_NO_RL=1: the one-sample-per-lane kernel, A/B runs); fewer, longer
     // parts: its tasks are bound by the scan of the samples, not by LDS atomics (NS_ENC_RL_PARTS=coarse,multi overrides)
     static const bool no_rl = getenv("NS_ENC_BWD_NO_RL") != nullptr;
-    static int rl_pc = 24, rl_pm = 12;
+    static int rl_pc = 16, rl_pm = 8;
     static const bool rl_env = [] {
       const char* e = getenv("NS_ENC_RL_PARTS");
       int a = 0, b = 0;

@@ -271,6 +271,7 @@ class NgpNerf:
         fx, fy, cx, cy = self.intr
         st, ctl = stream_ptr(), ptr(self.ctl)
         self.ray_n.fill_(-1)
+        self.s_dout.zero_()      # the loss gradient of the step these rays belong to (the previous step is done with it)
         check(L.ns_ngp_sample_rays_ctl(ptr(self.images), ptr(self.depths), ptr(self.depth_covs), ptr(self.c2w), n_cap, H, W,
                                        C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
                                        C.c_float(0.5 - 0.5 * s), C.c_float(0.5 + 0.5 * s), C.c_float(c.near), C.c_uint32(0), Rc,
@@ -293,7 +294,6 @@ class NgpNerf:
         s = float(c.aabb_scale)
         st = stream_ptr()
         ctl = ptr(self.ctl)
-        self.s_dout.zero_()
         self.loss_acc.zero_()
         # sample count of THIS step = end of the marcher's reserved ranges (device memory): the per-sample kernels are launched
         # over the whole budget S (fixed grids, fixed row strides) and skip the tail the marcher did not fill
