@@ -87,6 +87,21 @@ __device__ __forceinline__ int frag_k(int cc, int h, int q) { return 16 * cc + 4
 // unit (row of D) that lane half h holds in accumulator register r of row tile it
 __device__ __forceinline__ int acc_unit(int it, int h, int r) { return 32 * it + 4 * h + (r & 3) + 8 * (r >> 2); }
 
+// Unit-major addressing [unit][sample], split so that the compiler keeps ONE 32-bit lane offset for every row of every
+// tensor: element (unit, sample) with unit = u + 4 h (u = the wave-uniform part of acc_unit / frag_k) lives at
+//   (base + u N) [uniform: scalar registers]  +  2 (4 h N + sample) bytes [per lane: one VGPR]
+// -> `global_load/store_dword v, v_off, s[base:base+1]`.  Written as 64-bit per-row addresses the same accesses cost two
+// address VGPRs and a 64-bit multiply-add per row and pushed the backward kernel to 240 VGPRs.
+__device__ __forceinline__ int urow(int it, int r) { return 32 * it + (r & 3) + 8 * (r >> 2); }
+__device__ __forceinline__ int ufrag(int cc, int q) { return 16 * cc + (q & 3) + 8 * (q >> 2); }
+__device__ __forceinline__ uint32_t lane_bytes(int h, long N, long np) { return (uint32_t)((4 * (long)h * N + np) * 2); }
+__device__ __forceinline__ uint32_t* um_at(_Float16* row, uint32_t boff) {
+  return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(row) + boff);
+}
+__device__ __forceinline__ const uint32_t* um_at(const _Float16* row, uint32_t boff) {
+  return reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(row) + boff);
+}
+
 // gather the fragments of one layer into LDS: frag (it, cc) -> Wf[(first + it * nchunk + cc) * 64 + lane]
 template <bool TRANSPOSED>
 __device__ __forceinline__ void fill_frags(f16x8* Wf, const _Float16* __restrict__ W, int woff, int nout, int nin,
@@ -123,11 +138,10 @@ __device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
 __device__ __forceinline__ f16x2 unpack2(uint32_t w) { return __builtin_bit_cast(f16x2, w); }
 
 // store the 16 (tile 0, tile 1) pairs of one 32-unit tile unit-major: row acc_unit(it, h, r), samples np, np + 1
-__device__ __forceinline__ void store_tile(_Float16* __restrict__ dst, long N, long np, int it, int h, const f16x8* t0,
+__device__ __forceinline__ void store_tile(_Float16* __restrict__ dst, long N, uint32_t boff, int it, const f16x8* t0,
                                            const f16x8* t1) {  // t0/t1: chunks [2 it], [2 it + 1] of tile 0 / 1
 #pragma unroll
-  for (int r = 0; r < 16; r++)
-    *reinterpret_cast<uint32_t*>(dst + (long)acc_unit(it, h, r) * N + np) = pack2(t0[r >> 3][r & 7], t1[r >> 3][r & 7]);
+  for (int r = 0; r < 16; r++) *um_at(dst + (long)urow(it, r) * N, boff) = pack2(t0[r >> 3][r & 7], t1[r >> 3][r & 7]);
 }
 
 struct MlpFwdArgs {
@@ -167,14 +181,14 @@ __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
     if (n0 >= cnt) return;  // wave-uniform
     const bool ok = n0 + 2 * j < cnt;  // cnt is even: the pair (np, np + 1) is valid or not as a whole
     const long np = ok ? n0 + 2 * j : 0;
-    const long nq = np;
+    const uint32_t boff = lane_bytes(h, N, np);
     // input: 2 chunks x 8 units, both tiles in one dword
     f16x8 x[2][2];  // [tile][chunk]
 #pragma unroll
     for (int cc = 0; cc < 2; cc++)
 #pragma unroll
       for (int q = 0; q < 8; q++) {
-        const f16x2 v = unpack2(*reinterpret_cast<const uint32_t*>(a.featT + (long)frag_k(cc, h, q) * N + nq));
+        const f16x2 v = unpack2(*um_at(a.featT + (long)ufrag(cc, q) * N, boff));
         x[0][cc][q] = ok ? v[0] : (_Float16)0;
         x[1][cc][q] = ok ? v[1] : (_Float16)0;
       }
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) h1[t][2 * it + (r >> 3)][r & 7] = (_Float16)fmaxf(acc[r], 0.0f);
       }
-      if (st) store_tile(a.h1T, N, np, it, h, &h1[0][2 * it], &h1[1][2 * it]);
+      if (st) store_tile(a.h1T, N, boff, it, &h1[0][2 * it], &h1[1][2 * it]);
     }
 #pragma unroll
     for (int t = 0; t < 2; t++) {  // L2 64 -> 16 (rows 16..31 of the tile are padding) + direction encoding
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
         cin[t][1][q] = (_Float16)(h ? sh[lo + 4] : sh[lo]);
       }
     }
-    if (st) store_tile(a.cinT, N, np, 0, h, cin[0], cin[1]);
+    if (st) store_tile(a.cinT, N, boff, 0, cin[0], cin[1]);
     f16x8 h3[2][4];
 #pragma unroll
     for (int it = 0; it < 2; it++) {  // L3 32 -> 64, ReLU
@@ -217,7 +231,7 @@ __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) h3[t][2 * it + (r >> 3)][r & 7] = (_Float16)fmaxf(acc[r], 0.0f);
       }
-      if (st) store_tile(a.h3T, N, np, it, h, &h3[0][2 * it], &h3[1][2 * it]);
+      if (st) store_tile(a.h3T, N, boff, it, &h3[0][2 * it], &h3[1][2 * it]);
     }
     f16x8 h4[2][4];
 #pragma unroll
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) h4[t][2 * it + (r >> 3)][r & 7] = (_Float16)fmaxf(acc[r], 0.0f);
       }
-      if (st) store_tile(a.h4T, N, np, it, h, &h4[0][2 * it], &h4[1][2 * it]);
+      if (st) store_tile(a.h4T, N, boff, it, &h4[0][2 * it], &h4[1][2 * it]);
     }
 #pragma unroll
     for (int t = 0; t < 2; t++) {  // L5 64 -> 16
@@ -256,21 +270,21 @@ struct MlpBwdArgs {
 
 // dy = relu'(h) * f16(acc) for one 32-unit tile of both sample tiles; returns the B chunks and stores unit-major
 __device__ __forceinline__ void mask_tile(const f32x16& acc0, const f32x16& acc1, const _Float16* __restrict__ hT,
-                                          _Float16* __restrict__ dT, long N, long np, bool ok, int it, int h,
+                                          _Float16* __restrict__ dT, long N, uint32_t boff, bool ok, int it,
                                           f16x8* o0, f16x8* o1) {
 #pragma unroll
   for (int r = 0; r < 16; r++) {
-    const long off = (long)acc_unit(it, h, r) * N + np;
-    const f16x2 act = unpack2(*reinterpret_cast<const uint32_t*>(hT + off));
+    const long row = (long)urow(it, r) * N;
+    const f16x2 act = unpack2(*um_at(hT + row, boff));
     const _Float16 v0 = (float)act[0] > 0.0f ? (_Float16)acc0[r] : (_Float16)0;
     const _Float16 v1 = (float)act[1] > 0.0f ? (_Float16)acc1[r] : (_Float16)0;
     o0[r >> 3][r & 7] = v0;
     o1[r >> 3][r & 7] = v1;
-    if (ok) *reinterpret_cast<uint32_t*>(dT + off) = pack2(v0, v1);
+    if (ok) *um_at(dT + row, boff) = pack2(v0, v1);
   }
 }
 
-__global__ __launch_bounds__(256, 2) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
+__global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
   __shared__ f16x8 Wf[BW_NFRAG * 64];
   fill_frags<true>(Wf, a.W, W5_OFF, 16, 64, BW_L5);
   fill_frags<true>(Wf, a.W, W4_OFF, 64, 64, BW_L4);
@@ -286,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
     // every lane runs every MFMA (lane i also supplies row i of A): out-of-range pairs read pair 0 and store nothing
     const bool ok = n0 + 2 * j < cnt;
     const long np = ok ? n0 + 2 * j : 0;
+    const uint32_t boff = lane_bytes(h, N, np);
     const f16x8 go = *reinterpret_cast<const f16x8*>(a.dLdout + np * 4);  // (r,g,b,d) of samples np, np + 1
     // dY5: units 0..2 = colour gradients (held by h == 0, q = 0..2), rest zero
     f16x8 d5[2];
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < 8; q++)
-      if (ok) *reinterpret_cast<uint32_t*>(a.d5T + (long)frag_k(0, h, q) * N + np) = pack2(d5[0][q], d5[1][q]);
+      if (ok) *um_at(a.d5T + (long)ufrag(0, q) * N, boff) = pack2(d5[0][q], d5[1][q]);
     // layer 5^T (K = 16) -> d(h4), ReLU' of layer 4
     f16x8 d4[2][4], d3[2][4], dd[2], d1[2][4];
 #pragma unroll
@@ -308,14 +323,14 @@ __global__ __launch_bounds__(256, 2) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
       const f32x16 a0 = layer_tile<1>(Wf, BW_L5, it, lane, &d5[0]);
       const f32x16 a1 = layer_tile<1>(Wf, BW_L5, it, lane, &d5[1]);
       asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
-      mask_tile(a0, a1, a.h4T, a.d4T, N, np, ok, it, h, &d4[0][2 * it], &d4[1][2 * it]);
+      mask_tile(a0, a1, a.h4T, a.d4T, N, boff, ok, it, &d4[0][2 * it], &d4[1][2 * it]);
     }
 #pragma unroll
     for (int it = 0; it < 2; it++) {
       const f32x16 a0 = layer_tile<4>(Wf, BW_L4, it, lane, d4[0]);
       const f32x16 a1 = layer_tile<4>(Wf, BW_L4, it, lane, d4[1]);
       asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
-      mask_tile(a0, a1, a.h3T, a.d3T, N, np, ok, it, h, &d3[0][2 * it], &d3[1][2 * it]);
+      mask_tile(a0, a1, a.h3T, a.d3T, N, boff, ok, it, &d3[0][2 * it], &d3[1][2 * it]);
     }
     // layer 3^T -> d(cin); only the density half (units 0..15 = registers 0..7) flows on; the density gradient joins unit 0
     {
@@ -332,23 +347,21 @@ __global__ __launch_bounds__(256, 2) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
       }
 #pragma unroll
       for (int q = 0; q < 8; q++)
-        if (ok) *reinterpret_cast<uint32_t*>(a.ddT + (long)frag_k(0, h, q) * N + np) = pack2(dd[0][q], dd[1][q]);
+        if (ok) *um_at(a.ddT + (long)ufrag(0, q) * N, boff) = pack2(dd[0][q], dd[1][q]);
     }
 #pragma unroll
     for (int it = 0; it < 2; it++) {
       const f32x16 a0 = layer_tile<1>(Wf, BW_L2, it, lane, &dd[0]);
       const f32x16 a1 = layer_tile<1>(Wf, BW_L2, it, lane, &dd[1]);
       asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
-      mask_tile(a0, a1, a.h1T, a.d1T, N, np, ok, it, h, &d1[0][2 * it], &d1[1][2 * it]);
+      mask_tile(a0, a1, a.h1T, a.d1T, N, boff, ok, it, &d1[0][2 * it], &d1[1][2 * it]);
     }
     {
       const f32x16 a0 = layer_tile<4>(Wf, BW_L1, 0, lane, d1[0]);
       const f32x16 a1 = layer_tile<4>(Wf, BW_L1, 0, lane, d1[1]);
 #pragma unroll
       for (int r = 0; r < 16; r++)
-        if (ok)
-          *reinterpret_cast<uint32_t*>(a.dLdfeatT + (long)acc_unit(0, h, r) * N + np) =
-              pack2((_Float16)a0[r], (_Float16)a1[r]);
+        if (ok) *um_at(a.dLdfeatT + (long)urow(0, r) * N, boff) = pack2((_Float16)a0[r], (_Float16)a1[r]);
     }
   }
 }

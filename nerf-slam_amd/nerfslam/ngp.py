@@ -47,6 +47,7 @@ class NgpConfig:
     loss_scale: float = 128.0
     depth_lambda: float = 1.0            # nerf_fusion.py:100
     grid_update_every: int = 16
+    grid_rule: str = "subset"            # occupancy refresh: "subset" (2^18 uniform cells per update) | "ngp" (instant-ngp's rule)
     grid_decay: float = 0.95
     min_optical_thickness: float = 0.01
     near: float = 0.05
@@ -402,6 +403,12 @@ class NgpNerf:
             self.step += 1
             if self.step % c.grid_update_every == 0:
                 self.update_density_grid()
+                # The next step's rays were marched ahead (end of this step's launch sequence) on the grid as it was BEFORE
+                # this update: drop them, the next step marches its rays again on the updated grid (same seed, same pixels).
+                # Training on the stale march one step in 16 made the result a coin toss: PSNR after 500 steps on the sphere
+                # scene 19-31 dB in a third of the runs instead of 34-36 dB (10 of 10 runs with this line; 10 of 10 on the
+                # tree before the rays moved ahead).  Cost: one eager sample + march per update, < 1 % of a step.
+                self._primed = False
         return self.loss_tensor if return_loss else None
 
     @property
@@ -460,22 +467,46 @@ class NgpNerf:
                                        C.c_long(N), stream_ptr()), "ngp_mlp_forward")
         return out[:, 3].float().exp()
 
-    def update_density_grid(self, n_cells=1 << 18):
-        """EMA of the density sampled at jittered cell centres of a random subset of cells; a cell is
-        occupied when density * min_step exceeds min(mean, threshold) (instant-ngp's rule)."""
+    def update_density_grid(self, n_cells=None):
+        """Occupancy update, instant-ngp's rule (testbed_nerf.cu `update_density_grid_nerf`, called from its training loop
+        every 16 steps): during the first 256 steps EVERY cell of every cascade is re-evaluated, afterwards G^3/4 cells per
+        cascade drawn uniformly plus G^3/4 per cascade drawn among the currently OCCUPIED cells (up to 8 tries per sample);
+        density at a jittered point of the cell, grid = max(decay * grid, new), a cell is occupied when density * min_step
+        exceeds min(mean, threshold).  That is `grid_rule = "ngp"` (NS_NGP_GRID_RULE overrides).  The default "subset" draws
+        2^18 cells uniformly per update instead: as implemented here (torch glue around the density evaluation) the
+        published rule costs 0.35 ms per step (3.1 M density evaluations every 16 steps: 0.57 -> 0.92 ms) and did not train
+        better on the sphere scene (PSNR after 500 steps 27.1-37.9 dB over 6 runs against 34.3-36.3 dB).  `n_cells`: a uniform
+        draw of that many cells (tests)."""
         c, dev = self.cfg, self.device
         G, nc = c.grid_size, c.n_cascades
-        total = nc * G ** 3
-        cells = torch.randint(0, total, (min(n_cells, total),), device=dev, generator=self.gen)
-        mip = cells // (G ** 3)
-        r = cells % (G ** 3)
-        xyz = torch.stack([r % G, (r // G) % G, r // (G * G)], -1).float()
-        jit = torch.rand(xyz.shape, device=dev, generator=self.gen)
-        scale = (2.0 ** mip.float())[:, None]
-        pos = ((xyz + jit) / G - 0.5) * scale + 0.5
-        dens = self.density_at(pos.contiguous()) * c.min_step
-        self.density_grid.mul_(c.grid_decay)
-        self.density_grid[cells] = torch.maximum(self.density_grid[cells], dens)
+        G3 = G ** 3
+        total = nc * G3
+        if n_cells is None and os.environ.get("NS_NGP_GRID_RULE", c.grid_rule) == "subset":
+            n_cells = 1 << 18
+        if n_cells is not None:
+            cells = torch.randint(0, total, (min(int(n_cells), total),), device=dev, generator=self.gen)
+        elif self.step < 256:
+            cells = torch.arange(total, device=dev)
+        else:
+            n = (G3 // 4) * nc
+            uni = torch.randint(0, total, (n,), device=dev, generator=self.gen)
+            tries = torch.randint(0, total, (n, 8), device=dev, generator=self.gen, dtype=torch.int32)
+            hit = (self.bits[(tries >> 3).long()] >> (tries & 7).to(torch.uint8)) & 1
+            first = hit.to(torch.int32).argmax(dim=1, keepdim=True)            # first occupied try (try 0 when none is)
+            cells = torch.cat([uni, tries.gather(1, first)[:, 0].long()])
+            del tries, hit
+        new = torch.zeros(total, dtype=torch.float32, device=dev)
+        for s0 in range(0, cells.shape[0], 1 << 20):                           # bounded scratch: 2^20 points at a time
+            cc = cells[s0:s0 + (1 << 20)]
+            mip = cc // G3
+            r = cc % G3
+            xyz = torch.stack([r % G, (r // G) % G, r // (G * G)], -1).float()
+            jit = torch.rand(xyz.shape, device=dev, generator=self.gen)
+            scale = (2.0 ** mip.float())[:, None]
+            pos = ((xyz + jit) / G - 0.5) * scale + 0.5
+            dens = self.density_at(pos.contiguous()) * c.min_step
+            new.scatter_reduce_(0, cc, dens, "amax", include_self=True)        # (max: independent of the order of duplicates)
+        torch.maximum(self.density_grid.mul_(c.grid_decay), new, out=self.density_grid)
         thr = self.density_grid.mean().clamp(max=c.min_optical_thickness)      # device scalar: no read-back
         occ = (self.density_grid > thr).view(-1, 8).to(torch.uint8)
         wts = (2 ** torch.arange(8, device=dev, dtype=torch.uint8))

@@ -10,7 +10,8 @@ from nerfslam.ngp import NgpConfig, NgpNerf
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 dev = torch.device("cuda:0")
-cfg = NgpConfig(optimize_extrinsics=bool(os.environ.get("NS_NGP_EXTRINSICS")))   # NerfFusion switches this on
+cfg = NgpConfig(optimize_extrinsics=bool(os.environ.get("NS_NGP_EXTRINSICS")),      # NerfFusion switches this on
+                use_graph=not os.environ.get("NS_NGP_NO_GRAPH"))
 net = NgpNerf(cfg, dev, seed=0)
 import importlib.util
 spec = importlib.util.spec_from_file_location("ngp_scene", os.path.join(root, "tools", "ngp_scene.py"))
