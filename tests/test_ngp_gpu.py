@@ -325,6 +325,17 @@ def test_training_converges_on_a_synthetic_scene(dev):
     assert np.mean(losses[-10:]) < 0.5 * np.mean(losses[:5]), (losses[:5], losses[-10:])
     rgb, dep = net.render(torch.tensor(np.array(poses[0])), H, W)
     assert torch.isfinite(rgb).all() and rgb.shape == (H, W, 3)
+    # the rays of a step are marched at the end of the previous one; an occupancy update in between invalidates them: the
+    # step after an update must march on the UPDATED grid (training on the stale march made the result a coin toss)
+    while net.step % cfg.grid_update_every != cfg.grid_update_every - 1:
+        net.train_step(return_loss=False)
+    assert net._primed
+    net.train_step(return_loss=False)                       # this step ends with the occupancy update
+    assert net.step % cfg.grid_update_every == 0 and not net._primed
+    net.bits.zero_()                                        # an (artificial) update that empties the grid ...
+    net.train_step(return_loss=False)
+    torch.cuda.synchronize()
+    assert net.last_samples == 0 and net._primed            # ... is what the next step marches on: no samples at all
 
 
 def test_pyngp_surface_as_nerf_fusion_drives_it(dev):
