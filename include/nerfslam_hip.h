@@ -101,6 +101,14 @@ int ns_corr_volume_pyramid(const void* fmap1, const void* fmap2, const int64_t* 
 int ns_altcorr_forward(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B,
                        int H1, int W1, int H2, int W2, int C, int N, int radius, void* stream);
 
+/* altcorr_backward (src/droid.cpp:315-327 -> altcorr_kernel.cu:150-355): fmap1_grad [B,H1,W1,C] (fully written) and
+ * fmap2_grad [B,H2,W2,C] (ACCUMULATED into: zero it first, as the reference's torch::zeros does) for corr_grad
+ * [B,N,49,H1,W1]; the reference's third output, coords_grad, is all zeros (:340, never written).  Radius 3 only
+ * (NS_ENOSUP otherwise), C <= 512.  Dead in the reference's live path; float atomics on fmap2_grad like the reference. */
+int ns_altcorr_backward(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
+                        float* fmap1_grad, float* fmap2_grad, int B, int H1, int W1, int H2, int W2, int C, int N,
+                        int radius, void* stream);
+
 /* Fused AltCorrBlock.__call__ (networks/modules/corr.py:107-126): every pyramid level in one launch.
  *   fmaps_host[l] -> [nframes, H1>>l, W1>>l, C] f32 channels-last (features already divided by 4 and
  *   average-pooled as corr.py:98-105 does), ii,jj [E] i64 frame ids, coords [E,H1,W1,2] f32 (divided

@@ -328,3 +328,88 @@ extern "C" int ns_altcorr_forward(const float* fmap1, const float* fmap2, const 
   NS_CHECK_LAUNCH("altcorr_forward_kernel");
   return NS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// altcorr_backward (src/droid.cpp:315-327 -> altcorr_kernel.cu:150-288): gradients of the on-the-fly correlation with
+// respect to both feature maps.  Dead in the reference's live path (inference only, examples/slam_demo.py:198) -- kept so
+// that every op of the module answers.  One wave per source pixel (b, h1, w1), lanes over channels: per coordinate set the
+// 49 output gradients are folded back onto the 8x8 raw taps with the transposed bilinear weights (:232-248),
+//   fmap1_grad[b,h1,w1,:]  += G(tap) * fmap2[b, tap, :]      (one writer: plain store at the end)
+//   fmap2_grad[b, tap, :]  += G(tap) * fmap1[b,h1,w1,:]      (float atomics, like the reference's :266-267)
+// ---------------------------------------------------------------------------------------------
+#define ALTB_MAXC 8   // channels per lane: C <= 512
+
+__global__ __launch_bounds__(256) void altcorr_backward_kernel(const float* __restrict__ fmap1, const float* __restrict__ fmap2,
+                                                               const float* __restrict__ coords,
+                                                               const float* __restrict__ corr_grad,
+                                                               float* __restrict__ fmap1_grad, float* __restrict__ fmap2_grad,
+                                                               int B, int H1, int W1, int H2, int W2, int C, int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long HW1 = (long)H1 * W1;
+  const long task = (long)blockIdx.x * 4 + wave;     // (b, pixel)
+  if (task >= (long)B * HW1) return;                 // wave-uniform
+  const int b = (int)(task / HW1);
+  const long pix = task - (long)b * HW1;
+  const float* __restrict__ f1 = fmap1 + task * C;
+  float a[ALTB_MAXC], ga[ALTB_MAXC];
+#pragma unroll
+  for (int k = 0; k < ALTB_MAXC; k++) {
+    const int c = lane + 64 * k;
+    a[k] = c < C ? f1[c] : 0.0f;
+    ga[k] = 0.0f;
+  }
+  for (int n = 0; n < N; n++) {
+    const float2 xy = *reinterpret_cast<const float2*>(coords + (((long)b * N + n) * HW1 + pix) * 2);
+    if (!(fabsf(xy.x) < 1.0e6f) || !(fabsf(xy.y) < 1.0e6f)) continue;   // the forward pass writes zeros there
+    const float fx0 = floorf(xy.x), fy0 = floorf(xy.y);
+    const float dx = xy.x - fx0, dy = xy.y - fy0;
+    const int xb = (int)fx0 - 3, yb = (int)fy0 - 3;
+    // channel iy + 7 ix of the output gradient on lane iy + 7 ix
+    const float gl = lane < 49 ? corr_grad[(((long)b * N + n) * 49 + lane) * HW1 + pix] : 0.0f;
+    for (int iy = 0; iy < 8; iy++) {
+      for (int ix = 0; ix < 8; ix++) {
+        float G = 0.0f;   // (altcorr_kernel.cu:237-248: nw, ne, sw, se of the raw tap)
+        const float g_nw = __shfl(gl, max((iy - 1) + 7 * (ix - 1), 0), 64), g_ne = __shfl(gl, max((iy - 1) + 7 * min(ix, 6), 0), 64);
+        const float g_sw = __shfl(gl, max(min(iy, 6) + 7 * (ix - 1), 0), 64), g_se = __shfl(gl, min(iy, 6) + 7 * min(ix, 6), 64);
+        if (iy > 0 && ix > 0) G += g_nw * dy * dx;
+        if (iy > 0 && ix < 7) G += g_ne * dy * (1.0f - dx);
+        if (iy < 7 && ix > 0) G += g_sw * (1.0f - dy) * dx;
+        if (iy < 7 && ix < 7) G += g_se * (1.0f - dy) * (1.0f - dx);
+        const int h2 = yb + iy, w2 = xb + ix;
+        if (h2 < 0 || h2 >= H2 || w2 < 0 || w2 >= W2 || G == 0.0f) continue;   // wave-uniform
+        const long o2 = (((long)b * H2 + h2) * W2 + w2) * C;
+#pragma unroll
+        for (int k = 0; k < ALTB_MAXC; k++) {
+          const int c = lane + 64 * k;
+          if (c < C) {
+            ga[k] = fmaf(G, fmap2[o2 + c], ga[k]);
+            atomicAdd(&fmap2_grad[o2 + c], G * a[k]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ALTB_MAXC; k++) {
+    const int c = lane + 64 * k;
+    if (c < C) fmap1_grad[task * C + c] = ga[k];
+  }
+}
+
+extern "C" int ns_altcorr_backward(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
+                                   float* fmap1_grad, float* fmap2_grad, int B, int H1, int W1, int H2, int W2, int C, int N,
+                                   int radius, void* stream) {
+  NS_REQUIRE(fmap1 && fmap2 && coords && corr_grad && fmap1_grad && fmap2_grad, "ns_altcorr_backward: null pointer");
+  NS_REQUIRE(B >= 0 && N >= 0 && H1 > 0 && W1 > 0 && H2 > 0 && W2 > 0 && C > 0 && C <= 64 * ALTB_MAXC,
+             "ns_altcorr_backward: bad shape (C = %d, at most %d channels)", C, 64 * ALTB_MAXC);
+  if (radius != 3) {
+    ns_set_error("ns_altcorr_backward: only radius 3 is built (the reference never uses another, corr.py:93)");
+    return NS_ENOSUP;
+  }
+  const long tasks = (long)B * H1 * W1;
+  if (tasks == 0) return NS_OK;
+  hipLaunchKernelGGL(altcorr_backward_kernel, dim3(ns_cdiv(tasks, 4)), dim3(256), 0, (hipStream_t)stream, fmap1, fmap2, coords,
+                     corr_grad, fmap1_grad, fmap2_grad, B, H1, W1, H2, W2, C, N);
+  NS_CHECK_LAUNCH("altcorr_backward_kernel");
+  return NS_OK;
+}

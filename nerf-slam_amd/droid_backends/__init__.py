@@ -74,10 +74,22 @@ def altcorr_forward(fmap1, fmap2, coords, radius):
 
 
 def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
-    """src/droid.cpp:315-327.  Dead in the reference's live path (grad is disabled globally,
-    examples/slam_demo.py:198); kept for API parity."""
-    raise NotImplementedError("altcorr_backward: training-only op, unused by NeRF-SLAM inference "
-                              "(examples/slam_demo.py:198 disables grad)")
+    """src/droid.cpp:315-327 -> [fmap1_grad, fmap2_grad, coords_grad] (the last one all zeros, as in the reference:
+    altcorr_kernel.cu:340 allocates it and no kernel writes it).  Dead in the reference's live path (grad is disabled
+    globally, examples/slam_demo.py:198); answered for API parity."""
+    check_contiguous(fmap1=fmap1, fmap2=fmap2, coords=coords, corr_grad=corr_grad)
+    require_cuda(fmap1, fmap2, coords, corr_grad)
+    B, H1, W1, Cc = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    N = coords.shape[1]
+    out_dtype = fmap1.dtype
+    g1 = torch.empty((B, H1, W1, Cc), dtype=torch.float32, device=fmap1.device)
+    g2 = torch.zeros((B, H2, W2, Cc), dtype=torch.float32, device=fmap1.device)
+    with torch.cuda.device(fmap1.device):
+        check(lib().ns_altcorr_backward(ptr(fmap1.float().contiguous()), ptr(fmap2.float().contiguous()),
+                                        ptr(coords.float().contiguous()), ptr(corr_grad.float().contiguous()), ptr(g1), ptr(g2),
+                                        B, H1, W1, H2, W2, Cc, N, int(radius), stream_ptr()), "altcorr_backward")
+    return [g1.to(out_dtype), g2.to(out_dtype), torch.zeros_like(coords)]
 
 
 # ------------------------------------------------------------------------------------------------

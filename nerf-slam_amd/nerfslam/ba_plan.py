@@ -198,12 +198,32 @@ def ba_reference_loop(plan, poses, disps, intrinsics, extrinsics, disps_sens, ta
     HW = ht * wd
     dx = dz = None
     for _ in range(iterations):
-        before = disps.clone()
+        before = None if motion_only else disps.clone()
+        if motion_only:
+            # poses only (droid_kernels.cu:1505-1522): the pose x pose block A of K1's per-edge blocks -- no depth terms, no
+            # Schur complement -- solved with the same damping; the disparities stay.  A dead branch of a dead op: assembled
+            # with torch index_put, solved by the device Cholesky (which reads the upper triangle: A^T hands it the LOWER
+            # triangle of A, the one Eigen's SimplicialLLT reads, :1323-1329).
+            o = projective_transform(targets, weights, poses, disps, intrinsics, extrinsics, ii, jj)
+            P, kf0 = plan.kf1 - plan.kf0, plan.kf0
+            ri = torch.cat([ii, ii, jj, jj]) - kf0
+            ci = torch.cat([ii, jj, ii, jj]) - kf0
+            ok = (ri >= 0) & (ci >= 0) & (ri < P) & (ci < P)              # SparseBlock::update_lhs drops fixed poses (:1270)
+            A = torch.zeros((P, P, 6, 6), dtype=torch.float64, device=poses.device)
+            A.index_put_((ri[ok], ci[ok]), o["Hs"].reshape(-1, 6, 6)[ok].double(), accumulate=True)
+            A = A.permute(0, 2, 1, 3).reshape(6 * P, 6 * P)
+            bi = torch.cat([ii, jj]) - kf0
+            okb = (bi >= 0) & (bi < P)
+            b = torch.zeros((P, 6), dtype=torch.float64, device=poses.device)
+            b.index_put_((bi[okb],), o["vs"].reshape(-1, 6)[okb].double(), accumulate=True)
+            sol = ba_solve(A.t().float().contiguous(), b.reshape(-1).float().contiguous(), plan.kf0, plan.kf1, ep=ep, lm=lm,
+                           retract=False)
+            dx = sol["dx"]
+            with torch.cuda.device(poses.device):
+                check(lib().ns_pose_retr(ptr(poses), ptr(dx), plan.kf0, plan.kf1, stream_ptr()), "pose_retr")
+            continue
         H, v, Q, E, w = reduced_camera_matrix(plan, poses, disps, intrinsics, extrinsics, disps_sens, targets, weights,
                                               eta, ii, jj)
-        if motion_only:
-            raise NotImplementedError("ba(motion_only=True): the reference solves the un-reduced pose block here; "
-                                      "unused by NeRF-SLAM")
         # SparseBlock::solve adds the damping to A-S, get_dense() transposes: H is symmetric
         sol = ba_solve(H, v, plan.kf0, plan.kf1, ep=ep, lm=lm, retract=False)
         dx = sol["dx"]

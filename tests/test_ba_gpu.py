@@ -203,3 +203,46 @@ def test_dead_ops_api_parity(oracle_mod, dev):
     pp = poses.clone()
     assert droid_backends.solve_poses(pp, T(dx, dev), 1, 4) is None
     close(pp, oracle_mod.pose_retr(p["poses"], dx, 1, 4), 1e-6, "pose_retr")
+
+
+@pytest.mark.parametrize("motion_only", [False, True])
+def test_dead_ba_op_both_modes(oracle_mod, dev, motion_only):
+    """droid_backends.ba (src/droid.cpp:133-165 -> ba_cuda, droid_kernels.cu:1441-1568; dead in NeRF-SLAM's live path): one
+    iteration against the oracle's pieces put together the way ba_cuda does -- reduced camera matrix (or, motion_only, the
+    plain pose block of K1's per-edge blocks), (ep + lm diag) damping, float64 solve, Exp(dx) * T retraction, depth update."""
+    import droid_backends
+    p = synth.make_problem(ht=12, wd=16, P=5, M=24, seed=8)
+    lm, ep = 1e-4, 0.1
+    kf0, kf1 = int(p["kf0"]), int(p["kf1"])
+    P = kf1 - kf0
+    t = {k: T(p[k], dev) for k in ("poses", "disps", "intr", "extr", "disps_sens", "targets", "weights", "eta", "ii", "jj")}
+    poses, disps = t["poses"].clone(), t["disps"].clone()
+    dx, dz = droid_backends.ba(poses, poses.clone(), disps, t["intr"], t["extr"], t["disps_sens"], t["targets"], t["weights"],
+                               t["eta"], t["ii"], t["jj"], kf0, kf1, 1, lm, ep, motion_only)
+    if motion_only:
+        o = oracle_mod.projective_transform(p["targets"], p["weights"], p["poses"], p["disps"], p["intr"], p["extr"], p["ii"], p["jj"])
+        A, b = np.zeros((6 * P, 6 * P)), np.zeros(6 * P)
+        ri = np.concatenate([p["ii"], p["ii"], p["jj"], p["jj"]]) - kf0
+        ci = np.concatenate([p["ii"], p["jj"], p["ii"], p["jj"]]) - kf0
+        for blk, (r, c) in zip(o["Hs"].reshape(-1, 6, 6).astype(np.float64), zip(ri, ci)):
+            if 0 <= r < P and 0 <= c < P:
+                A[6 * r:6 * r + 6, 6 * c:6 * c + 6] += blk
+        for vec, r in zip(o["vs"].reshape(-1, 6).astype(np.float64), np.concatenate([p["ii"], p["jj"]]) - kf0):
+            if 0 <= r < P:
+                b[6 * r:6 * r + 6] += vec
+        A = np.tril(A) + np.tril(A, -1).T                                    # SimplicialLLT reads the lower triangle
+        new_disps = p["disps"]
+        assert dz is None
+    else:
+        H, v, Q, E, w, kx = oracle_mod.reduced_camera_matrix(p["poses"], p["disps"], p["intr"], p["extr"], p["disps_sens"],
+                                                            p["targets"], p["weights"], p["eta"], p["ii"], p["jj"], kf0, kf1)
+        A, b = H.astype(np.float64), v.astype(np.float64).reshape(-1)
+        A = np.triu(A) + np.triu(A, 1).T
+    A = A + np.diag(ep + lm * np.diag(A))
+    rdx = np.linalg.solve(A, b).reshape(P, 6).astype(np.float32)
+    close(dx, rdx, 2e-3, "dx")
+    close(poses, oracle_mod.pose_retr(p["poses"], rdx, kf0, kf1), 1e-4, "retracted poses")
+    if not motion_only:
+        new_disps = oracle_mod.solve_depth(rdx, p["disps"], Q, E, w, p["ii"], p["jj"], kf0, kf1)
+        assert dz is not None and dz.shape[0] == kx.shape[0]
+    close(disps, new_disps, 2e-3, "disparities")

@@ -192,6 +192,45 @@ def test_altcorr_block_smooth_flow_and_tiles_that_leave_the_image(oracle_mod, de
         lv = torch.nn.functional.avg_pool2d(lv, 2, stride=2)
 
 
+def test_altcorr_backward_against_autograd(dev):
+    """droid_backends.altcorr_backward (dead in the reference's inference path, src/droid.cpp:315-327) against torch autograd
+    through a float64 restatement of the forward pass (raw 8x8 taps, bilinear blend, channel = iy + 7 ix)."""
+    import droid_backends
+    g = torch.Generator().manual_seed(3)
+    B, N, H1, W1, H2, W2, Cc = 2, 2, 7, 9, 6, 8, 72
+    f1 = torch.randn((B, H1, W1, Cc), generator=g, dtype=torch.float64, requires_grad=True)
+    f2 = torch.randn((B, H2, W2, Cc), generator=g, dtype=torch.float64, requires_grad=True)
+    gy, gx = torch.meshgrid(torch.arange(H1), torch.arange(W1), indexing="ij")
+    coords = torch.stack([gx, gy], -1)[None, None].double() * (W2 / W1) + (torch.rand((B, N, H1, W1, 2), generator=g, dtype=torch.float64) * 8 - 4)
+    coords = coords.float().double()
+    up = torch.randn((B, N, 49, H1, W1), generator=g, dtype=torch.float64).float().double()
+    x0, y0 = coords[..., 0].floor(), coords[..., 1].floor()
+    dx, dy = coords[..., 0] - x0, coords[..., 1] - y0
+    f2p = torch.nn.functional.pad(f2, (0, 0, 12, 12, 12, 12))                   # zero border: out-of-bounds taps contribute 0
+    bidx = torch.arange(B)[:, None, None, None].expand(B, N, H1, W1)
+    raw = {}
+    for ty in range(8):
+        for tx in range(8):
+            hy = (y0 - 3 + ty).long().clamp(-12, H2 + 11) + 12
+            hx = (x0 - 3 + tx).long().clamp(-12, W2 + 11) + 12
+            raw[ty, tx] = (f1[:, None] * f2p[bidx, hy, hx]).sum(-1)             # [B,N,H1,W1]
+    out = torch.zeros((B, N, 49, H1, W1), dtype=torch.float64)
+    chans = []
+    for ix in range(7):
+        for iy in range(7):
+            chans.append(raw[iy, ix] * (1 - dy) * (1 - dx) + raw[iy, ix + 1] * (1 - dy) * dx + raw[iy + 1, ix] * dy * (1 - dx)
+                         + raw[iy + 1, ix + 1] * dy * dx)                       # channel iy + 7 ix
+    out = torch.stack(chans, 2)
+    fwd, = droid_backends.altcorr_forward(f1.detach().float().to(dev), f2.detach().float().to(dev), coords.float().to(dev), 3)
+    assert (fwd.cpu().double() - out.detach()).abs().max() <= 1e-5 * out.detach().abs().max()      # the restatement is the op
+    (out * up).sum().backward()
+    g1, g2, gc = droid_backends.altcorr_backward(f1.detach().float().to(dev), f2.detach().float().to(dev), coords.float().to(dev),
+                                                 up.float().to(dev), 3)
+    assert g1.shape == f1.shape and g2.shape == f2.shape and gc.shape == coords.shape and not gc.any()
+    assert (g1.cpu().double() - f1.grad).abs().max() <= 2e-5 * f1.grad.abs().max()
+    assert (g2.cpu().double() - f2.grad).abs().max() <= 2e-5 * f2.grad.abs().max()
+
+
 @pytest.mark.parametrize("shape", [(16, 24), (43, 77), (60, 80)])
 def test_tiled_layout_same_volume_and_same_lookup_bits(dev, shape):
     """the private 8x8-tiled slice layout (levels 0 / 1): the volume values are those of the row-major build, and the
