@@ -503,6 +503,18 @@ int ns_ngp_mlp_wgrad_n(const void* featT, const void* h1T, const void* cinT, con
                        const void* d4T, const void* d3T, const void* ddT, const void* d1T, float* partial_ws, int ksplit,
                        float* grad_weights, long N, const int* n_dev, void* stream);
 
+/* Occupancy-grid refresh (instant-ngp's update_density_grid, subset form; nerfslam/ngp.py:update_density_grid):
+ *   ns_ngp_grid_cells   draws n cells uniformly over all cascades (PCG hash of seed + index; cell = (mip G + z) G^2 + y G + x)
+ *                       and a jittered point in each, written in the unit cube of the render box [box_lo, box_hi]^3:
+ *                       cells int32 [n], pos_unit f32 [n,3] -- the caller runs ns_ngp_encode_forward + ns_ngp_mlp_forward on them;
+ *   ns_ngp_grid_update  net_out f16 [n,4] (log-density in column 3): grid *= decay; grid[cell] = max(grid[cell],
+ *                       exp(log-density) * min_step); occupied = grid > min(mean(grid), max_threshold); bits[j] bit i = cell 8j+i.
+ *                       partial_ws: 256 doubles.  Order-independent (integer atomicMax on the float bits, fixed-order mean).  */
+int ns_ngp_grid_cells(int grid_size, int n_cascades, unsigned seed, int n, float box_lo, float box_hi, int* cells, float* pos_unit,
+                      void* stream);
+int ns_ngp_grid_update(const void* net_out, const int* cells, int n, float min_step, float decay, float max_threshold,
+                       float* density_grid, long n_cells_total, double* partial_ws, unsigned char* bits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2015,3 +2015,120 @@ extern "C" int ns_ngp_step_advance(int* ctl, int* counter, int* last, float fill
   const int rc = ns_ngp_step_rays(ctl, counter, last, fill, max_samples, min_rays, max_rays, stream);
   return rc != NS_OK ? rc : ns_ngp_step_count(ctl, beta1, beta2, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Occupancy-grid refresh (instant-ngp `update_density_grid_nerf`, the subset form of nerfslam/ngp.py): what used to be
+// ~35 torch launches per update (randint / rand / stack / index_put / mean / compare / pack ...: 0.26 ms of GPU time and as
+// much host time on the mapper thread, once per 16 optimiser steps) as five kernels around the encode + density network:
+//   ngp_grid_cells     n cells drawn uniformly over all cascades (PCG hash of seed + index), a jittered point in each, in the
+//                      unit cube of the render box;
+//   (ns_ngp_encode_forward + ns_ngp_mlp_forward on those points)
+//   ngp_grid_decay     grid *= decay  (every cell)
+//   ngp_grid_max       grid[cell] = max(grid[cell], exp(log-density) * min_step): integer atomicMax on the float bits
+//                      (both sides >= 0), order independent -> replicas stay in lockstep;
+//   ngp_grid_sum / ngp_grid_bits   mean of the grid (two-stage, fixed order), occupied = grid > min(mean, threshold),
+//                      8 cells per output byte (bit i of byte j = cell 8 j + i, the marcher's layout).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ngp_grid_cells_kernel(int G, int ncasc, uint32_t seed, int n, float box_lo, float inv_box,
+                                                             int* __restrict__ cells, float* __restrict__ pos_unit) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t G3 = (uint32_t)G * G * G, total = G3 * (uint32_t)ncasc;
+  const uint32_t base = seed + 4u * (uint32_t)i;
+  const uint32_t cell = ns_pcg(base) % total;
+  const uint32_t mip = cell / G3, r = cell - mip * G3;
+  const uint32_t x = r % (uint32_t)G, y = (r / (uint32_t)G) % (uint32_t)G, z = r / ((uint32_t)G * G);
+  const float scale = (float)(1u << mip), inv_g = 1.0f / (float)G;
+  const float j0 = (float)(ns_pcg(base + 1u) >> 8) * (1.0f / 16777216.0f), j1 = (float)(ns_pcg(base + 2u) >> 8) * (1.0f / 16777216.0f),
+              j2 = (float)(ns_pcg(base + 3u) >> 8) * (1.0f / 16777216.0f);
+  const float sx = (((float)x + j0) * inv_g - 0.5f) * scale + 0.5f, sy = (((float)y + j1) * inv_g - 0.5f) * scale + 0.5f,
+              sz = (((float)z + j2) * inv_g - 0.5f) * scale + 0.5f;
+  cells[i] = (int)cell;
+  pos_unit[3 * (long)i] = (sx - box_lo) * inv_box;
+  pos_unit[3 * (long)i + 1] = (sy - box_lo) * inv_box;
+  pos_unit[3 * (long)i + 2] = (sz - box_lo) * inv_box;
+}
+
+__global__ __launch_bounds__(256) void ngp_grid_decay_kernel(float* __restrict__ grid, long n4, float decay) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = reinterpret_cast<float4*>(grid)[i];
+  v.x *= decay; v.y *= decay; v.z *= decay; v.w *= decay;
+  reinterpret_cast<float4*>(grid)[i] = v;
+}
+
+__global__ __launch_bounds__(256) void ngp_grid_max_kernel(const _Float16* __restrict__ net_out, const int* __restrict__ cells, int n,
+                                                           float min_step, float* __restrict__ grid) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float dens = __expf((float)net_out[4 * (long)i + 3]) * min_step;
+  if (dens == dens) atomicMax(reinterpret_cast<int*>(grid) + cells[i], __float_as_int(fmaxf(dens, 0.0f)));
+}
+
+#define NS_GRID_PARTS 256
+__global__ __launch_bounds__(256) void ngp_grid_sum_kernel(const float* __restrict__ grid, long n, double* __restrict__ partial) {
+  __shared__ double red[256];
+  const long per = (n + NS_GRID_PARTS - 1) / NS_GRID_PARTS;
+  const long lo = (long)blockIdx.x * per, hi = min(n, lo + per);
+  double s = 0.0;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) s += (double)grid[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void ngp_grid_bits_kernel(const float* __restrict__ grid, long n, const double* __restrict__ partial,
+                                                            float max_thr, uint8_t* __restrict__ bits) {
+  __shared__ double red[256];
+  red[threadIdx.x] = partial[threadIdx.x];     // NS_GRID_PARTS == blockDim.x
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  const float thr = fminf((float)(red[0] / (double)n), max_thr);
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;       // output byte
+  if (j * 8 >= n) return;
+  const float4 a = reinterpret_cast<const float4*>(grid)[2 * j], b = reinterpret_cast<const float4*>(grid)[2 * j + 1];
+  const uint32_t byte = (a.x > thr ? 1u : 0u) | (a.y > thr ? 2u : 0u) | (a.z > thr ? 4u : 0u) | (a.w > thr ? 8u : 0u) |
+                        (b.x > thr ? 16u : 0u) | (b.y > thr ? 32u : 0u) | (b.z > thr ? 64u : 0u) | (b.w > thr ? 128u : 0u);
+  bits[j] = (uint8_t)byte;
+}
+
+extern "C" int ns_ngp_grid_cells(int grid_size, int n_cascades, unsigned seed, int n, float box_lo, float box_hi, int* cells,
+                                 float* pos_unit, void* stream) {
+  NS_REQUIRE(cells && pos_unit, "ns_ngp_grid_cells: null pointer");
+  NS_REQUIRE(grid_size > 0 && grid_size <= 512 && n_cascades >= 1 && n_cascades <= 8 && box_hi > box_lo && n >= 0,
+             "ns_ngp_grid_cells: bad grid / box");
+  if (n == 0) return NS_OK;
+  hipLaunchKernelGGL(ngp_grid_cells_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, grid_size, n_cascades,
+                     (uint32_t)seed, n, box_lo, 1.0f / (box_hi - box_lo), cells, pos_unit);
+  NS_CHECK_LAUNCH("ngp_grid_cells_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_ngp_grid_update(const void* net_out, const int* cells, int n, float min_step, float decay, float max_threshold,
+                                  float* density_grid, long n_cells_total, double* partial_ws, unsigned char* bits, void* stream) {
+  NS_REQUIRE(net_out && cells && density_grid && partial_ws && bits, "ns_ngp_grid_update: null pointer");
+  NS_REQUIRE(n >= 0 && n_cells_total > 0 && n_cells_total % 8 == 0 && ((uintptr_t)density_grid % 16) == 0,
+             "ns_ngp_grid_update: the grid must hold a multiple of 8 cells and be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ngp_grid_decay_kernel, dim3(ns_cdiv(n_cells_total / 4, 256)), dim3(256), 0, st, density_grid,
+                     n_cells_total / 4, decay);
+  NS_CHECK_LAUNCH("ngp_grid_decay_kernel");
+  if (n > 0) {
+    hipLaunchKernelGGL(ngp_grid_max_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, st, (const _Float16*)net_out, cells, n, min_step,
+                       density_grid);
+    NS_CHECK_LAUNCH("ngp_grid_max_kernel");
+  }
+  hipLaunchKernelGGL(ngp_grid_sum_kernel, dim3(NS_GRID_PARTS), dim3(256), 0, st, density_grid, n_cells_total, partial_ws);
+  NS_CHECK_LAUNCH("ngp_grid_sum_kernel");
+  hipLaunchKernelGGL(ngp_grid_bits_kernel, dim3(ns_cdiv(n_cells_total / 8, 256)), dim3(256), 0, st, density_grid, n_cells_total,
+                     partial_ws, max_threshold, bits);
+  NS_CHECK_LAUNCH("ngp_grid_bits_kernel");
+  return NS_OK;
+}

@@ -133,6 +133,7 @@ class NgpNerf:
         self._static = False
         self.gen = torch.Generator(device=dev).manual_seed(base_seed)
         self.seed = int(seed)
+        self.base_seed = base_seed
         # training views
         self.images = self.depths = self.depth_covs = self.c2w = None
         self.intr = None
@@ -476,13 +477,38 @@ class NgpNerf:
         2^18 cells uniformly per update instead: as implemented here (torch glue around the density evaluation) the
         published rule costs 0.35 ms per step (3.1 M density evaluations every 16 steps: 0.57 -> 0.92 ms) and did not train
         better on the sphere scene (PSNR after 500 steps 27.1-37.9 dB over 6 runs against 34.3-36.3 dB).  `n_cells`: a uniform
-        draw of that many cells (tests)."""
+        draw of that many cells (tests).  The subset rule runs on the HIP kernels of csrc/ngp.hip ("occupancy-grid refresh":
+        cells + jittered points, encode + density network, decay / max / mean / bit packing: 7 launches instead of ~35 torch
+        ones; NS_NGP_GRID_TORCH=1 keeps the torch form for A/B runs)."""
         c, dev = self.cfg, self.device
         G, nc = c.grid_size, c.n_cascades
         G3 = G ** 3
         total = nc * G3
         if n_cells is None and os.environ.get("NS_NGP_GRID_RULE", c.grid_rule) == "subset":
             n_cells = 1 << 18
+        if n_cells is not None and not os.environ.get("NS_NGP_GRID_TORCH"):
+            # the subset rule on the HIP kernels (csrc/ngp.hip, "occupancy-grid refresh"): 7 launches, no allocation
+            n = min(int(n_cells), total) & ~1
+            ws = getattr(self, "_grid_ws", None)
+            if ws is None or ws[0].shape[0] != n:
+                ws = self._grid_ws = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty((n, 3), dtype=torch.float32, device=dev),
+                                      torch.zeros((32, n), dtype=torch.float16, device=dev), torch.zeros((n, 4), dtype=torch.float16, device=dev),
+                                      torch.zeros((n, 3), dtype=torch.float32, device=dev), torch.zeros(256, dtype=torch.float64, device=dev))
+            cells, pos, feat, out, dirs, part = ws
+            self._grid_updates = getattr(self, "_grid_updates", 0) + 1
+            seed = (self.base_seed * 0x9E3779B1 + self._grid_updates * 0x85EBCA77 + 0x27D4EB2F) & 0xFFFFFFFF   # same on every replica
+            s_box = float(c.aabb_scale)
+            L, nul, st = lib(), C.c_void_p(0), stream_ptr()
+            check(L.ns_ngp_grid_cells(G, nc, C.c_uint32(seed), n, C.c_float(0.5 - 0.5 * s_box), C.c_float(0.5 + 0.5 * s_box), ptr(cells),
+                                      ptr(pos), st), "ngp_grid_cells")
+            check(L.ns_ngp_encode_forward(*self._grid_args(), ptr(pos), ptr(self.grid_half), ptr(feat), 1, C.c_long(n), st),
+                  "ngp_encode_forward")
+            check(L.ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(feat), ptr(dirs), ptr(out), nul, nul, nul, nul, C.c_long(n), st),
+                  "ngp_mlp_forward")
+            check(L.ns_ngp_grid_update(ptr(out), ptr(cells), n, C.c_float(c.min_step), C.c_float(c.grid_decay),
+                                       C.c_float(c.min_optical_thickness), ptr(self.density_grid), C.c_long(total), ptr(part),
+                                       ptr(self.bits), st), "ngp_grid_update")
+            return
         if n_cells is not None:
             cells = torch.randint(0, total, (min(int(n_cells), total),), device=dev, generator=self.gen)
         elif self.step < 256:

@@ -644,3 +644,56 @@ def test_hash_encode_backward_full_budget_properties(oracle_mod, dev):
     check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(sub), 1, ptr(gf), None, C.c_float(0), C.c_long(n), stream_ptr()), "bwd")
     gref = oracle_mod.ngp_encode_bwd(cfg, pos[:n], np.ascontiguousarray(dLT[:, :n].T), n_par)
     assert np.abs(gf.cpu().numpy() - gref).max() <= 2e-5 * np.abs(gref).max()
+
+
+def test_occupancy_refresh_kernels_against_torch(dev):
+    """ns_ngp_grid_cells + ns_ngp_grid_update (the subset form of update_density_grid on HIP kernels) against the torch
+    statement of the same rule: cells uniform over all cascades, a jittered point INSIDE each drawn cell, grid = max(decay *
+    grid, exp(log-density) * min_step), occupied = grid > min(mean, threshold), bit i of byte j = cell 8 j + i."""
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    from nerfslam.ngp import NgpConfig, NgpNerf
+    cfg = NgpConfig()
+    net = NgpNerf(cfg, dev, seed=3)
+    g = torch.Generator(device=dev).manual_seed(0)
+    net.grid_half.copy_((torch.rand(net.grid_half.shape, device=dev, generator=g) - 0.5).half())     # a field with structure
+    net.density_grid.copy_(torch.rand(net.density_grid.shape, device=dev, generator=g) * 0.02)
+    G, nc = cfg.grid_size, cfg.n_cascades
+    total, n = nc * G ** 3, 1 << 16
+    s = float(cfg.aabb_scale)
+    cells = torch.empty(n, dtype=torch.int32, device=dev)
+    pos = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    check(lib().ns_ngp_grid_cells(G, nc, C.c_uint32(12345), n, C.c_float(0.5 - 0.5 * s), C.c_float(0.5 + 0.5 * s), ptr(cells), ptr(pos),
+                                  stream_ptr()), "grid_cells")
+    cl = cells.long()
+    assert int(cl.min()) >= 0 and int(cl.max()) < total
+    counts = torch.bincount(cl // (G ** 3), minlength=nc).float() / n
+    assert (counts - 1.0 / nc).abs().max().item() < 0.02                       # uniform over the cascades
+    scene = pos * s + (0.5 - 0.5 * s)
+    mip, r = cl // (G ** 3), cl % (G ** 3)
+    xyz = torch.stack([r % G, (r // G) % G, r // (G * G)], -1)
+    inside = ((scene - 0.5) / (2.0 ** mip.float())[:, None] + 0.5) * G
+    assert (inside.floor().long() == xyz).float().mean().item() > 0.999       # (a point exactly on a cell face may round out)
+    # expected update, in torch
+    before = net.density_grid.clone()
+    dens = net.density_at(scene.contiguous()) * cfg.min_step
+    want = before * cfg.grid_decay
+    want.scatter_reduce_(0, cl, dens, "amax", include_self=True)
+    thr = min(float(want.double().mean()), cfg.min_optical_thickness)
+    feat = net.encode(pos)
+    out = torch.empty((n, 4), dtype=torch.float16, device=dev)
+    dirs = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+    nul = C.c_void_p(0)
+    check(lib().ns_ngp_mlp_forward(ptr(net.mlp_half), ptr(feat), ptr(dirs), ptr(out), nul, nul, nul, nul, C.c_long(n), stream_ptr()), "mlp")
+    part = torch.zeros(256, dtype=torch.float64, device=dev)
+    check(lib().ns_ngp_grid_update(ptr(out), ptr(cells), n, C.c_float(cfg.min_step), C.c_float(cfg.grid_decay),
+                                   C.c_float(cfg.min_optical_thickness), ptr(net.density_grid), C.c_long(total), ptr(part), ptr(net.bits),
+                                   stream_ptr()), "grid_update")
+    assert torch.allclose(net.density_grid, want, rtol=2e-3, atol=1e-9)
+    occ = ((net.bits[:, None] >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).reshape(-1).bool()
+    sure = (want - thr).abs() > 1e-3 * thr                                    # cells a rounding of the mean could flip are not judged
+    assert torch.equal(occ[sure], (want > thr)[sure]) and sure.float().mean().item() > 0.99
+    # the trainer's own update path runs the same kernels and is reproducible (replicas must stay in lockstep)
+    a, b = NgpNerf(cfg, dev, seed=5), NgpNerf(cfg, dev, seed=5)
+    for m in (a, b):
+        m.update_density_grid(); m.update_density_grid()
+    assert torch.equal(a.bits, b.bits) and torch.equal(a.density_grid, b.density_grid) and a._grid_updates == 2
