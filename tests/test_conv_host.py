@@ -62,3 +62,49 @@ def test_update_operator_packs_the_torch_modules_weights():
                      g.convr_glo(glo[:, :, None, None])[:, :, 0, 0] + g.convr.bias,
                      g.convq_glo(glo[:, :, None, None])[:, :, 0, 0] + g.convq.bias], 1)
     assert torch.allclose(torch.addmm(op.glo_b, glo, op.glo_w), ref.detach(), atol=1e-5)
+
+
+def _unpack(layer):
+    """PackedConv fragments -> dense [cout, cin_padded, taps] f32 (inverse of pack_weights)"""
+    p = layer.w.float()                                  # c, t, ct, h, i, e
+    nc, nt, nct = p.shape[:3]
+    return p.permute(2, 4, 0, 3, 5, 1).reshape(nct * 32, nc * 16, nt)[:layer.cout]
+
+
+def test_encoder_layers_as_1x1_over_patches():
+    """nerfslam/encoder_op.py host logic (CPU): the 7x7 / stride-2 stem and the stride-2 3x3 layers become 1x1 convolutions
+    over tap-major patches, and a block's 1x1 / stride-2 shortcut reads the centre-tap slice of the same patches -- the
+    re-ordered weights times a numpy statement of the patch kernels' layout (csrc/encoder.hip) must equal F.conv2d."""
+    import torch.nn.functional as F
+    from nerfslam.droid_nets import BasicEncoder
+    from nerfslam.encoder_op import HipEncoder, _half_out
+
+    def patches(x, k, pad):            # [N,C,H,W] -> [N,Ho,Wo,k*k*C], out[..., (ky*k+kx)*C + c] = x[n, c, 2oy+ky-pad, 2ox+kx-pad]
+        N, Cc, H, W = x.shape
+        Ho, Wo = _half_out(H), _half_out(W)
+        xp = F.pad(x, (pad, pad + 2, pad, pad + 2))
+        out = torch.zeros((N, Ho, Wo, k * k * Cc))
+        for ky in range(k):
+            for kx in range(k):
+                out[..., (ky * k + kx) * Cc:(ky * k + kx + 1) * Cc] = xp[:, :, ky:ky + 2 * Ho:2, kx:kx + 2 * Wo:2].permute(0, 2, 3, 1)
+        return out
+
+    torch.manual_seed(1)
+    enc = BasicEncoder(128, "instance").eval()
+    op = HipEncoder(enc, True, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    assert len(op.blocks) == 6 and [b.stride2 for b in op.blocks] == [False, False, True, False, True, False]
+    h = lambda t: t.half().float()                       # the packed weights are f16
+    with torch.no_grad():
+        x = torch.randn(2, 3, 33, 47)
+        w = _unpack(op.stem)[:, :, 0]                    # [32, 160]: 147 taps + zero padding
+        assert op.stem.cin_padded == 160 and not w[:, 147:].any()
+        got = patches(x, 7, 3) @ w[:, :147].t() + enc.conv1.bias
+        assert torch.allclose(got.permute(0, 3, 1, 2), F.conv2d(x, h(enc.conv1.weight), enc.conv1.bias, stride=2, padding=3), atol=2e-5)
+        for blk, rb, cin in ((op.blocks[2], enc.layer2[0], 32), (op.blocks[4], enc.layer3[0], 64)):
+            y = torch.randn(1, cin, 17, 24)
+            P = patches(y, 3, 1)
+            got = P @ _unpack(blk.conv1)[:, :, 0].t() + rb.conv1.bias
+            assert torch.allclose(got.permute(0, 3, 1, 2), F.conv2d(y, h(rb.conv1.weight), rb.conv1.bias, stride=2, padding=1), atol=1e-4)
+            got = P[..., 4 * cin:5 * cin] @ _unpack(blk.down)[:, :, 0].t() + rb.downsample[0].bias
+            assert torch.allclose(got.permute(0, 3, 1, 2), F.conv2d(y, h(rb.downsample[0].weight), rb.downsample[0].bias, stride=2), atol=1e-4)
+    assert _half_out(480) == 240 and _half_out(47) == 24 and _half_out(1) == 1
