@@ -113,6 +113,11 @@ __device__ __forceinline__ uint32_t grid_index(uint32_t hashmap_size, uint32_t r
 // subtraction is the modulo.  `hashed` is uniform per level.
 __device__ __forceinline__ uint32_t grid_index_lvl(bool hashed, uint32_t hs, uint32_t res, uint32_t x, uint32_t y, uint32_t z) {
   if (hashed) return (x ^ (y * 2654435761u) ^ (z * 805459861u)) & (hs - 1u);
+  // Clamp first: the bound above holds for coordinates <= res only.  A position outside the unit cube (the up-to-7 tail slots
+  // of the 8-rounded sample count hold whatever the sample array held before -- after render() that is SCENE coordinates, e.g.
+  // -1.2) gives a negative cell coordinate, i.e. a huge unsigned one, and without a modulo an index far outside the table:
+  // an intermittent memory fault in the training steps that follow a render() (found by tests/test_ngp_gpu.py in a loop).
+  x = min(x, res); y = min(y, res); z = min(z, res);
   const uint32_t idx = x + (y + z * res) * res;
   return idx >= hs ? idx - hs : idx;
 }
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
       for (int dd = 0; dd < 3; dd++) {
         const float p = fmaf(scale, cpos[dd], 0.5f);
         const float fl = floorf(p);
-        c[dd] = (uint32_t)(int)fl;
+        c[dd] = hashed ? (uint32_t)(int)fl : min((uint32_t)(int)fl, res - 1u);   // (dense: see grid_index_lvl)
         w[dd] = p - fl;
       }
     }
@@ -607,7 +612,7 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_dense_rl_kernel(GridLayou
       for (int dd = 0; dd < 3; dd++) {
         const float p = fmaf(scale, pf[3 * j + dd], 0.5f);
         const float fl = floorf(p);
-        c[dd] = (uint32_t)(int)fl;
+        c[dd] = min((uint32_t)(int)fl, res - 1u);   // (a position outside the unit cube must not index outside the table)
         w[dd] = p - fl;
       }
       const uint32_t base = c[0] + c[1] * res + c[2] * r2;

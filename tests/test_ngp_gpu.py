@@ -697,3 +697,40 @@ def test_occupancy_refresh_kernels_against_torch(dev):
     for m in (a, b):
         m.update_density_grid(); m.update_density_grid()
     assert torch.equal(a.bits, b.bits) and torch.equal(a.density_grid, b.density_grid) and a._grid_updates == 2
+
+
+def test_hash_encode_survives_positions_outside_the_unit_cube(dev):
+    """Positions outside [0,1]^3 have no meaning for the encoding, but they reach the kernels: the 8-rounded sample count covers
+    up to 7 stale slots of the sample array, which after render() hold SCENE coordinates (e.g. -1.2).  On the dense levels such
+    a position used to index gigabytes outside the table (no modulo in the fast index): an intermittent memory fault in the
+    training steps that follow a render().  Forward, input gradient and table gradient must stay inside the tables."""
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    from nerfslam.ngp import NgpConfig, NgpNerf
+    net = NgpNerf(NgpConfig(), dev, seed=2)
+    args = net._grid_args()
+    N = 4096
+    g = torch.Generator(device=dev).manual_seed(4)
+    pos = torch.rand((N, 3), device=dev, generator=g)
+    wild = torch.tensor([-1.2, 2.7, -1e-7, 1.0000001, -3.0e9, 4.0e9, 1e30, -1e30], device=dev)
+    pos[::5] = wild[torch.randint(0, 8, (pos[::5].shape[0], 3), device=dev, generator=g)]
+    pos[7] = float("nan")
+    feat = torch.empty((32, N), dtype=torch.float16, device=dev)
+    dfe = (torch.randn((32, N), device=dev, generator=g) * 1e-2).half()
+    dpos = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    gq = torch.zeros(net.n_grid // 2, dtype=torch.int64, device=dev)
+    ws = torch.zeros(lib().ns_ngp_encode_backward_workspace_bytes(*args, C.c_long(N)) // 4 + 1, device=dev)
+    for _ in range(3):
+        check(lib().ns_ngp_encode_forward(*args, ptr(pos), ptr(net.grid_half), ptr(feat), 1, C.c_long(N), stream_ptr()), "fwd")
+        check(lib().ns_ngp_encode_backward_input_n(*args, ptr(pos), ptr(net.grid_half), ptr(dfe), ptr(dpos), C.c_long(N), None,
+                                                   stream_ptr()), "bwd_input")
+        for w in (None, ws):
+            check(lib().ns_ngp_encode_backward(*args, ptr(pos), ptr(dfe), 1, ptr(gq), ptr(w), C.c_float(262144.0), C.c_long(N),
+                                               stream_ptr()), "bwd")
+        torch.cuda.synchronize()
+    ok = torch.isfinite(pos).all(-1) & (pos.abs() < 1e6).all(-1)
+    assert torch.isfinite(feat[:, ok].float()).all()
+    inside = ((pos >= 0) & (pos <= 1)).all(-1)
+    ref = torch.empty((32, int(inside.sum())), dtype=torch.float16, device=dev)   # the in-cube samples are unaffected by their neighbours
+    check(lib().ns_ngp_encode_forward(*args, ptr(pos[inside].contiguous()), ptr(net.grid_half), ptr(ref), 1, C.c_long(ref.shape[1]),
+                                      stream_ptr()), "fwd")
+    assert torch.equal(feat[:, inside], ref)
