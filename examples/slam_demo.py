@@ -3,7 +3,8 @@
 (:62-190): DataModule -> SlamModule("VioSLAM") -> FusionModule("nerf").
 
 --parallel_run --multi_gpu runs one process per GPU under torch.distributed (RCCL): rank 0 tracks on its GPU
-and ships the dirty keyframes with nerfslam.transport; ranks >= 1 train the NeRF.  Launch with
+and ships the dirty keyframes with nerfslam.transport.PacketChannel; ranks >= 1 are replicated NeRF trainers that never
+block on the tracker (they train on every poll without a packet) and all-reduce their gradients.  Launch with
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 examples/slam_demo.py --slam \
         --fusion nerf --parallel_run --multi_gpu ...
 Datasets and the DROID weights are not part of this project: `--dataset_dir` takes a .npz sequence
@@ -44,6 +45,7 @@ def parse_args(argv=None):
     p.add_argument("--network", default="")
     p.add_argument("--eval", action="store_true")
     p.add_argument("--stop_iters", type=int, default=25000, help="NeRF training iterations (nerf_fusion.py:54 hard-codes 25000)")
+    p.add_argument("--force_keyframes", action="store_true", help=argparse.SUPPRESS)      # test aid (random-weight runs)
     return p.parse_args(argv)
 
 
@@ -62,21 +64,57 @@ def load_sequence(args):
 def run(args, return_modules=False, tweak=None):
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     split = args.parallel_run and args.multi_gpu and world > 1
+    chan = None
     if split:
+        # rank 0 tracks, ranks 1.. are replicated FREE-RUNNING NeRF trainers (fusion_module.py:30-45: the reference's mapper
+        # never blocks on its input and trains on every spin without a packet): nerfslam.transport.PacketChannel -- headers
+        # through the rendezvous store, keyframe payloads over RCCL, gradients all-reduced in the trainer sub-group.
+        # NS_DEMO_DIST_BACKEND=gloo + NS_DEMO_ONE_DEVICE=1 run the same topology on a one-GPU box (tests).
         import torch.distributed as dist
         from nerfslam import transport
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
-        dist.init_process_group("nccl")
+        backend = os.environ.get("NS_DEMO_DIST_BACKEND", "nccl")
+        local = 0 if os.environ.get("NS_DEMO_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", rank))
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        trainers = list(range(1, world))
+        control = dist.new_group(list(range(world)), backend="gloo")
+        trainer_control = dist.new_group(trainers, backend="gloo")
+        trainer_data = dist.new_group(trainers, backend=backend) if len(trainers) > 1 else None
+        chan = transport.PacketChannel(torch.device("cuda", local), tracker=0, trainers=trainers, control_group=control,
+                                       data_group=None, trainer_control_group=trainer_control)
     dev = f"cuda:{torch.cuda.current_device()}"
     args_seq = argparse.Namespace(**{**vars(args), "parallel_run": False})
     if split and rank > 0:                                   # NeRF trainer rank
+        args_seq.trainer_group = trainer_data
         fusion = FusionModule("nerf", args_seq, device=dev)
         fusion.initialize_module()
-        while not fusion.shutdown:
-            pkt = transport.broadcast_packet(None, 0, dev)
-            fusion.spin_once({"slam": [None, pkt]})
-            if pkt["is_last_frame"]:
+        import time
+        while True:                                          # (a trainer that reached its stop condition keeps answering the
+            msg = chan.poll()                                #  tracker's broadcasts until STOP: collectives must stay matched)
+            if msg is None:
+                if not fusion.shutdown:
+                    fusion.spin_once(False)                  # nothing arrived: train (nerf_fusion.py:249-253)
+                else:
+                    time.sleep(0.001)
+                continue
+            kind, pkt = msg
+            if kind == transport.KIND_PACKET and not fusion.shutdown:
+                fusion.spin_once({"slam": [None, pkt]})
+            elif kind == transport.KIND_STOP:
                 break
+        ngp = fusion.fusion.ngp
+        net = ngp._net
+        print("slam_demo trainer %d: %d training views, %d iterations, %d optimiser steps, parameter checksum %.6f" % (
+            rank, int(ngp.nerf.training.n_images_for_training), int(fusion.fusion.total_iters), int(ngp.training_step),
+            float(net.grid_master.double().sum().item()) + float(net.mlp_master.double().sum().item())), flush=True)
+        dist.barrier(group=control)
+        if return_modules:
+            return {"data": None, "slam": None, "fusion": fusion}
+        dist.destroy_process_group()
         return
     data_q, slam_q = Queue(), Queue()
     data = DataModule(args.dataset_name, args_seq, dataset=load_sequence(args))
@@ -91,7 +129,7 @@ def run(args, return_modules=False, tweak=None):
         slam = SlamModule("VioSLAM", args_seq, device=dev)
         slam.register_input_queue("data", data_q)
         if split:
-            slam.register_output_callback(lambda out: transport.broadcast_packet(out[1], 0, dev) if out[1] else None)
+            slam.register_output_callback(lambda out: chan.publish(out[1]) if (out and out[1] and "cam0_poses" in out[1]) else None)
     threaded = bool(args.parallel_run and args.fusion and not split and slam is not None)
     if args.fusion and not split:
         if threaded:
@@ -105,9 +143,12 @@ def run(args, return_modules=False, tweak=None):
         if slam:
             slam.register_output_queue(slam_q)
             fusion.register_input_queue("slam", slam_q)
-    if slam is not None and tweak is not None:
+    if slam is not None and (tweak is not None or args.force_keyframes):
         slam.initialize_module()
-        tweak(slam)
+        if args.force_keyframes:                             # test aid: every frame passes the motion filter and stays a keyframe
+            slam.slam.motion_filter_thresh = slam.slam.keyframe_thresh = -1.0
+        if tweak is not None:
+            tweak(slam)
     if threaded:
         fusion.initialize_module()
         worker = spin_in_thread(fusion, dev)
@@ -120,6 +161,11 @@ def run(args, return_modules=False, tweak=None):
         return
     while data.spin() and (slam is None or slam.spin()) and (fusion is None or fusion.spin()):
         pass
+    if chan is not None:
+        chan.close()                                         # STOP to the trainers, payload broadcasts drained
+        dist.barrier(group=control)                          # (the rendezvous store lives in this process: leave last)
+        if not return_modules:
+            dist.destroy_process_group()
     while fusion is not None and not fusion.shutdown and fusion.spin():
         pass
     if return_modules:

@@ -126,3 +126,38 @@ def test_demo_driver_sequential_slam_plus_nerf(dev, tmp_path, parallel):
     assert fusion.shutdown and (slam.shutdown or parallel)
     assert fusion.fusion.ngp.nerf.training.n_images_for_training >= (1 if parallel else 9) and fusion.fusion.total_iters > 400
     assert np.isfinite(fusion.fusion.ngp.loss)
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_demo_driver_multi_gpu_split_on_one_device(tmp_path, nproc):
+    """examples/slam_demo.py --parallel_run --multi_gpu under torch.distributed.run (examples/slam_demo.py:63-77 of the
+    reference): rank 0 tracks, ranks 1.. are free-running replicated trainers behind nerfslam.transport.PacketChannel.  All
+    ranks on the one GPU of the test box over gloo (NS_DEMO_ONE_DEVICE): the same code path as the RCCL run except the
+    backend name.  The run must end by itself (STOP, final barrier) with every rank exiting 0."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    H, W, n = 96, 128, 11
+    g = np.random.default_rng(0)
+    base = g.integers(0, 255, (H + 40, W + 40, 3), dtype=np.uint8)
+    imgs = np.stack([base[2 * k:2 * k + H, 3 * k:3 * k + W] for k in range(n)])
+    seq = tmp_path / "seq.npz"
+    np.savez(seq, images=imgs, intrinsics=np.array([100.0, 100.0, W / 2, H / 2], np.float32))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, NS_DEMO_DIST_BACKEND="gloo", NS_DEMO_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "examples", "slam_demo.py"), "--slam", "--fusion", "nerf", "--parallel_run",
+           "--multi_gpu", "--dataset_dir", str(seq), "--buffer", "16", "--weights", "/nonexistent.pth", "--stop_iters", "400",
+           "--force_keyframes"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    import re
+    rows = re.findall(r"slam_demo trainer (\d+): (\d+) training views, (\d+) iterations, (\d+) optimiser steps, parameter checksum (\S+)", r.stdout)
+    assert sorted(int(x[0]) for x in rows) == list(range(1, nproc)), r.stdout[-1500:]
+    # packets arrived and the trainers trained; how many views they saw before their stop condition depends on the race between
+    # the tracker's start-up and the free-running trainers (as in the one-GPU --parallel_run test above)
+    assert all(int(x[1]) >= 1 and int(x[2]) > 0 and int(x[3]) > 0 for x in rows), rows
+    if nproc > 2:
+        assert rows[0][3] == rows[1][3] and rows[0][4] == rows[1][4], rows                     # replicas in lockstep
