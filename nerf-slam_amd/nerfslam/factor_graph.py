@@ -10,6 +10,7 @@ Device-side per-edge payloads (targets, weights, volumes, hidden states) are own
 every mutating method returns the masks / permutations the caller must apply to them.
 """
 import numpy as np
+import torch
 
 
 def _diamond(radius):
@@ -29,6 +30,8 @@ class FactorGraph:
         self.ii_inactive, self.jj_inactive = z.copy(), z.copy()
         self.ii_bad, self.jj_bad = z.copy(), z.copy()
         self.version = 0  # bumped on every change: consumers cache their BaPlan on it
+        # device on which the age permutation of add() is sorted (see add()): the reference sorts a device tensor
+        self.sort_device = "cpu"
 
     def reset(self, max_factors=None):
         """drop every edge list (global-BA passes, visual_frontend.py:1263-1283); the version keeps growing so that
@@ -112,8 +115,12 @@ class FactorGraph:
             return ii, jj, None
         removed = None
         if self.max_factors > 0 and self.ii.shape[0] + ii.shape[0] > self.max_factors and have_volumes and remove:
-            # positional mask through the age permutation (DROID quirk, :826-828)
-            pos = np.arange(self.age.shape[0])[np.argsort(self.age, kind="stable")]
+            # positional mask through the age permutation (DROID quirk, :826-828).  Edges added by one call share an
+            # age and the reference sorts them with `torch.argsort(self.age)` -- NOT a stable sort -- so which edges go
+            # depends on that routine's tie order (found by replaying the reference's own methods: tools/
+            # gen_golden_graph.py).  The same torch call is made here, on the same kind of device as the reference's
+            # (the frontend sets `sort_device` to its GPU; the golden sequences were produced by CPU torch).
+            pos = torch.argsort(torch.from_numpy(self.age).to(self.sort_device)).cpu().numpy()
             removed = pos >= (self.max_factors - ii.shape[0])
             self.remove(removed, store=True)
         self.ii = np.concatenate([self.ii, ii])

@@ -62,6 +62,7 @@ class TrackingFrontend:
         self.coords0 = torch.stack([gx, gy], -1).float()        # [ht,wd,2]
         # graph + per-edge payloads
         self.graph = FactorGraph(max_factors=max_factors)
+        self.graph.sort_device = dev     # the age permutation of add_factors is sorted where the reference sorts it (:826)
         self.ii = self.jj = torch.zeros(0, dtype=torch.long, device=dev)
         # correlation volumes: a slot-addressed pool (nerfslam.corr.CorrPool); `corr` is None until the first edge has one
         self.corr = None
@@ -176,7 +177,7 @@ class TrackingFrontend:
         self._drop_payload(mask, store)
 
     def add_neighborhood_factors(self, kf0, kf1, radius=3):
-        ii, jj = FactorGraph.neighborhood_edges(kf0, kf1, radius)
+        ii, jj = FactorGraph.neighborhood_edges(kf0, kf1, radius, self.graph.stereo)
         self.add_factors(ii, jj)
 
     def add_proximity_factors(self, kf0=0, kf1=0, rad=2, nms=2, thresh=16.0, remove=False):
