@@ -192,6 +192,37 @@ def test_altcorr_block_smooth_flow_and_tiles_that_leave_the_image(oracle_mod, de
         lv = torch.nn.functional.avg_pool2d(lv, 2, stride=2)
 
 
+def test_altcorr_block_vs_oracle_at_c1280(oracle_mod, dev):
+    """altcorr_tile_kernel at config #5's grid (1280x720 -> 90x160; 90 is not a multiple of 8) against the oracle, every
+    level: a smooth flow (LDS-staged path), a flow that leaves the image on the right and at the bottom, a per-pixel random
+    flow (windows of one tile far apart: the box does not fit the staging buffer), and an edge entirely outside."""
+    from nerfslam.corr import AltCorrBlock
+    rng = np.random.default_rng(1280)
+    nfr, Cc, H, W = 4, 128, 90, 160
+    fm = rng.standard_normal((1, nfr, Cc, H, W)).astype(np.float16)
+    ii, jj = np.array([0, 1, 2, 3], np.int64), np.array([1, 2, 3, 0], np.int64)
+    gy, gx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    base = np.stack([gx, gy], -1).astype(np.float32)
+    swirl = np.stack([3.5 * np.sin(gy / 17.0) + 0.013 * gx, 2.5 * np.cos(gx / 23.0) - 0.02 * gy], -1).astype(np.float32)
+    coords = np.stack([base + swirl,
+                       base + [W - 30.25, H - 20.5] + 0.5 * swirl,
+                       base + rng.uniform(-12, 12, base.shape).astype(np.float32),
+                       base + [-2.0 * W, 3.0 * H]])[None].astype(np.float32)
+    blk = AltCorrBlock(torch.from_numpy(fm).to(dev))
+    got = blk(torch.from_numpy(coords).to(dev), torch.from_numpy(ii).to(dev), torch.from_numpy(jj).to(dev))[0].cpu().numpy()
+    assert got.shape == (4, 196, H, W)
+    assert np.all(got[3] == 0.0)
+    lv = torch.from_numpy(fm[0]).float() / 4.0
+    f0 = lv.permute(0, 2, 3, 1).contiguous().numpy()
+    for l in range(4):
+        f = lv.permute(0, 2, 3, 1).contiguous().numpy()
+        ref = oracle_mod.altcorr_forward(f0[ii], f[jj], coords[0][:, None] / np.float32(2 ** l), 3)[:, 0]
+        g = got[:, 49 * l:49 * (l + 1)]
+        assert np.abs(ref[:3]).max() > 0.2 and (ref[1] == 0).mean() > 0.5 and (ref[1] != 0).mean() > 0.005
+        np.testing.assert_allclose(g, ref, rtol=0, atol=1e-5 * np.abs(ref).max(), err_msg=f"level {l}")
+        lv = torch.nn.functional.avg_pool2d(lv, 2, stride=2)
+
+
 def test_altcorr_backward_against_autograd(dev):
     """droid_backends.altcorr_backward (dead in the reference's inference path, src/droid.cpp:315-327) against torch autograd
     through a float64 restatement of the forward pass (raw 8x8 taps, bilinear blend, channel = iy + 7 ix)."""
