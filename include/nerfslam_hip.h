@@ -237,8 +237,8 @@ int ns_projective_transform(const float* targets, const float* weights, const fl
                             float* Ejz, float* Cii, float* bz, float* etab_ws, void* stream);
 
 /* Device-resident replacement of the GTSAM round trip in ba() (visual_frontend.py:1123-1158),
- * one workgroup, f64 in LDS, 6P <= 192 (NS_ENOSUP above that: the host falls back to rocSOLVER
- * via torch.linalg + ns_ba_retract):
+ * one workgroup, f64 in LDS, 6P <= 192 (6P <= 108 with L^-1 / sigma_g); NS_ENOSUP above that: the host then
+ * calls ns_ba_solve_large:
  *   (triu(H) mirrored [+ ep + lm*diag] [+ prior]) delta = v      (dense blocked Cholesky)
  *   mode 0:  world_T_body[kf0+i] <- world_T_body[kf0+i] * Exp(delta_i)   (delta = [omega, v]),
  *            cam_T_world[kf0+i]  <- cam_T_body * world_T_body[kf0+i]^-1
@@ -253,6 +253,16 @@ int ns_ba_solve(const float* H, const float* v, float* world_T_body, float* cam_
                 const float* cam_T_body, const float* prior_pose, float prior_sigma, float ep, float lm, int kf0,
                 int kf1, int mode, float* dx, double* Hfull_out, float* Linv_out, double* Linv_ws,
                 float* sigma_g_out, int32_t* info, void* stream);
+
+/* ns_ba_solve for systems beyond one workgroup's LDS -- the global BA over the whole buffer (backend(),
+ * visual_frontend.py:1255-1295: 6P = 1536 for 256 keyframes) and windows with covariances above 18 poses.  Same
+ * arguments, semantics and outputs; blocked right-looking Cholesky in f64 through a caller-provided workspace of
+ * ns_ba_solve_large_workspace_bytes(6P, want L^-1 / sigma_g) bytes (device memory); 6P <= ~19000.                  */
+size_t ns_ba_solve_large_workspace_bytes(int n6, int want_inv);
+int ns_ba_solve_large(const float* H, const float* v, float* world_T_body, float* cam_T_world,
+                      const float* cam_T_body, const float* prior_pose, float prior_sigma, float ep, float lm, int kf0,
+                      int kf1, int mode, float* dx, double* Hfull_out, float* Linv_out, float* sigma_g_out,
+                      int32_t* info, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The retraction of ns_ba_solve mode 0 on its own (dx given).                                 */
 int ns_ba_retract(const float* dx, float* world_T_body, float* cam_T_world, const float* cam_T_body, int kf0,

@@ -355,6 +355,65 @@ __global__ __launch_bounds__(256) void ba_depth_cov_kernel(const float* __restri
   z_cov[(long)k * HW + p] = q + total;
 }
 
+// The same sum for windows whose L^-1 does not fit LDS whole (6P x ceil32(6P) floats > 160 KB, P >= 33): L^-1 is staged
+// one 32-column tile and COVC_ROWS rows at a time; the accumulators of a column tile stay in registers across the row
+// chunks.  Chunk boundaries are multiples of 6, so the six rows of a pose never straddle two chunks.
+#define COVC_ROWS 1020
+__global__ __launch_bounds__(256) void ba_depth_cov_chunked_kernel(const float* __restrict__ Linv,
+                                                                   const float* __restrict__ Q,
+                                                                   const float* __restrict__ E,
+                                                                   const int32_t* __restrict__ row_pose,
+                                                                   const int32_t* __restrict__ slot_rows_ptr,
+                                                                   const int32_t* __restrict__ slot_rows, int HW, int P,
+                                                                   float* __restrict__ z_cov) {
+  extern __shared__ __attribute__((aligned(16))) float Ls[];  // [COVC_ROWS][COV_TILE]
+  const int k = blockIdx.x;
+  const int p = blockIdx.y * 256 + threadIdx.x;
+  const bool live = p < HW;
+  const int n = 6 * P;
+  const float q = live ? Q[(long)k * HW + p] : 0.0f;
+  float total = 0.0f;
+  const int r0 = slot_rows_ptr[k], r1 = slot_rows_ptr[k + 1];
+  for (int j0 = 0; j0 < n; j0 += COV_TILE) {
+    float acc[COV_TILE];
+#pragma unroll
+    for (int j = 0; j < COV_TILE; j++) acc[j] = 0.0f;
+    for (int rc0 = (j0 / 6) * 6; rc0 < n; rc0 += COVC_ROWS) {   // L^-1 is lower triangular: rows < j0 hold zeros here
+      const int rows = min(COVC_ROWS, n - rc0);
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < rows * COV_TILE; idx += 256) {
+        const int r = idx / COV_TILE, c = idx % COV_TILE;
+        Ls[idx] = (j0 + c < n) ? Linv[(long)(rc0 + r) * n + j0 + c] : 0.0f;
+      }
+      __syncthreads();
+      if (!live) continue;
+      for (int r = r0; r < r1; r++) {
+        const int row = slot_rows[r];
+        const int pose = row_pose[row];
+        if (pose < 0 || pose >= P) continue;
+        const int lr = 6 * pose - rc0;
+        if (lr < 0 || lr >= rows) continue;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          const float e = E[((long)row * 6 + c) * HW + p] * q;
+          const float4* __restrict__ Lr = reinterpret_cast<const float4*>(Ls + (lr + c) * COV_TILE);
+#pragma unroll
+          for (int j = 0; j < COV_TILE / 4; j++) {
+            const float4 l = Lr[j];
+            acc[4 * j + 0] += e * l.x;
+            acc[4 * j + 1] += e * l.y;
+            acc[4 * j + 2] += e * l.z;
+            acc[4 * j + 3] += e * l.w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < COV_TILE; j++) total += acc[j] * acc[j];
+  }
+  if (live) z_cov[(long)k * HW + p] = q + total;
+}
+
 // standalone retraction (used after the large-system rocSOLVER path): same arithmetic as above
 __global__ void ba_retract_kernel(const float* __restrict__ dx, float* __restrict__ wTb, float* __restrict__ cTw,
                                   const float* __restrict__ cTb, int kf0, int P) {
@@ -457,8 +516,21 @@ extern "C" int ns_ba_depth_cov(const float* Linv, const float* Q, const float* E
   const int n = 6 * plan->P, ns = (n + COV_TILE - 1) / COV_TILE * COV_TILE;
   const size_t lds = sizeof(float) * (size_t)n * ns;
   if (lds > 160 * 1024 - 256) {
-    ns_set_error("ns_ba_depth_cov: 6P=%d does not fit LDS (the reference skips covariances in global BA too)", n);
-    return NS_ENOSUP;
+    // window too large to keep L^-1 in LDS whole (P >= 33): the chunked kernel (the reference has no such limit)
+    const size_t ldc = sizeof(float) * (size_t)COVC_ROWS * COV_TILE;
+    static thread_local bool configured_c = false;
+    if (!configured_c) {
+      if (hipFuncSetAttribute((const void*)ba_depth_cov_chunked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)ldc) != hipSuccess) {
+        ns_set_error("ns_ba_depth_cov: hipFuncSetAttribute failed");
+        return NS_ELAUNCH;
+      }
+      configured_c = true;
+    }
+    hipLaunchKernelGGL(ba_depth_cov_chunked_kernel, dim3(plan->K, ns_cdiv(HW, 256)), dim3(256), ldc, (hipStream_t)stream,
+                       Linv, Q, E, index + off[2], index + off[6], index + off[7], HW, plan->P, z_cov);
+    NS_CHECK_LAUNCH("ba_depth_cov_chunked_kernel");
+    return NS_OK;
   }
   static thread_local size_t configured = 0;
   if (lds > configured && lds > 64 * 1024) {

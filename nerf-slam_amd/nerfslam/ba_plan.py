@@ -138,7 +138,7 @@ def ba_solve(H, v, kf0, kf1, world_T_body=None, cam_T_world=None, cam_T_body=Non
     sig = torch.empty((P, 6, 6), dtype=torch.float32, device=dev) if want_cov else None
     if n > MAX_SMALL_SYSTEM or (want_cov and n > MAX_SMALL_SYSTEM_COV):
         return _ba_solve_large(H, v, kf0, kf1, world_T_body, cam_T_world, cam_T_body, prior_pose, prior_sigma, ep, lm,
-                               retract, want_cov)
+                               retract, want_cov, want_hfull)
     with torch.cuda.device(dev):
         check(lib().ns_ba_solve(ptr(H), ptr(v), ptr(world_T_body), ptr(cam_T_world), ptr(cam_T_body),
                                 ptr(prior_pose), C.c_float(prior_sigma), C.c_float(ep), C.c_float(lm), int(kf0),
@@ -147,37 +147,35 @@ def ba_solve(H, v, kf0, kf1, world_T_body=None, cam_T_world=None, cam_T_body=Non
     return dict(dx=dx, info=info, Hfull=Hfull, Linv=Linv, sigma_g=sig)
 
 
+_large_ws = {}   # (device, bytes) workspace of ns_ba_solve_large, grown on demand and reused (f64, up to 2 x (6P)^2 + 6P)
+
+
 def _ba_solve_large(H, v, kf0, kf1, world_T_body, cam_T_world, cam_T_body, prior_pose, prior_sigma, ep, lm, retract,
-                    want_cov):
-    """6P > 192 (global BA over the whole buffer): dense f64 Cholesky through rocSOLVER
-    (torch.linalg), then the retraction kernel.  Same semantics as the LDS path."""
-    from . import se3 as _se3
+                    want_cov, want_hfull=False):
+    """6P beyond the single-workgroup LDS solve (global BA over the whole buffer, visual_frontend.py:1255-1295; windows
+    with covariances above 18 poses): blocked f64 Cholesky through HBM, csrc/ba_solve_large.hip.  Same semantics and
+    outputs as the LDS path; nothing leaves the device."""
     dev = H.device
     P = int(kf1) - int(kf0)
     n = 6 * P
-    Hd = torch.triu(H.double())
-    Hd = Hd + torch.triu(Hd, 1).t()
-    d = torch.diagonal(Hd)
-    d += ep + lm * d
-    vd = v.double().reshape(n, 1).clone()
-    if prior_pose is not None:
-        e = _se3.log_wv(_se3.mul(_se3.inv(prior_pose.double()), world_T_body[kf0].double()))
-        Hd[:6, :6] += torch.eye(6, dtype=torch.float64, device=dev) / prior_sigma ** 2
-        vd[:6, 0] += -e / prior_sigma ** 2
-    L, info = torch.linalg.cholesky_ex(Hd)
-    dxd = torch.cholesky_solve(vd, L).reshape(P, 6)
-    dx = torch.where(info == 0, dxd, torch.zeros_like(dxd)).float().contiguous()
-    if retract:
-        with torch.cuda.device(dev):
-            check(lib().ns_ba_retract(ptr(dx), ptr(world_T_body), ptr(cam_T_world), ptr(cam_T_body), int(kf0),
-                                      int(kf1), stream_ptr()), "ba_retract")
-    out = dict(dx=dx, info=info.to(torch.int32).reshape(1), Hfull=Hd, Linv=None, sigma_g=None)
-    if want_cov:
-        Linv = torch.linalg.solve_triangular(L, torch.eye(n, dtype=torch.float64, device=dev), upper=False)
-        sig = (Linv.t() @ Linv).view(P, 6, P, 6)
-        out["Linv"] = Linv.float().contiguous()
-        out["sigma_g"] = torch.stack([sig[i, :, i, :] for i in range(P)]).float().contiguous()
-    return out
+    L = lib()
+    L.ns_ba_solve_large_workspace_bytes.restype = C.c_size_t
+    need = int(L.ns_ba_solve_large_workspace_bytes(n, 1 if want_cov else 0))
+    key = (dev.type, dev.index)
+    ws = _large_ws.get(key)
+    if ws is None or ws.numel() * 8 < need:
+        ws = _large_ws[key] = torch.empty((need + 7) // 8, dtype=torch.float64, device=dev)
+    dx = torch.empty((P, 6), dtype=torch.float32, device=dev)
+    info = torch.empty((1,), dtype=torch.int32, device=dev)
+    Hfull = torch.empty((n, n), dtype=torch.float64, device=dev) if want_hfull else None
+    Linv = torch.empty((n, n), dtype=torch.float32, device=dev) if want_cov else None
+    sig = torch.empty((P, 6, 6), dtype=torch.float32, device=dev) if want_cov else None
+    with torch.cuda.device(dev):
+        check(L.ns_ba_solve_large(ptr(H), ptr(v), ptr(world_T_body), ptr(cam_T_world), ptr(cam_T_body), ptr(prior_pose),
+                                  C.c_float(prior_sigma), C.c_float(ep), C.c_float(lm), int(kf0), int(kf1),
+                                  0 if retract else 1, ptr(dx), ptr(Hfull), ptr(Linv), ptr(sig), ptr(info), ptr(ws),
+                                  C.c_size_t(ws.numel() * 8), stream_ptr()), "ba_solve_large")
+    return dict(dx=dx, info=info, Hfull=Hfull, Linv=Linv, sigma_g=sig)
 
 
 def depth_cov(plan, Linv, Q, E, HW):

@@ -19,13 +19,12 @@ weights (`droid.pth`) are missing from the reference tree; they are injected as 
                                                                           [, upmask [n_unique_ii, 576, ht, wd] or channels-last [n_unique_ii, ht, wd, 576] f16])
 """
 import ctypes as C
-import warnings
 
 import numpy as np
 import torch
 
 from . import ba_plan, se3
-from ._lib import NS_ENOSUP, NerfSlamHipError, check, lib, ptr, stream_ptr
+from ._lib import check, lib, ptr, stream_ptr
 from .corr import CorrPool
 from .factor_graph import FactorGraph
 
@@ -263,15 +262,7 @@ class TrackingFrontend:
                                    prior_pose=prior, ep=ep, lm=lm, want_cov=cov and last)
             ba_plan.solve_depth(plan, sol["dx"], self.cam0_idepths, Q, E, w, clamp_min=0.001)   # :1161-1162
         if cov and sol["Linv"] is not None:
-            try:
-                z = ba_plan.depth_cov(plan, sol["Linv"], Q, E, self.HW).view(-1, self.ht, self.wd)  # :1191-1219
-            except NerfSlamHipError as e:
-                if e.status != NS_ENOSUP:
-                    raise
-                # window larger than the kernel's LDS staging of L^-1 (6P x ceil32(6P) floats <= 160 KB, P <= 32): keep the
-                # previous covariances rather than abort tracking (the reference has no such limit)
-                warnings.warn(f"depth covariances skipped for a {kf1 - kf0}-pose window: {e}")
-                return sol
+            z = ba_plan.depth_cov(plan, sol["Linv"], Q, E, self.HW).view(-1, self.ht, self.wd)      # :1191-1219
             self.world_T_body_cov[kf0:kf1] = sol["sigma_g"]
             self.cam0_idepths_cov[kx] = z
             self.cam0_depths_cov[kx] = z / self.cam0_idepths[kx] ** 4                          # :1229
