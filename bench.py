@@ -246,9 +246,20 @@ def kernel_rooflines(dev, hp, ngp_net):
     def enc_fwd(pos):
         net.encode(pos, net.s_feat)
 
+    # table gradient WITH the optimiser step on the touched entries (round 3: Adam lives in the flush of the accumulation),
+    # on scratch copies of the parameters / moments
+    cf = net.cfg
+    bw = {k: torch.zeros_like(net.grid_master) for k in ("master", "m1", "m2")}
+    bw["hp"] = torch.zeros_like(net.grid_half)
+    wsb = int(lib().ns_ngp_encode_backward_fused_workspace_bytes(*net._grid_args(), C.c_long(N)))
+    bws = torch.zeros(wsb // 8 + 1, dtype=torch.int64, device=dev)
+
     def enc_bwd(pos):
-        check(lib().ns_ngp_encode_backward(*net._grid_args(), ptr(pos), ptr(dfeat), 1, ptr(net.grid_grad), ptr(net.enc_ws),
-                                           C.c_float(net.cfg.grad_fixed_scale), C.c_long(N), stream_ptr()), "ngp_encode_backward")
+        check(lib().ns_ngp_encode_backward_fused_n(*net._grid_args(), ptr(pos), ptr(dfeat), None, ptr(bws), C.c_size_t(wsb),
+                                                   C.c_float(cf.grad_fixed_scale), C.c_long(N), None, ptr(bw["master"]), ptr(bw["hp"]),
+                                                   ptr(bw["m1"]), ptr(bw["m2"]), 7, C.c_float(cf.lr), C.c_float(cf.beta1),
+                                                   C.c_float(cf.beta2), C.c_float(cf.eps), C.c_float(cf.loss_scale), None, 15, stream_ptr()),
+              "ngp_encode_backward_fused")
     for k, fn, per in (("ngp_encode_fwd_kernel[2^18]", enc_fwd, 588), ("ngp_encode_bwd[2^18]", enc_bwd, 1100)):
         us = _train_us(lambda: fn(pos_rays))
         us_u = _train_us(lambda: fn(pos_unif))
@@ -257,9 +268,10 @@ def kernel_rooflines(dev, hp, ngp_net):
                   "avg_launch_us_uniform_random_positions": us_u,
                   "note": "samples ordered along rays as the marcher emits them (2048 rays x 128 steps); uniform random positions "
                           "(worst case for locality) in avg_launch_us_uniform_random_positions"}
-    out["ngp_encode_bwd[2^18]"]["note"] += ("; one call = 7 launches: ngp_zero_ints, ngp_enc_bin_count, ngp_enc_bin_scatter, "
-                                            "ngp_enc_bin_accum (hashed levels), ngp_encode_bwd_dense_rl, ngp_enc_dense_reduce (dense levels)")
-    net.grid_grad.zero_()
+    out["ngp_encode_bwd[2^18]"]["note"] += ("; one call = 4 launches: ngp_enc_fscatter, ngp_enc_faccum (hashed levels, Adam in the "
+                                            "flush), ngp_encode_bwd_dense_rl, ngp_enc_dense_reduce (dense levels, Adam in the reduce); the "
+                                            "optimiser step of the touched entries is INSIDE this time (round 2: a separate 93-us pass)")
+    del bw, bws
     # Adam over the hash grid: 18 B read (master, gradient word, two moments, ...) + 14 B written per parameter
     c = net.cfg
     n_par = net.grid_master.numel()

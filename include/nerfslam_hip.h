@@ -480,6 +480,12 @@ int ns_ngp_adam_ctl(float* master, void* half_params, float* grad, float* m1, fl
                     float beta2, float eps, float l2, float grad_scale, float fixed_scale, const int* ctl, void* stream);
 int ns_ngp_step_advance(int* ctl, int* counter, int* last, float fill, long max_samples, int min_rays, int max_rays,
                         float beta1, float beta2, void* stream);
+/* Double-buffered form of the above (round 3; nerfslam/ngp.py): opens the side branch of step k that samples and marches the
+ * rays of step k + 1 into the OTHER set of {control block, counters, ray tables, sample arrays}: ctl_dst <- {step + 1, ray
+ * count adapted from THIS step's sample count, seed, views, Adam bias corrections}, last <- this step's counters (lazy host
+ * reads), counter_dst <- 0.                                                                                              */
+int ns_ngp_step_prepare(const int* ctl_src, int* ctl_dst, const int* counter_src, int* counter_dst, int* last, float fill,
+                        long max_samples, int min_rays, int max_rays, float beta1, float beta2, void* stream);
 /* the two halves of ns_ngp_step_advance: `_rays` (counters -> last, next ray count, counters cleared) may run as soon as the
  * backward pass is done, so that the next step's ns_ngp_sample_rays_ctl(step_offset = 1) + ns_ngp_march_ctl overlap this
  * step's optimiser pass; `_count` (ctl[0] += 1, Adam's bias corrections) closes the step after both have finished. */
@@ -499,6 +505,27 @@ int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_hashmap, int
 int ns_ngp_encode_backward_input_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
                                    const float* positions, const void* params, const void* dLdoutT, float* dLdpos, long N,
                                    const int* n_dev, void* stream);
+/* Table gradient of the hash grid with the optimiser step fused into it (round 3; tiny-cuda-nn GridEncoding backward +
+ * Adam with its skip-zero-gradient rule, [EXTERNAL] instant-ngp behind fusion/nerf_fusion.py:291-307):
+ *   dLdoutT: unit-major [2 n_levels][N] f16 (what ns_ngp_mlp_dgrad_n writes); fixed_scale > 0 (packed Q fixed point);
+ *   workspace: ns_ngp_encode_backward_fused_workspace_bytes(..., max_samples >= N) bytes of device memory, ZEROED ONCE by
+ *     the caller and private to this entry point afterwards (it leaves its overflow counter cleared); the size is checked;
+ *   master != NULL: Adam is applied to every touched table entry in the flush of the accumulation (master / m1 / m2 f32,
+ *     half_params the f16 working copy; bias corrections from `step`, or from the device control block `ctl` as
+ *     ns_ngp_adam_ctl); grad_params is then not written and may be NULL;
+ *   master == NULL: the packed sums are ADDED to grad_params (same bits as ns_ngp_encode_backward).
+ *   parts: mask of 1 = scatter of the hashed levels (records), 2 = their accumulation (+ Adam), 4 = accumulation of the dense
+ *     levels (partial planes), 8 = their reduction (+ Adam); 15 = the whole gradient.  1 before 2, 4 before 8; the hashed and
+ *     the dense halves touch disjoint table entries and disjoint parts of the workspace (the trainer runs them on two streams,
+ *     and holds the two Adam-applying passes back until the pose refinement has read the table).
+ * No count pass, no global atomics on table entries, nothing dropped: runs that outgrow their slot spill to a list.   */
+size_t ns_ngp_encode_backward_fused_workspace_bytes(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                                    float per_level_scale, long max_samples);
+int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                                   const float* positions, const void* dLdoutT, float* grad_params, void* workspace,
+                                   size_t workspace_bytes, float fixed_scale, long N, const int* n_dev, float* master,
+                                   void* half_params, float* m1, float* m2, int step, float lr, float beta1, float beta2,
+                                   float eps, float grad_scale, const int* ctl, int parts, void* stream);
 int ns_ngp_mlp_forward_n(const void* weights, const void* featT, const float* dirs, void* out, void* h1T, void* cinT, void* h3T,
                          void* h4T, long N, const int* n_dev, void* stream);
 int ns_ngp_mlp_backward_n(const void* weights, const void* dLdout, const void* featT, const void* h1T, const void* cinT,

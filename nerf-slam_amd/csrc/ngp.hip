@@ -207,6 +207,24 @@ __device__ __forceinline__ void unpack_fixed(unsigned long long w, float inv_S, 
   g1 = (float)hi * inv_S;
 }
 
+// One Adam update of one parameter (tiny-cuda-nn semantics; the caller skips zero-gradient entries when there is no weight
+// decay).  ONE definition, inlined into the streaming pass (ngp_adam_kernel) and into the fused flushes of the table
+// gradient (ngp_enc_faccum_kernel / ngp_enc_dense_reduce_kernel): the same expression tree, hence the same contractions
+// and the same bits from either path (tests/test_ngp_gpu.py::test_fused_table_gradient_adam_is_bit_identical).
+__device__ __forceinline__ float adam_apply(float p, float g, float l2, float& m1, float& m2, float c1, float c2, float lr,
+                                            float beta1, float beta2, float eps) {
+  // every operation pinned (no contraction left to the compiler: the two call sites contracted `beta * m + (1 - beta) * g`
+  // differently and their parameters drifted apart by an ulp from the second step on)
+  g = __fmaf_rn(l2, p, g);
+  const float a = __fmaf_rn(beta1, m1, __fmul_rn(1.0f - beta1, g));
+  const float b = __fmaf_rn(beta2, m2, __fmul_rn(__fmul_rn(1.0f - beta2, g), g));
+  m1 = a;
+  m2 = b;
+  const float num = __fmul_rn(lr, __fdiv_rn(a, c1));
+  const float den = __fadd_rn(__fsqrt_rn(__fdiv_rn(b, c2)), eps);
+  return __fsub_rn(p, __fdiv_rn(num, den));
+}
+
 // Backward of the encode: scatter-add of the 8 trilinear corner contributions per (sample, level).
 // Samples arrive in ray order, so on the coarse levels long runs of consecutive lanes fall into the SAME
 // cell (level 0: every sample of a small scene hits a few dozen table entries); plain atomics then
@@ -647,11 +665,46 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_dense_rl_kernel(GridLayou
   }
 }
 
-// sum of the partial planes of the dense levels (entries [0, n_dense) of the grid) into the gradient
+// Adam state handed to the fused flushes (master == nullptr: gradient only)
+struct AdamFuse {
+  float* master;
+  _Float16* hp;
+  float* m1;
+  float* m2;
+  float c1, c2, lr, beta1, beta2, eps, inv_grad_scale, inv_fixed_scale;
+  const int* ctl;
+};
+
+// Adam on the two parameters of table entry `entry` from the packed fixed-point sum `word` (!= 0); parameters whose own
+// gradient is zero are skipped, as ngp_adam_kernel does with l2 = 0
+__device__ __forceinline__ void adam_entry(const AdamFuse& ad, long entry, unsigned long long word, float c1, float c2) {
+  float g0, g1;
+  unpack_fixed(word, ad.inv_fixed_scale, g0, g1);
+  g0 *= ad.inv_grad_scale;
+  g1 *= ad.inv_grad_scale;
+  float2* __restrict__ mp = reinterpret_cast<float2*>(ad.master) + entry;
+  float2* __restrict__ ap = reinterpret_cast<float2*>(ad.m1) + entry;
+  float2* __restrict__ bp = reinterpret_cast<float2*>(ad.m2) + entry;
+  float2 p = *mp, a = *ap, b = *bp;
+  if (g0 != 0.0f) p.x = adam_apply(p.x, g0, 0.0f, a.x, b.x, c1, c2, ad.lr, ad.beta1, ad.beta2, ad.eps);
+  if (g1 != 0.0f) p.y = adam_apply(p.y, g1, 0.0f, a.y, b.y, c1, c2, ad.lr, ad.beta1, ad.beta2, ad.eps);
+  *mp = p;
+  *ap = a;
+  *bp = b;
+  h2_t h;
+  h[0] = (_Float16)p.x;
+  h[1] = (_Float16)p.y;
+  reinterpret_cast<h2_t*>(ad.hp)[entry] = h;
+}
+
+// sum of the partial planes of the dense levels (entries [0, n_dense) of the grid) into the gradient -- or, with Adam state,
+// straight into the parameters (the gradient buffer is then not touched).  `reset` (may be null): counters of the fused
+// binned path cleared by this, the last kernel of its launch sequence.
 __global__ __launch_bounds__(256) void ngp_enc_dense_reduce_kernel(GridLayout g, EncBwdPlan plan, int n_levels,
                                                                    const unsigned long long* __restrict__ partial, long n_dense,
-                                                                   float* __restrict__ grad) {
+                                                                   float* __restrict__ grad, AdamFuse ad, int* __restrict__ reset) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (reset != nullptr && e == 0) *reset = 0;
   if (e >= n_dense) return;
   int l = 0;
   while (l + 1 < n_levels && (long)g.offset[l + 1] <= e) l++;
@@ -659,7 +712,13 @@ __global__ __launch_bounds__(256) void ngp_enc_dense_reduce_kernel(GridLayout g,
   const unsigned long long* __restrict__ src = partial + plan.plane_base[l] + (e - (long)g.offset[l]);
   unsigned long long sum = 0ull;
   for (int p = 0; p < plan.parts[l]; p++) sum += src[(long)p * hs];
-  if (sum != 0ull) reinterpret_cast<unsigned long long*>(grad)[e] += sum;
+  if (sum == 0ull) return;
+  if (ad.master != nullptr) {
+    const float c1 = ad.ctl ? __int_as_float(ad.ctl[NS_CTL_C1]) : ad.c1, c2 = ad.ctl ? __int_as_float(ad.ctl[NS_CTL_C2]) : ad.c2;
+    adam_entry(ad, e, sum, c1, c2);
+  } else {
+    reinterpret_cast<unsigned long long*>(grad)[e] += sum;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -946,6 +1005,323 @@ __global__ __launch_bounds__(1024) void ngp_enc_bin_accum_kernel(GridLayout g, B
 }
 
 // ---------------------------------------------------------------------------------------------
+// Binned path, round 3: NO count pass, NO global atomics at all, runs merged before they are written, finer bins, Adam fused
+// into the flush.
+//
+// The count kernel existed to give every (tile, bin) run its place in a densely packed queue, and paid for it with a pass
+// over the samples and a returning global atomic per (tile, bin).  Here every (level, bin, tile) owns a FIXED slot of
+// NS_FB_SLOT records (4 x the mean load) and the scatter writes the number of records it put there next to it: no
+// reservation, no counters to keep zeroed, no dependency on another workgroup anywhere in the kernel.  A run that outgrows its
+// slot spills into an overflow list sized for the worst case (one atomic per spilling run; every accumulate workgroup scans
+// the list, which is empty unless more than 1/16 of a tile's records meet in one of the 64 bins), so no record is ever lost.
+// A lane owns FOUR CONSECUTIVE samples -- consecutive steps of one ray -- and sums the contributions of neighbours that fall
+// into the same cell of the level before it emits records (exact: the per-contribution roundings are integers already):
+// on the coarser hashed levels a cell holds several steps of a ray, which removes a quarter of the record stream on the
+// trainer's rays; the positions arrive as three 16-byte loads, the gradients as 8-byte ones.
+// Bins are 8192-entry slices (64 KB of LDS accumulators, two 512-lane workgroups per CU): 768 work items of half the length
+// balance better over 256 CUs than 384, and one workgroup's flush (an HBM stream) overlaps its neighbour's record loop.
+// The flush applies Adam to the touched entries in place (`AdamFuse`): the sums sit in LDS, the entry's master / moments are
+// read once and written once -- the round-2 sequence wrote the sum to the gradient buffer (16 B per entry), and a separate
+// pass streamed the whole table (68 B per entry, touched or not: 105 us with real gradients).  Semantics unchanged:
+// zero-gradient parameters are skipped (tiny-cuda-nn), arithmetic shared with ngp_adam_kernel through adam_apply().
+// ---------------------------------------------------------------------------------------------
+#define NS_FB_SLICE 8192
+#define NS_FB_SHIFT 13
+#define NS_FB_BINS 64
+#define NS_FB_SLOT 512
+#define NS_FB_RUN 4      // consecutive samples per lane
+struct FusedPlan {
+  int nh;            // hashed levels
+  int level[16];     // k -> level
+  int nbins[16];     // k -> bins of the level (<= 64)
+  int ntiles;        // ceil(N / 1024)
+  long ovf_cap;      // entries of the overflow list
+};
+
+static bool fused_plan_host(const GridLayout& g, int n_levels, long N, FusedPlan& f) {
+  f.nh = 0;
+  for (int l = 0; l < n_levels; l++) {
+    if (!level_is_hashed(g, l)) continue;
+    const uint32_t hs = g.offset[l + 1] - g.offset[l];
+    const int nb = (int)((hs + NS_FB_SLICE - 1) / NS_FB_SLICE);
+    if (nb > NS_FB_BINS) return false;
+    f.level[f.nh] = l;
+    f.nbins[f.nh] = nb;
+    f.nh++;
+  }
+  for (int k = f.nh; k < 16; k++) f.level[k] = f.nbins[k] = 0;
+  f.ntiles = (int)((N + NS_BIN_TILE - 1) / NS_BIN_TILE);
+  f.ovf_cap = (long)f.ntiles * NS_BIN_TILE * 8 * (f.nh > 0 ? f.nh : 1);
+  return f.nh > 0;
+}
+// workspace: [ctr: {overflow count, error flag}] [cnt: nh*64*ntiles run lengths] [queue: nh*64*ntiles slots of NS_FB_SLOT
+// records] [overflow list] [partial planes of the dense levels]
+static size_t fused_ws_ctr_bytes(const FusedPlan&) { return 256; }
+static size_t fused_ws_cnt_bytes(const FusedPlan& f) { return ((size_t)f.nh * NS_FB_BINS * f.ntiles * 4 + 255) / 256 * 256; }
+static size_t fused_ws_queue_bytes(const FusedPlan& f) { return (size_t)f.nh * NS_FB_BINS * (size_t)f.ntiles * NS_FB_SLOT * 8; }
+static size_t fused_ws_ovf_bytes(const FusedPlan& f) { return (size_t)f.ovf_cap * 16; }
+static size_t fused_ws_bytes(const FusedPlan& f, const GridLayout& g, int n_levels) {
+  const long nd = dense_prefix_entries(g, n_levels);
+  return fused_ws_ctr_bytes(f) + fused_ws_cnt_bytes(f) + fused_ws_queue_bytes(f) + fused_ws_ovf_bytes(f) +
+         (nd > 0 ? (size_t)NS_ENC_PARTS_COARSE * (size_t)nd * 8 : 0);
+}
+
+// one merged run of a lane: the cell and the summed integer contributions of its 8 corners
+struct FbRun {
+  uint32_t c[3];
+  int a[8], b[8];
+};
+
+__device__ __forceinline__ void fb_indices(const uint32_t c[3], uint32_t hs, uint32_t idx[8]) {
+  const uint32_t hx[2] = {c[0], c[0] + 1u};
+  const uint32_t hy0 = c[1] * 2654435761u, hz0 = c[2] * 805459861u;
+  const uint32_t hy[2] = {hy0, hy0 + 2654435761u};
+  const uint32_t hz[2] = {hz0, hz0 + 805459861u};
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) idx[corner] = (hx[corner & 1] ^ hy[(corner >> 1) & 1] ^ hz[corner >> 2]) & (hs - 1u);
+}
+
+__global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, FusedPlan fp, const float* __restrict__ pos,
+                                                               const _Float16* __restrict__ dpu, long N, float fixed_scale,
+                                                               int* __restrict__ ctr, int* __restrict__ cnt,
+                                                               unsigned long long* __restrict__ queue,
+                                                               ulonglong2* __restrict__ ovf, const int* __restrict__ n_dev,
+                                                               int vec) {
+  __shared__ unsigned long long rec[8 * NS_BIN_TILE];   // 64 KB: the tile's records, bin-sorted
+  __shared__ int lbase[NS_FB_BINS + 1], lcnt[NS_FB_BINS], odst[NS_FB_BINS];
+  const int k = blockIdx.y, l = fp.level[k], tile = blockIdx.x, tid = threadIdx.x;
+  const uint32_t hs = g.offset[l + 1] - g.offset[l];
+  const long nvalid = n_dev ? min(N, (long)*n_dev) : N;
+  if ((long)tile * NS_BIN_TILE >= nvalid) return;       // (uniform) nothing marched into this tile
+  if (tid < NS_FB_BINS) lcnt[tid] = 0;
+  // ---- loads: 4 consecutive samples per lane ----
+  const long i0 = (long)tile * NS_BIN_TILE + (long)tid * NS_FB_RUN;
+  float px[NS_FB_RUN][3], d0[NS_FB_RUN], d1[NS_FB_RUN];
+  const _Float16* __restrict__ g0p = dpu + (long)(2 * l) * N;
+  const _Float16* __restrict__ g1p = g0p + N;
+  if (vec && i0 + NS_FB_RUN <= nvalid) {
+    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(pos + i0 * 3);
+    const float4 A = p4[0], B = p4[1], Cc = p4[2];
+    px[0][0] = A.x; px[0][1] = A.y; px[0][2] = A.z;
+    px[1][0] = A.w; px[1][1] = B.x; px[1][2] = B.y;
+    px[2][0] = B.z; px[2][1] = B.w; px[2][2] = Cc.x;
+    px[3][0] = Cc.y; px[3][1] = Cc.z; px[3][2] = Cc.w;
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    const h4_t ga = *reinterpret_cast<const h4_t*>(g0p + i0), gb = *reinterpret_cast<const h4_t*>(g1p + i0);
+#pragma unroll
+    for (int j = 0; j < NS_FB_RUN; j++) {
+      d0[j] = (float)ga[j];
+      d1[j] = (float)gb[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NS_FB_RUN; j++) {
+      const long i = i0 + j;
+      const bool ok = i < nvalid;
+      px[j][0] = ok ? pos[i * 3] : 0.0f;
+      px[j][1] = ok ? pos[i * 3 + 1] : 0.0f;
+      px[j][2] = ok ? pos[i * 3 + 2] : 0.0f;
+      d0[j] = ok ? (float)g0p[i] : 0.0f;
+      d1[j] = ok ? (float)g1p[i] : 0.0f;
+    }
+  }
+  // ---- merge neighbours that share a cell ----
+  FbRun run[NS_FB_RUN];
+  int nrun = 0;
+  bool open = false, open_small = false;
+  const float scale = g.scale[l];
+  const float lim = 16777215.0f;   // 25-bit signed record fields
+#pragma unroll
+  for (int j = 0; j < NS_FB_RUN; j++) {
+    if (d0[j] == 0.0f && d1[j] == 0.0f) continue;   // zero upstream gradient: the sample contributes nothing (as bin_sample)
+    uint32_t c[3];
+    float w[3];
+#pragma unroll
+    for (int dd = 0; dd < 3; dd++) {
+      const float p = fmaf(scale, px[j][dd], 0.5f);
+      const float fl = floorf(p);
+      c[dd] = (uint32_t)(int)fl;
+      w[dd] = p - fl;
+    }
+    const float wx[2] = {1.0f - w[0], w[0]}, wy[2] = {1.0f - w[1], w[1]}, wz[2] = {1.0f - w[2], w[2]};
+    int ca[8], cb[8];
+    int big = 0;
+#pragma unroll
+    for (int corner = 0; corner < 8; corner++) {
+      const float wt = wx[corner & 1] * wy[(corner >> 1) & 1] * wz[corner >> 2];
+      ca[corner] = (int)__float2int_rn(fminf(fmaxf(wt * d0[j] * fixed_scale, -lim), lim));
+      cb[corner] = (int)__float2int_rn(fminf(fmaxf(wt * d1[j] * fixed_scale, -lim), lim));
+      big |= abs(ca[corner]) | abs(cb[corner]);
+    }
+    const bool small = big < (1 << 21);   // four such contributions stay inside the 25-bit field
+    // (static indexing only: `run` must stay in registers, so the open run is always run[nrun - 1] addressed by unrolled selects)
+    bool merged = false;
+#pragma unroll
+    for (int r = 0; r < NS_FB_RUN; r++) {
+      if (r == nrun - 1 && open && open_small && small && run[r].c[0] == c[0] && run[r].c[1] == c[1] && run[r].c[2] == c[2]) {
+#pragma unroll
+        for (int corner = 0; corner < 8; corner++) {
+          run[r].a[corner] += ca[corner];
+          run[r].b[corner] += cb[corner];
+        }
+        merged = true;
+      }
+    }
+    if (!merged) {
+#pragma unroll
+      for (int r = 0; r < NS_FB_RUN; r++) {
+        if (r == nrun) {
+          run[r].c[0] = c[0]; run[r].c[1] = c[1]; run[r].c[2] = c[2];
+#pragma unroll
+          for (int corner = 0; corner < 8; corner++) {
+            run[r].a[corner] = ca[corner];
+            run[r].b[corner] = cb[corner];
+          }
+        }
+      }
+      nrun++;
+      open = true;
+      open_small = small;
+    }
+  }
+  __syncthreads();
+  // ---- rank the records inside their bins ----
+  int rank[NS_FB_RUN][8];
+#pragma unroll
+  for (int r = 0; r < NS_FB_RUN; r++) {
+    if (r < nrun) {
+      uint32_t idx[8];
+      fb_indices(run[r].c, hs, idx);
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) rank[r][corner] = atomicAdd(&lcnt[idx[corner] >> NS_FB_SHIFT], 1);
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {   // one wave: the tile's bin counts -> LDS bases, run lengths next to the slots, spills reserved
+    const int c = lcnt[tid];
+    int ci = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int uc = __shfl_up(ci, d, 64);
+      if (tid >= d) ci += uc;
+    }
+    lbase[tid] = ci - c;
+    if (tid == 63) lbase[64] = ci;
+    cnt[(long)(k * NS_FB_BINS + tid) * fp.ntiles + tile] = min(c, NS_FB_SLOT);
+    odst[tid] = c > NS_FB_SLOT ? atomicAdd(&ctr[0], c - NS_FB_SLOT) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < NS_FB_RUN; r++) {
+    if (r < nrun) {
+      uint32_t idx[8];
+      fb_indices(run[r].c, hs, idx);
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++)
+        rec[lbase[idx[corner] >> NS_FB_SHIFT] + rank[r][corner]] =
+            ((unsigned long long)(idx[corner] & (NS_FB_SLICE - 1u)) << 50) |
+            ((unsigned long long)((uint32_t)run[r].b[corner] & 0x1ffffffu) << 25) |
+            (unsigned long long)((uint32_t)run[r].a[corner] & 0x1ffffffu);
+    }
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int b = wave; b < NS_FB_BINS; b += 4) {
+    const int b0 = lbase[b], n = lbase[b + 1] - b0;
+    unsigned long long* __restrict__ dst = queue + ((long)(k * NS_FB_BINS + b) * fp.ntiles + tile) * NS_FB_SLOT;
+    for (int e = lane; e < n; e += 64) {
+      const unsigned long long r = rec[b0 + e];
+      if (e < NS_FB_SLOT) {
+        dst[e] = r;
+      } else {
+        const long o = (long)odst[b] + (e - NS_FB_SLOT);
+        if (o < fp.ovf_cap) ovf[o] = make_ulonglong2(r, (unsigned long long)((k << 8) | b));
+        else ctr[1] = 1;   // cannot happen with the worst-case list; flagged, never silent
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void fb_add(unsigned long long* tab, unsigned long long r) {
+  const uint32_t rel = (uint32_t)(r >> 50);
+  const long long a = ((long long)(r << 39)) >> 39;          // sign-extended 25-bit fields
+  const long long c = ((long long)(r << 14)) >> 39;
+  atomicAdd(&tab[rel], (unsigned long long)(a + (c << 32)));
+}
+
+#define NS_FB_THREADS 512
+#define NS_FB_GROUP 4     // slots a wave has in flight (two 64-record chunks each)
+__global__ __launch_bounds__(NS_FB_THREADS) void ngp_enc_faccum_kernel(GridLayout g, FusedPlan fp, const int* __restrict__ ctr,
+                                                                       const int* __restrict__ cnt,
+                                                                       const unsigned long long* __restrict__ queue,
+                                                                       const ulonglong2* __restrict__ ovf,
+                                                                       float* __restrict__ grad, AdamFuse ad, long N,
+                                                                       const int* __restrict__ n_dev) {
+  __shared__ unsigned long long tab[NS_FB_SLICE];
+  __shared__ int scnt[NS_FB_THREADS];
+  const int k = blockIdx.y, l = fp.level[k], b = blockIdx.x, tid = threadIdx.x;
+  if (b >= fp.nbins[k]) return;
+  const uint32_t hs = g.offset[l + 1] - g.offset[l];
+  const uint32_t lo = (uint32_t)b * NS_FB_SLICE;
+  const uint32_t n_e = min((uint32_t)NS_FB_SLICE, hs - lo);
+  const long nvalid = n_dev ? min(N, (long)*n_dev) : N;
+  const int ntv = (int)((nvalid + NS_BIN_TILE - 1) / NS_BIN_TILE);   // tiles the scatter pass wrote
+  for (uint32_t e = tid; e < NS_FB_SLICE; e += NS_FB_THREADS) tab[e] = 0ull;
+  const long row = (long)(k * NS_FB_BINS + b) * fp.ntiles;
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int t0 = 0; t0 < ntv; t0 += NS_FB_THREADS) {
+    __syncthreads();
+    scnt[tid] = t0 + tid < ntv ? cnt[row + t0 + tid] : 0;
+    __syncthreads();
+    const int nt = min(NS_FB_THREADS, ntv - t0);
+    for (int tt = wave * NS_FB_GROUP; tt < nt; tt += (NS_FB_THREADS / 64) * NS_FB_GROUP) {
+      int c[NS_FB_GROUP];
+      unsigned long long r[NS_FB_GROUP][2];
+#pragma unroll
+      for (int u = 0; u < NS_FB_GROUP; u++) {
+        c[u] = tt + u < nt ? scnt[tt + u] : 0;
+        const unsigned long long* __restrict__ q = queue + (row + t0 + tt + u) * NS_FB_SLOT;
+        r[u][0] = lane < c[u] ? q[lane] : 0ull;          // (a zero record adds zero to entry 0: no branch in the add loop)
+        r[u][1] = lane + 64 < c[u] ? q[lane + 64] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < NS_FB_GROUP; u++) {
+        if (r[u][0] != 0ull) fb_add(tab, r[u][0]);
+        if (r[u][1] != 0ull) fb_add(tab, r[u][1]);
+      }
+#pragma unroll
+      for (int u = 0; u < NS_FB_GROUP; u++) {            // slots filled beyond the mean: the rest of the run
+        const unsigned long long* __restrict__ q = queue + (row + t0 + tt + u) * NS_FB_SLOT;
+        for (int e = lane + 128; e < c[u]; e += 64) fb_add(tab, q[e]);
+      }
+    }
+  }
+  const int novf = (int)min((long)ctr[0], fp.ovf_cap);
+  if (novf > 0) {
+    const unsigned long long tag = (unsigned long long)((k << 8) | b);
+    for (int e = tid; e < novf; e += NS_FB_THREADS) {
+      const ulonglong2 r = ovf[e];
+      if (r.y == tag) fb_add(tab, r.x);
+    }
+  }
+  __syncthreads();
+  const long base = (long)g.offset[l] + lo;
+  if (ad.master != nullptr) {
+    const float c1 = ad.ctl ? __int_as_float(ad.ctl[NS_CTL_C1]) : ad.c1, c2 = ad.ctl ? __int_as_float(ad.ctl[NS_CTL_C2]) : ad.c2;
+    for (uint32_t e = tid; e < n_e; e += NS_FB_THREADS) {
+      const unsigned long long word = tab[e];
+      if (word != 0ull) adam_entry(ad, base + e, word, c1, c2);
+    }
+  } else {
+    unsigned long long* __restrict__ g64 = reinterpret_cast<unsigned long long*>(grad) + base;
+    for (uint32_t e = tid; e < n_e; e += NS_FB_THREADS) {
+      const unsigned long long word = tab[e];
+      if (word != 0ull) g64[e] += word;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Camera-pose refinement (`optimize_extrinsics`, nerf_fusion.py:99,123 [EXTERNAL arithmetic: instant-ngp]).
 //   dL/dpos of every sample  = the encoding's input gradient (trilinear weights differentiated),
 //   per ray:  g_o = sum dL/dpos,   g_d = sum t * dL/dpos            (pos = o + t d)
@@ -1160,12 +1536,10 @@ __global__ __launch_bounds__(256) void ngp_adam_kernel(float* __restrict__ maste
   grad[i] = 0.0f;  // leaves the gradient buffer ready for the next step (each lane clears its half of the word)
   float p = master[i];
   if (!(g == 0.0f && l2 == 0.0f)) {
-    g += l2 * p;
-    const float a = beta1 * m1[i] + (1.0f - beta1) * g;
-    const float b = beta2 * m2[i] + (1.0f - beta2) * g * g;
+    float a = m1[i], b = m2[i];
+    p = adam_apply(p, g, l2, a, b, c1, c2, lr, beta1, beta2, eps);
     m1[i] = a;
     m2[i] = b;
-    p -= lr * (a / c1) / (sqrtf(b / c2) + eps);
     master[i] = p;
   }
   hp[i] = (_Float16)p;
@@ -1769,8 +2143,9 @@ extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_h
                              (const h2_t*)dLdout, grad_params, N, n_levels, n_levels, unit_major, fixed_scale, partial, n_dev);
           NS_CHECK_LAUNCH("ngp_encode_bwd_lds_kernel");
         }
+        AdamFuse no_adam{};
         hipLaunchKernelGGL(ngp_enc_dense_reduce_kernel, dim3(ns_cdiv(nd, 256)), dim3(256), 0, (hipStream_t)stream, g, plan, n_levels,
-                           partial, nd, grad_params);
+                           partial, nd, grad_params, no_adam, (int*)nullptr);
         NS_CHECK_LAUNCH("ngp_enc_dense_reduce_kernel");
         return NS_OK;
       }
@@ -1796,6 +2171,107 @@ extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_h
                        n_levels, workspace, grad_params, fixed_scale);
     NS_CHECK_LAUNCH("ngp_encode_bwd_reduce_kernel");
   }
+  return NS_OK;
+}
+
+extern "C" size_t ns_ngp_encode_backward_fused_workspace_bytes(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                                               float per_level_scale, long max_samples) {
+  GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
+  GridLayout g;
+  if (grid_layout_host(c, g) != NS_OK) return 0;
+  FusedPlan fp;
+  if (!fused_plan_host(g, n_levels, max_samples > 0 ? max_samples : 1, fp)) return 0;
+  return fused_ws_bytes(fp, g, n_levels);
+}
+
+extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                              float per_level_scale, const float* positions, const void* dLdoutT,
+                                              float* grad_params, void* workspace, size_t workspace_bytes, float fixed_scale,
+                                              long N, const int* n_dev, float* master, void* half_params, float* m1,
+                                              float* m2, int step, float lr, float beta1, float beta2, float eps,
+                                              float grad_scale, const int* ctl, int parts, void* stream) {
+  NS_REQUIRE(positions && dLdoutT && workspace, "ns_ngp_encode_backward_fused: null pointer");
+  NS_REQUIRE(parts >= 1 && parts <= 15, "ns_ngp_encode_backward_fused: parts is a mask of 1 | 2 | 4 | 8");
+  NS_REQUIRE(fixed_scale > 0.0f, "ns_ngp_encode_backward_fused: packed fixed-point sums only (fixed_scale > 0)");
+  const bool adam = master != nullptr;
+  NS_REQUIRE(adam || grad_params, "ns_ngp_encode_backward_fused: neither a gradient buffer nor Adam state");
+  NS_REQUIRE(!adam || (half_params && m1 && m2 && grad_scale > 0.0f && (ctl || step >= 1)),
+             "ns_ngp_encode_backward_fused: incomplete Adam state");
+  GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
+  GridLayout g;
+  if (grid_layout_host(c, g) != NS_OK) {
+    ns_set_error("ns_ngp_encode_backward_fused: need 1..16 levels and 2 features per level");
+    return NS_ENOSUP;
+  }
+  if (N <= 0) return NS_OK;
+  FusedPlan fp;
+  if (!fused_plan_host(g, n_levels, N, fp)) {
+    ns_set_error("ns_ngp_encode_backward_fused: no hashed level / tables above 64 x 8192 entries: use ns_ngp_encode_backward");
+    return NS_ENOSUP;
+  }
+  const size_t need = fused_ws_bytes(fp, g, n_levels);
+  NS_REQUIRE(workspace_bytes >= need, "ns_ngp_encode_backward_fused: workspace of %zu B, N=%ld needs %zu", workspace_bytes, N, need);
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = reinterpret_cast<char*>(workspace);
+  int* ctr = reinterpret_cast<int*>(ws);
+  int* cnt = reinterpret_cast<int*>(ws + fused_ws_ctr_bytes(fp));
+  unsigned long long* queue = reinterpret_cast<unsigned long long*>(ws + fused_ws_ctr_bytes(fp) + fused_ws_cnt_bytes(fp));
+  ulonglong2* ovf = reinterpret_cast<ulonglong2*>(ws + fused_ws_ctr_bytes(fp) + fused_ws_cnt_bytes(fp) + fused_ws_queue_bytes(fp));
+  unsigned long long* partial = reinterpret_cast<unsigned long long*>(ws + fused_ws_ctr_bytes(fp) + fused_ws_cnt_bytes(fp) +
+                                                                      fused_ws_queue_bytes(fp) + fused_ws_ovf_bytes(fp));
+  AdamFuse ad{};
+  if (adam) {
+    ad.master = master;
+    ad.hp = (_Float16*)half_params;
+    ad.m1 = m1;
+    ad.m2 = m2;
+    ad.c1 = 1.0f - powf(beta1, (float)(step < 1 ? 1 : step));
+    ad.c2 = 1.0f - powf(beta2, (float)(step < 1 ? 1 : step));
+    ad.lr = lr;
+    ad.beta1 = beta1;
+    ad.beta2 = beta2;
+    ad.eps = eps;
+    ad.inv_grad_scale = 1.0f / grad_scale;
+    ad.inv_fixed_scale = 1.0f / fixed_scale;
+    ad.ctl = ctl;
+  }
+  const long nd = dense_prefix_entries(g, n_levels);
+  NS_REQUIRE(nd >= 0, "ns_ngp_encode_backward_fused: dense levels above hashed ones");
+  if (parts & 1) {
+    const int vec = (N % 4 == 0 && ((uintptr_t)positions % 16) == 0 && ((uintptr_t)dLdoutT % 8) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(ngp_enc_fscatter_kernel, dim3(fp.ntiles, fp.nh), dim3(256), 0, st, g, fp, positions, (const _Float16*)dLdoutT,
+                       N, fixed_scale, ctr, cnt, queue, ovf, n_dev, vec);
+    NS_CHECK_LAUNCH("ngp_enc_fscatter_kernel");
+  }
+  if (parts & 2) {
+    hipLaunchKernelGGL(ngp_enc_faccum_kernel, dim3(NS_FB_BINS, fp.nh), dim3(NS_FB_THREADS), 0, st, g, fp, ctr, cnt, queue, ovf,
+                       grad_params, ad, N, n_dev);
+    NS_CHECK_LAUNCH("ngp_enc_faccum_kernel");
+    // the overflow list is empty again for the next call (its only readers, the accumulate workgroups, are done)
+    hipLaunchKernelGGL(ngp_zero_ints_kernel, dim3(1), dim3(256), 0, st, ctr, 1);
+    NS_CHECK_LAUNCH("ngp_zero_ints_kernel");
+  }
+  if (!(parts & 12) || nd == 0) return NS_OK;
+  EncBwdPlan plan;
+  const bool rl = N % 8 == 0 && ((uintptr_t)positions % 16) == 0 && ((uintptr_t)dLdoutT % 16) == 0;
+  const int tasks = rl ? enc_bwd_plan_host(g, n_levels, plan, true, 16, 8) : enc_bwd_plan_host(g, n_levels, plan, true);
+  const int blocks = (tasks + 7) / 8 * 8;
+  // the dense levels always go through their partial planes here (the reduce pass is where Adam is applied)
+  if (parts & 4) {
+    if (rl) {
+      hipLaunchKernelGGL(ngp_encode_bwd_dense_rl_kernel, dim3(blocks), dim3(1024), 0, st, g, plan, positions,
+                         (const _Float16*)dLdoutT, grad_params, N, fixed_scale, partial, n_dev);
+      NS_CHECK_LAUNCH("ngp_encode_bwd_dense_rl_kernel");
+    } else {
+      hipLaunchKernelGGL(ngp_encode_bwd_lds_kernel<true>, dim3(blocks), dim3(1024), 0, st, g, plan, positions,
+                         (const h2_t*)dLdoutT, grad_params, N, n_levels, n_levels, 1, fixed_scale, partial, n_dev);
+      NS_CHECK_LAUNCH("ngp_encode_bwd_lds_kernel");
+    }
+  }
+  if (!(parts & 8)) return NS_OK;
+  hipLaunchKernelGGL(ngp_enc_dense_reduce_kernel, dim3(ns_cdiv(nd, 256)), dim3(256), 0, st, g, plan, n_levels, partial, nd,
+                     grad_params, ad, (int*)nullptr);
+  NS_CHECK_LAUNCH("ngp_enc_dense_reduce_kernel");
   return NS_OK;
 }
 
@@ -1996,6 +2472,45 @@ __global__ void ngp_step_count_kernel(int* __restrict__ ctl, float beta1, float 
   ctl[NS_CTL_STEP] = done;
   ctl[NS_CTL_C1] = __float_as_int(1.0f - powf(beta1, (float)(done + 1)));
   ctl[NS_CTL_C2] = __float_as_int(1.0f - powf(beta2, (float)(done + 1)));
+}
+
+// Double-buffered form (round 3): every step owns a SET {control block, march counters, ray tables, sample arrays}; the rays of
+// step k + 1 are sampled and marched into the other set at the START of step k's launch sequence, on a side stream, next to
+// step k's forward / backward passes (the marcher is latency bound and reads only the occupancy bits and the images).  This
+// kernel opens that side branch: it derives the next step's control block from this step's -- step number + 1, ray count
+// adapted from THIS step's sample count (known since its march finished, one step earlier than the in-line rule could use
+// it), Adam's bias corrections -- records this step's march counters for lazy host reads and clears the other set's.
+__global__ void ngp_step_prepare_kernel(const int* __restrict__ ctl_src, int* __restrict__ ctl_dst,
+                                        const int* __restrict__ counter_src, int* __restrict__ counter_dst, int* __restrict__ last,
+                                        float fill, long max_samples, int min_rays, int max_rays, float beta1, float beta2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int requested = counter_src[0], R = ctl_src[NS_CTL_RAYS];
+  last[0] = requested;
+  last[1] = counter_src[1];
+  last[2] = counter_src[2];
+  last[3] = R;
+  const float want = (float)R * fill * (float)max_samples / (float)max(requested, 1);
+  int Rn = (int)fminf(fmaxf(want, (float)min_rays), (float)max_rays);
+  Rn = Rn / 128 * 128;
+  const int done = ctl_src[NS_CTL_STEP] + 1;
+  ctl_dst[NS_CTL_STEP] = done;
+  ctl_dst[NS_CTL_RAYS] = max(Rn, 128);
+  ctl_dst[NS_CTL_SEED] = ctl_src[NS_CTL_SEED];
+  ctl_dst[NS_CTL_VIEWS] = ctl_src[NS_CTL_VIEWS];
+  ctl_dst[NS_CTL_C1] = __float_as_int(1.0f - powf(beta1, (float)(done + 1)));
+  ctl_dst[NS_CTL_C2] = __float_as_int(1.0f - powf(beta2, (float)(done + 1)));
+  counter_dst[0] = counter_dst[1] = counter_dst[2] = 0;
+}
+
+extern "C" int ns_ngp_step_prepare(const int* ctl_src, int* ctl_dst, const int* counter_src, int* counter_dst, int* last, float fill,
+                                   long max_samples, int min_rays, int max_rays, float beta1, float beta2, void* stream) {
+  NS_REQUIRE(ctl_src && ctl_dst && counter_src && counter_dst && last, "ns_ngp_step_prepare: null pointer");
+  NS_REQUIRE(ctl_src != ctl_dst && counter_src != counter_dst, "ns_ngp_step_prepare: the two sets must be distinct");
+  NS_REQUIRE(fill > 0.0f && max_samples > 0 && min_rays >= 128 && max_rays >= min_rays, "ns_ngp_step_prepare: bad limits");
+  hipLaunchKernelGGL(ngp_step_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl_src, ctl_dst, counter_src, counter_dst,
+                     last, fill, max_samples, min_rays, max_rays, beta1, beta2);
+  NS_CHECK_LAUNCH("ngp_step_prepare_kernel");
+  return NS_OK;
 }
 
 extern "C" int ns_ngp_step_rays(int* ctl, int* counter, int* last, float fill, long max_samples, int min_rays, int max_rays,

@@ -16,6 +16,10 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libnerfslam_hip.so")
 
 _lock = threading.Lock()
 _lib = None
+# Held while a HIP graph is being captured; host threads that synchronise with the device (the tracker's read-backs under
+# --parallel_run) take it around those calls: ROCm 7.2 answered a synchronising call made by one thread while another was
+# capturing with hipErrorIllegalState even in thread-local capture mode.
+capture_lock = threading.RLock()
 
 
 NS_OK, NS_EINVAL, NS_ELAUNCH, NS_ENOSUP = 0, -1, -2, -3   # status codes of include/nerfslam_hip.h
@@ -42,6 +46,8 @@ def lib():
                 for name in [n for n in ("ns_ba_plan_index_count", "ns_ba_workspace_bytes") if hasattr(L, n)]:
                     getattr(L, name).restype = C.c_size_t
                 L.ns_ngp_encode_backward_workspace_bytes.restype = C.c_long
+                L.ns_ngp_encode_backward_fused_workspace_bytes.restype = C.c_size_t
+                L.ns_ba_solve_large_workspace_bytes.restype = C.c_size_t
                 _lib = L
     return _lib
 

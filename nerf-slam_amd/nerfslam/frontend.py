@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import ba_plan, se3
-from ._lib import check, lib, ptr, stream_ptr
+from ._lib import capture_lock, check, lib, ptr, stream_ptr
 from .corr import CorrPool
 from .factor_graph import FactorGraph
 
@@ -183,11 +183,13 @@ class TrackingFrontend:
         """(:712-775): distances on the device (one D2H of the distance vector), selection on the host."""
         t = self.kf_idx + 1
         I, J = np.meshgrid(np.arange(kf0, t), np.arange(kf1, t), indexing="ij")
-        d = self.distance(I.reshape(-1), J.reshape(-1)).cpu().numpy()
+        with capture_lock:      # (host read-back: not while the mapper thread captures its step graphs, see _lib.capture_lock)
+            d = self.distance(I.reshape(-1), J.reshape(-1)).cpu().numpy()
         es = self.graph.proximity_edges(d, self.kf_idx, kf0, kf1, rad, nms, thresh)
         if es:
             e = np.asarray(es, np.int64)
-            self.add_factors(e[:, 0], e[:, 1], remove)
+            with capture_lock:  # (the age permutation of add() is sorted on the device and read back)
+                self.add_factors(e[:, 0], e[:, 1], remove)
 
     # ---------------------------------------------------------------------------------------------
     def _edges(self):

@@ -141,18 +141,27 @@ class NgpNerf:
         # scratch sized for max_samples
         S = c.max_samples
         h = dict(dtype=torch.float16, device=dev)
+        # sample arrays of the RENDER path (render() / march()); the training step has its own two sets (_alloc_static)
         self.s_pos, self.s_dir = torch.empty((S, 3), **f), torch.empty((S, 3), **f)
         self.s_dt, self.s_t = torch.empty(S, **f), torch.empty(S, **f)
         # (zero-initialised, not torch.empty: the training step skips the unused tail of the budget, and what it skips must
         # never hold NaN bits -- see csrc/ngp.hip:ngp_encode_fwd_kernel)
-        self.s_feat, self.s_out, self.s_dout = torch.zeros((S, 32), **h), torch.zeros((S, 4), **h), torch.zeros((S, 4), **h)
+        self.s_feat, self.s_out = torch.zeros((S, 32), **h), torch.zeros((S, 4), **h)
         self.s_dfeat = torch.zeros((S, 32), **h)
         self.act = [torch.zeros((u, S), **h) for u in (64, 32, 64, 64)]         # h1T cinT h3T h4T
         self.dact = [torch.zeros((u, S), **h) for u in (16, 64, 64, 16, 64)]    # d5T d4T d3T ddT d1T
         self.partial = torch.zeros((c.wgrad_ksplit, MLP_TOTAL), **f)
-        self.counter = torch.zeros(3, dtype=torch.int32, device=dev)
-        ws_bytes = lib().ns_ngp_encode_backward_workspace_bytes(*self._grid_args(), C.c_long(c.max_samples))
-        self.enc_ws = torch.zeros(max(ws_bytes // 4, 1), **f)   # record queues / counters of the binned encode backward
+        # Table gradient.  One trainer: the round-3 path (csrc/ngp.hip: no count pass, Adam applied to the touched entries in
+        # the flush of the accumulation; the gradient buffer is not used).  Replicated trainers: gradient buffer + all-reduce
+        # + streaming Adam, so the binned path that writes the buffer keeps its own workspace.
+        self.fused_adam = self.world == 1 and c.grad_fixed_scale > 0 and not os.environ.get("NS_NGP_TWO_PASS_ADAM")
+        self.enc_ws_bytes = int(lib().ns_ngp_encode_backward_fused_workspace_bytes(*self._grid_args(), C.c_long(c.max_samples)))
+        if self.fused_adam and self.enc_ws_bytes > 0:
+            self.enc_ws = torch.zeros(self.enc_ws_bytes // 8 + 1, dtype=torch.int64, device=dev)   # zeroed once: counters
+        else:
+            self.fused_adam = False
+            ws_bytes = lib().ns_ngp_encode_backward_workspace_bytes(*self._grid_args(), C.c_long(c.max_samples))
+            self.enc_ws = torch.zeros(max(ws_bytes // 4, 1), **f)   # record queues / counters of the binned encode backward
         self.rays_per_batch = c.n_rays
         self.samples_requested = 0
 
@@ -188,7 +197,7 @@ class NgpNerf:
         self.intr = [float(v) for v in intr]
         self.n_images = self.images.shape[0] if n_images is None else int(n_images)
         if getattr(self, "_static", False):
-            self.ctl[3] = max(self.n_images, 1)
+            self.set_views(self.n_images)
 
     def _rays(self, img_idx, u, v):
         fx, fy, cx, cy = self.intr
@@ -212,8 +221,8 @@ class NgpNerf:
         s = float(c.aabb_scale)
         lo, inv = (0.5 - 0.5 * s, 1.0 / s) if unit else (0.0, 1.0)
         R = o.shape[0]
-        self._primed = False       # the sample arrays are shared with training: the next training step re-marches its rays
-        # (rendering path: its own counters / ray tables -- the training step's are part of a captured graph)
+        # (rendering path: its own counters / ray tables / sample arrays -- the training step's are part of captured graphs and
+        # hold the rays marched ahead for the next step)
         self.rm_counter = torch.zeros(3, dtype=torch.int32, device=self.device)
         self.rm_start = torch.empty(R, dtype=torch.int32, device=self.device)
         self.rm_n = torch.empty(R, dtype=torch.int32, device=self.device)
@@ -236,27 +245,44 @@ class NgpNerf:
         c, dev = self.cfg, self.device
         f = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
+        h = dict(dtype=torch.float16, device=dev)
+        S = c.max_samples
         Rc = self.ray_cap = int(min(c.max_rays, 16384))
-        self.r_o, self.r_d, self.r_tr = torch.zeros((Rc, 3), **f), torch.zeros((Rc, 3), **f), torch.zeros((Rc, 2), **f)
-        self.r_rgb, self.r_depth, self.r_cov = torch.zeros((Rc, 3), **f), torch.zeros(Rc, **f), torch.ones(Rc, **f)
-        self.r_img = torch.zeros(Rc, **i32)
-        self.ray_start, self.ray_n = torch.zeros(Rc, **i32), torch.full((Rc,), -1, **i32)
+        import struct
+        fbits = lambda x: struct.unpack("<i", struct.pack("<f", x))[0]
+        # TWO sets of {control block, march counters, ray tables, sample arrays, loss gradient}: step k trains on one while the
+        # rays of step k + 1 are sampled and marched into the other (side stream, from the START of step k's launch sequence)
+        self.sets = []
+        for _ in range(2):
+            t = dict(r_o=torch.zeros((Rc, 3), **f), r_d=torch.zeros((Rc, 3), **f), r_tr=torch.zeros((Rc, 2), **f),
+                     r_rgb=torch.zeros((Rc, 3), **f), r_depth=torch.zeros(Rc, **f), r_cov=torch.ones(Rc, **f),
+                     r_img=torch.zeros(Rc, **i32), ray_start=torch.zeros(Rc, **i32), ray_n=torch.full((Rc,), -1, **i32),
+                     # unused sample slots must hold finite inputs: the per-sample kernels run over all of them
+                     s_pos=torch.full((S, 3), 0.5, **f), s_dir=torch.zeros((S, 3), **f), s_dt=torch.zeros(S, **f),
+                     s_t=torch.zeros(S, **f), s_dout=torch.zeros((S, 4), **h), counter=torch.zeros(3, **i32),
+                     ctl=torch.tensor([self.step, min(self.rays_per_batch, Rc), self.seed & 0x7FFFFFFF, max(self.n_images, 1),
+                                       fbits(1.0 - c.beta1 ** (self.step + 1)), fbits(1.0 - c.beta2 ** (self.step + 1)), 0, 0], **i32))
+            self.sets.append(t)
+        self.cur = 0                                     # set of the step about to be trained
         self.out_rgb, self.out_depth = torch.zeros((Rc, 3), **f), torch.zeros(Rc, **f)
         self.loss_acc = torch.zeros(1, **f)
         self.dpos = torch.zeros((c.max_samples, 3), **f)
         self.ray_g = torch.zeros((Rc, 6), **f)
-        import struct
-        fbits = lambda x: struct.unpack("<i", struct.pack("<f", x))[0]
-        self.ctl = torch.tensor([self.step, min(self.rays_per_batch, Rc), self.seed & 0x7FFFFFFF, max(self.n_images, 1),
-                                 fbits(1.0 - c.beta1 ** (self.step + 1)), fbits(1.0 - c.beta2 ** (self.step + 1)), 0, 0], **i32)
         self.last = torch.zeros(4, **i32)
-        self.counter.zero_()
-        # unused sample slots must hold finite inputs: the per-sample kernels run over all of them
-        self.s_pos.fill_(0.5); self.s_dir.zero_(); self.s_dt.zero_(); self.s_t.zero_(); self.s_dout.zero_()
-        self._graph, self._graph_key = None, None
-        self._side = torch.cuda.Stream(device=dev)       # next step's ray marching overlaps this step's optimiser pass
+        self._graphs, self._graph_key = [None, None], None
+        self._side = torch.cuda.Stream(device=dev)       # next step's ray marching, then weight / pose gradients
+        self._side2 = torch.cuda.Stream(device=dev)      # dense levels of the table gradient
         self._primed = False
         self._static = True
+
+    @property
+    def ctl(self):
+        """control block of the step about to be trained (device int32[8]: step, rays, seed, views, Adam c1 / c2 bits)"""
+        return self.sets[self.cur]["ctl"]
+
+    def set_views(self, n):
+        for t in self.sets:
+            t["ctl"][3] = max(int(n), 1)
 
     def _step_key(self):
         c = self.cfg
@@ -264,90 +290,116 @@ class NgpNerf:
                 tuple(self.images.shape[1:3]), tuple(self.intr), c.depth_lambda, c.optimize_extrinsics,
                 None if getattr(self, "cam_grad", None) is None else self.cam_grad.data_ptr(), self.bits.data_ptr())
 
-    def _enqueue_rays(self, step_offset):
-        """sample the rays of step ctl[0] + step_offset and march them (fills the sample arrays and the march counters)"""
+    def _enqueue_rays(self, t):
+        """sample the rays of the step set `t` belongs to (its control block names step, seed and ray count) and march them:
+        fills the set's ray tables, sample arrays and march counters (which must be zero)"""
         c, L = self.cfg, lib()
         S, Rc = c.max_samples, self.ray_cap
         n_cap, H, W = self.images.shape[:3]
         s = float(c.aabb_scale)
         fx, fy, cx, cy = self.intr
-        st, ctl = stream_ptr(), ptr(self.ctl)
-        self.ray_n.fill_(-1)
-        self.s_dout.zero_()      # the loss gradient of the step these rays belong to (the previous step is done with it)
+        st, ctl = stream_ptr(), ptr(t["ctl"])
+        t["ray_n"].fill_(-1)
+        t["s_dout"].zero_()      # the loss gradient of the step these rays belong to
         check(L.ns_ngp_sample_rays_ctl(ptr(self.images), ptr(self.depths), ptr(self.depth_covs), ptr(self.c2w), n_cap, H, W,
                                        C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
                                        C.c_float(0.5 - 0.5 * s), C.c_float(0.5 + 0.5 * s), C.c_float(c.near), C.c_uint32(0), Rc,
-                                       ptr(self.r_o), ptr(self.r_d), ptr(self.r_tr), ptr(self.r_rgb), ptr(self.r_depth),
-                                       ptr(self.r_cov), ptr(self.r_img), ctl, int(step_offset), st), "ngp_sample_rays")
-        check(L.ns_ngp_march_ctl(ptr(self.bits), c.grid_size, c.n_cascades, ptr(self.r_o), ptr(self.r_d), ptr(self.r_tr), Rc,
+                                       ptr(t["r_o"]), ptr(t["r_d"]), ptr(t["r_tr"]), ptr(t["r_rgb"]), ptr(t["r_depth"]),
+                                       ptr(t["r_cov"]), ptr(t["r_img"]), ctl, 0, st), "ngp_sample_rays")
+        check(L.ns_ngp_march_ctl(ptr(self.bits), c.grid_size, c.n_cascades, ptr(t["r_o"]), ptr(t["r_d"]), ptr(t["r_tr"]), Rc,
                                  C.c_float(c.cone_angle), C.c_float(c.min_step), C.c_float(c.max_step),
-                                 C.c_float(0.5 - 0.5 * s), C.c_float(1.0 / s), c.max_steps_per_ray, C.c_long(S), ptr(self.counter),
-                                 ptr(self.ray_start), ptr(self.ray_n), ptr(self.s_pos), ptr(self.s_dir), ptr(self.s_dt),
-                                 ptr(self.s_t), ctl, st), "ngp_march")
+                                 C.c_float(0.5 - 0.5 * s), C.c_float(1.0 / s), c.max_steps_per_ray, C.c_long(S), ptr(t["counter"]),
+                                 ptr(t["ray_start"]), ptr(t["ray_n"]), ptr(t["s_pos"]), ptr(t["s_dir"]), ptr(t["s_dt"]),
+                                 ptr(t["s_t"]), ctl, st), "ngp_march")
 
-    def _enqueue_step(self):
-        """one optimiser step on the current stream (+ a side stream); no host synchronisation, no allocation.
-        The rays of a step are sampled and marched at the END of the previous step's launch sequence, on a side stream,
-        while that step's optimiser pass (a pure HBM stream over the 12.6 M grid parameters) runs: the marcher is latency
-        bound (84 us at low occupancy), Adam is bandwidth bound (94 us) -- together they take the time of one."""
+    def _enqueue_step(self, x):
+        """one optimiser step on set `x` on the current stream (+ two side streams); no host synchronisation, no allocation.
+
+        main  : encode -> MLP -> composite -> MLP activation gradients -> table gradient of the HASHED levels with Adam in its
+                flush (scatter, accumulate) -> camera step -> MLP Adam
+        side  : [from the start] control block of step k + 1, its rays sampled and marched into the OTHER set (the marcher is
+                latency bound and reads only the occupancy bits and the images) ; [after the activation gradients] MLP weight
+                gradients, pose refinement's input gradient + reductions
+        side2 : [after the activation gradients] table gradient of the DENSE levels (LDS-atomic bound) with Adam in its reduce
+        Round 2 marched the next rays next to the streaming Adam pass at the end of the step; that pass no longer exists."""
         c, dev = self.cfg, self.device
         L = lib()
         S, Rc = c.max_samples, self.ray_cap
         s = float(c.aabb_scale)
+        X, Y = self.sets[x], self.sets[1 - x]
         st = stream_ptr()
-        ctl = ptr(self.ctl)
+        ctl = ptr(X["ctl"])
+        main = torch.cuda.current_stream()
         self.loss_acc.zero_()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            check(L.ns_ngp_step_prepare(ptr(X["ctl"]), ptr(Y["ctl"]), ptr(X["counter"]), ptr(Y["counter"]), ptr(self.last),
+                                        C.c_float(0.9), C.c_long(S), 256, Rc, C.c_float(c.beta1), C.c_float(c.beta2), stream_ptr()),
+                  "ngp_step_prepare")
+            self._enqueue_rays(Y)
         # sample count of THIS step = end of the marcher's reserved ranges (device memory): the per-sample kernels are launched
         # over the whole budget S (fixed grids, fixed row strides) and skip the tail the marcher did not fill
-        n_dev = C.c_void_p(self.counter.data_ptr() + 8)
+        n_dev = C.c_void_p(X["counter"].data_ptr() + 8)
         featT = self.s_feat.view(-1)[:32 * S].view(32, S)
-        check(L.ns_ngp_encode_forward_n(*self._grid_args(), ptr(self.s_pos), ptr(self.grid_half), ptr(featT), 1, C.c_long(S), n_dev,
+        check(L.ns_ngp_encode_forward_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.grid_half), ptr(featT), 1, C.c_long(S), n_dev,
                                         st), "ngp_encode_forward")
         acts, dacts = self.act, self.dact
-        check(L.ns_ngp_mlp_forward_n(ptr(self.mlp_half), ptr(featT), ptr(self.s_dir), ptr(self.s_out),
+        check(L.ns_ngp_mlp_forward_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out),
                                      *[ptr(a) for a in acts], C.c_long(S), n_dev, st), "ngp_mlp_forward")
-        check(L.ns_ngp_composite_ctl(ptr(self.s_out), ptr(self.s_dt), ptr(self.s_t), ptr(self.ray_start), ptr(self.ray_n), Rc,
-                                     ptr(self.r_rgb), ptr(self.r_depth), ptr(self.r_cov), C.c_float(c.depth_lambda),
+        check(L.ns_ngp_composite_ctl(ptr(self.s_out), ptr(X["s_dt"]), ptr(X["s_t"]), ptr(X["ray_start"]), ptr(X["ray_n"]), Rc,
+                                     ptr(X["r_rgb"]), ptr(X["r_depth"]), ptr(X["r_cov"]), C.c_float(c.depth_lambda),
                                      C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), ptr(self.loss_acc),
-                                     ptr(self.s_dout), ctl, st), "ngp_composite")
-        # activation gradients on this stream; the weight gradients (and the pose refinement's input gradient) only READ what
-        # they wrote, so they go to the side stream, next to the table gradient: that one is bound by LDS atomics and
-        # scattered records, they by streaming reads (NS_NGP_WGRAD_MAIN=1 keeps the weight gradients in line: A/B runs)
+                                     ptr(X["s_dout"]), ctl, st), "ngp_composite")
         h1T, cinT, h3T, h4T = acts
         d5T, d4T, d3T, ddT, d1T = dacts
-        check(L.ns_ngp_mlp_dgrad_n(ptr(self.mlp_half), ptr(self.s_dout), ptr(h1T), ptr(h3T), ptr(h4T), ptr(self.s_dfeat),
+        check(L.ns_ngp_mlp_dgrad_n(ptr(self.mlp_half), ptr(X["s_dout"]), ptr(h1T), ptr(h3T), ptr(h4T), ptr(self.s_dfeat),
                                    ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT), ptr(d1T), C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
-
-        def wgrad(stream):
+        # everything below only READS what the activation backward wrote: three branches
+        self._side.wait_stream(main)
+        table_read = None
+        with torch.cuda.stream(self._side):
+            st2 = stream_ptr()
+            if c.optimize_extrinsics:
+                # pose refinement (input gradient of the encoding: 8 gathers x 16 levels per sample, L2-request bound; per-ray
+                # and per-image reductions).  First on this stream: it reads the f16 table, which the Adam-applying passes of the
+                # table gradient rewrite -- they are held back until it is through (`table_read`)
+                check(L.ns_ngp_encode_backward_input_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.grid_half),
+                                                       ptr(self.s_dfeat), ptr(self.dpos), C.c_long(S), n_dev, st2),
+                      "ngp_encode_backward_input")
+                table_read = torch.cuda.Event()
+                table_read.record()
+                n_cam = self.cam_grad.shape[0]
+                check(L.ns_ngp_camera_gradient_2stage(ptr(self.dpos), ptr(X["s_t"]), ptr(X["r_d"]), ptr(X["ray_start"]),
+                                                      ptr(X["ray_n"]), ptr(X["r_img"]), C.c_float(1.0 / s), ptr(self.cam_grad), Rc,
+                                                      ctl, ptr(self.ray_g) if n_cam <= 4096 else None, n_cam, st2),
+                      "ngp_camera_gradient")
             check(L.ns_ngp_mlp_wgrad_n(ptr(featT), ptr(h1T), ptr(cinT), ptr(h3T), ptr(h4T), ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT),
-                                       ptr(d1T), ptr(self.partial), c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(S), n_dev, stream),
+                                       ptr(d1T), ptr(self.partial), c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(S), n_dev, st2),
                   "ngp_mlp_wgrad")
-        main = torch.cuda.current_stream()
-        wgrad_side = not os.environ.get("NS_NGP_WGRAD_MAIN")
-        if not wgrad_side:
-            wgrad(st)
-        if c.optimize_extrinsics or wgrad_side:
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                st2 = stream_ptr()
-                if wgrad_side:
-                    wgrad(st2)
-                if c.optimize_extrinsics:
-                    # pose refinement (input gradient of the encoding: 8 gathers x 16 levels per sample, L2-request bound;
-                    # per-ray and per-image reductions)
-                    check(L.ns_ngp_encode_backward_input_n(*self._grid_args(), ptr(self.s_pos), ptr(self.grid_half),
-                                                           ptr(self.s_dfeat), ptr(self.dpos), C.c_long(S), n_dev, st2),
-                          "ngp_encode_backward_input")
-                    n_cam = self.cam_grad.shape[0]
-                    check(L.ns_ngp_camera_gradient_2stage(ptr(self.dpos), ptr(self.s_t), ptr(self.r_d), ptr(self.ray_start),
-                                                          ptr(self.ray_n), ptr(self.r_img), C.c_float(1.0 / s), ptr(self.cam_grad), Rc,
-                                                          ctl, ptr(self.ray_g) if n_cam <= 4096 else None, n_cam, st2),
-                          "ngp_camera_gradient")
-        check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(self.s_pos), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
-                                         ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev, st),
-              "ngp_encode_backward")
-        if c.optimize_extrinsics or wgrad_side:
-            main.wait_stream(self._side)
+
+        def table_gradient(parts, stream):
+            check(L.ns_ngp_encode_backward_fused_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat), None, ptr(self.enc_ws),
+                                                   C.c_size_t(self.enc_ws_bytes), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev,
+                                                   ptr(self.grid_master), ptr(self.grid_half), ptr(self.grid_m1), ptr(self.grid_m2),
+                                                   0, C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
+                                                   C.c_float(c.loss_scale * self.world), ctl, parts, stream), "ngp_encode_backward_fused")
+        if self.fused_adam:
+            self._side2.wait_stream(main)
+            with torch.cuda.stream(self._side2):
+                table_gradient(4, stream_ptr())
+                if table_read is not None:
+                    self._side2.wait_event(table_read)
+                table_gradient(8, stream_ptr())
+            table_gradient(1, st)
+            if table_read is not None:
+                main.wait_event(table_read)
+            table_gradient(2, st)
+            main.wait_stream(self._side2)
+        else:
+            check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
+                                             ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev, st),
+                  "ngp_encode_backward")
+        main.wait_stream(self._side)
         if self.world > 1:
             self._allreduce_gradients()
         if c.optimize_extrinsics:   # after the all-reduce: every replica applies the SAME pose update (ADVICE r01)
@@ -355,20 +407,12 @@ class NgpNerf:
                                            self.cam_grad.shape[0], 0, C.c_float(c.extrinsic_lr_pos), C.c_float(c.extrinsic_lr_rot),
                                            C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
                                            C.c_float(c.loss_scale * self.world), ctl, st), "ngp_camera_step")
-        # this step no longer needs its rays / samples: record the march counters, adapt the next batch, clear them
-        check(L.ns_ngp_step_rays(ptr(self.ctl), ptr(self.counter), ptr(self.last), C.c_float(0.9), C.c_long(S), 256, Rc, st),
-              "ngp_step_rays")
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):          # next step's rays, concurrently with this step's optimiser pass
-            self._enqueue_rays(1)
         for (m, hp, g, m1, m2, l2, fxs) in (
                 (self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale),
-                (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0)):
+                (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0))[1 if self.fused_adam else 0:]:
             check(L.ns_ngp_adam_ctl(ptr(m), ptr(hp), ptr(g), ptr(m1), ptr(m2), C.c_long(m.numel()), 0, C.c_float(c.lr),
                                     C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps), C.c_float(l2),
                                     C.c_float(c.loss_scale * self.world), C.c_float(fxs), ctl, st), "ngp_adam")
-        main.wait_stream(self._side)
-        check(L.ns_ngp_step_count(ptr(self.ctl), C.c_float(c.beta1), C.c_float(c.beta2), st), "ngp_step_count")
 
     def train_step(self, return_loss=True):
         if self.n_images == 0:
@@ -379,36 +423,45 @@ class NgpNerf:
                 self._alloc_static()
             if c.optimize_extrinsics:
                 self._grow_camera_state(self.images.shape[0])
+            x = self.cur
             if not self._primed:
-                # no predecessor step marched this step's rays (first step, or render() has used the sample arrays since)
-                self.counter.zero_()
-                self._enqueue_rays(0)
+                # no predecessor marched this step's rays (first step), or they were marched on an occupancy grid that has been
+                # updated since: march them (again: same control block, same seed, same pixels) before the step
+                X = self.sets[x]
+                X["counter"].zero_()
+                self._enqueue_rays(X)
                 self._primed = True
             if self.world > 1 or not c.use_graph:
-                self._enqueue_step()
+                self._enqueue_step(x)
             else:
                 key = self._step_key()
                 if self._graph_key != key:
-                    # (re)capture: the first step after a (re)allocation runs eagerly -- it is also the warm-up
-                    self._graph, self._graph_key = None, key
-                    self._enqueue_step()
-                elif self._graph is None:
-                    torch.cuda.synchronize(dev)
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other host threads (the tracker under
-                        self._enqueue_step()                                        # --parallel_run) keep launching meanwhile
-                    self._graph = g             # (capturing does not execute: the step runs with the first replay)
+                    # (re)capture: the first steps after a (re)allocation run eagerly -- they are also the warm-up
+                    self._graphs, self._graph_key = [None, None], key
+                    self._eager_left = 2
+                if self._eager_left > 0:
+                    self._eager_left -= 1
+                    self._enqueue_step(x)
+                elif self._graphs[x] is None:
+                    from ._lib import capture_lock
+                    with capture_lock:          # the tracker thread takes the same lock around its host read-backs
+                        torch.cuda.synchronize(dev)
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                            self._enqueue_step(x)
+                    self._graphs[x] = g         # (capturing does not execute: the step runs with the first replay)
                     g.replay()
                 else:
-                    self._graph.replay()
+                    self._graphs[x].replay()
+            self.cur = 1 - x
             self.step += 1
             if self.step % c.grid_update_every == 0:
                 self.update_density_grid()
-                # The next step's rays were marched ahead (end of this step's launch sequence) on the grid as it was BEFORE
-                # this update: drop them, the next step marches its rays again on the updated grid (same seed, same pixels).
-                # Training on the stale march one step in 16 made the result a coin toss: PSNR after 500 steps on the sphere
-                # scene 19-31 dB in a third of the runs instead of 34-36 dB (10 of 10 runs with this line; 10 of 10 on the
-                # tree before the rays moved ahead).  Cost: one eager sample + march per update, < 1 % of a step.
+                # The next step's rays were marched ahead (side branch of this step's launch sequence) on the grid as it was
+                # BEFORE this update: drop them, the next step marches its rays again on the updated grid (same seed, same
+                # pixels).  Training on the stale march one step in 16 made the result a coin toss: PSNR after 500 steps on
+                # the sphere scene 19-31 dB in a third of the runs instead of 34-36 dB (10 of 10 runs with this line; 10 of
+                # 10 on the tree before the rays moved ahead).  Cost: one eager sample + march per update, < 1 % of a step.
                 self._primed = False
         return self.loss_tensor if return_loss else None
 

@@ -20,6 +20,7 @@ The GTSAM Values / NonlinearFactorGraph the reference returns empty (:248-250) a
 import numpy as np
 import torch
 
+from ._lib import capture_lock
 from .corr import AltCorrBlock, CorrBlock
 from .frontend import TrackingFrontend
 
@@ -72,7 +73,8 @@ class TrackingSLAM:
         pyr = CorrBlock.build_pyramid(f1, f2, None, None, 1, fe.ht, fe.wd, tiled=True)
         corr = CorrBlock.from_pyramid(pyr, tiled=True, hw=(fe.ht, fe.wd))(fe.coords0[None, None])
         delta = self.net.motion(corr, self.last_kf)
-        return float(delta.norm(dim=-1).mean()) > self.motion_filter_thresh
+        with capture_lock:      # host read-back (see _lib.capture_lock)
+            return float(delta.norm(dim=-1).mean()) > self.motion_filter_thresh
 
     def _frontend(self, data):
         k = int(data["k"][0])
@@ -168,7 +170,9 @@ class TrackingSLAM:
         fe.cam0_idepths[k] = torch.where(s > 0, s, fe.cam0_idepths[k])
         for _ in range(self.iters1):
             fe.update()
-        if float(fe.distance([k - 2], [k - 1])) < fe.keyframe_thresh:
+        with capture_lock:      # host read-back (see _lib.capture_lock)
+            reject = float(fe.distance([k - 2], [k - 1])) < fe.keyframe_thresh
+        if reject:
             return False
         for _ in range(self.iters2):
             fe.update()

@@ -734,3 +734,110 @@ def test_hash_encode_survives_positions_outside_the_unit_cube(dev):
     check(lib().ns_ngp_encode_forward(*args, ptr(pos[inside].contiguous()), ptr(net.grid_half), ptr(ref), 1, C.c_long(ref.shape[1]),
                                       stream_ptr()), "fwd")
     assert torch.equal(feat[:, inside], ref)
+
+
+def _fused_setup(oracle_mod, dev, N, seed, clustered=False):
+    from nerfslam._lib import lib
+    from nerfslam.ngp import NgpConfig
+    c = NgpConfig()
+    cfg = oracle_mod.ngp_cfg(n_levels=c.n_levels, log2_hashmap=c.log2_hashmap, base_res=c.base_res, per_level_scale=c.per_level_scale)
+    _, _, off = oracle_mod.ngp_grid_layout(cfg)
+    L = c.n_levels
+    args = (L, 2, c.log2_hashmap, c.base_res, C.c_float(c.per_level_scale))
+    rng = np.random.default_rng(seed)
+    R = 2048
+    if clustered:      # every sample in one of two x-adjacent finest-level cells, alternating (neighbours never merge there):
+        pos = (0.5 + rng.uniform(0, 1e-6, (N, 3))).astype(np.float32)   # a dozen indices per level carry all of its records
+        pos[1::2, 0] += np.float32(1.3e-4)
+    else:
+        o = rng.uniform(0.3, 0.7, (R, 1, 3))
+        d = rng.standard_normal((R, 1, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        t = (0.02 + 0.0017 * np.arange(N // R))[None, :, None]
+        pos = np.clip(o + t * d, 0.0, 1.0).reshape(N, 3).astype(np.float32)
+    dLT = (rng.standard_normal((2 * L, N)) * 1e-2).astype(np.float16)
+    dLT[:, rng.uniform(size=N) < 0.2] = 0
+    wsb = int(lib().ns_ngp_encode_backward_fused_workspace_bytes(*args, C.c_long(N)))
+    assert wsb > 0
+    ws = torch.zeros(wsb // 8 + 1, dtype=torch.int64, device=dev)
+    return c, args, int(off[-1]) * 2, pos, dLT, ws, wsb
+
+
+@pytest.mark.parametrize("clustered", [False, True], ids=["rays", "one_cell"])
+def test_fused_table_gradient_matches_the_other_paths(oracle_mod, dev, clustered):
+    """round-3 binned path (no count pass, 64 bins, fixed regions + overflow list): the packed sums equal the owner-computes
+    path bit for bit -- also when a handful of bins receive every record (regions overflow into the list), with the sample
+    count in device memory, and when called repeatedly on the same workspace (it leaves its counters cleared)."""
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    N = 1 << 18 if not clustered else 1 << 16
+    c, args, n_par, pos, dLT, ws, wsb = _fused_setup(oracle_mod, dev, N, 11, clustered)
+    d_pos, d_dLT = T(pos, dev), T(dLT, dev)
+    S = 262144.0
+    nul = C.c_void_p(0)
+    ref = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(ref), None, C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
+
+    def fused(n_dev=None, dl=d_dLT):
+        gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
+        check(lib().ns_ngp_encode_backward_fused_n(*args, ptr(d_pos), ptr(dl), ptr(gq), ptr(ws), C.c_size_t(wsb), C.c_float(S),
+                                                   C.c_long(N), ptr(n_dev), nul, nul, nul, nul, 1, C.c_float(0), C.c_float(0),
+                                                   C.c_float(0), C.c_float(0), C.c_float(1), nul, 15, stream_ptr()), "fused")
+        return gq
+    for _ in range(3):
+        assert torch.equal(fused(), ref)
+    w32 = ws.view(torch.int32)
+    assert int(w32[0]) == 0 and int(w32[1]) == 0, "overflow counter not left cleared / error flag set"
+    ntiles = (N + 1023) // 1024
+    run_lengths = w32[64:64 + 12 * 64 * ntiles]
+    if clustered:   # the overflow list was really used: runs longer than their 512-record slots
+        assert int((run_lengths == 512).sum()) > 0
+    else:
+        assert 0 < int(run_lengths.max()) < 512
+    # sample count in device memory; the tail holds poison that must not be read
+    n_odd = 100003 if not clustered else 33331
+    ref_n = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
+    sub = T(np.ascontiguousarray(dLT[:, :n_odd]), dev)
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(sub), 1, ptr(ref_n), None, C.c_float(S), C.c_long(n_odd), stream_ptr()), "bwd")
+    poisoned = dLT.copy(); poisoned[:, n_odd:] = np.float16(3.0)
+    nd = torch.tensor([n_odd], dtype=torch.int32, device=dev)
+    assert torch.equal(fused(nd, T(poisoned, dev)), ref_n)
+    # workspace size is checked
+    with pytest.raises(Exception):
+        check(lib().ns_ngp_encode_backward_fused_n(*args, ptr(d_pos), ptr(d_dLT), ptr(ref), ptr(ws), C.c_size_t(wsb // 2), C.c_float(S),
+                                                   C.c_long(N), nul, nul, nul, nul, nul, 1, C.c_float(0), C.c_float(0), C.c_float(0),
+                                                   C.c_float(0), C.c_float(1), nul, 15, stream_ptr()), "fused")
+
+
+def test_fused_table_gradient_adam_is_bit_identical(oracle_mod, dev):
+    """Adam applied in the flush of the accumulation == table gradient into the buffer, then ns_ngp_adam over the whole table:
+    master, both moments and the f16 working copy bit for bit, over three consecutive steps (moments carried)"""
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    N = 1 << 17
+    c, args, n_par, pos, dLT, ws, wsb = _fused_setup(oracle_mod, dev, N, 12)
+    S, lr, b1, b2, eps, gs = 262144.0, 1e-2, 0.9, 0.99, 1e-15, 128.0
+    g = torch.Generator().manual_seed(3)
+    m0 = (torch.rand(n_par, generator=g) * 2e-4 - 1e-4).to(dev)
+    st = {}
+    for name in ("two_pass", "fused"):
+        st[name] = dict(master=m0.clone(), hp=m0.half(), m1=torch.zeros(n_par, device=dev), m2=torch.zeros(n_par, device=dev))
+    rng = np.random.default_rng(5)
+    nul = C.c_void_p(0)
+    d_pos = T(pos, dev)
+    for step in (1, 2, 3):
+        dl = dLT.copy()
+        dl[:, rng.uniform(size=N) < 0.5] = 0          # different entries touched each step
+        d_dl = T(dl, dev)
+        a = st["two_pass"]
+        gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
+        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dl), 1, ptr(gq), None, C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
+        touched = int((gq != 0).sum())
+        check(lib().ns_ngp_adam(ptr(a["master"]), ptr(a["hp"]), ptr(gq), ptr(a["m1"]), ptr(a["m2"]), C.c_long(n_par), step, C.c_float(lr),
+                                C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(0.0), C.c_float(gs), C.c_float(S), stream_ptr()),
+              "adam")
+        f = st["fused"]
+        check(lib().ns_ngp_encode_backward_fused_n(*args, ptr(d_pos), ptr(d_dl), nul, ptr(ws), C.c_size_t(wsb), C.c_float(S), C.c_long(N),
+                                                   nul, ptr(f["master"]), ptr(f["hp"]), ptr(f["m1"]), ptr(f["m2"]), step, C.c_float(lr),
+                                                   C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(gs), nul, 15, stream_ptr()), "fused")
+        assert 0.02 * n_par / 2 < touched < 0.9 * n_par / 2
+        for k in ("master", "m1", "m2", "hp"):
+            assert torch.equal(a[k], f[k]), (step, k, int((a[k] != f[k]).sum()))
+    assert not torch.equal(st["fused"]["master"], m0)
