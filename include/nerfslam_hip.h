@@ -483,9 +483,10 @@ int ns_ngp_step_advance(int* ctl, int* counter, int* last, float fill, long max_
 /* Double-buffered form of the above (round 3; nerfslam/ngp.py): opens the side branch of step k that samples and marches the
  * rays of step k + 1 into the OTHER set of {control block, counters, ray tables, sample arrays}: ctl_dst <- {step + 1, ray
  * count adapted from THIS step's sample count, seed, views, Adam bias corrections}, last <- this step's counters (lazy host
- * reads), counter_dst <- 0.                                                                                              */
+ * reads), counter_dst <- 0, *loss_dst <- 0 (the other set's loss accumulator).                                           */
 int ns_ngp_step_prepare(const int* ctl_src, int* ctl_dst, const int* counter_src, int* counter_dst, int* last, float fill,
-                        long max_samples, int min_rays, int max_rays, float beta1, float beta2, void* stream);
+                        long max_samples, int min_rays, int max_rays, float beta1, float beta2, float* loss_dst /* cleared; may be
+                        NULL */, void* stream);
 /* the two halves of ns_ngp_step_advance: `_rays` (counters -> last, next ray count, counters cleared) may run as soon as the
  * backward pass is done, so that the next step's ns_ngp_sample_rays_ctl(step_offset = 1) + ns_ngp_march_ctl overlap this
  * step's optimiser pass; `_count` (ctl[0] += 1, Adam's bias corrections) closes the step after both have finished. */
@@ -505,6 +506,16 @@ int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_hashmap, int
 int ns_ngp_encode_backward_input_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
                                    const float* positions, const void* params, const void* dLdoutT, float* dLdpos, long N,
                                    const int* n_dev, void* stream);
+/* Pose refinement without a second gather of the table (round 3): the encode forward also writes, per level and feature, the
+ * derivative of the feature with respect to the position divided by the level's scale -- jacT: unit-major [6 n_levels][N] f16,
+ * row 6 l + 3 f + d -- from the corner values it has in registers; ns_ngp_encode_jacobian_dot_n then forms
+ * dL/dpos[n] = sum_l scale_l sum_f dL/dfeature[2 l + f][n] J[6 l + 3 f + :][n]  (what ns_ngp_encode_backward_input_n computes
+ * with 8 x n_levels gathers per sample; equal to it up to the f16 rounding of J).  jacT == NULL: ns_ngp_encode_forward_n.   */
+int ns_ngp_encode_forward_j_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                              const float* positions, const void* params, void* out, int unit_major, void* jacT, long N,
+                              const int* n_dev, void* stream);
+int ns_ngp_encode_jacobian_dot_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                                 const void* jacT, const void* dLdoutT, float* dLdpos, long N, const int* n_dev, void* stream);
 /* Table gradient of the hash grid with the optimiser step fused into it (round 3; tiny-cuda-nn GridEncoding backward +
  * Adam with its skip-zero-gradient rule, [EXTERNAL] instant-ngp behind fusion/nerf_fusion.py:291-307):
  *   dLdoutT: unit-major [2 n_levels][N] f16 (what ns_ngp_mlp_dgrad_n writes); fixed_scale > 0 (packed Q fixed point);
@@ -531,6 +542,14 @@ int ns_ngp_mlp_forward_n(const void* weights, const void* featT, const float* di
 int ns_ngp_mlp_backward_n(const void* weights, const void* dLdout, const void* featT, const void* h1T, const void* cinT,
                           const void* h3T, const void* h4T, void* dLdfeatT, void* d5T, void* d4T, void* d3T, void* ddT, void* d1T,
                           float* partial_ws, int ksplit, float* grad_weights, long N, const int* n_dev, void* stream);
+/* ReLU bit masks (round 3): the forward pass can also write one bit per hidden unit and sample -- relu_masks: 6 N uint32
+ * ([3 layers h1, h3, h4][2 lane halves][N], the MFMA accumulator layout of the kernels) -- and ns_ngp_mlp_dgrad_m_n takes the
+ * ReLU derivatives from them instead of re-reading the three 64-unit f16 activations (24 B instead of 384 B per sample, and no
+ * dependent loads between the layers of the backward chain).  Same results bit for bit.                                  */
+int ns_ngp_mlp_forward_m_n(const void* weights, const void* featT, const float* dirs, void* out, void* h1T, void* cinT, void* h3T,
+                           void* h4T, void* relu_masks, long N, const int* n_dev, void* stream);
+int ns_ngp_mlp_dgrad_m_n(const void* weights, const void* dLdout, const void* relu_masks, void* dLdfeatT, void* d5T, void* d4T,
+                         void* d3T, void* ddT, void* d1T, long N, const int* n_dev, void* stream);
 /* the two halves of ns_ngp_mlp_backward_n: activation gradients (writes dLdfeatT and the d*T buffers), then the weight
  * gradients (reads them).  Separate entries so that the caller can put the second half on another stream, next to the
  * hash-grid backward that consumes dLdfeatT (nerfslam/ngp.py).                                                       */

@@ -132,7 +132,7 @@ typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const float* __restrict__ pos,
                                                              const h2_t* __restrict__ params,
                                                              h2_t* __restrict__ out, long N, int L, int unit_major,
-                                                             const int* __restrict__ n_dev) {
+                                                             const int* __restrict__ n_dev, _Float16* __restrict__ jacT) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   // N stays the row stride of the unit-major output.  The device count is rounded up to 8 like in the MLP kernels, which
   // read the features of the (up to 7) tail slots: left unwritten they are whatever the allocation held -- NaN bits there
@@ -181,6 +181,25 @@ __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const
     wt *= (corner & 4) ? w[2] : 1.0f - w[2];
     a0 = fmaf(wt, (float)v[corner][0], a0);
     a1 = fmaf(wt, (float)v[corner][1], a1);
+  }
+  if (jacT != nullptr) {
+    // d(feature f)/d(position d) / scale, from the corner values already in registers: the pose refinement's input gradient
+    // then is a dot product with dL/dfeature (ngp_encode_jac_dot_kernel) instead of a second gather of the table
+    // (ngp_encode_bwd_input_kernel: 8 x 16 gathers per sample again, 104 us per step).  The level's scale is applied there
+    // (in f32): scale x value differences would leave the f16 range on the fine levels.
+    const float wx0 = 1.0f - w[0], wx1 = w[0], wy0 = 1.0f - w[1], wy1 = w[1], wz0 = 1.0f - w[2], wz1 = w[2];
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+      float s8[8];
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) s8[corner] = (float)v[corner][f];
+      const float jx = wy0 * wz0 * (s8[1] - s8[0]) + wy1 * wz0 * (s8[3] - s8[2]) + wy0 * wz1 * (s8[5] - s8[4]) + wy1 * wz1 * (s8[7] - s8[6]);
+      const float jy = wx0 * wz0 * (s8[2] - s8[0]) + wx1 * wz0 * (s8[3] - s8[1]) + wx0 * wz1 * (s8[6] - s8[4]) + wx1 * wz1 * (s8[7] - s8[5]);
+      const float jz = wx0 * wy0 * (s8[4] - s8[0]) + wx1 * wy0 * (s8[5] - s8[1]) + wx0 * wy1 * (s8[6] - s8[2]) + wx1 * wy1 * (s8[7] - s8[3]);
+      jacT[(long)(6 * l + 3 * f + 0) * N + i] = (_Float16)jx;
+      jacT[(long)(6 * l + 3 * f + 1) * N + i] = (_Float16)jy;
+      jacT[(long)(6 * l + 3 * f + 2) * N + i] = (_Float16)jz;
+    }
   }
   if (unit_major) {  // [2L][N]: 128 contiguous bytes per wave and feature
     _Float16* o = reinterpret_cast<_Float16*>(out);
@@ -1256,9 +1275,11 @@ __global__ __launch_bounds__(NS_FB_THREADS) void ngp_enc_faccum_kernel(GridLayou
                                                                        const unsigned long long* __restrict__ queue,
                                                                        const ulonglong2* __restrict__ ovf,
                                                                        float* __restrict__ grad, AdamFuse ad, long N,
-                                                                       const int* __restrict__ n_dev) {
+                                                                       const int* __restrict__ n_dev, int* __restrict__ ctr_rw,
+                                                                       int n_groups) {
   __shared__ unsigned long long tab[NS_FB_SLICE];
   __shared__ int scnt[NS_FB_THREADS];
+  __shared__ int s_novf;
   const int k = blockIdx.y, l = fp.level[k], b = blockIdx.x, tid = threadIdx.x;
   if (b >= fp.nbins[k]) return;
   const uint32_t hs = g.offset[l + 1] - g.offset[l];
@@ -1267,6 +1288,17 @@ __global__ __launch_bounds__(NS_FB_THREADS) void ngp_enc_faccum_kernel(GridLayou
   const long nvalid = n_dev ? min(N, (long)*n_dev) : N;
   const int ntv = (int)((nvalid + NS_BIN_TILE - 1) / NS_BIN_TILE);   // tiles the scatter pass wrote
   for (uint32_t e = tid; e < NS_FB_SLICE; e += NS_FB_THREADS) tab[e] = 0ull;
+  if (tid == 0) {
+    s_novf = (int)min((long)ctr[0], fp.ovf_cap);
+    // the LAST workgroup to have read the overflow count clears it (and this arrival counter): the list is empty for the next
+    // call without a trailing launch
+    __threadfence();
+    if (atomicAdd(&ctr_rw[2], 1) == n_groups - 1) {
+      ctr_rw[0] = 0;
+      ctr_rw[2] = 0;
+    }
+  }
+  __syncthreads();
   const long row = (long)(k * NS_FB_BINS + b) * fp.ntiles;
   const int wave = tid >> 6, lane = tid & 63;
   for (int t0 = 0; t0 < ntv; t0 += NS_FB_THREADS) {
@@ -1296,7 +1328,7 @@ __global__ __launch_bounds__(NS_FB_THREADS) void ngp_enc_faccum_kernel(GridLayou
       }
     }
   }
-  const int novf = (int)min((long)ctr[0], fp.ovf_cap);
+  const int novf = s_novf;     // (written before the first barrier of the tile loop / the one below)
   if (novf > 0) {
     const unsigned long long tag = (unsigned long long)((k << 8) | b);
     for (int e = tid; e < novf; e += NS_FB_THREADS) {
@@ -1368,6 +1400,27 @@ __global__ __launch_bounds__(256) void ngp_encode_bwd_input_kernel(GridLayout g,
     gx += scale * (wy0 * wz0 * (s[1] - s[0]) + wy1 * wz0 * (s[3] - s[2]) + wy0 * wz1 * (s[5] - s[4]) + wy1 * wz1 * (s[7] - s[6]));
     gy += scale * (wx0 * wz0 * (s[2] - s[0]) + wx1 * wz0 * (s[3] - s[1]) + wx0 * wz1 * (s[6] - s[4]) + wx1 * wz1 * (s[7] - s[5]));
     gz += scale * (wx0 * wy0 * (s[4] - s[0]) + wx1 * wy0 * (s[5] - s[1]) + wx0 * wy1 * (s[6] - s[2]) + wx1 * wy1 * (s[7] - s[3]));
+  }
+  dLdpos[i * 3] = gx;
+  dLdpos[i * 3 + 1] = gy;
+  dLdpos[i * 3 + 2] = gz;
+}
+
+// dL/dpos from the Jacobian rows the forward pass wrote (jacT [6 L][N] f16, without the level scale) and dL/dfeature
+// ([2 L][N] f16): 256 B streamed per sample, no gathers
+__global__ __launch_bounds__(256) void ngp_encode_jac_dot_kernel(GridLayout g, const _Float16* __restrict__ jacT,
+                                                                 const _Float16* __restrict__ dLdfeatT, float* __restrict__ dLdpos,
+                                                                 long N, int L, const int* __restrict__ n_dev) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N || (n_dev != nullptr && i >= (long)*n_dev)) return;
+  float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+  for (int l = 0; l < L; l++) {
+    const float sc = g.scale[l];
+    const float d0 = (float)dLdfeatT[(long)(2 * l) * N + i] * sc, d1 = (float)dLdfeatT[(long)(2 * l + 1) * N + i] * sc;
+    const _Float16* __restrict__ j = jacT + (long)(6 * l) * N + i;
+    gx += d0 * (float)j[0] + d1 * (float)j[3 * N];
+    gy += d0 * (float)j[N] + d1 * (float)j[4 * N];
+    gz += d0 * (float)j[2 * N] + d1 * (float)j[5 * N];
   }
   dLdpos[i * 3] = gx;
   dLdpos[i * 3 + 1] = gy;
@@ -2009,6 +2062,13 @@ extern "C" int ns_ngp_encode_forward(int n_levels, int n_features, int log2_hash
 extern "C" int ns_ngp_encode_forward_n(int n_levels, int n_features, int log2_hashmap, int base_res,
                                      float per_level_scale, const float* positions, const void* params, void* out,
                                      int unit_major, long N, const int* n_dev, void* stream) {
+  return ns_ngp_encode_forward_j_n(n_levels, n_features, log2_hashmap, base_res, per_level_scale, positions, params, out, unit_major,
+                                   nullptr, N, n_dev, stream);
+}
+
+extern "C" int ns_ngp_encode_forward_j_n(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                       float per_level_scale, const float* positions, const void* params, void* out,
+                                       int unit_major, void* jacT, long N, const int* n_dev, void* stream) {
   NS_REQUIRE(positions && params && out, "ns_ngp_encode_forward: null pointer");
   GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
   GridLayout g;
@@ -2018,8 +2078,26 @@ extern "C" int ns_ngp_encode_forward_n(int n_levels, int n_features, int log2_ha
   }
   if (N <= 0) return NS_OK;
   hipLaunchKernelGGL(ngp_encode_fwd_kernel, dim3(ns_cdiv(N, 256), n_levels), dim3(256), 0, (hipStream_t)stream, g,
-                     positions, (const h2_t*)params, (h2_t*)out, N, n_levels, unit_major, n_dev);
+                     positions, (const h2_t*)params, (h2_t*)out, N, n_levels, unit_major, n_dev, (_Float16*)jacT);
   NS_CHECK_LAUNCH("ngp_encode_fwd_kernel");
+  return NS_OK;
+}
+
+// dL/dpos [N,3] = sum over levels of scale_l * J_l^T dL/dfeature_l, J from ns_ngp_encode_forward_j_n
+extern "C" int ns_ngp_encode_jacobian_dot_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                                          const void* jacT, const void* dLdoutT, float* dLdpos, long N, const int* n_dev,
+                                          void* stream) {
+  NS_REQUIRE(jacT && dLdoutT && dLdpos, "ns_ngp_encode_jacobian_dot: null pointer");
+  GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
+  GridLayout g;
+  if (grid_layout_host(c, g) != NS_OK) {
+    ns_set_error("ns_ngp_encode_jacobian_dot: need 1..16 levels and 2 features per level");
+    return NS_ENOSUP;
+  }
+  if (N <= 0) return NS_OK;
+  hipLaunchKernelGGL(ngp_encode_jac_dot_kernel, dim3(ns_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, g, (const _Float16*)jacT,
+                     (const _Float16*)dLdoutT, dLdpos, N, n_levels, n_dev);
+  NS_CHECK_LAUNCH("ngp_encode_jac_dot_kernel");
   return NS_OK;
 }
 
@@ -2244,12 +2322,11 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
     NS_CHECK_LAUNCH("ngp_enc_fscatter_kernel");
   }
   if (parts & 2) {
+    int n_groups = 0;
+    for (int k = 0; k < fp.nh; k++) n_groups += fp.nbins[k];
     hipLaunchKernelGGL(ngp_enc_faccum_kernel, dim3(NS_FB_BINS, fp.nh), dim3(NS_FB_THREADS), 0, st, g, fp, ctr, cnt, queue, ovf,
-                       grad_params, ad, N, n_dev);
+                       grad_params, ad, N, n_dev, ctr, n_groups);
     NS_CHECK_LAUNCH("ngp_enc_faccum_kernel");
-    // the overflow list is empty again for the next call (its only readers, the accumulate workgroups, are done)
-    hipLaunchKernelGGL(ngp_zero_ints_kernel, dim3(1), dim3(256), 0, st, ctr, 1);
-    NS_CHECK_LAUNCH("ngp_zero_ints_kernel");
   }
   if (!(parts & 12) || nd == 0) return NS_OK;
   EncBwdPlan plan;
@@ -2482,8 +2559,10 @@ __global__ void ngp_step_count_kernel(int* __restrict__ ctl, float beta1, float 
 // it), Adam's bias corrections -- records this step's march counters for lazy host reads and clears the other set's.
 __global__ void ngp_step_prepare_kernel(const int* __restrict__ ctl_src, int* __restrict__ ctl_dst,
                                         const int* __restrict__ counter_src, int* __restrict__ counter_dst, int* __restrict__ last,
-                                        float fill, long max_samples, int min_rays, int max_rays, float beta1, float beta2) {
+                                        float fill, long max_samples, int min_rays, int max_rays, float beta1, float beta2,
+                                        float* __restrict__ loss_dst) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (loss_dst != nullptr) *loss_dst = 0.0f;
   const int requested = counter_src[0], R = ctl_src[NS_CTL_RAYS];
   last[0] = requested;
   last[1] = counter_src[1];
@@ -2503,12 +2582,13 @@ __global__ void ngp_step_prepare_kernel(const int* __restrict__ ctl_src, int* __
 }
 
 extern "C" int ns_ngp_step_prepare(const int* ctl_src, int* ctl_dst, const int* counter_src, int* counter_dst, int* last, float fill,
-                                   long max_samples, int min_rays, int max_rays, float beta1, float beta2, void* stream) {
+                                   long max_samples, int min_rays, int max_rays, float beta1, float beta2, float* loss_dst,
+                                   void* stream) {
   NS_REQUIRE(ctl_src && ctl_dst && counter_src && counter_dst && last, "ns_ngp_step_prepare: null pointer");
   NS_REQUIRE(ctl_src != ctl_dst && counter_src != counter_dst, "ns_ngp_step_prepare: the two sets must be distinct");
   NS_REQUIRE(fill > 0.0f && max_samples > 0 && min_rays >= 128 && max_rays >= min_rays, "ns_ngp_step_prepare: bad limits");
   hipLaunchKernelGGL(ngp_step_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl_src, ctl_dst, counter_src, counter_dst,
-                     last, fill, max_samples, min_rays, max_rays, beta1, beta2);
+                     last, fill, max_samples, min_rays, max_rays, beta1, beta2, loss_dst);
   NS_CHECK_LAUNCH("ngp_step_prepare_kernel");
   return NS_OK;
 }

@@ -156,7 +156,28 @@ struct MlpFwdArgs {
   _Float16* h4T;          // [64,N]
   long N;
   const int* n_dev;       // optional: device sample count (<= N); N stays the row stride of the unit-major tensors
+  uint32_t* masks;        // optional [3 layers (h1, h3, h4)][2 lane halves][N]: ReLU bit masks for the backward pass (see below)
 };
+
+// ReLU masks.  The backward pass needs, per hidden unit, only whether the forward activation was positive; re-reading the f16
+// activations for that cost 384 B per sample and put three rounds of 16 dependent loads on the critical path of the
+// activation-gradient kernel.  The forward pass therefore also writes ONE BIT per unit: lane (j, h) holds, for its two samples,
+// the 32 units {acc_unit(it, h, r)} of each 64-wide layer -- exactly the units the backward lane (j, h) will hold in its
+// accumulators (same instruction, same layout) -- so its word for sample n is  bit (16 it + r) = [h(unit) > 0],  stored at
+// masks[layer][h][n]: the two words of a lane are adjacent (8 B per lane, 256 contiguous bytes per half-wave).  24 B per sample
+// written by the forward pass, 24 B read by the backward pass at its very start.
+__device__ __forceinline__ uint32_t relu_bits(const f16x8& lo, const f16x8& hi, int it) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    m |= ((float)lo[r] > 0.0f ? 1u : 0u) << (16 * it + r);
+    m |= ((float)hi[r] > 0.0f ? 1u : 0u) << (16 * it + 8 + r);
+  }
+  return m;
+}
+__device__ __forceinline__ uint2* mask_at(uint32_t* masks, int layer, int h, long N, long np) {
+  return reinterpret_cast<uint2*>(masks + ((long)(layer * 2 + h) * N + np));
+}
 
 // samples to process: the by-value N, or the device count rounded up to 8 (the tail slots carry zero gradients)
 __device__ __forceinline__ long ngp_count(long N, const int* n_dev) {
@@ -206,6 +227,9 @@ __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
       }
       if (st) store_tile(a.h1T, N, boff, it, &h1[0][2 * it], &h1[1][2 * it]);
     }
+    if (st && a.masks)
+      *mask_at(a.masks, 0, h, N, np) = make_uint2(relu_bits(h1[0][0], h1[0][1], 0) | relu_bits(h1[0][2], h1[0][3], 1),
+                                                  relu_bits(h1[1][0], h1[1][1], 0) | relu_bits(h1[1][2], h1[1][3], 1));
 #pragma unroll
     for (int t = 0; t < 2; t++) {  // L2 64 -> 16 (rows 16..31 of the tile are padding) + direction encoding
       const f32x16 acc = layer_tile<4>(Wf, FW_L2, 0, lane, h1[t]);
@@ -233,6 +257,9 @@ __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
       }
       if (st) store_tile(a.h3T, N, boff, it, &h3[0][2 * it], &h3[1][2 * it]);
     }
+    if (st && a.masks)
+      *mask_at(a.masks, 1, h, N, np) = make_uint2(relu_bits(h3[0][0], h3[0][1], 0) | relu_bits(h3[0][2], h3[0][3], 1),
+                                                  relu_bits(h3[1][0], h3[1][1], 0) | relu_bits(h3[1][2], h3[1][3], 1));
     f16x8 h4[2][4];
 #pragma unroll
     for (int it = 0; it < 2; it++) {  // L4 64 -> 64, ReLU
@@ -244,6 +271,9 @@ __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
       }
       if (st) store_tile(a.h4T, N, boff, it, &h4[0][2 * it], &h4[1][2 * it]);
     }
+    if (st && a.masks)
+      *mask_at(a.masks, 2, h, N, np) = make_uint2(relu_bits(h4[0][0], h4[0][1], 0) | relu_bits(h4[0][2], h4[0][3], 1),
+                                                  relu_bits(h4[1][0], h4[1][1], 0) | relu_bits(h4[1][2], h4[1][3], 1));
 #pragma unroll
     for (int t = 0; t < 2; t++) {  // L5 64 -> 16
       const f32x16 acc = layer_tile<4>(Wf, FW_L5, 0, lane, h4[t]);
@@ -266,6 +296,7 @@ struct MlpBwdArgs {
   _Float16 *d5T, *d4T, *d3T, *ddT, *d1T;  // [16,N] [64,N] [64,N] [16,N] [64,N] unit-major output gradients
   long N;
   const int* n_dev;
+  const uint32_t* masks;  // optional: the forward pass's ReLU bit masks (then h1T / h3T / h4T are not read)
 };
 
 // dy = relu'(h) * f16(acc) for one 32-unit tile of both sample tiles; returns the B chunks and stores unit-major
@@ -284,6 +315,21 @@ __device__ __forceinline__ void mask_tile(const f32x16& acc0, const f32x16& acc1
   }
 }
 
+// the same with the ReLU derivative taken from the forward pass's bit mask (bit 16 it + r of the lane's word): no loads
+__device__ __forceinline__ void mask_tile_bits(const f32x16& acc0, const f32x16& acc1, uint32_t m0, uint32_t m1,
+                                               _Float16* __restrict__ dT, long N, uint32_t boff, bool ok, int it, f16x8* o0,
+                                               f16x8* o1) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const _Float16 v0 = (m0 >> (16 * it + r)) & 1u ? (_Float16)acc0[r] : (_Float16)0;
+    const _Float16 v1 = (m1 >> (16 * it + r)) & 1u ? (_Float16)acc1[r] : (_Float16)0;
+    o0[r >> 3][r & 7] = v0;
+    o1[r >> 3][r & 7] = v1;
+    if (ok) *um_at(dT + (long)urow(it, r) * N, boff) = pack2(v0, v1);
+  }
+}
+
+template <bool BITS>
 __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
   __shared__ f16x8 Wf[BW_NFRAG * 64];
   fill_frags<true>(Wf, a.W, W5_OFF, 16, 64, BW_L5);
@@ -302,6 +348,12 @@ __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
     const long np = ok ? n0 + 2 * j : 0;
     const uint32_t boff = lane_bytes(h, N, np);
     const f16x8 go = *reinterpret_cast<const f16x8*>(a.dLdout + np * 4);  // (r,g,b,d) of samples np, np + 1
+    uint2 mk1 = make_uint2(0, 0), mk3 = mk1, mk4 = mk1;
+    if (BITS) {
+      mk1 = *reinterpret_cast<const uint2*>(a.masks + ((long)(0 * 2 + h) * N + np));
+      mk3 = *reinterpret_cast<const uint2*>(a.masks + ((long)(1 * 2 + h) * N + np));
+      mk4 = *reinterpret_cast<const uint2*>(a.masks + ((long)(2 * 2 + h) * N + np));
+    }
     // dY5: units 0..2 = colour gradients (held by h == 0, q = 0..2), rest zero
     f16x8 d5[2];
 #pragma unroll
@@ -322,15 +374,23 @@ __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
     for (int it = 0; it < 2; it++) {
       const f32x16 a0 = layer_tile<1>(Wf, BW_L5, it, lane, &d5[0]);
       const f32x16 a1 = layer_tile<1>(Wf, BW_L5, it, lane, &d5[1]);
-      asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
-      mask_tile(a0, a1, a.h4T, a.d4T, N, boff, ok, it, &d4[0][2 * it], &d4[1][2 * it]);
+      if (BITS) {
+        mask_tile_bits(a0, a1, mk4.x, mk4.y, a.d4T, N, boff, ok, it, &d4[0][2 * it], &d4[1][2 * it]);
+      } else {
+        asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
+        mask_tile(a0, a1, a.h4T, a.d4T, N, boff, ok, it, &d4[0][2 * it], &d4[1][2 * it]);
+      }
     }
 #pragma unroll
     for (int it = 0; it < 2; it++) {
       const f32x16 a0 = layer_tile<4>(Wf, BW_L4, it, lane, d4[0]);
       const f32x16 a1 = layer_tile<4>(Wf, BW_L4, it, lane, d4[1]);
-      asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
-      mask_tile(a0, a1, a.h3T, a.d3T, N, boff, ok, it, &d3[0][2 * it], &d3[1][2 * it]);
+      if (BITS) {
+        mask_tile_bits(a0, a1, mk3.x, mk3.y, a.d3T, N, boff, ok, it, &d3[0][2 * it], &d3[1][2 * it]);
+      } else {
+        asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
+        mask_tile(a0, a1, a.h3T, a.d3T, N, boff, ok, it, &d3[0][2 * it], &d3[1][2 * it]);
+      }
     }
     // layer 3^T -> d(cin); only the density half (units 0..15 = registers 0..7) flows on; the density gradient joins unit 0
     {
@@ -353,8 +413,12 @@ __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
     for (int it = 0; it < 2; it++) {
       const f32x16 a0 = layer_tile<1>(Wf, BW_L2, it, lane, &dd[0]);
       const f32x16 a1 = layer_tile<1>(Wf, BW_L2, it, lane, &dd[1]);
-      asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
-      mask_tile(a0, a1, a.h1T, a.d1T, N, boff, ok, it, &d1[0][2 * it], &d1[1][2 * it]);
+      if (BITS) {
+        mask_tile_bits(a0, a1, mk1.x, mk1.y, a.d1T, N, boff, ok, it, &d1[0][2 * it], &d1[1][2 * it]);
+      } else {
+        asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
+        mask_tile(a0, a1, a.h1T, a.d1T, N, boff, ok, it, &d1[0][2 * it], &d1[1][2 * it]);
+      }
     }
     {
       const f32x16 a0 = layer_tile<4>(Wf, BW_L1, 0, lane, d1[0]);
@@ -444,18 +508,33 @@ __global__ __launch_bounds__(256) void ngp_mlp_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// grid W_TOTAL / 64: thread (idx = tid & 63, group = tid >> 6) sums every 4th split of weight 64 * block + idx
-// (256-byte coalesced rows), the four groups meet in LDS in a fixed order (deterministic).
+// grid W_TOTAL / 16: thread (idx = tid & 15, group = tid >> 4) sums every 16th split of weight 16 * block + idx with all of
+// its loads in flight at once (the round-2 form walked 64 splits per thread one dependent load at a time: 34 us for 10 MB);
+// the sixteen groups meet in LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void ngp_mlp_wgrad_reduce_kernel(const float* __restrict__ partial, int ksplit,
                                                                    float* __restrict__ grad) {
-  __shared__ float part[4][64];
-  const int idx = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + idx;
+  __shared__ float part[16][17];
+  const int idx = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + idx;
   float s = 0.0f;
-  for (int k = grp; k < ksplit; k += 4) s += partial[(long)k * W_TOTAL + i];
+  for (int k0 = grp; k0 < ksplit; k0 += 16 * 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int k = k0 + 16 * u;
+      v[u] = k < ksplit ? partial[(long)k * W_TOTAL + i] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) s += v[u];
+  }
   part[grp][idx] = s;
   __syncthreads();
-  if (grp == 0) grad[i] += (part[0][idx] + part[1][idx]) + (part[2][idx] + part[3][idx]);
+  if (grp == 0) {
+    float t = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) t += part[q][idx];
+    grad[i] += t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -468,14 +547,21 @@ extern "C" int ns_ngp_mlp_forward(const void* weights, const void* featT, const 
 
 extern "C" int ns_ngp_mlp_forward_n(const void* weights, const void* featT, const float* dirs, void* out, void* h1T,
                                     void* cinT, void* h3T, void* h4T, long N, const int* n_dev, void* stream) {
+  return ns_ngp_mlp_forward_m_n(weights, featT, dirs, out, h1T, cinT, h3T, h4T, nullptr, N, n_dev, stream);
+}
+
+extern "C" int ns_ngp_mlp_forward_m_n(const void* weights, const void* featT, const float* dirs, void* out, void* h1T,
+                                      void* cinT, void* h3T, void* h4T, void* relu_masks, long N, const int* n_dev,
+                                      void* stream) {
   NS_REQUIRE(weights && featT && dirs && out, "ns_ngp_mlp_forward: null pointer");
+  NS_REQUIRE(relu_masks == nullptr || h1T != nullptr, "ns_ngp_mlp_forward: ReLU masks are written with the activations (training)");
   NS_REQUIRE((h1T == nullptr) == (cinT == nullptr) && (h1T == nullptr) == (h3T == nullptr) &&
                  (h1T == nullptr) == (h4T == nullptr),
              "ns_ngp_mlp_forward: pass all activation buffers (training) or none (inference)");
   NS_REQUIRE(N % 2 == 0, "ns_ngp_mlp_forward: N must be even (a lane owns two adjacent samples)");
   if (N <= 0) return NS_OK;
   MlpFwdArgs a{(const _Float16*)weights, (const _Float16*)featT, dirs, (_Float16*)out, (_Float16*)h1T,
-               (_Float16*)cinT, (_Float16*)h3T, (_Float16*)h4T, N, n_dev};
+               (_Float16*)cinT, (_Float16*)h3T, (_Float16*)h4T, N, n_dev, (uint32_t*)relu_masks};
   hipLaunchKernelGGL(ngp_mlp_fwd_kernel, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, (hipStream_t)stream, a);
   NS_CHECK_LAUNCH("ngp_mlp_fwd_kernel");
   return NS_OK;
@@ -491,12 +577,15 @@ extern "C" int ns_ngp_mlp_backward(const void* weights, const void* dLdout, cons
 
 static int mlp_dgrad_launch(const void* weights, const void* dLdout, const void* h1T, const void* h3T, const void* h4T,
                             void* dLdfeatT, void* d5T, void* d4T, void* d3T, void* ddT, void* d1T, long N, const int* n_dev,
-                            hipStream_t st) {
+                            hipStream_t st, const void* relu_masks = nullptr) {
   MlpBwdArgs b{(const _Float16*)weights, (const _Float16*)dLdout, (const _Float16*)h1T, (const _Float16*)h3T,
                (const _Float16*)h4T,     (_Float16*)dLdfeatT,     (_Float16*)d5T,       (_Float16*)d4T,
                (_Float16*)d3T,           (_Float16*)ddT,          (_Float16*)d1T,       N,
-               n_dev};
-  hipLaunchKernelGGL(ngp_mlp_bwd_kernel, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, st, b);
+               n_dev,                    (const uint32_t*)relu_masks};
+  if (relu_masks != nullptr)
+    hipLaunchKernelGGL(ngp_mlp_bwd_kernel<true>, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, st, b);
+  else
+    hipLaunchKernelGGL(ngp_mlp_bwd_kernel<false>, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, st, b);
   NS_CHECK_LAUNCH("ngp_mlp_bwd_kernel");
   return NS_OK;
 }
@@ -516,7 +605,7 @@ static int mlp_wgrad_launch(const void* featT, const void* h1T, const void* cinT
   w.n_dev = n_dev;
   hipLaunchKernelGGL(ngp_mlp_wgrad_kernel, dim3(ksplit, 5), dim3(256), 0, st, w);
   NS_CHECK_LAUNCH("ngp_mlp_wgrad_kernel");
-  hipLaunchKernelGGL(ngp_mlp_wgrad_reduce_kernel, dim3(W_TOTAL / 64), dim3(256), 0, st, partial_ws, ksplit,
+  hipLaunchKernelGGL(ngp_mlp_wgrad_reduce_kernel, dim3(W_TOTAL / 16), dim3(256), 0, st, partial_ws, ksplit,
                      grad_weights);
   NS_CHECK_LAUNCH("ngp_mlp_wgrad_reduce_kernel");
   return NS_OK;
@@ -546,6 +635,17 @@ extern "C" int ns_ngp_mlp_dgrad_n(const void* weights, const void* dLdout, const
   NS_REQUIRE(N % 8 == 0, "ns_ngp_mlp_dgrad: N must be a multiple of 8");
   if (N <= 0) return NS_OK;
   return mlp_dgrad_launch(weights, dLdout, h1T, h3T, h4T, dLdfeatT, d5T, d4T, d3T, ddT, d1T, N, n_dev, (hipStream_t)stream);
+}
+
+// the activation gradients with the ReLU derivatives taken from the forward pass's bit masks (ns_ngp_mlp_forward_m_n): the saved
+// activations are not read here at all (the weight gradients still read them)
+extern "C" int ns_ngp_mlp_dgrad_m_n(const void* weights, const void* dLdout, const void* relu_masks, void* dLdfeatT, void* d5T,
+                                    void* d4T, void* d3T, void* ddT, void* d1T, long N, const int* n_dev, void* stream) {
+  NS_REQUIRE(weights && dLdout && relu_masks && dLdfeatT && d5T && d4T && d3T && ddT && d1T, "ns_ngp_mlp_dgrad_m: null pointer");
+  NS_REQUIRE(N % 8 == 0, "ns_ngp_mlp_dgrad_m: N must be a multiple of 8");
+  if (N <= 0) return NS_OK;
+  return mlp_dgrad_launch(weights, dLdout, nullptr, nullptr, nullptr, dLdfeatT, d5T, d4T, d3T, ddT, d1T, N, n_dev, (hipStream_t)stream,
+                          relu_masks);
 }
 
 extern "C" int ns_ngp_mlp_wgrad_n(const void* featT, const void* h1T, const void* cinT, const void* h3T, const void* h4T,

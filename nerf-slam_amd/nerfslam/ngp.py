@@ -151,6 +151,7 @@ class NgpNerf:
         self.act = [torch.zeros((u, S), **h) for u in (64, 32, 64, 64)]         # h1T cinT h3T h4T
         self.dact = [torch.zeros((u, S), **h) for u in (16, 64, 64, 16, 64)]    # d5T d4T d3T ddT d1T
         self.partial = torch.zeros((c.wgrad_ksplit, MLP_TOTAL), **f)
+        self.relu_masks = torch.zeros(6 * S, dtype=torch.int32, device=dev)     # one bit per hidden unit and sample (csrc/ngp_mlp.hip)
         # Table gradient.  One trainer: the round-3 path (csrc/ngp.hip: no count pass, Adam applied to the touched entries in
         # the flush of the accumulation; the gradient buffer is not used).  Replicated trainers: gradient buffer + all-reduce
         # + streaming Adam, so the binned path that writes the buffer keeps its own workspace.
@@ -260,12 +261,12 @@ class NgpNerf:
                      # unused sample slots must hold finite inputs: the per-sample kernels run over all of them
                      s_pos=torch.full((S, 3), 0.5, **f), s_dir=torch.zeros((S, 3), **f), s_dt=torch.zeros(S, **f),
                      s_t=torch.zeros(S, **f), s_dout=torch.zeros((S, 4), **h), counter=torch.zeros(3, **i32),
+                     loss=torch.zeros(1, **f),
                      ctl=torch.tensor([self.step, min(self.rays_per_batch, Rc), self.seed & 0x7FFFFFFF, max(self.n_images, 1),
                                        fbits(1.0 - c.beta1 ** (self.step + 1)), fbits(1.0 - c.beta2 ** (self.step + 1)), 0, 0], **i32))
             self.sets.append(t)
         self.cur = 0                                     # set of the step about to be trained
         self.out_rgb, self.out_depth = torch.zeros((Rc, 3), **f), torch.zeros(Rc, **f)
-        self.loss_acc = torch.zeros(1, **f)
         self.dpos = torch.zeros((c.max_samples, 3), **f)
         self.ray_g = torch.zeros((Rc, 6), **f)
         self.last = torch.zeros(4, **i32)
@@ -330,44 +331,53 @@ class NgpNerf:
         st = stream_ptr()
         ctl = ptr(X["ctl"])
         main = torch.cuda.current_stream()
-        self.loss_acc.zero_()
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             check(L.ns_ngp_step_prepare(ptr(X["ctl"]), ptr(Y["ctl"]), ptr(X["counter"]), ptr(Y["counter"]), ptr(self.last),
-                                        C.c_float(0.9), C.c_long(S), 256, Rc, C.c_float(c.beta1), C.c_float(c.beta2), stream_ptr()),
-                  "ngp_step_prepare")
+                                        C.c_float(0.9), C.c_long(S), 256, Rc, C.c_float(c.beta1), C.c_float(c.beta2), ptr(Y["loss"]),
+                                        stream_ptr()), "ngp_step_prepare")
             self._enqueue_rays(Y)
         # sample count of THIS step = end of the marcher's reserved ranges (device memory): the per-sample kernels are launched
         # over the whole budget S (fixed grids, fixed row strides) and skip the tail the marcher did not fill
         n_dev = C.c_void_p(X["counter"].data_ptr() + 8)
         featT = self.s_feat.view(-1)[:32 * S].view(32, S)
-        check(L.ns_ngp_encode_forward_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.grid_half), ptr(featT), 1, C.c_long(S), n_dev,
-                                        st), "ngp_encode_forward")
+        jac = None
+        if c.optimize_extrinsics and not os.environ.get("NS_NGP_POSE_GATHER"):
+            # the forward pass also writes d(feature)/d(position): the pose refinement's input gradient is then a dot product
+            if getattr(self, "s_jac", None) is None:
+                self.s_jac = torch.zeros((6 * c.n_levels, S), dtype=torch.float16, device=dev)
+            jac = self.s_jac
+        check(L.ns_ngp_encode_forward_j_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.grid_half), ptr(featT), 1, ptr(jac),
+                                          C.c_long(S), n_dev, st), "ngp_encode_forward")
         acts, dacts = self.act, self.dact
-        check(L.ns_ngp_mlp_forward_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out),
-                                     *[ptr(a) for a in acts], C.c_long(S), n_dev, st), "ngp_mlp_forward")
+        check(L.ns_ngp_mlp_forward_m_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out),
+                                       *[ptr(a) for a in acts], ptr(self.relu_masks), C.c_long(S), n_dev, st), "ngp_mlp_forward")
         check(L.ns_ngp_composite_ctl(ptr(self.s_out), ptr(X["s_dt"]), ptr(X["s_t"]), ptr(X["ray_start"]), ptr(X["ray_n"]), Rc,
                                      ptr(X["r_rgb"]), ptr(X["r_depth"]), ptr(X["r_cov"]), C.c_float(c.depth_lambda),
-                                     C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), ptr(self.loss_acc),
+                                     C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), ptr(X["loss"]),
                                      ptr(X["s_dout"]), ctl, st), "ngp_composite")
         h1T, cinT, h3T, h4T = acts
         d5T, d4T, d3T, ddT, d1T = dacts
-        check(L.ns_ngp_mlp_dgrad_n(ptr(self.mlp_half), ptr(X["s_dout"]), ptr(h1T), ptr(h3T), ptr(h4T), ptr(self.s_dfeat),
-                                   ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT), ptr(d1T), C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
+        check(L.ns_ngp_mlp_dgrad_m_n(ptr(self.mlp_half), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
+                                     ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT), ptr(d1T), C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
         # everything below only READS what the activation backward wrote: three branches
         self._side.wait_stream(main)
         table_read = None
         with torch.cuda.stream(self._side):
             st2 = stream_ptr()
             if c.optimize_extrinsics:
-                # pose refinement (input gradient of the encoding: 8 gathers x 16 levels per sample, L2-request bound; per-ray
-                # and per-image reductions).  First on this stream: it reads the f16 table, which the Adam-applying passes of the
-                # table gradient rewrite -- they are held back until it is through (`table_read`)
-                check(L.ns_ngp_encode_backward_input_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.grid_half),
-                                                       ptr(self.s_dfeat), ptr(self.dpos), C.c_long(S), n_dev, st2),
-                      "ngp_encode_backward_input")
-                table_read = torch.cuda.Event()
-                table_read.record()
+                # pose refinement: input gradient of the encoding, then per-ray and per-image reductions
+                if jac is not None:
+                    check(L.ns_ngp_encode_jacobian_dot_n(*self._grid_args(), ptr(jac), ptr(self.s_dfeat), ptr(self.dpos),
+                                                         C.c_long(S), n_dev, st2), "ngp_encode_jacobian_dot")
+                else:
+                    # (A/B form, NS_NGP_POSE_GATHER=1: 8 gathers x 16 levels per sample again.  It reads the f16 table, which
+                    # the Adam-applying passes of the table gradient rewrite: they are held back until it is through)
+                    check(L.ns_ngp_encode_backward_input_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.grid_half),
+                                                           ptr(self.s_dfeat), ptr(self.dpos), C.c_long(S), n_dev, st2),
+                          "ngp_encode_backward_input")
+                    table_read = torch.cuda.Event()
+                    table_read.record()
                 n_cam = self.cam_grad.shape[0]
                 check(L.ns_ngp_camera_gradient_2stage(ptr(self.dpos), ptr(X["s_t"]), ptr(X["r_d"]), ptr(X["ray_start"]),
                                                       ptr(X["ray_n"]), ptr(X["r_img"]), C.c_float(1.0 / s), ptr(self.cam_grad), Rc,
@@ -399,6 +409,16 @@ class NgpNerf:
             check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
                                              ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev, st),
                   "ngp_encode_backward")
+        def adam(m, hp, g, m1, m2, l2, fxs, stream):
+            check(L.ns_ngp_adam_ctl(ptr(m), ptr(hp), ptr(g), ptr(m1), ptr(m2), C.c_long(m.numel()), 0, C.c_float(c.lr),
+                                    C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps), C.c_float(l2),
+                                    C.c_float(c.loss_scale * self.world), C.c_float(fxs), ctl, stream), "ngp_adam")
+        mlp = (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0)
+        if self.world == 1:
+            # the MLP's optimiser step follows its weight gradients on the side stream (nothing on the main stream reads the
+            # weights after the activation gradients): the main stream ends with the accumulate pass
+            with torch.cuda.stream(self._side):
+                adam(*mlp, stream_ptr())
         main.wait_stream(self._side)
         if self.world > 1:
             self._allreduce_gradients()
@@ -407,12 +427,10 @@ class NgpNerf:
                                            self.cam_grad.shape[0], 0, C.c_float(c.extrinsic_lr_pos), C.c_float(c.extrinsic_lr_rot),
                                            C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
                                            C.c_float(c.loss_scale * self.world), ctl, st), "ngp_camera_step")
-        for (m, hp, g, m1, m2, l2, fxs) in (
-                (self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale),
-                (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0))[1 if self.fused_adam else 0:]:
-            check(L.ns_ngp_adam_ctl(ptr(m), ptr(hp), ptr(g), ptr(m1), ptr(m2), C.c_long(m.numel()), 0, C.c_float(c.lr),
-                                    C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps), C.c_float(l2),
-                                    C.c_float(c.loss_scale * self.world), C.c_float(fxs), ctl, st), "ngp_adam")
+        if not self.fused_adam:
+            adam(self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale, st)
+        if self.world > 1:
+            adam(*mlp, st)
 
     def train_step(self, return_loss=True):
         if self.n_images == 0:
@@ -429,6 +447,7 @@ class NgpNerf:
                 # updated since: march them (again: same control block, same seed, same pixels) before the step
                 X = self.sets[x]
                 X["counter"].zero_()
+                X["loss"].zero_()
                 self._enqueue_rays(X)
                 self._primed = True
             if self.world > 1 or not c.use_graph:
@@ -467,9 +486,9 @@ class NgpNerf:
 
     @property
     def loss_tensor(self):
-        """mean per-ray loss of the last step (device scalar): loss sum over the step's rays / their number (the ray tables
-        themselves already belong to the NEXT step: its rays are marched while this step's optimiser pass runs)"""
-        return self.loss_acc / self.last[3].clamp(min=1).float()
+        """mean per-ray loss of the last step (device scalar): loss sum over the step's rays (accumulated in its set) / their
+        number (recorded by ns_ngp_step_prepare at the start of that step)"""
+        return self.sets[1 - self.cur]["loss"] / self.last[3].clamp(min=1).float()
 
     @property
     def last_samples(self):

@@ -141,6 +141,24 @@ def test_mlp_forward_backward(oracle_mod, dev):
         gg = g[off:off + w.size].reshape(w.shape)
         assert np.abs(gg - r).max() <= 1e-2 * np.abs(r).max(), w.shape
         off += w.size
+    # ReLU bit masks (round 3): the forward pass writes one bit per hidden unit, the activation backward takes the ReLU
+    # derivative from them instead of re-reading the activations -- same outputs bit for bit, also for a device sample count
+    masks = torch.zeros(6 * N, dtype=torch.int32, device=dev)
+    out_m = torch.empty_like(out)
+    bufs_m = [torch.empty_like(b) for b in bufs[1:]]
+    check(lib().ns_ngp_mlp_forward_m_n(ptr(Wd), ptr(d_featT), ptr(d_dirs), ptr(out_m), *[ptr(b) for b in bufs_m], ptr(masks),
+                                       C.c_long(N), None, stream_ptr()), "mlp fwd masks")
+    assert torch.equal(out_m, out) and all(torch.equal(a, b) for a, b in zip(bufs_m, bufs[1:]))
+    for n_dev in (None, torch.tensor([500], dtype=torch.int32, device=dev)):
+        ref_d = [torch.zeros_like(b) for b in [dfeat] + dbufs]
+        got_d = [torch.zeros_like(b) for b in [dfeat] + dbufs]
+        check(lib().ns_ngp_mlp_dgrad_n(ptr(Wd), ptr(d_dout), ptr(bufs[1]), ptr(bufs[3]), ptr(bufs[4]), *[ptr(b) for b in ref_d],
+                                       C.c_long(N), ptr(n_dev), stream_ptr()), "dgrad")
+        check(lib().ns_ngp_mlp_dgrad_m_n(ptr(Wd), ptr(d_dout), ptr(masks), *[ptr(b) for b in got_d], C.c_long(N), ptr(n_dev),
+                                         stream_ptr()), "dgrad masks")
+        for a, b in zip(ref_d, got_d):
+            assert torch.equal(a, b)
+        assert n_dev is not None or torch.equal(ref_d[0], dfeat)
 
 
 def test_composite_loss_and_adam(oracle_mod, dev):
@@ -841,3 +859,35 @@ def test_fused_table_gradient_adam_is_bit_identical(oracle_mod, dev):
         for k in ("master", "m1", "m2", "hp"):
             assert torch.equal(a[k], f[k]), (step, k, int((a[k] != f[k]).sum()))
     assert not torch.equal(st["fused"]["master"], m0)
+
+
+def test_pose_gradient_from_forward_jacobian(oracle_mod, dev):
+    """ns_ngp_encode_forward_j_n + ns_ngp_encode_jacobian_dot_n == ns_ngp_encode_backward_input_n (8 x 16 gathers per sample) up
+    to the f16 rounding of the Jacobian rows; features unchanged by the extra output; device sample count honoured"""
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    from nerfslam.ngp import NgpConfig, NgpNerf
+    net = NgpNerf(NgpConfig(), dev, seed=5)
+    g = torch.Generator(device=dev).manual_seed(6)
+    net.grid_half.copy_(((torch.rand(net.n_grid, device=dev, generator=g) - 0.5) * 0.2).half())     # a "trained" table
+    args = net._grid_args()
+    N = 8192
+    pos = torch.rand((N, 3), device=dev, generator=g).contiguous()
+    dfe = (torch.randn((32, N), device=dev, generator=g) * 1e-2).half().contiguous()
+    feat, feat_j = (torch.empty((32, N), dtype=torch.float16, device=dev) for _ in range(2))
+    jac = torch.zeros((96, N), dtype=torch.float16, device=dev)
+    nd = torch.tensor([5000], dtype=torch.int32, device=dev)
+    for n_dev in (None, nd):
+        ref, got = torch.zeros((N, 3), device=dev), torch.zeros((N, 3), device=dev)
+        check(lib().ns_ngp_encode_forward_n(*args, ptr(pos), ptr(net.grid_half), ptr(feat), 1, C.c_long(N), ptr(n_dev), stream_ptr()), "fwd")
+        check(lib().ns_ngp_encode_forward_j_n(*args, ptr(pos), ptr(net.grid_half), ptr(feat_j), 1, ptr(jac), C.c_long(N), ptr(n_dev),
+                                              stream_ptr()), "fwd j")
+        n = N if n_dev is None else 5000
+        assert torch.equal(feat[:, :n], feat_j[:, :n])
+        check(lib().ns_ngp_encode_backward_input_n(*args, ptr(pos), ptr(net.grid_half), ptr(dfe), ptr(ref), C.c_long(N), ptr(n_dev),
+                                                   stream_ptr()), "bwd input")
+        check(lib().ns_ngp_encode_jacobian_dot_n(*args, ptr(jac), ptr(dfe), ptr(got), C.c_long(N), ptr(n_dev), stream_ptr()), "jac dot")
+        assert ref[:n].abs().max() > 0 and torch.equal(ref[n:], got[n:])
+        err = (got[:n] - ref[:n]).abs().max().item()
+        assert err <= 2e-3 * ref[:n].abs().max().item(), (err, ref[:n].abs().max().item())
+        rel = ((got[:n] - ref[:n]).norm() / ref[:n].norm()).item()
+        assert rel < 5e-4, rel
