@@ -110,7 +110,7 @@ def run(args, return_modules=False, tweak=None):
         net = ngp._net
         print("slam_demo trainer %d: %d training views, %d iterations, %d optimiser steps, parameter checksum %.6f" % (
             rank, int(ngp.nerf.training.n_images_for_training), int(fusion.fusion.total_iters), int(ngp.training_step),
-            float(net.grid_master.double().sum().item()) + float(net.mlp_master.double().sum().item())), flush=True)
+            float(net.grid_half[:net.n_grid].double().sum().item()) + float(net.mlp_master.double().sum().item())), flush=True)
         dist.barrier(group=control)
         if return_modules:
             return {"data": None, "slam": None, "fusion": fusion}

@@ -120,9 +120,23 @@ class NgpNerf:
             lim = math.sqrt(6.0 / (o + i))
             w.append((torch.rand(o * i, generator=g) * 2 - 1) * lim)
         self.mlp_master = torch.cat(w).to(dev)
-        self.grid_half = self.grid_master.half()
+        # Replicated trainers exchange the table gradient SHARDED (round 3): the table's entries are cut into `world` equal
+        # shards; after the backward pass every trainer sends shard r of its packed-integer gradient to trainer r (one
+        # all-to-all: xGMI is a full mesh, every pair has its own link), sums what it receives (exact: int64), runs Adam on ITS
+        # shard only and all-gathers the f16 working copy.  Per trainer and step: (R-1)/R x (8 + 4) B per entry on the wire and 1/R
+        # of the optimiser traffic, against 2 (R-1)/R x 8 B per entry of a ring all-reduce (which is bound by ONE link) and R
+        # identical optimiser passes.  The f32 master copy and the moments of the other shards are not kept current (nothing
+        # reads them: every kernel of the step reads the f16 copy).
+        n_entries = self.n_grid // 2
+        self.shard_entries = ((n_entries + self.world - 1) // self.world + 1023) // 1024 * 1024 if self.world > 1 else n_entries
+        pad_params = 2 * self.shard_entries * self.world if self.world > 1 else self.n_grid
+        self.grid_half = torch.zeros(pad_params, dtype=torch.float16, device=dev)
+        self.grid_half[:self.n_grid] = self.grid_master.half()
         self.mlp_half = self.mlp_master.half()
-        self.grid_grad, self.mlp_grad = torch.zeros(self.n_grid, **f), torch.zeros(MLP_TOTAL, **f)
+        self.grid_grad, self.mlp_grad = torch.zeros(pad_params, **f), torch.zeros(MLP_TOTAL, **f)
+        if self.world > 1:
+            self._recv = torch.zeros((self.world, self.shard_entries), dtype=torch.int64, device=dev)
+            self._gshard = torch.zeros(self.shard_entries, dtype=torch.int64, device=dev)
         self.grid_m1, self.grid_m2 = torch.zeros(self.n_grid, **f), torch.zeros(self.n_grid, **f)
         self.mlp_m1, self.mlp_m2 = torch.zeros(MLP_TOTAL, **f), torch.zeros(MLP_TOTAL, **f)
         G, nc = c.grid_size, c.n_cascades
@@ -157,12 +171,13 @@ class NgpNerf:
         # + streaming Adam, so the binned path that writes the buffer keeps its own workspace.
         self.fused_adam = self.world == 1 and c.grad_fixed_scale > 0 and not os.environ.get("NS_NGP_TWO_PASS_ADAM")
         self.enc_ws_bytes = int(lib().ns_ngp_encode_backward_fused_workspace_bytes(*self._grid_args(), C.c_long(c.max_samples)))
-        if self.fused_adam and self.enc_ws_bytes > 0:
-            self.enc_ws = torch.zeros(self.enc_ws_bytes // 8 + 1, dtype=torch.int64, device=dev)   # zeroed once: counters
+        self.fused_ws = c.grad_fixed_scale > 0 and self.enc_ws_bytes > 0 and not os.environ.get("NS_NGP_R02_BACKWARD")
+        if self.fused_ws:
+            self.enc_ws = torch.zeros(self.enc_ws_bytes // 8 + 1, dtype=torch.int64, device=dev)   # zeroed once: overflow counter
         else:
             self.fused_adam = False
             ws_bytes = lib().ns_ngp_encode_backward_workspace_bytes(*self._grid_args(), C.c_long(c.max_samples))
-            self.enc_ws = torch.zeros(max(ws_bytes // 4, 1), **f)   # record queues / counters of the binned encode backward
+            self.enc_ws = torch.zeros(max(ws_bytes // 4, 1), **f)   # record queues / counters of round 2's binned encode backward
         self.rays_per_batch = c.n_rays
         self.samples_requested = 0
 
@@ -388,20 +403,24 @@ class NgpNerf:
                   "ngp_mlp_wgrad")
 
         def table_gradient(parts, stream):
-            check(L.ns_ngp_encode_backward_fused_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat), None, ptr(self.enc_ws),
+            # one trainer: Adam in the flushes (no gradient buffer); replicated trainers: the packed sums into the gradient buffer
+            fa = self.fused_adam
+            check(L.ns_ngp_encode_backward_fused_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat),
+                                                   None if fa else ptr(self.grid_grad), ptr(self.enc_ws),
                                                    C.c_size_t(self.enc_ws_bytes), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev,
-                                                   ptr(self.grid_master), ptr(self.grid_half), ptr(self.grid_m1), ptr(self.grid_m2),
+                                                   ptr(self.grid_master) if fa else None, ptr(self.grid_half) if fa else None,
+                                                   ptr(self.grid_m1) if fa else None, ptr(self.grid_m2) if fa else None,
                                                    0, C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
                                                    C.c_float(c.loss_scale * self.world), ctl, parts, stream), "ngp_encode_backward_fused")
-        if self.fused_adam:
+        if self.fused_ws:
             self._side2.wait_stream(main)
             with torch.cuda.stream(self._side2):
                 table_gradient(4, stream_ptr())
-                if table_read is not None:
+                if table_read is not None and self.fused_adam:
                     self._side2.wait_event(table_read)
                 table_gradient(8, stream_ptr())
             table_gradient(1, st)
-            if table_read is not None:
+            if table_read is not None and self.fused_adam:
                 main.wait_event(table_read)
             table_gradient(2, st)
             main.wait_stream(self._side2)
@@ -421,13 +440,22 @@ class NgpNerf:
                 adam(*mlp, stream_ptr())
         main.wait_stream(self._side)
         if self.world > 1:
-            self._allreduce_gradients()
+            self._exchange_gradients()
         if c.optimize_extrinsics:   # after the all-reduce: every replica applies the SAME pose update
             check(L.ns_ngp_camera_step_ctl(ptr(self.c2w), ptr(self.cam_grad), ptr(self.cam_m1), ptr(self.cam_m2),
                                            self.cam_grad.shape[0], 0, C.c_float(c.extrinsic_lr_pos), C.c_float(c.extrinsic_lr_rot),
                                            C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
                                            C.c_float(c.loss_scale * self.world), ctl, st), "ngp_camera_step")
-        if not self.fused_adam:
+        if self.world > 1 and c.grad_fixed_scale > 0:
+            # Adam on THIS trainer's shard of the table (summed gradient in `_gshard`), then the f16 copies of all shards
+            Ns = self.shard_entries
+            lo = 2 * Ns * self.rank
+            n = max(0, min(2 * Ns, self.n_grid - lo))
+            if n > 0:
+                adam(self.grid_master[lo:lo + n], self.grid_half[lo:lo + n], self._gshard.view(torch.float32)[:n], self.grid_m1[lo:lo + n],
+                     self.grid_m2[lo:lo + n], 0.0, c.grad_fixed_scale, st)
+            self._gather_parameters()
+        elif not self.fused_adam:
             adam(self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale, st)
         if self.world > 1:
             adam(*mlp, st)
@@ -502,15 +530,42 @@ class NgpNerf:
     def samples_requested_last(self):
         return int(self.last[0].item()) if getattr(self, "_static", False) else 0
 
-    def _allreduce_gradients(self):
-        """sum over the replicas; Adam then divides by loss_scale * world (mean gradient)"""
+    def _exchange_gradients(self):
+        """replicated trainers: the table gradient summed over the replicas lands SHARDED (this trainer's shard in `_gshard`),
+        the small MLP / pose gradients are all-reduced; Adam then divides by loss_scale * world (mean gradient)"""
         import torch.distributed as dist
-        g = self.grid_grad.view(torch.int64) if self.cfg.grad_fixed_scale > 0 else self.grid_grad
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+        R, Ns = self.world, self.shard_entries
+        if self.cfg.grad_fixed_scale > 0:
+            send = self.grid_grad.view(torch.int64)                      # [R * Ns] packed words, shard r = entries [r Ns, (r+1) Ns)
+            try:
+                dist.all_to_all_single(self._recv.view(-1), send, group=self.group)
+            except Exception:                                             # a backend without device all-to-all (gloo): via the host
+                h_in, h_out = send.cpu(), torch.empty((R * Ns,), dtype=torch.int64)
+                dist.all_to_all_single(h_out, h_in, group=self.group)
+                self._recv.view(-1).copy_(h_out)
+            torch.sum(self._recv, dim=0, out=self._gshard)               # exact integer sum, fixed order
+            self.grid_grad.zero_()                                       # (the streaming Adam pass that used to clear it is gone)
+            wire = (R - 1) * Ns * 8
+        else:
+            dist.all_reduce(self.grid_grad, op=dist.ReduceOp.SUM, group=self.group)
+            wire = 2 * (R - 1) * self.grid_grad.numel() * 4 // R
         dist.all_reduce(self.mlp_grad, op=dist.ReduceOp.SUM, group=self.group)
         if self.cfg.optimize_extrinsics and getattr(self, "cam_grad", None) is not None:
             dist.all_reduce(self.cam_grad, op=dist.ReduceOp.SUM, group=self.group)   # 24 B per training view
-        self.bytes_allreduced = getattr(self, "bytes_allreduced", 0) + g.numel() * g.element_size() + self.mlp_grad.numel() * 4
+        self.bytes_allreduced = getattr(self, "bytes_allreduced", 0) + wire + self.mlp_grad.numel() * 4
+
+    def _gather_parameters(self):
+        """every trainer's freshly updated shard of the f16 table -> all trainers"""
+        import torch.distributed as dist
+        R, Ns = self.world, self.shard_entries
+        mine = self.grid_half[2 * Ns * self.rank: 2 * Ns * (self.rank + 1)]
+        try:
+            dist.all_gather_into_tensor(self.grid_half, mine.clone(), group=self.group)
+        except Exception:
+            h = torch.empty(self.grid_half.shape, dtype=torch.float16)
+            dist.all_gather_into_tensor(h, mine.cpu(), group=self.group)
+            self.grid_half.copy_(h)
+        self.bytes_allreduced = getattr(self, "bytes_allreduced", 0) + (R - 1) * 2 * Ns * 2
 
     def _grow_camera_state(self, n):
         """per-view Adam moments of the pose refinement: GROWN when keyframes are added (a reset would restart the bias

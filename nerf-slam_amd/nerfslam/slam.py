@@ -43,6 +43,7 @@ class TrackingSLAM:
         self.is_initialized, self.stop = False, False
         self.kf_to_frame = {}
         self.stats = {"frames": 0, "candidates": 0, "rejected": 0, "updates": 0}   # bookkeeping only (bench / logs)
+        self.leg_ms = None     # set to a dict: backend() attributes its time per leg (adds device synchronisations: bench only)
 
     # the reference's nn.Module call
     def __call__(self, batch):
@@ -196,8 +197,31 @@ class TrackingSLAM:
         fe._drop_payload(drop_active, store=False)
 
     # ---------------------------------------------------------------------------------------------
-    def backend(self, steps):
-        """global BA over all keyframes with on-the-fly correlation (:1255-1300, :474-527)."""
+    def _leg(self, name):
+        """context manager: with `leg_ms` set, synchronise on both sides and add the elapsed time to leg `name`"""
+        import contextlib
+        import time
+        if self.leg_ms is None:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def timed():
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            yield
+            torch.cuda.synchronize(self.device)
+            self.leg_ms[name] = self.leg_ms.get(name, 0.0) + 1e3 * (time.perf_counter() - t0)
+        return timed()
+
+    def backend(self, steps, group=None):
+        """global BA over all keyframes with on-the-fly correlation (:1255-1300, :474-527).
+
+        group (torch.distributed process group, every rank holding the SAME keyframe buffer): the pass is SHARDED BY SOURCE
+        FRAME over the group's ranks (nerfslam.parallel): a rank correlates / runs the update operator /
+        linearises only the edges whose source frame it owns -- the edges of a source frame share its depth map, so every
+        Schur contribution is local and additive -- one all-reduce of the reduced camera system ((6P)^2 + 6P floats) and one of
+        the depth-map updates per BA iteration make poses and depths identical on all ranks.  The reference has no such mode
+        (its only split is tracker | mapper)."""
         fe, t = self.fe, self.fe.kf_idx
         if not bool(torch.any(fe.cam0_idepths_sensed)):                    # normalize (:1302-1307)
             s = fe.cam0_idepths[:t].mean()
@@ -219,28 +243,49 @@ class TrackingSLAM:
             fmaps = (fe.feat_bank.float() * 4.0).transpose(1, 2).reshape(1, self.buffer, 128, fe.ht, fe.wd)
             corr_op = AltCorrBlock(fmaps)
             target, weight = fe.reproject(ii, jj), torch.zeros((ii.shape[0], fe.ht, fe.wd, 2), device=self.device)
+            sba, own = None, np.ones(ii_h.shape[0], bool)
+            if group is not None:
+                import torch.distributed as dist
+                from .parallel import ShardedBA
+                if dist.get_world_size(group) > 1:
+                    sba = ShardedBA(ii_h, jj_h, 0, int(max(ii_h.max(), jj_h.max())) + 1, self.device, group=group)
+                    own = np.zeros(ii_h.shape[0], bool)
+                    own[sba.mine] = True
+                    self.last_backend_edges_mine = int(own.sum())
             for _ in range(steps):
-                coords1 = fe.reproject(ii, jj)
-                motion = fe.motion_features(coords1, target)
+                with self._leg("reproject + motion features"):
+                    coords1 = fe.reproject(ii, jj)
+                    motion = fe.motion_features(coords1, target)
                 for lo in range(0, int(jj_h.max()) + 1, 8):                # windows of 8 source frames (:494-499)
-                    vh = np.nonzero((ii_h >= lo) & (ii_h < lo + 8))[0]     # (the edge lists are host arrays: the window
+                    vh = np.nonzero(own & (ii_h >= lo) & (ii_h < lo + 8))[0]   # (the edge lists are host arrays: the window
                     if vh.shape[0] == 0:                                   #  selection costs no device read-back)
                         continue
                     v = torch.from_numpy(vh).to(self.device)
                     iv, jv = ii[v], jj[v]
-                    corr = corr_op(coords1[None, v], iv, jv)
-                    if getattr(self.net.update, "host_indices", False):
-                        res = self.net.update(corr, motion[None, v], iv, jv, ii_host=ii_h[vh].tolist(), jj_host=jj_h[vh].tolist())
-                    else:
-                        res = self.net.update(corr, motion[None, v], iv, jv)
-                    delta, w, damping = res[:3]
-                    target[v], weight[v] = coords1[v] + delta[0].float(), w[0].float()
-                    kxv = torch.from_numpy(np.unique(ii_h[vh])).to(self.device)
-                    fe.damping[kxv] = damping
-                    if len(res) > 3:
-                        fe.upsample(kxv, res[3])
-                fe.ba(target.permute(0, 3, 1, 2).contiguous(), weight.permute(0, 3, 1, 2).contiguous(), ii_h, jj_h,
-                      kf0=0, itrs=2, compute_covariances=False)   # :523-526 (its lm / ep arguments are dead: ba() never reads them)
+                    with self._leg("on-the-fly correlation (altcorr)"):
+                        corr = corr_op(coords1[None, v], iv, jv)
+                    with self._leg("update operator"):
+                        if getattr(self.net.update, "host_indices", False):
+                            res = self.net.update(corr, motion[None, v], iv, jv, ii_host=ii_h[vh].tolist(), jj_host=jj_h[vh].tolist())
+                        else:
+                            res = self.net.update(corr, motion[None, v], iv, jv)
+                    with self._leg("targets / damping / upsampling"):
+                        delta, w, damping = res[:3]
+                        target[v], weight[v] = coords1[v] + delta[0].float(), w[0].float()
+                        kxv = torch.from_numpy(np.unique(ii_h[vh])).to(self.device)
+                        fe.damping[kxv] = damping
+                        if len(res) > 3:
+                            fe.upsample(kxv, res[3])
+                with self._leg("dense BA (2 iterations)"):
+                    tg, wg = target.permute(0, 3, 1, 2).contiguous(), weight.permute(0, 3, 1, 2).contiguous()
+                    if sba is None:
+                        fe.ba(tg, wg, ii_h, jj_h, kf0=0, itrs=2, compute_covariances=False)   # :523-526 (its lm / ep arguments are
+                    else:                                                                      #  dead: ba() never reads them)
+                        kx_all = torch.from_numpy(sba.kx_all).to(self.device)
+                        eta = (0.2 * fe.damping[kx_all] + 1e-7).reshape(kx_all.shape[0], -1).contiguous()   # :428, rows like kx_all
+                        for _it in range(2):
+                            sba.iteration(fe.cam0_T_world, fe.cam0_idepths, fe.intr8, fe.cam0_T_body, fe.cam0_idepths_sensed, tg,
+                                          wg, eta, fe.world_T_body, prior_pose=fe.prior_pose)
         g.reset(max_factors=saved)
         fe._sync_edges()
         fe.viz_idx[:t] = True

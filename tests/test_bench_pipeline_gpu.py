@@ -74,3 +74,27 @@ def test_bench_multi_gpu_topology_on_one_device(nproc):
         assert tr[0]["c2w_checksum"] == tr[1]["c2w_checksum"], tr
         assert tr[0]["steps_total"] == tr[1]["steps_total"]
         assert out["rccl_bytes_per_frame"]["gradient_allreduce_per_trainer"] > 0
+
+
+def test_bench_c1280_sharded_global_ba_on_one_device():
+    """bench.py --config c1280 --gpus 2 (reduced stream, both ranks on the one GPU over gloo): the global BA sharded by source
+    frame ends with the SAME poses and depth maps on both ranks, and they equal the single-rank pass within f32 summation order"""
+    def run(nproc):
+        env = dict(os.environ, NS_BENCH_DIST_BACKEND="gloo", NS_BENCH_ONE_DEVICE="1", NS_BENCH_C1280_SMALL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        base = [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--config", "c1280"]
+        if nproc > 1:
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                   "--master-port", str(port)] + base
+        else:
+            cmd = [sys.executable] + base
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    one, two = run(1), run(2)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and one["breakdown"] is not None
+    c1, c2 = one["config"]["state_checksums"], two["config"]["state_checksums"]
+    assert c2["per_rank"][0] == c2["per_rank"][1], c2                     # identical state on both ranks
+    assert abs(c1["poses"] - c2["poses"]) <= 1e-4 * abs(c1["poses"]) and abs(c1["inverse_depths"] - c2["inverse_depths"]) <= 1e-4 * abs(c1["inverse_depths"])
+    e = two["config"]["keyframe_centre_rmse_before_after"]
+    assert e[1] < e[0]
