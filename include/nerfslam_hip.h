@@ -116,6 +116,13 @@ int ns_altcorr_backward(const float* fmap1, const float* fmap2, const float* coo
 int ns_altcorr_pyramid(const float* const* fmaps_host, int num_levels, const int64_t* ii, const int64_t* jj,
                        const float* coords, float* out, int E, int H1, int W1, int C, void* stream);
 
+/* The same for a HALF-precision pyramid -- what the reference's AltCorrBlock holds when it is given the frontend's half
+ * features (corr.py:96-105 keeps `/ 4` and avg_pool2d in the input dtype; visual_frontend.py:209) -- on the matrix cores:
+ * fmaps_host[l] -> [nframes, H1>>l, W1>>l, 128] f16 channels-last, 16-byte aligned.  Products of f16 values are exact in
+ * f32: the result equals ns_altcorr_pyramid on the same (f16-representable) values up to summation order.  C = 128 only. */
+int ns_altcorr_pyramid_f16(const void* const* fmaps_host, int num_levels, const int64_t* ii, const int64_t* jj,
+                           const float* coords, float* out, int E, int H1, int W1, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Geometry
  * ---------------------------------------------------------------------------------------- */

@@ -311,6 +311,253 @@ extern "C" int ns_altcorr_pyramid(const float* const* fmaps_host, int num_levels
   return NS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA variant for HALF-precision feature pyramids (round 3).  The reference's AltCorrBlock holds its pyramid in the dtype of
+// the features it is given -- half, in RaftVisualFrontend (visual_frontend.py:209, corr.py:96-105: `/ 4.0` and avg_pool2d
+// stay in half; only the call casts to float, :121) -- so every operand of the dot products is an f16 value, products of f16
+// values are exact in f32, and v_mfma_f32_32x32x16_f16 computes the same sums as the f32 FMA kernels above up to summation order.
+//
+// The work IS GEMM-shaped: a workgroup owns an 8 x 8 source-pixel tile of one (edge, level); D = A B^T with A = the tile's 64
+// feature vectors (64 x 128) and B = the feature vectors of the union of the tile's windows (R x 128, R ~ 15 x 15 for a smooth
+// flow): each source pixel needs 64 of its row's R dot products, the rest is the price of a dense product -- at ~4x the
+// flops the matrix cores still finish in a fraction of the time of the vector FMAs (the tile kernel above: 22 TFLOP/s of f32
+// FMAs, LDS-read bound).  No operand staging: an A or B fragment is 8 consecutive channels of one pixel = one 16-byte load
+// from the channels-last map (L1 / L2 serve the reuse); the A fragments of a wave's 32 pixels stay in registers for all of its
+// column tiles.  The accumulators are scattered straight into the 64 x 64 raw-tap table in LDS (a column = region pixel
+// belongs to the window of row m iff its offset from the window origin is in [0, 8)^2), the bilinear blend reads that table.
+// Tiles whose union exceeds AM_MAXR pixels (wild flow) take the wave-per-pixel routine.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v_t __attribute__((ext_vector_type(4)));
+typedef float f16acc_t __attribute__((ext_vector_type(16)));
+#define AM_MAXR 1024
+#define AM_C 128
+
+struct AltPyramidH {
+  const _Float16* fmap[4];  // level l: [nframes, H>>l, W>>l, 128] channels-last f16 (already / 4, pooled in half)
+  int num_levels;
+};
+
+// wave-per-pixel fallback on f16 maps (same scheme as altcorr_pixel)
+__device__ __forceinline__ void altcorr_pixel_h(const _Float16* __restrict__ f1, const _Float16* __restrict__ f2b, int H2, int W2,
+                                                float x2, float y2, float* __restrict__ out, long cs, int lane) {
+  const int half = lane >> 5, cl = lane & 31;
+  const int oy = cl >> 2, ox = half + 2 * (cl & 3);
+  const int src_x1 = (half == 0) ? lane + 32 : lane - 32 + 1;
+  const int src_y1 = lane + 4;
+  const int src_xy = src_x1 + 4;
+  const bool sane = (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
+  const float fx0 = floorf(x2), fy0 = floorf(y2);
+  const float dx = sane ? x2 - fx0 : 0.0f, dy = sane ? y2 - fy0 : 0.0f;
+  const int xb = sane ? (int)fx0 - 3 : -100000;
+  const int yb = sane ? (int)fy0 - 3 : -100000;
+  float p[32];
+#pragma unroll
+  for (int v = 0; v < 32; v++) p[v] = 0.0f;
+  const h4v_t ah = *reinterpret_cast<const h4v_t*>(f1 + 4 * cl);
+  const float4 a = make_float4((float)ah[0], (float)ah[1], (float)ah[2], (float)ah[3]);
+#pragma unroll
+  for (int iy = 0; iy < 8; iy++) {
+    const int h2 = yb + iy;
+    const bool rowok = h2 >= 0 && h2 < H2;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int w2 = xb + half + 2 * k;
+      if (rowok && w2 >= 0 && w2 < W2) {
+        const h4v_t fh = *reinterpret_cast<const h4v_t*>(f2b + ((long)h2 * W2 + w2) * AM_C + 4 * cl);
+        p[iy * 4 + k] += dot4(a, make_float4((float)fh[0], (float)fh[1], (float)fh[2], (float)fh[3]));
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 4; s >= 0; s--) {
+    const int cnt = 1 << s;
+    const bool up = (cl >> s) & 1;
+#pragma unroll
+    for (int i = 0; i < cnt; i++) {
+      const float lo = p[i], hi = p[i + cnt];
+      const float send = up ? lo : hi;
+      const float keep = up ? hi : lo;
+      p[i] = keep + __shfl_xor(send, cnt, 64);
+    }
+  }
+  const float s00 = p[0];
+  const float s01 = __shfl(s00, src_x1, 64);
+  const float s10 = __shfl(s00, src_y1, 64);
+  const float s11 = __shfl(s00, src_xy, 64);
+  if (oy < 7 && ox < 7)
+    out[(long)(oy + 7 * ox) * cs] = s00 * ((1.0f - dy) * (1.0f - dx)) + s01 * ((1.0f - dy) * dx) + s10 * (dy * (1.0f - dx)) +
+                                    s11 * (dy * dx);
+}
+
+__global__ __launch_bounds__(256) void altcorr_tile_mfma_kernel(AltPyramidH P, const int64_t* __restrict__ ii,
+                                                                const int64_t* __restrict__ jj,
+                                                                const float* __restrict__ coords, float* __restrict__ out,
+                                                                int E, int H1, int W1, int xcd_order) {
+  __shared__ float taps[64 * AT_TAPP];
+  __shared__ int bbox[4], sxb[64], syb[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lvl = blockIdx.y, e = blockIdx.z;
+  const int ntx = (W1 + 7) >> 3;
+  // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by linear id, and an 8-pixel-wide tile writes 32-byte
+  // pieces of the 128-byte lines of its 49 output planes -- horizontally adjacent tiles complete each other's lines only if
+  // they meet in the SAME L2.  Tile t of the launch therefore goes to workgroup (t % per) * 8 + t / per, per = tiles / 8:
+  // every XCD owns a contiguous run of tiles.
+  int tile = blockIdx.x;
+  if (xcd_order && (gridDim.x & 7) == 0) {
+    const int per = gridDim.x >> 3;
+    tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  }
+  const int ty = tile / ntx, tx = tile - ty * ntx;
+  const long HW1 = (long)H1 * W1;
+  const int H2 = H1 >> lvl, W2 = W1 >> lvl;
+  const float scale = 1.0f / (float)(1 << lvl);
+  const long fi = ii[e], fj = jj[e];
+  const _Float16* __restrict__ f1 = P.fmap[0] + fi * HW1 * AM_C;
+  const _Float16* __restrict__ f2 = P.fmap[lvl] + fj * (long)H2 * W2 * AM_C;
+  float* __restrict__ obase = out + ((long)e * P.num_levels * 49 + lvl * 49) * HW1;
+  // ---- per source pixel (threads 0..63): window origin, blend weights; bounding box of the windows that touch the image ----
+  bool inimg = false;
+  long pix = 0;
+  if (tid < 4) bbox[tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;
+  for (int t = tid; t < 64 * AT_TAPP; t += 256) taps[t] = 0.0f;
+  __syncthreads();
+  if (tid < 64) {
+    const int py = 8 * ty + (tid >> 3), px = 8 * tx + (tid & 7);
+    inimg = py < H1 && px < W1;
+    pix = inimg ? (long)py * W1 + px : 0;
+    float x2 = 0.0f, y2 = 0.0f;
+    if (inimg) {
+      const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + pix) * 2);
+      x2 = c.x * scale;
+      y2 = c.y * scale;
+    }
+    const bool sane = inimg && (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
+    const float fx0 = floorf(x2), fy0 = floorf(y2);
+    const int xb = sane ? (int)fx0 - 3 : -100000, yb = sane ? (int)fy0 - 3 : -100000;
+    sxb[tid] = xb;
+    syb[tid] = yb;
+    if (sane && xb > -8 && xb < W2 && yb > -8 && yb < H2) {
+      atomicMin(&bbox[0], max(xb, 0));
+      atomicMin(&bbox[1], max(yb, 0));
+      atomicMax(&bbox[2], min(xb + 8, W2));
+      atomicMax(&bbox[3], min(yb + 8, H2));
+    }
+  }
+  __syncthreads();
+  const bool empty = bbox[0] == 0x7fffffff || bbox[2] == -0x7fffffff;
+  const int x0 = bbox[0], y0 = bbox[1], RW = empty ? 0 : bbox[2] - bbox[0], RH = empty ? 0 : bbox[3] - bbox[1];
+  if (RW <= 0 || RH <= 0) {  // nothing of this tile looks into the image: zeros
+    if (tid < 64 && inimg)
+      for (int ch = 0; ch < 49; ch++) obase[(long)ch * HW1 + pix] = 0.0f;
+    return;
+  }
+  const int R = RW * RH;
+  if (R > AM_MAXR) {         // workgroup-uniform: wild flow -> wave per pixel
+    for (int k = 0; k < 16; k++) {
+      const int pp = wave * 16 + k;
+      const int qy = 8 * ty + (pp >> 3), qx = 8 * tx + (pp & 7);
+      if (qy >= H1 || qx >= W1) continue;  // wave-uniform
+      const long qpix = (long)qy * W1 + qx;
+      const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + qpix) * 2);
+      altcorr_pixel_h(f1 + qpix * AM_C, f2, H2, W2, c.x * scale, c.y * scale, obase + qpix, HW1, lane);
+    }
+    return;
+  }
+  // ---- D = A B^T on the matrix cores: wave -> row tile (wave & 1), column tiles (wave >> 1), +2, ... ----
+  const int j = lane & 31, kg = lane >> 5;
+  const int mt = wave & 1;
+  h8_t afrag[AM_C / 16];
+  {
+    const int m = 32 * mt + j;                                 // source pixel of the tile this lane supplies as A row
+    const int py = 8 * ty + (m >> 3), px = 8 * tx + (m & 7);
+    const bool ok = py < H1 && px < W1;
+    const _Float16* __restrict__ src = f1 + ((long)py * W1 + px) * AM_C + 8 * kg;
+#pragma unroll
+    for (int cc = 0; cc < AM_C / 16; cc++) afrag[cc] = ok ? *reinterpret_cast<const h8_t*>(src + 16 * cc) : (h8_t)(_Float16)0;
+  }
+  // window origins of the 16 accumulator rows of this lane (rows 4 kg + (q & 3) + 8 (q >> 2) of row tile mt), in registers
+  int wxb[16], wyb[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const int m = 32 * mt + 4 * kg + (q & 3) + 8 * (q >> 2);
+    wxb[q] = sxb[m];
+    wyb[q] = syb[m];
+  }
+  const int nnt = (R + 31) >> 5;
+  // (software-pipelining the fragment loads of the next column tile behind the matrix cores was SLOWER, 1.07 -> 1.45 ms per
+  // 48-edge launch: 32 more VGPRs cost more occupancy than the overlap won.  Counters, profiles/r03_altcorr_pmc.json: the
+  // matrix cores are ~4 % busy, HBM traffic is 0.97 GB per launch = the output written once + the maps read once; what the
+  // kernel waits for is the vector-memory pipeline -- every fragment is a 16-byte piece per lane, 32 different lines per load.)
+  for (int nt = wave >> 1; nt < nnt; nt += 2) {
+    const int r = 32 * nt + j;                                 // region pixel this lane supplies as B column
+    const bool rok = r < R;
+    const int ry = rok ? r / RW : 0, rx = rok ? r - ry * RW : 0;
+    const _Float16* __restrict__ src = f2 + ((long)(y0 + ry) * W2 + (x0 + rx)) * AM_C + 8 * kg;
+    h8_t bfrag[AM_C / 16];
+#pragma unroll
+    for (int cc = 0; cc < AM_C / 16; cc++) bfrag[cc] = rok ? *reinterpret_cast<const h8_t*>(src + 16 * cc) : (h8_t)(_Float16)0;
+    f16acc_t acc = (f16acc_t)0.0f;
+#pragma unroll
+    for (int cc = 0; cc < AM_C / 16; cc++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[cc], bfrag[cc], acc, 0, 0, 0);
+    // this lane holds column j (its own region pixel) of rows 4 kg + (q & 3) + 8 (q >> 2)
+    if (rok) {
+      const int gx = x0 + rx, gy = y0 + ry;
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int m = 32 * mt + 4 * kg + (q & 3) + 8 * (q >> 2);
+        const int tx8 = gx - wxb[q], ty8 = gy - wyb[q];
+        if ((unsigned)tx8 < 8u && (unsigned)ty8 < 8u) taps[m * AT_TAPP + ty8 * 8 + tx8] = acc[q];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- bilinear blend: thread (pixel p, quarter q4) writes output rows 2 q4, 2 q4 + 1 ----
+  const int p = tid >> 2, q4 = tid & 3;
+  const int py = 8 * ty + (p >> 3), px = 8 * tx + (p & 7);
+  if (py >= H1 || px >= W1) return;
+  const long opix = (long)py * W1 + px;
+  const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + opix) * 2);
+  const float x2 = c.x * scale, y2 = c.y * scale;
+  const bool sane = (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
+  const float ddx = sane ? x2 - floorf(x2) : 0.0f, ddy = sane ? y2 - floorf(y2) : 0.0f;
+  const float w00 = (1.0f - ddy) * (1.0f - ddx), w01 = (1.0f - ddy) * ddx, w10 = ddy * (1.0f - ddx), w11 = ddy * ddx;
+#pragma unroll
+  for (int r2 = 0; r2 < 2; r2++) {
+    const int oy = 2 * q4 + r2;
+    if (oy >= 7) continue;
+    const float* T0 = taps + p * AT_TAPP + oy * 8;
+#pragma unroll
+    for (int ox = 0; ox < 7; ox++)
+      obase[(long)(oy + 7 * ox) * HW1 + opix] = T0[ox] * w00 + T0[ox + 1] * w01 + T0[8 + ox] * w10 + T0[8 + ox + 1] * w11;
+  }
+}
+
+extern "C" int ns_altcorr_pyramid_f16(const void* const* fmaps_host, int num_levels, const int64_t* ii, const int64_t* jj,
+                                      const float* coords, float* out, int E, int H1, int W1, int C, void* stream) {
+  if (E == 0) return NS_OK;
+  NS_REQUIRE(fmaps_host && ii && jj && coords && out, "ns_altcorr_pyramid_f16: null pointer");
+  NS_REQUIRE(num_levels >= 1 && num_levels <= 4, "ns_altcorr_pyramid_f16: num_levels=%d not in 1..4", num_levels);
+  NS_REQUIRE(E >= 0 && H1 > 0 && W1 > 0, "ns_altcorr_pyramid_f16: bad shape");
+  NS_REQUIRE((H1 >> (num_levels - 1)) > 0 && (W1 >> (num_levels - 1)) > 0, "ns_altcorr_pyramid_f16: level is empty");
+  if (C != AM_C || E > 65535) {
+    ns_set_error("ns_altcorr_pyramid_f16: built for 128 channels and at most 65535 edges per call (C=%d, E=%d): use the f32 entry", C, E);
+    return NS_ENOSUP;
+  }
+  AltPyramidH P;
+  P.num_levels = num_levels;
+  for (int l = 0; l < 4; l++) {
+    P.fmap[l] = (const _Float16*)fmaps_host[l < num_levels ? l : num_levels - 1];
+    NS_REQUIRE(P.fmap[l] != nullptr && ((uintptr_t)P.fmap[l] % 16) == 0, "ns_altcorr_pyramid_f16: fmaps[%d] null or not 16-byte aligned", l);
+  }
+  dim3 grid(((H1 + 7) / 8) * ((W1 + 7) / 8), num_levels, E);
+  static const bool no_xcd = getenv("NS_ALTCORR_NO_XCD") != nullptr;   // A/B switch: linear tile order
+  hipLaunchKernelGGL(altcorr_tile_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, out, E, H1, W1,
+                     no_xcd ? 0 : 1);
+  NS_CHECK_LAUNCH("altcorr_tile_mfma_kernel");
+  return NS_OK;
+}
+
 extern "C" int ns_altcorr_forward(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B,
                                   int H1, int W1, int H2, int W2, int C, int N, int radius, void* stream) {
   NS_REQUIRE(fmap1 && fmap2 && coords && corr, "ns_altcorr_forward: null pointer");

@@ -10,6 +10,7 @@ libnerfslam_hip.so:
     [.., 196, ht, wd] tensor directly (the reference does 4 launches + permute + cat).
 """
 import ctypes as C
+import os as _os
 
 import torch
 
@@ -242,7 +243,13 @@ class AltCorrBlock:
         if B != 1:
             raise NerfSlamHipError("AltCorrBlock: batch size 1 only (visual_frontend.py:479 always passes 1)")
         self.shape = (N, Cc, H, W)
-        level = fmaps.reshape(N, Cc, H, W).float() / 4.0  # corr.py:98
+        # The reference keeps the pyramid in the dtype of the features it is given (corr.py:96-105: `/ 4.0` and avg_pool2d stay
+        # in that dtype; only the kernel call casts to float, :121).  Half features (what RaftVisualFrontend holds,
+        # visual_frontend.py:209) therefore give a HALF pyramid, rounded to half after every pooling -- kept that way here and
+        # correlated on the matrix cores (csrc/altcorr.hip: altcorr_tile_mfma_kernel); anything else takes the f32 kernels.
+        self.half = fmaps.dtype == torch.float16 and Cc == 128 and not _os.environ.get("NS_ALTCORR_F32")
+        level = fmaps.reshape(N, Cc, H, W)
+        level = (level / 4.0) if self.half else (level.float() / 4.0)  # corr.py:98
         self.pyramid = []
         for l in range(num_levels):
             self.pyramid.append(level.permute(0, 2, 3, 1).contiguous())  # [N, h, w, C]
@@ -265,8 +272,8 @@ class AltCorrBlock:
             cs = coords[0, :, :, :, s].contiguous().float()
             out = torch.empty((E, self.num_levels * 49, H, W), dtype=torch.float32, device=coords.device)
             with torch.cuda.device(coords.device):
-                check(lib().ns_altcorr_pyramid(arr, self.num_levels, ptr(ii), ptr(jj), ptr(cs), ptr(out), E, H, W, Cc,
-                                               stream_ptr()), "altcorr_pyramid")
+                fn = lib().ns_altcorr_pyramid_f16 if self.half else lib().ns_altcorr_pyramid
+                check(fn(arr, self.num_levels, ptr(ii), ptr(jj), ptr(cs), ptr(out), E, H, W, Cc, stream_ptr()), "altcorr_pyramid")
             outs.append(out)
         out = outs[0][None] if squeeze else torch.stack(outs, dim=-1)[None]
         return out.contiguous()

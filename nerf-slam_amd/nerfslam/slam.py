@@ -240,7 +240,8 @@ class TrackingSLAM:
             ii_h, jj_h, _ = g.add(es[:, 0], es[:, 1])
             self.last_backend_edges = int(ii_h.shape[0])
             ii, jj = torch.from_numpy(ii_h).to(self.device), torch.from_numpy(jj_h).to(self.device)
-            fmaps = (fe.feat_bank.float() * 4.0).transpose(1, 2).reshape(1, self.buffer, 128, fe.ht, fe.wd)
+            # (half, like the reference's features_imgs: AltCorrBlock then keeps a half pyramid and correlates on the matrix cores)
+            fmaps = (fe.feat_bank * 4.0).transpose(1, 2).reshape(1, self.buffer, 128, fe.ht, fe.wd)
             corr_op = AltCorrBlock(fmaps)
             target, weight = fe.reproject(ii, jj), torch.zeros((ii.shape[0], fe.ht, fe.wd, 2), device=self.device)
             sba, own = None, np.ones(ii_h.shape[0], bool)

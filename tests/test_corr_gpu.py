@@ -145,7 +145,20 @@ def test_altcorr_forward(oracle_mod, dev, cfg):
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=1e-5 * np.abs(ref).max())
 
 
-def test_altcorr_block_fused_pyramid(oracle_mod, dev):
+def _ref_levels(fm, half):
+    """reference pyramid of AltCorrBlock (corr.py:96-105) as channels-last float32 arrays: `/ 4` and avg_pool2d in the dtype of
+    the features -- half features give a pyramid ROUNDED TO HALF after every pooling (the float cast happens at the call, :121)"""
+    lv = torch.from_numpy(fm[0])
+    lv = lv / 4.0 if half else lv.float() / 4.0
+    out = []
+    for _ in range(4):
+        out.append(lv.float().permute(0, 2, 3, 1).contiguous().numpy())
+        lv = torch.nn.functional.avg_pool2d(lv, 2, stride=2)
+    return out
+
+
+@pytest.mark.parametrize("half", [True, False], ids=["f16_mfma", "f32"])
+def test_altcorr_block_fused_pyramid(oracle_mod, dev, half):
     """AltCorrBlock (fused, frame-indexed) == per-level altcorr_forward of the oracle on gathered maps."""
     from nerfslam.corr import AltCorrBlock
     rng = np.random.default_rng(7)
@@ -155,20 +168,20 @@ def test_altcorr_block_fused_pyramid(oracle_mod, dev):
     jj = rng.integers(0, nfr, E).astype(np.int64)
     gy, gx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
     coords = (np.stack([gx, gy], -1)[None, None] + rng.uniform(-7, 7, (1, E, H, W, 2))).astype(np.float32)
-    blk = AltCorrBlock(torch.from_numpy(fm).to(dev))
+    fmt = torch.from_numpy(fm).to(dev)
+    blk = AltCorrBlock(fmt if half else fmt.float())
+    assert blk.half == half
     got = blk(torch.from_numpy(coords).to(dev), torch.from_numpy(ii).to(dev), torch.from_numpy(jj).to(dev))
     assert got.shape == (1, E, 196, H, W)
-    lv = torch.from_numpy(fm[0]).float() / 4.0
-    f0 = lv.permute(0, 2, 3, 1).contiguous().numpy()
+    lvs = _ref_levels(fm, half)
     for l in range(4):
-        f = lv.permute(0, 2, 3, 1).contiguous().numpy()
-        ref = oracle_mod.altcorr_forward(f0[ii], f[jj], coords[0][:, None] / np.float32(2 ** l), 3)[:, 0]
+        ref = oracle_mod.altcorr_forward(lvs[0][ii], lvs[l][jj], coords[0][:, None] / np.float32(2 ** l), 3)[:, 0]
         g = got[0, :, 49 * l:49 * (l + 1)].cpu().numpy()
         np.testing.assert_allclose(g, ref, rtol=0, atol=1e-5 * np.abs(ref).max())
-        lv = torch.nn.functional.avg_pool2d(lv, 2, stride=2)
 
 
-def test_altcorr_block_smooth_flow_and_tiles_that_leave_the_image(oracle_mod, dev):
+@pytest.mark.parametrize("half", [True, False], ids=["f16_mfma", "f32"])
+def test_altcorr_block_smooth_flow_and_tiles_that_leave_the_image(oracle_mod, dev, half):
     """The staged (LDS) path of the tile kernel: a smooth flow keeps a tile's windows inside a small box.  Edge 1 is shifted
     so far that whole 8x8 tiles look outside the image (their box stays empty -> exact zeros, altcorr_kernel.cu:63-66 `within`),
     edge 2 leaves only on the right-hand side; H is not a multiple of 8 (the 1280x720 grid is 90 rows)."""
@@ -180,19 +193,18 @@ def test_altcorr_block_smooth_flow_and_tiles_that_leave_the_image(oracle_mod, de
     gy, gx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
     base = np.stack([gx, gy], -1).astype(np.float32)
     coords = np.stack([base + [1.3, -0.6], base + [3.0 * W, 0.4], base + [W - 20.25, 2.5]])[None].astype(np.float32)
-    blk = AltCorrBlock(torch.from_numpy(fm).to(dev))
+    fmt = torch.from_numpy(fm).to(dev)
+    blk = AltCorrBlock(fmt if half else fmt.float())
     got = blk(torch.from_numpy(coords).to(dev), torch.from_numpy(ii).to(dev), torch.from_numpy(jj).to(dev))[0].cpu().numpy()
     assert np.all(got[1] == 0.0), "windows entirely outside the image correlate to exact zeros"
-    lv = torch.from_numpy(fm[0]).float() / 4.0
-    f0 = lv.permute(0, 2, 3, 1).contiguous().numpy()
+    lvs = _ref_levels(fm, half)
     for l in range(4):
-        f = lv.permute(0, 2, 3, 1).contiguous().numpy()
-        ref = oracle_mod.altcorr_forward(f0[ii], f[jj], coords[0][:, None] / np.float32(2 ** l), 3)[:, 0]
+        ref = oracle_mod.altcorr_forward(lvs[0][ii], lvs[l][jj], coords[0][:, None] / np.float32(2 ** l), 3)[:, 0]
         np.testing.assert_allclose(got[:, 49 * l:49 * (l + 1)], ref, rtol=0, atol=1e-5 * np.abs(ref).max())
-        lv = torch.nn.functional.avg_pool2d(lv, 2, stride=2)
 
 
-def test_altcorr_block_vs_oracle_at_c1280(oracle_mod, dev):
+@pytest.mark.parametrize("half", [True, False], ids=["f16_mfma", "f32"])
+def test_altcorr_block_vs_oracle_at_c1280(oracle_mod, dev, half):
     """altcorr_tile_kernel at config #5's grid (1280x720 -> 90x160; 90 is not a multiple of 8) against the oracle, every
     level: a smooth flow (LDS-staged path), a flow that leaves the image on the right and at the bottom, a per-pixel random
     flow (windows of one tile far apart: the box does not fit the staging buffer), and an edge entirely outside."""
@@ -208,19 +220,17 @@ def test_altcorr_block_vs_oracle_at_c1280(oracle_mod, dev):
                        base + [W - 30.25, H - 20.5] + 0.5 * swirl,
                        base + rng.uniform(-12, 12, base.shape).astype(np.float32),
                        base + [-2.0 * W, 3.0 * H]])[None].astype(np.float32)
-    blk = AltCorrBlock(torch.from_numpy(fm).to(dev))
+    fmt = torch.from_numpy(fm).to(dev)
+    blk = AltCorrBlock(fmt if half else fmt.float())
     got = blk(torch.from_numpy(coords).to(dev), torch.from_numpy(ii).to(dev), torch.from_numpy(jj).to(dev))[0].cpu().numpy()
     assert got.shape == (4, 196, H, W)
     assert np.all(got[3] == 0.0)
-    lv = torch.from_numpy(fm[0]).float() / 4.0
-    f0 = lv.permute(0, 2, 3, 1).contiguous().numpy()
+    lvs = _ref_levels(fm, half)
     for l in range(4):
-        f = lv.permute(0, 2, 3, 1).contiguous().numpy()
-        ref = oracle_mod.altcorr_forward(f0[ii], f[jj], coords[0][:, None] / np.float32(2 ** l), 3)[:, 0]
+        ref = oracle_mod.altcorr_forward(lvs[0][ii], lvs[l][jj], coords[0][:, None] / np.float32(2 ** l), 3)[:, 0]
         g = got[:, 49 * l:49 * (l + 1)]
         assert np.abs(ref[:3]).max() > 0.2 and (ref[1] == 0).mean() > 0.5 and (ref[1] != 0).mean() > 0.005
         np.testing.assert_allclose(g, ref, rtol=0, atol=1e-5 * np.abs(ref).max(), err_msg=f"level {l}")
-        lv = torch.nn.functional.avg_pool2d(lv, 2, stride=2)
 
 
 def test_altcorr_backward_against_autograd(dev):
@@ -314,10 +324,15 @@ def test_full_size_c1280_properties(dev):
     vol = a.corr_pyramid[0][0]
     own = vol.reshape(ht * wd, ht * wd).diagonal().view(ht, wd)
     assert torch.equal(centre, own)
-    alt = AltCorrBlock(torch.cat([f1, f2], 1).float())
-    rc = alt(coords, torch.tensor([0], device=dev), torch.tensor([1], device=dev))
     scale = ra.float().abs().max().item()
-    assert (rc[0, 0] - ra[0, 0].float()).abs().max().item() <= 4e-3 * scale     # f16 volume vs f32 on-the-fly
+    outs = []
+    for feats in (torch.cat([f1, f2], 1).float(), torch.cat([f1, f2], 1)):       # f32 kernels, then the half pyramid on the matrix cores
+        alt = AltCorrBlock(feats)
+        rc = alt(coords, torch.tensor([0], device=dev), torch.tensor([1], device=dev))
+        assert (rc[0, 0] - ra[0, 0].float()).abs().max().item() <= 4e-3 * scale     # f16 volume vs f32 on-the-fly
+        outs.append(rc)
+    # level 0 of both on-the-fly paths sees the same f16 values: equal up to the summation order
+    assert (outs[0][0, 0, :49] - outs[1][0, 0, :49]).abs().max().item() <= 1e-5 * scale
 
 
 def test_empty_edge_sets(dev):
