@@ -93,13 +93,16 @@ def run(args, return_modules=False, tweak=None):
         fusion = FusionModule("nerf", args_seq, device=dev)
         fusion.initialize_module()
         import time
+        idle = 0
         while True:                                          # (a trainer that reached its stop condition keeps answering the
             msg = chan.poll()                                #  tracker's broadcasts until STOP: collectives must stay matched)
             if msg is None:
                 if not fusion.shutdown:
                     fusion.spin_once(False)                  # nothing arrived: train (nerf_fusion.py:249-253)
+                    idle = 0
                 else:
-                    time.sleep(0.001)
+                    idle = min(idle + 1, 50)                 # done training: back off (1 .. 50 ms) instead of hammering the
+                    time.sleep(0.001 * idle)                 # tracker's rendezvous store with a poll per millisecond
                 continue
             kind, pkt = msg
             if kind == transport.KIND_PACKET and not fusion.shutdown:
@@ -152,10 +155,13 @@ def run(args, return_modules=False, tweak=None):
     if threaded:
         fusion.initialize_module()
         worker = spin_in_thread(fusion, dev)
+        slam_q.consumer_alive = lambda: worker.is_alive() and getattr(fusion, "error", None) is None
         while data.spin() and slam.spin() and not fusion.shutdown:
             pass
         while worker.is_alive() and not fusion.shutdown:      # the data ran out: let the mapper reach its stop condition
             worker.join(timeout=0.05)
+        if getattr(fusion, "error", None) is not None:        # the mapper thread died: surface its exception here
+            raise fusion.error
         if return_modules:
             return {"data": data, "slam": slam, "fusion": fusion}
         return

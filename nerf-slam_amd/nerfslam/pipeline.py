@@ -34,13 +34,24 @@ class StreamQueue(_queue.Queue):
     examples/slam_demo.py:100-160).  put() records an event on the producer's current stream; get() makes the consumer's
     current stream wait for it and tells the caching allocator that the packet's tensors are in use there."""
 
+    consumer_alive = None      # optional callable: False once the consuming thread has died (set by the driver)
+
     def put(self, item, block=True, timeout=None):
         import torch
         ev = None
         if item is not None and torch.cuda.is_available():
             ev = torch.cuda.Event()
             ev.record()
-        super().put((item, ev), block, timeout)
+        if not block or timeout is not None or self.consumer_alive is None:
+            return super().put((item, ev), block, timeout)
+        # a blocking put into a bounded queue must not outlive its consumer: with the mapper thread dead (a graph-capture
+        # fault, an out-of-memory) the tracker used to block here forever once the queue was full (ADVICE r02)
+        while True:
+            try:
+                return super().put((item, ev), True, 0.25)
+            except _queue.Full:
+                if not self.consumer_alive():
+                    raise RuntimeError("StreamQueue: the consumer of this queue has died") from None
 
     def get(self, block=True, timeout=None):
         import torch
@@ -56,19 +67,24 @@ class StreamQueue(_queue.Queue):
 
 def spin_in_thread(module, device, stream=None):
     """run `module.spin()` (its parallel_run loop) in a host thread under its own HIP stream; returns the thread"""
+    import contextlib
     import torch
-    stream = stream or torch.cuda.Stream(device=device)
+    on_gpu = torch.device(device).type == "cuda"
+    if on_gpu:
+        stream = stream or torch.cuda.Stream(device=device)
 
     def work():
-        torch.cuda.set_device(device)
+        if on_gpu:
+            torch.cuda.set_device(device)
         torch.set_grad_enabled(False)
-        with torch.cuda.stream(stream):
+        with (torch.cuda.stream(stream) if on_gpu else contextlib.nullcontext()):
             try:
                 module.spin()
             except BaseException as e:       # noqa: BLE001 -- surfaced through the module's failure callbacks
                 log.error("module %s died: %s", module.name, e)
                 module.error = e
                 module.notify_on_failure()
+                module.shutdown_module()         # drivers poll `shutdown`: a dead module must not look like a busy one
     t = threading.Thread(target=work, name=f"nerfslam-{module.name}", daemon=True)
     t.start()
     return t

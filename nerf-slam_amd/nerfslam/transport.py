@@ -132,6 +132,9 @@ class PacketChannel:
         self._store = dist.PrefixStore("nerfslam_packet_channel", _get_default_store())
         self.bytes_sent = 0
         self.packets = 0
+        self.max_inflight = 4          # payload broadcasts the tracker keeps in flight before it waits for the oldest (ADVICE r02:
+                                       # ~4.7 MB per keyframe stay alive while the trainers lag; unbounded before)
+        self.tracker_lost = False      # leader: the rendezvous store (hosted by the tracker process) stopped answering
 
     # ---- tracker --------------------------------------------------------------------------------------------
     def _reap(self, block=False):
@@ -152,6 +155,9 @@ class PacketChannel:
             header, payload = torch.tensor([MAGIC, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int64), None
         header[7] = kind
         if payload is not None:
+            while len(self._inflight) >= self.max_inflight:      # trainers are behind: wait for the oldest broadcast
+                work, _hold = self._inflight.pop(0)
+                work.wait()
             self._inflight.append((dist.broadcast(payload, self.tracker, group=self.data, async_op=True), payload))
             self.bytes_sent += payload.numel() * len(self.trainers)
             self.packets += 1
@@ -175,11 +181,16 @@ class PacketChannel:
         header = torch.zeros(HEADER, dtype=torch.int64)
         if self.rank == self.leader:
             key = f"h{self._seq}"
-            if self._store.check([key]):
-                import numpy as np
-                header = torch.from_numpy(np.frombuffer(self._store.get(key), dtype=np.int64).copy())
-                self._store.delete_key(key)
-                self._seq += 1
+            try:
+                found = self._store.check([key])
+                if found:
+                    import numpy as np
+                    header = torch.from_numpy(np.frombuffer(self._store.get(key), dtype=np.int64).copy())
+                    self._store.delete_key(key)
+                    self._seq += 1
+            except Exception:          # the store lives in the tracker's process: it is gone (crashed before publishing STOP).
+                self.tracker_lost = True   # Tell every trainer to stop instead of polling a dead mailbox forever
+                header = torch.tensor([MAGIC, 0, 0, 0, 0, 0, 0, KIND_STOP], dtype=torch.int64)
         if len(self.trainers) > 1:
             dist.broadcast(header, self.leader, group=self.trainer_control)
         if int(header[0]) != MAGIC:

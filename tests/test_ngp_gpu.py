@@ -1,6 +1,7 @@
 """GPU parity of the mapping-path kernels against oracle/ngp_oracle.c (parity UNPINNED by the reference:
 instant-ngp is an un-vendored dependency, see the oracle header)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -891,3 +892,60 @@ def test_pose_gradient_from_forward_jacobian(oracle_mod, dev):
         assert err <= 2e-3 * ref[:n].abs().max().item(), (err, ref[:n].abs().max().item())
         rel = ((got[:n] - ref[:n]).norm() / ref[:n].norm()).item()
         assert rel < 5e-4, rel
+
+
+def test_graph_capture_while_another_thread_synchronises(dev):
+    """--parallel_run on one GPU: the mapper thread captures its step graphs (again whenever an address in the step
+    changes) while the tracker thread launches kernels and reads results back.  ROCm 7.2 answered a synchronising call made
+    during another thread's capture with hipErrorIllegalState; captures and the tracker's read-backs therefore share
+    nerfslam._lib.capture_lock.  Loop both for a while: no exception in either thread, training still converges."""
+    import importlib.util
+    import threading
+    import time
+    from nerfslam._lib import capture_lock
+    from nerfslam.ngp import NgpConfig, NgpNerf
+    spec = importlib.util.spec_from_file_location("ngp_scene", os.path.join(os.path.dirname(__file__), "..", "tools", "ngp_scene.py"))
+    sc = importlib.util.module_from_spec(spec); spec.loader.exec_module(sc)
+    imgs, deps, covs, poses, intr = sc.sphere_scene(n=4, H=60, W=80, f=75.0)
+    net = NgpNerf(NgpConfig(), dev, seed=0)
+    net.set_images(imgs, deps, covs, poses, intr)
+    errors, stop, captures = [], threading.Event(), [0]
+    side = torch.cuda.Stream(device=dev)
+
+    def mapper():
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(side):
+                for k in range(240):
+                    if k % 12 == 0:               # a changed constant of the captured step: both parities are captured again
+                        net.cfg.depth_lambda = 1.0 + 1e-3 * (k // 12)
+                        captures[0] += 1
+                    net.train_step(return_loss=False)
+                torch.cuda.current_stream().synchronize()
+        except BaseException as e:               # noqa: BLE001
+            errors.append(("mapper", e))
+        finally:
+            stop.set()
+
+    def tracker():
+        try:
+            torch.cuda.set_device(dev)
+            x = torch.randn((256, 256), device=dev)
+            n = 0
+            while not stop.is_set():
+                y = x @ x                          # launches outside the lock, like the tracker's kernels
+                with capture_lock:                 # host read-backs under the lock, like TrackingSLAM's
+                    float(y[0, 0])
+                    torch.cuda.current_stream().synchronize()
+                n += 1
+            assert n > 20
+        except BaseException as e:               # noqa: BLE001
+            errors.append(("tracker", e))
+
+    ta, tb = threading.Thread(target=mapper), threading.Thread(target=tracker)
+    t0 = time.time()
+    ta.start(); tb.start()
+    ta.join(timeout=180); tb.join(timeout=30)
+    assert not ta.is_alive() and not tb.is_alive(), "threads hung"
+    assert not errors, errors
+    assert captures[0] >= 20 and net.step == 240 and np.isfinite(float(net.loss_tensor)) and time.time() - t0 < 180

@@ -70,3 +70,38 @@ def test_mimo_contract():
     assert m.spin() is False
     m.restart()
     assert not m.shutdown
+
+
+def test_dead_consumer_does_not_block_the_producer():
+    """--parallel_run on one GPU: the mapper spins in a host thread and consumes a BOUNDED StreamQueue.  If that thread dies
+    (a graph-capture fault, an out-of-memory), the module must read as shut down and a blocking put must raise instead of
+    waiting forever on a queue nobody drains."""
+    import time
+
+    import pytest
+
+    from nerfslam.pipeline import StreamQueue, spin_in_thread
+
+    class _Boom:
+        def fuse(self, packets):
+            raise MemoryError("simulated mapper fault")
+
+        def stop_condition(self):
+            return False
+
+    args = argparse.Namespace(parallel_run=True)
+    fusion = FusionModule("nerf", args)
+    fusion.fusion, fusion.is_initialized = _Boom(), True
+    q = StreamQueue(maxsize=2)
+    fusion.register_input_queue("slam", q)
+    called = []
+    fusion.register_on_failure_callback(lambda: called.append(1))
+    worker = spin_in_thread(fusion, "cpu")
+    q.consumer_alive = lambda: worker.is_alive() and getattr(fusion, "error", None) is None
+    worker.join(timeout=10)
+    assert not worker.is_alive() and fusion.shutdown and isinstance(fusion.error, MemoryError) and called == [1]
+    q.put({"k": 0}); q.put({"k": 1})          # fills the queue
+    t0 = time.time()
+    with pytest.raises(RuntimeError):
+        q.put({"k": 2})                       # would have blocked forever
+    assert time.time() - t0 < 5
