@@ -577,6 +577,12 @@ int ns_ngp_grid_cells(int grid_size, int n_cascades, unsigned seed, int n, float
                       void* stream);
 int ns_ngp_grid_update(const void* net_out, const int* cells, int n, float min_step, float decay, float max_threshold,
                        float* density_grid, long n_cells_total, double* partial_ws, unsigned char* bits, void* stream);
+/* The same refresh with the decay applied ONLY to the cells drawn in this update (grid[c] = max(decay grid[c], new maximum of c);
+ * undrawn cells keep their value): the subset rule draws 4 % of the grid per update, decaying all of it lets unobserved dense
+ * cells fade below the threshold between two draws.  tmp_grid: n_cells_total floats, zeroed once by the caller, left zeroed.   */
+int ns_ngp_grid_update_sampled(const void* net_out, const int* cells, int n, float min_step, float decay, float max_threshold,
+                               float* density_grid, float* tmp_grid, long n_cells_total, double* partial_ws, unsigned char* bits,
+                               void* stream);
 
 #ifdef __cplusplus
 }

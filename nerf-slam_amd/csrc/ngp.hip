@@ -2665,6 +2665,33 @@ __global__ __launch_bounds__(256) void ngp_grid_max_kernel(const _Float16* __res
   if (dens == dens) atomicMax(reinterpret_cast<int*>(grid) + cells[i], __float_as_int(fmaxf(dens, 0.0f)));
 }
 
+// The subset refresh re-evaluates 2^18 of the 3 x 128^3 cells per update.  Decaying EVERY cell on every update (the rule above,
+// instant-ngp's -- which however re-evaluates HALF of the grid each time) lets a moderately dense cell fall to 0.95^25 ~ 0.28 of
+// its value before it is drawn again: cells drop below the occupancy threshold although nothing changed.  The
+// sampled form advances a cell's moving maximum only when the cell is observed:
+//   grid[c] = max(decay * grid[c], max over this update's samples of c)       for the drawn cells, nothing elsewhere.
+// Three passes over the samples, deterministic whatever the number of draws of a cell (`tmp`: a zeroed float per cell, left
+// zeroed): maximum into tmp (integer atomicMax on the float bits), the ONE lane that swaps a cell's maximum out applies it, reset.
+__global__ __launch_bounds__(256) void ngp_grid_tmpmax_kernel(const _Float16* __restrict__ net_out, const int* __restrict__ cells, int n,
+                                                              float min_step, float* __restrict__ tmp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float dens = __expf((float)net_out[4 * (long)i + 3]) * min_step;
+  if (dens == dens) atomicMax(reinterpret_cast<int*>(tmp) + cells[i], __float_as_int(fmaxf(dens, 0.0f)));
+}
+__global__ __launch_bounds__(256) void ngp_grid_apply_kernel(const int* __restrict__ cells, int n, float decay, float* __restrict__ tmp,
+                                                             float* __restrict__ grid) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = cells[i];
+  const int v = atomicExch(reinterpret_cast<int*>(tmp) + c, (int)0x80000000);   // -0.0f: taken
+  if (v >= 0) grid[c] = fmaxf(grid[c] * decay, __int_as_float(v));
+}
+__global__ __launch_bounds__(256) void ngp_grid_tmpclear_kernel(const int* __restrict__ cells, int n, float* __restrict__ tmp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) tmp[cells[i]] = 0.0f;
+}
+
 #define NS_GRID_PARTS 256
 __global__ __launch_bounds__(256) void ngp_grid_sum_kernel(const float* __restrict__ grid, long n, double* __restrict__ partial) {
   __shared__ double red[256];
@@ -2708,6 +2735,29 @@ extern "C" int ns_ngp_grid_cells(int grid_size, int n_cascades, unsigned seed, i
   hipLaunchKernelGGL(ngp_grid_cells_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, grid_size, n_cascades,
                      (uint32_t)seed, n, box_lo, 1.0f / (box_hi - box_lo), cells, pos_unit);
   NS_CHECK_LAUNCH("ngp_grid_cells_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_ngp_grid_update_sampled(const void* net_out, const int* cells, int n, float min_step, float decay,
+                                          float max_threshold, float* density_grid, float* tmp_grid, long n_cells_total,
+                                          double* partial_ws, unsigned char* bits, void* stream) {
+  NS_REQUIRE(net_out && cells && density_grid && tmp_grid && partial_ws && bits, "ns_ngp_grid_update_sampled: null pointer");
+  NS_REQUIRE(n >= 0 && n_cells_total > 0 && n_cells_total % 8 == 0, "ns_ngp_grid_update_sampled: the grid must hold a multiple of 8 cells");
+  hipStream_t st = (hipStream_t)stream;
+  if (n > 0) {
+    hipLaunchKernelGGL(ngp_grid_tmpmax_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, st, (const _Float16*)net_out, cells, n, min_step,
+                       tmp_grid);
+    NS_CHECK_LAUNCH("ngp_grid_tmpmax_kernel");
+    hipLaunchKernelGGL(ngp_grid_apply_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, st, cells, n, decay, tmp_grid, density_grid);
+    NS_CHECK_LAUNCH("ngp_grid_apply_kernel");
+    hipLaunchKernelGGL(ngp_grid_tmpclear_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, st, cells, n, tmp_grid);
+    NS_CHECK_LAUNCH("ngp_grid_tmpclear_kernel");
+  }
+  hipLaunchKernelGGL(ngp_grid_sum_kernel, dim3(NS_GRID_PARTS), dim3(256), 0, st, density_grid, n_cells_total, partial_ws);
+  NS_CHECK_LAUNCH("ngp_grid_sum_kernel");
+  hipLaunchKernelGGL(ngp_grid_bits_kernel, dim3(ns_cdiv(n_cells_total / 8, 256)), dim3(256), 0, st, density_grid, n_cells_total,
+                     partial_ws, max_threshold, bits);
+  NS_CHECK_LAUNCH("ngp_grid_bits_kernel");
   return NS_OK;
 }
 

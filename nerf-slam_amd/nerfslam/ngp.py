@@ -49,6 +49,7 @@ class NgpConfig:
     grid_update_every: int = 16
     grid_rule: str = "subset"            # occupancy refresh: "subset" (2^18 uniform cells per update) | "ngp" (instant-ngp's rule)
     grid_decay: float = 0.95
+    grid_decay_all: bool = False         # subset rule: decay every cell on every update (round 2) instead of the drawn ones only
     min_optical_thickness: float = 0.01
     near: float = 0.05
     wgrad_ksplit: int = 256
@@ -632,9 +633,17 @@ class NgpNerf:
                   "ngp_encode_forward")
             check(L.ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(feat), ptr(dirs), ptr(out), nul, nul, nul, nul, C.c_long(n), st),
                   "ngp_mlp_forward")
-            check(L.ns_ngp_grid_update(ptr(out), ptr(cells), n, C.c_float(c.min_step), C.c_float(c.grid_decay),
-                                       C.c_float(c.min_optical_thickness), ptr(self.density_grid), C.c_long(total), ptr(part),
-                                       ptr(self.bits), st), "ngp_grid_update")
+            if os.environ.get("NS_NGP_GRID_DECAY_ALL", "1" if c.grid_decay_all else ""):
+                check(L.ns_ngp_grid_update(ptr(out), ptr(cells), n, C.c_float(c.min_step), C.c_float(c.grid_decay),
+                                           C.c_float(c.min_optical_thickness), ptr(self.density_grid), C.c_long(total), ptr(part),
+                                           ptr(self.bits), st), "ngp_grid_update")
+            else:
+                # decay only what was re-evaluated: a draw of 4 % of the grid per update must not fade the other 96 %
+                if getattr(self, "_grid_tmp", None) is None:
+                    self._grid_tmp = torch.zeros(total, dtype=torch.float32, device=dev)
+                check(L.ns_ngp_grid_update_sampled(ptr(out), ptr(cells), n, C.c_float(c.min_step), C.c_float(c.grid_decay),
+                                                   C.c_float(c.min_optical_thickness), ptr(self.density_grid), ptr(self._grid_tmp),
+                                                   C.c_long(total), ptr(part), ptr(self.bits), st), "ngp_grid_update_sampled")
             return
         if n_cells is not None:
             cells = torch.randint(0, total, (min(int(n_cells), total),), device=dev, generator=self.gen)
