@@ -4,10 +4,10 @@
 committed and are what tests/test_oracle_pins.py checks the CPU oracle against on any machine.
 
 What can be imported from the reference without its un-vendored dependencies:
-  networks/geom/projective_ops.py   (needs `lietorch.SE3`: provided here by a ~40-line stand-in on top
-                                     of nerfslam.se3 -- group algebra only, cross-checked in the pin
-                                     tests against the reference's own CUDA formulas restated in the
-                                     oracle, src/droid_kernels.cu:66-120)
+  networks/geom/projective_ops.py   (needs `lietorch.SE3`: provided here by a stand-in that is INDEPENDENT of the
+                                     repository's algebra -- 4x4 / 6x6 matrices in float64 + scipy Rotation --
+                                     group algebra only, cross-checked in the pin tests against the reference's
+                                     own CUDA formulas restated in the oracle, src/droid_kernels.cu:66-120)
   networks/geom/chol.py             (pure torch)
   networks/modules/corr.py          (needs a `droid_backends` module object at import time only)
 Nothing from the reference is copied into the repository.
@@ -25,14 +25,19 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "nerf-slam_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from nerfslam import se3  # noqa: E402  (plain torch SE3 algebra; no HIP involved)
+from scipy.spatial.transform import Rotation  # noqa: E402
 
 
 # ---------------------------------------------------------------------------------------------
 # stand-ins for the reference's missing third-party modules (import-time needs only)
 # ---------------------------------------------------------------------------------------------
 class SE3:
-    """Minimal lietorch.SE3 look-alike: data [...,7] = [t, q(xyzw)]."""
+    """Minimal lietorch.SE3 look-alike: data [...,7] = [t, q(xyzw)].
+
+    INDEPENDENT of the repository's own algebra (round 3; the round-1/2 stand-in delegated to nerfslam.se3, so the golden
+    Jacobians were not independent of the code they pin): every operation goes through 4x4 homogeneous matrices and the
+    6x6 adjoint in float64, with scipy's Rotation for quaternion <-> matrix.  Tangent order [translation, rotation], as
+    lietorch's SE3 and src/droid_kernels.cu:88-105."""
 
     manifold_dim = 6
 
@@ -47,22 +52,48 @@ class SE3:
     def shape(self):
         return self.data.shape[:-1]
 
+    # -- matrix forms ------------------------------------------------------------------------------
+    def _Rt(self):
+        d = self.data.detach().cpu().numpy().astype(np.float64)
+        R = Rotation.from_quat(d[..., 3:].reshape(-1, 4)).as_matrix().reshape(d.shape[:-1] + (3, 3))
+        return R, d[..., :3]
+
+    def _mat(self):
+        R, t = self._Rt()
+        M = np.zeros(R.shape[:-2] + (4, 4))
+        M[..., :3, :3], M[..., :3, 3], M[..., 3, 3] = R, t, 1.0
+        return M
+
+    @staticmethod
+    def _from_mat(M, like):
+        q = Rotation.from_matrix(M[..., :3, :3].reshape(-1, 3, 3)).as_quat().reshape(M.shape[:-2] + (4,))
+        return SE3(torch.from_numpy(np.concatenate([M[..., :3, 3], q], -1)).to(like.dtype))
+
     def __mul__(self, other):
         if isinstance(other, SE3):
-            return SE3(se3.mul(self.data, other.data))
-        return se3.act(self.data, other)  # action on homogeneous points [...,4]
+            return SE3._from_mat(self._mat() @ other._mat(), self.data)
+        X = other.detach().cpu().numpy().astype(np.float64)              # homogeneous points [...,4]
+        return torch.from_numpy(np.einsum("...ij,...j->...i", self._mat(), X)).to(other.dtype)
 
     def inv(self):
-        return SE3(se3.inv(self.data))
+        return SE3._from_mat(np.linalg.inv(self._mat()), self.data)
 
     def adjT(self, J):
-        return se3.adjT(self.data, J)
+        """Adj(T)^T J with Adj(T) = [[R, [t]x R], [0, R]]"""
+        R, t = self._Rt()
+        tx = np.zeros(R.shape)
+        tx[..., 0, 1], tx[..., 0, 2], tx[..., 1, 0] = -t[..., 2], t[..., 1], t[..., 2]
+        tx[..., 1, 2], tx[..., 2, 0], tx[..., 2, 1] = -t[..., 0], -t[..., 1], t[..., 0]
+        A = np.zeros(R.shape[:-2] + (6, 6))
+        A[..., :3, :3], A[..., :3, 3:], A[..., 3:, 3:] = R, tx @ R, R
+        Jn = J.detach().cpu().numpy().astype(np.float64)
+        return torch.from_numpy(np.einsum("...ji,...j->...i", A, Jn)).to(J.dtype)
 
     def __getitem__(self, idx):
         return SE3(self.data[idx])
 
     def matrix(self):
-        return se3.matrix(self.data)
+        return torch.from_numpy(self._mat()).to(self.data.dtype)
 
     def vec(self):
         return self.data
