@@ -557,6 +557,14 @@ int ns_ngp_mlp_forward_m_n(const void* weights, const void* featT, const float* 
                            void* h4T, void* relu_masks, long N, const int* n_dev, void* stream);
 int ns_ngp_mlp_dgrad_m_n(const void* weights, const void* dLdout, const void* relu_masks, void* dLdfeatT, void* d5T, void* d4T,
                          void* d3T, void* ddT, void* d1T, long N, const int* n_dev, void* stream);
+/* Fused backward pass of the two MLPs (round 3): the forward chain is recomputed from the features, the activation gradients
+ * follow in registers, and every layer's weight gradient is contracted on chip (LDS transposes + MFMA) -- nothing but
+ * dLdfeatT [32,N] f16 and the weight gradients leaves the kernel: 148 B of HBM traffic per sample instead of ~1.95 KB for
+ * ns_ngp_mlp_forward_n (with activation buffers) + ns_ngp_mlp_dgrad_n + ns_ngp_mlp_wgrad_n.  Same dLdfeatT bit for bit; the
+ * weight gradients differ by summation order.  grad_weights is ADDED to; partial_ws: wgs * 10240 floats; wgs workgroups
+ * (512 fill the chip twice over).                                                                                      */
+int ns_ngp_mlp_backward_fused_n(const void* weights, const void* featT, const float* dirs, const void* dLdout, void* dLdfeatT,
+                                float* partial_ws, int wgs, float* grad_weights, long N, const int* n_dev, void* stream);
 /* the two halves of ns_ngp_mlp_backward_n: activation gradients (writes dLdfeatT and the d*T buffers), then the weight
  * gradients (reads them).  Separate entries so that the caller can put the second half on another stream, next to the
  * hash-grid backward that consumes dLdfeatT (nerfslam/ngp.py).                                                       */

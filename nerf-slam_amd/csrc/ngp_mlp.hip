@@ -538,6 +538,235 @@ __global__ __launch_bounds__(256) void ngp_mlp_wgrad_reduce_kernel(const float* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// FUSED backward pass (round 3): forward recompute + activation gradients + weight gradients in ONE kernel.
+//
+// Round 2's sequence moved ~1.95 KB per sample through HBM for the two MLPs: the forward pass wrote the four saved activations
+// (448 B), the activation-gradient kernel wrote five gradient tensors (448 B) and dL/dfeature, and the weight-gradient kernel read
+// all nine of them back (960 B) -- for 48 MFMAs per 32 samples.  Here a workgroup keeps all of it on chip:
+//   * the forward chain is RECOMPUTED from the 64-byte feature vector (24 MFMAs per 32 samples, the same instruction sequence
+//     as ngp_mlp_fwd_kernel, hence the same bits: the ReLU derivative is the sign of the recomputed activation);
+//   * the backward chain follows in the same registers;
+//   * dW = dY X^T contracts over SAMPLES, i.e. needs both operands with the sample index along k, while the chains hold them
+//     with the sample index across lanes: each layer's (dY, X) pair of the workgroup's 128 samples is transposed through one
+//     34-KB LDS tile [unit][sample] and read back as MFMA operands (16-byte reads); the 12 output tiles of the five weight
+//     matrices are spread over the 4 waves (3 accumulator tiles = 48 VGPRs each) and stay in registers for the whole launch.
+// HBM traffic per sample: 64 B features + 12 B direction + 8 B loss gradient read, 64 B dL/dfeature written: 148 B.
+// Per workgroup one 40-KB slab of partial weight gradients at the end (summed by ngp_mlp_wgrad_reduce_kernel in slab order:
+// deterministic).  The forward kernel proper only writes the network output then (no activation buffers).
+// ---------------------------------------------------------------------------------------------
+#define FU_SP 136   // halfs per stage row: 128 samples + 8 pad (272 B: 16-byte aligned rows)
+// stage rows: the X operands of the five weight gradients stay resident for the whole block, the dY operand is rewritten per layer
+#define FU_XF 0      // features   (32 rows)
+#define FU_XH1 32    // h1         (64)
+#define FU_XC 96     // cin        (32)
+#define FU_XH3 128   // h3         (64)
+#define FU_XH4 192   // h4         (64)
+#define FU_DY 256    // dY         (64)
+#define FU_ROWS 320
+
+struct MlpFusedArgs {
+  const _Float16* W;
+  const _Float16* featT;   // [32,N] unit-major
+  const float* dirs;       // [N,3]
+  const _Float16* dLdout;  // [N,4]
+  _Float16* dLdfeatT;      // [32,N] unit-major
+  float* partial;          // [gridDim.x][W_TOTAL]
+  long N;
+  const int* n_dev;
+};
+
+// one B-layout chunk (element q of lane half h = unit frag_k(cc, h, q)) into the stage tile, column `col`
+__device__ __forceinline__ void stage_chunk(_Float16* stage, int row0, const f16x8& v, int cc, int h, int col) {
+#pragma unroll
+  for (int q = 0; q < 8; q++) stage[(row0 + frag_k(cc, h, q)) * FU_SP + col] = v[q];
+}
+
+// one 32 x 32 tile of dW over the 128 staged samples: rows (to) of dY (nout valid rows), rows (ti) of X at xrow0 (nin valid rows)
+__device__ __forceinline__ void wgrad_tile(const _Float16* stage, int xrow0, int to, int ti, int nout, int nin, int lane,
+                                           f32x16& acc) {
+  const int col = lane & 31, half = lane >> 5;
+  const int ro = to * 32 + col, ri = ti * 32 + col;
+  const bool oko = ro < nout, oki = ri < nin;
+  const _Float16* pa = stage + (FU_DY + (oko ? ro : 0)) * FU_SP + 8 * half;
+  const _Float16* pb = stage + (xrow0 + (oki ? ri : 0)) * FU_SP + 8 * half;
+#pragma unroll
+  for (int ks = 0; ks < 8; ks++) {   // 8 x 16 samples
+    f16x8 av = *reinterpret_cast<const f16x8*>(pa + 16 * ks);
+    f16x8 bv = *reinterpret_cast<const f16x8*>(pb + 16 * ks);
+    if (!oko) av = (f16x8)(_Float16)0;
+    if (!oki) bv = (f16x8)(_Float16)0;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void wgrad_store(float* P, int woff, int to, int ti, int nout, int nin, int lane, const f32x16& acc) {
+  const int col = lane & 31, half = lane >> 5;
+  const int j = ti * 32 + col;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int i = to * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (i < nout && j < nin) P[woff + i * nin + j] = acc[r];
+  }
+}
+
+// relu + f16 of one accumulator tile -> two B chunks, staged, sign bits into bits 16 it .. 16 it + 15 of `mask`
+__device__ __forceinline__ void relu_stage(const f32x16& acc, int it, _Float16* stage, int row0, int h, int col, f16x8* out,
+                                           uint32_t& mask) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const _Float16 v = (_Float16)fmaxf(acc[r], 0.0f);
+    out[2 * it + (r >> 3)][r & 7] = v;
+    mask |= ((float)v > 0.0f ? 1u : 0u) << (16 * it + r);
+  }
+  stage_chunk(stage, row0, out[2 * it], 2 * it, h, col);
+  stage_chunk(stage, row0, out[2 * it + 1], 2 * it + 1, h, col);
+}
+
+// f16(acc) gated by the mask bits -> two B chunks of the gradient, staged as the dY operand
+__device__ __forceinline__ void gate_stage(const f32x16& acc, int it, uint32_t mask, _Float16* stage, int h, int col, f16x8* out) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) out[2 * it + (r >> 3)][r & 7] = (mask >> (16 * it + r)) & 1u ? (_Float16)acc[r] : (_Float16)0;
+  stage_chunk(stage, FU_DY, out[2 * it], 2 * it, h, col);
+  stage_chunk(stage, FU_DY, out[2 * it + 1], 2 * it + 1, h, col);
+}
+
+__global__ __launch_bounds__(256, 1) void ngp_mlp_bwd_fused_kernel(MlpFusedArgs a) {
+  __shared__ f16x8 Wff[FW_NFRAG * 64];   // forward fragments (24 KB)
+  __shared__ f16x8 Wfb[BW_NFRAG * 64];   // transposed fragments (20 KB)
+  __shared__ __attribute__((aligned(16))) _Float16 stage[FU_ROWS * FU_SP];   // 85 KB: [unit rows][128 samples]
+  fill_frags<false>(Wff, a.W, W1_OFF, 64, 32, FW_L1);
+  fill_frags<false>(Wff, a.W, W2_OFF, 16, 64, FW_L2);
+  fill_frags<false>(Wff, a.W, W3_OFF, 64, 32, FW_L3);
+  fill_frags<false>(Wff, a.W, W4_OFF, 64, 64, FW_L4);
+  fill_frags<true>(Wfb, a.W, W5_OFF, 16, 64, BW_L5);
+  fill_frags<true>(Wfb, a.W, W4_OFF, 64, 64, BW_L4);
+  fill_frags<true>(Wfb, a.W, W3_OFF, 64, 32, BW_L3);
+  fill_frags<true>(Wfb, a.W, W2_OFF, 16, 64, BW_L2);
+  fill_frags<true>(Wfb, a.W, W1_OFF, 64, 32, BW_L1);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  const long N = a.N, cnt = ngp_count(a.N, a.n_dev);
+  const long nblk = (cnt + 127) / 128;
+  const int col = wave * 32 + j;
+  // weight-gradient tiles of this wave: waves 0,1: W4 (wave>>1, wave&1), W2 (0, wave), W1 (wave, 0);
+  //                                     waves 2,3: W4 (wave>>1, wave&1), W5 (0, wave-2), W3 (wave-2, 0)
+  f32x16 acc4 = (f32x16)0.0f, accA = (f32x16)0.0f, accB = (f32x16)0.0f;
+  // inputs of a block (features, direction, loss gradient: 84 B per sample) are loaded ONE BLOCK AHEAD: with one workgroup per
+  // CU nothing else hides their latency (two dependent HBM round trips per block were a third of the kernel's time)
+  typedef _Float16 f16x4l __attribute__((ext_vector_type(4)));
+  f16x8 xn[2];
+  f16x4l gon;
+  float dn[3];
+  auto fetch = [&](long blk) {
+    const long np = blk * 128 + col;
+    const bool ok = blk < nblk && np < cnt;
+    const long ns = ok ? np : 0;
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+      for (int q = 0; q < 8; q++) xn[cc][q] = ok ? a.featT[(long)frag_k(cc, h, q) * N + ns] : (_Float16)0;
+    gon = ok ? *reinterpret_cast<const f16x4l*>(a.dLdout + ns * 4) : (f16x4l)(_Float16)0;   // (r, g, b, d)
+    dn[0] = a.dirs[ns * 3];
+    dn[1] = a.dirs[ns * 3 + 1];
+    dn[2] = a.dirs[ns * 3 + 2];
+  };
+  fetch(blockIdx.x);
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long np = blk * 128 + col;
+    const bool ok = np < cnt;
+    uint32_t m1 = 0, m3 = 0, m4 = 0;
+    f16x8 x[2] = {xn[0], xn[1]};
+    const f16x4l go = gon;
+    const float dir[3] = {dn[0], dn[1], dn[2]};
+    fetch(blk + gridDim.x);
+    // ---- forward recompute (one 32-sample tile; same MFMA sequence as ngp_mlp_fwd_kernel); every activation is staged as the
+    //      X operand of its layer's weight gradient as soon as it exists, only its sign bits stay in registers ----
+    __syncthreads();   // the previous block's last weight-gradient tile has been read
+    {
+      f16x8 h1[4], cin[2], h3[4], h4[4];
+      stage_chunk(stage, FU_XF, x[0], 0, h, col);
+      stage_chunk(stage, FU_XF, x[1], 1, h, col);
+#pragma unroll
+      for (int it = 0; it < 2; it++) relu_stage(layer_tile<2>(Wff, FW_L1, it, lane, x), it, stage, FU_XH1, h, col, h1, m1);
+      {
+        const f32x16 acc = layer_tile<4>(Wff, FW_L2, 0, lane, h1);
+#pragma unroll
+        for (int r = 0; r < 8; r++) cin[0][r] = (_Float16)acc[r];
+        float sh[16];
+        sh16(dir[0], dir[1], dir[2], sh);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int lo = (q & 3) + 8 * (q >> 2);
+          cin[1][q] = (_Float16)(h ? sh[lo + 4] : sh[lo]);
+        }
+        stage_chunk(stage, FU_XC, cin[0], 0, h, col);
+        stage_chunk(stage, FU_XC, cin[1], 1, h, col);
+      }
+#pragma unroll
+      for (int it = 0; it < 2; it++) relu_stage(layer_tile<2>(Wff, FW_L3, it, lane, cin), it, stage, FU_XH3, h, col, h3, m3);
+#pragma unroll
+      for (int it = 0; it < 2; it++) relu_stage(layer_tile<4>(Wff, FW_L4, it, lane, h3), it, stage, FU_XH4, h, col, h4, m4);
+    }
+    // ---- backward chain; each layer's dY through the stage tile, its weight gradient contracted over the 128 samples ----
+    f16x8 d5 = (f16x8)(_Float16)0;
+    if (h == 0) {
+      d5[0] = go[0];
+      d5[1] = go[1];
+      d5[2] = go[2];
+    }
+    stage_chunk(stage, FU_DY, d5, 0, h, col);                        // W5: dY = d5 (16 rows), X = h4
+    __syncthreads();
+    if (wave >= 2) wgrad_tile(stage, FU_XH4, 0, wave - 2, 16, 64, lane, accA);
+    __syncthreads();
+    f16x8 d4[4];
+#pragma unroll
+    for (int it = 0; it < 2; it++) gate_stage(layer_tile<1>(Wfb, BW_L5, it, lane, &d5), it, m4, stage, h, col, d4);
+    __syncthreads();                                                 // W4: dY = d4, X = h3
+    wgrad_tile(stage, FU_XH3, wave >> 1, wave & 1, 64, 64, lane, acc4);
+    __syncthreads();
+    f16x8 d3[4];
+#pragma unroll
+    for (int it = 0; it < 2; it++) gate_stage(layer_tile<4>(Wfb, BW_L4, it, lane, d4), it, m3, stage, h, col, d3);
+    __syncthreads();                                                 // W3: dY = d3, X = cin (32 rows)
+    if (wave >= 2) wgrad_tile(stage, FU_XC, wave - 2, 0, 64, 32, lane, accB);
+    __syncthreads();
+    // layer 3^T -> d(cin): only the density half (units 0..15 = registers 0..7) flows on; the density gradient joins unit 0
+    f16x8 dd;
+    {
+      const f32x16 acc = layer_tile<4>(Wfb, BW_L3, 0, lane, d3);
+#pragma unroll
+      for (int r = 0; r < 8; r++) dd[r] = (_Float16)acc[r];
+      if (h == 0) dd[0] = (_Float16)((float)dd[0] + (float)go[3]);
+    }
+    stage_chunk(stage, FU_DY, dd, 0, h, col);                        // W2: dY = dd (16 rows), X = h1
+    __syncthreads();
+    if (wave < 2) wgrad_tile(stage, FU_XH1, 0, wave, 16, 64, lane, accA);
+    __syncthreads();
+    f16x8 d1[4];
+#pragma unroll
+    for (int it = 0; it < 2; it++) gate_stage(layer_tile<1>(Wfb, BW_L2, it, lane, &dd), it, m1, stage, h, col, d1);
+    __syncthreads();                                                 // W1: dY = d1, X = the features
+    if (wave < 2) wgrad_tile(stage, FU_XF, wave, 0, 64, 32, lane, accB);
+    {
+      const f32x16 acc = layer_tile<4>(Wfb, BW_L1, 0, lane, d1);
+      if (ok) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) a.dLdfeatT[(long)acc_unit(0, h, r) * N + np] = (_Float16)acc[r];
+      }
+    }
+  }
+  float* P = a.partial + (long)blockIdx.x * W_TOTAL;
+  wgrad_store(P, W4_OFF, wave >> 1, wave & 1, 64, 64, lane, acc4);
+  if (wave < 2) {
+    wgrad_store(P, W2_OFF, 0, wave, 16, 64, lane, accA);
+    wgrad_store(P, W1_OFF, wave, 0, 64, 32, lane, accB);
+  } else {
+    wgrad_store(P, W5_OFF, 0, wave - 2, 16, 64, lane, accA);
+    wgrad_store(P, W3_OFF, wave - 2, 0, 64, 32, lane, accB);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
 extern "C" int ns_ngp_mlp_forward(const void* weights, const void* featT, const float* dirs, void* out, void* h1T,
@@ -646,6 +875,22 @@ extern "C" int ns_ngp_mlp_dgrad_m_n(const void* weights, const void* dLdout, con
   if (N <= 0) return NS_OK;
   return mlp_dgrad_launch(weights, dLdout, nullptr, nullptr, nullptr, dLdfeatT, d5T, d4T, d3T, ddT, d1T, N, n_dev, (hipStream_t)stream,
                           relu_masks);
+}
+
+// activation gradients AND weight gradients from the features alone (forward recomputed on chip): writes dLdfeatT [32,N]
+// and ADDS the weight gradients to grad_weights; partial_ws holds `wgs` slabs of W_TOTAL floats (wgs = launched workgroups)
+extern "C" int ns_ngp_mlp_backward_fused_n(const void* weights, const void* featT, const float* dirs, const void* dLdout,
+                                           void* dLdfeatT, float* partial_ws, int wgs, float* grad_weights, long N,
+                                           const int* n_dev, void* stream) {
+  NS_REQUIRE(weights && featT && dirs && dLdout && dLdfeatT && partial_ws && grad_weights, "ns_ngp_mlp_backward_fused: null pointer");
+  NS_REQUIRE(wgs >= 1 && wgs <= 65535 && N % 8 == 0, "ns_ngp_mlp_backward_fused: 1 <= wgs <= 65535 and N a multiple of 8 are required");
+  if (N <= 0) return NS_OK;
+  MlpFusedArgs a{(const _Float16*)weights, (const _Float16*)featT, dirs, (const _Float16*)dLdout, (_Float16*)dLdfeatT, partial_ws, N, n_dev};
+  hipLaunchKernelGGL(ngp_mlp_bwd_fused_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, a);
+  NS_CHECK_LAUNCH("ngp_mlp_bwd_fused_kernel");
+  hipLaunchKernelGGL(ngp_mlp_wgrad_reduce_kernel, dim3(W_TOTAL / 16), dim3(256), 0, (hipStream_t)stream, partial_ws, wgs, grad_weights);
+  NS_CHECK_LAUNCH("ngp_mlp_wgrad_reduce_kernel");
+  return NS_OK;
 }
 
 extern "C" int ns_ngp_mlp_wgrad_n(const void* featT, const void* h1T, const void* cinT, const void* h3T, const void* h4T,

@@ -166,6 +166,7 @@ class NgpNerf:
         self.act = [torch.zeros((u, S), **h) for u in (64, 32, 64, 64)]         # h1T cinT h3T h4T
         self.dact = [torch.zeros((u, S), **h) for u in (16, 64, 64, 16, 64)]    # d5T d4T d3T ddT d1T
         self.partial = torch.zeros((c.wgrad_ksplit, MLP_TOTAL), **f)
+        self.mlp_wgs = 512     # workgroups (= partial weight-gradient slabs) of the fused MLP backward pass: 2 per CU
         self.relu_masks = torch.zeros(6 * S, dtype=torch.int32, device=dev)     # one bit per hidden unit and sample (csrc/ngp_mlp.hip)
         # Table gradient.  One trainer: the round-3 path (csrc/ngp.hip: no count pass, Adam applied to the touched entries in
         # the flush of the accumulation; the gradient buffer is not used).  Replicated trainers: gradient buffer + all-reduce
@@ -366,16 +367,33 @@ class NgpNerf:
         check(L.ns_ngp_encode_forward_j_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.grid_half), ptr(featT), 1, ptr(jac),
                                           C.c_long(S), n_dev, st), "ngp_encode_forward")
         acts, dacts = self.act, self.dact
-        check(L.ns_ngp_mlp_forward_m_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out),
-                                       *[ptr(a) for a in acts], ptr(self.relu_masks), C.c_long(S), n_dev, st), "ngp_mlp_forward")
+        h1T, cinT, h3T, h4T = acts
+        d5T, d4T, d3T, ddT, d1T = dacts
+        fused_mlp = not os.environ.get("NS_NGP_MLP_UNFUSED")
+        if fused_mlp:
+            # round 3: the forward pass writes only the network output; the backward pass recomputes the activations on chip
+            # and contracts the weight gradients there too (csrc/ngp_mlp.hip: ngp_mlp_bwd_fused_kernel)
+            check(L.ns_ngp_mlp_forward_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), None, None, None, None,
+                                         C.c_long(S), n_dev, st), "ngp_mlp_forward")
+        else:
+            check(L.ns_ngp_mlp_forward_m_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out),
+                                           *[ptr(a) for a in acts], ptr(self.relu_masks), C.c_long(S), n_dev, st), "ngp_mlp_forward")
         check(L.ns_ngp_composite_ctl(ptr(self.s_out), ptr(X["s_dt"]), ptr(X["s_t"]), ptr(X["ray_start"]), ptr(X["ray_n"]), Rc,
                                      ptr(X["r_rgb"]), ptr(X["r_depth"]), ptr(X["r_cov"]), C.c_float(c.depth_lambda),
                                      C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), ptr(X["loss"]),
                                      ptr(X["s_dout"]), ctl, st), "ngp_composite")
-        h1T, cinT, h3T, h4T = acts
-        d5T, d4T, d3T, ddT, d1T = dacts
-        check(L.ns_ngp_mlp_dgrad_m_n(ptr(self.mlp_half), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
-                                     ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT), ptr(d1T), C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
+        if fused_mlp:
+            # (tried: the fused kernel with the weight gradients on a stream of its own, next to the table gradient, and a store-free
+            # activation-gradient kernel on the main stream -- 0.466 -> 0.54-0.57 ms per step: one of its workgroups takes 145 KB of
+            # a CU's LDS, so the scatter / accumulate workgroups of the table gradient cannot start next to it)
+            if getattr(self, "partial_fused", None) is None:
+                self.partial_fused = torch.zeros((self.mlp_wgs, MLP_TOTAL), dtype=torch.float32, device=dev)
+            check(L.ns_ngp_mlp_backward_fused_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]), ptr(self.s_dfeat),
+                                                ptr(self.partial_fused), self.mlp_wgs, ptr(self.mlp_grad), C.c_long(S), n_dev, st),
+                  "ngp_mlp_backward_fused")
+        else:
+            check(L.ns_ngp_mlp_dgrad_m_n(ptr(self.mlp_half), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
+                                         ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT), ptr(d1T), C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
         # everything below only READS what the activation backward wrote: three branches
         self._side.wait_stream(main)
         table_read = None
@@ -399,9 +417,10 @@ class NgpNerf:
                                                       ptr(X["ray_n"]), ptr(X["r_img"]), C.c_float(1.0 / s), ptr(self.cam_grad), Rc,
                                                       ctl, ptr(self.ray_g) if n_cam <= 4096 else None, n_cam, st2),
                       "ngp_camera_gradient")
-            check(L.ns_ngp_mlp_wgrad_n(ptr(featT), ptr(h1T), ptr(cinT), ptr(h3T), ptr(h4T), ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT),
-                                       ptr(d1T), ptr(self.partial), c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(S), n_dev, st2),
-                  "ngp_mlp_wgrad")
+            if not fused_mlp:
+                check(L.ns_ngp_mlp_wgrad_n(ptr(featT), ptr(h1T), ptr(cinT), ptr(h3T), ptr(h4T), ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT),
+                                           ptr(d1T), ptr(self.partial), c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(S), n_dev, st2),
+                      "ngp_mlp_wgrad")
 
         def table_gradient(parts, stream):
             # one trainer: Adam in the flushes (no gradient buffer); replicated trainers: the packed sums into the gradient buffer

@@ -160,6 +160,26 @@ def test_mlp_forward_backward(oracle_mod, dev):
         for a, b in zip(ref_d, got_d):
             assert torch.equal(a, b)
         assert n_dev is not None or torch.equal(ref_d[0], dfeat)
+    # fused backward pass (round 3): forward recomputed on chip, weight gradients contracted on chip -- dL/dfeature bit for bit
+    # (same MFMA sequence), weight gradients equal up to summation order; also with a device sample count and several workgroup
+    # counts (the partial slabs are summed in slab order)
+    for n_dev, n_valid in ((None, N), (torch.tensor([500], dtype=torch.int32, device=dev), 504)):
+        ref_feat = torch.zeros_like(dfeat)
+        ref_db = [torch.zeros_like(b) for b in dbufs]
+        gw_ref = torch.zeros(10240, dtype=torch.float32, device=dev)
+        part = torch.empty((7, 10240), dtype=torch.float32, device=dev)
+        check(lib().ns_ngp_mlp_backward_n(ptr(Wd), ptr(d_dout), *[ptr(b) for b in bufs], ptr(ref_feat), *[ptr(b) for b in ref_db],
+                                          ptr(part), 7, ptr(gw_ref), C.c_long(N), ptr(n_dev), stream_ptr()), "mlp bwd")
+        for wgs in (1, 3, 64):
+            got_feat = torch.zeros_like(dfeat)
+            gw_got = torch.zeros(10240, dtype=torch.float32, device=dev)
+            part_f = torch.full((wgs, 10240), float("nan"), dtype=torch.float32, device=dev)
+            check(lib().ns_ngp_mlp_backward_fused_n(ptr(Wd), ptr(d_featT), ptr(d_dirs), ptr(d_dout), ptr(got_feat), ptr(part_f), wgs,
+                                                    ptr(gw_got), C.c_long(N), ptr(n_dev), stream_ptr()), "mlp bwd fused")
+            assert torch.equal(got_feat[:, :n_valid], ref_feat[:, :n_valid]), wgs
+            assert torch.isfinite(gw_got).all()
+            err = (gw_got - gw_ref).abs().max().item()
+            assert err <= 2e-3 * gw_ref.abs().max().item(), (wgs, err, gw_ref.abs().max().item())
 
 
 def test_composite_loss_and_adam(oracle_mod, dev):

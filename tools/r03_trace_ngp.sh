@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out/r03_ngp; mkdir -p $o
-NS_NGP_POSE=1 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $o/prof -o ngp -- python tools/ngp_bench.py 100 200 > $o/bench.log 2>&1
+NS_NGP_EXTRINSICS=1 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $o/prof -o ngp -- python tools/ngp_bench.py 100 200 > $o/bench.log 2>&1
 grep "steps/s" $o/bench.log
 python - <<PY
 import csv
