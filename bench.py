@@ -261,13 +261,23 @@ def micro_benches(dev, hp, ngp_net):
     note = ("samples ordered along rays as the marcher emits them (2048 rays x 128 steps); uniform random positions (worst case "
             "for locality) in avg_launch_us_uniform_random_positions")
     out["ngp_encode_fwd_kernel[2^18]"] = dict(fn=lambda: enc_fwd(pos_rays), alt=lambda: enc_fwd(pos_unif), bound="hbm", per_launch=588 * N, note=note)
-    out["ngp_encode_bwd[2^18]"] = dict(fn=lambda: enc_bwd(pos_rays), alt=lambda: enc_bwd(pos_unif), bound="hbm", per_launch=1100 * N,
+    # table entries the call touches (their optimiser step is part of the call): one gradient-only run, non-zero words counted
+    gq = torch.zeros(net.n_grid // 2, dtype=torch.int64, device=dev)
+    check(lib().ns_ngp_encode_backward_fused_n(*net._grid_args(), ptr(pos_rays), ptr(dfeat), ptr(gq), ptr(bws), C.c_size_t(wsb),
+                                               C.c_float(cf.grad_fixed_scale), C.c_long(N), None, None, None, None, None, 7, C.c_float(0),
+                                               C.c_float(0), C.c_float(0), C.c_float(0), C.c_float(1), None, 15, stream_ptr()), "touched")
+    touched = int((gq != 0).sum())
+    del gq
+    out["ngp_encode_bwd[2^18]"] = dict(fn=lambda: enc_bwd(pos_rays), alt=lambda: enc_bwd(pos_unif), bound="hbm",
+                                       per_launch=1100 * N + 52 * touched,
                                        note=note + "; one call = 4 launches: ngp_enc_fscatter, ngp_enc_faccum (hashed levels, Adam in "
-                                       "the flush), ngp_encode_bwd_dense_rl, ngp_enc_dense_reduce (dense levels, Adam in the reduce); the "
-                                       "optimiser step of the touched entries is INSIDE this time (round 2: a separate pass over the "
-                                       "whole table, 93-105 us); the algorithmic bytes are round 2's definition (no optimiser traffic), "
-                                       "so `frac` understates what the call moves",
-                                       keep=(bw, bws))
+                                       "the flush), ngp_encode_bwd_dense_rl, ngp_enc_dense_reduce (dense levels, Adam in the reduce).  "
+                                       "Algorithmic bytes: round 2's 1100 B per sample for the gradient (16 levels x 8 corners x 8-B "
+                                       "packed read-modify-write + 12 B position + 64 B upstream gradient) PLUS the optimiser step of "
+                                       "the %d table entries the call touches, which lives in its flushes (master + two moments read "
+                                       "and written, f16 copy written: 52 B per entry; round 2 ran it as a separate pass over the "
+                                       "whole table, 93-105 us)" % touched,
+                                       keep=(bw, bws), touched_entries=touched)
     # the update operator's gate convolution (the largest MFMA launch of an update)
     from nerfslam.conv import PackedConv, conv_nhwc
     w = (torch.randn((256, 448, 3, 3), device=dev) / 60).half().float()
@@ -295,6 +305,9 @@ def kernel_rooflines(dev, hp, ngp_net):
             out[k]["avg_launch_us_uniform_random_positions"] = _train_us(m["alt"])
         if m.get("note"):
             out[k]["note"] = m["note"]
+        if "touched_entries" in m:
+            out[k]["touched_table_entries"] = m["touched_entries"]
+            out[k]["gradient_only_algorithmic_bytes"] = 1100 * ngp_net.cfg.max_samples
     return out
 
 

@@ -453,19 +453,24 @@ class NgpNerf:
                                     C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps), C.c_float(l2),
                                     C.c_float(c.loss_scale * self.world), C.c_float(fxs), ctl, stream), "ngp_adam")
         mlp = (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0)
+
+        def camera_step(stream):
+            check(L.ns_ngp_camera_step_ctl(ptr(self.c2w), ptr(self.cam_grad), ptr(self.cam_m1), ptr(self.cam_m2),
+                                           self.cam_grad.shape[0], 0, C.c_float(c.extrinsic_lr_pos), C.c_float(c.extrinsic_lr_rot),
+                                           C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
+                                           C.c_float(c.loss_scale * self.world), ctl, stream), "ngp_camera_step")
         if self.world == 1:
-            # the MLP's optimiser step follows its weight gradients on the side stream (nothing on the main stream reads the
-            # weights after the activation gradients): the main stream ends with the accumulate pass
+            # the MLP's optimiser step and the pose update follow their gradients on the side stream (nothing on the main stream
+            # reads the weights or the poses after the activation gradients): the main stream ends with the accumulate pass
             with torch.cuda.stream(self._side):
+                if c.optimize_extrinsics:
+                    camera_step(stream_ptr())
                 adam(*mlp, stream_ptr())
         main.wait_stream(self._side)
         if self.world > 1:
             self._exchange_gradients()
-        if c.optimize_extrinsics:   # after the all-reduce: every replica applies the SAME pose update
-            check(L.ns_ngp_camera_step_ctl(ptr(self.c2w), ptr(self.cam_grad), ptr(self.cam_m1), ptr(self.cam_m2),
-                                           self.cam_grad.shape[0], 0, C.c_float(c.extrinsic_lr_pos), C.c_float(c.extrinsic_lr_rot),
-                                           C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
-                                           C.c_float(c.loss_scale * self.world), ctl, st), "ngp_camera_step")
+            if c.optimize_extrinsics:   # after the all-reduce: every replica applies the SAME pose update
+                camera_step(st)
         if self.world > 1 and c.grad_fixed_scale > 0:
             # Adam on THIS trainer's shard of the table (summed gradient in `_gshard`), then the f16 copies of all shards
             Ns = self.shard_entries
