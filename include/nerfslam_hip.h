@@ -565,6 +565,15 @@ int ns_ngp_mlp_dgrad_m_n(const void* weights, const void* dLdout, const void* re
  * (512 fill the chip twice over).                                                                                      */
 int ns_ngp_mlp_backward_fused_n(const void* weights, const void* featT, const float* dirs, const void* dLdout, void* dLdfeatT,
                                 float* partial_ws, int wgs, float* grad_weights, long N, const int* n_dev, void* stream);
+/* Weight gradients off the critical path (round 3, the trainer's default): ns_ngp_mlp_dgrad_m_n accepts NULL for its five
+ * gradient buffers (it then writes dLdfeatT only: 96 B of traffic per sample) and ns_ngp_mlp_wgrad_recompute_n recomputes both
+ * chains on chip from the features and the loss gradient and contracts the five weight gradients there -- a 46-KB-LDS kernel
+ * that runs on a side stream NEXT TO the table gradient.  frags: ns_ngp_mlp_fragment_table_bytes() bytes, written by
+ * ns_ngp_mlp_pack_fragments from the current f16 weights (once per optimiser step).                                        */
+size_t ns_ngp_mlp_fragment_table_bytes(void);
+int ns_ngp_mlp_pack_fragments(const void* weights, void* frags, void* stream);
+int ns_ngp_mlp_wgrad_recompute_n(const void* frags, const void* featT, const float* dirs, const void* dLdout, float* partial_ws,
+                                 int wgs, float* grad_weights, long N, const int* n_dev, void* stream);
 /* the two halves of ns_ngp_mlp_backward_n: activation gradients (writes dLdfeatT and the d*T buffers), then the weight
  * gradients (reads them).  Separate entries so that the caller can put the second half on another stream, next to the
  * hash-grid backward that consumes dLdfeatT (nerfslam/ngp.py).                                                       */

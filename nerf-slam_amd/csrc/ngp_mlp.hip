@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
       }
       if (st) store_tile(a.h1T, N, boff, it, &h1[0][2 * it], &h1[1][2 * it]);
     }
-    if (st && a.masks)
+    if (ok && a.masks)
       *mask_at(a.masks, 0, h, N, np) = make_uint2(relu_bits(h1[0][0], h1[0][1], 0) | relu_bits(h1[0][2], h1[0][3], 1),
                                                   relu_bits(h1[1][0], h1[1][1], 0) | relu_bits(h1[1][2], h1[1][3], 1));
 #pragma unroll
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
       }
       if (st) store_tile(a.h3T, N, boff, it, &h3[0][2 * it], &h3[1][2 * it]);
     }
-    if (st && a.masks)
+    if (ok && a.masks)
       *mask_at(a.masks, 1, h, N, np) = make_uint2(relu_bits(h3[0][0], h3[0][1], 0) | relu_bits(h3[0][2], h3[0][3], 1),
                                                   relu_bits(h3[1][0], h3[1][1], 0) | relu_bits(h3[1][2], h3[1][3], 1));
     f16x8 h4[2][4];
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
       }
       if (st) store_tile(a.h4T, N, boff, it, &h4[0][2 * it], &h4[1][2 * it]);
     }
-    if (st && a.masks)
+    if (ok && a.masks)
       *mask_at(a.masks, 2, h, N, np) = make_uint2(relu_bits(h4[0][0], h4[0][1], 0) | relu_bits(h4[0][2], h4[0][3], 1),
                                                   relu_bits(h4[1][0], h4[1][1], 0) | relu_bits(h4[1][2], h4[1][3], 1));
 #pragma unroll
@@ -325,7 +325,7 @@ __device__ __forceinline__ void mask_tile_bits(const f32x16& acc0, const f32x16&
     const _Float16 v1 = (m1 >> (16 * it + r)) & 1u ? (_Float16)acc1[r] : (_Float16)0;
     o0[r >> 3][r & 7] = v0;
     o1[r >> 3][r & 7] = v1;
-    if (ok) *um_at(dT + (long)urow(it, r) * N, boff) = pack2(v0, v1);
+    if (ok && dT != nullptr) *um_at(dT + (long)urow(it, r) * N, boff) = pack2(v0, v1);   // (dT: wave-uniform)
   }
 }
 
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < 8; q++)
-      if (ok) *um_at(a.d5T + (long)ufrag(0, q) * N, boff) = pack2(d5[0][q], d5[1][q]);
+      if (ok && a.d5T != nullptr) *um_at(a.d5T + (long)ufrag(0, q) * N, boff) = pack2(d5[0][q], d5[1][q]);
     // layer 5^T (K = 16) -> d(h4), ReLU' of layer 4
     f16x8 d4[2][4], d3[2][4], dd[2], d1[2][4];
 #pragma unroll
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
       }
 #pragma unroll
       for (int q = 0; q < 8; q++)
-        if (ok) *um_at(a.ddT + (long)ufrag(0, q) * N, boff) = pack2(dd[0][q], dd[1][q]);
+        if (ok && a.ddT != nullptr) *um_at(a.ddT + (long)ufrag(0, q) * N, boff) = pack2(dd[0][q], dd[1][q]);
     }
 #pragma unroll
     for (int it = 0; it < 2; it++) {
@@ -783,7 +783,6 @@ extern "C" int ns_ngp_mlp_forward_m_n(const void* weights, const void* featT, co
                                       void* cinT, void* h3T, void* h4T, void* relu_masks, long N, const int* n_dev,
                                       void* stream) {
   NS_REQUIRE(weights && featT && dirs && out, "ns_ngp_mlp_forward: null pointer");
-  NS_REQUIRE(relu_masks == nullptr || h1T != nullptr, "ns_ngp_mlp_forward: ReLU masks are written with the activations (training)");
   NS_REQUIRE((h1T == nullptr) == (cinT == nullptr) && (h1T == nullptr) == (h3T == nullptr) &&
                  (h1T == nullptr) == (h4T == nullptr),
              "ns_ngp_mlp_forward: pass all activation buffers (training) or none (inference)");
@@ -870,11 +869,267 @@ extern "C" int ns_ngp_mlp_dgrad_n(const void* weights, const void* dLdout, const
 // activations are not read here at all (the weight gradients still read them)
 extern "C" int ns_ngp_mlp_dgrad_m_n(const void* weights, const void* dLdout, const void* relu_masks, void* dLdfeatT, void* d5T,
                                     void* d4T, void* d3T, void* ddT, void* d1T, long N, const int* n_dev, void* stream) {
-  NS_REQUIRE(weights && dLdout && relu_masks && dLdfeatT && d5T && d4T && d3T && ddT && d1T, "ns_ngp_mlp_dgrad_m: null pointer");
+  NS_REQUIRE(weights && dLdout && relu_masks && dLdfeatT, "ns_ngp_mlp_dgrad_m: null pointer");
+  NS_REQUIRE((d5T == nullptr) == (d4T == nullptr) && (d5T == nullptr) == (d3T == nullptr) && (d5T == nullptr) == (ddT == nullptr) &&
+                 (d5T == nullptr) == (d1T == nullptr),
+             "ns_ngp_mlp_dgrad_m: pass all five gradient buffers (for ns_ngp_mlp_wgrad_n) or none (dLdfeatT only)");
   NS_REQUIRE(N % 8 == 0, "ns_ngp_mlp_dgrad_m: N must be a multiple of 8");
   if (N <= 0) return NS_OK;
   return mlp_dgrad_launch(weights, dLdout, nullptr, nullptr, nullptr, dLdfeatT, d5T, d4T, d3T, ddT, d1T, N, n_dev, (hipStream_t)stream,
                           relu_masks);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradients OFF the critical path (round 3, second form).  ngp_mlp_bwd_fused_kernel needs 145 KB of LDS per workgroup:
+// one workgroup per CU, one wave per SIMD, every LDS / MFMA / VALU dependency exposed (98 us), and no other LDS-using kernel
+// can start next to it.  The training step therefore splits the backward pass:
+//   main stream  ngp_mlp_bwd_kernel<BITS> WITHOUT its five gradient stores: dL/dfeature only (96 B per sample), then the table
+//                gradient that consumes it;
+//   side stream  THIS kernel: forward and backward chains recomputed once more (72 MFMAs per 32 samples: nothing), every layer's
+//                weight gradient contracted on chip as in the fused kernel -- but with 2 waves and 64 samples per workgroup (46 KB
+//                of LDS: it co-resides with the scatter / accumulate workgroups of the table gradient) and the weight
+//                fragments read from a packed table in global memory (44 KB, L1 / L2 resident) instead of LDS.
+// 6 accumulator tiles per wave: wave 0: W4 (0,0) (0,1), W2 (0,0) (0,1), W1 (0,0) (1,0); wave 1: W4 (1,0) (1,1), W5 (0,0) (0,1), W3 (0,0) (1,0).
+// ---------------------------------------------------------------------------------------------
+#define FR_SP 72    // halfs per stage row: 64 samples + 8 pad
+
+__global__ __launch_bounds__(256) void ngp_mlp_pack_frags_kernel(const _Float16* __restrict__ W, f16x8* __restrict__ out) {
+  // out = [forward fragments FW_NFRAG x 64 | transposed fragments BW_NFRAG x 64], the layout the LDS tables of the kernels have
+  fill_frags<false>(out, W, W1_OFF, 64, 32, FW_L1);
+  fill_frags<false>(out, W, W2_OFF, 16, 64, FW_L2);
+  fill_frags<false>(out, W, W3_OFF, 64, 32, FW_L3);
+  fill_frags<false>(out, W, W4_OFF, 64, 64, FW_L4);
+  fill_frags<false>(out, W, W5_OFF, 16, 64, FW_L5);
+  f16x8* ob = out + FW_NFRAG * 64;
+  fill_frags<true>(ob, W, W5_OFF, 16, 64, BW_L5);
+  fill_frags<true>(ob, W, W4_OFF, 64, 64, BW_L4);
+  fill_frags<true>(ob, W, W3_OFF, 64, 32, BW_L3);
+  fill_frags<true>(ob, W, W2_OFF, 16, 64, BW_L2);
+  fill_frags<true>(ob, W, W1_OFF, 64, 32, BW_L1);
+}
+
+struct MlpWgradArgs {
+  const f16x8* frags;      // ngp_mlp_pack_frags_kernel's table
+  const _Float16* featT;
+  const float* dirs;
+  const _Float16* dLdout;
+  float* partial;          // [gridDim.x][W_TOTAL]
+  long N;
+  const int* n_dev;
+};
+
+__device__ __forceinline__ void stage_chunk64(_Float16* stage, int row0, const f16x8& v, int cc, int h, int col) {
+#pragma unroll
+  for (int q = 0; q < 8; q++) stage[(row0 + frag_k(cc, h, q)) * FR_SP + col] = v[q];
+}
+
+__device__ __forceinline__ void wgrad_tile64(const _Float16* stage, int xrow0, int to, int ti, int nout, int nin, int lane,
+                                             f32x16& acc) {
+  const int col = lane & 31, half = lane >> 5;
+  const int ro = to * 32 + col, ri = ti * 32 + col;
+  const bool oko = ro < nout, oki = ri < nin;
+  const _Float16* pa = stage + (FU_DY + (oko ? ro : 0)) * FR_SP + 8 * half;
+  const _Float16* pb = stage + (xrow0 + (oki ? ri : 0)) * FR_SP + 8 * half;
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {   // 4 x 16 samples
+    f16x8 av = *reinterpret_cast<const f16x8*>(pa + 16 * ks);
+    f16x8 bv = *reinterpret_cast<const f16x8*>(pb + 16 * ks);
+    if (!oko) av = (f16x8)(_Float16)0;
+    if (!oki) bv = (f16x8)(_Float16)0;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(128, 1) void ngp_mlp_wgrad_recompute_kernel(MlpWgradArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 stage[FU_ROWS * FR_SP];   // 46 KB: [unit rows][64 samples]
+  const f16x8* __restrict__ Wff = a.frags;
+  const f16x8* __restrict__ Wfb = a.frags + FW_NFRAG * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  const long N = a.N, cnt = ngp_count(a.N, a.n_dev);
+  const long nblk = (cnt + 63) / 64;
+  const int col = wave * 32 + j;
+  f32x16 t0 = (f32x16)0.0f, t1 = (f32x16)0.0f, t2 = (f32x16)0.0f, t3 = (f32x16)0.0f, t4 = (f32x16)0.0f, t5 = (f32x16)0.0f;
+  typedef _Float16 f16x4l __attribute__((ext_vector_type(4)));
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long np = blk * 64 + col;
+    const bool ok = np < cnt;
+    const long ns = ok ? np : 0;
+    uint32_t m1 = 0, m3 = 0, m4 = 0;
+    __syncthreads();   // the previous block's last weight-gradient tiles have been read
+    {
+      f16x8 x[2], h1[4], cin[2], h3[4], h4[4];
+#pragma unroll
+      for (int cc = 0; cc < 2; cc++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[cc][q] = ok ? a.featT[(long)frag_k(cc, h, q) * N + ns] : (_Float16)0;
+        stage_chunk64(stage, FU_XF, x[cc], cc, h, col);
+      }
+#pragma unroll
+      for (int it = 0; it < 2; it++) {
+        const f32x16 acc = layer_tile<2>(Wff, FW_L1, it, lane, x);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const _Float16 v = (_Float16)fmaxf(acc[r], 0.0f);
+          h1[2 * it + (r >> 3)][r & 7] = v;
+          m1 |= ((float)v > 0.0f ? 1u : 0u) << (16 * it + r);
+        }
+        stage_chunk64(stage, FU_XH1, h1[2 * it], 2 * it, h, col);
+        stage_chunk64(stage, FU_XH1, h1[2 * it + 1], 2 * it + 1, h, col);
+      }
+      {
+        const f32x16 acc = layer_tile<4>(Wff, FW_L2, 0, lane, h1);
+#pragma unroll
+        for (int r = 0; r < 8; r++) cin[0][r] = (_Float16)acc[r];
+        float sh[16];
+        sh16(a.dirs[ns * 3], a.dirs[ns * 3 + 1], a.dirs[ns * 3 + 2], sh);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int lo = (q & 3) + 8 * (q >> 2);
+          cin[1][q] = (_Float16)(h ? sh[lo + 4] : sh[lo]);
+        }
+        stage_chunk64(stage, FU_XC, cin[0], 0, h, col);
+        stage_chunk64(stage, FU_XC, cin[1], 1, h, col);
+      }
+#pragma unroll
+      for (int it = 0; it < 2; it++) {
+        const f32x16 acc = layer_tile<2>(Wff, FW_L3, it, lane, cin);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const _Float16 v = (_Float16)fmaxf(acc[r], 0.0f);
+          h3[2 * it + (r >> 3)][r & 7] = v;
+          m3 |= ((float)v > 0.0f ? 1u : 0u) << (16 * it + r);
+        }
+        stage_chunk64(stage, FU_XH3, h3[2 * it], 2 * it, h, col);
+        stage_chunk64(stage, FU_XH3, h3[2 * it + 1], 2 * it + 1, h, col);
+      }
+#pragma unroll
+      for (int it = 0; it < 2; it++) {
+        const f32x16 acc = layer_tile<4>(Wff, FW_L4, it, lane, h3);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const _Float16 v = (_Float16)fmaxf(acc[r], 0.0f);
+          h4[2 * it + (r >> 3)][r & 7] = v;
+          m4 |= ((float)v > 0.0f ? 1u : 0u) << (16 * it + r);
+        }
+        stage_chunk64(stage, FU_XH4, h4[2 * it], 2 * it, h, col);
+        stage_chunk64(stage, FU_XH4, h4[2 * it + 1], 2 * it + 1, h, col);
+      }
+    }
+    f16x4l go = (f16x4l)(_Float16)0;
+    if (ok) go = *reinterpret_cast<const f16x4l*>(a.dLdout + np * 4);   // (r, g, b, d)
+    f16x8 d5 = (f16x8)(_Float16)0;
+    if (h == 0) {
+      d5[0] = go[0];
+      d5[1] = go[1];
+      d5[2] = go[2];
+    }
+    stage_chunk64(stage, FU_DY, d5, 0, h, col);                        // W5: dY = d5 (16 rows), X = h4
+    __syncthreads();
+    if (wave == 1) {
+      wgrad_tile64(stage, FU_XH4, 0, 0, 16, 64, lane, t2);
+      wgrad_tile64(stage, FU_XH4, 0, 1, 16, 64, lane, t3);
+    }
+    __syncthreads();
+    f16x8 d4[4];
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const f32x16 acc = layer_tile<1>(Wfb, BW_L5, it, lane, &d5);
+#pragma unroll
+      for (int r = 0; r < 16; r++) d4[2 * it + (r >> 3)][r & 7] = (m4 >> (16 * it + r)) & 1u ? (_Float16)acc[r] : (_Float16)0;
+      stage_chunk64(stage, FU_DY, d4[2 * it], 2 * it, h, col);
+      stage_chunk64(stage, FU_DY, d4[2 * it + 1], 2 * it + 1, h, col);
+    }
+    __syncthreads();                                                   // W4: dY = d4, X = h3
+    wgrad_tile64(stage, FU_XH3, wave, 0, 64, 64, lane, t0);
+    wgrad_tile64(stage, FU_XH3, wave, 1, 64, 64, lane, t1);
+    __syncthreads();
+    f16x8 d3[4];
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const f32x16 acc = layer_tile<4>(Wfb, BW_L4, it, lane, d4);
+#pragma unroll
+      for (int r = 0; r < 16; r++) d3[2 * it + (r >> 3)][r & 7] = (m3 >> (16 * it + r)) & 1u ? (_Float16)acc[r] : (_Float16)0;
+      stage_chunk64(stage, FU_DY, d3[2 * it], 2 * it, h, col);
+      stage_chunk64(stage, FU_DY, d3[2 * it + 1], 2 * it + 1, h, col);
+    }
+    __syncthreads();                                                   // W3: dY = d3, X = cin (32 rows)
+    if (wave == 1) {
+      wgrad_tile64(stage, FU_XC, 0, 0, 64, 32, lane, t4);
+      wgrad_tile64(stage, FU_XC, 1, 0, 64, 32, lane, t5);
+    }
+    __syncthreads();
+    f16x8 dd;
+    {
+      const f32x16 acc = layer_tile<4>(Wfb, BW_L3, 0, lane, d3);
+#pragma unroll
+      for (int r = 0; r < 8; r++) dd[r] = (_Float16)acc[r];
+      if (h == 0) dd[0] = (_Float16)((float)dd[0] + (float)go[3]);
+    }
+    stage_chunk64(stage, FU_DY, dd, 0, h, col);                        // W2: dY = dd (16 rows), X = h1
+    __syncthreads();
+    if (wave == 0) {
+      wgrad_tile64(stage, FU_XH1, 0, 0, 16, 64, lane, t2);
+      wgrad_tile64(stage, FU_XH1, 0, 1, 16, 64, lane, t3);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const f32x16 acc = layer_tile<1>(Wfb, BW_L2, it, lane, &dd);
+      f16x8 lo8, hi8;
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        lo8[r] = (m1 >> (16 * it + r)) & 1u ? (_Float16)acc[r] : (_Float16)0;
+        hi8[r] = (m1 >> (16 * it + 8 + r)) & 1u ? (_Float16)acc[8 + r] : (_Float16)0;
+      }
+      stage_chunk64(stage, FU_DY, lo8, 2 * it, h, col);
+      stage_chunk64(stage, FU_DY, hi8, 2 * it + 1, h, col);
+    }
+    __syncthreads();                                                   // W1: dY = d1, X = the features
+    if (wave == 0) {
+      wgrad_tile64(stage, FU_XF, 0, 0, 64, 32, lane, t4);
+      wgrad_tile64(stage, FU_XF, 1, 0, 64, 32, lane, t5);
+    }
+  }
+  float* P = a.partial + (long)blockIdx.x * W_TOTAL;
+  wgrad_store(P, W4_OFF, wave, 0, 64, 64, lane, t0);
+  wgrad_store(P, W4_OFF, wave, 1, 64, 64, lane, t1);
+  if (wave == 0) {
+    wgrad_store(P, W2_OFF, 0, 0, 16, 64, lane, t2);
+    wgrad_store(P, W2_OFF, 0, 1, 16, 64, lane, t3);
+    wgrad_store(P, W1_OFF, 0, 0, 64, 32, lane, t4);
+    wgrad_store(P, W1_OFF, 1, 0, 64, 32, lane, t5);
+  } else {
+    wgrad_store(P, W5_OFF, 0, 0, 16, 64, lane, t2);
+    wgrad_store(P, W5_OFF, 0, 1, 16, 64, lane, t3);
+    wgrad_store(P, W3_OFF, 0, 0, 64, 32, lane, t4);
+    wgrad_store(P, W3_OFF, 1, 0, 64, 32, lane, t5);
+  }
+}
+
+extern "C" size_t ns_ngp_mlp_fragment_table_bytes(void) { return (size_t)(FW_NFRAG + BW_NFRAG) * 64 * sizeof(f16x8); }
+
+// packed MFMA fragment table of the current weights (forward + transposed), for ns_ngp_mlp_wgrad_recompute_n
+extern "C" int ns_ngp_mlp_pack_fragments(const void* weights, void* frags, void* stream) {
+  NS_REQUIRE(weights && frags && ((uintptr_t)frags % 16) == 0, "ns_ngp_mlp_pack_fragments: null / unaligned pointer");
+  hipLaunchKernelGGL(ngp_mlp_pack_frags_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const _Float16*)weights, (f16x8*)frags);
+  NS_CHECK_LAUNCH("ngp_mlp_pack_frags_kernel");
+  return NS_OK;
+}
+
+// weight gradients alone, forward and backward chains recomputed on chip from the features and the loss gradient: ADDS to
+// grad_weights; partial_ws: wgs * 10240 floats
+extern "C" int ns_ngp_mlp_wgrad_recompute_n(const void* frags, const void* featT, const float* dirs, const void* dLdout,
+                                            float* partial_ws, int wgs, float* grad_weights, long N, const int* n_dev,
+                                            void* stream) {
+  NS_REQUIRE(frags && featT && dirs && dLdout && partial_ws && grad_weights, "ns_ngp_mlp_wgrad_recompute: null pointer");
+  NS_REQUIRE(wgs >= 1 && wgs <= 65535 && N % 8 == 0, "ns_ngp_mlp_wgrad_recompute: 1 <= wgs <= 65535 and N a multiple of 8 are required");
+  if (N <= 0) return NS_OK;
+  MlpWgradArgs a{(const f16x8*)frags, (const _Float16*)featT, dirs, (const _Float16*)dLdout, partial_ws, N, n_dev};
+  hipLaunchKernelGGL(ngp_mlp_wgrad_recompute_kernel, dim3(wgs), dim3(128), 0, (hipStream_t)stream, a);
+  NS_CHECK_LAUNCH("ngp_mlp_wgrad_recompute_kernel");
+  hipLaunchKernelGGL(ngp_mlp_wgrad_reduce_kernel, dim3(W_TOTAL / 16), dim3(256), 0, (hipStream_t)stream, partial_ws, wgs, grad_weights);
+  NS_CHECK_LAUNCH("ngp_mlp_wgrad_reduce_kernel");
+  return NS_OK;
 }
 
 // activation gradients AND weight gradients from the features alone (forward recomputed on chip): writes dLdfeatT [32,N]

@@ -48,6 +48,7 @@ def lib():
                 L.ns_ngp_encode_backward_workspace_bytes.restype = C.c_long
                 L.ns_ngp_encode_backward_fused_workspace_bytes.restype = C.c_size_t
                 L.ns_ba_solve_large_workspace_bytes.restype = C.c_size_t
+                L.ns_ngp_mlp_fragment_table_bytes.restype = C.c_size_t
                 _lib = L
     return _lib
 

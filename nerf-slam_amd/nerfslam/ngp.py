@@ -369,12 +369,17 @@ class NgpNerf:
         acts, dacts = self.act, self.dact
         h1T, cinT, h3T, h4T = acts
         d5T, d4T, d3T, ddT, d1T = dacts
-        fused_mlp = not os.environ.get("NS_NGP_MLP_UNFUSED")
-        if fused_mlp:
-            # round 3: the forward pass writes only the network output; the backward pass recomputes the activations on chip
-            # and contracts the weight gradients there too (csrc/ngp_mlp.hip: ngp_mlp_bwd_fused_kernel)
+        # MLP backward, three forms: "split" (default) = bit-mask activation gradients WITHOUT their five gradient
+        # stores on this stream + the weight gradients recomputed on chip on a side stream next to the table gradient; "fused" =
+        # everything in one kernel on this stream (NS_NGP_MLP=fused); "r3a" = round 3's first form, separate weight-gradient kernel
+        # over stored activations / gradients (NS_NGP_MLP=r3a)
+        mlp_mode = os.environ.get("NS_NGP_MLP", "split")
+        if mlp_mode == "fused":
             check(L.ns_ngp_mlp_forward_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), None, None, None, None,
                                          C.c_long(S), n_dev, st), "ngp_mlp_forward")
+        elif mlp_mode == "split":
+            check(L.ns_ngp_mlp_forward_m_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), None, None, None, None,
+                                           ptr(self.relu_masks), C.c_long(S), n_dev, st), "ngp_mlp_forward")
         else:
             check(L.ns_ngp_mlp_forward_m_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out),
                                            *[ptr(a) for a in acts], ptr(self.relu_masks), C.c_long(S), n_dev, st), "ngp_mlp_forward")
@@ -382,72 +387,14 @@ class NgpNerf:
                                      ptr(X["r_rgb"]), ptr(X["r_depth"]), ptr(X["r_cov"]), C.c_float(c.depth_lambda),
                                      C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), ptr(X["loss"]),
                                      ptr(X["s_dout"]), ctl, st), "ngp_composite")
-        if fused_mlp:
-            # (tried: the fused kernel with the weight gradients on a stream of its own, next to the table gradient, and a store-free
-            # activation-gradient kernel on the main stream -- 0.466 -> 0.54-0.57 ms per step: one of its workgroups takes 145 KB of
-            # a CU's LDS, so the scatter / accumulate workgroups of the table gradient cannot start next to it)
-            if getattr(self, "partial_fused", None) is None:
-                self.partial_fused = torch.zeros((self.mlp_wgs, MLP_TOTAL), dtype=torch.float32, device=dev)
-            check(L.ns_ngp_mlp_backward_fused_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]), ptr(self.s_dfeat),
-                                                ptr(self.partial_fused), self.mlp_wgs, ptr(self.mlp_grad), C.c_long(S), n_dev, st),
-                  "ngp_mlp_backward_fused")
-        else:
-            check(L.ns_ngp_mlp_dgrad_m_n(ptr(self.mlp_half), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
-                                         ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT), ptr(d1T), C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
-        # everything below only READS what the activation backward wrote: three branches
-        self._side.wait_stream(main)
-        table_read = None
-        with torch.cuda.stream(self._side):
-            st2 = stream_ptr()
-            if c.optimize_extrinsics:
-                # pose refinement: input gradient of the encoding, then per-ray and per-image reductions
-                if jac is not None:
-                    check(L.ns_ngp_encode_jacobian_dot_n(*self._grid_args(), ptr(jac), ptr(self.s_dfeat), ptr(self.dpos),
-                                                         C.c_long(S), n_dev, st2), "ngp_encode_jacobian_dot")
-                else:
-                    # (A/B form, NS_NGP_POSE_GATHER=1: 8 gathers x 16 levels per sample again.  It reads the f16 table, which
-                    # the Adam-applying passes of the table gradient rewrite: they are held back until it is through)
-                    check(L.ns_ngp_encode_backward_input_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.grid_half),
-                                                           ptr(self.s_dfeat), ptr(self.dpos), C.c_long(S), n_dev, st2),
-                          "ngp_encode_backward_input")
-                    table_read = torch.cuda.Event()
-                    table_read.record()
-                n_cam = self.cam_grad.shape[0]
-                check(L.ns_ngp_camera_gradient_2stage(ptr(self.dpos), ptr(X["s_t"]), ptr(X["r_d"]), ptr(X["ray_start"]),
-                                                      ptr(X["ray_n"]), ptr(X["r_img"]), C.c_float(1.0 / s), ptr(self.cam_grad), Rc,
-                                                      ctl, ptr(self.ray_g) if n_cam <= 4096 else None, n_cam, st2),
-                      "ngp_camera_gradient")
-            if not fused_mlp:
-                check(L.ns_ngp_mlp_wgrad_n(ptr(featT), ptr(h1T), ptr(cinT), ptr(h3T), ptr(h4T), ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT),
-                                           ptr(d1T), ptr(self.partial), c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(S), n_dev, st2),
-                      "ngp_mlp_wgrad")
+        if mlp_mode != "r3a" and getattr(self, "partial_fused", None) is None:
+            self.partial_fused = torch.zeros((self.mlp_wgs, MLP_TOTAL), dtype=torch.float32, device=dev)
+            self.mlp_frags = torch.zeros(int(L.ns_ngp_mlp_fragment_table_bytes()) // 2, dtype=torch.float16, device=dev)
+        single = self.world == 1
+        pose = c.optimize_extrinsics
+        gather_pose = pose and jac is None          # A/B form: second gather of the table (reads what Adam rewrites)
 
-        def table_gradient(parts, stream):
-            # one trainer: Adam in the flushes (no gradient buffer); replicated trainers: the packed sums into the gradient buffer
-            fa = self.fused_adam
-            check(L.ns_ngp_encode_backward_fused_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat),
-                                                   None if fa else ptr(self.grid_grad), ptr(self.enc_ws),
-                                                   C.c_size_t(self.enc_ws_bytes), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev,
-                                                   ptr(self.grid_master) if fa else None, ptr(self.grid_half) if fa else None,
-                                                   ptr(self.grid_m1) if fa else None, ptr(self.grid_m2) if fa else None,
-                                                   0, C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
-                                                   C.c_float(c.loss_scale * self.world), ctl, parts, stream), "ngp_encode_backward_fused")
-        if self.fused_ws:
-            self._side2.wait_stream(main)
-            with torch.cuda.stream(self._side2):
-                table_gradient(4, stream_ptr())
-                if table_read is not None and self.fused_adam:
-                    self._side2.wait_event(table_read)
-                table_gradient(8, stream_ptr())
-            table_gradient(1, st)
-            if table_read is not None and self.fused_adam:
-                main.wait_event(table_read)
-            table_gradient(2, st)
-            main.wait_stream(self._side2)
-        else:
-            check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
-                                             ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev, st),
-                  "ngp_encode_backward")
+        # ---- the pieces ----
         def adam(m, hp, g, m1, m2, l2, fxs, stream):
             check(L.ns_ngp_adam_ctl(ptr(m), ptr(hp), ptr(g), ptr(m1), ptr(m2), C.c_long(m.numel()), 0, C.c_float(c.lr),
                                     C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps), C.c_float(l2),
@@ -459,31 +406,116 @@ class NgpNerf:
                                            self.cam_grad.shape[0], 0, C.c_float(c.extrinsic_lr_pos), C.c_float(c.extrinsic_lr_rot),
                                            C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
                                            C.c_float(c.loss_scale * self.world), ctl, stream), "ngp_camera_step")
-        if self.world == 1:
-            # the MLP's optimiser step and the pose update follow their gradients on the side stream (nothing on the main stream
-            # reads the weights or the poses after the activation gradients): the main stream ends with the accumulate pass
+
+        def pose_gradient(stream):
+            """input gradient of the encoding -> per-ray / per-image 6-dof gradients; -> event after the last read of the table"""
+            ev = None
+            if jac is not None:
+                check(L.ns_ngp_encode_jacobian_dot_n(*self._grid_args(), ptr(jac), ptr(self.s_dfeat), ptr(self.dpos),
+                                                     C.c_long(S), n_dev, stream), "ngp_encode_jacobian_dot")
+            else:
+                check(L.ns_ngp_encode_backward_input_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.grid_half),
+                                                       ptr(self.s_dfeat), ptr(self.dpos), C.c_long(S), n_dev, stream),
+                      "ngp_encode_backward_input")
+                ev = torch.cuda.Event()
+                ev.record()
+            n_cam = self.cam_grad.shape[0]
+            check(L.ns_ngp_camera_gradient_2stage(ptr(self.dpos), ptr(X["s_t"]), ptr(X["r_d"]), ptr(X["ray_start"]),
+                                                  ptr(X["ray_n"]), ptr(X["r_img"]), C.c_float(1.0 / s), ptr(self.cam_grad), Rc,
+                                                  ctl, ptr(self.ray_g) if n_cam <= 4096 else None, n_cam, stream), "ngp_camera_gradient")
+            return ev
+
+        def table_gradient(parts, stream):
+            # one trainer: Adam in the flushes (no gradient buffer); replicated trainers: the packed sums into the gradient buffer
+            fa = self.fused_adam
+            check(L.ns_ngp_encode_backward_fused_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat),
+                                                   None if fa else ptr(self.grid_grad), ptr(self.enc_ws),
+                                                   C.c_size_t(self.enc_ws_bytes), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev,
+                                                   ptr(self.grid_master) if fa else None, ptr(self.grid_half) if fa else None,
+                                                   ptr(self.grid_m1) if fa else None, ptr(self.grid_m2) if fa else None,
+                                                   0, C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
+                                                   C.c_float(c.loss_scale * self.world), ctl, parts, stream), "ngp_encode_backward_fused")
+
+        # ---- THREE streams (a HIP graph runs its branches on a handful of hardware queues: a fourth concurrent branch shared a
+        #      queue with the main one and the table gradient waited behind the pose refinement, +100 us):
+        #   main  : activation gradients -> table gradient of the hashed levels (scatter, accumulate + Adam)
+        #   side  : MLP weight gradients (+ the MLP's Adam); in the split form from the END OF THE COMPOSITE, i.e. next to the
+        #           activation gradients already (the rays of the next step were marched on this stream before)
+        #   side2 : dense levels of the table gradient, then the pose refinement's chain (+ the pose step)
+        if mlp_mode == "split":
+            self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
-                if c.optimize_extrinsics:
-                    camera_step(stream_ptr())
-                adam(*mlp, stream_ptr())
+                st1 = stream_ptr()
+                check(L.ns_ngp_mlp_pack_fragments(ptr(self.mlp_half), ptr(self.mlp_frags), st1), "ngp_mlp_pack_fragments")
+                check(L.ns_ngp_mlp_wgrad_recompute_n(ptr(self.mlp_frags), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]),
+                                                     ptr(self.partial_fused), self.mlp_wgs, ptr(self.mlp_grad), C.c_long(S), n_dev, st1),
+                      "ngp_mlp_wgrad_recompute")
+                if single:
+                    adam(*mlp, st1)
+            check(L.ns_ngp_mlp_dgrad_m_n(ptr(self.mlp_half), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
+                                         None, None, None, None, None, C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
+        elif mlp_mode == "fused":
+            # (one workgroup of this kernel takes 145 KB of LDS: nothing LDS-using can run next to it, so it sits on this stream)
+            check(L.ns_ngp_mlp_backward_fused_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]), ptr(self.s_dfeat),
+                                                ptr(self.partial_fused), self.mlp_wgs, ptr(self.mlp_grad), C.c_long(S), n_dev, st),
+                  "ngp_mlp_backward_fused")
+            if single:
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    adam(*mlp, stream_ptr())
+        else:
+            check(L.ns_ngp_mlp_dgrad_m_n(ptr(self.mlp_half), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
+                                         ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT), ptr(d1T), C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                st1 = stream_ptr()
+                check(L.ns_ngp_mlp_wgrad_n(ptr(featT), ptr(h1T), ptr(cinT), ptr(h3T), ptr(h4T), ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT),
+                                           ptr(d1T), ptr(self.partial), c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(S), n_dev, st1),
+                      "ngp_mlp_wgrad")
+                if single:
+                    adam(*mlp, st1)
+        table_read = None
+        self._side2.wait_stream(main)
+        with torch.cuda.stream(self._side2):
+            st2 = stream_ptr()
+            if gather_pose:                      # reads the f16 table: before anything on this stream rewrites it
+                table_read = pose_gradient(st2)
+            if self.fused_ws:
+                table_gradient(4, st2)
+                table_gradient(8, st2)
+            if pose and not gather_pose:
+                pose_gradient(st2)
+            if pose and single:
+                camera_step(st2)
+        if self.fused_ws:
+            table_gradient(1, st)
+            if table_read is not None and self.fused_adam:
+                main.wait_event(table_read)
+            table_gradient(2, st)
+        else:
+            check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
+                                             ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev, st),
+                  "ngp_encode_backward")
+        main.wait_stream(self._side2)
         main.wait_stream(self._side)
-        if self.world > 1:
+        if not single:
             self._exchange_gradients()
-            if c.optimize_extrinsics:   # after the all-reduce: every replica applies the SAME pose update
+            if pose:   # after the all-reduce: every replica applies the SAME pose update (ADVICE r01)
                 camera_step(st)
-        if self.world > 1 and c.grad_fixed_scale > 0:
-            # Adam on THIS trainer's shard of the table (summed gradient in `_gshard`), then the f16 copies of all shards
-            Ns = self.shard_entries
-            lo = 2 * Ns * self.rank
-            n = max(0, min(2 * Ns, self.n_grid - lo))
-            if n > 0:
-                adam(self.grid_master[lo:lo + n], self.grid_half[lo:lo + n], self._gshard.view(torch.float32)[:n], self.grid_m1[lo:lo + n],
-                     self.grid_m2[lo:lo + n], 0.0, c.grad_fixed_scale, st)
-            self._gather_parameters()
+            if c.grad_fixed_scale > 0:
+                # Adam on THIS trainer's shard of the table (summed gradient in `_gshard`), then the f16 copies of all shards
+                Ns = self.shard_entries
+                lo = 2 * Ns * self.rank
+                n = max(0, min(2 * Ns, self.n_grid - lo))
+                if n > 0:
+                    adam(self.grid_master[lo:lo + n], self.grid_half[lo:lo + n], self._gshard.view(torch.float32)[:n],
+                         self.grid_m1[lo:lo + n], self.grid_m2[lo:lo + n], 0.0, c.grad_fixed_scale, st)
+                self._gather_parameters()
+            else:
+                adam(self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale, st)
+            adam(*mlp, st)
         elif not self.fused_adam:
             adam(self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale, st)
-        if self.world > 1:
-            adam(*mlp, st)
 
     def train_step(self, return_loss=True):
         if self.n_images == 0:

@@ -180,6 +180,27 @@ def test_mlp_forward_backward(oracle_mod, dev):
             assert torch.isfinite(gw_got).all()
             err = (gw_got - gw_ref).abs().max().item()
             assert err <= 2e-3 * gw_ref.abs().max().item(), (wgs, err, gw_ref.abs().max().item())
+        # split form (the trainer's default): activation gradients without their five stores + weight gradients recomputed on
+        # chip from a packed fragment table (46-KB-LDS kernel for a side stream); masks-only forward (no activation buffers)
+        masks2 = torch.zeros(6 * N, dtype=torch.int32, device=dev)
+        out2 = torch.empty_like(out)
+        check(lib().ns_ngp_mlp_forward_m_n(ptr(Wd), ptr(d_featT), ptr(d_dirs), ptr(out2), None, None, None, None, ptr(masks2),
+                                           C.c_long(N), ptr(n_dev), stream_ptr()), "mlp fwd masks only")
+        assert torch.equal(out2[:n_valid], out[:n_valid])
+        lean = torch.zeros_like(dfeat)
+        check(lib().ns_ngp_mlp_dgrad_m_n(ptr(Wd), ptr(d_dout), ptr(masks2), ptr(lean), None, None, None, None, None, C.c_long(N),
+                                         ptr(n_dev), stream_ptr()), "lean dgrad")
+        assert torch.equal(lean[:, :n_valid], ref_feat[:, :n_valid])
+        frags = torch.zeros(int(lib().ns_ngp_mlp_fragment_table_bytes()) // 2, dtype=torch.float16, device=dev)
+        check(lib().ns_ngp_mlp_pack_fragments(ptr(Wd), ptr(frags), stream_ptr()), "pack")
+        for wgs in (1, 5, 64):
+            gw_got = torch.zeros(10240, dtype=torch.float32, device=dev)
+            part_f = torch.full((wgs, 10240), float("nan"), dtype=torch.float32, device=dev)
+            check(lib().ns_ngp_mlp_wgrad_recompute_n(ptr(frags), ptr(d_featT), ptr(d_dirs), ptr(d_dout), ptr(part_f), wgs, ptr(gw_got),
+                                                     C.c_long(N), ptr(n_dev), stream_ptr()), "wgrad recompute")
+            assert torch.isfinite(gw_got).all()
+            err = (gw_got - gw_ref).abs().max().item()
+            assert err <= 2e-3 * gw_ref.abs().max().item(), ("recompute", wgs, err, gw_ref.abs().max().item())
 
 
 def test_composite_loss_and_adam(oracle_mod, dev):
