@@ -287,7 +287,7 @@ class NgpNerf:
         self.dpos = torch.zeros((c.max_samples, 3), **f)
         self.ray_g = torch.zeros((Rc, 6), **f)
         self.last = torch.zeros(4, **i32)
-        self._graphs, self._graph_key = [None, None], None
+        self._graphs, self._graph_key, self._pair = [None, None], None, None
         self._side = torch.cuda.Stream(device=dev)       # next step's ray marching, then weight / pose gradients
         self._side2 = torch.cuda.Stream(device=dev)      # dense levels of the table gradient
         self._primed = False
@@ -348,6 +348,8 @@ class NgpNerf:
         st = stream_ptr()
         ctl = ptr(X["ctl"])
         main = torch.cuda.current_stream()
+        # (under capture the ORDER of these calls decides which hardware queue a branch gets: with the forward pass enqueued
+        #  before this branch, the executor put the branch behind side2's kernels on one queue and the step took 0.58 ms)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             check(L.ns_ngp_step_prepare(ptr(X["ctl"]), ptr(Y["ctl"]), ptr(X["counter"]), ptr(Y["counter"]), ptr(self.last),
@@ -437,65 +439,75 @@ class NgpNerf:
                                                    C.c_float(c.loss_scale * self.world), ctl, parts, stream), "ngp_encode_backward_fused")
 
         # ---- THREE streams (a HIP graph runs its branches on a handful of hardware queues: a fourth concurrent branch shared a
-        #      queue with the main one and the table gradient waited behind the pose refinement, +100 us):
-        #   main  : activation gradients -> table gradient of the hashed levels (scatter, accumulate + Adam)
-        #   side  : MLP weight gradients (+ the MLP's Adam); in the split form from the END OF THE COMPOSITE, i.e. next to the
-        #           activation gradients already (the rays of the next step were marched on this stream before)
-        #   side2 : dense levels of the table gradient, then the pose refinement's chain (+ the pose step)
+        #      queue with the main one and the table gradient waited behind the pose refinement, +100 us).  Every fork costs the
+        #      main stream ~10 us; ONE two-way fork after the activation gradients cost it 29 us and started all three branches'
+        #      heaviest kernels at the same instant (0.46 -> 0.50 ms), so the two forks stay apart:
+        #   main  : [fork 1] activation gradients [fork 2] table gradient of the hashed levels (scatter, accumulate + Adam)
+        #   side  : (the next step's rays, from the start of the step) [1] MLP weight gradients + the MLP's Adam, then [2] the
+        #           pose refinement's chain + the pose step
+        #   side2 : [2] dense levels of the table gradient
+        table_read = None
         if mlp_mode == "split":
-            self._side.wait_stream(main)
+            fork1 = torch.cuda.Event()
+            fork1.record(main)
+            check(L.ns_ngp_mlp_dgrad_m_n(ptr(self.mlp_half), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
+                                         None, None, None, None, None, C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
             with torch.cuda.stream(self._side):
                 st1 = stream_ptr()
+                self._side.wait_event(fork1)
                 check(L.ns_ngp_mlp_pack_fragments(ptr(self.mlp_half), ptr(self.mlp_frags), st1), "ngp_mlp_pack_fragments")
                 check(L.ns_ngp_mlp_wgrad_recompute_n(ptr(self.mlp_frags), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]),
                                                      ptr(self.partial_fused), self.mlp_wgs, ptr(self.mlp_grad), C.c_long(S), n_dev, st1),
                       "ngp_mlp_wgrad_recompute")
                 if single:
                     adam(*mlp, st1)
-            check(L.ns_ngp_mlp_dgrad_m_n(ptr(self.mlp_half), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
-                                         None, None, None, None, None, C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
         elif mlp_mode == "fused":
             # (one workgroup of this kernel takes 145 KB of LDS: nothing LDS-using can run next to it, so it sits on this stream)
             check(L.ns_ngp_mlp_backward_fused_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]), ptr(self.s_dfeat),
                                                 ptr(self.partial_fused), self.mlp_wgs, ptr(self.mlp_grad), C.c_long(S), n_dev, st),
                   "ngp_mlp_backward_fused")
-            if single:
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    adam(*mlp, stream_ptr())
         else:
             check(L.ns_ngp_mlp_dgrad_m_n(ptr(self.mlp_half), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
                                          ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT), ptr(d1T), C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                st1 = stream_ptr()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        # (enqueue order matters under capture although the dependencies do not change: the graph executor keeps the FIRST
+        #  successor created for a node on that node's hardware queue and hands later ones to other queues -- enqueued after the
+        #  side branches, the scatter landed on the side stream's queue BEHIND the pose refinement, 0.49 ms)
+        def hashed_levels():
+            if self.fused_ws:
+                table_gradient(1, st)
+                if table_read is not None and self.fused_adam:
+                    main.wait_event(table_read)
+                table_gradient(2, st)
+            else:
+                check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
+                                                 ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev, st),
+                      "ngp_encode_backward")
+        if not gather_pose:
+            hashed_levels()
+        with torch.cuda.stream(self._side2):
+            self._side2.wait_event(fork)
+            if gather_pose:                      # reads the f16 table: before anything rewrites it
+                table_read = pose_gradient(stream_ptr())
+            if self.fused_ws:
+                table_gradient(4, stream_ptr())
+                table_gradient(8, stream_ptr())
+        if gather_pose:
+            hashed_levels()
+        with torch.cuda.stream(self._side):
+            st1 = stream_ptr()
+            self._side.wait_event(fork)
+            if mlp_mode == "r3a":
                 check(L.ns_ngp_mlp_wgrad_n(ptr(featT), ptr(h1T), ptr(cinT), ptr(h3T), ptr(h4T), ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT),
                                            ptr(d1T), ptr(self.partial), c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(S), n_dev, st1),
                       "ngp_mlp_wgrad")
-                if single:
-                    adam(*mlp, st1)
-        table_read = None
-        self._side2.wait_stream(main)
-        with torch.cuda.stream(self._side2):
-            st2 = stream_ptr()
-            if gather_pose:                      # reads the f16 table: before anything on this stream rewrites it
-                table_read = pose_gradient(st2)
-            if self.fused_ws:
-                table_gradient(4, st2)
-                table_gradient(8, st2)
+            if single and mlp_mode != "split":
+                adam(*mlp, st1)
             if pose and not gather_pose:
-                pose_gradient(st2)
+                pose_gradient(st1)
             if pose and single:
-                camera_step(st2)
-        if self.fused_ws:
-            table_gradient(1, st)
-            if table_read is not None and self.fused_adam:
-                main.wait_event(table_read)
-            table_gradient(2, st)
-        else:
-            check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
-                                             ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev, st),
-                  "ngp_encode_backward")
+                camera_step(st1)
         main.wait_stream(self._side2)
         main.wait_stream(self._side)
         if not single:
@@ -516,6 +528,49 @@ class NgpNerf:
             adam(*mlp, st)
         elif not self.fused_adam:
             adam(self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale, st)
+
+    def train_steps(self, n, return_loss=True):
+        """`n` optimiser steps.  Same as n calls of train_step(); two steps at a time are replayed from ONE graph where that is
+        possible (both single-step graphs captured, nothing reallocated, no occupancy update between the two): the gap between
+        two graph launches (join, launch, fork: 25-35 us on the device) is paid once per pair."""
+        c = self.cfg
+        i = 0
+        while i < n:
+            if n - i >= 2 and self._pair_ready():
+                with torch.cuda.device(self.device):
+                    if self._pair is None:
+                        from ._lib import capture_lock
+                        with capture_lock:
+                            torch.cuda.synchronize(self.device)
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                                self._enqueue_step(0)
+                                self._enqueue_step(1)
+                        self._pair = g
+                    self._pair.replay()
+                    self.step += 2
+                    if self.step % c.grid_update_every == 0:
+                        self.update_density_grid()
+                        self._primed = False
+                i += 2
+            else:
+                self.train_step(return_loss=False)
+                i += 1
+        return self.loss_tensor if (return_loss and self.n_images > 0) else None
+
+    def _pair_ready(self):
+        c = self.cfg
+        if self.world > 1 or not c.use_graph or os.environ.get("NS_NGP_NO_PAIR") or self.n_images == 0:
+            return False
+        if not getattr(self, "_static", False) or not self._primed or self.cur != 0:
+            return False
+        if self._graphs[0] is None or self._graphs[1] is None:
+            return False
+        if c.optimize_extrinsics:
+            self._grow_camera_state(self.images.shape[0])
+        if self._graph_key != self._step_key():
+            return False
+        return self.step % c.grid_update_every <= c.grid_update_every - 2
 
     def train_step(self, return_loss=True):
         if self.n_images == 0:
@@ -541,7 +596,7 @@ class NgpNerf:
                 key = self._step_key()
                 if self._graph_key != key:
                     # (re)capture: the first steps after a (re)allocation run eagerly -- they are also the warm-up
-                    self._graphs, self._graph_key = [None, None], key
+                    self._graphs, self._graph_key, self._pair = [None, None], key, None
                     self._eager_left = 2
                 if self._eager_left > 0:
                     self._eager_left -= 1

@@ -188,9 +188,7 @@ class Testbed:
         """One instant-ngp "frame" (nerf_fusion.py:299): a slice of training steps (no GUI here)."""
         if self.shall_train and self._net is not None and self._net.n_images > 0:
             t0 = time.time()
-            loss = None
-            for i in range(self.steps_per_frame):
-                loss = self._net.train_step(return_loss=(i == self.steps_per_frame - 1))
+            loss = self._net.train_steps(self.steps_per_frame)
             if loss is not None:
                 self._loss_t = loss                      # device scalar; converted when `loss` is read (no per-frame sync)
             self.training_step = self._net.step

@@ -990,3 +990,43 @@ def test_graph_capture_while_another_thread_synchronises(dev):
     assert not ta.is_alive() and not tb.is_alive(), "threads hung"
     assert not errors, errors
     assert captures[0] >= 20 and net.step == 240 and np.isfinite(float(net.loss_tensor)) and time.time() - t0 < 180
+
+
+@pytest.mark.gpu
+def test_paired_step_graph_trains_like_single_steps(dev):
+    """train_steps(n) replays two steps from one graph where it can (no occupancy update in between, both single-step graphs
+    there): same bookkeeping (step count, set parity, marched-ahead rays, occupancy updates on the same steps) and the same
+    training as n calls of train_step() -- up to the summation order of the MLP weight gradients (the marcher hands out sample
+    ranges with an atomic, so two runs of the SAME path differ by as much)."""
+    import importlib.util
+    from nerfslam.ngp import NgpConfig, NgpNerf
+    spec = importlib.util.spec_from_file_location("ngp_scene", os.path.join(os.path.dirname(__file__), "..", "tools", "ngp_scene.py"))
+    sc = importlib.util.module_from_spec(spec); spec.loader.exec_module(sc)
+    scene = sc.sphere_scene(n=4, H=60, W=80, f=75.0)
+    nets = []
+    for mode in ("single", "single", "paired"):
+        net = NgpNerf(NgpConfig(optimize_extrinsics=True), dev, seed=0)
+        net.set_images(*scene)
+        if mode == "single":
+            for _ in range(23 + 64):
+                net.train_step(return_loss=False)
+        else:
+            for _ in range(23):                       # an odd start: pairs begin on an even step, never straddle an update
+                net.train_step(return_loss=False)
+            assert net._pair is None
+            net.train_steps(64, return_loss=False)
+            assert net._pair is not None
+        torch.cuda.synchronize()
+        assert net.step == 87 and net.cur == 1
+        nets.append(net)
+    a, b, p = nets
+
+    def rel(x, y):
+        return float((x.double() - y.double()).norm() / y.double().norm())
+    same_path = max(rel(a.grid_master, b.grid_master), rel(a.mlp_master, b.mlp_master), 1e-6)
+    assert rel(p.grid_master, a.grid_master) <= 4 * same_path + 1e-3, (rel(p.grid_master, a.grid_master), same_path)
+    assert rel(p.mlp_master, a.mlp_master) <= 4 * same_path + 1e-3, (rel(p.mlp_master, a.mlp_master), same_path)
+    assert rel(p.c2w, a.c2w) <= 4 * rel(b.c2w, a.c2w) + 1e-3, (rel(p.c2w, a.c2w), rel(b.c2w, a.c2w))
+    assert torch.equal(p.bits, a.bits) or (p.bits != a.bits).float().mean() < 0.02
+    la, lp = float(a.loss_tensor), float(p.loss_tensor)
+    assert abs(la - lp) <= 0.25 * la + 1e-5, (la, lp)

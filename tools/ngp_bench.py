@@ -17,12 +17,13 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("ngp_scene", os.path.join(root, "tools", "ngp_scene.py"))
 sc = importlib.util.module_from_spec(spec); spec.loader.exec_module(sc)
 net.set_images(*sc.sphere_scene())
-for _ in range(warm):
-    net.train_step(return_loss=False)
+for _ in range(warm // 16):                 # 16 steps per call, as pyngp's frame() asks for them
+    net.train_steps(16, return_loss=False)
 torch.cuda.synchronize()
+steps = steps // 16 * 16
 t0 = time.perf_counter(); ns = 0; nr = 0
-for _ in range(steps):
-    net.train_step(return_loss=False)
+for _ in range(steps // 16):
+    net.train_steps(16, return_loss=False)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 ns, nr = steps * net.last_samples, steps * int(net.last[1].item())   # (read once, after the timed loop: no per-step sync)
