@@ -473,6 +473,13 @@ int ns_ngp_composite_ctl(const void* net_out, const float* dt, const float* tmid
                          const float* gt_rgb, const float* gt_depth, const float* gt_depth_cov, float depth_lambda,
                          float loss_scale, float* out_rgb, float* out_depth, float* loss, void* dLdout, const int* ctl,
                          void* stream);
+/* ns_ngp_composite_ctl with the loss PER RAY: ray_loss[R] is written (0 for rays beyond the batch's device-side count), `loss`
+ * is not touched.  One atomicAdd per ray on the one address of `loss` serialises in the L2 (36 of the kernel's 46 us with ~4000
+ * rays); the trainer sums the per-ray values when the loss is read (testbed.loss, nerf_fusion.py:312).                       */
+int ns_ngp_composite_rays(const void* net_out, const float* dt, const float* tmid, const int* ray_start, const int* ray_n, int R,
+                          const float* gt_rgb, const float* gt_depth, const float* gt_depth_cov, float depth_lambda,
+                          float loss_scale, float* out_rgb, float* out_depth, float* loss, float* ray_loss, void* dLdout,
+                          const int* ctl, void* stream);
 int ns_ngp_camera_gradient_ctl(const float* dLdpos, const float* tmid, const float* rays_d, const int* ray_start,
                                const int* ray_n, const int* ray_img, float pos_inv, float* cam_grad, int R, const int* ctl,
                                void* stream);

@@ -1919,26 +1919,41 @@ struct CompositeArgs {
   float* out_rgb;    // [R,3]
   float* out_depth;  // [R]
   float* loss;       // [1] accumulated sum over rays of the per-ray loss (caller zeroes, divides by R)
+  float* ray_loss;   // [R] or null: per-ray loss WRITTEN here instead (0 for rays beyond the batch); `loss` is not touched
   _Float16* dLdout;  // [S,4] or null (inference)
   int R;
   const int* ctl;
 };
 
-__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float u = __shfl_up(v, d);
-    if (lane >= d) v += u;
-  }
+// wave64 inclusive scans on the VALU (DPP row shifts + the two row broadcasts): `__shfl_up` lowers to ds_bpermute_b32 (~100
+// cycles per step, six dependent steps per scan, five scans per round of the backward pass).  A lane without a source in
+// its row keeps `old` = the identity.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float v, float identity) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL,
+                                                               ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_incl_sum(float v, int) {
+  v += dpp_take<0x111, 0xf>(v, 0.0f);  // row_shr:1
+  v += dpp_take<0x112, 0xf>(v, 0.0f);  // row_shr:2
+  v += dpp_take<0x114, 0xf>(v, 0.0f);  // row_shr:4
+  v += dpp_take<0x118, 0xf>(v, 0.0f);  // row_shr:8  -> scan within every 16-lane row
+  v += dpp_take<0x142, 0xa>(v, 0.0f);  // row_bcast15 into rows 1, 3
+  v += dpp_take<0x143, 0xc>(v, 0.0f);  // row_bcast31 into rows 2, 3
   return v;
 }
-__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float u = __shfl_up(v, d);
-    if (lane >= d) v *= u;
-  }
+__device__ __forceinline__ float wave_incl_prod(float v, int) {
+  v *= dpp_take<0x111, 0xf>(v, 1.0f);
+  v *= dpp_take<0x112, 0xf>(v, 1.0f);
+  v *= dpp_take<0x114, 0xf>(v, 1.0f);
+  v *= dpp_take<0x118, 0xf>(v, 1.0f);
+  v *= dpp_take<0x142, 0xa>(v, 1.0f);
+  v *= dpp_take<0x143, 0xc>(v, 1.0f);
   return v;
+}
+__device__ __forceinline__ float wave_prev(float v, float first) { return dpp_take<0x138, 0xf>(v, first); }   // wave_shr:1
+__device__ __forceinline__ float wave_last(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 struct CompSample {
@@ -1965,25 +1980,44 @@ __device__ __forceinline__ CompSample comp_load(const CompositeArgs& a, long s, 
 // suffix sums of the backward pass = totals minus inclusive prefix sums (wave scans), carried across
 // rounds in wave-uniform registers.  (The one-lane-per-ray version walked up to 1024 samples serially:
 // 157 us for ~2500 live rays.)
+// The kernel's time is its LONGEST ray's (every ray has its wave resident from the start), and that ray's time was one
+// exposed load latency per round and pass (load -> scans -> next load ...: 42 us with rays of 1024 samples in the batch).
+// Now the first CP_NC rounds (256 samples: all but a few rays) are loaded up front and stay in registers for the backward
+// pass; rounds beyond that are loaded one round ahead of their scans.
+#define CP_NC 4
 __global__ __launch_bounds__(256) void ngp_composite_kernel(CompositeArgs a) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int R = a.ctl ? min(a.ctl[NS_CTL_RAYS], a.R) : a.R;
-  if (r >= R) return;  // wave-uniform
+  if (r >= R) {        // wave-uniform
+    if (a.ray_loss != nullptr && lane == 0 && r < a.R) a.ray_loss[r] = 0.0f;
+    return;
+  }
   const int s0 = a.ray_start[r], n = a.ray_n[r];
+  CompSample cache[CP_NC];
+#pragma unroll
+  for (int i = 0; i < CP_NC; i++) cache[i] = comp_load(a, (long)s0 + 64 * i + lane, 64 * i + lane < n);
   float Tin = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, D = 0.0f;
-  for (int k0 = 0; k0 < n; k0 += 64) {
-    const bool valid = k0 + lane < n;
-    const CompSample q = comp_load(a, (long)s0 + k0 + lane, valid);
+  auto fwd = [&](const CompSample& q) __attribute__((always_inline)) {
     const float incl = wave_incl_prod(1.0f - q.alpha, lane);
-    float excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = 1.0f;
+    const float excl = wave_prev(incl, 1.0f);
     const float wgt = q.alpha * Tin * excl;
     C0 += wave_sum(wgt * q.c0);
     C1 += wave_sum(wgt * q.c1);
     C2 += wave_sum(wgt * q.c2);
     D += wave_sum(wgt * q.tm);
-    Tin *= __shfl(incl, 63);
+    Tin *= wave_last(incl);
+  };
+#pragma unroll
+  for (int i = 0; i < CP_NC; i++)
+    if (64 * i < n) fwd(cache[i]);                                   // (wave-uniform)
+  if (64 * CP_NC < n) {
+    CompSample cur = comp_load(a, (long)s0 + 64 * CP_NC + lane, 64 * CP_NC + lane < n);
+    for (int k0 = 64 * CP_NC; k0 < n; k0 += 64) {
+      const CompSample nxt = comp_load(a, (long)s0 + k0 + 64 + lane, k0 + 64 + lane < n);
+      fwd(cur);
+      cur = nxt;
+    }
   }
   if (lane == 0) {
     a.out_rgb[r * 3] = C0;
@@ -2002,17 +2036,20 @@ __global__ __launch_bounds__(256) void ngp_composite_kernel(CompositeArgs a) {
     l += a.depth_lambda * ed * ed * icov;
     dD = a.depth_lambda * 2.0f * ed * icov;
   }
-  if (lane == 0) atomicAdd(a.loss, l);
+  // (one atomicAdd per ray on ONE address: ~4000 same-address atomics serialise in the L2 at ~10 ns each -- 36 of this kernel's
+  //  46 us, on the step's critical path.  The trainer takes the per-ray values and sums them when somebody asks for the loss.)
+  if (lane == 0) {
+    if (a.ray_loss != nullptr) a.ray_loss[r] = l;
+    else atomicAdd(a.loss, l);
+  }
   const float sc = a.loss_scale / (float)R;
   Tin = 1.0f;
   float P0 = 0.0f, P1 = 0.0f, P2 = 0.0f, PD = 0.0f;  // prefix sums carried across rounds
-  for (int k0 = 0; k0 < n; k0 += 64) {
+  auto bwd = [&](const CompSample& q, int k0) __attribute__((always_inline)) {
     const bool valid = k0 + lane < n;
     const long s = (long)s0 + k0 + lane;
-    const CompSample q = comp_load(a, s, valid);
     const float incl = wave_incl_prod(1.0f - q.alpha, lane);
-    float excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = 1.0f;
+    const float excl = wave_prev(incl, 1.0f);
     const float T = Tin * excl, wgt = q.alpha * T, Tn = Tin * incl;
     const float p0 = P0 + wave_incl_sum(wgt * q.c0, lane), p1 = P1 + wave_incl_sum(wgt * q.c1, lane);
     const float p2 = P2 + wave_incl_sum(wgt * q.c2, lane), pd = PD + wave_incl_sum(wgt * q.tm, lane);
@@ -2024,11 +2061,22 @@ __global__ __launch_bounds__(256) void ngp_composite_kernel(CompositeArgs a) {
                        (_Float16)(sc * wgt * dC2 * q.c2 * (1.0f - q.c2)), (_Float16)(sc * q.dt * gsum * q.sigma)};
       *reinterpret_cast<f16x4*>(a.dLdout + s * 4) = g;
     }
-    P0 = __shfl(p0, 63);
-    P1 = __shfl(p1, 63);
-    P2 = __shfl(p2, 63);
-    PD = __shfl(pd, 63);
-    Tin *= __shfl(incl, 63);
+    P0 = wave_last(p0);
+    P1 = wave_last(p1);
+    P2 = wave_last(p2);
+    PD = wave_last(pd);
+    Tin *= wave_last(incl);
+  };
+#pragma unroll
+  for (int i = 0; i < CP_NC; i++)
+    if (64 * i < n) bwd(cache[i], 64 * i);
+  if (64 * CP_NC < n) {
+    CompSample cur = comp_load(a, (long)s0 + 64 * CP_NC + lane, 64 * CP_NC + lane < n);
+    for (int k0 = 64 * CP_NC; k0 < n; k0 += 64) {
+      const CompSample nxt = comp_load(a, (long)s0 + k0 + 64 + lane, k0 + 64 + lane < n);
+      bwd(cur, k0);
+      cur = nxt;
+    }
   }
 }
 
@@ -2510,12 +2558,20 @@ extern "C" int ns_ngp_composite_ctl(const void* net_out, const float* dt, const 
                                     const int* ray_n, int R, const float* gt_rgb, const float* gt_depth,
                                     const float* gt_depth_cov, float depth_lambda, float loss_scale, float* out_rgb,
                                     float* out_depth, float* loss, void* dLdout, const int* ctl, void* stream) {
+  return ns_ngp_composite_rays(net_out, dt, tmid, ray_start, ray_n, R, gt_rgb, gt_depth, gt_depth_cov, depth_lambda, loss_scale,
+                               out_rgb, out_depth, loss, nullptr, dLdout, ctl, stream);
+}
+
+extern "C" int ns_ngp_composite_rays(const void* net_out, const float* dt, const float* tmid, const int* ray_start,
+                                     const int* ray_n, int R, const float* gt_rgb, const float* gt_depth,
+                                     const float* gt_depth_cov, float depth_lambda, float loss_scale, float* out_rgb,
+                                     float* out_depth, float* loss, float* ray_loss, void* dLdout, const int* ctl, void* stream) {
   NS_REQUIRE(net_out && dt && tmid && ray_start && ray_n && out_rgb && out_depth, "ns_ngp_composite: null pointer");
-  NS_REQUIRE(dLdout == nullptr || (gt_rgb && gt_depth && gt_depth_cov && loss),
-             "ns_ngp_composite: training mode needs the ground truth and the loss pointer");
+  NS_REQUIRE(dLdout == nullptr || (gt_rgb && gt_depth && gt_depth_cov && (loss || ray_loss)),
+             "ns_ngp_composite: training mode needs the ground truth and a loss pointer");
   if (R <= 0) return NS_OK;
   CompositeArgs a{(const _Float16*)net_out, dt, tmid, ray_start, ray_n, gt_rgb, gt_depth, gt_depth_cov,
-                  depth_lambda, loss_scale, out_rgb, out_depth, loss, (_Float16*)dLdout, R, ctl};
+                  depth_lambda, loss_scale, out_rgb, out_depth, loss, ray_loss, (_Float16*)dLdout, R, ctl};
   hipLaunchKernelGGL(ngp_composite_kernel, dim3(ns_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, a);
   NS_CHECK_LAUNCH("ngp_composite_kernel");
   return NS_OK;

@@ -278,7 +278,7 @@ class NgpNerf:
                      # unused sample slots must hold finite inputs: the per-sample kernels run over all of them
                      s_pos=torch.full((S, 3), 0.5, **f), s_dir=torch.zeros((S, 3), **f), s_dt=torch.zeros(S, **f),
                      s_t=torch.zeros(S, **f), s_dout=torch.zeros((S, 4), **h), counter=torch.zeros(3, **i32),
-                     loss=torch.zeros(1, **f),
+                     loss=torch.zeros(Rc, **f),       # per ray (summed when the loss is read)
                      ctl=torch.tensor([self.step, min(self.rays_per_batch, Rc), self.seed & 0x7FFFFFFF, max(self.n_images, 1),
                                        fbits(1.0 - c.beta1 ** (self.step + 1)), fbits(1.0 - c.beta2 ** (self.step + 1)), 0, 0], **i32))
             self.sets.append(t)
@@ -349,11 +349,12 @@ class NgpNerf:
         ctl = ptr(X["ctl"])
         main = torch.cuda.current_stream()
         # (under capture the ORDER of these calls decides which hardware queue a branch gets: with the forward pass enqueued
-        #  before this branch, the executor put the branch behind side2's kernels on one queue and the step took 0.58 ms)
+        #  before this branch, the executor put the branch behind side2's kernels on one queue and the step took 0.58 ms; the
+        #  same swap in the second step of a paired graph only: 0.43 -> 0.50 ms)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             check(L.ns_ngp_step_prepare(ptr(X["ctl"]), ptr(Y["ctl"]), ptr(X["counter"]), ptr(Y["counter"]), ptr(self.last),
-                                        C.c_float(0.9), C.c_long(S), 256, Rc, C.c_float(c.beta1), C.c_float(c.beta2), ptr(Y["loss"]),
+                                        C.c_float(0.9), C.c_long(S), 256, Rc, C.c_float(c.beta1), C.c_float(c.beta2), None,
                                         stream_ptr()), "ngp_step_prepare")
             self._enqueue_rays(Y)
         # sample count of THIS step = end of the marcher's reserved ranges (device memory): the per-sample kernels are launched
@@ -385,10 +386,10 @@ class NgpNerf:
         else:
             check(L.ns_ngp_mlp_forward_m_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out),
                                            *[ptr(a) for a in acts], ptr(self.relu_masks), C.c_long(S), n_dev, st), "ngp_mlp_forward")
-        check(L.ns_ngp_composite_ctl(ptr(self.s_out), ptr(X["s_dt"]), ptr(X["s_t"]), ptr(X["ray_start"]), ptr(X["ray_n"]), Rc,
-                                     ptr(X["r_rgb"]), ptr(X["r_depth"]), ptr(X["r_cov"]), C.c_float(c.depth_lambda),
-                                     C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), ptr(X["loss"]),
-                                     ptr(X["s_dout"]), ctl, st), "ngp_composite")
+        check(L.ns_ngp_composite_rays(ptr(self.s_out), ptr(X["s_dt"]), ptr(X["s_t"]), ptr(X["ray_start"]), ptr(X["ray_n"]), Rc,
+                                      ptr(X["r_rgb"]), ptr(X["r_depth"]), ptr(X["r_cov"]), C.c_float(c.depth_lambda),
+                                      C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), None, ptr(X["loss"]),
+                                      ptr(X["s_dout"]), ctl, st), "ngp_composite")
         if mlp_mode != "r3a" and getattr(self, "partial_fused", None) is None:
             self.partial_fused = torch.zeros((self.mlp_wgs, MLP_TOTAL), dtype=torch.float32, device=dev)
             self.mlp_frags = torch.zeros(int(L.ns_ngp_mlp_fragment_table_bytes()) // 2, dtype=torch.float16, device=dev)
@@ -626,9 +627,9 @@ class NgpNerf:
 
     @property
     def loss_tensor(self):
-        """mean per-ray loss of the last step (device scalar): loss sum over the step's rays (accumulated in its set) / their
+        """mean per-ray loss of the last step (device scalar): sum of the per-ray losses the step left in its set / their
         number (recorded by ns_ngp_step_prepare at the start of that step)"""
-        return self.sets[1 - self.cur]["loss"] / self.last[3].clamp(min=1).float()
+        return self.sets[1 - self.cur]["loss"].sum(dim=0, keepdim=True) / self.last[3].clamp(min=1).float()
 
     @property
     def last_samples(self):
