@@ -301,8 +301,9 @@ int ns_ngp_encode_forward(int n_levels, int n_features, int log2_hashmap, int ba
  * unit_major = 1).  No global atomics on table entries (csrc/ngp.hip: on this 8-XCD part they execute at the memory side):
  *   workspace == NULL   owner-computes kernel on every level: a workgroup owns a 16384-entry table slice in LDS and scans
  *                       all samples of the level for corners that fall into it;
- *   workspace != NULL   (ns_ngp_encode_backward_workspace_bytes(..., max_samples >= N) bytes, zero-filled once by the
- *                       caller; packed fixed-point mode only) the hashed levels are BINNED instead -- count / scatter /
+ *   workspace != NULL   (workspace_bytes >= ns_ngp_encode_backward_workspace_bytes(..., max_samples >= N), zero-filled once
+ *                       by the caller; packed fixed-point mode only; a SMALLER buffer is never written: the call then
+ *                       takes the owner-computes kernels) the hashed levels are BINNED instead -- count / scatter /
  *                       accumulate passes over 64-bit (slice index, 2 x 25-bit Q(S) gradient) records, 8 B written + 8 B read
  *                       per (sample, corner); the dense coarse levels keep the owner-computes kernel.
  * All three paths (NS_ENC_BWD_ATOMIC=1 selects round 1's atomic scatter) produce the same integer sums bit for bit.
@@ -314,7 +315,7 @@ long ns_ngp_encode_backward_workspace_bytes(int n_levels, int n_features, int lo
                                             float per_level_scale, long max_samples);
 int ns_ngp_encode_backward(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
                            const float* positions, const void* dLdout, int unit_major, float* grad_params,
-                           float* workspace, float fixed_scale, long N, void* stream);
+                           float* workspace, size_t workspace_bytes, float fixed_scale, long N, void* stream);
 
 /* density MLP 32->64->16 + colour MLP (16 + SH16)->64->64->16, f16 weights packed row-major
  * [W1 64x32 | W2 16x64 | W3 64x32 | W4 64x64 | W5 16x64]; featT [32,N] f16 UNIT-MAJOR (what
@@ -516,7 +517,7 @@ int ns_ngp_encode_forward_n(int n_levels, int n_features, int log2_hashmap, int 
                             void* stream);
 int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
                              const float* positions, const void* dLdout, int unit_major, float* grad_params, float* workspace,
-                             float fixed_scale, long N, const int* n_dev, void* stream);
+                             size_t workspace_bytes, float fixed_scale, long N, const int* n_dev, void* stream);
 int ns_ngp_encode_backward_input_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
                                    const float* positions, const void* params, const void* dLdoutT, float* dLdpos, long N,
                                    const int* n_dev, void* stream);

@@ -2196,17 +2196,20 @@ extern "C" long ns_ngp_encode_backward_workspace_bytes(int n_levels, int n_featu
 
 extern "C" int ns_ngp_encode_backward(int n_levels, int n_features, int log2_hashmap, int base_res,
                                       float per_level_scale, const float* positions, const void* dLdout,
-                                      int unit_major, float* grad_params, float* workspace, float fixed_scale, long N,
-                                      void* stream) {
+                                      int unit_major, float* grad_params, float* workspace, size_t workspace_bytes,
+                                      float fixed_scale, long N, void* stream) {
   return ns_ngp_encode_backward_n(n_levels, n_features, log2_hashmap, base_res, per_level_scale, positions, dLdout, unit_major,
-                                  grad_params, workspace, fixed_scale, N, nullptr, stream);
+                                  grad_params, workspace, workspace_bytes, fixed_scale, N, nullptr, stream);
 }
 
 extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_hashmap, int base_res,
                                       float per_level_scale, const float* positions, const void* dLdout,
-                                      int unit_major, float* grad_params, float* workspace, float fixed_scale, long N,
-                                      const int* n_dev, void* stream) {
+                                      int unit_major, float* grad_params, float* workspace, size_t workspace_bytes,
+                                      float fixed_scale, long N, const int* n_dev, void* stream) {
   NS_REQUIRE(positions && dLdout && grad_params, "ns_ngp_encode_backward: null pointer");
+  // (the workspace layout follows from THIS call's N; a buffer sized for fewer samples must not be written past
+  //  its end -- such a call takes the owner-computes kernels, which need no workspace)
+  if (workspace == nullptr) workspace_bytes = 0;
   GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
   GridLayout g;
   if (grid_layout_host(c, g) != NS_OK) {
@@ -2219,7 +2222,8 @@ extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_h
     static const bool no_bins = getenv("NS_ENC_BWD_NO_BINS") != nullptr;   // A/B switch: owner-computes kernel on every level
     BinPlan bp;
     bin_plan_host(g, n_levels, N, bp);
-    const bool binned = workspace != nullptr && fixed_scale > 0.0f && bin_plan_ok(bp) && !no_bins;
+    const bool binned = workspace != nullptr && fixed_scale > 0.0f && bin_plan_ok(bp) && !no_bins &&
+                        workspace_bytes >= bin_ws_bytes(bp, g, n_levels);
     EncBwdPlan plan;
     // run-length kernel for the dense levels (NS_ENC_BWD_NO_RL=1: the one-sample-per-lane kernel, A/B runs); fewer, longer
     // parts: its tasks are bound by the scan of the samples, not by LDS atomics (NS_ENC_RL_PARTS=coarse,multi overrides)
@@ -2289,6 +2293,7 @@ extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_h
   }
   ReplicaPlan rp;
   replica_plan_host(g, n_levels, rp);
+  if (workspace_bytes < rp.total_floats * sizeof(float)) workspace = nullptr;   // (then: global atomics on every level)
   hipLaunchKernelGGL(ngp_encode_bwd_kernel, dim3(ns_cdiv(N, 256), n_levels), dim3(256), 0, (hipStream_t)stream, g,
                      positions, (const h2_t*)dLdout, grad_params, N, n_levels, 0, rp, workspace, unit_major, fixed_scale);
   NS_CHECK_LAUNCH("ngp_encode_bwd_kernel");

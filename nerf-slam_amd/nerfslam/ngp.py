@@ -483,7 +483,8 @@ class NgpNerf:
                 table_gradient(2, st)
             else:
                 check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
-                                                 ptr(self.enc_ws), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev, st),
+                                                 ptr(self.enc_ws), C.c_size_t(self.enc_ws_bytes), C.c_float(c.grad_fixed_scale),
+                                                 C.c_long(S), n_dev, st),
                       "ngp_encode_backward")
         if not gather_pose:
             hashed_levels()

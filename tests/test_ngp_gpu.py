@@ -53,23 +53,23 @@ def test_hash_encode_forward_backward(oracle_mod, dev, which):
     dL[rng.uniform(size=N) < 0.3] = 0
     grad = torch.zeros(n_par, dtype=torch.float32, device=dev)
     d_dL = T(dL, dev)
-    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dL), 0, ptr(grad), None, C.c_float(0), C.c_long(N), stream_ptr()), "bwd")
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dL), 0, ptr(grad), None, C.c_size_t(0), C.c_float(0), C.c_long(N), stream_ptr()), "bwd")
     # unit-major gradient rows (the trainer's layout), workspace argument accepted (unused by the owner-computes kernel)
     ws = torch.zeros(max(lib().ns_ngp_encode_backward_workspace_bytes(*args, C.c_long(N)) // 4, 1), device=dev)
     grad_ws = torch.zeros_like(grad)
     d_dLT = d_dL.t().contiguous()
-    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(grad_ws), ptr(ws), C.c_float(0), C.c_long(N), stream_ptr()), "bwd")
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(grad_ws), ptr(ws), C.c_size_t(ws.numel() * ws.element_size()), C.c_float(0), C.c_long(N), stream_ptr()), "bwd")
     assert not ws.any()
     assert (grad_ws - grad).abs().max().item() <= 1e-5 * grad.abs().max().item()
     # += semantics: a second call on top of the first doubles the gradient
-    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(grad_ws), ptr(ws), C.c_float(0), C.c_long(N), stream_ptr()), "bwd")
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(grad_ws), ptr(ws), C.c_size_t(ws.numel() * ws.element_size()), C.c_float(0), C.c_long(N), stream_ptr()), "bwd")
     assert (grad_ws - 2 * grad).abs().max().item() <= 2e-5 * grad.abs().max().item()
     # packed fixed-point accumulation (Q18 pairs in one 64-bit word): order-independent -> two runs agree bit for bit
     S = 262144.0
     packed = []
     for _ in range(2):
         gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
-        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(gq), ptr(ws), C.c_float(S), C.c_long(N),
+        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(gq), ptr(ws), C.c_size_t(ws.numel() * ws.element_size()), C.c_float(S), C.c_long(N),
                                            stream_ptr()), "bwd")
         packed.append(gq.cpu().numpy())
     w = packed[0]
@@ -674,15 +674,21 @@ def test_hash_encode_backward_full_budget_properties(oracle_mod, dev):
     runs = []
     for _ in range(2):
         gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
-        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(gq), None, C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
+        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(gq), None, C.c_size_t(0), C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
         runs.append(gq.cpu().numpy())
     assert np.array_equal(runs[0], runs[1])
     # the binned path (workspace given) == the owner-computes path (no workspace), bit for bit, and reproducible
     ws = torch.zeros(lib().ns_ngp_encode_backward_workspace_bytes(*args, C.c_long(N)) // 4 + 1, device=dev)
     for _ in range(2):
         gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
-        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(gq), ptr(ws), C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
+        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(gq), ptr(ws), C.c_size_t(ws.numel() * ws.element_size()), C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
         assert np.array_equal(gq.cpu().numpy(), runs[0])
+    # a workspace that is too small for this N is never written: the call takes the owner-computes kernels
+    before = ws.clone()
+    gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(gq), ptr(ws), C.c_size_t(ws.numel() * ws.element_size() // 3),
+                                       C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
+    assert np.array_equal(gq.cpu().numpy(), runs[0]) and torch.equal(ws, before)
     # ... also for a sample count that is not a multiple of the 1024-sample tiles, and for the non-unit-major layout
     n_odd = 100003
     sub_T = T(np.ascontiguousarray(dLT[:, :n_odd]), dev)
@@ -690,7 +696,7 @@ def test_hash_encode_backward_full_budget_properties(oracle_mod, dev):
     outs = []
     for (dl, um, w) in ((sub_T, 1, None), (sub_T, 1, ws), (sub_N, 0, ws)):
         gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
-        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(dl), um, ptr(gq), ptr(w), C.c_float(S), C.c_long(n_odd), stream_ptr()), "bwd")
+        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(dl), um, ptr(gq), ptr(w), C.c_size_t(0 if w is None else w.numel() * w.element_size()), C.c_float(S), C.c_long(n_odd), stream_ptr()), "bwd")
         outs.append(gq.cpu().numpy())
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     # ... and for the training step's form: the full-budget buffers with the sample count in device memory (the tail of the
@@ -702,7 +708,7 @@ def test_hash_encode_backward_full_budget_properties(oracle_mod, dev):
     outs_n = []
     for w in (None, ws):
         gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
-        check(lib().ns_ngp_encode_backward_n(*args, ptr(d_pos), ptr(d_poison), 1, ptr(gq), ptr(w), C.c_float(S), C.c_long(N), ptr(n_dev),
+        check(lib().ns_ngp_encode_backward_n(*args, ptr(d_pos), ptr(d_poison), 1, ptr(gq), ptr(w), C.c_size_t(w.numel() * w.element_size()), C.c_float(S), C.c_long(N), ptr(n_dev),
                                              stream_ptr()), "bwd_n")
         outs_n.append(gq.cpu().numpy())
     assert np.array_equal(outs_n[0], outs[0]) and np.array_equal(outs_n[1], outs[0])
@@ -717,7 +723,7 @@ def test_hash_encode_backward_full_budget_properties(oracle_mod, dev):
     n = 20000
     gf = torch.zeros(n_par, dtype=torch.float32, device=dev)
     sub = T(np.ascontiguousarray(dLT[:, :n]), dev)
-    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(sub), 1, ptr(gf), None, C.c_float(0), C.c_long(n), stream_ptr()), "bwd")
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(sub), 1, ptr(gf), None, C.c_size_t(0), C.c_float(0), C.c_long(n), stream_ptr()), "bwd")
     gref = oracle_mod.ngp_encode_bwd(cfg, pos[:n], np.ascontiguousarray(dLT[:, :n].T), n_par)
     assert np.abs(gf.cpu().numpy() - gref).max() <= 2e-5 * np.abs(gref).max()
 
@@ -800,7 +806,7 @@ def test_hash_encode_survives_positions_outside_the_unit_cube(dev):
         check(lib().ns_ngp_encode_backward_input_n(*args, ptr(pos), ptr(net.grid_half), ptr(dfe), ptr(dpos), C.c_long(N), None,
                                                    stream_ptr()), "bwd_input")
         for w in (None, ws):
-            check(lib().ns_ngp_encode_backward(*args, ptr(pos), ptr(dfe), 1, ptr(gq), ptr(w), C.c_float(262144.0), C.c_long(N),
+            check(lib().ns_ngp_encode_backward(*args, ptr(pos), ptr(dfe), 1, ptr(gq), ptr(w), C.c_size_t(w.numel() * w.element_size()), C.c_float(262144.0), C.c_long(N),
                                                stream_ptr()), "bwd")
         torch.cuda.synchronize()
     ok = torch.isfinite(pos).all(-1) & (pos.abs() < 1e6).all(-1)
@@ -850,7 +856,7 @@ def test_fused_table_gradient_matches_the_other_paths(oracle_mod, dev, clustered
     S = 262144.0
     nul = C.c_void_p(0)
     ref = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
-    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(ref), None, C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(ref), None, C.c_size_t(0), C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
 
     def fused(n_dev=None, dl=d_dLT):
         gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
@@ -872,7 +878,7 @@ def test_fused_table_gradient_matches_the_other_paths(oracle_mod, dev, clustered
     n_odd = 100003 if not clustered else 33331
     ref_n = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
     sub = T(np.ascontiguousarray(dLT[:, :n_odd]), dev)
-    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(sub), 1, ptr(ref_n), None, C.c_float(S), C.c_long(n_odd), stream_ptr()), "bwd")
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(sub), 1, ptr(ref_n), None, C.c_size_t(0), C.c_float(S), C.c_long(n_odd), stream_ptr()), "bwd")
     poisoned = dLT.copy(); poisoned[:, n_odd:] = np.float16(3.0)
     nd = torch.tensor([n_odd], dtype=torch.int32, device=dev)
     assert torch.equal(fused(nd, T(poisoned, dev)), ref_n)
@@ -904,7 +910,7 @@ def test_fused_table_gradient_adam_is_bit_identical(oracle_mod, dev):
         d_dl = T(dl, dev)
         a = st["two_pass"]
         gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
-        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dl), 1, ptr(gq), None, C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
+        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dl), 1, ptr(gq), None, C.c_size_t(0), C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
         touched = int((gq != 0).sum())
         check(lib().ns_ngp_adam(ptr(a["master"]), ptr(a["hp"]), ptr(gq), ptr(a["m1"]), ptr(a["m2"]), C.c_long(n_par), step, C.c_float(lr),
                                 C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(0.0), C.c_float(gs), C.c_float(S), stream_ptr()),

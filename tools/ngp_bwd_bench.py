@@ -53,7 +53,7 @@ def main():
     ws_new = torch.zeros(wsb // 8 + 1, dtype=torch.int64, device=dev)
 
     def old_grad():
-        check(lib().ns_ngp_encode_backward(*args, ptr(pos), ptr(dfeat), 1, ptr(grad), ptr(ws_old), C.c_float(S), C.c_long(N), stream_ptr()), "old")
+        check(lib().ns_ngp_encode_backward(*args, ptr(pos), ptr(dfeat), 1, ptr(grad), ptr(ws_old), C.c_size_t(ws_old.numel() * ws_old.element_size()), C.c_float(S), C.c_long(N), stream_ptr()), "old")
 
     def adam():
         check(lib().ns_ngp_adam(ptr(st["master"]), ptr(hp), ptr(grad), ptr(st["m1"]), ptr(st["m2"]), C.c_long(n_par), 7, C.c_float(c.lr),
