@@ -1212,7 +1212,9 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
       uint32_t idx[8];
       fb_indices(run[r].c, hs, idx);
 #pragma unroll
-      for (int corner = 0; corner < 8; corner++) rank[r][corner] = atomicAdd(&lcnt[idx[corner] >> NS_FB_SHIFT], 1);
+      for (int corner = 0; corner < 8; corner++)   // (a contribution that rounds to zero in both fields is not a record: most
+        rank[r][corner] = (run[r].a[corner] | run[r].b[corner]) != 0   //  corners of a converged scene's tiny gradients)
+                              ? atomicAdd(&lcnt[idx[corner] >> NS_FB_SHIFT], 1) : -1;
     }
   }
   __syncthreads();
@@ -1237,10 +1239,11 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
       fb_indices(run[r].c, hs, idx);
 #pragma unroll
       for (int corner = 0; corner < 8; corner++)
-        rec[lbase[idx[corner] >> NS_FB_SHIFT] + rank[r][corner]] =
-            ((unsigned long long)(idx[corner] & (NS_FB_SLICE - 1u)) << 50) |
-            ((unsigned long long)((uint32_t)run[r].b[corner] & 0x1ffffffu) << 25) |
-            (unsigned long long)((uint32_t)run[r].a[corner] & 0x1ffffffu);
+        if (rank[r][corner] >= 0)
+          rec[lbase[idx[corner] >> NS_FB_SHIFT] + rank[r][corner]] =
+              ((unsigned long long)(idx[corner] & (NS_FB_SLICE - 1u)) << 50) |
+              ((unsigned long long)((uint32_t)run[r].b[corner] & 0x1ffffffu) << 25) |
+              (unsigned long long)((uint32_t)run[r].a[corner] & 0x1ffffffu);
     }
   }
   __syncthreads();

@@ -688,7 +688,7 @@ def test_hash_encode_backward_full_budget_properties(oracle_mod, dev):
     gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
     check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dLT), 1, ptr(gq), ptr(ws), C.c_size_t(ws.numel() * ws.element_size() // 3),
                                        C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
-    assert np.array_equal(gq.cpu().numpy(), runs[0]) and torch.equal(ws, before)
+    assert np.array_equal(gq.cpu().numpy(), runs[0]) and torch.equal(ws.view(torch.int32), before.view(torch.int32))
     # ... also for a sample count that is not a multiple of the 1024-sample tiles, and for the non-unit-major layout
     n_odd = 100003
     sub_T = T(np.ascontiguousarray(dLT[:, :n_odd]), dev)
@@ -708,7 +708,7 @@ def test_hash_encode_backward_full_budget_properties(oracle_mod, dev):
     outs_n = []
     for w in (None, ws):
         gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
-        check(lib().ns_ngp_encode_backward_n(*args, ptr(d_pos), ptr(d_poison), 1, ptr(gq), ptr(w), C.c_size_t(w.numel() * w.element_size()), C.c_float(S), C.c_long(N), ptr(n_dev),
+        check(lib().ns_ngp_encode_backward_n(*args, ptr(d_pos), ptr(d_poison), 1, ptr(gq), ptr(w), C.c_size_t(0 if w is None else w.numel() * w.element_size()), C.c_float(S), C.c_long(N), ptr(n_dev),
                                              stream_ptr()), "bwd_n")
         outs_n.append(gq.cpu().numpy())
     assert np.array_equal(outs_n[0], outs[0]) and np.array_equal(outs_n[1], outs[0])
@@ -806,7 +806,7 @@ def test_hash_encode_survives_positions_outside_the_unit_cube(dev):
         check(lib().ns_ngp_encode_backward_input_n(*args, ptr(pos), ptr(net.grid_half), ptr(dfe), ptr(dpos), C.c_long(N), None,
                                                    stream_ptr()), "bwd_input")
         for w in (None, ws):
-            check(lib().ns_ngp_encode_backward(*args, ptr(pos), ptr(dfe), 1, ptr(gq), ptr(w), C.c_size_t(w.numel() * w.element_size()), C.c_float(262144.0), C.c_long(N),
+            check(lib().ns_ngp_encode_backward(*args, ptr(pos), ptr(dfe), 1, ptr(gq), ptr(w), C.c_size_t(0 if w is None else w.numel() * w.element_size()), C.c_float(262144.0), C.c_long(N),
                                                stream_ptr()), "bwd")
         torch.cuda.synchronize()
     ok = torch.isfinite(pos).all(-1) & (pos.abs() < 1e6).all(-1)
