@@ -674,6 +674,11 @@ def main():
                 if k in tr:
                     e = out["roofline"] if k == dom else out["roofline"]["other"][k]
                     e["traffic"] = tr[k].get("traffic_bytes")
+                    if e["traffic"] and e.get("bound") == "hbm":
+                        # what the north star's ">= 60 % HBM-bandwidth utilisation (rocprof)" clause reads: bytes the memory
+                        # system actually moved per launch / launch time / peak -- next to `frac`, which prices only the
+                        # ALGORITHMIC bytes (traffic / algorithmic = the re-read factor)
+                        e["hbm_utilisation"] = e["traffic"] / (e["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
                     for kk in ("rocprof_avg_launch_us", "in_pipeline_avg_us", "l2_hit_rate", "traffic_by_kernel"):
                         if kk in tr[k]:
                             e[kk] = tr[k][kk]

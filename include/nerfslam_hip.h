@@ -579,6 +579,13 @@ int ns_ngp_mlp_backward_fused_n(const void* weights, const void* featT, const fl
  * that runs on a side stream NEXT TO the table gradient.  frags: ns_ngp_mlp_fragment_table_bytes() bytes, written by
  * ns_ngp_mlp_pack_fragments from the current f16 weights (once per optimiser step).                                        */
 size_t ns_ngp_mlp_fragment_table_bytes(void);
+/* forward pass / activation backward of the split form with the weights taken from the fragment table (no activation buffers,
+ * bit masks only; dLdfeatT only): bit-identical to ns_ngp_mlp_forward_m_n / ns_ngp_mlp_dgrad_m_n, without the per-workgroup
+ * element-wise gather of 24 / 20 weight fragments                                                                            */
+int ns_ngp_mlp_forward_f_n(const void* frags, const void* featT, const float* dirs, void* out, void* relu_masks, long N,
+                           const int* n_dev, void* stream);
+int ns_ngp_mlp_dgrad_f_n(const void* frags, const void* dLdout, const void* relu_masks, void* dLdfeatT, long N, const int* n_dev,
+                         void* stream);
 int ns_ngp_mlp_pack_fragments(const void* weights, void* frags, void* stream);
 int ns_ngp_mlp_wgrad_recompute_n(const void* frags, const void* featT, const float* dirs, const void* dLdout, float* partial_ws,
                                  int wgs, float* grad_weights, long N, const int* n_dev, void* stream);

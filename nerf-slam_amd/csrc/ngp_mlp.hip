@@ -157,6 +157,8 @@ struct MlpFwdArgs {
   long N;
   const int* n_dev;       // optional: device sample count (<= N); N stays the row stride of the unit-major tensors
   uint32_t* masks;        // optional [3 layers (h1, h3, h4)][2 lane halves][N]: ReLU bit masks for the backward pass (see below)
+  const f16x8* frags;     // optional: ngp_mlp_pack_frags_kernel's table (then W is not read: 6 16-byte loads per thread instead
+                          // of 48 element gathers with their index arithmetic, per workgroup)
 };
 
 // ReLU masks.  The backward pass needs, per hidden unit, only whether the forward activation was positive; re-reading the f16
@@ -188,11 +190,16 @@ __device__ __forceinline__ long ngp_count(long N, const int* n_dev) {
 
 __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
   __shared__ f16x8 Wf[FW_NFRAG * 64];
-  fill_frags<false>(Wf, a.W, W1_OFF, 64, 32, FW_L1);
-  fill_frags<false>(Wf, a.W, W2_OFF, 16, 64, FW_L2);
-  fill_frags<false>(Wf, a.W, W3_OFF, 64, 32, FW_L3);
-  fill_frags<false>(Wf, a.W, W4_OFF, 64, 64, FW_L4);
-  fill_frags<false>(Wf, a.W, W5_OFF, 16, 64, FW_L5);
+  if (a.frags != nullptr) {      // (workgroup-uniform)
+#pragma unroll
+    for (int e = threadIdx.x; e < FW_NFRAG * 64; e += 256) Wf[e] = a.frags[e];
+  } else {
+    fill_frags<false>(Wf, a.W, W1_OFF, 64, 32, FW_L1);
+    fill_frags<false>(Wf, a.W, W2_OFF, 16, 64, FW_L2);
+    fill_frags<false>(Wf, a.W, W3_OFF, 64, 32, FW_L3);
+    fill_frags<false>(Wf, a.W, W4_OFF, 64, 64, FW_L4);
+    fill_frags<false>(Wf, a.W, W5_OFF, 16, 64, FW_L5);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   const long N = a.N, cnt = ngp_count(a.N, a.n_dev);
@@ -297,6 +304,7 @@ struct MlpBwdArgs {
   long N;
   const int* n_dev;
   const uint32_t* masks;  // optional: the forward pass's ReLU bit masks (then h1T / h3T / h4T are not read)
+  const f16x8* frags;     // optional: packed fragment table (see MlpFwdArgs)
 };
 
 // dy = relu'(h) * f16(acc) for one 32-unit tile of both sample tiles; returns the B chunks and stores unit-major
@@ -332,11 +340,16 @@ __device__ __forceinline__ void mask_tile_bits(const f32x16& acc0, const f32x16&
 template <bool BITS>
 __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
   __shared__ f16x8 Wf[BW_NFRAG * 64];
-  fill_frags<true>(Wf, a.W, W5_OFF, 16, 64, BW_L5);
-  fill_frags<true>(Wf, a.W, W4_OFF, 64, 64, BW_L4);
-  fill_frags<true>(Wf, a.W, W3_OFF, 64, 32, BW_L3);
-  fill_frags<true>(Wf, a.W, W2_OFF, 16, 64, BW_L2);
-  fill_frags<true>(Wf, a.W, W1_OFF, 64, 32, BW_L1);
+  if (a.frags != nullptr) {      // (workgroup-uniform)
+#pragma unroll
+    for (int e = threadIdx.x; e < BW_NFRAG * 64; e += 256) Wf[e] = a.frags[FW_NFRAG * 64 + e];
+  } else {
+    fill_frags<true>(Wf, a.W, W5_OFF, 16, 64, BW_L5);
+    fill_frags<true>(Wf, a.W, W4_OFF, 64, 64, BW_L4);
+    fill_frags<true>(Wf, a.W, W3_OFF, 64, 32, BW_L3);
+    fill_frags<true>(Wf, a.W, W2_OFF, 16, 64, BW_L2);
+    fill_frags<true>(Wf, a.W, W1_OFF, 64, 32, BW_L1);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   const long N = a.N, cnt = ngp_count(a.N, a.n_dev);
@@ -789,7 +802,21 @@ extern "C" int ns_ngp_mlp_forward_m_n(const void* weights, const void* featT, co
   NS_REQUIRE(N % 2 == 0, "ns_ngp_mlp_forward: N must be even (a lane owns two adjacent samples)");
   if (N <= 0) return NS_OK;
   MlpFwdArgs a{(const _Float16*)weights, (const _Float16*)featT, dirs, (_Float16*)out, (_Float16*)h1T,
-               (_Float16*)cinT, (_Float16*)h3T, (_Float16*)h4T, N, n_dev, (uint32_t*)relu_masks};
+               (_Float16*)cinT, (_Float16*)h3T, (_Float16*)h4T, N, n_dev, (uint32_t*)relu_masks, nullptr};
+  hipLaunchKernelGGL(ngp_mlp_fwd_kernel, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, (hipStream_t)stream, a);
+  NS_CHECK_LAUNCH("ngp_mlp_fwd_kernel");
+  return NS_OK;
+}
+
+// The trainer's forward pass (split form): no activation buffers, ReLU bit masks only, weights taken from the packed fragment
+// table (ns_ngp_mlp_pack_fragments, once per optimiser step) -- same MFMA sequence, same outputs bit for bit.
+extern "C" int ns_ngp_mlp_forward_f_n(const void* frags, const void* featT, const float* dirs, void* out, void* relu_masks, long N,
+                                      const int* n_dev, void* stream) {
+  NS_REQUIRE(frags && featT && dirs && out, "ns_ngp_mlp_forward_f: null pointer");
+  NS_REQUIRE(N % 2 == 0, "ns_ngp_mlp_forward_f: N must be even (a lane owns two adjacent samples)");
+  if (N <= 0) return NS_OK;
+  MlpFwdArgs a{nullptr, (const _Float16*)featT, dirs, (_Float16*)out, nullptr, nullptr, nullptr, nullptr, N, n_dev,
+               (uint32_t*)relu_masks, (const f16x8*)frags};
   hipLaunchKernelGGL(ngp_mlp_fwd_kernel, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, (hipStream_t)stream, a);
   NS_CHECK_LAUNCH("ngp_mlp_fwd_kernel");
   return NS_OK;
@@ -805,11 +832,11 @@ extern "C" int ns_ngp_mlp_backward(const void* weights, const void* dLdout, cons
 
 static int mlp_dgrad_launch(const void* weights, const void* dLdout, const void* h1T, const void* h3T, const void* h4T,
                             void* dLdfeatT, void* d5T, void* d4T, void* d3T, void* ddT, void* d1T, long N, const int* n_dev,
-                            hipStream_t st, const void* relu_masks = nullptr) {
+                            hipStream_t st, const void* relu_masks = nullptr, const void* frags = nullptr) {
   MlpBwdArgs b{(const _Float16*)weights, (const _Float16*)dLdout, (const _Float16*)h1T, (const _Float16*)h3T,
                (const _Float16*)h4T,     (_Float16*)dLdfeatT,     (_Float16*)d5T,       (_Float16*)d4T,
                (_Float16*)d3T,           (_Float16*)ddT,          (_Float16*)d1T,       N,
-               n_dev,                    (const uint32_t*)relu_masks};
+               n_dev,                    (const uint32_t*)relu_masks, (const f16x8*)frags};
   if (relu_masks != nullptr)
     hipLaunchKernelGGL(ngp_mlp_bwd_kernel<true>, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, st, b);
   else
@@ -877,6 +904,17 @@ extern "C" int ns_ngp_mlp_dgrad_m_n(const void* weights, const void* dLdout, con
   if (N <= 0) return NS_OK;
   return mlp_dgrad_launch(weights, dLdout, nullptr, nullptr, nullptr, dLdfeatT, d5T, d4T, d3T, ddT, d1T, N, n_dev, (hipStream_t)stream,
                           relu_masks);
+}
+
+// the trainer's activation backward (split form): dL/dfeature only, ReLU derivatives from the bit masks, transposed weight
+// fragments from the packed table
+extern "C" int ns_ngp_mlp_dgrad_f_n(const void* frags, const void* dLdout, const void* relu_masks, void* dLdfeatT, long N,
+                                    const int* n_dev, void* stream) {
+  NS_REQUIRE(frags && dLdout && relu_masks && dLdfeatT, "ns_ngp_mlp_dgrad_f: null pointer");
+  NS_REQUIRE(N % 8 == 0, "ns_ngp_mlp_dgrad_f: N must be a multiple of 8");
+  if (N <= 0) return NS_OK;
+  return mlp_dgrad_launch(nullptr, dLdout, nullptr, nullptr, nullptr, dLdfeatT, nullptr, nullptr, nullptr, nullptr, nullptr, N, n_dev,
+                          (hipStream_t)stream, relu_masks, frags);
 }
 
 // ---------------------------------------------------------------------------------------------

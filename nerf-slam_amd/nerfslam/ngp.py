@@ -377,12 +377,17 @@ class NgpNerf:
         # everything in one kernel on this stream (NS_NGP_MLP=fused); "r3a" = round 3's first form, separate weight-gradient kernel
         # over stored activations / gradients (NS_NGP_MLP=r3a)
         mlp_mode = os.environ.get("NS_NGP_MLP", "split")
+        if mlp_mode != "r3a" and getattr(self, "partial_fused", None) is None:     # (first step after construction: eager)
+            self.partial_fused = torch.zeros((self.mlp_wgs, MLP_TOTAL), dtype=torch.float32, device=dev)
+            self.mlp_frags = torch.zeros(int(L.ns_ngp_mlp_fragment_table_bytes()) // 2, dtype=torch.float16, device=dev)
+            # the weights in MFMA operand order (forward + transposed fragments): packed here once, then after every MLP Adam
+            check(L.ns_ngp_mlp_pack_fragments(ptr(self.mlp_half), ptr(self.mlp_frags), st), "ngp_mlp_pack_fragments")
         if mlp_mode == "fused":
             check(L.ns_ngp_mlp_forward_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), None, None, None, None,
                                          C.c_long(S), n_dev, st), "ngp_mlp_forward")
         elif mlp_mode == "split":
-            check(L.ns_ngp_mlp_forward_m_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), None, None, None, None,
-                                           ptr(self.relu_masks), C.c_long(S), n_dev, st), "ngp_mlp_forward")
+            check(L.ns_ngp_mlp_forward_f_n(ptr(self.mlp_frags), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), ptr(self.relu_masks),
+                                           C.c_long(S), n_dev, st), "ngp_mlp_forward")
         else:
             check(L.ns_ngp_mlp_forward_m_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out),
                                            *[ptr(a) for a in acts], ptr(self.relu_masks), C.c_long(S), n_dev, st), "ngp_mlp_forward")
@@ -390,9 +395,6 @@ class NgpNerf:
                                       ptr(X["r_rgb"]), ptr(X["r_depth"]), ptr(X["r_cov"]), C.c_float(c.depth_lambda),
                                       C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), None, ptr(X["loss"]),
                                       ptr(X["s_dout"]), ctl, st), "ngp_composite")
-        if mlp_mode != "r3a" and getattr(self, "partial_fused", None) is None:
-            self.partial_fused = torch.zeros((self.mlp_wgs, MLP_TOTAL), dtype=torch.float32, device=dev)
-            self.mlp_frags = torch.zeros(int(L.ns_ngp_mlp_fragment_table_bytes()) // 2, dtype=torch.float16, device=dev)
         single = self.world == 1
         pose = c.optimize_extrinsics
         gather_pose = pose and jac is None          # A/B form: second gather of the table (reads what Adam rewrites)
@@ -403,6 +405,11 @@ class NgpNerf:
                                     C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps), C.c_float(l2),
                                     C.c_float(c.loss_scale * self.world), C.c_float(fxs), ctl, stream), "ngp_adam")
         mlp = (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0)
+
+        def mlp_adam(stream):
+            adam(*mlp, stream)
+            if mlp_mode != "r3a":   # the fragment table follows the weights (read by the next step's forward / backward kernels)
+                check(L.ns_ngp_mlp_pack_fragments(ptr(self.mlp_half), ptr(self.mlp_frags), stream), "ngp_mlp_pack_fragments")
 
         def camera_step(stream):
             check(L.ns_ngp_camera_step_ctl(ptr(self.c2w), ptr(self.cam_grad), ptr(self.cam_m1), ptr(self.cam_m2),
@@ -451,17 +458,16 @@ class NgpNerf:
         if mlp_mode == "split":
             fork1 = torch.cuda.Event()
             fork1.record(main)
-            check(L.ns_ngp_mlp_dgrad_m_n(ptr(self.mlp_half), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
-                                         None, None, None, None, None, C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
+            check(L.ns_ngp_mlp_dgrad_f_n(ptr(self.mlp_frags), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
+                                         C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
             with torch.cuda.stream(self._side):
                 st1 = stream_ptr()
                 self._side.wait_event(fork1)
-                check(L.ns_ngp_mlp_pack_fragments(ptr(self.mlp_half), ptr(self.mlp_frags), st1), "ngp_mlp_pack_fragments")
                 check(L.ns_ngp_mlp_wgrad_recompute_n(ptr(self.mlp_frags), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]),
                                                      ptr(self.partial_fused), self.mlp_wgs, ptr(self.mlp_grad), C.c_long(S), n_dev, st1),
                       "ngp_mlp_wgrad_recompute")
                 if single:
-                    adam(*mlp, st1)
+                    mlp_adam(st1)
         elif mlp_mode == "fused":
             # (one workgroup of this kernel takes 145 KB of LDS: nothing LDS-using can run next to it, so it sits on this stream)
             check(L.ns_ngp_mlp_backward_fused_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]), ptr(self.s_dfeat),
@@ -505,7 +511,7 @@ class NgpNerf:
                                            ptr(d1T), ptr(self.partial), c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(S), n_dev, st1),
                       "ngp_mlp_wgrad")
             if single and mlp_mode != "split":
-                adam(*mlp, st1)
+                mlp_adam(st1)
             if pose and not gather_pose:
                 pose_gradient(st1)
             if pose and single:
@@ -527,7 +533,7 @@ class NgpNerf:
                 self._gather_parameters()
             else:
                 adam(self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale, st)
-            adam(*mlp, st)
+            mlp_adam(st)
         elif not self.fused_adam:
             adam(self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale, st)
 

@@ -193,6 +193,16 @@ def test_mlp_forward_backward(oracle_mod, dev):
         assert torch.equal(lean[:, :n_valid], ref_feat[:, :n_valid])
         frags = torch.zeros(int(lib().ns_ngp_mlp_fragment_table_bytes()) // 2, dtype=torch.float16, device=dev)
         check(lib().ns_ngp_mlp_pack_fragments(ptr(Wd), ptr(frags), stream_ptr()), "pack")
+        # ... and the same two kernels with their weights taken from that table (what the trainer launches): same bits
+        masks3 = torch.zeros(6 * N, dtype=torch.int32, device=dev)
+        out3 = torch.empty_like(out)
+        check(lib().ns_ngp_mlp_forward_f_n(ptr(frags), ptr(d_featT), ptr(d_dirs), ptr(out3), ptr(masks3), C.c_long(N), ptr(n_dev),
+                                           stream_ptr()), "mlp fwd frags")
+        assert torch.equal(out3[:n_valid], out[:n_valid]) and torch.equal(masks3.view(6, N)[:, :n_valid], masks2.view(6, N)[:, :n_valid])
+        lean3 = torch.zeros_like(dfeat)
+        check(lib().ns_ngp_mlp_dgrad_f_n(ptr(frags), ptr(d_dout), ptr(masks3), ptr(lean3), C.c_long(N), ptr(n_dev), stream_ptr()),
+              "lean dgrad frags")
+        assert torch.equal(lean3[:, :n_valid], ref_feat[:, :n_valid])
         for wgs in (1, 5, 64):
             gw_got = torch.zeros(10240, dtype=torch.float32, device=dev)
             part_f = torch.full((wgs, 10240), float("nan"), dtype=torch.float32, device=dev)
