@@ -43,6 +43,43 @@ __device__ __forceinline__ void sh16(float x, float y, float z, float* o) {
   o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
 }
 
+// The MFMA kernels want, per lane half h, the 8 terms {(q & 3) + 8 (q >> 2) + 4 h}.  Written as `h ? sh[lo + 4] : sh[lo]` over
+// the array above the compiler turned the select into an INDEXED load: the 16 terms went to scratch (or to 16 KB of LDS per
+// workgroup, where the private array could be promoted) and came back with a per-lane offset.  One term by compile-time index
+// instead (the switch folds away after unrolling, the shared products are CSE'd): no array at all.
+__device__ __forceinline__ float sh_term(int k, float x, float y, float z) {
+  switch (k) {
+    case 0: return 0.28209479177387814f;
+    case 1: return -0.48860251190291987f * y;
+    case 2: return 0.48860251190291987f * z;
+    case 3: return -0.48860251190291987f * x;
+    case 4: return 1.0925484305920792f * (x * y);
+    case 5: return -1.0925484305920792f * (y * z);
+    case 6: return 0.94617469575755997f * (z * z) - 0.31539156525251999f;
+    case 7: return -1.0925484305920792f * (x * z);
+    case 8: return 0.54627421529603959f * (x * x) - 0.54627421529603959f * (y * y);
+    case 9: return 0.59004358992664352f * y * (-3.0f * (x * x) + (y * y));
+    case 10: return 2.8906114426405538f * (x * y) * z;
+    case 11: return 0.45704579946446572f * y * (1.0f - 5.0f * (z * z));
+    case 12: return 0.3731763325901154f * z * (5.0f * (z * z) - 3.0f);
+    case 13: return 0.45704579946446572f * x * (1.0f - 5.0f * (z * z));
+    case 14: return 1.4453057213202769f * z * ((x * x) - (y * y));
+    default: return 0.59004358992664352f * x * (-(x * x) + 3.0f * (y * y));
+  }
+}
+typedef _Float16 sh_f16x8 __attribute__((ext_vector_type(8)));
+// chunk 1 of the colour MLP's input for lane half h (element q = SH term (q & 3) + 8 (q >> 2) + 4 h)
+__device__ __forceinline__ sh_f16x8 sh_chunk(float x, float y, float z, int h) {
+  sh_f16x8 c;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int lo = (q & 3) + 8 * (q >> 2);
+    const float a = sh_term(lo, x, y, z), b = sh_term(lo + 4, x, y, z);
+    c[q] = (_Float16)(h ? b : a);
+  }
+  return c;
+}
+
 // ---------------------------------------------------------------------------------------------
 // MFMA register chain.
 //
@@ -243,14 +280,8 @@ __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 8; r++) cin[t][0][r] = (_Float16)acc[r];
       res[t][3] = cin[t][0][0];  // log-density = unit 0 (held by h == 0)
-      float sh[16];
       const long ns = ok ? np + t : 0;
-      sh16(a.dirs[ns * 3], a.dirs[ns * 3 + 1], a.dirs[ns * 3 + 2], sh);
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int lo = (q & 3) + 8 * (q >> 2);  // SH index for h == 0; h == 1 adds 4
-        cin[t][1][q] = (_Float16)(h ? sh[lo + 4] : sh[lo]);
-      }
+      cin[t][1] = sh_chunk(a.dirs[ns * 3], a.dirs[ns * 3 + 1], a.dirs[ns * 3 + 2], h);
     }
     if (st) store_tile(a.cinT, N, boff, 0, cin[0], cin[1]);
     f16x8 h3[2][4];
@@ -705,13 +736,7 @@ __global__ __launch_bounds__(256, 1) void ngp_mlp_bwd_fused_kernel(MlpFusedArgs 
         const f32x16 acc = layer_tile<4>(Wff, FW_L2, 0, lane, h1);
 #pragma unroll
         for (int r = 0; r < 8; r++) cin[0][r] = (_Float16)acc[r];
-        float sh[16];
-        sh16(dir[0], dir[1], dir[2], sh);
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const int lo = (q & 3) + 8 * (q >> 2);
-          cin[1][q] = (_Float16)(h ? sh[lo + 4] : sh[lo]);
-        }
+        cin[1] = sh_chunk(dir[0], dir[1], dir[2], h);
         stage_chunk(stage, FU_XC, cin[0], 0, h, col);
         stage_chunk(stage, FU_XC, cin[1], 1, h, col);
       }
@@ -1018,13 +1043,7 @@ __global__ __launch_bounds__(128, 1) void ngp_mlp_wgrad_recompute_kernel(MlpWgra
         const f32x16 acc = layer_tile<4>(Wff, FW_L2, 0, lane, h1);
 #pragma unroll
         for (int r = 0; r < 8; r++) cin[0][r] = (_Float16)acc[r];
-        float sh[16];
-        sh16(a.dirs[ns * 3], a.dirs[ns * 3 + 1], a.dirs[ns * 3 + 2], sh);
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const int lo = (q & 3) + 8 * (q >> 2);
-          cin[1][q] = (_Float16)(h ? sh[lo + 4] : sh[lo]);
-        }
+        cin[1] = sh_chunk(a.dirs[ns * 3], a.dirs[ns * 3 + 1], a.dirs[ns * 3 + 2], h);
         stage_chunk64(stage, FU_XC, cin[0], 0, h, col);
         stage_chunk64(stage, FU_XC, cin[1], 1, h, col);
       }
