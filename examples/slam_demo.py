@@ -156,8 +156,13 @@ def run(args, return_modules=False, tweak=None):
         fusion.initialize_module()
         worker = spin_in_thread(fusion, dev)
         slam_q.consumer_alive = lambda: worker.is_alive() and getattr(fusion, "error", None) is None
-        while data.spin() and slam.spin() and not fusion.shutdown:
-            pass
+        # the tracker on a stream of its own, too: the legacy default stream synchronises implicitly with every blocking stream,
+        # and the internal streams of the mapper's HIP graphs are blocking ones (bench.py: 97 -> 104 frames/s)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            while data.spin() and slam.spin() and not fusion.shutdown:
+                pass
+            torch.cuda.current_stream().synchronize()
         while worker.is_alive() and not fusion.shutdown:      # the data ran out: let the mapper reach its stop condition
             worker.join(timeout=0.05)
         if getattr(fusion, "error", None) is not None:        # the mapper thread died: surface its exception here
