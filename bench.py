@@ -91,7 +91,7 @@ class Pipeline:
         self._out = None
         from nerfslam.pipeline import StreamQueue
         self.map_q = StreamQueue(maxsize=2)
-        self.map_stream = torch.cuda.Stream(device=dev)
+        self.map_stream = torch.cuda.Stream(device=dev)     # (normal priority: as a high-priority stream, 104 -> 70 frames/s)
         # --parallel_run: the tracker works on a stream of its own as well.  On the legacy default stream its kernels were
         # serialised against the branches of the mapper's HIP graphs (the null stream synchronises implicitly with every
         # blocking stream, and the graph executor's internal streams are blocking ones): 97 -> 104 frames/s.
