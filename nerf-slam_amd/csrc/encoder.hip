@@ -69,12 +69,20 @@ __global__ __launch_bounds__(256) void enc_im2col_3x3s2_kernel(const _Float16* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// instance-norm statistics: partial[n][p][0][c] = sum, [n][p][1][c] = sum of squares over the pixels of part p.
+// instance-norm statistics: partial[n][p][0][c] = sum, [n][p][1][c] = sum of squares over the pixels of part p; the LAST
+// workgroup of an image to arrive adds the P rows up (fixed order, double) and leaves the totals in row 0, which is all the
+// apply kernel reads.  (Round 2 stopped at the partial rows, at most 64 of them: a quarter of the CUs at 240x320, 19 dependent
+// load rounds per workgroup -- and every one of the apply kernel's ~600 workgroups added the 64 rows up again.)
 // grid (P, N); thread = (pixel group g = tid / C8, piece = tid % C8): 16-byte loads, whole rows coalesced.
 // ---------------------------------------------------------------------------------------------
+#define ENC_IN_MAXN 4096
+__device__ unsigned int enc_in_ticket[ENC_IN_MAXN];   // arrivals per image; the last arrival resets its entry
+
 __global__ __launch_bounds__(256) void enc_in_stats_kernel(const _Float16* __restrict__ x, float* __restrict__ partial, int HW, int C8,
                                                            int P) {
   __shared__ float red[4][2][128];
+  __shared__ double ps[256], pq[256];
+  __shared__ unsigned int s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int p = blockIdx.x, n = blockIdx.y;
   const int C = C8 * 8, G = 256 / C8;
@@ -85,14 +93,22 @@ __global__ __launch_bounds__(256) void enc_in_stats_kernel(const _Float16* __res
 #pragma unroll
   for (int e = 0; e < 8; e++) s[e] = q[e] = 0.0f;
   const _Float16* xb = x + (long)n * HW * C + piece * 8;
-  for (int pix = lo + g; pix < hi; pix += G) {
-    const en_f16x8 v = *reinterpret_cast<const en_f16x8*>(xb + (long)pix * C);
+  // four loads in flight per lane (a workgroup is a dozen dependent load rounds otherwise)
+  for (int pix = lo + g; pix < hi; pix += 4 * G) {
+    en_f16x8 v[4];
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-      const float f = (float)v[e];
-      s[e] += f;
-      q[e] += f * f;
+    for (int u = 0; u < 4; u++) {
+      const int px = pix + u * G;
+      v[u] = px < hi ? *reinterpret_cast<const en_f16x8*>(xb + (long)px * C) : (en_f16x8)(_Float16)0;
     }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float f = (float)v[u][e];
+        s[e] += f;
+        q[e] += f * f;
+      }
   }
   // lanes of one wave that hold the same piece are C8 apart (C8 = 4, 8 or 16 divides 64)
   for (int off = C8; off < 64; off <<= 1) {
@@ -110,9 +126,41 @@ __global__ __launch_bounds__(256) void enc_in_stats_kernel(const _Float16* __res
     }
   }
   __syncthreads();
+  float* rows = partial + (long)n * P * 2 * C;
   if (tid < 2 * C) {
     const int k = tid / C, c = tid - k * C;
-    partial[(((long)n * P + p) * 2 + k) * C + c] = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
+    rows[((long)p * 2 + k) * C + c] = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
+  }
+  if (P == 1) return;
+  // publish the row, take a ticket; the last arrival sees every row (agent-scope release / acquire around the counter)
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    s_ticket = atomicAdd(&enc_in_ticket[n], 1u);
+    __threadfence();
+  }
+  __syncthreads();
+  if (s_ticket != (unsigned)(P - 1)) return;
+  {
+    const int ncol = 2 * C, RG = 256 / ncol;
+    const int col = tid % ncol, rg = tid / ncol;
+    double ds = 0.0;                            // (row r = [sum C | sum of squares C]; 16 loads in flight, fixed order)
+    for (int r = rg; r < P; r += 16 * RG) {
+      float f[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) f[u] = r + u * RG < P ? rows[(long)(r + u * RG) * ncol + col] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 16; u++) ds += (double)f[u];
+    }
+    ps[tid] = ds;
+    __syncthreads();
+    if (tid < ncol) {
+      for (int gq = 1; gq < RG; gq++) ds += ps[tid + gq * ncol];
+      pq[tid] = ds;
+    }
+    __syncthreads();
+    if (tid < ncol) rows[tid] = (float)pq[tid];     // totals -> row 0 (every row has been read)
+    if (tid == 0) enc_in_ticket[n] = 0u;
   }
 }
 
@@ -129,41 +177,22 @@ struct InApplyArgs {
 // out = relu(x' + relu(y')), y' = IN(y) or y, x' = IN(x) or x or nothing.  grid (ceil(HW C8 / 1024), N).
 __global__ __launch_bounds__(256) void enc_in_apply_kernel(InApplyArgs a) {
   __shared__ float mu[2][128], rs[2][128];
-  __shared__ double ps[256], pq[256];
   const int tid = threadIdx.x, n = blockIdx.y;
   const int C = a.C8 * 8;
-  // finish the statistics: 2C columns (y | x, channel) x P partial rows; 256 / 2C threads share a column (a single
-  // thread per column walking all P rows was most of this kernel's time: 128 dependent-latency loads in front of 4 stores)
-  {
-    const int ncol = 2 * C, RG = 256 / ncol;
-    const int col = tid % ncol, rg = tid / ncol;
-    const int k = col / C, c = col - k * C;
+  // mean / 1 / sigma of the 2C columns (y | x, channel) from the totals the statistics kernel left in row 0 of the image
+  if (tid < 2 * C) {
+    const int k = tid / C, c = tid - k * C;
     const float* st = k == 0 ? a.ystats : a.xstats;
-    double s = 0.0, q = 0.0;
+    float m = 0.0f, r = 1.0f;
     if (st) {
-      const float* b = st + (long)n * a.P * 2 * C + c;
-      for (int p = rg; p < a.P; p += RG) {
-        s += (double)b[(long)(2 * p) * C];
-        q += (double)b[(long)(2 * p + 1) * C];
-      }
+      const float* b = st + (long)n * a.P * 2 * C;
+      const double s = (double)b[c], q = (double)b[C + c];
+      const double mean = s / a.HW, var = fmax(q / a.HW - mean * mean, 0.0);   // biased variance (InstanceNorm2d)
+      m = (float)mean;
+      r = (float)(1.0 / sqrt(var + (double)a.eps));
     }
-    ps[tid] = s;
-    pq[tid] = q;
-    __syncthreads();
-    if (tid < ncol) {
-      for (int g = 1; g < RG; g++) {
-        s += ps[tid + g * ncol];
-        q += pq[tid + g * ncol];
-      }
-      float m = 0.0f, r = 1.0f;
-      if (st) {
-        const double mean = s / a.HW, var = fmax(q / a.HW - mean * mean, 0.0);   // biased variance (InstanceNorm2d)
-        m = (float)mean;
-        r = (float)(1.0 / sqrt(var + (double)a.eps));
-      }
-      mu[k][c] = m;
-      rs[k][c] = r;
-    }
+    mu[k][c] = m;
+    rs[k][c] = r;
   }
   __syncthreads();
   const long total = (long)a.HW * a.C8;
@@ -223,15 +252,15 @@ extern "C" int ns_enc_im2col_3x3s2(const void* x, void* out, int N, int H, int W
 }
 
 extern "C" int ns_enc_in_parts(int HW) {
-  const int p = (HW + 1023) / 1024;
+  const int p = (HW + 511) / 512;
   return p < 1 ? 1 : (p > 64 ? 64 : p);
 }
 
 extern "C" int ns_enc_in_stats(const void* x, float* partial, int N, int HW, int C, void* stream) {
   if (N == 0) return NS_OK;
   NS_REQUIRE(x && partial, "ns_enc_in_stats: null pointer");
-  NS_REQUIRE(N > 0 && N <= 65535 && HW > 0 && (C == 32 || C == 64 || C == 128),
-             "ns_enc_in_stats: bad shape (N %d, HW %d, C %d: 32, 64 or 128 channels)", N, HW, C);
+  NS_REQUIRE(N > 0 && N <= ENC_IN_MAXN && HW > 0 && (C == 32 || C == 64 || C == 128),
+             "ns_enc_in_stats: bad shape (N %d <= 4096, HW %d, C %d: 32, 64 or 128 channels)", N, HW, C);
   NS_REQUIRE(((uintptr_t)x % 16) == 0, "ns_enc_in_stats: 16-byte alignment");
   const int P = ns_enc_in_parts(HW);
   hipLaunchKernelGGL(enc_in_stats_kernel, dim3(P, N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, partial, HW, C / 8, P);

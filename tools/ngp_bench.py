@@ -17,15 +17,18 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("ngp_scene", os.path.join(root, "tools", "ngp_scene.py"))
 sc = importlib.util.module_from_spec(spec); spec.loader.exec_module(sc)
 net.set_images(*sc.sphere_scene())
-for _ in range(warm // 16):                 # 16 steps per call, as pyngp's frame() asks for them
-    net.train_steps(16, return_loss=False)
-torch.cuda.synchronize()
-steps = steps // 16 * 16
-t0 = time.perf_counter(); ns = 0; nr = 0
-for _ in range(steps // 16):
-    net.train_steps(16, return_loss=False)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
+# (a stream of its own, like the mapper thread of the pipeline: NS_NGP_NULL_STREAM=1 for the legacy default stream)
+work = torch.cuda.current_stream() if os.environ.get("NS_NGP_NULL_STREAM") else torch.cuda.Stream(device=dev)
+with torch.cuda.stream(work):
+    for _ in range(warm // 16):                 # 16 steps per call, as pyngp's frame() asks for them
+        net.train_steps(16, return_loss=False)
+    torch.cuda.synchronize()
+    steps = steps // 16 * 16
+    t0 = time.perf_counter(); ns = 0; nr = 0
+    for _ in range(steps // 16):
+        net.train_steps(16, return_loss=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
 ns, nr = steps * net.last_samples, steps * int(net.last[1].item())   # (read once, after the timed loop: no per-step sync)
 print(f"steps/s {steps / dt:.1f}  ms/step {1e3 * dt / steps:.3f}  samples/step {ns / steps:.0f}  rays-with-samples/step {nr / steps:.0f}  Msamples/s {ns / dt / 1e6:.1f}  loss {float(net.loss_tensor):.4f}")
 
