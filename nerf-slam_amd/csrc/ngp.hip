@@ -127,18 +127,43 @@ __device__ __forceinline__ bool grid_level_hashed(uint32_t hs, uint32_t res) {
 
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 
-// grid (ceil(N/256), n_levels): all lanes of a workgroup gather from the same level's table, so the
-// coarse (dense, small) levels stay in L1/L2 and only the hashed fine levels go to HBM.
+// Which workgroup gathers from which level's table.  All lanes of a workgroup read ONE level; the 8 XCDs have 8 separate L2s,
+// and with the levels walked in order by the whole chip (round 2: grid (blocks, levels)) every XCD pulled every hashed level's
+// 2 MB table through its own L2 -- 8 x 23 MB, most of the kernel's 230 MB of fetches.  Workgroup ids are dealt round-robin to
+// the XCDs (observed placement: speed only, any placement is correct), so workgroup b belongs to XCD b % 8 and takes item b / 8
+// of that XCD's list: first ALL sample blocks of the one hashed level this XCD owns (the 8 finest hashed levels: their tables
+// are fetched once, by one L2), then every 8th block of the levels that are shared (coarser hashed levels, whose neighbouring
+// samples hit the same lines anyway, and the dense ones, which stay resident).
+struct EncFwdSched {
+  int own[8];       // XCD -> the level it owns, or -1
+  int shared[16];   // the other levels, costliest first
+  int n_shared;
+  int nblk, nblk8;  // sample blocks of 256; ceil(nblk / 8)
+  int seg;          // items of the owned segment: nblk, or 0 when no level is owned
+};
+
 __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const float* __restrict__ pos,
                                                              const h2_t* __restrict__ params,
                                                              h2_t* __restrict__ out, long N, int L, int unit_major,
-                                                             const int* __restrict__ n_dev, _Float16* __restrict__ jacT) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+                                                             const int* __restrict__ n_dev, _Float16* __restrict__ jacT,
+                                                             EncFwdSched sc) {
+  const int xcd = blockIdx.x & 7, item = blockIdx.x >> 3;
+  int l, blk;
+  if (item < sc.seg) {
+    l = sc.own[xcd];
+    blk = item;
+    if (l < 0) return;
+  } else {
+    const int k = item - sc.seg;
+    l = sc.shared[k / sc.nblk8];
+    blk = (k % sc.nblk8) * 8 + xcd;
+    if (blk >= sc.nblk) return;
+  }
+  const long i = (long)blk * 256 + threadIdx.x;
   // N stays the row stride of the unit-major output.  The device count is rounded up to 8 like in the MLP kernels, which
   // read the features of the (up to 7) tail slots: left unwritten they are whatever the allocation held -- NaN bits there
   // turn the weight gradient into NaN even though the tail's upstream gradient is zero (0 x NaN).
   if (i >= N || (n_dev != nullptr && i >= (((long)*n_dev + 7) & ~7L))) return;
-  const int l = blockIdx.y;
   const uint32_t hs = g.offset[l + 1] - g.offset[l];
   const float scale = g.scale[l];
   const uint32_t res = (uint32_t)g.res[l];
@@ -2128,8 +2153,27 @@ extern "C" int ns_ngp_encode_forward_j_n(int n_levels, int n_features, int log2_
     return NS_ENOSUP;
   }
   if (N <= 0) return NS_OK;
-  hipLaunchKernelGGL(ngp_encode_fwd_kernel, dim3(ns_cdiv(N, 256), n_levels), dim3(256), 0, (hipStream_t)stream, g,
-                     positions, (const h2_t*)params, (h2_t*)out, N, n_levels, unit_major, n_dev, (_Float16*)jacT);
+  EncFwdSched sc;
+  {
+    // the (up to) 8 finest hashed levels are owned by one XCD each; everything else is shared, hashed levels first
+    int hashed[16], nh = 0;
+    for (int l = n_levels - 1; l >= 0; l--)
+      if ((uint64_t)g.res[l] * g.res[l] * g.res[l] > (uint64_t)(g.offset[l + 1] - g.offset[l])) hashed[nh++] = l;   // finest first
+    static const bool no_own = getenv("NS_ENC_FWD_NO_XCD") != nullptr;   // A/B: every level shared (round 2's access pattern)
+    const int n_own = no_own ? 0 : (nh < 8 ? nh : 8);
+    for (int x = 0; x < 8; x++) sc.own[x] = x < n_own ? hashed[x] : -1;
+    sc.n_shared = 0;
+    for (int k = n_own; k < nh; k++) sc.shared[sc.n_shared++] = hashed[k];
+    for (int l = n_levels - 1; l >= 0; l--)
+      if (!((uint64_t)g.res[l] * g.res[l] * g.res[l] > (uint64_t)(g.offset[l + 1] - g.offset[l]))) sc.shared[sc.n_shared++] = l;
+    for (int k = sc.n_shared; k < 16; k++) sc.shared[k] = 0;
+    sc.nblk = ns_cdiv(N, 256);
+    sc.nblk8 = (sc.nblk + 7) / 8;
+    sc.seg = n_own > 0 ? sc.nblk : 0;
+  }
+  const long nwg = 8L * (sc.seg + (long)sc.n_shared * sc.nblk8);
+  hipLaunchKernelGGL(ngp_encode_fwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g,
+                     positions, (const h2_t*)params, (h2_t*)out, N, n_levels, unit_major, n_dev, (_Float16*)jacT, sc);
   NS_CHECK_LAUNCH("ngp_encode_fwd_kernel");
   return NS_OK;
 }
