@@ -1,5 +1,8 @@
+"""Distribution of the table gradient's inputs on the sphere scene (units of 2^-18 after the fixed-point scale): how many
+samples carry gradient at all, how large the contributions are (what a narrower record format would have to hold).
+usage: python tools/dfeat_hist.py"""
 import os, sys
-root = "/root/repo"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(root, "nerf-slam_amd")]
 import torch, importlib.util
 from nerfslam.ngp import NgpConfig, NgpNerf
