@@ -95,7 +95,10 @@ class Pipeline:
         # --parallel_run: the tracker works on a stream of its own as well.  On the legacy default stream its kernels were
         # serialised against the branches of the mapper's HIP graphs (the null stream synchronises implicitly with every
         # blocking stream, and the graph executor's internal streams are blocking ones): 97 -> 104 frames/s.
-        self.track_stream = torch.cuda.Stream(device=dev)
+        # (created at the first --parallel_run frame, i.e. AFTER the mapper's graphs exist: a stream gets its hardware queue when it
+        #  is first used, and one that was used before the graphs were instantiated ended up sharing a queue with a graph branch:
+        #  103 -> 93 frames/s)
+        self.track_stream = None
         self._was_parallel = False
         self.map_error = None
         self._thread = threading.Thread(target=self._mapper_loop, daemon=True) if fusion else None
@@ -165,6 +168,8 @@ class Pipeline:
         if self.parallel != self._was_parallel:             # the tracker changes streams: not with work in flight
             torch.cuda.synchronize()
             self._was_parallel = self.parallel
+        if self.parallel and self.track_stream is None:
+            self.track_stream = torch.cuda.Stream(device=self.dev)
         if self.parallel and torch.cuda.current_stream(self.dev) != self.track_stream:
             with torch.cuda.stream(self.track_stream):
                 return self.frame()

@@ -158,11 +158,19 @@ def run(args, return_modules=False, tweak=None):
         slam_q.consumer_alive = lambda: worker.is_alive() and getattr(fusion, "error", None) is None
         # the tracker on a stream of its own, too: the legacy default stream synchronises implicitly with every blocking stream,
         # and the internal streams of the mapper's HIP graphs are blocking ones (bench.py: 97 -> 104 frames/s)
-        torch.cuda.synchronize()
-        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        # -- taken once the mapper has instantiated its training graphs: a stream gets its hardware queue when it is first used,
+        # and one used before the graphs existed ended up sharing a queue with one of their branches (103 -> 93 frames/s)
+        own = None
+        try:
             while data.spin() and slam.spin() and not fusion.shutdown:
-                pass
+                if own is None and getattr(getattr(getattr(fusion.fusion, "ngp", None), "_net", None), "_pair", None) is not None:
+                    torch.cuda.synchronize()
+                    own = torch.cuda.stream(torch.cuda.Stream(device=dev))
+                    own.__enter__()
             torch.cuda.current_stream().synchronize()
+        finally:
+            if own is not None:
+                own.__exit__(None, None, None)
         while worker.is_alive() and not fusion.shutdown:      # the data ran out: let the mapper reach its stop condition
             worker.join(timeout=0.05)
         if getattr(fusion, "error", None) is not None:        # the mapper thread died: surface its exception here
