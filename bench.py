@@ -760,16 +760,28 @@ def main_split(args, rank, world, dev, backend, n_frames, buffer):
         tr = [s for s in stats if s and s.get("rank", 0) > 0]
         steps = [s["steps_timed"] for s in tr]
         ate = quality(pipe)
+        # `value` means the same thing at every N: frames/s that are tracked AND mapped with the N = 1 line's
+        # mapping work per frame.  At N = 1 the mapper trains 16 ray batches (= 16 optimiser steps) per frame in lockstep; here
+        # the trainers run free, every optimiser step consumes one ray batch per trainer, so the mapped rate they sustain is
+        # (ray batches/s of all trainers) / 16, and the job's rate is the slower of tracker and mappers.
+        tracked = K / dt
+        mapped = (sum(steps) / dt) / 16.0 if steps else 0.0
+        value = min(tracked, mapped) if steps else tracked
         out = {
             "metric": "frames/s tracked+mapped on Replica office0 640x480; PSNR + ATE-RMSE vs ref",
-            "value": K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K,
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K,
+            "tracked_frames_per_s": tracked, "mapped_frames_per_s_at_16_ray_batches_per_frame": mapped,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 conv nets + correlation volumes + NeRF MLP/hash grid (f32 master weights), f32 BA with f64 reduced-camera solve",
             "data": "synthetic 640x480 stream (tools/synth_stream.py), frames resident in HBM; random-init networks (see N=1 line)",
             "config": {"workload": "configs[3]: --multi_gpu split, rank 0 tracks the stream (same per-frame work as the N=1 line's "
                                    "tracker) and broadcasts every SLAM packet over RCCL to %d replicated free-running NeRF trainers "
-                                   "(gradients all-reduced in the trainer sub-group); value = tracked frames/s while the mappers train "
-                                   "concurrently; per-GPU mapping work is fixed as N grows (weak)" % len(trainers),
+                                   "(table gradient exchanged in shards, MLP / pose gradients all-reduced in the trainer sub-group); "
+                                   "per-GPU mapping work is fixed as N grows (weak: one ray batch per trainer and optimiser step)"
+                                   % len(trainers),
+                       "value_is": "min(tracked frames/s, ray batches/s of all trainers / 16): the N = 1 line's work per frame (16 "
+                                   "ray batches trained per tracked frame), sustained by free-running trainers; both terms are in the "
+                                   "line (`tracked_frames_per_s`, `mapped_frames_per_s_at_16_ray_batches_per_frame`)",
                        "parallelism": "1 tracker + %d replicated trainers" % len(trainers), "backend": backend, "buffer": buffer,
                        "init_frames_untimed": init_frames,
                        "keyframe_ratio_measured": {"candidates_per_frame": (st1["candidates"] - st0["candidates"]) / K,
