@@ -366,7 +366,8 @@ def hot_path_chain(dev, steps, warmup):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        from nerfslam._lib import graph_capture          # (cyclic GC off while capturing: see its docstring)
+        with graph_capture(graph):
             hp.step()
         graph.replay(); torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -225,6 +225,14 @@ __device__ __forceinline__ long ngp_count(long N, const int* n_dev) {
   return c < N ? c : N;
 }
 
+// the exact device count (ngp_count rounds it up to 8): the up to 7 slots between the two carry ZERO upstream gradient, whatever
+// the loss-gradient buffer holds there -- the kernels that read dL/dout mask them, so nobody has to clear that buffer per step
+__device__ __forceinline__ long ngp_exact(long N, const int* n_dev) {
+  if (n_dev == nullptr) return N;
+  const long c = (long)*n_dev;
+  return c < N ? c : N;
+}
+
 __global__ __launch_bounds__(256) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
   __shared__ f16x8 Wf[FW_NFRAG * 64];
   if (a.frags != nullptr) {      // (workgroup-uniform)
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  const long N = a.N, cnt = ngp_count(a.N, a.n_dev);
+  const long N = a.N, cnt = ngp_count(a.N, a.n_dev), exact = ngp_exact(a.N, a.n_dev);
   for (int iter = 0; iter < MLP_ITERS; iter++) {
     const long n0 = (((long)blockIdx.x * MLP_ITERS + iter) * 4 + wave) * 64;
     if (n0 >= cnt) return;
@@ -391,7 +399,10 @@ __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
     const bool ok = n0 + 2 * j < cnt;
     const long np = ok ? n0 + 2 * j : 0;
     const uint32_t boff = lane_bytes(h, N, np);
-    const f16x8 go = *reinterpret_cast<const f16x8*>(a.dLdout + np * 4);  // (r,g,b,d) of samples np, np + 1
+    f16x8 go = *reinterpret_cast<const f16x8*>(a.dLdout + np * 4);  // (r,g,b,d) of samples np, np + 1
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+      if (np + t >= exact) go[4 * t] = go[4 * t + 1] = go[4 * t + 2] = go[4 * t + 3] = (_Float16)0;
     uint2 mk1 = make_uint2(0, 0), mk3 = mk1, mk4 = mk1;
     if (BITS) {
       mk1 = *reinterpret_cast<const uint2*>(a.masks + ((long)(0 * 2 + h) * N + np));
@@ -689,7 +700,7 @@ __global__ __launch_bounds__(256, 1) void ngp_mlp_bwd_fused_kernel(MlpFusedArgs 
   fill_frags<true>(Wfb, a.W, W1_OFF, 64, 32, BW_L1);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  const long N = a.N, cnt = ngp_count(a.N, a.n_dev);
+  const long N = a.N, cnt = ngp_count(a.N, a.n_dev), exact = ngp_exact(a.N, a.n_dev);
   const long nblk = (cnt + 127) / 128;
   const int col = wave * 32 + j;
   // weight-gradient tiles of this wave: waves 0,1: W4 (wave>>1, wave&1), W2 (0, wave), W1 (wave, 0);
@@ -709,7 +720,7 @@ __global__ __launch_bounds__(256, 1) void ngp_mlp_bwd_fused_kernel(MlpFusedArgs 
     for (int cc = 0; cc < 2; cc++)
 #pragma unroll
       for (int q = 0; q < 8; q++) xn[cc][q] = ok ? a.featT[(long)frag_k(cc, h, q) * N + ns] : (_Float16)0;
-    gon = ok ? *reinterpret_cast<const f16x4l*>(a.dLdout + ns * 4) : (f16x4l)(_Float16)0;   // (r, g, b, d)
+    gon = (ok && np < exact) ? *reinterpret_cast<const f16x4l*>(a.dLdout + ns * 4) : (f16x4l)(_Float16)0;   // (r, g, b, d)
     dn[0] = a.dirs[ns * 3];
     dn[1] = a.dirs[ns * 3 + 1];
     dn[2] = a.dirs[ns * 3 + 2];
@@ -1008,7 +1019,7 @@ __global__ __launch_bounds__(128, 1) void ngp_mlp_wgrad_recompute_kernel(MlpWgra
   const f16x8* __restrict__ Wff = a.frags;
   const f16x8* __restrict__ Wfb = a.frags + FW_NFRAG * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  const long N = a.N, cnt = ngp_count(a.N, a.n_dev);
+  const long N = a.N, cnt = ngp_count(a.N, a.n_dev), exact = ngp_exact(a.N, a.n_dev);
   const long nblk = (cnt + 63) / 64;
   const int col = wave * 32 + j;
   f32x16 t0 = (f32x16)0.0f, t1 = (f32x16)0.0f, t2 = (f32x16)0.0f, t3 = (f32x16)0.0f, t4 = (f32x16)0.0f, t5 = (f32x16)0.0f;
@@ -1073,7 +1084,7 @@ __global__ __launch_bounds__(128, 1) void ngp_mlp_wgrad_recompute_kernel(MlpWgra
       }
     }
     f16x4l go = (f16x4l)(_Float16)0;
-    if (ok) go = *reinterpret_cast<const f16x4l*>(a.dLdout + np * 4);   // (r, g, b, d)
+    if (ok && np < exact) go = *reinterpret_cast<const f16x4l*>(a.dLdout + np * 4);   // (r, g, b, d)
     f16x8 d5 = (f16x8)(_Float16)0;
     if (h == 0) {
       d5[0] = go[0];

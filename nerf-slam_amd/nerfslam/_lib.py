@@ -83,3 +83,32 @@ def check_contiguous(**named):
     for name, t in named.items():
         if not t.is_contiguous():
             raise RuntimeError(f"{name} must be contiguous")
+
+
+import contextlib as _contextlib
+import gc as _gc
+
+
+_immortal_graphs = []
+
+
+@_contextlib.contextmanager
+def graph_capture(graph, **kw):
+    """`torch.cuda.graph(graph, **kw)`, with two precautions the GPU suite (a dozen trainers created and dropped in one process)
+    showed to be necessary on ROCm 7.2:
+    * the cyclic garbage collector is OFF for the duration of the capture -- a collection in the middle of a capture (any Python
+      allocation can trigger one) freed an unreachable trainer of earlier, and destroying its HIP graphs while a stream is
+      capturing aborts the process (`Fatal Python error: Aborted ... Garbage-collecting`, one run in ~5);
+    * a captured graph is never destroyed: destroying the graphs of an earlier trainer right BEFORE a capture (what the
+      collection at the head of `torch.cuda.graph` does) made the first replay of the new graph segfault, every time.  The
+      graphs of a dropped trainer therefore stay alive until the process ends (three small graphs per (re)capture)."""
+    import torch
+    was = _gc.isenabled()
+    _gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield
+    finally:
+        _immortal_graphs.append(graph)
+        if was:
+            _gc.enable()

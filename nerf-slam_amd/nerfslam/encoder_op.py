@@ -17,7 +17,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import NerfSlamHipError, check, lib, ptr, require_cuda, stream_ptr
+from ._lib import NerfSlamHipError, check, graph_capture, lib, ptr, require_cuda, stream_ptr
 from .conv import PackedConv
 
 EPS = 1e-5   # nn.InstanceNorm2d default
@@ -120,7 +120,7 @@ class HipEncoder:
                 self._forward(static_in)                                   # warm-up outside the capture (lazy initialisation)
                 torch.cuda.current_stream().synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with graph_capture(g, capture_error_mode="thread_local"):
                     static_out = self._forward(static_in)
                 entry = self._graphs[key] = (g, static_in, static_out)
             g, static_in, static_out = entry

@@ -317,8 +317,8 @@ class NgpNerf:
         s = float(c.aabb_scale)
         fx, fy, cx, cy = self.intr
         st, ctl = stream_ptr(), ptr(t["ctl"])
-        t["ray_n"].fill_(-1)
-        t["s_dout"].zero_()      # the loss gradient of the step these rays belong to
+        # (no per-step clears: the marcher writes ray_n of every ray of the batch, the composite pass the loss gradient of every
+        #  marched sample, and the MLP backward kernels mask the <= 7 slots between the sample count and its multiple of 8)
         check(L.ns_ngp_sample_rays_ctl(ptr(self.images), ptr(self.depths), ptr(self.depth_covs), ptr(self.c2w), n_cap, H, W,
                                        C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
                                        C.c_float(0.5 - 0.5 * s), C.c_float(0.5 + 0.5 * s), C.c_float(c.near), C.c_uint32(0), Rc,
@@ -552,11 +552,11 @@ class NgpNerf:
                 with torch.cuda.device(self.device):
                     g = self._pair if m == 2 else self._chains.get(m)
                     if g is None:
-                        from ._lib import capture_lock
+                        from ._lib import capture_lock, graph_capture
                         with capture_lock:
                             torch.cuda.synchronize(self.device)
                             g = torch.cuda.CUDAGraph()
-                            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                            with graph_capture(g, capture_error_mode="thread_local"):
                                 for k in range(m):
                                     self._enqueue_step(k & 1)
                         if m == 2:
@@ -618,11 +618,11 @@ class NgpNerf:
                     self._eager_left -= 1
                     self._enqueue_step(x)
                 elif self._graphs[x] is None:
-                    from ._lib import capture_lock
+                    from ._lib import capture_lock, graph_capture
                     with capture_lock:          # the tracker thread takes the same lock around its host read-backs
                         torch.cuda.synchronize(dev)
                         g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        with graph_capture(g, capture_error_mode="thread_local"):
                             self._enqueue_step(x)
                     self._graphs[x] = g         # (capturing does not execute: the step runs with the first replay)
                     g.replay()

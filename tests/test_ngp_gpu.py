@@ -150,12 +150,16 @@ def test_mlp_forward_backward(oracle_mod, dev):
     check(lib().ns_ngp_mlp_forward_m_n(ptr(Wd), ptr(d_featT), ptr(d_dirs), ptr(out_m), *[ptr(b) for b in bufs_m], ptr(masks),
                                        C.c_long(N), None, stream_ptr()), "mlp fwd masks")
     assert torch.equal(out_m, out) and all(torch.equal(a, b) for a, b in zip(bufs_m, bufs[1:]))
+    # (with a device-side count, whatever dL/dout holds beyond it is never used: the loss-gradient buffer is not cleared per step)
+    poisoned = d_dout.clone()
+    poisoned[500:] = float("nan")
     for n_dev in (None, torch.tensor([500], dtype=torch.int32, device=dev)):
+        dd_in = d_dout if n_dev is None else poisoned
         ref_d = [torch.zeros_like(b) for b in [dfeat] + dbufs]
         got_d = [torch.zeros_like(b) for b in [dfeat] + dbufs]
-        check(lib().ns_ngp_mlp_dgrad_n(ptr(Wd), ptr(d_dout), ptr(bufs[1]), ptr(bufs[3]), ptr(bufs[4]), *[ptr(b) for b in ref_d],
+        check(lib().ns_ngp_mlp_dgrad_n(ptr(Wd), ptr(dd_in), ptr(bufs[1]), ptr(bufs[3]), ptr(bufs[4]), *[ptr(b) for b in ref_d],
                                        C.c_long(N), ptr(n_dev), stream_ptr()), "dgrad")
-        check(lib().ns_ngp_mlp_dgrad_m_n(ptr(Wd), ptr(d_dout), ptr(masks), *[ptr(b) for b in got_d], C.c_long(N), ptr(n_dev),
+        check(lib().ns_ngp_mlp_dgrad_m_n(ptr(Wd), ptr(dd_in), ptr(masks), *[ptr(b) for b in got_d], C.c_long(N), ptr(n_dev),
                                          stream_ptr()), "dgrad masks")
         for a, b in zip(ref_d, got_d):
             assert torch.equal(a, b)
@@ -164,17 +168,18 @@ def test_mlp_forward_backward(oracle_mod, dev):
     # (same MFMA sequence), weight gradients equal up to summation order; also with a device sample count and several workgroup
     # counts (the partial slabs are summed in slab order)
     for n_dev, n_valid in ((None, N), (torch.tensor([500], dtype=torch.int32, device=dev), 504)):
+        dd_in = d_dout if n_dev is None else poisoned
         ref_feat = torch.zeros_like(dfeat)
         ref_db = [torch.zeros_like(b) for b in dbufs]
         gw_ref = torch.zeros(10240, dtype=torch.float32, device=dev)
         part = torch.empty((7, 10240), dtype=torch.float32, device=dev)
-        check(lib().ns_ngp_mlp_backward_n(ptr(Wd), ptr(d_dout), *[ptr(b) for b in bufs], ptr(ref_feat), *[ptr(b) for b in ref_db],
+        check(lib().ns_ngp_mlp_backward_n(ptr(Wd), ptr(dd_in), *[ptr(b) for b in bufs], ptr(ref_feat), *[ptr(b) for b in ref_db],
                                           ptr(part), 7, ptr(gw_ref), C.c_long(N), ptr(n_dev), stream_ptr()), "mlp bwd")
         for wgs in (1, 3, 64):
             got_feat = torch.zeros_like(dfeat)
             gw_got = torch.zeros(10240, dtype=torch.float32, device=dev)
             part_f = torch.full((wgs, 10240), float("nan"), dtype=torch.float32, device=dev)
-            check(lib().ns_ngp_mlp_backward_fused_n(ptr(Wd), ptr(d_featT), ptr(d_dirs), ptr(d_dout), ptr(got_feat), ptr(part_f), wgs,
+            check(lib().ns_ngp_mlp_backward_fused_n(ptr(Wd), ptr(d_featT), ptr(d_dirs), ptr(dd_in), ptr(got_feat), ptr(part_f), wgs,
                                                     ptr(gw_got), C.c_long(N), ptr(n_dev), stream_ptr()), "mlp bwd fused")
             assert torch.equal(got_feat[:, :n_valid], ref_feat[:, :n_valid]), wgs
             assert torch.isfinite(gw_got).all()
@@ -188,9 +193,10 @@ def test_mlp_forward_backward(oracle_mod, dev):
                                            C.c_long(N), ptr(n_dev), stream_ptr()), "mlp fwd masks only")
         assert torch.equal(out2[:n_valid], out[:n_valid])
         lean = torch.zeros_like(dfeat)
-        check(lib().ns_ngp_mlp_dgrad_m_n(ptr(Wd), ptr(d_dout), ptr(masks2), ptr(lean), None, None, None, None, None, C.c_long(N),
+        check(lib().ns_ngp_mlp_dgrad_m_n(ptr(Wd), ptr(dd_in), ptr(masks2), ptr(lean), None, None, None, None, None, C.c_long(N),
                                          ptr(n_dev), stream_ptr()), "lean dgrad")
-        assert torch.equal(lean[:, :n_valid], ref_feat[:, :n_valid])
+        assert torch.equal(lean[:, :n_valid], ref_feat[:, :n_valid]) and torch.isfinite(lean[:, :n_valid]).all()
+        assert n_dev is None or (lean[:, 500:504] == 0).all()
         frags = torch.zeros(int(lib().ns_ngp_mlp_fragment_table_bytes()) // 2, dtype=torch.float16, device=dev)
         check(lib().ns_ngp_mlp_pack_fragments(ptr(Wd), ptr(frags), stream_ptr()), "pack")
         # ... and the same two kernels with their weights taken from that table (what the trainer launches): same bits
@@ -200,13 +206,13 @@ def test_mlp_forward_backward(oracle_mod, dev):
                                            stream_ptr()), "mlp fwd frags")
         assert torch.equal(out3[:n_valid], out[:n_valid]) and torch.equal(masks3.view(6, N)[:, :n_valid], masks2.view(6, N)[:, :n_valid])
         lean3 = torch.zeros_like(dfeat)
-        check(lib().ns_ngp_mlp_dgrad_f_n(ptr(frags), ptr(d_dout), ptr(masks3), ptr(lean3), C.c_long(N), ptr(n_dev), stream_ptr()),
+        check(lib().ns_ngp_mlp_dgrad_f_n(ptr(frags), ptr(dd_in), ptr(masks3), ptr(lean3), C.c_long(N), ptr(n_dev), stream_ptr()),
               "lean dgrad frags")
         assert torch.equal(lean3[:, :n_valid], ref_feat[:, :n_valid])
         for wgs in (1, 5, 64):
             gw_got = torch.zeros(10240, dtype=torch.float32, device=dev)
             part_f = torch.full((wgs, 10240), float("nan"), dtype=torch.float32, device=dev)
-            check(lib().ns_ngp_mlp_wgrad_recompute_n(ptr(frags), ptr(d_featT), ptr(d_dirs), ptr(d_dout), ptr(part_f), wgs, ptr(gw_got),
+            check(lib().ns_ngp_mlp_wgrad_recompute_n(ptr(frags), ptr(d_featT), ptr(d_dirs), ptr(dd_in), ptr(part_f), wgs, ptr(gw_got),
                                                      C.c_long(N), ptr(n_dev), stream_ptr()), "wgrad recompute")
             assert torch.isfinite(gw_got).all()
             err = (gw_got - gw_ref).abs().max().item()
