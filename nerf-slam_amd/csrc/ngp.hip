@@ -2431,7 +2431,18 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
   if (!(parts & 12) || nd == 0) return NS_OK;
   EncBwdPlan plan;
   const bool rl = N % 8 == 0 && ((uintptr_t)positions % 16) == 0 && ((uintptr_t)dLdoutT % 16) == 0;
-  const int tasks = rl ? enc_bwd_plan_host(g, n_levels, plan, true, 16, 8) : enc_bwd_plan_host(g, n_levels, plan, true);
+  static int rl_pc = 16, rl_pm = 8;      // parts of the single-slice / multi-slice dense levels (NS_ENC_RL_PARTS=coarse,multi)
+  static const bool rl_env = [] {
+    const char* e = getenv("NS_ENC_RL_PARTS");
+    int a = 0, b = 0;
+    if (e && sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= NS_ENC_PARTS_COARSE && b >= 1 && b <= NS_ENC_PARTS_COARSE) {
+      rl_pc = a;
+      rl_pm = b;
+    }
+    return true;
+  }();
+  (void)rl_env;
+  const int tasks = rl ? enc_bwd_plan_host(g, n_levels, plan, true, rl_pc, rl_pm) : enc_bwd_plan_host(g, n_levels, plan, true);
   const int blocks = (tasks + 7) / 8 * 8;
   // the dense levels always go through their partial planes here (the reduce pass is where Adam is applied)
   if (parts & 4) {
