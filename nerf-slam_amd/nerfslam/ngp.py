@@ -333,13 +333,14 @@ class NgpNerf:
     def _enqueue_step(self, x):
         """one optimiser step on set `x` on the current stream (+ two side streams); no host synchronisation, no allocation.
 
-        main  : encode -> MLP -> composite -> MLP activation gradients -> table gradient of the HASHED levels with Adam in its
-                flush (scatter, accumulate) -> camera step -> MLP Adam
+        main  : encode (+ Jacobian rows) -> MLP forward (bit masks) -> composite (loss per ray) -> [fork 1] activation gradients
+                -> [fork 2] table gradient of the HASHED levels with Adam in its flush (scatter, accumulate)
         side  : [from the start] control block of step k + 1, its rays sampled and marched into the OTHER set (the marcher is
-                latency bound and reads only the occupancy bits and the images) ; [after the activation gradients] MLP weight
-                gradients, pose refinement's input gradient + reductions
-        side2 : [after the activation gradients] table gradient of the DENSE levels (LDS-atomic bound) with Adam in its reduce
-        Round 2 marched the next rays next to the streaming Adam pass at the end of the step; that pass no longer exists."""
+                latency bound and reads only the occupancy bits and the images); [1] MLP weight gradients from a recomputed
+                forward, reduce, MLP Adam, fragment pack; [2] pose refinement: Jacobian dot, camera gradient, pose step
+        side2 : [2] table gradient of the DENSE levels (LDS-atomic bound) with Adam in its reduce
+        Under capture the ORDER of the calls below decides which hardware queue a branch gets: the main stream's
+        kernels are enqueued first after every fork, the ray branch first at the start of the step."""
         c, dev = self.cfg, self.device
         L = lib()
         S, Rc = c.max_samples, self.ray_cap
