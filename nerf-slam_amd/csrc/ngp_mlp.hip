@@ -168,6 +168,22 @@ __device__ __forceinline__ f32x16 layer_tile(const f16x8* Wf, int first, int it,
   return acc;
 }
 
+// the same with the fragments in GLOBAL memory (the packed table, L1 / L2 resident), read through a BUFFER resource: the address of
+// fragment f is (SGPR resource) + (one VGPR: 16 x lane) + (scalar f x 1 KB).  Written as Wf[f * 64 + lane] the compiler built a
+// 64-bit per-lane address for every fragment whose offset does not fit the 12-bit immediate, hoisted all of them out of the sample
+// loop and kept them live: ~80 of the weight-gradient kernel's registers.
+typedef uint32_t mlp_u32x4 __attribute__((ext_vector_type(4)));
+template <int NCHUNK>
+__device__ __forceinline__ f32x16 layer_tile_b(__amdgpu_buffer_rsrc_t Wf, int first, int it, uint32_t lane16, const f16x8* bin) {
+  f32x16 acc = (f32x16)0.0f;
+#pragma unroll
+  for (int cc = 0; cc < NCHUNK; cc++) {
+    const mlp_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(Wf, lane16, (first + it * NCHUNK + cc) * 1024, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), bin[cc], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 __device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
   const f16x2 v = {a, b};
   return __builtin_bit_cast(uint32_t, v);
@@ -964,6 +980,11 @@ extern "C" int ns_ngp_mlp_dgrad_f_n(const void* frags, const void* dLdout, const
 //                of LDS: it co-resides with the scatter / accumulate workgroups of the table gradient) and the weight
 //                fragments read from a packed table in global memory (44 KB, L1 / L2 resident) instead of LDS.
 // 6 accumulator tiles per wave: wave 0: W4 (0,0) (0,1), W2 (0,0) (0,1), W1 (0,0) (1,0); wave 1: W4 (1,0) (1,1), W5 (0,0) (0,1), W3 (0,0) (1,0).
+// Registers: 256 (two waves per SIMD, `__launch_bounds__(128, 2)`; 40 B of scratch for loop-invariant values).  It was 384 -- one
+// wave owned a SIMD and nothing else could join it -- because of ADDRESSES, not data: a 64-bit per-lane address for each of the 44
+// weight fragments and each of the 16 feature rows, hoisted out of the sample loop and kept live.  The fragments are read through
+// a buffer resource now (SGPR descriptor + one VGPR lane offset + scalar fragment offset: layer_tile_b), the feature rows through
+// uniform row bases + one 32-bit lane offset, the LDS operands of the weight-gradient tiles at one per-lane base + immediates.
 // ---------------------------------------------------------------------------------------------
 #define FR_SP 72    // halfs per stage row: 64 samples + 8 pad
 
@@ -1002,8 +1023,10 @@ __device__ __forceinline__ void wgrad_tile64(const _Float16* stage, int xrow0, i
   const int col = lane & 31, half = lane >> 5;
   const int ro = to * 32 + col, ri = ti * 32 + col;
   const bool oko = ro < nout, oki = ri < nin;
-  const _Float16* pa = stage + (FU_DY + (oko ? ro : 0)) * FR_SP + 8 * half;
-  const _Float16* pb = stage + (xrow0 + (oki ? ri : 0)) * FR_SP + 8 * half;
+  // (rows beyond nout / nin are read all the same -- they exist in the stage -- and zeroed below: the address then is ONE per-lane
+  //  base + a compile-time offset for every tile, instead of a select per tile that the compiler keeps live across the loop)
+  const _Float16* pa = stage + (FU_DY + ro) * FR_SP + 8 * half;
+  const _Float16* pb = stage + (xrow0 + ri) * FR_SP + 8 * half;
 #pragma unroll
   for (int ks = 0; ks < 4; ks++) {   // 4 x 16 samples
     f16x8 av = *reinterpret_cast<const f16x8*>(pa + 16 * ks);
@@ -1014,12 +1037,12 @@ __device__ __forceinline__ void wgrad_tile64(const _Float16* stage, int xrow0, i
   }
 }
 
-__global__ __launch_bounds__(128, 1) void ngp_mlp_wgrad_recompute_kernel(MlpWgradArgs a) {
+__global__ __launch_bounds__(128, 2) void ngp_mlp_wgrad_recompute_kernel(MlpWgradArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 stage[FU_ROWS * FR_SP];   // 46 KB: [unit rows][64 samples]
-  const f16x8* __restrict__ Wff = a.frags;
-  const f16x8* __restrict__ Wfb = a.frags + FW_NFRAG * 64;
+  const __amdgpu_buffer_rsrc_t Wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16x8*>(a.frags), 0, (FW_NFRAG + BW_NFRAG) * 1024, 0x00027000);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   const long N = a.N, cnt = ngp_count(a.N, a.n_dev), exact = ngp_exact(a.N, a.n_dev);
+  const uint32_t lane16 = (uint32_t)lane * 16u;
   const long nblk = (cnt + 63) / 64;
   const int col = wave * 32 + j;
   f32x16 t0 = (f32x16)0.0f, t1 = (f32x16)0.0f, t2 = (f32x16)0.0f, t3 = (f32x16)0.0f, t4 = (f32x16)0.0f, t5 = (f32x16)0.0f;
@@ -1029,18 +1052,22 @@ __global__ __launch_bounds__(128, 1) void ngp_mlp_wgrad_recompute_kernel(MlpWgra
     const bool ok = np < cnt;
     const long ns = ok ? np : 0;
     uint32_t m1 = 0, m3 = 0, m4 = 0;
+    const uint32_t xoff = lane_bytes(h, N, ns);
     __syncthreads();   // the previous block's last weight-gradient tiles have been read
     {
       f16x8 x[2], h1[4], cin[2], h3[4], h4[4];
 #pragma unroll
       for (int cc = 0; cc < 2; cc++) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) x[cc][q] = ok ? a.featT[(long)frag_k(cc, h, q) * N + ns] : (_Float16)0;
+        for (int q = 0; q < 8; q++) {   // (uniform row base + one 32-bit lane offset: see lane_bytes)
+          const _Float16 v = *reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(a.featT + (long)ufrag(cc, q) * N) + xoff);
+          x[cc][q] = ok ? v : (_Float16)0;
+        }
         stage_chunk64(stage, FU_XF, x[cc], cc, h, col);
       }
 #pragma unroll
       for (int it = 0; it < 2; it++) {
-        const f32x16 acc = layer_tile<2>(Wff, FW_L1, it, lane, x);
+        const f32x16 acc = layer_tile_b<2>(Wrs, FW_L1, it, lane16, x);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const _Float16 v = (_Float16)fmaxf(acc[r], 0.0f);
@@ -1051,7 +1078,7 @@ __global__ __launch_bounds__(128, 1) void ngp_mlp_wgrad_recompute_kernel(MlpWgra
         stage_chunk64(stage, FU_XH1, h1[2 * it + 1], 2 * it + 1, h, col);
       }
       {
-        const f32x16 acc = layer_tile<4>(Wff, FW_L2, 0, lane, h1);
+        const f32x16 acc = layer_tile_b<4>(Wrs, FW_L2, 0, lane16, h1);
 #pragma unroll
         for (int r = 0; r < 8; r++) cin[0][r] = (_Float16)acc[r];
         cin[1] = sh_chunk(a.dirs[ns * 3], a.dirs[ns * 3 + 1], a.dirs[ns * 3 + 2], h);
@@ -1060,7 +1087,7 @@ __global__ __launch_bounds__(128, 1) void ngp_mlp_wgrad_recompute_kernel(MlpWgra
       }
 #pragma unroll
       for (int it = 0; it < 2; it++) {
-        const f32x16 acc = layer_tile<2>(Wff, FW_L3, it, lane, cin);
+        const f32x16 acc = layer_tile_b<2>(Wrs, FW_L3, it, lane16, cin);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const _Float16 v = (_Float16)fmaxf(acc[r], 0.0f);
@@ -1072,7 +1099,7 @@ __global__ __launch_bounds__(128, 1) void ngp_mlp_wgrad_recompute_kernel(MlpWgra
       }
 #pragma unroll
       for (int it = 0; it < 2; it++) {
-        const f32x16 acc = layer_tile<4>(Wff, FW_L4, it, lane, h3);
+        const f32x16 acc = layer_tile_b<4>(Wrs, FW_L4, it, lane16, h3);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const _Float16 v = (_Float16)fmaxf(acc[r], 0.0f);
@@ -1101,7 +1128,7 @@ __global__ __launch_bounds__(128, 1) void ngp_mlp_wgrad_recompute_kernel(MlpWgra
     f16x8 d4[4];
 #pragma unroll
     for (int it = 0; it < 2; it++) {
-      const f32x16 acc = layer_tile<1>(Wfb, BW_L5, it, lane, &d5);
+      const f32x16 acc = layer_tile_b<1>(Wrs, FW_NFRAG + BW_L5, it, lane16, &d5);
 #pragma unroll
       for (int r = 0; r < 16; r++) d4[2 * it + (r >> 3)][r & 7] = (m4 >> (16 * it + r)) & 1u ? (_Float16)acc[r] : (_Float16)0;
       stage_chunk64(stage, FU_DY, d4[2 * it], 2 * it, h, col);
@@ -1114,7 +1141,7 @@ __global__ __launch_bounds__(128, 1) void ngp_mlp_wgrad_recompute_kernel(MlpWgra
     f16x8 d3[4];
 #pragma unroll
     for (int it = 0; it < 2; it++) {
-      const f32x16 acc = layer_tile<4>(Wfb, BW_L4, it, lane, d4);
+      const f32x16 acc = layer_tile_b<4>(Wrs, FW_NFRAG + BW_L4, it, lane16, d4);
 #pragma unroll
       for (int r = 0; r < 16; r++) d3[2 * it + (r >> 3)][r & 7] = (m3 >> (16 * it + r)) & 1u ? (_Float16)acc[r] : (_Float16)0;
       stage_chunk64(stage, FU_DY, d3[2 * it], 2 * it, h, col);
@@ -1128,7 +1155,7 @@ __global__ __launch_bounds__(128, 1) void ngp_mlp_wgrad_recompute_kernel(MlpWgra
     __syncthreads();
     f16x8 dd;
     {
-      const f32x16 acc = layer_tile<4>(Wfb, BW_L3, 0, lane, d3);
+      const f32x16 acc = layer_tile_b<4>(Wrs, FW_NFRAG + BW_L3, 0, lane16, d3);
 #pragma unroll
       for (int r = 0; r < 8; r++) dd[r] = (_Float16)acc[r];
       if (h == 0) dd[0] = (_Float16)((float)dd[0] + (float)go[3]);
@@ -1142,7 +1169,7 @@ __global__ __launch_bounds__(128, 1) void ngp_mlp_wgrad_recompute_kernel(MlpWgra
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 2; it++) {
-      const f32x16 acc = layer_tile<1>(Wfb, BW_L2, it, lane, &dd);
+      const f32x16 acc = layer_tile_b<1>(Wrs, FW_NFRAG + BW_L2, it, lane16, &dd);
       f16x8 lo8, hi8;
 #pragma unroll
       for (int r = 0; r < 8; r++) {

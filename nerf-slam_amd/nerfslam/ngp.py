@@ -166,7 +166,7 @@ class NgpNerf:
         self.act = [torch.zeros((u, S), **h) for u in (64, 32, 64, 64)]         # h1T cinT h3T h4T
         self.dact = [torch.zeros((u, S), **h) for u in (16, 64, 64, 16, 64)]    # d5T d4T d3T ddT d1T
         self.partial = torch.zeros((c.wgrad_ksplit, MLP_TOTAL), **f)
-        self.mlp_wgs = 512     # workgroups (= partial weight-gradient slabs) of the fused MLP backward pass: 2 per CU
+        self.mlp_wgs = int(os.environ.get("NS_NGP_MLP_WGS", "512"))     # workgroups (= partial weight-gradient slabs) of the weight-gradient kernel (384 .. 1024 measured: within 2 %)
         self.relu_masks = torch.zeros(6 * S, dtype=torch.int32, device=dev)     # one bit per hidden unit and sample (csrc/ngp_mlp.hip)
         # Table gradient.  One trainer: the round-3 path (csrc/ngp.hip: no count pass, Adam applied to the touched entries in
         # the flush of the accumulation; the gradient buffer is not used).  Replicated trainers: gradient buffer + all-reduce
