@@ -400,7 +400,7 @@ static bool level_is_hashed(const GridLayout& g, int l) {
 
 // dense_only: the hashed levels are handled by the binned path below; the dense levels then get more (smaller) parts
 static int enc_bwd_plan_host(const GridLayout& g, int n_levels, EncBwdPlan& p, bool dense_only, int parts_coarse = NS_ENC_PARTS_COARSE,
-                             int parts_multi = NS_ENC_PARTS_BINNED) {
+                             int parts_multi = NS_ENC_PARTS_BINNED, int max_dense_level = 16) {   // dense levels >= it: not planned
   int k = 0, t = 0;
   for (int l = 0; l < 16; l++) p.slices[l] = p.parts[l] = 0;
   for (int pass = dense_only ? 1 : 0; pass < 2; pass++)  // hashed (1 part) levels first, then the dense ones, finest first
@@ -409,6 +409,7 @@ static int enc_bwd_plan_host(const GridLayout& g, int n_levels, EncBwdPlan& p, b
       const uint32_t hs = g.offset[l + 1] - g.offset[l];
       const bool hashed = level_is_hashed(g, l);
       if (hashed != (pass == 0)) continue;
+      if (!hashed && l >= max_dense_level) continue;
       p.slices[l] = (int)((hs + NS_ENC_SLICE - 1) / NS_ENC_SLICE);
       p.parts[l] = hashed ? 1 : (!dense_only ? NS_ENC_PARTS : (p.slices[l] == 1 ? parts_coarse : parts_multi));
       p.level[k] = l;
@@ -423,7 +424,7 @@ static int enc_bwd_plan_host(const GridLayout& g, int n_levels, EncBwdPlan& p, b
   long base = 0;
   for (int l = 0; l < 16; l++) {
     p.plane_base[l] = base;
-    if (l < n_levels && !level_is_hashed(g, l)) base += (long)p.parts[l] * (long)(g.offset[l + 1] - g.offset[l]);
+    if (l < n_levels && !level_is_hashed(g, l) && l < max_dense_level) base += (long)p.parts[l] * (long)(g.offset[l + 1] - g.offset[l]);
   }
   return t;
 }
@@ -1075,25 +1076,40 @@ __global__ __launch_bounds__(1024) void ngp_enc_bin_accum_kernel(GridLayout g, B
 #define NS_FB_SLOT 512
 #define NS_FB_RUN 4      // consecutive samples per lane
 struct FusedPlan {
-  int nh;            // hashed levels
+  int nh;            // binned levels: the hashed ones and (dense_too) the dense levels of more than one 16384-entry slice
   int level[16];     // k -> level
   int nbins[16];     // k -> bins of the level (<= 64)
+  int slot[16];      // k -> records per (bin, tile) slot: the level's 64 x 512 records per tile, divided among its bins
+  int hashed[16];    // k -> hash or dense index
   int ntiles;        // ceil(N / 1024)
   long ovf_cap;      // entries of the overflow list
 };
 
-static bool fused_plan_host(const GridLayout& g, int n_levels, long N, FusedPlan& f) {
+// Dense levels of ONE slice keep the owner-computes kernel (a workgroup holds the whole level in LDS); with dense_too the larger
+// dense levels go through the bins like the hashed ones: their owner-computes tasks scan every sample once per slice (22 x N
+// sample visits for the default grid's five dense levels) in whole-CU workgroups of 128 KB of LDS that nothing runs next to.
+static int fused_dense_levels(const GridLayout& g, int n_levels, bool dense_too) {
+  int l = 0;
+  while (l < n_levels && !level_is_hashed(g, l) && (!dense_too || g.offset[l + 1] - g.offset[l] <= (uint32_t)NS_ENC_SLICE)) l++;
+  return l;
+}
+
+static bool fused_plan_host(const GridLayout& g, int n_levels, long N, FusedPlan& f, bool dense_too = false) {
   f.nh = 0;
-  for (int l = 0; l < n_levels; l++) {
-    if (!level_is_hashed(g, l)) continue;
+  for (int l = fused_dense_levels(g, n_levels, dense_too); l < n_levels; l++) {
+    const bool hashed = level_is_hashed(g, l);
+    if (!hashed && !dense_too) continue;
     const uint32_t hs = g.offset[l + 1] - g.offset[l];
     const int nb = (int)((hs + NS_FB_SLICE - 1) / NS_FB_SLICE);
     if (nb > NS_FB_BINS) return false;
     f.level[f.nh] = l;
     f.nbins[f.nh] = nb;
+    f.hashed[f.nh] = hashed ? 1 : 0;
+    const int sl = (NS_FB_BINS * NS_FB_SLOT / nb) & ~3;
+    f.slot[f.nh] = sl < 8 * NS_BIN_TILE ? sl : 8 * NS_BIN_TILE;      // (a tile has at most 8 x 1024 records)
     f.nh++;
   }
-  for (int k = f.nh; k < 16; k++) f.level[k] = f.nbins[k] = 0;
+  for (int k = f.nh; k < 16; k++) f.level[k] = f.nbins[k] = f.slot[k] = f.hashed[k] = 0;
   f.ntiles = (int)((N + NS_BIN_TILE - 1) / NS_BIN_TILE);
   f.ovf_cap = (long)f.ntiles * NS_BIN_TILE * 8 * (f.nh > 0 ? f.nh : 1);
   return f.nh > 0;
@@ -1125,6 +1141,16 @@ __device__ __forceinline__ void fb_indices(const uint32_t c[3], uint32_t hs, uin
   for (int corner = 0; corner < 8; corner++) idx[corner] = (hx[corner & 1] ^ hy[(corner >> 1) & 1] ^ hz[corner >> 2]) & (hs - 1u);
 }
 
+__device__ __forceinline__ void fb_indices_any(bool hashed, const uint32_t c[3], uint32_t hs, uint32_t res, uint32_t idx[8]) {
+  if (hashed) {
+    fb_indices(c, hs, idx);
+  } else {
+#pragma unroll
+    for (int corner = 0; corner < 8; corner++)
+      idx[corner] = grid_index_lvl(false, hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2));
+  }
+}
+
 __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, FusedPlan fp, const float* __restrict__ pos,
                                                                const _Float16* __restrict__ dpu, long N, float fixed_scale,
                                                                int* __restrict__ ctr, int* __restrict__ cnt,
@@ -1134,7 +1160,9 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
   __shared__ unsigned long long rec[8 * NS_BIN_TILE];   // 64 KB: the tile's records, bin-sorted
   __shared__ int lbase[NS_FB_BINS + 1], lcnt[NS_FB_BINS], odst[NS_FB_BINS];
   const int k = blockIdx.y, l = fp.level[k], tile = blockIdx.x, tid = threadIdx.x;
-  const uint32_t hs = g.offset[l + 1] - g.offset[l];
+  const uint32_t hs = g.offset[l + 1] - g.offset[l], res = (uint32_t)g.res[l];
+  const bool hashed = fp.hashed[k] != 0;
+  const int slot = fp.slot[k];
   const long nvalid = n_dev ? min(N, (long)*n_dev) : N;
   if ((long)tile * NS_BIN_TILE >= nvalid) return;       // (uniform) nothing marched into this tile
   if (tid < NS_FB_BINS) lcnt[tid] = 0;
@@ -1235,7 +1263,7 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
   for (int r = 0; r < NS_FB_RUN; r++) {
     if (r < nrun) {
       uint32_t idx[8];
-      fb_indices(run[r].c, hs, idx);
+      fb_indices_any(hashed, run[r].c, hs, res, idx);
 #pragma unroll
       for (int corner = 0; corner < 8; corner++)   // (a contribution that rounds to zero in both fields is not a record: most
         rank[r][corner] = (run[r].a[corner] | run[r].b[corner]) != 0   //  corners of a converged scene's tiny gradients)
@@ -1253,15 +1281,15 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
     }
     lbase[tid] = ci - c;
     if (tid == 63) lbase[64] = ci;
-    cnt[(long)(k * NS_FB_BINS + tid) * fp.ntiles + tile] = min(c, NS_FB_SLOT);
-    odst[tid] = c > NS_FB_SLOT ? atomicAdd(&ctr[0], c - NS_FB_SLOT) : 0;
+    cnt[(long)(k * NS_FB_BINS + tid) * fp.ntiles + tile] = min(c, slot);
+    odst[tid] = c > slot ? atomicAdd(&ctr[0], c - slot) : 0;
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < NS_FB_RUN; r++) {
     if (r < nrun) {
       uint32_t idx[8];
-      fb_indices(run[r].c, hs, idx);
+      fb_indices_any(hashed, run[r].c, hs, res, idx);
 #pragma unroll
       for (int corner = 0; corner < 8; corner++)
         if (rank[r][corner] >= 0)
@@ -1275,13 +1303,13 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
   const int wave = tid >> 6, lane = tid & 63;
   for (int b = wave; b < NS_FB_BINS; b += 4) {
     const int b0 = lbase[b], n = lbase[b + 1] - b0;
-    unsigned long long* __restrict__ dst = queue + ((long)(k * NS_FB_BINS + b) * fp.ntiles + tile) * NS_FB_SLOT;
+    unsigned long long* __restrict__ dst = queue + (long)k * NS_FB_BINS * fp.ntiles * NS_FB_SLOT + ((long)b * fp.ntiles + tile) * slot;
     for (int e = lane; e < n; e += 64) {
       const unsigned long long r = rec[b0 + e];
-      if (e < NS_FB_SLOT) {
+      if (e < slot) {
         dst[e] = r;
       } else {
-        const long o = (long)odst[b] + (e - NS_FB_SLOT);
+        const long o = (long)odst[b] + (e - slot);
         if (o < fp.ovf_cap) ovf[o] = make_ulonglong2(r, (unsigned long long)((k << 8) | b));
         else ctr[1] = 1;   // cannot happen with the worst-case list; flagged, never silent
       }
@@ -1328,6 +1356,8 @@ __global__ __launch_bounds__(NS_FB_THREADS) void ngp_enc_faccum_kernel(GridLayou
   }
   __syncthreads();
   const long row = (long)(k * NS_FB_BINS + b) * fp.ntiles;
+  const int slot = fp.slot[k];
+  const unsigned long long* __restrict__ qbin = queue + (long)k * NS_FB_BINS * fp.ntiles * NS_FB_SLOT + (long)b * fp.ntiles * slot;
   const int wave = tid >> 6, lane = tid & 63;
   for (int t0 = 0; t0 < ntv; t0 += NS_FB_THREADS) {
     __syncthreads();
@@ -1340,7 +1370,7 @@ __global__ __launch_bounds__(NS_FB_THREADS) void ngp_enc_faccum_kernel(GridLayou
 #pragma unroll
       for (int u = 0; u < NS_FB_GROUP; u++) {
         c[u] = tt + u < nt ? scnt[tt + u] : 0;
-        const unsigned long long* __restrict__ q = queue + (row + t0 + tt + u) * NS_FB_SLOT;
+        const unsigned long long* __restrict__ q = qbin + (long)(t0 + tt + u) * slot;
         r[u][0] = lane < c[u] ? q[lane] : 0ull;          // (a zero record adds zero to entry 0: no branch in the add loop)
         r[u][1] = lane + 64 < c[u] ? q[lane + 64] : 0ull;
       }
@@ -1351,7 +1381,7 @@ __global__ __launch_bounds__(NS_FB_THREADS) void ngp_enc_faccum_kernel(GridLayou
       }
 #pragma unroll
       for (int u = 0; u < NS_FB_GROUP; u++) {            // slots filled beyond the mean: the rest of the run
-        const unsigned long long* __restrict__ q = queue + (row + t0 + tt + u) * NS_FB_SLOT;
+        const unsigned long long* __restrict__ q = qbin + (long)(t0 + tt + u) * slot;
         for (int e = lane + 128; e < c[u]; e += 64) fb_add(tab, q[e]);
       }
     }
@@ -2358,7 +2388,7 @@ extern "C" size_t ns_ngp_encode_backward_fused_workspace_bytes(int n_levels, int
   GridLayout g;
   if (grid_layout_host(c, g) != NS_OK) return 0;
   FusedPlan fp;
-  if (!fused_plan_host(g, n_levels, max_samples > 0 ? max_samples : 1, fp)) return 0;
+  if (!fused_plan_host(g, n_levels, max_samples > 0 ? max_samples : 1, fp, true)) return 0;   // (the larger of the two plans)
   return fused_ws_bytes(fp, g, n_levels);
 }
 
@@ -2382,8 +2412,14 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
     return NS_ENOSUP;
   }
   if (N <= 0) return NS_OK;
+  // NS_ENC_DENSE_BINNED=1: the multi-slice dense levels (30^3, 42^3, 58^3 entries) go through the bins too (per-level slot sizes,
+  // dense indices in the scatter).  Measured: the training step 0.372 -> 0.365 ms (192 -> 32 whole-CU owner-computes workgroups),
+  // but on the all-live micro-bench the accumulate pass 135 -> 301 us -- a dense level has 4 / 10 / 26 bins for the records that a
+  // hashed level spreads over 64, and every sample of a ray hits the same few cells of it: long, conflict-ridden bins set the
+  // kernel's time.  Off by default; kept for A/B (sums bit-identical either way: test_fused_table_gradient_matches_the_other_paths).
+  static const bool dense_too = [] { const char* e = getenv("NS_ENC_DENSE_BINNED"); return e != nullptr && e[0] == '1'; }();
   FusedPlan fp;
-  if (!fused_plan_host(g, n_levels, N, fp)) {
+  if (!fused_plan_host(g, n_levels, N, fp, dense_too)) {
     ns_set_error("ns_ngp_encode_backward_fused: no hashed level / tables above 64 x 8192 entries: use ns_ngp_encode_backward");
     return NS_ENOSUP;
   }
@@ -2413,8 +2449,9 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
     ad.inv_fixed_scale = 1.0f / fixed_scale;
     ad.ctl = ctl;
   }
-  const long nd = dense_prefix_entries(g, n_levels);
-  NS_REQUIRE(nd >= 0, "ns_ngp_encode_backward_fused: dense levels above hashed ones");
+  NS_REQUIRE(dense_prefix_entries(g, n_levels) >= 0, "ns_ngp_encode_backward_fused: dense levels above hashed ones");
+  const int n_rl = fused_dense_levels(g, n_levels, dense_too);     // dense levels that keep the owner-computes path
+  const long nd = (long)g.offset[n_rl];
   if (parts & 1) {
     const int vec = (N % 4 == 0 && ((uintptr_t)positions % 16) == 0 && ((uintptr_t)dLdoutT % 8) == 0) ? 1 : 0;
     hipLaunchKernelGGL(ngp_enc_fscatter_kernel, dim3(fp.ntiles, fp.nh), dim3(256), 0, st, g, fp, positions, (const _Float16*)dLdoutT,
@@ -2432,17 +2469,22 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
   EncBwdPlan plan;
   const bool rl = N % 8 == 0 && ((uintptr_t)positions % 16) == 0 && ((uintptr_t)dLdoutT % 16) == 0;
   static int rl_pc = 16, rl_pm = 8;      // parts of the single-slice / multi-slice dense levels (NS_ENC_RL_PARTS=coarse,multi)
+  static bool rl_set = false;
   static const bool rl_env = [] {
     const char* e = getenv("NS_ENC_RL_PARTS");
     int a = 0, b = 0;
     if (e && sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= NS_ENC_PARTS_COARSE && b >= 1 && b <= NS_ENC_PARTS_COARSE) {
       rl_pc = a;
       rl_pm = b;
+      rl_set = true;
     }
     return true;
   }();
   (void)rl_env;
-  const int tasks = rl ? enc_bwd_plan_host(g, n_levels, plan, true, rl_pc, rl_pm) : enc_bwd_plan_host(g, n_levels, plan, true);
+  // (with the multi-slice levels binned, the two or three single-slice levels are alone on this path: 64 parts each, or their
+  //  32 workgroups take 130 us when nothing runs next to them)
+  const int tasks = rl ? enc_bwd_plan_host(g, n_levels, plan, true, dense_too && !rl_set ? NS_ENC_PARTS_COARSE : rl_pc, rl_pm, n_rl)
+                       : enc_bwd_plan_host(g, n_levels, plan, true, NS_ENC_PARTS_COARSE, NS_ENC_PARTS_BINNED, n_rl);
   const int blocks = (tasks + 7) / 8 * 8;
   // the dense levels always go through their partial planes here (the reduce pass is where Adam is applied)
   if (parts & 4) {
