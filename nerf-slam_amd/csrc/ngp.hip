@@ -400,7 +400,8 @@ static bool level_is_hashed(const GridLayout& g, int l) {
 
 // dense_only: the hashed levels are handled by the binned path below; the dense levels then get more (smaller) parts
 static int enc_bwd_plan_host(const GridLayout& g, int n_levels, EncBwdPlan& p, bool dense_only, int parts_coarse = NS_ENC_PARTS_COARSE,
-                             int parts_multi = NS_ENC_PARTS_BINNED, int max_dense_level = 16) {   // dense levels >= it: not planned
+                             int parts_multi = NS_ENC_PARTS_BINNED, int max_dense_level = 16,      // dense levels >= it: not planned
+                             int slice_entries = NS_ENC_SLICE) {
   int k = 0, t = 0;
   for (int l = 0; l < 16; l++) p.slices[l] = p.parts[l] = 0;
   for (int pass = dense_only ? 1 : 0; pass < 2; pass++)  // hashed (1 part) levels first, then the dense ones, finest first
@@ -410,7 +411,7 @@ static int enc_bwd_plan_host(const GridLayout& g, int n_levels, EncBwdPlan& p, b
       const bool hashed = level_is_hashed(g, l);
       if (hashed != (pass == 0)) continue;
       if (!hashed && l >= max_dense_level) continue;
-      p.slices[l] = (int)((hs + NS_ENC_SLICE - 1) / NS_ENC_SLICE);
+      p.slices[l] = (int)((hs + slice_entries - 1) / slice_entries);
       p.parts[l] = hashed ? 1 : (!dense_only ? NS_ENC_PARTS : (p.slices[l] == 1 ? parts_coarse : parts_multi));
       p.level[k] = l;
       p.first[k] = t;
@@ -594,12 +595,13 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_lds_kernel(GridLayout g, 
 // A run is 96 B of positions + 2 x 16 B of gradient per lane, loaded as 16-byte vectors one chunk ahead.
 // ---------------------------------------------------------------------------------------------
 #define NS_RL_K 8
-__global__ __launch_bounds__(1024) void ngp_encode_bwd_dense_rl_kernel(GridLayout g, EncBwdPlan plan, const float* __restrict__ pos,
+template <int SLICE, int THREADS>
+__global__ __launch_bounds__(THREADS) void ngp_encode_bwd_dense_rl_kernel(GridLayout g, EncBwdPlan plan, const float* __restrict__ pos,
                                                                        const _Float16* __restrict__ dpu, float* __restrict__ grad,
                                                                        long N, float fixed_scale,
                                                                        unsigned long long* __restrict__ partial,
                                                                        const int* __restrict__ n_dev) {
-  __shared__ unsigned long long tab[NS_ENC_SLICE];
+  __shared__ unsigned long long tab[SLICE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = gridDim.x >> 3;
   const int v = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
@@ -611,11 +613,11 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_dense_rl_kernel(GridLayou
   const int nparts = plan.parts[l];
   const int slice = local / nparts, part = local - slice * nparts;
   const uint32_t hs = g.offset[l + 1] - g.offset[l];
-  const uint32_t lo = (uint32_t)slice * NS_ENC_SLICE;
-  const uint32_t cnt = min((uint32_t)NS_ENC_SLICE, hs - lo);
+  const uint32_t lo = (uint32_t)slice * SLICE;
+  const uint32_t cnt = min((uint32_t)SLICE, hs - lo);
   const float scale = g.scale[l];
   const uint32_t res = (uint32_t)g.res[l], r2 = res * res;
-  for (uint32_t e = tid; e < cnt; e += 1024) tab[e] = 0ull;
+  for (uint32_t e = tid; e < cnt; e += THREADS) tab[e] = 0ull;
   __syncthreads();
   const long nvalid = n_dev ? min(N, (long)*n_dev) : N;
   const long chunks = (nvalid + 64 * NS_RL_K - 1) / (64 * NS_RL_K);   // a wave chunk = 64 runs of 8 samples
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_dense_rl_kernel(GridLayou
     }
   };
   fetch(c_lo + wave);
-  for (long ch = c_lo + wave; ch < c_hi; ch += 16) {
+  for (long ch = c_lo + wave; ch < c_hi; ch += THREADS / 64) {
     float pf[24];
 #pragma unroll
     for (int q = 0; q < 6; q++) {
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_dense_rl_kernel(GridLayou
     }
     const uint32_t gw0[4] = {ng0.x, ng0.y, ng0.z, ng0.w}, gw1[4] = {ng1.x, ng1.y, ng1.z, ng1.w};
     const long i0 = (ch * 64 + lane) * NS_RL_K;
-    fetch(ch + 16);
+    fetch(ch + THREADS / 64);
     uint32_t cur = 0xffffffffu;          // dense index of the current cell's (0,0,0) corner
     unsigned long long acc[8];
 #pragma unroll
@@ -700,10 +702,10 @@ __global__ __launch_bounds__(1024) void ngp_encode_bwd_dense_rl_kernel(GridLayou
   unsigned long long* __restrict__ g64 = reinterpret_cast<unsigned long long*>(grad) + g.offset[l] + lo;
   if (partial != nullptr && nparts > 1) {
     unsigned long long* __restrict__ dst = partial + plan.plane_base[l] + (long)part * hs + lo;
-    for (uint32_t e = tid; e < cnt; e += 1024) dst[e] = tab[e];
+    for (uint32_t e = tid; e < cnt; e += THREADS) dst[e] = tab[e];
     return;
   }
-  for (uint32_t e = tid; e < cnt; e += 1024) {
+  for (uint32_t e = tid; e < cnt; e += THREADS) {
     const unsigned long long word = tab[e];
     if (word == 0ull) continue;
     if (nparts == 1) g64[e] += word; else atomicAdd(&g64[e], word);
@@ -2342,7 +2344,7 @@ extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_h
       if (nd > 0) {
         unsigned long long* partial = queue + bin_ws_queue_bytes(bp) / 8;
         if (rl) {
-          hipLaunchKernelGGL(ngp_encode_bwd_dense_rl_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
+          hipLaunchKernelGGL((ngp_encode_bwd_dense_rl_kernel<NS_ENC_SLICE, 1024>), dim3(blocks), dim3(1024), 0, (hipStream_t)stream, g, plan, positions,
                              (const _Float16*)dLdout, grad_params, N, fixed_scale, partial, n_dev);
           NS_CHECK_LAUNCH("ngp_encode_bwd_dense_rl_kernel");
         } else {
@@ -2483,13 +2485,20 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
   (void)rl_env;
   // (with the multi-slice levels binned, the two or three single-slice levels are alone on this path: 64 parts each, or their
   //  32 workgroups take 130 us when nothing runs next to them)
-  const int tasks = rl ? enc_bwd_plan_host(g, n_levels, plan, true, dense_too && !rl_set ? NS_ENC_PARTS_COARSE : rl_pc, rl_pm, n_rl)
+  // NS_ENC_RL_HALF=1: 8192-entry slices in 512-thread workgroups (64 KB of LDS: they fit next to a scatter workgroup).  Measured:
+  // training step unchanged (0.385-0.389 ms either way), all-live micro-bench 279 -> 311 us (twice the slices scan the samples).
+  static const bool half_slices = getenv("NS_ENC_RL_HALF") != nullptr;
+  const int tasks = rl ? enc_bwd_plan_host(g, n_levels, plan, true, dense_too && !rl_set ? NS_ENC_PARTS_COARSE : rl_pc, rl_pm, n_rl,
+                                           half_slices ? NS_ENC_SLICE / 2 : NS_ENC_SLICE)
                        : enc_bwd_plan_host(g, n_levels, plan, true, NS_ENC_PARTS_COARSE, NS_ENC_PARTS_BINNED, n_rl);
   const int blocks = (tasks + 7) / 8 * 8;
   // the dense levels always go through their partial planes here (the reduce pass is where Adam is applied)
   if (parts & 4) {
-    if (rl) {
-      hipLaunchKernelGGL(ngp_encode_bwd_dense_rl_kernel, dim3(blocks), dim3(1024), 0, st, g, plan, positions,
+    if (rl && half_slices) {
+      hipLaunchKernelGGL((ngp_encode_bwd_dense_rl_kernel<NS_ENC_SLICE / 2, 512>), dim3(blocks), dim3(512), 0, st, g, plan, positions,
+                         (const _Float16*)dLdoutT, grad_params, N, fixed_scale, partial, n_dev);
+    } else if (rl) {
+      hipLaunchKernelGGL((ngp_encode_bwd_dense_rl_kernel<NS_ENC_SLICE, 1024>), dim3(blocks), dim3(1024), 0, st, g, plan, positions,
                          (const _Float16*)dLdoutT, grad_params, N, fixed_scale, partial, n_dev);
       NS_CHECK_LAUNCH("ngp_encode_bwd_dense_rl_kernel");
     } else {
