@@ -90,6 +90,9 @@ import gc as _gc
 
 
 _immortal_graphs = []
+_capture_count_lock = threading.Lock()
+_captures = 0
+_gc_was_enabled = True
 
 
 @_contextlib.contextmanager
@@ -103,12 +106,18 @@ def graph_capture(graph, **kw):
       collection at the head of `torch.cuda.graph` does) made the first replay of the new graph segfault, every time.  The
       graphs of a dropped trainer therefore stay alive until the process ends (three small graphs per (re)capture)."""
     import torch
-    was = _gc.isenabled()
-    _gc.disable()
+    global _captures, _gc_was_enabled
+    with _capture_count_lock:            # (captures may overlap across threads: the collector comes back with the LAST one)
+        if _captures == 0:
+            _gc_was_enabled = _gc.isenabled()
+            _gc.disable()
+        _captures += 1
     try:
         with torch.cuda.graph(graph, **kw):
             yield
     finally:
         _immortal_graphs.append(graph)
-        if was:
-            _gc.enable()
+        with _capture_count_lock:
+            _captures -= 1
+            if _captures == 0 and _gc_was_enabled:
+                _gc.enable()

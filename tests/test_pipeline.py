@@ -105,3 +105,35 @@ def test_dead_consumer_does_not_block_the_producer():
     with pytest.raises(RuntimeError):
         q.put({"k": 2})                       # would have blocked forever
     assert time.time() - t0 < 5
+
+
+def test_graph_capture_keeps_the_collector_off_until_the_last_capture_ends(monkeypatch):
+    """nerfslam._lib.graph_capture: the cyclic GC goes off with the first capture and comes back with the LAST one (captures of
+    two threads may overlap), and every captured graph object stays referenced (never destroyed).  torch.cuda.graph itself is
+    replaced by a no-op here: the bookkeeping is host logic."""
+    import contextlib
+    import gc
+    import torch
+    from nerfslam import _lib
+
+    @contextlib.contextmanager
+    def fake_graph(g, **kw):
+        yield
+    monkeypatch.setattr(torch.cuda, "graph", fake_graph)
+    a, b = object(), object()
+    n0 = len(_lib._immortal_graphs)
+    assert gc.isenabled()
+    with _lib.graph_capture(a):
+        assert not gc.isenabled()
+        with _lib.graph_capture(b, capture_error_mode="thread_local"):
+            assert not gc.isenabled()
+        assert not gc.isenabled()                 # the outer capture is still running
+    assert gc.isenabled() and _lib._captures == 0
+    assert _lib._immortal_graphs[n0:] == [b, a]
+    gc.disable()                                  # a caller that runs without the collector keeps it off
+    try:
+        with _lib.graph_capture(object()):
+            pass
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
