@@ -129,7 +129,8 @@ class NgpNerf:
         # identical optimiser passes.  The f32 master copy and the moments of the other shards are not kept current (nothing
         # reads them: every kernel of the step reads the f16 copy).
         n_entries = self.n_grid // 2
-        self.shard_entries = ((n_entries + self.world - 1) // self.world + 1023) // 1024 * 1024 if self.world > 1 else n_entries
+        from .parallel import shard_size
+        self.shard_entries = shard_size(n_entries, self.world)
         pad_params = 2 * self.shard_entries * self.world if self.world > 1 else self.n_grid
         self.grid_half = torch.zeros(pad_params, dtype=torch.float16, device=dev)
         self.grid_half[:self.n_grid] = self.grid_master.half()
@@ -665,16 +666,10 @@ class NgpNerf:
         import torch.distributed as dist
         R, Ns = self.world, self.shard_entries
         if self.cfg.grad_fixed_scale > 0:
-            send = self.grid_grad.view(torch.int64)                      # [R * Ns] packed words, shard r = entries [r Ns, (r+1) Ns)
-            try:
-                dist.all_to_all_single(self._recv.view(-1), send, group=self.group)
-            except Exception:                                             # a backend without device all-to-all (gloo): via the host
-                h_in, h_out = send.cpu(), torch.empty((R * Ns,), dtype=torch.int64)
-                dist.all_to_all_single(h_out, h_in, group=self.group)
-                self._recv.view(-1).copy_(h_out)
-            torch.sum(self._recv, dim=0, out=self._gshard)               # exact integer sum, fixed order
+            from .parallel import exchange_sharded
+            # [R * Ns] packed words, shard r = entries [r Ns, (r+1) Ns): one all-to-all, exact integer sum in rank order
+            wire = exchange_sharded(self.grid_grad.view(torch.int64), self._recv, self._gshard, self.group)
             self.grid_grad.zero_()                                       # (the streaming Adam pass that used to clear it is gone)
-            wire = (R - 1) * Ns * 8
         else:
             dist.all_reduce(self.grid_grad, op=dist.ReduceOp.SUM, group=self.group)
             wire = 2 * (R - 1) * self.grid_grad.numel() * 4 // R
@@ -685,16 +680,8 @@ class NgpNerf:
 
     def _gather_parameters(self):
         """every trainer's freshly updated shard of the f16 table -> all trainers"""
-        import torch.distributed as dist
-        R, Ns = self.world, self.shard_entries
-        mine = self.grid_half[2 * Ns * self.rank: 2 * Ns * (self.rank + 1)]
-        try:
-            dist.all_gather_into_tensor(self.grid_half, mine.clone(), group=self.group)
-        except Exception:
-            h = torch.empty(self.grid_half.shape, dtype=torch.float16)
-            dist.all_gather_into_tensor(h, mine.cpu(), group=self.group)
-            self.grid_half.copy_(h)
-        self.bytes_allreduced = getattr(self, "bytes_allreduced", 0) + (R - 1) * 2 * Ns * 2
+        from .parallel import gather_shards
+        self.bytes_allreduced = getattr(self, "bytes_allreduced", 0) + gather_shards(self.grid_half, self.rank, self.group)
 
     def _grow_camera_state(self, n):
         """per-view Adam moments of the pose refinement: GROWN when keyframes are added (a reset would restart the bias

@@ -105,3 +105,42 @@ class ShardedBA:
         """depth maps whose update on this rank is the real one: the sources of this rank's edges, plus (rank 0) the
         window frames that are nobody's source (their update is the prior-only one on every rank)"""
         return self._owned
+
+
+# ---- replicated NeRF trainers: the table gradient lands SHARDED, the updated parameters are gathered (SURVEY 8(e) row 1) ----
+def shard_size(n_entries, world):
+    """entries per trainer: the table split evenly, rounded up to 1024 (every trainer's shard then starts on a bin boundary)"""
+    return ((n_entries + world - 1) // world + 1023) // 1024 * 1024 if world > 1 else n_entries
+
+
+def exchange_sharded(send, recv, out_shard, group=None):
+    """send: [world * Ns] packed int64 gradient words of THIS trainer (shard r = entries [r Ns, (r + 1) Ns)); recv: scratch
+    [world, Ns]; out_shard [Ns] <- the sum over the trainers of shard `rank`, added in rank order (integer: exact, and the same on
+    every run).  One all-to-all: every trainer sends (world - 1) / world of its buffer once -- an all-reduce would move twice that
+    and leave every trainer with sums it then does not need (Adam runs on the own shard only).  Backends without a device
+    all-to-all (gloo) go through host tensors."""
+    world, Ns = recv.shape
+    assert send.numel() == world * Ns and out_shard.numel() == Ns
+    try:
+        dist.all_to_all_single(recv.view(-1), send, group=group)
+    except Exception:                                             # (gloo: no all-to-all on device tensors)
+        h_in, h_out = send.cpu(), torch.empty((world * Ns,), dtype=send.dtype)
+        dist.all_to_all_single(h_out, h_in, group=group)
+        recv.view(-1).copy_(h_out)
+    torch.sum(recv, dim=0, out=out_shard)
+    return (world - 1) * Ns * send.element_size()                 # bytes this trainer put on the wire
+
+
+def gather_shards(full, rank, group=None):
+    """full: [world * n] tensor whose slice [rank n, (rank + 1) n) this trainer has just updated -> every trainer's slice, in
+    place (the f16 working copy of the table after the sharded Adam step)."""
+    world = dist.get_world_size(group)
+    n = full.numel() // world
+    mine = full[rank * n:(rank + 1) * n].clone()
+    try:
+        dist.all_gather_into_tensor(full, mine, group=group)
+    except Exception:
+        h = torch.empty(full.shape, dtype=full.dtype)
+        dist.all_gather_into_tensor(h, mine.cpu(), group=group)
+        full.copy_(h)
+    return (world - 1) * n * full.element_size()

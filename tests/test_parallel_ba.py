@@ -138,3 +138,48 @@ def test_sharded_iteration_touches_only_owned_depth_maps(dev):
         owned.append(sh.owned_depth_maps())
     assert len(np.intersect1d(owned[0], owned[1])) == 0
     assert np.array_equal(np.union1d(owned[0], owned[1]), kx)
+
+
+# ---- replicated NeRF trainers: sharded gradient exchange (nerfslam.parallel.exchange_sharded / gather_shards) ----
+def _exchange_worker(rank, world, port, n_entries, q):
+    from nerfslam.parallel import exchange_sharded, gather_shards, shard_size
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Ns = shard_size(n_entries, world)
+        g = torch.Generator().manual_seed(100 + rank)
+        # packed words as the trainers hold them: two signed 32-bit fixed-point fields per entry, zero beyond the table
+        lo = torch.randint(-2 ** 20, 2 ** 20, (n_entries,), generator=g, dtype=torch.int64)
+        hi = torch.randint(-2 ** 20, 2 ** 20, (n_entries,), generator=g, dtype=torch.int64)
+        send = torch.zeros(world * Ns, dtype=torch.int64)
+        send[:n_entries] = lo + (hi << 32)
+        recv, shard = torch.zeros((world, Ns), dtype=torch.int64), torch.zeros(Ns, dtype=torch.int64)
+        wire = exchange_sharded(send, recv, shard)
+        ref = send.clone()
+        dist.all_reduce(ref)                                      # what a dense all-reduce would have given everybody
+        ok = torch.equal(shard, ref[rank * Ns:(rank + 1) * Ns]) and wire == (world - 1) * Ns * 8
+        # every trainer "updates" its shard of the f16 table, then the shards are gathered
+        full = torch.zeros(world * 2 * Ns, dtype=torch.float16)
+        full[rank * 2 * Ns:(rank + 1) * 2 * Ns] = float(rank + 1)
+        gather_shards(full, rank)
+        want = torch.cat([torch.full((2 * Ns,), float(r + 1), dtype=torch.float16) for r in range(world)])
+        q.put((rank, bool(ok), bool(torch.equal(full, want))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gradient_exchange_equals_allreduce(world):
+    """the all-to-all of packed int64 gradient shards + the sum in rank order gives every trainer exactly its slice of the dense
+    all-reduce; the all-gather returns every trainer's updated parameter shard to all of them (table size not a multiple of
+    world x 1024: the last shard is padded)"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_exchange_worker, args=(r, world, port, 5000, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+    assert res == [(r, True, True) for r in range(world)]
