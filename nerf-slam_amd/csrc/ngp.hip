@@ -1567,6 +1567,48 @@ __global__ __launch_bounds__(1024) void ngp_camera_grad_reduce_kernel(const floa
   }
 }
 
+// The same for up to NS_CAM_SMALL views (the SLAM case: a dozen keyframes in the mapper at a time), as a workgroup that fits
+// ANYWHERE: 4 waves, 24 KB of LDS (a private table per wave, added up in wave order), four rays per lane with all their loads in
+// flight.  The kernel above is one 1024-thread workgroup with 98 KB of LDS at the tail of the pose chain, while two accumulate
+// workgroups of the table gradient sit on every CU: it waited for a whole CU to drain (21-58 us in the step's timeline).
+#define NS_CAM_SMALL 256
+__global__ __launch_bounds__(256) void ngp_camera_grad_reduce_small_kernel(const float* __restrict__ ray_g, const int* __restrict__ ray_n,
+                                                                           const int* __restrict__ ray_img, float* __restrict__ cam_grad,
+                                                                           int Rcap, int n_images, const int* __restrict__ ctl) {
+  __shared__ float tab[4 * NS_CAM_SMALL * 6];
+  const int R = ctl ? min(ctl[NS_CTL_RAYS], Rcap) : Rcap;
+  const int nimg = min(n_images, NS_CAM_SMALL), stride = nimg * 6;
+  for (int e = threadIdx.x; e < 4 * stride; e += 256) tab[e] = 0.0f;
+  __syncthreads();
+  float* mine = tab + (threadIdx.x >> 6) * stride;
+  for (int r0 = threadIdx.x; r0 < R; r0 += 4 * 256) {
+    int img[4];
+    float gv[4][6];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = r0 + u * 256;
+      const bool ok = r < R;
+      const int rr = ok ? r : 0;
+      const int n = ray_n[rr], im = ray_img[rr];
+      const float2* __restrict__ gp = reinterpret_cast<const float2*>(ray_g + (long)rr * 6);
+      const float2 a = gp[0], b = gp[1], c = gp[2];
+      gv[u][0] = a.x; gv[u][1] = a.y; gv[u][2] = b.x; gv[u][3] = b.y; gv[u][4] = c.x; gv[u][5] = c.y;
+      img[u] = (ok && n > 0 && im >= 0 && im < nimg) ? im : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (img[u] < 0) continue;
+#pragma unroll
+      for (int k = 0; k < 6; k++) atomicAdd(&mine[img[u] * 6 + k], gv[u][k]);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < stride; e += 256) {
+    const float v = (tab[e] + tab[stride + e]) + (tab[2 * stride + e] + tab[3 * stride + e]);
+    if (v != 0.0f) cam_grad[e] += v;
+  }
+}
+
 // one lane per image: Adam on (dt, dw), then c2w <- [exp(dw) R | t + dt]; clears the gradient
 __global__ __launch_bounds__(64) void ngp_camera_step_kernel(float* __restrict__ c2w, float* __restrict__ cam_grad,
                                                              float* __restrict__ m1, float* __restrict__ m2, int n, float c1,
@@ -2584,8 +2626,12 @@ extern "C" int ns_ngp_camera_gradient_2stage(const float* dLdpos, const float* t
                      ray_start, ray_n, ray_img, pos_inv, cam_grad, R, ctl, ray_scratch);
   NS_CHECK_LAUNCH("ngp_camera_grad_kernel");
   if (ray_scratch != nullptr) {
-    hipLaunchKernelGGL(ngp_camera_grad_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ray_scratch, ray_n, ray_img,
-                       cam_grad, R, n_images, ctl);
+    if (n_images <= NS_CAM_SMALL)
+      hipLaunchKernelGGL(ngp_camera_grad_reduce_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ray_scratch, ray_n, ray_img,
+                         cam_grad, R, n_images, ctl);
+    else
+      hipLaunchKernelGGL(ngp_camera_grad_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ray_scratch, ray_n, ray_img,
+                         cam_grad, R, n_images, ctl);
     NS_CHECK_LAUNCH("ngp_camera_grad_reduce_kernel");
   }
   return NS_OK;
