@@ -7,7 +7,11 @@
 //
 // Right-looking blocked Cholesky, block NB = 32, two launches per block column:
 //   panel    : every workgroup factors the 32 x 32 diagonal block in LDS (redundantly: cheaper than a launch and a
-//              dependency), then solves X L_kk^T = W[rows, k-block] for its 256 rows, one row per lane in registers
+//              dependency), then solves X L_kk^T = W[rows, k-block] for its 256 rows, one row per lane in registers.
+//              The UNFACTORED block in W is read by every workgroup of the launch and never written: workgroup 0 leaves
+//              the factor in a separate array of diagonal blocks (Dfac, behind W in the workspace), which the back
+//              substitution reads.  (Writing it back in place would race with late-dispatched workgroups that still
+//              have to read the input block -- nothing orders the workgroups of one launch.)
 //   trailing : W[i, j] -= P_i . P_j for the rows below and the columns right of the block, 64 x 64 tiles, 4 x 4 per lane,
 //              operands staged through LDS.  Plain v_fma_f64: on CDNA4 the vector and matrix f64 peaks are the same
 //              (78.6 TFLOP/s), so there is nothing for MFMA to win here, and n^3/3 = 1.2 GFLOP at 6P = 1536.
@@ -24,6 +28,7 @@ struct LargeArgs {
   double* W;
   int n, nrows;      // system size; rows of W (n + 1 or 2n + 1)
   int32_t* info;     // device flag: first non-positive pivot + 1
+  double* Dfac;      // [ceil(n / 32)][32 x 32] factored diagonal blocks (lower triangle, row-major, ld = 32)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void bsl_hfull_kernel(LargeArgs a, double* __r
 
 // ---------------------------------------------------------------------------------------------------------------------
 // panel: block column k0 .. k0+nb.  Workgroup b owns rows k0 + nb + 256 b ... (one per lane); workgroup 0 also writes the
-// factored diagonal block back.
+// factored diagonal block to a.Dfac (never into W: see the header).
 __global__ __launch_bounds__(256) void bsl_panel_kernel(LargeArgs a, int k0) {
   __shared__ double D[LNB * LPAD];
   __shared__ double rdiag[LNB];
@@ -114,11 +119,13 @@ __global__ __launch_bounds__(256) void bsl_panel_kernel(LargeArgs a, int k0) {
     }
     __syncthreads();
   }
-  if (blockIdx.x == 0)
+  if (blockIdx.x == 0) {
+    double* df = a.Dfac + (long)(k0 / LNB) * (LNB * LNB);
     for (int idx = tid; idx < LNB * LNB; idx += 256) {
       const int r = idx / LNB, c = idx % LNB;
-      if (r < nb && c <= r) a.W[(long)(k0 + r) * n + k0 + c] = D[r * LPAD + c];
+      df[idx] = (r < nb && c <= r) ? D[r * LPAD + c] : 0.0;
     }
+  }
   const int row = k0 + nb + blockIdx.x * 256 + tid;
   if (row >= a.nrows) return;
   double X[LNB];
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(1024) void bsl_backsolve_kernel(LargeArgs a, float*
     const int j0 = jb * LNB, nb = min(LNB, n - j0);
     for (int idx = tid; idx < LNB * LNB; idx += 1024) {
       const int r = idx / LNB, c = idx % LNB;
-      if (r < nb && c <= r) D[r * LPAD + c] = a.W[(long)(j0 + r) * n + j0 + c];
+      if (r < nb && c <= r) D[r * LPAD + c] = a.Dfac[(long)jb * (LNB * LNB) + idx];
     }
     __syncthreads();
     if (tid < 64) {                  // wave 0: column-oriented substitution, lane c owns x[j0 + c]
@@ -304,7 +311,8 @@ __global__ void bsl_retract_kernel(const float* __restrict__ dx, float* __restri
 extern "C" size_t ns_ba_solve_large_workspace_bytes(int n6, int want_inv) {
   if (n6 <= 0) return 0;
   const size_t rows = want_inv ? 2 * (size_t)n6 + 1 : (size_t)n6 + 1;
-  return rows * (size_t)n6 * sizeof(double);
+  const size_t nblk = ((size_t)n6 + LNB - 1) / LNB;
+  return (rows * (size_t)n6 + nblk * LNB * LNB) * sizeof(double);
 }
 
 extern "C" int ns_ba_solve_large(const float* H, const float* v, float* world_T_body, float* cam_T_world,
@@ -332,6 +340,7 @@ extern "C" int ns_ba_solve_large(const float* H, const float* v, float* world_T_
   a.n = n;
   a.nrows = want_inv ? 2 * n + 1 : n + 1;
   a.info = info;
+  a.Dfac = a.W + (size_t)a.nrows * n;
   const long total = (long)a.nrows * n;
   hipLaunchKernelGGL(bsl_load_kernel, dim3((unsigned)min((long)2048, (total + 255) / 256)), dim3(256), 0, st, H, v, ep, lm,
                      a, want_inv);

@@ -15,6 +15,7 @@
 // All activations are f16 channels-last, statistics f32 partials combined in f64, eps and the biased variance are
 // InstanceNorm2d's defaults (extractor.py:133-144 builds it without affine parameters).
 #include "common.h"
+#include <atomic>
 
 typedef _Float16 en_f16x8 __attribute__((ext_vector_type(8)));
 
@@ -76,10 +77,14 @@ __global__ __launch_bounds__(256) void enc_im2col_3x3s2_kernel(const _Float16* _
 // grid (P, N); thread = (pixel group g = tid / C8, piece = tid % C8): 16-byte loads, whole rows coalesced.
 // ---------------------------------------------------------------------------------------------
 #define ENC_IN_MAXN 4096
-__device__ unsigned int enc_in_ticket[ENC_IN_MAXN];   // arrivals per image; the last arrival resets its entry
+#define ENC_IN_SLOTS 32
+// arrivals per image; the last arrival resets its entry.  One row of counters per LAUNCH, handed out round-robin by the host
+// entry point: two statistics launches in flight at once (feature and context net on different streams, parallel graph
+// branches) then never share a counter unless 32 further launches were issued in between.
+__device__ unsigned int enc_in_ticket[ENC_IN_SLOTS][ENC_IN_MAXN];
 
 __global__ __launch_bounds__(256) void enc_in_stats_kernel(const _Float16* __restrict__ x, float* __restrict__ partial, int HW, int C8,
-                                                           int P) {
+                                                           int P, int slot) {
   __shared__ float red[4][2][128];
   __shared__ double ps[256], pq[256];
   __shared__ unsigned int s_ticket;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256) void enc_in_stats_kernel(const _Float16* __res
   __syncthreads();
   if (tid == 0) {
     __threadfence();
-    s_ticket = atomicAdd(&enc_in_ticket[n], 1u);
+    s_ticket = atomicAdd(&enc_in_ticket[slot][n], 1u);
     __threadfence();
   }
   __syncthreads();
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void enc_in_stats_kernel(const _Float16* __res
     }
     __syncthreads();
     if (tid < ncol) rows[tid] = (float)pq[tid];     // totals -> row 0 (every row has been read)
-    if (tid == 0) enc_in_ticket[n] = 0u;
+    if (tid == 0) enc_in_ticket[slot][n] = 0u;
   }
 }
 
@@ -263,7 +268,10 @@ extern "C" int ns_enc_in_stats(const void* x, float* partial, int N, int HW, int
              "ns_enc_in_stats: bad shape (N %d <= 4096, HW %d, C %d: 32, 64 or 128 channels)", N, HW, C);
   NS_REQUIRE(((uintptr_t)x % 16) == 0, "ns_enc_in_stats: 16-byte alignment");
   const int P = ns_enc_in_parts(HW);
-  hipLaunchKernelGGL(enc_in_stats_kernel, dim3(P, N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, partial, HW, C / 8, P);
+  static std::atomic<unsigned> next_slot{0};
+  const int slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) % ENC_IN_SLOTS);
+  hipLaunchKernelGGL(enc_in_stats_kernel, dim3(P, N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, partial, HW, C / 8, P,
+                     slot);
   NS_CHECK_LAUNCH("enc_in_stats_kernel");
   return NS_OK;
 }

@@ -2539,6 +2539,7 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
     if (rl && half_slices) {
       hipLaunchKernelGGL((ngp_encode_bwd_dense_rl_kernel<NS_ENC_SLICE / 2, 512>), dim3(blocks), dim3(512), 0, st, g, plan, positions,
                          (const _Float16*)dLdoutT, grad_params, N, fixed_scale, partial, n_dev);
+      NS_CHECK_LAUNCH("ngp_encode_bwd_dense_rl_kernel<half>");
     } else if (rl) {
       hipLaunchKernelGGL((ngp_encode_bwd_dense_rl_kernel<NS_ENC_SLICE, 1024>), dim3(blocks), dim3(1024), 0, st, g, plan, positions,
                          (const _Float16*)dLdoutT, grad_params, N, fixed_scale, partial, n_dev);

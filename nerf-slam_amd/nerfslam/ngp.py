@@ -49,7 +49,10 @@ class NgpConfig:
     grid_update_every: int = 16
     grid_rule: str = "subset"            # occupancy refresh: "subset" (2^18 uniform cells per update) | "ngp" (instant-ngp's rule)
     grid_decay: float = 0.95
-    grid_decay_all: bool = False         # subset rule: decay every cell on every update (round 2) instead of the drawn ones only
+    grid_decay_all: bool = True          # subset rule: EVERY cell decays on every update, as in instant-ngp's rule (max(prev * decay,
+                                         # new), new = 0 for cells not drawn), at grid_decay ** (cells drawn / half the grid): the same
+                                         # fading per re-evaluation as instant-ngp, which redraws half the grid per update.  False:
+                                         # only the drawn cells decay (a once-occupied cell then never fades unless it is drawn)
     min_optical_thickness: float = 0.01
     near: float = 0.05
     wgrad_ksplit: int = 256
@@ -93,10 +96,12 @@ def unpack_fixed(words, scale):
 
 
 class NgpNerf:
-    def __init__(self, cfg=None, device="cuda:0", seed=1337, group=None, world=None, rank=None):
+    def __init__(self, cfg=None, device="cuda:0", seed=1337, group=None, world=None, rank=None, replicated=None):
         """group / world / rank: REPLICATED trainers: every replica holds the full model and the same image
         set, samples its own rays (seed + rank) and the gradients are summed over the replicas before Adam -- one
-        all-reduce of the hash-grid gradient (packed fixed-point words add exactly as int64) and one of the MLP gradient."""
+        all-reduce of the hash-grid gradient (packed fixed-point words add exactly as int64) and one of the MLP gradient.
+        replicated=True runs the replicated trainers' launch sequence (gradient buffer, collectives, sharded Adam, parameter
+        gather) even in a group of ONE: the RCCL path of the step is then executable on a one-GPU box (tests/test_rccl_gpu.py)."""
         self.cfg = cfg or NgpConfig()
         self.device = torch.device(device)
         self.group = group
@@ -105,6 +110,7 @@ class NgpNerf:
             on = dist.is_available() and dist.is_initialized() and group is not None
             world, rank = (dist.get_world_size(group), dist.get_rank(group)) if on else (1, 0)
         self.world, self.rank = int(world), int(rank or 0)
+        self.replicated = self.world > 1 if replicated is None else bool(replicated) or self.world > 1
         # replicas start from the SAME parameters and keep the same occupancy-grid sampling sequence (base seed); only the
         # ray selection differs (seed + rank), so the summed gradient is the gradient of an R-times larger batch
         base_seed, seed = int(seed), int(seed) + self.rank
@@ -136,7 +142,7 @@ class NgpNerf:
         self.grid_half[:self.n_grid] = self.grid_master.half()
         self.mlp_half = self.mlp_master.half()
         self.grid_grad, self.mlp_grad = torch.zeros(pad_params, **f), torch.zeros(MLP_TOTAL, **f)
-        if self.world > 1:
+        if self.replicated:
             self._recv = torch.zeros((self.world, self.shard_entries), dtype=torch.int64, device=dev)
             self._gshard = torch.zeros(self.shard_entries, dtype=torch.int64, device=dev)
         self.grid_m1, self.grid_m2 = torch.zeros(self.n_grid, **f), torch.zeros(self.n_grid, **f)
@@ -172,7 +178,7 @@ class NgpNerf:
         # Table gradient.  One trainer: the round-3 path (csrc/ngp.hip: no count pass, Adam applied to the touched entries in
         # the flush of the accumulation; the gradient buffer is not used).  Replicated trainers: gradient buffer + all-reduce
         # + streaming Adam, so the binned path that writes the buffer keeps its own workspace.
-        self.fused_adam = self.world == 1 and c.grad_fixed_scale > 0 and not os.environ.get("NS_NGP_TWO_PASS_ADAM")
+        self.fused_adam = not self.replicated and c.grad_fixed_scale > 0 and not os.environ.get("NS_NGP_TWO_PASS_ADAM")
         self.enc_ws_bytes = int(lib().ns_ngp_encode_backward_fused_workspace_bytes(*self._grid_args(), C.c_long(c.max_samples)))
         self.fused_ws = c.grad_fixed_scale > 0 and self.enc_ws_bytes > 0 and not os.environ.get("NS_NGP_R02_BACKWARD")
         if self.fused_ws:
@@ -331,8 +337,9 @@ class NgpNerf:
                                  ptr(t["ray_start"]), ptr(t["ray_n"]), ptr(t["s_pos"]), ptr(t["s_dir"]), ptr(t["s_dt"]),
                                  ptr(t["s_t"]), ctl, st), "ngp_march")
 
-    def _enqueue_step(self, x):
+    def _enqueue_step(self, x, phase="all"):
         """one optimiser step on set `x` on the current stream (+ two side streams); no host synchronisation, no allocation.
+        phase="pre" (replicated trainers): everything up to the gradient exchange; returns the closure that enqueues what follows it.
 
         main  : encode (+ Jacobian rows) -> MLP forward (bit masks) -> composite (loss per ray) -> [fork 1] activation gradients
                 -> [fork 2] table gradient of the HASHED levels with Adam in its flush (scatter, accumulate)
@@ -397,7 +404,7 @@ class NgpNerf:
                                       ptr(X["r_rgb"]), ptr(X["r_depth"]), ptr(X["r_cov"]), C.c_float(c.depth_lambda),
                                       C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), None, ptr(X["loss"]),
                                       ptr(X["s_dout"]), ctl, st), "ngp_composite")
-        single = self.world == 1
+        single = not self.replicated
         pose = c.optimize_extrinsics
         gather_pose = pose and jac is None          # A/B form: second gather of the table (reads what Adam rewrites)
 
@@ -521,21 +528,27 @@ class NgpNerf:
         main.wait_stream(self._side2)
         main.wait_stream(self._side)
         if not single:
+            def post(stream):
+                """what follows the gradient exchange: pose step, Adam on THIS trainer's shard of the table (summed gradient in
+                `_gshard`), the MLP's Adam.  Fixed arguments: captured as the second graph of the replicated step."""
+                if pose:   # after the all-reduce: every replica applies the SAME pose update (ADVICE r01)
+                    camera_step(stream)
+                if c.grad_fixed_scale > 0:
+                    Ns = self.shard_entries
+                    lo = 2 * Ns * self.rank
+                    n = max(0, min(2 * Ns, self.n_grid - lo))
+                    if n > 0:
+                        adam(self.grid_master[lo:lo + n], self.grid_half[lo:lo + n], self._gshard.view(torch.float32)[:n],
+                             self.grid_m1[lo:lo + n], self.grid_m2[lo:lo + n], 0.0, c.grad_fixed_scale, stream)
+                else:
+                    adam(self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale, stream)
+                mlp_adam(stream)
+            if phase == "pre":          # (replicated step from two graphs: the caller runs the collectives between them)
+                return post
             self._exchange_gradients()
-            if pose:   # after the all-reduce: every replica applies the SAME pose update
-                camera_step(st)
+            post(st)
             if c.grad_fixed_scale > 0:
-                # Adam on THIS trainer's shard of the table (summed gradient in `_gshard`), then the f16 copies of all shards
-                Ns = self.shard_entries
-                lo = 2 * Ns * self.rank
-                n = max(0, min(2 * Ns, self.n_grid - lo))
-                if n > 0:
-                    adam(self.grid_master[lo:lo + n], self.grid_half[lo:lo + n], self._gshard.view(torch.float32)[:n],
-                         self.grid_m1[lo:lo + n], self.grid_m2[lo:lo + n], 0.0, c.grad_fixed_scale, st)
-                self._gather_parameters()
-            else:
-                adam(self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale, st)
-            mlp_adam(st)
+                self._gather_parameters()   # the f16 copies of all shards
         elif not self.fused_adam:
             adam(self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale, st)
 
@@ -578,7 +591,7 @@ class NgpNerf:
 
     def _pair_ready(self):
         c = self.cfg
-        if self.world > 1 or not c.use_graph or os.environ.get("NS_NGP_NO_PAIR") or self.n_images == 0:
+        if self.replicated or not c.use_graph or os.environ.get("NS_NGP_NO_PAIR") or self.n_images == 0:
             return False
         if not getattr(self, "_static", False) or not self._primed or self.cur != 0:
             return False
@@ -608,7 +621,9 @@ class NgpNerf:
                 X["loss"].zero_()
                 self._enqueue_rays(X)
                 self._primed = True
-            if self.world > 1 or not c.use_graph:
+            if self.replicated and c.use_graph and not os.environ.get("NS_NGP_REPL_EAGER"):
+                self._replicated_step(x)
+            elif self.replicated or not c.use_graph:
                 self._enqueue_step(x)
             else:
                 key = self._step_key()
@@ -641,6 +656,39 @@ class NgpNerf:
                 # 10 on the tree before the rays moved ahead).  Cost: one eager sample + march per update, < 1 % of a step.
                 self._primed = False
         return self.loss_tensor if return_loss else None
+
+    def _replicated_step(self, x):
+        """One step of a replicated trainer from TWO HIP graphs with the collectives between them:
+            graph A: forward, backward, packed table gradient into the gradient buffer, MLP / pose gradients (three streams)
+            eager  : all-to-all of the packed table gradient, all-reduce of the MLP and pose gradients (RCCL, this stream)
+            graph B: pose step, Adam on this trainer's shard, MLP Adam + fragment pack
+            eager  : all-gather of the f16 table
+        The collectives are stream-ordered behind graph A and ahead of graph B (RCCL waits for the current stream); nothing
+        synchronises with the host (under gloo the staging copies do).  Eager steps first, as in the one-trainer path."""
+        key = self._step_key()
+        if self._graph_key != key:
+            self._graphs, self._graph_key, self._pair, self._chains = [None, None], key, None, {}
+            self._eager_left = 2
+        if self._eager_left > 0:
+            self._eager_left -= 1
+            self._enqueue_step(x)
+            return
+        if self._graphs[x] is None:
+            from ._lib import capture_lock, graph_capture
+            with capture_lock:
+                torch.cuda.synchronize(self.device)
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with graph_capture(ga, capture_error_mode="thread_local"):
+                    post = self._enqueue_step(x, phase="pre")
+                with graph_capture(gb, capture_error_mode="thread_local"):
+                    post(stream_ptr())
+            self._graphs[x] = (ga, gb)
+        ga, gb = self._graphs[x]
+        ga.replay()
+        self._exchange_gradients()
+        gb.replay()
+        if self.cfg.grad_fixed_scale > 0:
+            self._gather_parameters()
 
     @property
     def loss_tensor(self):
@@ -748,8 +796,11 @@ class NgpNerf:
                   "ngp_encode_forward")
             check(L.ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(feat), ptr(dirs), ptr(out), nul, nul, nul, nul, C.c_long(n), st),
                   "ngp_mlp_forward")
-            if os.environ.get("NS_NGP_GRID_DECAY_ALL", "1" if c.grid_decay_all else ""):
-                check(L.ns_ngp_grid_update(ptr(out), ptr(cells), n, C.c_float(c.min_step), C.c_float(c.grid_decay),
+            if os.environ.get("NS_NGP_GRID_DECAY_ALL", "1" if c.grid_decay_all else "") not in ("", "0"):
+                # (fading all cells at instant-ngp's 0.95 with 4 % of the grid drawn would empty the grid 12 x
+                #  faster than the rule it stands in for; not fading the undrawn cells at all leaves floaters for ever)
+                decay_all = float(c.grid_decay) ** min(1.0, n / (0.5 * total))
+                check(L.ns_ngp_grid_update(ptr(out), ptr(cells), n, C.c_float(c.min_step), C.c_float(decay_all),
                                            C.c_float(c.min_optical_thickness), ptr(self.density_grid), C.c_long(total), ptr(part),
                                            ptr(self.bits), st), "ngp_grid_update")
             else:

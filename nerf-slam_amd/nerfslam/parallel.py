@@ -113,17 +113,23 @@ def shard_size(n_entries, world):
     return ((n_entries + world - 1) // world + 1023) // 1024 * 1024 if world > 1 else n_entries
 
 
+def _device_collectives(group=None):
+    """True when the group's backend runs all-to-all / all-gather on device tensors (nccl = RCCL).  Decided from the backend
+    name, once per call and never from a caught exception: a failing RCCL collective must surface as what it is."""
+    return str(dist.get_backend(group)).lower() == "nccl"
+
+
 def exchange_sharded(send, recv, out_shard, group=None):
     """send: [world * Ns] packed int64 gradient words of THIS trainer (shard r = entries [r Ns, (r + 1) Ns)); recv: scratch
     [world, Ns]; out_shard [Ns] <- the sum over the trainers of shard `rank`, added in rank order (integer: exact, and the same on
     every run).  One all-to-all: every trainer sends (world - 1) / world of its buffer once -- an all-reduce would move twice that
-    and leave every trainer with sums it then does not need (Adam runs on the own shard only).  Backends without a device
-    all-to-all (gloo) go through host tensors."""
+    and leave every trainer with sums it then does not need (Adam runs on the own shard only).  The gloo backend (CPU tests) has
+    no device all-to-all and goes through host tensors; that branch is chosen by backend name, not by catching errors."""
     world, Ns = recv.shape
     assert send.numel() == world * Ns and out_shard.numel() == Ns
-    try:
-        dist.all_to_all_single(recv.view(-1), send, group=group)
-    except Exception:                                             # (gloo: no all-to-all on device tensors)
+    if _device_collectives(group):
+        dist.all_to_all_single(recv.view(-1), send, group=group)   # RCCL: device tensors straight onto xGMI; errors propagate
+    else:                                                          # gloo (CPU tests): staged through host tensors
         h_in, h_out = send.cpu(), torch.empty((world * Ns,), dtype=send.dtype)
         dist.all_to_all_single(h_out, h_in, group=group)
         recv.view(-1).copy_(h_out)
@@ -137,9 +143,9 @@ def gather_shards(full, rank, group=None):
     world = dist.get_world_size(group)
     n = full.numel() // world
     mine = full[rank * n:(rank + 1) * n].clone()
-    try:
+    if _device_collectives(group):
         dist.all_gather_into_tensor(full, mine, group=group)
-    except Exception:
+    else:
         h = torch.empty(full.shape, dtype=full.dtype)
         dist.all_gather_into_tensor(h, mine.cpu(), group=group)
         full.copy_(h)

@@ -287,9 +287,29 @@ class TrackingSLAM:
                         for _it in range(2):
                             sba.iteration(fe.cam0_T_world, fe.cam0_idepths, fe.intr8, fe.cam0_T_body, fe.cam0_idepths_sensed, tg,
                                           wg, eta, fe.world_T_body, prior_pose=fe.prior_pose)
+            if sba is not None:
+                self._replicate_source_frame_state(ii_h, own, group)
         g.reset(max_factors=saved)
         fe._sync_edges()
         fe.viz_idx[:t] = True
+
+    def _replicate_source_frame_state(self, ii_h, own, group):
+        """End of a sharded backend pass: the update operator's per-source-frame outputs -- damping and the convex-upsampled
+        depth / covariance maps -- exist only on the rank that owns the source frame; poses and low-resolution depths are already
+        identical (ShardedBA.iteration).  Every source frame has exactly one owner, so a sum of the owner-masked rows IS the
+        exchange: three all-reduces per pass, after which every rank again holds the SAME keyframe buffer (the precondition of
+        the next pass, and what the mapper is handed)."""
+        import torch.distributed as dist
+        fe = self.fe
+        src = np.unique(ii_h)
+        mine = np.isin(src, np.unique(ii_h[own]))
+        idx = torch.from_numpy(src).to(self.device)
+        m = torch.from_numpy(mine.astype(np.float32)).to(self.device)[:, None, None]
+        for buf in (fe.damping, fe.cam0_idepths_up, fe.cam0_depths_cov_up):
+            rows = buf[idx] * m.to(buf.dtype)
+            dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=group)
+            buf[idx] = rows
+        fe.has_up[idx] = True
 
     def terminate(self):
         """:1309-1335"""

@@ -1,0 +1,121 @@
+"""Worker of tests/test_rccl_gpu.py: ONE rank, backend "nccl" (= RCCL on ROCm), device tensors on cuda:0.
+
+Every collective the --multi_gpu split issues (examples/slam_demo.py:63-77; the CPU bounce of
+slam/visual_frontends/visual_frontend.py:1355-1360 is what they replace) is driven through RCCL here exactly as the
+N-GPU run drives it -- same call sites (nerfslam.parallel / nerfslam.transport / NgpNerf), same dtypes (int64 all-to-all of
+the packed table gradient, f16 all-gather of the table, f32 all-reduces, uint8 broadcast) -- in a group of one, which is what
+a one-GPU box can execute.  A one-rank collective moves no bytes over xGMI; what this pins is that the RCCL entry points accept
+these tensors, are stream-ordered with the HIP-graph replays around them, and leave the right values.
+
+Prints one JSON line; exit code 0 = all checks passed."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "nerf-slam_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def main():
+    port = int(sys.argv[1]) if len(sys.argv) > 1 else 29611
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    res = {"backend": str(dist.get_backend()), "checks": {}}
+    ok = res["checks"]
+    from nerfslam import parallel, transport
+    assert parallel._device_collectives(None)
+
+    # ---- nerfslam.parallel: the replicated trainers' table exchange ----
+    g = torch.Generator(device="cpu").manual_seed(1)
+    Ns = 1 << 20
+    send = torch.randint(-2 ** 40, 2 ** 40, (Ns,), generator=g, dtype=torch.int64).to(dev)
+    recv = torch.zeros((1, Ns), dtype=torch.int64, device=dev)
+    out = torch.zeros(Ns, dtype=torch.int64, device=dev)
+    wire = parallel.exchange_sharded(send, recv, out, None)
+    ok["exchange_sharded_int64_all_to_all"] = bool(torch.equal(out, send)) and wire == 0
+    full = torch.randn(1 << 20, generator=g).half().to(dev)
+    ref = full.clone()
+    parallel.gather_shards(full, 0, None)
+    ok["gather_shards_f16_all_gather"] = bool(torch.equal(full, ref))
+    H, v = torch.randn((60, 60), generator=g).to(dev), torch.randn(60, generator=g).to(dev)
+    H0, v0 = H.clone(), v.clone()
+    parallel.allreduce_reduced_system(H, v, None)
+    ok["allreduce_reduced_system"] = bool(torch.equal(H, H0) and torch.equal(v, v0))
+
+    # ---- nerfslam.transport: the SLAM -> mapper packet ----
+    from test_transport import _make_packet
+    pkt = {k: (t.to(dev) if isinstance(t, torch.Tensor) else t) for k, t in _make_packet(3, 48, 64).items()}
+    got = transport.broadcast_packet(pkt, 0, dev, None)
+    ok["broadcast_packet"] = all(torch.equal(got[k], t) if isinstance(t, torch.Tensor) else got[k] == t for k, t in pkt.items())
+    gs = [torch.full((1000,), 3.0, device=dev), torch.full((10,), 30.0, device=dev)]
+    transport.allreduce_gradients(gs, None)
+    ok["allreduce_gradients"] = bool((gs[0] == 3.0).all() and (gs[1] == 30.0).all())
+    # PacketChannel: tracker and (only) trainer are this rank, each side with its own channel object (its own mailbox cursor);
+    # the payload broadcast is RCCL, the header goes through the rendezvous store
+    chan = transport.PacketChannel(dev, tracker=0, trainers=[0], control_group=None, data_group=None, trainer_control_group=None)
+    chan_t = transport.PacketChannel(dev, tracker=0, trainers=[0], control_group=None, data_group=None, trainer_control_group=None)
+    chan.publish(pkt)
+    polled = None
+    for _ in range(200):
+        polled = chan_t.poll()
+        if polled is not None:
+            break
+        time.sleep(0.01)
+    ok["packet_channel_publish_poll"] = polled is not None and polled[0] == transport.KIND_PACKET and \
+        int(polled[1]["cam0_images"].numel()) == int(pkt["cam0_images"].numel()) and polled[1]["kf_idx"] == pkt["kf_idx"]
+    chan._reap(block=True)
+
+    # ---- the replicated trainer's step: graph A, RCCL collectives, graph B, RCCL all-gather (NgpNerf._replicated_step) ----
+    from ngp_scene import sphere_scene
+    from nerfslam.ngp import NgpConfig, NgpNerf
+    scene = sphere_scene(n=6, H=48, W=64, f=60.0, radius=0.9)
+
+    def train(replicated, steps, eager=False):
+        if eager:
+            os.environ["NS_NGP_REPL_EAGER"] = "1"
+        else:
+            os.environ.pop("NS_NGP_REPL_EAGER", None)
+        net = NgpNerf(NgpConfig(n_rays=2048, max_samples=1 << 17, optimize_extrinsics=True), dev, seed=0,
+                      group=dist.group.WORLD if replicated else None, replicated=replicated)
+        net.set_images(*scene)
+        losses = [float(net.train_step()) for _ in range(steps)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(64):
+            net.train_step(return_loss=False)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 64 * 1e3
+        return net, np.array(losses), ms
+    single, l1, ms1 = train(False, 120)
+    repl, l2, ms2 = train(True, 120)
+    repl_e, l3, ms3 = train(True, 120, eager=True)
+    res["ms_per_step"] = {"one_trainer_graph": ms1, "replicated_two_graphs": ms2, "replicated_eager": ms3}
+    res["loss_first5_last10"] = {k: [float(l[:5].mean()), float(l[-10:].mean())] for k, l in (("one", l1), ("repl", l2), ("eager", l3))}
+    ok["replicated_step_graphs_were_used"] = isinstance(repl._graphs[0], tuple) and isinstance(repl._graphs[1], tuple)
+    ok["replicated_step_converges"] = bool(np.isfinite(l2).all() and l2[-10:].mean() < 0.5 * l2[:5].mean())
+    # the two forms of the replicated step are the same launch sequence (the step itself is not bit-reproducible from run to run:
+    # f32 LDS atomics in the dense levels, see test_paired_step_graph_trains_like_single_steps): same loss level at the end
+    ok["replicated_graphs_track_eager"] = bool(abs(l2[-10:].mean() - l3[-10:].mean()) <= 0.25 * l3[-10:].mean() + 1e-4)
+    # replicated (gradient buffer + sharded Adam) vs one trainer (Adam in the flush): same arithmetic on the same rays
+    ok["replicated_tracks_one_trainer"] = bool(abs(l2[-10:].mean() - l1[-10:].mean()) <= 0.25 * l1[-10:].mean() + 1e-4)
+    res["bytes_exchanged"] = int(getattr(repl, "bytes_allreduced", 0))
+    dist.barrier()
+    dist.destroy_process_group()
+    res["ok"] = all(ok.values())
+    print(json.dumps(res))
+    return 0 if res["ok"] else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
