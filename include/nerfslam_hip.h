@@ -540,13 +540,17 @@ int ns_ngp_encode_jacobian_dot_n(int n_levels, int n_features, int log2_hashmap,
  *     half_params the f16 working copy; bias corrections from `step`, or from the device control block `ctl` as
  *     ns_ngp_adam_ctl); grad_params is then not written and may be NULL;
  *   master == NULL: the packed sums are ADDED to grad_params (same bits as ns_ngp_encode_backward).
- *   parts: mask of 1 = scatter of the hashed levels (records), 2 = their accumulation (+ Adam), 4 = accumulation of the dense
- *     levels (partial planes), 8 = their reduction (+ Adam); 15 = the whole gradient.  1 before 2, 4 before 8; the hashed and
- *     the dense halves touch disjoint table entries and disjoint parts of the workspace (the trainer runs them on two streams,
- *     and holds the two Adam-applying passes back until the pose refinement has read the table).
+ *   parts: mask of 1 = scatter of the binned levels (records), 2 = their accumulation (+ Adam), 4 = accumulation of the
+ *     owner-computes dense levels (partial planes), 8 = their reduction (+ Adam); 15 = the whole gradient.  1 before 2, 4
+ *     before 8; the two halves touch disjoint table entries and disjoint parts of the workspace.  Round 4: by default EVERY
+ *     level is binned (the scatter merges the runs of neighbouring lanes on the dense levels) and parts 4 / 8 launch
+ *     nothing -- ns_ngp_encode_backward_fused_dense_levels() = 0; NS_ENC_DENSE_BINNED=0 | 1 restore round 3's two forms.
  * No count pass, no global atomics on table entries, nothing dropped: runs that outgrow their slot spill to a list.   */
 size_t ns_ngp_encode_backward_fused_workspace_bytes(int n_levels, int n_features, int log2_hashmap, int base_res,
                                                     float per_level_scale, long max_samples);
+/* number of (leading, dense) levels that parts 4 | 8 of ns_ngp_encode_backward_fused_n handle; 0: those parts are no-ops */
+int ns_ngp_encode_backward_fused_dense_levels(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                              float per_level_scale);
 int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
                                    const float* positions, const void* dLdoutT, float* grad_params, void* workspace,
                                    size_t workspace_bytes, float fixed_scale, long N, const int* n_dev, float* master,

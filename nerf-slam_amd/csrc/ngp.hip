@@ -1083,6 +1083,8 @@ struct FusedPlan {
   int nbins[16];     // k -> bins of the level (<= 64)
   int slot[16];      // k -> records per (bin, tile) slot: the level's 64 x 512 records per tile, divided among its bins
   int hashed[16];    // k -> hash or dense index
+  int merge[16];     // k -> merge the single-cell runs of neighbouring lanes before records are emitted (fb_wave_merge)
+  int shift[16];     // k -> log2 of the level's bin size (13 = 8192 entries; small dense levels: smaller bins, >= 8 of them)
   int ntiles;        // ceil(N / 1024)
   long ovf_cap;      // entries of the overflow list
 };
@@ -1090,28 +1092,53 @@ struct FusedPlan {
 // Dense levels of ONE slice keep the owner-computes kernel (a workgroup holds the whole level in LDS); with dense_too the larger
 // dense levels go through the bins like the hashed ones: their owner-computes tasks scan every sample once per slice (22 x N
 // sample visits for the default grid's five dense levels) in whole-CU workgroups of 128 KB of LDS that nothing runs next to.
-static int fused_dense_levels(const GridLayout& g, int n_levels, bool dense_too) {
+// dense_mode 0: every dense level owner-computes; 1: the dense levels of more than one 16384-entry slice through the bins (round
+// 3's A/B form); 2 (round 4, default): EVERY dense level through the bins -- the scatter merges the runs of neighbouring lanes
+// first (fb_wave_merge), which is what keeps a coarse level's few bins from drowning in records -- and no owner-computes
+// workgroup, no partial planes, no reduce pass and no third stream are left in the step.
+static int fused_dense_levels(const GridLayout& g, int n_levels, int dense_mode) {
+  if (dense_mode >= 2) return 0;
   int l = 0;
-  while (l < n_levels && !level_is_hashed(g, l) && (!dense_too || g.offset[l + 1] - g.offset[l] <= (uint32_t)NS_ENC_SLICE)) l++;
+  while (l < n_levels && !level_is_hashed(g, l) && (!dense_mode || g.offset[l + 1] - g.offset[l] <= (uint32_t)NS_ENC_SLICE)) l++;
   return l;
 }
+static int fused_dense_mode() {
+  static const int mode = [] {
+    const char* e = getenv("NS_ENC_DENSE_BINNED");
+    return e != nullptr && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 2;
+  }();
+  return mode;
+}
+// wave-level merge of single-cell lanes (fb_wave_merge) on levels up to this resolution (dense levels always; NS_FB_MERGE_RES)
+static int fused_merge_res() {
+  static const int r = [] { const char* e = getenv("NS_FB_MERGE_RES"); return e ? atoi(e) : 0; }();
+  return r;
+}
 
-static bool fused_plan_host(const GridLayout& g, int n_levels, long N, FusedPlan& f, bool dense_too = false) {
+static bool fused_plan_host(const GridLayout& g, int n_levels, long N, FusedPlan& f, int dense_too = 0) {
   f.nh = 0;
   for (int l = fused_dense_levels(g, n_levels, dense_too); l < n_levels; l++) {
     const bool hashed = level_is_hashed(g, l);
     if (!hashed && !dense_too) continue;
     const uint32_t hs = g.offset[l + 1] - g.offset[l];
-    const int nb = (int)((hs + NS_FB_SLICE - 1) / NS_FB_SLICE);
+    // a level of few 8192-entry bins (the coarse dense ones) gets smaller bins until there are at least 8: their records --
+    // one set per (wave, cell) after the merge, still several times a hashed bin's load on the coarsest level -- then spread
+    // over 8+ work items of the accumulate pass instead of 1 / 2 / 7
+    int sh = NS_FB_SHIFT;
+    if (!hashed && dense_too >= 2)
+      while (sh > 9 && (hs + (1u << sh) - 1) >> sh < 8u) sh--;
+    const int nb = (int)((hs + (1u << sh) - 1) >> sh);
     if (nb > NS_FB_BINS) return false;
+    f.shift[f.nh] = sh;
     f.level[f.nh] = l;
     f.nbins[f.nh] = nb;
     f.hashed[f.nh] = hashed ? 1 : 0;
+    f.merge[f.nh] = (!hashed && dense_too >= 2) || g.res[l] <= fused_merge_res() ? 1 : 0;
     const int sl = (NS_FB_BINS * NS_FB_SLOT / nb) & ~3;
     f.slot[f.nh] = sl < 8 * NS_BIN_TILE ? sl : 8 * NS_BIN_TILE;      // (a tile has at most 8 x 1024 records)
     f.nh++;
   }
-  for (int k = f.nh; k < 16; k++) f.level[k] = f.nbins[k] = f.slot[k] = f.hashed[k] = 0;
+  for (int k = f.nh; k < 16; k++) f.level[k] = f.nbins[k] = f.slot[k] = f.hashed[k] = f.merge[k] = f.shift[k] = 0;
   f.ntiles = (int)((N + NS_BIN_TILE - 1) / NS_BIN_TILE);
   f.ovf_cap = (long)f.ntiles * NS_BIN_TILE * 8 * (f.nh > 0 ? f.nh : 1);
   return f.nh > 0;
@@ -1153,21 +1180,73 @@ __device__ __forceinline__ void fb_indices_any(bool hashed, const uint32_t c[3],
   }
 }
 
-__global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, FusedPlan fp, const float* __restrict__ pos,
-                                                               const _Float16* __restrict__ dpu, long N, float fixed_scale,
-                                                               int* __restrict__ ctr, int* __restrict__ cnt,
-                                                               unsigned long long* __restrict__ queue,
-                                                               ulonglong2* __restrict__ ovf, const int* __restrict__ n_dev,
-                                                               int vec) {
-  __shared__ unsigned long long rec[8 * NS_BIN_TILE];   // 64 KB: the tile's records, bin-sorted
-  __shared__ int lbase[NS_FB_BINS + 1], lcnt[NS_FB_BINS], odst[NS_FB_BINS];
-  const int k = blockIdx.y, l = fp.level[k], tile = blockIdx.x, tid = threadIdx.x;
-  const uint32_t hs = g.offset[l + 1] - g.offset[l], res = (uint32_t)g.res[l];
-  const bool hashed = fp.hashed[k] != 0;
-  const int slot = fp.slot[k];
-  const long nvalid = n_dev ? min(N, (long)*n_dev) : N;
-  if ((long)tile * NS_BIN_TILE >= nvalid) return;       // (uniform) nothing marched into this tile
-  if (tid < NS_FB_BINS) lcnt[tid] = 0;
+// Merge across the lanes of a wave.  Lane i holds samples [4 i, 4 i + 4) of the sample array: consecutive steps of a ray.  On a
+// coarse level a cell holds tens of steps, so whole sequences of lanes sit in ONE cell.  Every lane has a FIRST run (which may
+// continue the cell the previous lane ended in) and a LAST run (which the next lane may continue); for a lane of one run they
+// are the same run and the chain passes through it.  A segmented inclusive scan over the last runs (segment = a maximal
+// chain) leaves the chain's total in the lane that ends it -- in its only run, or in the FIRST run of a lane that goes on to
+// other cells -- and the lanes before it drop the run they passed on: one record set per (wave, chain) instead of one per
+// (lane, run).  Exact: integer sums of the same per-contribution roundings (any grouping gives the same table sums), as long as
+// the record's 25-bit fields hold the total -- only runs below 2^17 per field take part (64 of them stay below 2^23).
+// 16 sums x 7 shuffle rounds per wave.  The default grid's coarsest level: ~2.4 -> ~0.5 records per sample.
+__device__ __forceinline__ void fb_wave_merge(FbRun (&run)[NS_FB_RUN], int& nrun) {
+  const int lane = threadIdx.x & 63;
+  // the last run (run[nrun - 1], static indexing only) in registers of its own
+  FbRun v = run[0];
+#pragma unroll
+  for (int r = 1; r < NS_FB_RUN; r++)
+    if (r == nrun - 1) v = run[r];
+  int big_f = 0, big_l = 0;
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) {
+    big_f |= abs(run[0].a[corner]) | abs(run[0].b[corner]);
+    big_l |= abs(v.a[corner]) | abs(v.b[corner]);
+  }
+  const bool can_f = nrun >= 1 && big_f < (1 << 17), can_l = nrun >= 1 && big_l < (1 << 17);
+  const uint32_t p0 = __shfl_up(v.c[0], 1, 64), p1 = __shfl_up(v.c[1], 1, 64), p2 = __shfl_up(v.c[2], 1, 64);
+  const int pcan = __shfl_up((int)can_l, 1, 64);
+  // recv: this lane's first run continues the previous lane's last run; cont: and it is this lane's only run
+  const bool recv = lane > 0 && can_f && pcan && p0 == run[0].c[0] && p1 == run[0].c[1] && p2 == run[0].c[2];
+  const bool cont = recv && nrun == 1;
+  int head = cont ? 0 : lane;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(head, d, 64);
+    if (lane >= d) head = max(head, o);
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const bool take = lane - d >= head;
+#pragma unroll
+    for (int corner = 0; corner < 8; corner++) {
+      const int oa = __shfl_up(v.a[corner], d, 64), ob = __shfl_up(v.b[corner], d, 64);
+      if (take) {
+        v.a[corner] += oa;
+        v.b[corner] += ob;
+      }
+    }
+  }
+  // a lane of several runs takes the chain's total into its first run; a lane of one run has it in v already
+  const bool recv_multi = recv && nrun > 1;
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) {
+    const int oa = __shfl_up(v.a[corner], 1, 64), ob = __shfl_up(v.b[corner], 1, 64);
+    if (recv_multi) {
+      run[0].a[corner] += oa;
+      run[0].b[corner] += ob;
+    } else if (nrun == 1) {
+      run[0].a[corner] = v.a[corner];
+      run[0].b[corner] = v.b[corner];
+    }
+  }
+  const int nrecv = __shfl_down((int)recv, 1, 64);
+  if (lane < 63 && nrecv) nrun--;           // the next lane carries this lane's last run on
+}
+
+// The runs of one lane: its FOUR CONSECUTIVE samples of tile `tile` on level l, neighbours that share a cell summed (exact).
+__device__ __forceinline__ void fb_build_runs(const GridLayout& g, int l, int tile, int tid, const float* __restrict__ pos,
+                                              const _Float16* __restrict__ dpu, long N, long nvalid, float fixed_scale, int vec,
+                                              FbRun (&run)[NS_FB_RUN], int& nrun_out) {
   // ---- loads: 4 consecutive samples per lane ----
   const long i0 = (long)tile * NS_BIN_TILE + (long)tid * NS_FB_RUN;
   float px[NS_FB_RUN][3], d0[NS_FB_RUN], d1[NS_FB_RUN];
@@ -1200,7 +1279,9 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
     }
   }
   // ---- merge neighbours that share a cell ----
-  FbRun run[NS_FB_RUN];
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) run[0].a[corner] = run[0].b[corner] = 0;   // (read by fb_wave_merge's shuffles)
+  run[0].c[0] = run[0].c[1] = run[0].c[2] = 0u;
   int nrun = 0;
   bool open = false, open_small = false;
   const float scale = g.scale[l];
@@ -1258,6 +1339,29 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
       open_small = small;
     }
   }
+  nrun_out = nrun;
+}
+
+__global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, FusedPlan fp, const float* __restrict__ pos,
+                                                               const _Float16* __restrict__ dpu, long N, float fixed_scale,
+                                                               int* __restrict__ ctr, int* __restrict__ cnt,
+                                                               unsigned long long* __restrict__ queue,
+                                                               ulonglong2* __restrict__ ovf, const int* __restrict__ n_dev,
+                                                               int vec) {
+  __shared__ unsigned long long rec[8 * NS_BIN_TILE];   // 64 KB: the tile's records, bin-sorted
+  __shared__ int lbase[NS_FB_BINS + 1], lcnt[NS_FB_BINS], odst[NS_FB_BINS];
+  const int k = blockIdx.y, l = fp.level[k], tile = blockIdx.x, tid = threadIdx.x;
+  const uint32_t hs = g.offset[l + 1] - g.offset[l], res = (uint32_t)g.res[l];
+  const bool hashed = fp.hashed[k] != 0;
+  const int slot = fp.slot[k], shift = fp.shift[k];
+  const uint32_t bmask = (1u << shift) - 1u;
+  const long nvalid = n_dev ? min(N, (long)*n_dev) : N;
+  if ((long)tile * NS_BIN_TILE >= nvalid) return;       // (uniform) nothing marched into this tile
+  if (tid < NS_FB_BINS) lcnt[tid] = 0;
+  FbRun run[NS_FB_RUN];
+  int nrun;
+  fb_build_runs(g, l, tile, tid, pos, dpu, N, nvalid, fixed_scale, vec, run, nrun);
+  if (fp.merge[k]) fb_wave_merge(run, nrun);     // (uniform per workgroup)
   __syncthreads();
   // ---- rank the records inside their bins ----
   int rank[NS_FB_RUN][8];
@@ -1269,7 +1373,7 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
 #pragma unroll
       for (int corner = 0; corner < 8; corner++)   // (a contribution that rounds to zero in both fields is not a record: most
         rank[r][corner] = (run[r].a[corner] | run[r].b[corner]) != 0   //  corners of a converged scene's tiny gradients)
-                              ? atomicAdd(&lcnt[idx[corner] >> NS_FB_SHIFT], 1) : -1;
+                              ? atomicAdd(&lcnt[idx[corner] >> shift], 1) : -1;
     }
   }
   __syncthreads();
@@ -1295,8 +1399,8 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
 #pragma unroll
       for (int corner = 0; corner < 8; corner++)
         if (rank[r][corner] >= 0)
-          rec[lbase[idx[corner] >> NS_FB_SHIFT] + rank[r][corner]] =
-              ((unsigned long long)(idx[corner] & (NS_FB_SLICE - 1u)) << 50) |
+          rec[lbase[idx[corner] >> shift] + rank[r][corner]] =
+              ((unsigned long long)(idx[corner] & bmask) << 50) |
               ((unsigned long long)((uint32_t)run[r].b[corner] & 0x1ffffffu) << 25) |
               (unsigned long long)((uint32_t)run[r].a[corner] & 0x1ffffffu);
     }
@@ -1313,6 +1417,88 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
       } else {
         const long o = (long)odst[b] + (e - slot);
         if (o < fp.ovf_cap) ovf[o] = make_ulonglong2(r, (unsigned long long)((k << 8) | b));
+        else ctr[1] = 1;   // cannot happen with the worst-case list; flagged, never silent
+      }
+    }
+  }
+}
+
+// The scatter WITHOUT the LDS staging (round 4, default; NS_FB_SCATTER=1 selects the staged kernel above).  A record's place
+// in its (bin, tile) slot is the value its LDS rank atomic returns -- no prefix sum over the bins is needed for that -- so every
+// lane stores its records straight from registers: 8-byte stores that land in the slot's few 128-byte lines within one
+// workgroup's lifetime and merge in the L2.  What goes: 64 KB of LDS per workgroup (two workgroups, 8 waves, per CU; now the
+// registers bound it: 4 waves per SIMD), the pass that wrote the records to LDS, the pass that copied them out and two of the
+// four barriers.  Records beyond a slot (rank >= slot: possible only when > 1/16 of a tile's records meet in one bin) go to
+// the overflow list as before, after the one barrier that makes the counts final (a bit per record remembers which).
+__global__ __launch_bounds__(256) void ngp_enc_fscatter_direct_kernel(GridLayout g, FusedPlan fp, const float* __restrict__ pos,
+                                                                      const _Float16* __restrict__ dpu, long N, float fixed_scale,
+                                                                      int* __restrict__ ctr, int* __restrict__ cnt,
+                                                                      unsigned long long* __restrict__ queue,
+                                                                      ulonglong2* __restrict__ ovf, const int* __restrict__ n_dev,
+                                                                      int vec) {
+  __shared__ int lcnt[NS_FB_BINS], odst[NS_FB_BINS];
+  __shared__ int s_spill;
+  const int k = blockIdx.y, l = fp.level[k], tile = blockIdx.x, tid = threadIdx.x;
+  const uint32_t hs = g.offset[l + 1] - g.offset[l], res = (uint32_t)g.res[l];
+  const bool hashed = fp.hashed[k] != 0;
+  const int slot = fp.slot[k], shift = fp.shift[k];
+  const uint32_t bmask = (1u << shift) - 1u;
+  const long nvalid = n_dev ? min(N, (long)*n_dev) : N;
+  if ((long)tile * NS_BIN_TILE >= nvalid) return;       // (uniform) nothing marched into this tile
+  if (tid < NS_FB_BINS) lcnt[tid] = 0;
+  if (tid == 0) s_spill = 0;
+  FbRun run[NS_FB_RUN];
+  int nrun;
+  fb_build_runs(g, l, tile, tid, pos, dpu, N, nvalid, fixed_scale, vec, run, nrun);
+  if (fp.merge[k]) fb_wave_merge(run, nrun);     // (uniform per workgroup)
+  __syncthreads();
+  unsigned long long* __restrict__ qlev = queue + (long)k * NS_FB_BINS * fp.ntiles * NS_FB_SLOT + (long)tile * slot;
+  const long bstride = (long)fp.ntiles * slot;
+  uint32_t spill = 0u;            // bit (8 r + corner): that record found its slot full
+#pragma unroll
+  for (int r = 0; r < NS_FB_RUN; r++) {
+    if (r < nrun) {
+      uint32_t idx[8];
+      fb_indices_any(hashed, run[r].c, hs, res, idx);
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) {
+        if ((run[r].a[corner] | run[r].b[corner]) == 0) continue;   // rounds to zero in both fields: not a record
+        const int b = (int)(idx[corner] >> shift);
+        const int rank = atomicAdd(&lcnt[b], 1);
+        if (rank < slot)
+          qlev[(long)b * bstride + rank] = ((unsigned long long)(idx[corner] & bmask) << 50) |
+                                           ((unsigned long long)((uint32_t)run[r].b[corner] & 0x1ffffffu) << 25) |
+                                           (unsigned long long)((uint32_t)run[r].a[corner] & 0x1ffffffu);
+        else
+          spill |= 1u << (8 * r + corner);
+      }
+    }
+  }
+  if (spill) s_spill = 1;
+  __syncthreads();
+  if (tid < NS_FB_BINS) {
+    const int c = lcnt[tid];
+    cnt[(long)(k * NS_FB_BINS + tid) * fp.ntiles + tile] = min(c, slot);
+    odst[tid] = c > slot ? atomicAdd(&ctr[0], c - slot) : 0;
+    lcnt[tid] = 0;                // (ranks among the spilled records, spilling tiles only)
+  }
+  if (!s_spill) return;           // (uniform)
+  __syncthreads();
+  // rare: a bin took more than its slot; the records that found it full go to the list, ranked among themselves
+#pragma unroll
+  for (int r = 0; r < NS_FB_RUN; r++) {
+    if (r < nrun && ((spill >> (8 * r)) & 0xffu)) {
+      uint32_t idx[8];
+      fb_indices_any(hashed, run[r].c, hs, res, idx);
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) {
+        if (!((spill >> (8 * r + corner)) & 1u)) continue;
+        const int b = (int)(idx[corner] >> shift);
+        const long o = (long)odst[b] + atomicAdd(&lcnt[b], 1);
+        const unsigned long long rec = ((unsigned long long)(idx[corner] & bmask) << 50) |
+                                       ((unsigned long long)((uint32_t)run[r].b[corner] & 0x1ffffffu) << 25) |
+                                       (unsigned long long)((uint32_t)run[r].a[corner] & 0x1ffffffu);
+        if (o < fp.ovf_cap) ovf[o] = make_ulonglong2(rec, (unsigned long long)((k << 8) | b));
         else ctr[1] = 1;   // cannot happen with the worst-case list; flagged, never silent
       }
     }
@@ -1341,11 +1527,12 @@ __global__ __launch_bounds__(NS_FB_THREADS) void ngp_enc_faccum_kernel(GridLayou
   const int k = blockIdx.y, l = fp.level[k], b = blockIdx.x, tid = threadIdx.x;
   if (b >= fp.nbins[k]) return;
   const uint32_t hs = g.offset[l + 1] - g.offset[l];
-  const uint32_t lo = (uint32_t)b * NS_FB_SLICE;
-  const uint32_t n_e = min((uint32_t)NS_FB_SLICE, hs - lo);
+  const uint32_t bsize = 1u << fp.shift[k];
+  const uint32_t lo = (uint32_t)b * bsize;
+  const uint32_t n_e = min(bsize, hs - lo);
   const long nvalid = n_dev ? min(N, (long)*n_dev) : N;
   const int ntv = (int)((nvalid + NS_BIN_TILE - 1) / NS_BIN_TILE);   // tiles the scatter pass wrote
-  for (uint32_t e = tid; e < NS_FB_SLICE; e += NS_FB_THREADS) tab[e] = 0ull;
+  for (uint32_t e = tid; e < bsize; e += NS_FB_THREADS) tab[e] = 0ull;
   if (tid == 0) {
     s_novf = (int)min((long)ctr[0], fp.ovf_cap);
     // the LAST workgroup to have read the overflow count clears it (and this arrival counter): the list is empty for the next
@@ -2432,8 +2619,16 @@ extern "C" size_t ns_ngp_encode_backward_fused_workspace_bytes(int n_levels, int
   GridLayout g;
   if (grid_layout_host(c, g) != NS_OK) return 0;
   FusedPlan fp;
-  if (!fused_plan_host(g, n_levels, max_samples > 0 ? max_samples : 1, fp, true)) return 0;   // (the larger of the two plans)
+  if (!fused_plan_host(g, n_levels, max_samples > 0 ? max_samples : 1, fp, 2)) return 0;   // (the largest of the three plans)
   return fused_ws_bytes(fp, g, n_levels);
+}
+
+extern "C" int ns_ngp_encode_backward_fused_dense_levels(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                                         float per_level_scale) {
+  GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
+  GridLayout g;
+  if (grid_layout_host(c, g) != NS_OK) return 0;
+  return fused_dense_levels(g, n_levels, fused_dense_mode());
 }
 
 extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int log2_hashmap, int base_res,
@@ -2461,7 +2656,7 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
   // but on the all-live micro-bench the accumulate pass 135 -> 301 us -- a dense level has 4 / 10 / 26 bins for the records that a
   // hashed level spreads over 64, and every sample of a ray hits the same few cells of it: long, conflict-ridden bins set the
   // kernel's time.  Off by default; kept for A/B (sums bit-identical either way: test_fused_table_gradient_matches_the_other_paths).
-  static const bool dense_too = [] { const char* e = getenv("NS_ENC_DENSE_BINNED"); return e != nullptr && e[0] == '1'; }();
+  const int dense_too = fused_dense_mode();
   FusedPlan fp;
   if (!fused_plan_host(g, n_levels, N, fp, dense_too)) {
     ns_set_error("ns_ngp_encode_backward_fused: no hashed level / tables above 64 x 8192 entries: use ns_ngp_encode_backward");
@@ -2498,9 +2693,16 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
   const long nd = (long)g.offset[n_rl];
   if (parts & 1) {
     const int vec = (N % 4 == 0 && ((uintptr_t)positions % 16) == 0 && ((uintptr_t)dLdoutT % 8) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(ngp_enc_fscatter_kernel, dim3(fp.ntiles, fp.nh), dim3(256), 0, st, g, fp, positions, (const _Float16*)dLdoutT,
-                       N, fixed_scale, ctr, cnt, queue, ovf, n_dev, vec);
-    NS_CHECK_LAUNCH("ngp_enc_fscatter_kernel");
+    static const bool staged = [] { const char* e = getenv("NS_FB_SCATTER"); return e != nullptr && e[0] == '1'; }();
+    if (staged) {
+      hipLaunchKernelGGL(ngp_enc_fscatter_kernel, dim3(fp.ntiles, fp.nh), dim3(256), 0, st, g, fp, positions, (const _Float16*)dLdoutT,
+                         N, fixed_scale, ctr, cnt, queue, ovf, n_dev, vec);
+      NS_CHECK_LAUNCH("ngp_enc_fscatter_kernel");
+    } else {
+      hipLaunchKernelGGL(ngp_enc_fscatter_direct_kernel, dim3(fp.ntiles, fp.nh), dim3(256), 0, st, g, fp, positions,
+                         (const _Float16*)dLdoutT, N, fixed_scale, ctr, cnt, queue, ovf, n_dev, vec);
+      NS_CHECK_LAUNCH("ngp_enc_fscatter_direct_kernel");
+    }
   }
   if (parts & 2) {
     int n_groups = 0;

@@ -503,13 +503,18 @@ class NgpNerf:
                       "ngp_encode_backward")
         if not gather_pose:
             hashed_levels()
-        with torch.cuda.stream(self._side2):
-            self._side2.wait_event(fork)
-            if gather_pose:                      # reads the f16 table: before anything rewrites it
-                table_read = pose_gradient(stream_ptr())
-            if self.fused_ws:
-                table_gradient(4, stream_ptr())
-                table_gradient(8, stream_ptr())
+        # (round 4: every dense level goes through the bins by default -- no owner-computes pass, and without the A/B gather
+        #  form of the pose gradient no third stream either)
+        dense_pass = self.fused_ws and int(L.ns_ngp_encode_backward_fused_dense_levels(*self._grid_args())) > 0
+        use_side2 = gather_pose or dense_pass
+        if use_side2:
+            with torch.cuda.stream(self._side2):
+                self._side2.wait_event(fork)
+                if gather_pose:                      # reads the f16 table: before anything rewrites it
+                    table_read = pose_gradient(stream_ptr())
+                if dense_pass:
+                    table_gradient(4, stream_ptr())
+                    table_gradient(8, stream_ptr())
         if gather_pose:
             hashed_levels()
         with torch.cuda.stream(self._side):
@@ -525,7 +530,8 @@ class NgpNerf:
                 pose_gradient(st1)
             if pose and single:
                 camera_step(st1)
-        main.wait_stream(self._side2)
+        if use_side2:
+            main.wait_stream(self._side2)
         main.wait_stream(self._side)
         if not single:
             def post(stream):
