@@ -13,184 +13,7 @@
 #include "common.h"
 #include <algorithm>
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// weights (f16, row-major [out][in]) packed back to back: W1[64,32] W2[16,64] W3[64,32] W4[64,64] W5[16,64]
-#define W1_OFF 0
-#define W2_OFF 2048
-#define W3_OFF 3072
-#define W4_OFF 5120
-#define W5_OFF 9216
-#define W_TOTAL 10240
-
-__device__ __forceinline__ void sh16(float x, float y, float z, float* o) {
-  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
-  o[0] = 0.28209479177387814f;
-  o[1] = -0.48860251190291987f * y;
-  o[2] = 0.48860251190291987f * z;
-  o[3] = -0.48860251190291987f * x;
-  o[4] = 1.0925484305920792f * xy;
-  o[5] = -1.0925484305920792f * yz;
-  o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
-  o[7] = -1.0925484305920792f * xz;
-  o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
-  o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
-  o[10] = 2.8906114426405538f * xy * z;
-  o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
-  o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
-  o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
-  o[14] = 1.4453057213202769f * z * (x2 - y2);
-  o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
-}
-
-// The MFMA kernels want, per lane half h, the 8 terms {(q & 3) + 8 (q >> 2) + 4 h}.  Written as `h ? sh[lo + 4] : sh[lo]` over
-// the array above the compiler turned the select into an INDEXED load: the 16 terms went to scratch (or to 16 KB of LDS per
-// workgroup, where the private array could be promoted) and came back with a per-lane offset.  One term by compile-time index
-// instead (the switch folds away after unrolling, the shared products are CSE'd): no array at all.
-__device__ __forceinline__ float sh_term(int k, float x, float y, float z) {
-  switch (k) {
-    case 0: return 0.28209479177387814f;
-    case 1: return -0.48860251190291987f * y;
-    case 2: return 0.48860251190291987f * z;
-    case 3: return -0.48860251190291987f * x;
-    case 4: return 1.0925484305920792f * (x * y);
-    case 5: return -1.0925484305920792f * (y * z);
-    case 6: return 0.94617469575755997f * (z * z) - 0.31539156525251999f;
-    case 7: return -1.0925484305920792f * (x * z);
-    case 8: return 0.54627421529603959f * (x * x) - 0.54627421529603959f * (y * y);
-    case 9: return 0.59004358992664352f * y * (-3.0f * (x * x) + (y * y));
-    case 10: return 2.8906114426405538f * (x * y) * z;
-    case 11: return 0.45704579946446572f * y * (1.0f - 5.0f * (z * z));
-    case 12: return 0.3731763325901154f * z * (5.0f * (z * z) - 3.0f);
-    case 13: return 0.45704579946446572f * x * (1.0f - 5.0f * (z * z));
-    case 14: return 1.4453057213202769f * z * ((x * x) - (y * y));
-    default: return 0.59004358992664352f * x * (-(x * x) + 3.0f * (y * y));
-  }
-}
-typedef _Float16 sh_f16x8 __attribute__((ext_vector_type(8)));
-// chunk 1 of the colour MLP's input for lane half h (element q = SH term (q & 3) + 8 (q >> 2) + 4 h)
-__device__ __forceinline__ sh_f16x8 sh_chunk(float x, float y, float z, int h) {
-  sh_f16x8 c;
-#pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const int lo = (q & 3) + 8 * (q >> 2);
-    const float a = sh_term(lo, x, y, z), b = sh_term(lo + 4, x, y, z);
-    c[q] = (_Float16)(h ? b : a);
-  }
-  return c;
-}
-
-// ---------------------------------------------------------------------------------------------
-// MFMA register chain.
-//
-// Every layer is computed TRANSPOSED: H^T[unit][sample] = W[unit][k] * X^T[k][sample] with
-// v_mfma_f32_32x32x16_f16 (A = 32 weight rows x 16 k, B = 16 k x 32 samples).  The accumulator layout of
-// that instruction gives lane (j = lane & 31, h = lane >> 5) the 16 units {4h + (r & 3) + 8 (r >> 2)} of
-// sample j -- and the B operand of the next layer wants, per 16-wide k chunk, 8 k values of sample j from
-// each half-wave.  A matrix product does not care in which order k is summed, so the k order of every
-// chunk is DEFINED as "what the accumulator already holds": chunk 0 of a 32-unit tile = registers r 0..7
-// (units 4h..4h+3, 8+4h..8+4h+3), chunk 1 = r 8..15; the weight fragments are gathered into LDS in that
-// same order once per workgroup.  A layer's output becomes the next layer's input by ReLU + cvt_f16 in
-// place: no LDS round trip, no shuffles, no transposes between the five layers.
-//
-// A wave handles 64 samples per iteration as two column tiles: tile 0 = even samples, tile 1 = odd ones, so
-// lane j owns samples (2j, 2j+1) and every unit-major load / store is one dword per lane = 128 contiguous
-// bytes per half-wave.  The kernels are HBM-bound on the saved activations (forward ~0.5 KB, backward
-// ~0.9 KB per sample); the 40 MFMAs per 32 samples are a few microseconds per 2^18 samples.
-// ---------------------------------------------------------------------------------------------
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-#define MLP_ITERS 2  // 64-sample iterations per wave
-
-// fragment tables: (weight offset, rows of A, columns of A (= K), first fragment); A = W (forward) or W^T (backward)
-// forward : L1 W1[64][32]  L2 W2[16][64]  L3 W3[64][32]  L4 W4[64][64]  L5 W5[16][64]
-#define FW_L1 0
-#define FW_L2 4
-#define FW_L3 8
-#define FW_L4 12
-#define FW_L5 20
-#define FW_NFRAG 24
-// backward: L5^T [64][16]  L4^T [64][64]  L3^T [32][64]  L2^T [64][16]  L1^T [32][64]
-#define BW_L5 0
-#define BW_L4 2
-#define BW_L3 10
-#define BW_L2 14
-#define BW_L1 16
-#define BW_NFRAG 20
-
-// k (column of A) that lane half h supplies as element q of chunk cc
-__device__ __forceinline__ int frag_k(int cc, int h, int q) { return 16 * cc + 4 * h + (q & 3) + 8 * (q >> 2); }
-// unit (row of D) that lane half h holds in accumulator register r of row tile it
-__device__ __forceinline__ int acc_unit(int it, int h, int r) { return 32 * it + 4 * h + (r & 3) + 8 * (r >> 2); }
-
-// Unit-major addressing [unit][sample], split so that the compiler keeps ONE 32-bit lane offset for every row of every
-// tensor: element (unit, sample) with unit = u + 4 h (u = the wave-uniform part of acc_unit / frag_k) lives at
-//   (base + u N) [uniform: scalar registers]  +  2 (4 h N + sample) bytes [per lane: one VGPR]
-// -> `global_load/store_dword v, v_off, s[base:base+1]`.  Written as 64-bit per-row addresses the same accesses cost two
-// address VGPRs and a 64-bit multiply-add per row and pushed the backward kernel to 240 VGPRs.
-__device__ __forceinline__ int urow(int it, int r) { return 32 * it + (r & 3) + 8 * (r >> 2); }
-__device__ __forceinline__ int ufrag(int cc, int q) { return 16 * cc + (q & 3) + 8 * (q >> 2); }
-__device__ __forceinline__ uint32_t lane_bytes(int h, long N, long np) { return (uint32_t)((4 * (long)h * N + np) * 2); }
-__device__ __forceinline__ uint32_t* um_at(_Float16* row, uint32_t boff) {
-  return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(row) + boff);
-}
-__device__ __forceinline__ const uint32_t* um_at(const _Float16* row, uint32_t boff) {
-  return reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(row) + boff);
-}
-
-// gather the fragments of one layer into LDS: frag (it, cc) -> Wf[(first + it * nchunk + cc) * 64 + lane]
-template <bool TRANSPOSED>
-__device__ __forceinline__ void fill_frags(f16x8* Wf, const _Float16* __restrict__ W, int woff, int nout, int nin,
-                                           int first) {
-  const int rows = TRANSPOSED ? nin : nout, cols = TRANSPOSED ? nout : nin;  // of A
-  const int ntile = (rows + 31) / 32, nchunk = cols / 16;
-  for (int e = threadIdx.x; e < ntile * nchunk * 64; e += 256) {
-    const int lane = e & 63, f = e >> 6, it = f / nchunk, cc = f % nchunk;
-    const int row = 32 * it + (lane & 31), h = lane >> 5;
-    f16x8 v;
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int k = frag_k(cc, h, q);
-      v[q] = row < rows ? (TRANSPOSED ? W[woff + k * nin + row] : W[woff + row * nin + k]) : (_Float16)0;
-    }
-    Wf[(first + f) * 64 + lane] = v;
-  }
-}
-
-// one row tile of one layer: acc = sum over chunks A(it, cc) * B(cc)
-template <int NCHUNK>
-__device__ __forceinline__ f32x16 layer_tile(const f16x8* Wf, int first, int it, int lane, const f16x8* bin) {
-  f32x16 acc = (f32x16)0.0f;
-#pragma unroll
-  for (int cc = 0; cc < NCHUNK; cc++)
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[(first + it * NCHUNK + cc) * 64 + lane], bin[cc], acc, 0, 0, 0);
-  return acc;
-}
-
-// the same with the fragments in GLOBAL memory (the packed table, L1 / L2 resident), read through a BUFFER resource: the address of
-// fragment f is (SGPR resource) + (one VGPR: 16 x lane) + (scalar f x 1 KB).  Written as Wf[f * 64 + lane] the compiler built a
-// 64-bit per-lane address for every fragment whose offset does not fit the 12-bit immediate, hoisted all of them out of the sample
-// loop and kept them live: ~80 of the weight-gradient kernel's registers.
-typedef uint32_t mlp_u32x4 __attribute__((ext_vector_type(4)));
-template <int NCHUNK>
-__device__ __forceinline__ f32x16 layer_tile_b(__amdgpu_buffer_rsrc_t Wf, int first, int it, uint32_t lane16, const f16x8* bin) {
-  f32x16 acc = (f32x16)0.0f;
-#pragma unroll
-  for (int cc = 0; cc < NCHUNK; cc++) {
-    const mlp_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(Wf, lane16, (first + it * NCHUNK + cc) * 1024, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), bin[cc], acc, 0, 0, 0);
-  }
-  return acc;
-}
-
-__device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
-  const f16x2 v = {a, b};
-  return __builtin_bit_cast(uint32_t, v);
-}
-__device__ __forceinline__ f16x2 unpack2(uint32_t w) { return __builtin_bit_cast(f16x2, w); }
-
+#include "ngp_mlp_common.h"
 // store the 16 (tile 0, tile 1) pairs of one 32-unit tile unit-major: row acc_unit(it, h, r), samples np, np + 1
 __device__ __forceinline__ void store_tile(_Float16* __restrict__ dst, long N, uint32_t boff, int it, const f16x8* t0,
                                            const f16x8* t1) {  // t0/t1: chunks [2 it], [2 it + 1] of tile 0 / 1
@@ -233,21 +56,6 @@ __device__ __forceinline__ uint32_t relu_bits(const f16x8& lo, const f16x8& hi, 
 }
 __device__ __forceinline__ uint2* mask_at(uint32_t* masks, int layer, int h, long N, long np) {
   return reinterpret_cast<uint2*>(masks + ((long)(layer * 2 + h) * N + np));
-}
-
-// samples to process: the by-value N, or the device count rounded up to 8 (the tail slots carry zero gradients)
-__device__ __forceinline__ long ngp_count(long N, const int* n_dev) {
-  if (n_dev == nullptr) return N;
-  const long c = ((long)*n_dev + 7) & ~7L;
-  return c < N ? c : N;
-}
-
-// the exact device count (ngp_count rounds it up to 8): the up to 7 slots between the two carry ZERO upstream gradient, whatever
-// the loss-gradient buffer holds there -- the kernels that read dL/dout mask them, so nobody has to clear that buffer per step
-__device__ __forceinline__ long ngp_exact(long N, const int* n_dev) {
-  if (n_dev == nullptr) return N;
-  const long c = (long)*n_dev;
-  return c < N ? c : N;
 }
 
 // SAVE = the activation buffers are written (round 2's training form, inference never).  As a template parameter, not a run-time
@@ -1008,15 +816,6 @@ __global__ __launch_bounds__(256) void ngp_mlp_pack_frags_kernel(const _Float16*
   fill_frags<true>(ob, W, W1_OFF, 64, 32, BW_L1);
 }
 
-struct MlpWgradArgs {
-  const f16x8* frags;      // ngp_mlp_pack_frags_kernel's table
-  const _Float16* featT;
-  const float* dirs;
-  const _Float16* dLdout;
-  float* partial;          // [gridDim.x][W_TOTAL]
-  long N;
-  const int* n_dev;
-};
 
 __device__ __forceinline__ void stage_chunk64(_Float16* stage, int row0, const f16x8& v, int cc, int h, int col) {
 #pragma unroll
@@ -1206,281 +1005,6 @@ __global__ __launch_bounds__(128, 2) void ngp_mlp_wgrad_recompute_kernel(MlpWgra
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Weight gradients WITHOUT LDS staging and without barriers (round 4, default; NS_NGP_WGRAD=staged selects the kernel above).
-//
-// dW = dY X^T contracts over samples: both MFMA operands need the sample index along k, i.e. INSIDE a lane's fragment, while the
-// forward / backward chains hold a sample per lane and the units inside the fragment.  The kernel above turned every activation and
-// gradient around through a 46-KB LDS tile (240 two-byte LDS stores per lane and 11 barriers per 64 samples, two waves per workgroup:
-// 105-167 us for 6 us worth of MFMA work, and the longest link of the training step's side stream).  The matrix core can do the
-// turning itself: for a chain fragment F (lane = sample s, elements = 16 units) and the selection matrix E (E[k][j] = 1 iff unit k
-// lands in column j), the product F x E has the SAME values with lane = unit and elements = samples -- exactly a k-fragment of the
-// weight-gradient MFMA, because the accumulator layout of v_mfma_f32_32x32x16 (rows 4h + (r & 3) + 8 (r >> 2)) is the operand
-// layout the chains already use (frag_k).  Exact: every output is one f16 value times 1 plus zeros.  Two MFMAs per 32 units.
-// The features are read UNIT-MAJOR as stored (lane = unit, 8-byte loads of 4 consecutive samples): that is already the turned
-// form, and the chain's form of them is one more such product.  Everything a 32-sample tile needs stays in the registers of ONE
-// wave: 90 MFMAs per tile (36 chain + 30 turning + 24 weight-gradient), all twelve 32 x 32 accumulator tiles of the five weight
-// matrices resident (192 registers; one wave per SIMD), the weight fragments read from a 44-KB LDS copy of the packed table.
-// No barrier inside the sample loop; the four waves of a workgroup meet once, at the end, to add their accumulators in LDS in
-// wave order (deterministic) into one 40-KB slab per workgroup.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tr_pair(const f16x8& a0, const f16x8& a1, const f16x8& E0, const f16x8& E1, f16x8 (&out)[2]) {
-  f32x16 acc = (f32x16)0.0f;
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, E0, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, E1, acc, 0, 0, 0);
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    out[0][r] = (_Float16)acc[r];
-    out[1][r] = (_Float16)acc[8 + r];
-  }
-}
-__device__ __forceinline__ void tr_one(const f16x8& a0, const f16x8& E0, f16x8 (&out)[2]) {
-  f32x16 acc = (f32x16)0.0f;
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, E0, acc, 0, 0, 0);
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    out[0][r] = (_Float16)acc[r];
-    out[1][r] = (_Float16)acc[8 + r];
-  }
-}
-// dW tile += dY^T (rows = output units) x X^T (columns = input units) over the tile's 32 samples (two k chunks)
-__device__ __forceinline__ void wg_acc(f32x16& acc, const f16x8 (&dyT)[2], const f16x8 (&xT)[2]) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(dyT[0], xT[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(dyT[1], xT[1], acc, 0, 0, 0);
-}
-template <int NCHUNK>
-__device__ __forceinline__ f32x16 layer_tile_l(const f16x8* Wf, int first, int it, int lane, const f16x8* bin) {
-  f32x16 acc = (f32x16)0.0f;
-#pragma unroll
-  for (int cc = 0; cc < NCHUNK; cc++)
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[(first + it * NCHUNK + cc) * 64 + lane], bin[cc], acc, 0, 0, 0);
-  return acc;
-}
-// ReLU on PACKED halves, and its mask as one bit per unit in a layout of this kernel's own: pair p (registers 2p, 2p + 1 of the
-// accumulator tile) of row tile `it` -> bits (8 it + p) and (16 + 8 it + p).  Four instructions per pair for the mask (add,
-// shift, and, shift-or), four for the gate (shift, and, multiply by 0xffff, and).
-__device__ __forceinline__ void relu_frag(const f32x16& acc, int it, f16x8* out, uint32_t& mask) {
-#pragma unroll
-  for (int p = 0; p < 8; p++) {
-    f16x2 v = {(_Float16)acc[2 * p], (_Float16)acc[2 * p + 1]};
-    v = __builtin_elementwise_max(v, (f16x2)(_Float16)0);
-    out[2 * it + (p >> 2)][2 * (p & 3)] = v[0];
-    out[2 * it + (p >> 2)][2 * (p & 3) + 1] = v[1];
-    // (relu output >= +0, i.e. halves 0x0000 .. 0x7c00: adding 0x7fff sets bit 15 exactly when the half is non-zero, no carry out)
-    const uint32_t nz = ((__builtin_bit_cast(uint32_t, v) + 0x7fff7fffu) >> 15) & 0x00010001u;
-    mask |= nz << (8 * it + p);
-  }
-}
-__device__ __forceinline__ void gate_frag(const f32x16& acc, int it, uint32_t mask, f16x8* out) {
-#pragma unroll
-  for (int p = 0; p < 8; p++) {
-    const f16x2 v = {(_Float16)acc[2 * p], (_Float16)acc[2 * p + 1]};
-    const uint32_t keep = ((mask >> (8 * it + p)) & 0x00010001u) * 0xffffu;
-    const f16x2 g = __builtin_bit_cast(f16x2, __builtin_bit_cast(uint32_t, v) & keep);
-    out[2 * it + (p >> 2)][2 * (p & 3)] = g[0];
-    out[2 * it + (p >> 2)][2 * (p & 3) + 1] = g[1];
-  }
-}
-// one wave's accumulator tile into the workgroup's slab (LDS): stored by the first wave, added by the others
-__device__ __forceinline__ void wgrad_slab(float* S, bool add, int woff, int to, int ti, int nout, int nin, int lane, const f32x16& acc) {
-  const int col = lane & 31, half = lane >> 5;
-  const int j = ti * 32 + col;
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int i = to * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (i < nout && j < nin) {
-      float* p = S + woff + i * nin + j;
-      *p = add ? *p + acc[r] : acc[r];
-    }
-  }
-}
-
-#define WT_SLAB_FLOATS (((FW_NFRAG + BW_NFRAG) * 64 * 16) / 4)   // the fragment table's LDS doubles as the slab (11264 >= 10240 floats)
-__global__ __launch_bounds__(256, 1) void ngp_mlp_wgrad_tr_kernel(MlpWgradArgs a) {
-  __shared__ __attribute__((aligned(16))) f16x8 Wf0[(FW_NFRAG + BW_NFRAG) * 64];   // 44 KB
-#pragma unroll 4
-  for (int e = threadIdx.x; e < (FW_NFRAG + BW_NFRAG) * 64; e += 256) Wf0[e] = a.frags[e];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  const long N = a.N, cnt = ngp_count(a.N, a.n_dev), exact = ngp_exact(a.N, a.n_dev);
-  // selection matrices: E0 sends unit k(h, q) of an even chunk to column k, E1 unit k of an odd chunk to column 16 + k
-  f16x8 E0, E1;
-#pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const int kq = frag_k(0, h, q);
-    E0[q] = (j == kq) ? (_Float16)1.0f : (_Float16)0.0f;
-    E1[q] = (j == 16 + kq) ? (_Float16)1.0f : (_Float16)0.0f;
-  }
-  f32x16 w5[2], w4[2][2], w3[2], w2[2], w1[2];
-#pragma unroll
-  for (int t = 0; t < 2; t++) {
-    w5[t] = w3[t] = w2[t] = w1[t] = (f32x16)0.0f;
-    w4[t][0] = w4[t][1] = (f32x16)0.0f;
-  }
-  typedef _Float16 f16x4l __attribute__((ext_vector_type(4)));
-  const long ntile = (cnt + 31) / 32;
-  // the tile's global inputs are fetched ONE TILE AHEAD: with one wave per SIMD nothing else covers a load's ~2 us
-  struct TileIn {
-    f16x4l xlo[2], xhi[2];   // features, unit-major: lane = unit j, samples s0 + 16 c + 4 h + {0..3}, {8..11}
-    float dx, dy, dz;        // direction of sample s0 + j
-    f16x4l go;               // loss gradient (r, g, b, d) of sample s0 + j
-  };
-  auto fetch = [&](long tile, TileIn& in) {
-    const long s0 = tile * 32;
-    const bool live = tile < ntile;
-    const _Float16* row = a.featT + (long)j * N + (live ? s0 : 0) + 4 * h;
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-      in.xlo[c] = *reinterpret_cast<const f16x4l*>(row + 16 * c);
-      in.xhi[c] = *reinterpret_cast<const f16x4l*>(row + 16 * c + 8);
-    }
-    const long np = s0 + j;
-    const long ns = live && np < cnt ? np : 0;
-    in.dx = a.dirs[ns * 3];
-    in.dy = a.dirs[ns * 3 + 1];
-    in.dz = a.dirs[ns * 3 + 2];
-    in.go = (f16x4l)(_Float16)0;
-    if (live && np < exact) in.go = *reinterpret_cast<const f16x4l*>(a.dLdout + np * 4);
-  };
-  TileIn cur, nxt;
-  fetch((long)blockIdx.x * 4 + wave, cur);
-  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntile; tile += (long)gridDim.x * 4) {
-    const long s0 = tile * 32;
-    fetch(tile + (long)gridDim.x * 4, nxt);
-    // (an offset the compiler cannot see through: the 36 fragment reads of a tile are loop-invariant LDS loads, and hoisted out of
-    //  the tile loop they would occupy 144 registers for the whole kernel)
-    int opq = 0;
-    asm volatile("" : "+v"(opq));
-    const f16x8* Wf = Wf0 + opq;
-    const f16x8* Wb = Wf + FW_NFRAG * 64;
-    f16x8 xT[2];
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        xT[c][q] = cur.xlo[c][q];
-        xT[c][4 + q] = cur.xhi[c][q];
-      }
-    if (s0 + 32 > cnt) {          // (wave-uniform: the last tile) slots the marcher did not fill hold stale features
-#pragma unroll
-      for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-          if (s0 + 16 * c + frag_k(0, h, q) >= cnt) xT[c][q] = (_Float16)0;
-    }
-    const f16x4l go = cur.go;
-    // ---- forward chain (the instruction sequence of ngp_mlp_fwd_kernel), every activation also turned for the weight gradients ----
-    f16x8 x[2];
-    tr_pair(xT[0], xT[1], E0, E1, x);                 // lane = sample, elements = units: the chain's form of the features
-    uint32_t m1 = 0, m3 = 0, m4 = 0;
-    f16x8 h1T[2][2], cinT[2], h3T[2][2], h4T[2][2];
-    f16x8 cin[2];
-    {
-      f16x8 h1[4];
-#pragma unroll
-      for (int it = 0; it < 2; it++) relu_frag(layer_tile_l<2>(Wf, FW_L1, it, lane, x), it, h1, m1);
-      tr_pair(h1[0], h1[1], E0, E1, h1T[0]);
-      tr_pair(h1[2], h1[3], E0, E1, h1T[1]);
-      const f32x16 acc = layer_tile_l<4>(Wf, FW_L2, 0, lane, h1);
-#pragma unroll
-      for (int r = 0; r < 8; r++) cin[0][r] = (_Float16)acc[r];
-      cin[1] = sh_chunk(cur.dx, cur.dy, cur.dz, h);
-      tr_pair(cin[0], cin[1], E0, E1, cinT);
-    }
-    f16x8 d4[4];
-    {
-      f16x8 h3[4], h4[4];
-#pragma unroll
-      for (int it = 0; it < 2; it++) relu_frag(layer_tile_l<2>(Wf, FW_L3, it, lane, cin), it, h3, m3);
-      tr_pair(h3[0], h3[1], E0, E1, h3T[0]);
-      tr_pair(h3[2], h3[3], E0, E1, h3T[1]);
-#pragma unroll
-      for (int it = 0; it < 2; it++) relu_frag(layer_tile_l<4>(Wf, FW_L4, it, lane, h3), it, h4, m4);
-      tr_pair(h4[0], h4[1], E0, E1, h4T[0]);
-      tr_pair(h4[2], h4[3], E0, E1, h4T[1]);
-    }
-    // ---- backward chain; every gradient turned and contracted with the turned activation of its layer's input ----
-    f16x8 d5 = (f16x8)(_Float16)0;
-    if (h == 0) {
-      d5[0] = go[0];
-      d5[1] = go[1];
-      d5[2] = go[2];
-    }
-    {
-      f16x8 d5T[2];
-      tr_one(d5, E0, d5T);                            // W5: dY = d5 (16 rows), X = h4
-      wg_acc(w5[0], d5T, h4T[0]);
-      wg_acc(w5[1], d5T, h4T[1]);
-    }
-#pragma unroll
-    for (int it = 0; it < 2; it++) gate_frag(layer_tile_l<1>(Wb, BW_L5, it, lane, &d5), it, m4, d4);
-    {
-      f16x8 d4T[2][2];
-      tr_pair(d4[0], d4[1], E0, E1, d4T[0]);
-      tr_pair(d4[2], d4[3], E0, E1, d4T[1]);          // W4: dY = d4, X = h3
-#pragma unroll
-      for (int to = 0; to < 2; to++)
-#pragma unroll
-        for (int ti = 0; ti < 2; ti++) wg_acc(w4[to][ti], d4T[to], h3T[ti]);
-    }
-    f16x8 d3[4];
-#pragma unroll
-    for (int it = 0; it < 2; it++) gate_frag(layer_tile_l<4>(Wb, BW_L4, it, lane, d4), it, m3, d3);
-    {
-      f16x8 d3T[2][2];
-      tr_pair(d3[0], d3[1], E0, E1, d3T[0]);
-      tr_pair(d3[2], d3[3], E0, E1, d3T[1]);          // W3: dY = d3, X = cin (32 rows)
-      wg_acc(w3[0], d3T[0], cinT);
-      wg_acc(w3[1], d3T[1], cinT);
-    }
-    f16x8 dd;
-    {
-      const f32x16 acc = layer_tile_l<4>(Wb, BW_L3, 0, lane, d3);
-#pragma unroll
-      for (int r = 0; r < 8; r++) dd[r] = (_Float16)acc[r];
-      if (h == 0) dd[0] = (_Float16)((float)dd[0] + (float)go[3]);
-      f16x8 ddT[2];
-      tr_one(dd, E0, ddT);                            // W2: dY = dd (16 rows), X = h1
-      wg_acc(w2[0], ddT, h1T[0]);
-      wg_acc(w2[1], ddT, h1T[1]);
-    }
-    {
-      f16x8 d1[4], d1T[2][2];
-#pragma unroll
-      for (int it = 0; it < 2; it++) gate_frag(layer_tile_l<1>(Wb, BW_L2, it, lane, &dd), it, m1, d1);
-      tr_pair(d1[0], d1[1], E0, E1, d1T[0]);
-      tr_pair(d1[2], d1[3], E0, E1, d1T[1]);          // W1: dY = d1, X = the features
-      wg_acc(w1[0], d1T[0], xT);
-      wg_acc(w1[1], d1T[1], xT);
-    }
-    cur = nxt;
-  }
-  // ---- the four waves' accumulators -> one slab per workgroup, added in wave order ----
-  float* S = reinterpret_cast<float*>(Wf0);
-  for (int w = 0; w < 4; w++) {
-    __syncthreads();          // (first round: every wave has read its last weight fragment)
-    if (wave == w) {
-      const bool add = w > 0;
-      wgrad_slab(S, add, W5_OFF, 0, 0, 16, 64, lane, w5[0]);
-      wgrad_slab(S, add, W5_OFF, 0, 1, 16, 64, lane, w5[1]);
-#pragma unroll
-      for (int to = 0; to < 2; to++)
-#pragma unroll
-        for (int ti = 0; ti < 2; ti++) wgrad_slab(S, add, W4_OFF, to, ti, 64, 64, lane, w4[to][ti]);
-      wgrad_slab(S, add, W3_OFF, 0, 0, 64, 32, lane, w3[0]);
-      wgrad_slab(S, add, W3_OFF, 1, 0, 64, 32, lane, w3[1]);
-      wgrad_slab(S, add, W2_OFF, 0, 0, 16, 64, lane, w2[0]);
-      wgrad_slab(S, add, W2_OFF, 0, 1, 16, 64, lane, w2[1]);
-      wgrad_slab(S, add, W1_OFF, 0, 0, 64, 32, lane, w1[0]);
-      wgrad_slab(S, add, W1_OFF, 1, 0, 64, 32, lane, w1[1]);
-    }
-  }
-  __syncthreads();
-  float4* P = reinterpret_cast<float4*>(a.partial + (long)blockIdx.x * W_TOTAL);
-  const float4* S4 = reinterpret_cast<const float4*>(S);
-  for (int e = threadIdx.x; e < W_TOTAL / 4; e += 256) P[e] = S4[e];
-}
-
 extern "C" size_t ns_ngp_mlp_fragment_table_bytes(void) { return (size_t)(FW_NFRAG + BW_NFRAG) * 64 * sizeof(f16x8); }
 
 // packed MFMA fragment table of the current weights (forward + transposed), for ns_ngp_mlp_wgrad_recompute_n
@@ -1511,8 +1035,8 @@ extern "C" int ns_ngp_mlp_wgrad_recompute_n(const void* frags, const void* featT
     wgs = (int)std::max(1L, std::min((long)std::min(wgs, cus), tiles4));
     NS_REQUIRE(((uintptr_t)featT % 8) == 0 && ((uintptr_t)dLdout % 8) == 0 && ((uintptr_t)partial_ws % 16) == 0,
                "ns_ngp_mlp_wgrad_recompute: featT / dLdout must be 8-byte, partial_ws 16-byte aligned");
-    hipLaunchKernelGGL(ngp_mlp_wgrad_tr_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, a);
-    NS_CHECK_LAUNCH("ngp_mlp_wgrad_tr_kernel");
+    const int rc = ngp_mlp_wgrad_tr_launch(a, wgs, (hipStream_t)stream);
+    if (rc != NS_OK) return rc;
   }
   hipLaunchKernelGGL(ngp_mlp_wgrad_reduce_kernel, dim3(W_TOTAL / 16), dim3(256), 0, (hipStream_t)stream, partial_ws, wgs, grad_weights);
   NS_CHECK_LAUNCH("ngp_mlp_wgrad_reduce_kernel");

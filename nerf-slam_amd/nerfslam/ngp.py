@@ -506,7 +506,10 @@ class NgpNerf:
         # (round 4: every dense level goes through the bins by default -- no owner-computes pass, and without the A/B gather
         #  form of the pose gradient no third stream either)
         dense_pass = self.fused_ws and int(L.ns_ngp_encode_backward_fused_dense_levels(*self._grid_args())) > 0
-        use_side2 = gather_pose or dense_pass
+        # the pose refinement's chain (Jacobian dot, camera gradient, reduce, pose step: ~45 us of small kernels) runs on the third
+        # stream, next to the weight-gradient chain of `side` instead of behind it (NS_NGP_POSE_ON_SIDE=1: round 3's placement)
+        pose_on_side2 = pose and not gather_pose and not os.environ.get("NS_NGP_POSE_ON_SIDE")
+        use_side2 = gather_pose or dense_pass or pose_on_side2
         if use_side2:
             with torch.cuda.stream(self._side2):
                 self._side2.wait_event(fork)
@@ -515,6 +518,10 @@ class NgpNerf:
                 if dense_pass:
                     table_gradient(4, stream_ptr())
                     table_gradient(8, stream_ptr())
+                if pose_on_side2:
+                    pose_gradient(stream_ptr())
+                    if single:
+                        camera_step(stream_ptr())
         if gather_pose:
             hashed_levels()
         with torch.cuda.stream(self._side):
@@ -526,9 +533,9 @@ class NgpNerf:
                       "ngp_mlp_wgrad")
             if single and mlp_mode != "split":
                 mlp_adam(st1)
-            if pose and not gather_pose:
+            if pose and not gather_pose and not pose_on_side2:
                 pose_gradient(st1)
-            if pose and single:
+            if pose and single and not pose_on_side2:
                 camera_step(st1)
         if use_side2:
             main.wait_stream(self._side2)
