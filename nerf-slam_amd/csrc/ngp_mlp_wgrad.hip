@@ -282,6 +282,12 @@ __global__ __launch_bounds__(256, 1) void ngp_mlp_wgrad_tr_kernel(MlpWgradArgs a
 }
 
 
+// Tried and dropped (round 4): the same kernel in TWO ROLES (workgroup A: dW4, dW5; workgroup B: dW3, dW2, dW1; 96 accumulator
+// registers each, both chains recomputed by both) so that a wave leaves room for another kernel's waves on its SIMD: 301 registers
+// without spills (256 only with 40 of them in scratch), 60.8 us stand-alone against 44.4, and no gain in the training step
+// (0.289-0.293 against 0.282-0.286 ms) or in the pipeline (123.7 against 122.6-124.8 frames/s).  One role it stays.
+
+// wgs = slabs of a.partial that end up written (the caller reduces exactly that many)
 int ngp_mlp_wgrad_tr_launch(const MlpWgradArgs& a, int wgs, hipStream_t stream) {
   hipLaunchKernelGGL(ngp_mlp_wgrad_tr_kernel, dim3(wgs), dim3(256), 0, stream, a);
   NS_CHECK_LAUNCH("ngp_mlp_wgrad_tr_kernel");

@@ -360,8 +360,12 @@ class NgpNerf:
         # (under capture the ORDER of these calls decides which hardware queue a branch gets: with the forward pass enqueued
         #  before this branch, the executor put the branch behind side2's kernels on one queue and the step took 0.58 ms; the
         #  same swap in the second step of a paired graph only: 0.43 -> 0.50 ms)
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
+        # (round 4: the next step's rays go to the THIRD stream, which is idle until the pose chain forks after the activation
+        #  gradients; on `side` the march (~95 us of latency-bound work in a handful of waves) held the weight-gradient kernel back
+        #  until the scatter had filled the CUs, and that kernel needs whole SIMDs.  NS_NGP_RAYS_ON_SIDE=1: round 3's placement)
+        ray_stream = self._side if os.environ.get("NS_NGP_RAYS_ON_SIDE") else self._side2
+        ray_stream.wait_stream(main)
+        with torch.cuda.stream(ray_stream):
             check(L.ns_ngp_step_prepare(ptr(X["ctl"]), ptr(Y["ctl"]), ptr(X["counter"]), ptr(Y["counter"]), ptr(self.last),
                                         C.c_float(0.9), C.c_long(S), 256, Rc, C.c_float(c.beta1), C.c_float(c.beta2), None,
                                         stream_ptr()), "ngp_step_prepare")
@@ -509,8 +513,8 @@ class NgpNerf:
         # the pose refinement's chain (Jacobian dot, camera gradient, reduce, pose step: ~45 us of small kernels) runs on the third
         # stream, next to the weight-gradient chain of `side` instead of behind it (NS_NGP_POSE_ON_SIDE=1: round 3's placement)
         pose_on_side2 = pose and not gather_pose and not os.environ.get("NS_NGP_POSE_ON_SIDE")
-        use_side2 = gather_pose or dense_pass or pose_on_side2
-        if use_side2:
+        use_side2 = gather_pose or dense_pass or pose_on_side2 or ray_stream is self._side2
+        if gather_pose or dense_pass or pose_on_side2:
             with torch.cuda.stream(self._side2):
                 self._side2.wait_event(fork)
                 if gather_pose:                      # reads the f16 table: before anything rewrites it
