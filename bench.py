@@ -46,6 +46,17 @@ for p in (ROOT, os.path.join(ROOT, "nerf-slam_amd"), os.path.join(ROOT, "tools")
 import numpy as np
 import torch
 
+def _lib_sha256():
+    """sha256 of the HIP library this process runs (what profiles/r04_traffic.json is checked against)"""
+    import hashlib
+    from nerfslam._lib import LIB_PATH
+    h = hashlib.sha256()
+    with open(LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak
 
@@ -242,58 +253,85 @@ def micro_benches(dev, hp, ngp_net):
     from nerfslam._lib import check, lib, ptr, stream_ptr
     out = {"corr_lookup_coop_kernel[E=48]": dict(fn=hp.op_lookup48, bound="hbm", per_launch=ALG_BYTES["lookup48"]),
            "corr_volume_tiled_kernel[E=10]": dict(fn=lambda: hp.op_build(hp.new_i, hp.new_j), bound="hbm", per_launch=ALG_BYTES["build10"])}
-    # hash grid at a full sample budget (2^18 samples), positions along rays like the trainer's
+    # ---- the NeRF trainer's kernels ON A TRAINED STEP'S OWN SAMPLE SET: `ngp_net` has just trained (the
+    # pipeline's mapper, or the sphere-scene trainer of --microbench); its last step left the marched samples, the encoding, the
+    # loss gradient and dL/dfeature in place, and every kernel below is re-launched on exactly those arrays.
     net = ngp_net
-    N = net.cfg.max_samples
-    g = torch.Generator(device=dev).manual_seed(1)
-    # samples in the order the marcher emits them: consecutive steps of one ray are consecutive samples (2048 rays x 128
-    # steps of ~1/600 of the cube); the uniform-random figure (no two consecutive samples share a cell on any level: the
-    # worst case for every cache and for the run-length accumulation of the dense levels) is reported next to it
-    R = 2048
-    o = torch.rand((R, 1, 3), device=dev, generator=g) * 0.4 + 0.3
-    d = torch.nn.functional.normalize(torch.randn((R, 1, 3), device=dev, generator=g), dim=-1)
-    t = (0.02 + 0.0017 * torch.arange(N // R, device=dev))[None, :, None]
-    pos_rays = (o + t * d).clamp(0.0, 1.0).reshape(N, 3).contiguous()
-    pos_unif = torch.rand((N, 3), device=dev, generator=g).contiguous()
-    dfeat = (torch.randn((32, N), device=dev, generator=g) * 1e-3).half().contiguous()
-
-    def enc_fwd(pos):
-        net.encode(pos, net.s_feat)
-
-    # table gradient WITH the optimiser step on the touched entries (round 3: Adam lives in the flush of the accumulation),
-    # on scratch copies of the parameters / moments
     cf = net.cfg
+    S = cf.max_samples
+    X = net.sets[1 - net.cur]                       # the set the last step trained on
+    n = int(X["counter"][2].item())                 # samples the marcher emitted for it
+    n_dev = C.c_void_p(X["counter"].data_ptr() + 8)
+    featT = net.s_feat.view(-1)[:32 * S].view(32, S)
+    args = net._grid_args()
+    L = lib()
+    scr = {"feat": torch.zeros_like(net.s_feat), "out": torch.zeros_like(net.s_out), "masks": torch.zeros_like(net.relu_masks),
+           "dfeat": torch.zeros_like(net.s_dfeat), "gw": torch.zeros_like(net.mlp_grad),
+           "jac": torch.zeros_like(net.s_jac) if getattr(net, "s_jac", None) is not None else None}
+    featS = scr["feat"].view(-1)[:32 * S].view(32, S)
+
+    def enc_fwd():
+        check(L.ns_ngp_encode_forward_j_n(*args, ptr(X["s_pos"]), ptr(net.grid_half), ptr(featS), 1, ptr(scr["jac"]), C.c_long(S), n_dev,
+                                          stream_ptr()), "ngp_encode_forward")
+
+    # table gradient WITH the optimiser step on the touched entries, on scratch copies of the parameters / moments
     bw = {k: torch.zeros_like(net.grid_master) for k in ("master", "m1", "m2")}
     bw["hp"] = torch.zeros_like(net.grid_half)
-    wsb = int(lib().ns_ngp_encode_backward_fused_workspace_bytes(*net._grid_args(), C.c_long(N)))
+    wsb = int(L.ns_ngp_encode_backward_fused_workspace_bytes(*args, C.c_long(S)))
     bws = torch.zeros(wsb // 8 + 1, dtype=torch.int64, device=dev)
 
-    def enc_bwd(pos):
-        check(lib().ns_ngp_encode_backward_fused_n(*net._grid_args(), ptr(pos), ptr(dfeat), None, ptr(bws), C.c_size_t(wsb),
-                                                   C.c_float(cf.grad_fixed_scale), C.c_long(N), None, ptr(bw["master"]), ptr(bw["hp"]),
-                                                   ptr(bw["m1"]), ptr(bw["m2"]), 7, C.c_float(cf.lr), C.c_float(cf.beta1),
-                                                   C.c_float(cf.beta2), C.c_float(cf.eps), C.c_float(cf.loss_scale), None, 15, stream_ptr()),
+    def enc_bwd(parts=15):
+        check(L.ns_ngp_encode_backward_fused_n(*args, ptr(X["s_pos"]), ptr(net.s_dfeat), None, ptr(bws), C.c_size_t(wsb),
+                                               C.c_float(cf.grad_fixed_scale), C.c_long(S), n_dev, ptr(bw["master"]), ptr(bw["hp"]),
+                                               ptr(bw["m1"]), ptr(bw["m2"]), 7, C.c_float(cf.lr), C.c_float(cf.beta1),
+                                               C.c_float(cf.beta2), C.c_float(cf.eps), C.c_float(cf.loss_scale), None, parts, stream_ptr()),
               "ngp_encode_backward_fused")
-    note = ("samples ordered along rays as the marcher emits them (2048 rays x 128 steps); uniform random positions (worst case "
-            "for locality) in avg_launch_us_uniform_random_positions")
-    out["ngp_encode_fwd_kernel[2^18]"] = dict(fn=lambda: enc_fwd(pos_rays), alt=lambda: enc_fwd(pos_unif), bound="hbm", per_launch=588 * N, note=note)
     # table entries the call touches (their optimiser step is part of the call): one gradient-only run, non-zero words counted
     gq = torch.zeros(net.n_grid // 2, dtype=torch.int64, device=dev)
-    check(lib().ns_ngp_encode_backward_fused_n(*net._grid_args(), ptr(pos_rays), ptr(dfeat), ptr(gq), ptr(bws), C.c_size_t(wsb),
-                                               C.c_float(cf.grad_fixed_scale), C.c_long(N), None, None, None, None, None, 7, C.c_float(0),
-                                               C.c_float(0), C.c_float(0), C.c_float(0), C.c_float(1), None, 15, stream_ptr()), "touched")
+    check(L.ns_ngp_encode_backward_fused_n(*args, ptr(X["s_pos"]), ptr(net.s_dfeat), ptr(gq), ptr(bws), C.c_size_t(wsb),
+                                           C.c_float(cf.grad_fixed_scale), C.c_long(S), n_dev, None, None, None, None, 7, C.c_float(0),
+                                           C.c_float(0), C.c_float(0), C.c_float(0), C.c_float(1), None, 15, stream_ptr()), "touched")
     touched = int((gq != 0).sum())
+    live = int((net.s_dfeat.view(-1)[:32 * S].view(32, S)[:, :n] != 0).any(dim=0).sum())
     del gq
-    out["ngp_encode_bwd[2^18]"] = dict(fn=lambda: enc_bwd(pos_rays), alt=lambda: enc_bwd(pos_unif), bound="hbm",
-                                       per_launch=1100 * N + 52 * touched,
-                                       note=note + "; one call = 4 launches: ngp_enc_fscatter, ngp_enc_faccum (hashed levels, Adam in "
-                                       "the flush), ngp_encode_bwd_dense_rl, ngp_enc_dense_reduce (dense levels, Adam in the reduce).  "
-                                       "Algorithmic bytes: round 2's 1100 B per sample for the gradient (16 levels x 8 corners x 8-B "
-                                       "packed read-modify-write + 12 B position + 64 B upstream gradient) PLUS the optimiser step of "
-                                       "the %d table entries the call touches, which lives in its flushes (master + two moments read "
-                                       "and written, f16 copy written: 52 B per entry; round 2 ran it as a separate pass over the "
-                                       "whole table, 93-105 us)" % touched,
-                                       keep=(bw, bws), touched_entries=touched)
+    frags, partial = net.mlp_frags, net.partial_fused
+
+    def mlp_fwd():
+        check(L.ns_ngp_mlp_forward_f_n(ptr(frags), ptr(featT), ptr(X["s_dir"]), ptr(scr["out"]), ptr(scr["masks"]), C.c_long(S), n_dev,
+                                       stream_ptr()), "ngp_mlp_forward")
+
+    def mlp_bwd():
+        check(L.ns_ngp_mlp_dgrad_f_n(ptr(frags), ptr(X["s_dout"]), ptr(net.relu_masks), ptr(scr["dfeat"]), C.c_long(S), n_dev,
+                                     stream_ptr()), "ngp_mlp_dgrad")
+
+    def mlp_wgrad():
+        check(L.ns_ngp_mlp_wgrad_recompute_n(ptr(frags), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]), ptr(partial), net.mlp_wgs,
+                                             ptr(scr["gw"]), C.c_long(S), n_dev, stream_ptr()), "ngp_mlp_wgrad_recompute")
+    where = "the last optimiser step's own %d marched samples (%d of them with a non-zero upstream gradient), budget 2^18" % (n, live)
+    out["ngp_encode_fwd_kernel[step samples]"] = dict(fn=enc_fwd, bound="hbm", per_launch=588 * n, keep=scr, samples=n,
+                                                      note=where + "; 16 levels x 8 corners x 4 B gathered + 12 B position + 64 B "
+                                                      "features per sample (the 192 B / sample of Jacobian rows the pose refinement "
+                                                      "makes it write are not counted)")
+    out["ngp_encode_bwd[step samples]"] = dict(
+        fn=enc_bwd, bound="hbm", per_launch=1100 * n + 52 * touched, keep=(bw, bws), samples=n, touched_entries=touched,
+        parts={"ngp_enc_fscatter_direct_kernel": lambda: enc_bwd(1), "ngp_enc_faccum_kernel": lambda: enc_bwd(2)},
+        in_step=["ngp_enc_fscatter_direct_kernel", "ngp_enc_faccum_kernel"],
+        note=where + "; one call = 2 launches (round 4: every level, dense ones included, through the bins): ngp_enc_fscatter_direct "
+        "(records straight from registers) + ngp_enc_faccum (LDS accumulation, Adam in the flush).  Algorithmic bytes: SURVEY 8(d)'s "
+        "1100 B per sample (16 levels x 8 corners x 8-B packed read-modify-write + 12 B position + 64 B upstream gradient) PLUS the "
+        "optimiser step of the %d table entries the call touches (master + two moments read and written, f16 copy written: 52 B per "
+        "entry)" % touched)
+    out["ngp_mlp_fwd_kernel[step samples]"] = dict(fn=mlp_fwd, bound="mfma", per_launch=20480.0 * n, samples=n, in_step=["ngp_mlp_fwd_kernel"],
+                                                   note=where + "; SURVEY 8(d): 10240 multiply-adds per sample (32->64->16, 32->64->64->16)")
+    out["ngp_mlp_bwd_kernel[step samples]"] = dict(fn=mlp_bwd, bound="mfma", per_launch=20480.0 * n, samples=n, in_step=["ngp_mlp_bwd_kernel"],
+                                                   note=where + "; activation gradients from the ReLU bit masks, dL/dfeature only")
+    out["ngp_mlp_wgrad_tr_kernel[step samples]"] = dict(
+        fn=mlp_wgrad, bound="mfma", per_launch=20480.0 * n, samples=n, in_step=["ngp_mlp_wgrad_tr_kernel + ngp_mlp_wgrad_reduce_kernel"],
+        executed_flop_per_launch=90 * 2.0 * 32 * 32 * 16 * ((n + 31) // 32),
+        note=where + "; algorithmic = the weight-gradient contraction alone (10240 multiply-adds per sample); the kernel EXECUTES 90 "
+        "32x32x16 MFMAs per 32 samples (forward and backward chains recomputed, 30 of them are the turn-arounds through the matrix "
+        "core): `executed_flop_per_launch`; the launch time includes the 256-slab reduce")
+    out["ngp_encode_fwd_kernel[step samples]"]["in_step"] = ["ngp_encode_fwd_kernel"]
     # the update operator's gate convolution (the largest MFMA launch of an update)
     from nerfslam.conv import PackedConv, conv_nhwc
     w = (torch.randn((256, 448, 3, 3), device=dev) / 60).half().float()
@@ -305,10 +343,13 @@ def micro_benches(dev, hp, ngp_net):
 
 
 def kernel_rooflines(dev, hp, ngp_net):
-    """-> {name: {avg_launch_us, algorithmic units per launch, achieved, frac, bound}} from HIP events around trains of
-    back-to-back launches of micro_benches()"""
+    """-> {name: {avg_launch_us, algorithmic units per launch, achieved, frac, bound, in_step_us ...}}: `avg_launch_us` from HIP
+    events around trains of back-to-back launches of micro_benches() (the kernel ALONE on the device); `in_step_us` = the same
+    kernel's duration inside the trainer's optimiser step, next to the kernels of the step's other streams (NgpNerf.probe_steps)."""
     out = {}
-    for k, m in micro_benches(dev, hp, ngp_net).items():
+    ms = micro_benches(dev, hp, ngp_net)          # (built BEFORE the probe: it reads the arrays the last replayed step left)
+    in_step = ngp_net.probe_steps(8) if ngp_net is not None else {}
+    for k, m in ms.items():
         us = _train_us(m["fn"], m.get("reps", 20))
         if m["bound"] == "hbm":
             out[k] = {"bound": "hbm", "avg_launch_us": us, "algorithmic_bytes_per_launch": m["per_launch"],
@@ -317,23 +358,43 @@ def kernel_rooflines(dev, hp, ngp_net):
         else:
             out[k] = {"bound": "mfma", "avg_launch_us": us, "flop_per_launch": m["per_launch"], "achieved": m["per_launch"] / us / 1e6,
                       "unit": "TFLOP/s", "peak": MFMA_F16_PEAK_TFLOPS, "frac": m["per_launch"] / us / 1e6 / MFMA_F16_PEAK_TFLOPS}
-        if m.get("alt") is not None:
-            out[k]["avg_launch_us_uniform_random_positions"] = _train_us(m["alt"])
-        if m.get("note"):
-            out[k]["note"] = m["note"]
+        for kk in ("note", "samples", "executed_flop_per_launch"):
+            if m.get(kk) is not None:
+                out[k][kk] = m[kk]
         if "touched_entries" in m:
             out[k]["touched_table_entries"] = m["touched_entries"]
-            out[k]["gradient_only_algorithmic_bytes"] = 1100 * ngp_net.cfg.max_samples
+            out[k]["gradient_only_algorithmic_bytes"] = 1100 * m["samples"]
+        if m.get("parts"):
+            out[k]["standalone_us_by_kernel"] = {kk: _train_us(fn) for kk, fn in m["parts"].items()}
+        if m.get("in_step"):
+            got = {kk: in_step[kk] for kk in m["in_step"] if kk in in_step}
+            if len(got) == len(m["in_step"]):
+                tot = sum(got.values())
+                out[k]["in_step_us"] = tot
+                out[k]["in_step_us_by_kernel"] = got
+                out[k]["frac_in_step"] = out[k]["frac"] * us / tot
+    if in_step:
+        out["_in_step_all"] = in_step
     return out
+
+
+def _sphere_trainer(dev, steps=208):
+    """a trainer with a trained step behind it for `--microbench` (the PMC passes): tools/ngp_scene.py's sphere, pose refinement on"""
+    from ngp_scene import sphere_scene
+    from nerfslam.ngp import NgpConfig, NgpNerf
+    net = NgpNerf(NgpConfig(optimize_extrinsics=True), dev, seed=0)
+    net.set_images(*sphere_scene())
+    net.train_steps(steps, return_loss=False)
+    torch.cuda.synchronize()
+    return net
 
 
 def run_microbench(dev, name, reps):
     """`bench.py --microbench NAME [--reps n]`: n back-to-back launches of ONE roofline micro-bench and nothing else timed -- the
-    command tools/r03_final.sh wraps in rocprofv3 --kernel-trace --stats / --pmc passes"""
+    command tools/r04_final.sh wraps in rocprofv3 --kernel-trace --stats / --pmc passes"""
     from hot_path_chain import HotPath
-    from nerfslam.ngp import NgpConfig, NgpNerf
     hp = HotPath(dev, seed=0)
-    net = NgpNerf(NgpConfig(), dev, seed=0)
+    net = _sphere_trainer(dev)
     ms = micro_benches(dev, hp, net)
     key = [k for k in ms if k.startswith(name)]
     if len(key) != 1:
@@ -341,7 +402,8 @@ def run_microbench(dev, name, reps):
     m = ms[key[0]]
     m["fn"](); torch.cuda.synchronize()
     us = _train_us(m["fn"], reps)
-    print(json.dumps({"microbench": key[0], "reps": reps, "avg_launch_us": us}))
+    print(json.dumps({"microbench": key[0], "reps": reps, "avg_launch_us": us, "samples": m.get("samples"),
+                      "algorithmic_per_launch": m["per_launch"], "bound": m["bound"]}))
 
 
 # =================================================================================================
@@ -541,7 +603,7 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="report the sequential (no --parallel_run) mode as `value`")
     ap.add_argument("--microbench", default="", help="run ONE roofline micro-bench back to back (for rocprofv3 --pmc passes)")
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps frames each; `value` is their median")
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps frames each; `value` is their median")
     ap.add_argument("--config", default="c640", choices=["c640", "c1280"],
                     help="c640: BASELINE configs[2]/[3] (default, the headline metric); c1280: configs[4], global BA over a 256-keyframe buffer at 1280x720")
     args = ap.parse_args()
@@ -579,8 +641,10 @@ def main():
         if init_frames > 100:
             raise SystemExit("tracker did not initialise within 100 frames")
 
+    nets = pipe.nets
+
     def snapshot():
-        return dict(pipe.tracker.stats), pipe.tracker.fe.n_updates, int(ngp.training_step)
+        return dict(pipe.tracker.stats), pipe.tracker.fe.n_updates, int(ngp.training_step), int(getattr(nets, "harness_launches", 0))
 
     def timed(nframes):
         """exactly `nframes` frames of the stream; device idle and mapper queue empty on both sides"""
@@ -591,10 +655,10 @@ def main():
             pipe.frame()
         pipe.drain()
         dt = time.perf_counter() - t0
-        (st0, up0, ns0), (st1, up1, ns1) = s0, snapshot()
+        (st0, up0, ns0, hl0), (st1, up1, ns1, hl1) = s0, snapshot()
         cnt = {"frames": nframes, "keyframe_candidates": st1["candidates"] - st0["candidates"],
                "candidates_rejected_by_distance_test": st1["rejected"] - st0["rejected"], "updates": up1 - up0,
-               "nerf_train_steps": ns1 - ns0}
+               "nerf_train_steps": ns1 - ns0, "harness_only_launches": hl1 - hl0}
         return dt, cnt
 
     # ---- (1) the reported number: --parallel_run on one GPU (tracker thread + mapper thread, two HIP streams) ----
@@ -657,7 +721,13 @@ def main():
                    "init_frames_untimed": init_frames, "buffer": buffer, "parallelism": "single GPU",
                    "launch": "tracker: eager launches, no host synchronisation inside update(); mapper: one HIP-graph replay per optimiser step"},
         "counts": counts,
+        "harness": {"launches_per_frame": counts["harness_only_launches"] / K,
+                    "note": "device launches of the synthetic HARNESS inside the timed region (tools/synth_stream.py: the scene's true flow "
+                            "computed after the real networks ran -- 2 reprojections + subtract + fill per update, 6 small ones per "
+                            "motion-filter pass); they are not product work and make `value` conservative"},
         "windows": windows,
+        "windows_frames_per_s": {"min": min(w["frames_per_s"] for w in windows), "median": K / dt,
+                                 "max": max(w["frames_per_s"] for w in windows)},
         "nerf_train_steps_per_s": counts["nerf_train_steps"] / dt,
         "sequential": sequential,
         "breakdown": breakdown,
@@ -668,35 +738,56 @@ def main():
         hp, extra["hot_path_chain"] = hot_path_chain(dev, 10, 2)
         roofs = kernel_rooflines(dev, hp, ngp._net)
         # share of the timed region per candidate kernel (launch time x launches per timed frame)
+        steps_pf = counts["nerf_train_steps"] / K
         per_frame = {"corr_lookup_coop_kernel[E=48]": counts["updates"] / K, "corr_volume_tiled_kernel[E=10]": counts["keyframe_candidates"] / K,
-                     "ngp_encode_fwd_kernel[2^18]": counts["nerf_train_steps"] / K, "ngp_encode_bwd[2^18]": counts["nerf_train_steps"] / K,
-                     "ngp_adam_kernel[hash grid]": counts["nerf_train_steps"] / K,
                      "conv_nhwc_kernel<3x3,448->256>[E=48]": counts["updates"] / K}
+        in_step_all = roofs.pop("_in_step_all", {})
         for k, r in roofs.items():
-            r["launches_per_frame"] = per_frame.get(k, 0.0)
+            r["launches_per_frame"] = steps_pf if k.startswith("ngp_") else per_frame.get(k, 0.0)
             r["ms_per_frame"] = r["avg_launch_us"] * r["launches_per_frame"] / 1e3
         dom = max(roofs, key=lambda k: roofs[k]["ms_per_frame"])
         d = roofs[dom]
-        out["roofline"] = {"bound": d["bound"], "kernel": dom, "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                           "frac": d["frac"], "traffic": None, "avg_launch_us": d["avg_launch_us"],
-                           "ms_per_frame_of_this_kernel": d["ms_per_frame"],
-                           "other": {k: v for k, v in roofs.items() if k != dom}}
-        # rocprofv3 evidence of the SAME launches (tools/r03_final.sh): HBM bytes per launch from separate --pmc passes over
+        out["roofline"] = {"kernel": dom, "traffic": None, "ms_per_frame_of_this_kernel": d["ms_per_frame"]}
+        out["roofline"].update({k: v for k, v in d.items() if k != "ms_per_frame"})
+        out["roofline"]["other"] = {k: v for k, v in roofs.items() if k != dom}
+        # B3: the marcher is latency-bound (a ray is a chain of dependent occupancy look-ups; ~1000 rays per step keep a few dozen
+        # waves busy): its bytes are a footnote, its duration inside the step is what the step pays for it on the third stream
+        if in_step_all.get("ngp_sample_rays + ngp_march (next step's rays)") is not None:
+            n_s, n_r = counts["nerf_samples_per_step"], counts["nerf_rays_per_step"]
+            us = in_step_all["ngp_sample_rays + ngp_march (next step's rays)"]
+            byt = 32.0 * n_s + 60.0 * n_r
+            out["roofline"]["other"]["ngp_sample_rays + ngp_march_kernel[step rays]"] = {
+                "bound": "hbm", "in_step_us": us, "avg_launch_us": us, "algorithmic_bytes_per_launch": byt, "achieved": byt / us / 1e3,
+                "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": byt / us / 1e3 / HBM_PEAK_GBS, "launches_per_frame": steps_pf,
+                "ms_per_frame": us * steps_pf / 1e3,
+                "note": "latency-bound, not bandwidth-bound: %d rays x up to 1024 dependent DDA steps through the occupancy bits, 32 B "
+                        "written per emitted sample; runs on the third stream from the start of the step, beside the forward pass "
+                        "(duration measured in the step: there is no stand-alone launch of it)" % n_r}
+        # rocprofv3 evidence of the SAME kernels (tools/r04_final.sh): HBM bytes per launch from separate --pmc passes over
         # `bench.py --microbench NAME` (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md), their rocprof average duration, and the
-        # average duration of the same kernels INSIDE the timed pipeline (profiles/r03_bench_kernel_stats.csv)
-        tf = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        # average duration of the same kernels INSIDE the timed pipeline (profiles/r04_bench_kernel_stats.csv).  The file carries
+        # the commit and the sha256 of the library it was measured on: `traffic_stale` says whether that is the library running now.
+        tf = os.path.join(ROOT, "profiles", "r04_traffic.json")
         if os.path.exists(tf):
             tr = json.load(open(tf))
+            meta = tr.get("_meta", {})
+            out["roofline"]["traffic_source"] = {"file": "profiles/r04_traffic.json", "git_head": meta.get("git_head"),
+                                                 "lib_sha256": meta.get("lib_sha256"),
+                                                 "traffic_stale": meta.get("lib_sha256") != _lib_sha256()}
             for k in roofs:
                 if k in tr:
                     e = out["roofline"] if k == dom else out["roofline"]["other"][k]
-                    e["traffic"] = tr[k].get("traffic_bytes")
+                    scale = 1.0
+                    if tr[k].get("samples") and e.get("samples"):       # PMC passes ran on another trainer's step: per sample
+                        scale = e["samples"] / tr[k]["samples"]
+                        e["traffic_measured_on_samples"] = tr[k]["samples"]
+                    e["traffic"] = int(tr[k]["traffic_bytes"] * scale) if tr[k].get("traffic_bytes") else None
                     if e["traffic"] and e.get("bound") == "hbm":
                         # what the north star's ">= 60 % HBM-bandwidth utilisation (rocprof)" clause reads: bytes the memory
                         # system actually moved per launch / launch time / peak -- next to `frac`, which prices only the
                         # ALGORITHMIC bytes (traffic / algorithmic = the re-read factor)
                         e["hbm_utilisation"] = e["traffic"] / (e["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-                    for kk in ("rocprof_avg_launch_us", "in_pipeline_avg_us", "l2_hit_rate", "traffic_by_kernel"):
+                    for kk in ("rocprof_avg_launch_us", "in_pipeline_avg_us", "l2_hit_rate", "traffic_by_kernel", "mfma_busy"):
                         if kk in tr[k]:
                             e[kk] = tr[k][kk]
         if not args.no_cpu_baseline:

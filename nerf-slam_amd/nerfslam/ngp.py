@@ -357,6 +357,15 @@ class NgpNerf:
         st = stream_ptr()
         ctl = ptr(X["ctl"])
         main = torch.cuda.current_stream()
+        probe = getattr(self, "_probe", None)
+
+        def mark(name):
+            """probe_steps(): a timing event on the CURRENT stream; kernel `name` is what ran since the previous mark of that
+            stream.  (Never under capture: the probed step runs eagerly.)"""
+            if probe is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                probe.append((torch.cuda.current_stream().cuda_stream, name, ev))
         # (under capture the ORDER of these calls decides which hardware queue a branch gets: with the forward pass enqueued
         #  before this branch, the executor put the branch behind side2's kernels on one queue and the step took 0.58 ms; the
         #  same swap in the second step of a paired graph only: 0.43 -> 0.50 ms)
@@ -369,7 +378,9 @@ class NgpNerf:
             check(L.ns_ngp_step_prepare(ptr(X["ctl"]), ptr(Y["ctl"]), ptr(X["counter"]), ptr(Y["counter"]), ptr(self.last),
                                         C.c_float(0.9), C.c_long(S), 256, Rc, C.c_float(c.beta1), C.c_float(c.beta2), None,
                                         stream_ptr()), "ngp_step_prepare")
+            mark(None)
             self._enqueue_rays(Y)
+            mark("ngp_sample_rays + ngp_march (next step's rays)")
         # sample count of THIS step = end of the marcher's reserved ranges (device memory): the per-sample kernels are launched
         # over the whole budget S (fixed grids, fixed row strides) and skip the tail the marcher did not fill
         n_dev = C.c_void_p(X["counter"].data_ptr() + 8)
@@ -380,8 +391,10 @@ class NgpNerf:
             if getattr(self, "s_jac", None) is None:
                 self.s_jac = torch.zeros((6 * c.n_levels, S), dtype=torch.float16, device=dev)
             jac = self.s_jac
+        mark(None)
         check(L.ns_ngp_encode_forward_j_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.grid_half), ptr(featT), 1, ptr(jac),
                                           C.c_long(S), n_dev, st), "ngp_encode_forward")
+        mark("ngp_encode_fwd_kernel")
         acts, dacts = self.act, self.dact
         h1T, cinT, h3T, h4T = acts
         d5T, d4T, d3T, ddT, d1T = dacts
@@ -401,6 +414,7 @@ class NgpNerf:
         elif mlp_mode == "split":
             check(L.ns_ngp_mlp_forward_f_n(ptr(self.mlp_frags), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), ptr(self.relu_masks),
                                            C.c_long(S), n_dev, st), "ngp_mlp_forward")
+            mark("ngp_mlp_fwd_kernel")
         else:
             check(L.ns_ngp_mlp_forward_m_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out),
                                            *[ptr(a) for a in acts], ptr(self.relu_masks), C.c_long(S), n_dev, st), "ngp_mlp_forward")
@@ -408,6 +422,7 @@ class NgpNerf:
                                       ptr(X["r_rgb"]), ptr(X["r_depth"]), ptr(X["r_cov"]), C.c_float(c.depth_lambda),
                                       C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), None, ptr(X["loss"]),
                                       ptr(X["s_dout"]), ctl, st), "ngp_composite")
+        mark("ngp_composite_kernel")
         single = not self.replicated
         pose = c.optimize_extrinsics
         gather_pose = pose and jac is None          # A/B form: second gather of the table (reads what Adam rewrites)
@@ -471,14 +486,18 @@ class NgpNerf:
         if mlp_mode == "split":
             fork1 = torch.cuda.Event()
             fork1.record(main)
+            mark(None)
             check(L.ns_ngp_mlp_dgrad_f_n(ptr(self.mlp_frags), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
                                          C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
+            mark("ngp_mlp_bwd_kernel")
             with torch.cuda.stream(self._side):
                 st1 = stream_ptr()
                 self._side.wait_event(fork1)
+                mark(None)
                 check(L.ns_ngp_mlp_wgrad_recompute_n(ptr(self.mlp_frags), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]),
                                                      ptr(self.partial_fused), self.mlp_wgs, ptr(self.mlp_grad), C.c_long(S), n_dev, st1),
                       "ngp_mlp_wgrad_recompute")
+                mark("ngp_mlp_wgrad_tr_kernel + ngp_mlp_wgrad_reduce_kernel")
                 if single:
                     mlp_adam(st1)
         elif mlp_mode == "fused":
@@ -496,10 +515,13 @@ class NgpNerf:
         #  side branches, the scatter landed on the side stream's queue BEHIND the pose refinement, 0.49 ms)
         def hashed_levels():
             if self.fused_ws:
+                mark(None)
                 table_gradient(1, st)
+                mark("ngp_enc_fscatter_direct_kernel")
                 if table_read is not None and self.fused_adam:
                     main.wait_event(table_read)
                 table_gradient(2, st)
+                mark("ngp_enc_faccum_kernel")
             else:
                 check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
                                                  ptr(self.enc_ws), C.c_size_t(self.enc_ws_bytes), C.c_float(c.grad_fixed_scale),
@@ -640,7 +662,7 @@ class NgpNerf:
                 self._primed = True
             if self.replicated and c.use_graph and not os.environ.get("NS_NGP_REPL_EAGER"):
                 self._replicated_step(x)
-            elif self.replicated or not c.use_graph:
+            elif self.replicated or not c.use_graph or getattr(self, "_probe", None) is not None:
                 self._enqueue_step(x)
             else:
                 key = self._step_key()
@@ -673,6 +695,27 @@ class NgpNerf:
                 # 10 on the tree before the rays moved ahead).  Cost: one eager sample + march per update, < 1 % of a step.
                 self._primed = False
         return self.loss_tensor if return_loss else None
+
+    def probe_steps(self, n=8):
+        """-> {kernel: mean microseconds over `n` optimiser steps run EAGERLY with timing events between the kernels of every
+        stream}: each kernel's duration IN the step -- on the step's own samples, with the other streams' kernels running next to
+        it as they do in the replayed graph (the events themselves cost a stream a few us per mark: durations, not the step time,
+        are what this is for).  bench.py prints them beside the stand-alone launch times of the same kernels."""
+        acc, cnt = {}, {}
+        for _ in range(n):
+            self._probe = []
+            try:
+                self.train_step(return_loss=False)
+                torch.cuda.synchronize(self.device)
+                last = {}
+                for stream, name, ev in self._probe:
+                    if name is not None and stream in last:
+                        acc[name] = acc.get(name, 0.0) + 1e3 * last[stream].elapsed_time(ev)
+                        cnt[name] = cnt.get(name, 0) + 1
+                    last[stream] = ev
+            finally:
+                self._probe = None
+        return {k: acc[k] / cnt[k] for k in acc}
 
     def _replicated_step(self, x):
         """One step of a replicated trainer from TWO HIP graphs with the collectives between them:

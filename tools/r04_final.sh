@@ -1,0 +1,43 @@
+#!/bin/bash
+# Round-4 evidence on ONE tree (one gpurun call): bench line, kernel table of the same command, PMC passes over bench.py's OWN
+# micro-benches (the launches `avg_launch_us` times, on a trained step's sample set), config #5, the one-device records of the
+# N > 1 topologies, the one-rank RCCL record.  Everything lands in gpurun_out/r04final/; copy what is to be judged to profiles/.
+# usage (from the container): NS_GIT_HEAD=$(git rev-parse HEAD) gpurun ... -- "NS_GIT_HEAD=$NS_GIT_HEAD bash tools/r04_final.sh"
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+o=gpurun_out/r04final; mkdir -p $o
+REPS=20
+timeout 600 python bench.py --steps 20 --warmup 5 > $o/bench.json 2> $o/bench.err; tail -c 300 $o/bench.err
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $o/bprof -o b -- python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $o/bench_under_rocprof.json 2> /dev/null
+cp $o/bprof/b_kernel_stats.csv $o/bench_kernel_stats.csv 2>/dev/null
+timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $o/ngp -o ngp -- env NS_NGP_EXTRINSICS=1 python tools/ngp_bench.py 160 320 > $o/ngp.log 2>&1; grep steps/s $o/ngp.log
+cp $o/ngp/ngp_kernel_stats.csv $o/ngp_kernel_stats.csv 2>/dev/null
+for name in ngp_bwd ngp_fwd mlp_fwd mlp_bwd mlp_wgrad lookup volume conv; do
+  case $name in ngp_bwd) mb="ngp_encode_bwd";; ngp_fwd) mb="ngp_encode_fwd";; mlp_fwd) mb="ngp_mlp_fwd";; mlp_bwd) mb="ngp_mlp_bwd";; mlp_wgrad) mb="ngp_mlp_wgrad";; lookup) mb="corr_lookup";; volume) mb="corr_volume";; conv) mb="conv_nhwc";; esac
+  d=$o/pmc/$name; mkdir -p $d
+  timeout 200 rocprofv3 --kernel-trace -f csv -d $d/trace -o t -- python bench.py --microbench $mb --reps $REPS > $d/trace.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $d/fetch -o f -- python bench.py --microbench $mb --reps $REPS > $d/fetch.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -f csv -d $d/write -o w -- python bench.py --microbench $mb --reps $REPS > $d/write.log 2>&1
+  case $name in mlp_*|conv) timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -f csv -d $d/mfma -o m -- python bench.py --microbench $mb --reps $REPS > $d/mfma.log 2>&1;; esac
+  grep '^{' $d/trace.log | tail -1
+done
+python tools/r04_traffic.py $o/pmc $o/bench_kernel_stats.csv $REPS $o/traffic.json
+# config #5
+timeout 400 python bench.py --config c1280 --steps 2 --warmup 1 > $o/bench_c1280.json 2> $o/bench_c1280.err
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $o/c1280 -o c -- python bench.py --config c1280 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cp $o/c1280/c_kernel_stats.csv $o/c1280_kernel_stats.csv 2>/dev/null
+# N > 1 topologies on the ONE device over gloo (functional records)
+for n in 2 3; do
+  NS_BENCH_DIST_BACKEND=gloo NS_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29600+n)) bench.py --gpus $n --steps 12 --warmup 2 2>/dev/null | grep '^{' | tail -1 > $o/bench_gpus${n}_one_device_gloo.json
+done
+NS_BENCH_DIST_BACKEND=gloo NS_BENCH_ONE_DEVICE=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29610 bench.py --gpus 2 --steps 2 --warmup 1 --config c1280 2>/dev/null | grep '^{' | tail -1 > $o/bench_c1280_gpus2_one_device_gloo.json
+# the RCCL path with one rank
+timeout 300 python tests/rccl_worker.py 29655 2>/dev/null | grep '^{' | tail -1 > $o/rccl_one_rank.json
+rm -rf $o/bprof $o/ngp $o/c1280; find $o/pmc -name "*agent_info.csv" -delete
+ls -la $o; du -sh $o
+python - <<PY
+import json
+d = json.load(open("$o/bench.json")); r = d["roofline"]
+print(d["value"], d["windows_frames_per_s"], r["kernel"], round(r["frac"], 3), r.get("frac_in_step"), r["traffic"], r.get("traffic_source"), d["cpu_baseline"]["value"] if d["cpu_baseline"] else None)
+for k, v in r["other"].items():
+    print(" ", k, round(v["avg_launch_us"], 1), v.get("in_step_us") and round(v["in_step_us"], 1), round(v["frac"], 4), v.get("traffic"))
+PY
