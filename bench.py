@@ -603,6 +603,7 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="report the sequential (no --parallel_run) mode as `value`")
     ap.add_argument("--microbench", default="", help="run ONE roofline micro-bench back to back (for rocprofv3 --pmc passes)")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--quality-only", action="store_true", help="extras: the quality block only (no rooflines, no chain figure)")
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps frames each; `value` is their median")
     ap.add_argument("--config", default="c640", choices=["c640", "c1280"],
                     help="c640: BASELINE configs[2]/[3] (default, the headline metric); c1280: configs[4], global BA over a 256-keyframe buffer at 1280x720")
@@ -735,6 +736,7 @@ def main():
     extra = {}
     if not args.no_extras:
         extra["quality"] = quality(pipe)
+    if not args.no_extras and not args.quality_only:
         hp, extra["hot_path_chain"] = hot_path_chain(dev, 10, 2)
         roofs = kernel_rooflines(dev, hp, ngp._net)
         # share of the timed region per candidate kernel (launch time x launches per timed frame)

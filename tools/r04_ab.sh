@@ -1,8 +1,14 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python tools/r04_bwd_ab.py 0.6 2>&1 | tail -1
-python tools/r04_bwd_ab.py 1.0 2>&1 | tail -1
-NS_NGP_EXTRINSICS=1 python tools/ngp_bench.py 800 320 2>&1 | tail -2 | head -1
-python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), [round(w['frames_per_s'],1) for w in d['windows']], d['breakdown']['ms_per_frame_by_leg'])"
-timeout 300 python -m pytest tests/test_ngp_gpu.py -x -q -m gpu 2>&1 | tail -2
+for v in "" 1; do
+  echo "== trainer NS_NGP_WGRAD_ON_MAIN=$v"; NS_NGP_WGRAD_ON_MAIN=$v NS_NGP_EXTRINSICS=1 python tools/ngp_bench.py 800 320 2>&1 | tail -2
+done
+q='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d["value"],1), [round(w["frames_per_s"],1) for w in d["windows"]], d["breakdown"]["ms_per_frame_by_leg"], d["extra"]["quality"])'
+for v in "" 1; do
+  echo "== bench NS_NGP_WGRAD_ON_MAIN=$v"; NS_NGP_WGRAD_ON_MAIN=$v python bench.py --steps 20 --warmup 5 --no-cpu-baseline --quality-only 2>/dev/null | python -c "$q"
+done
+for v in 0 1; do
+  echo "== bench NS_NGP_GRID_DECAY_ALL=$v"; NS_NGP_GRID_DECAY_ALL=$v python bench.py --steps 20 --warmup 5 --no-cpu-baseline --quality-only 2>/dev/null | python -c "$q"
+  echo "== sphere NS_NGP_GRID_DECAY_ALL=$v"; NS_NGP_GRID_DECAY_ALL=$v NS_NGP_EXTRINSICS=1 python tools/ngp_bench.py 800 320 2>&1 | tail -1
+  NS_NGP_GRID_DECAY_ALL=$v NS_NGP_EXTRINSICS=1 python tools/ngp_bench.py 800 320 2>&1 | tail -1
+done
