@@ -120,6 +120,14 @@ class FactorGraph:
             # depends on that routine's tie order (found by replaying the reference's own methods: tools/
             # gen_golden_graph.py).  The same torch call is made here, on the same kind of device as the reference's
             # (the frontend sets `sort_device` to its GPU; the golden sequences were produced by CPU torch).
+            # THE TIE RULE, stated once: the mask is positional through the permutation VALUES, so two tied ages that swap
+            # places in the permutation change WHICH edges leave.  torch.argsort's tie order is a property of the sorting
+            # routine (CPU torch, CUDA's and ROCm's radix / merge sorts need not agree), hence "identical factor-graph
+            # indices" is exact (a) whenever no two ages tie -- the permutation is then unique, whatever sorts it:
+            # tests/test_factor_graph.py::test_eviction_is_sort_independent_when_ages_are_unique -- and (b) for tied ages
+            # only against a reference run whose sort is the same routine.  The golden replay and the closed-loop test sort on
+            # the CPU (`sort_device = "cpu"`), which is what the fixtures were generated with; the live product sorts on its
+            # GPU like the reference does, and is then pinned to ROCm's tie order, not to CUDA's.
             pos = torch.argsort(torch.from_numpy(self.age).to(self.sort_device)).cpu().numpy()
             removed = pos >= (self.max_factors - ii.shape[0])
             self.remove(removed, store=True)

