@@ -392,6 +392,24 @@ def _sphere_trainer(dev, steps=208):
 def run_microbench(dev, name, reps):
     """`bench.py --microbench NAME [--reps n]`: n back-to-back launches of ONE roofline micro-bench and nothing else timed -- the
     command tools/r04_final.sh wraps in rocprofv3 --kernel-trace --stats / --pmc passes"""
+    if name.startswith("altcorr"):           # config #5's on-the-fly correlation: 48 edges x 4 levels at 160x90, half features
+        from nerfslam.corr import AltCorrBlock
+        g = torch.Generator(device=dev).manual_seed(0)
+        NB, ht, wd, E = 64, 90, 160, 48
+        fm = torch.randn((1, NB, 128, ht, wd), device=dev, generator=g).half()
+        alt = AltCorrBlock(fm)
+        ii = torch.arange(0, E, device=dev) % NB
+        jj = (ii + 1) % NB
+        gy, gx = torch.meshgrid(torch.arange(ht, device=dev), torch.arange(wd, device=dev), indexing="ij")
+        coords = (torch.stack([gx, gy], -1).float()[None] + 3.0 * torch.randn((E, ht, wd, 2), device=dev, generator=g))[None].contiguous()
+        fn = lambda: alt(coords, ii, jj)
+        fn(); torch.cuda.synchronize()
+        us = _train_us(fn, reps)
+        HWp = ht * wd
+        alg = E * (HWp * 128 * 2 * (1 + 1 + 0.25 + 0.0625 + 0.015625) + 196 * HWp * 4 + HWp * 8)
+        print(json.dumps({"microbench": "altcorr_tile_mfma_kernel[E=48, 160x90]", "reps": reps, "avg_launch_us": us,
+                          "algorithmic_per_launch": alg, "bound": "hbm"}))
+        return
     from hot_path_chain import HotPath
     hp = HotPath(dev, seed=0)
     net = _sphere_trainer(dev)
@@ -546,6 +564,9 @@ def bench_c1280(args, dev, rank=0, world=1, backend="nccl"):
                      "note": "one further pass, synchronised around every leg; the remainder is the edge selection (frame distances, "
                              "proximity graph on the host) and launch gaps"}
         slam.leg_ms = None
+    cpu_base = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline_c1280(fe, NB, n_edges)
     # altcorr kernel alone: one 4-level lookup over a window of edges (HIP events around back-to-back launches)
     from nerfslam.corr import AltCorrBlock
     fm = (fe.feat_bank * 4.0).transpose(1, 2).reshape(1, NB, 128, fe.ht, fe.wd)      # half, as TrackingSLAM.backend passes them
@@ -580,13 +601,80 @@ def bench_c1280(args, dev, rank=0, world=1, backend="nccl"):
                      "note": "per edge: both feature maps (f16, channels-last, pyramid of the target) read once + 196 f32 output planes "
                              "(which are 96 % of the bytes); round 2's f32 FMA tile kernel ran this launch in 2.0 ms (0.085 of the "
                              "HBM peak on twice the input bytes), the matrix-core kernel computes the dense tile x region product"},
-        "cpu_baseline": None,
+        "cpu_baseline": cpu_base,
         "breakdown": breakdown,
     }
+    if world == 1:
+        tf = os.path.join(ROOT, "profiles", "r04_traffic.json")
+        if os.path.exists(tf):
+            tr = json.load(open(tf))
+            e = tr.get("altcorr_tile_mfma_kernel[E=48, 160x90]")
+            if e:
+                r = out["roofline"]
+                r["traffic"] = e.get("traffic_bytes")
+                if r["traffic"]:
+                    r["hbm_utilisation"] = r["traffic"] / (r["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                for kk in ("rocprof_avg_launch_us", "l2_hit_rate", "traffic_by_kernel"):
+                    if kk in e:
+                        r[kk] = e[kk]
+                meta = tr.get("_meta", {})
+                r["traffic_source"] = {"file": "profiles/r04_traffic.json", "git_head": meta.get("git_head"),
+                                       "traffic_stale": meta.get("lib_sha256") != _lib_sha256()}
     print(json.dumps(out))
     if world > 1:
         dist.barrier(group=group)
         dist.destroy_process_group()
+
+
+def cpu_baseline_c1280(fe, NB, n_edges):
+    """The oracle (C restatement of the reference kernels) on config #5's shapes, on a bounded sample: the on-the-fly correlation
+    (K14, reference src/altcorr_kernel.cu: oracle `orc_altcorr_forward_f32`, a scalar loop -- one edge per host thread here) of 64
+    edges x 4 levels at 160x90, and one dense-BA linearisation + Schur reduction + depth update (K1/K6/K9/K10/K11) at M = 96
+    edges of a 49-pose window; extrapolated LINEARLY in the edge count to one global-BA pass (every edge correlated once, 2 BA
+    iterations over all edges).  The update operator (conv nets) is not part of the CPU figure: an upper bound of a CPU pass."""
+    import concurrent.futures as cf
+    import oracle
+    ht, wd = fe.ht, fe.wd
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    thr = max(1, min(cores, 64))
+    E_s = thr
+    bank = fe.feat_bank[:min(NB, E_s + 1)].float().cpu().numpy().reshape(-1, ht, wd, 128) * 4.0      # [k, ht, wd, 128] f32
+    ii = np.arange(E_s) % (bank.shape[0] - 1)
+    jj = ii + 1
+    coords = fe.reproject(torch.from_numpy(ii).to(fe.device), torch.from_numpy(jj).to(fe.device)).cpu().numpy()    # [E, ht, wd, 2]
+
+    def pool(f):                           # 2x2 average pooling of the target map (corr.py:63-72 builds the pyramid of fmap2)
+        h, w = f.shape[0] // 2 * 2, f.shape[1] // 2 * 2
+        return f[:h, :w].reshape(h // 2, 2, w // 2, 2, -1).mean(axis=(1, 3))
+
+    def one_edge(e):
+        f1, f2 = bank[ii[e]][None], bank[jj[e]]
+        for l in range(4):
+            oracle.altcorr_forward(f1, np.ascontiguousarray(f2[None]), np.ascontiguousarray(coords[e][None, None] / np.float32(2 ** l)), 3)
+            f2 = pool(f2)
+    oracle.lib()
+    t0 = time.time()
+    with cf.ThreadPoolExecutor(thr) as ex:
+        list(ex.map(one_edge, range(E_s)))
+    t_alt = time.time() - t0                                   # E_s edges on thr threads
+    # dense BA on a 49-pose window with its 96 neighbour edges
+    P, M = 49, 96
+    bi = np.concatenate([np.arange(48), np.arange(1, 49)]).astype(np.int64)
+    bj = np.concatenate([np.arange(1, 49), np.arange(48)]).astype(np.int64)
+    tg = fe.reproject(torch.from_numpy(bi).to(fe.device), torch.from_numpy(bj).to(fe.device)).permute(0, 3, 1, 2).contiguous().cpu().numpy()
+    a = [fe.cam0_T_world[:P].cpu().numpy(), fe.cam0_idepths[:P].cpu().numpy(), fe.intr8.cpu().numpy(), fe.cam0_T_body.cpu().numpy(),
+         fe.cam0_idepths_sensed[:P].cpu().numpy(), tg, np.ones_like(tg), np.full((P, ht * wd), 1e-4, np.float32)]
+    t0 = time.time()
+    Hh, vv, Q, Ee, w, kx = oracle.reduced_camera_matrix(*a, bi, bj, 0, P)
+    oracle.solve_depth(np.zeros((P, 6), np.float32), a[1], Q, Ee, w, bi, bj, 0, P)
+    t_ba = time.time() - t0
+    per_pass = n_edges * (t_alt / E_s) + 2.0 * (n_edges / M) * t_ba
+    return {"value": 1.0 / per_pass, "unit": "global-BA passes/s (correlation + BA only: no conv nets)", "cores": cores, "kind": "port",
+            "seconds_per_pass": per_pass,
+            "sample": "oracle: on-the-fly correlation of %d edges x 4 levels at %dx%d on %d host threads (one edge per thread, scalar C "
+                      "loop) %.2f s; one dense-BA iteration (linearisation, Schur, depth update) at M = %d, P = %d: %.2f s (OpenMP over "
+                      "the edges); extrapolated linearly in the edge count to a pass of %d edges correlated once + 2 BA iterations"
+                      % (E_s, wd, ht, thr, t_alt, M, P, t_ba, n_edges)}
 
 
 # =================================================================================================

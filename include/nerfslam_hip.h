@@ -77,6 +77,16 @@ int ns_corr_lookup_pyramid(const void* const* pyr_host, int num_levels, const fl
  * volume.  slot == NULL: identical to the plain entry points. */
 int ns_corr_lookup_pyramid_slots(const void* const* pyr_host, int num_levels, const float* coords, int coords_interleaved,
                                  void* out, int E, int h1, int w1, int tiled, const int* slot, int capacity, void* stream);
+
+/* Lookup fused with the update operator's correlation encoder (round 4): CorrBlock.__call__ (networks/modules/corr.py:40-50,
+ * four levels, radius 3) followed by UpdateModule.corr_encoder[0:2] = Conv2d(196,128,1) + ReLU (networks/droid_net.py:83-87,
+ * 133) in one launch; the [E,196,h1,w1] tensor is never written.  wfrag: the 196 x 128 weight as MFMA fragments, f16
+ * [4 (32-channel tile)][13 (16-channel chunk of the 196 -> 208 inputs)][64 lanes][8]: element q of lane l of fragment (nt, c) =
+ * W[32 nt + (l & 31)][16 c + 8 (l >> 5) + q], zero beyond input 195 (nerfslam/update_op.py packs it); bias [128] f32;
+ * out [E,h1,w1,128] f16 channels-last = relu(W x + b).  Volumes, coords, slot, capacity as ns_corr_lookup_pyramid_slots. */
+int ns_corr_lookup_encode_slots(const void* const* pyr_host, const float* coords, int coords_interleaved, const void* wfrag,
+                                const float* bias, void* out, int E, int h1, int w1, int tiled, const int* slot, int capacity,
+                                void* stream);
 int ns_corr_volume_pyramid_slots(const void* fmap1, const void* fmap2, const int64_t* ii, const int64_t* jj,
                                  void* const* pyr_host, int num_levels, int E, int C, int ht, int wd, int tiled,
                                  const int* slot, void* stream);

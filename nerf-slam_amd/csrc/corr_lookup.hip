@@ -230,34 +230,15 @@ __global__ __launch_bounds__(256) void corr_lookup_pyramid_kernel(LookupLevels L
 // ---------------------------------------------------------------------------------------------
 #define COOP_PITCH 72  // halves per LDS plane row (64 pixels + pad; 144 B keeps 16-byte reads aligned)
 
-__global__ __launch_bounds__(512) void corr_lookup_coop_kernel(LookupLevels L, const float* __restrict__ coords,
-                                                               int interleaved, _Float16* __restrict__ out, int E,
-                                                               int HW1, const int* __restrict__ slot) {
-  __shared__ __attribute__((aligned(16))) uint16_t ob[49 * COOP_PITCH];
-  const int t = threadIdx.x, r = t & 7, pl = t >> 3;
-  const int lvl = blockIdx.y;
-  const long idx0 = (long)blockIdx.x * 64;
-  const long total_px = (long)E * HW1;
-  const long idx = idx0 + pl;
-  const bool live = idx < total_px;
-  const long idc = live ? idx : total_px - 1;
-  const int n = (int)(idc / HW1);
-  const int p = (int)(idc - (long)n * HW1);
-  float cx, cy;
-  if (interleaved) {
-    const float2 c = *reinterpret_cast<const float2*>(coords + 2 * idc);
-    cx = c.x;
-    cy = c.y;
-  } else {
-    cx = coords[((long)n * 2 + 0) * HW1 + p];
-    cy = coords[((long)n * 2 + 1) * HW1 + p];
-  }
+// one level of one (edge, pixel) by its 8-lane group: lane r owns one window row; the 49 outputs of the pixel land in
+// ob[(a * 7 + b) * COOP_PITCH + pl] (49 planes of 64 pixels).  Shared by the plain kernel and the encoder-fused one below.
+__device__ __forceinline__ void coop_level(const LookupLevels& L, int lvl, float cx, float cy, bool live, long vidx, int t,
+                                           uint16_t* __restrict__ ob) {
+  const int r = t & 7, pl = t >> 3;
   const float sc = L.scale[lvl];
   const float x0 = cx * sc, y0 = cy * sc;
   const int h2 = L.h2[lvl], w2 = L.w2[lvl], ntx = L.ntx[lvl];
   const _Float16* __restrict__ vol = L.vol[lvl];
-  // slot-addressed pools: edge n reads volume index slot[n] (the edge list is reordered / shrunk without moving volumes)
-  const long vidx = slot ? (long)slot[n] * HW1 + p : idc;
   const long slice_off = vidx * L.slice_elems[lvl], total = L.total_elems[lvl];
   const float fx0 = floorf(x0), fy0 = floorf(y0);
   const bool sane = live && (fabsf(x0) < 1.0e6f) && (fabsf(y0) < 1.0e6f);
@@ -348,6 +329,33 @@ __global__ __launch_bounds__(512) void corr_lookup_coop_kernel(LookupLevels L, c
       if (a0 + 1 < 7) ob[((a0 + 1) * 7 + j) * COOP_PITCH + pl] = (uint16_t)(u >> 16);
     }
   }
+}
+
+__global__ __launch_bounds__(512) void corr_lookup_coop_kernel(LookupLevels L, const float* __restrict__ coords,
+                                                               int interleaved, _Float16* __restrict__ out, int E,
+                                                               int HW1, const int* __restrict__ slot) {
+  __shared__ __attribute__((aligned(16))) uint16_t ob[49 * COOP_PITCH];
+  const int t = threadIdx.x, pl = t >> 3;
+  const int lvl = blockIdx.y;
+  const long idx0 = (long)blockIdx.x * 64;
+  const long total_px = (long)E * HW1;
+  const long idx = idx0 + pl;
+  const bool live = idx < total_px;
+  const long idc = live ? idx : total_px - 1;
+  const int n = (int)(idc / HW1);
+  const int p = (int)(idc - (long)n * HW1);
+  float cx, cy;
+  if (interleaved) {
+    const float2 c = *reinterpret_cast<const float2*>(coords + 2 * idc);
+    cx = c.x;
+    cy = c.y;
+  } else {
+    cx = coords[((long)n * 2 + 0) * HW1 + p];
+    cy = coords[((long)n * 2 + 1) * HW1 + p];
+  }
+  // slot-addressed pools: edge n reads volume index slot[n] (the edge list is reordered / shrunk without moving volumes)
+  const long vidx = slot ? (long)slot[n] * HW1 + p : idc;
+  coop_level(L, lvl, cx, cy, live, vidx, t, ob);
   __syncthreads();
   // 49 channel planes x 64 pixels -> whole lines where the 8 pixels of a piece are consecutive in one plane
   uint16_t* o16 = reinterpret_cast<uint16_t*>(out);
@@ -371,6 +379,77 @@ __global__ __launch_bounds__(512) void corr_lookup_coop_kernel(LookupLevels L, c
         const int pe = (int)(ie - (long)ne * HW1);
         o16[((long)ne * (L.num_levels * 49) + lvl * 49 + ch) * HW1 + pe] = src[e];
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lookup + correlation encoder in ONE launch (round 4; SURVEY 8(f) row 2: "fuse corr-encoder 1x1 conv onto the K12 output").
+// Reference chain: CorrBlock.__call__ (networks/modules/corr.py:40-50) -> UpdateModule.corr_encoder[0:2] = Conv2d(196, 128, 1)
+// + ReLU (networks/droid_net.py:83-87, applied at :133).  Unfused, the lookup writes [E,196,ht,wd] f16 (90 MB at E = 48, 42 % of
+// its algorithmic bytes), a transposition kernel re-reads and re-writes it channels-last, and the 1x1 convolution reads it a
+// third time.  Here a workgroup keeps the 196 values of its 64 pixels in LDS (all four levels, the same 8-lane rows as above,
+// bit-identical values), multiplies them by the 196 x 128 weight matrix on the matrix cores -- out[64 px][128] =
+// X[64][208] W^T[208][128], 13 k-chunks, one 32 x 32 output tile per wave, the wave's 13 weight fragments resident in
+// registers across the workgroup's pixel groups -- adds the bias, applies the ReLU and writes [E,ht,wd,128] f16 channels-last:
+// what the second encoder convolution reads.  f32 accumulation like the convolution kernel it replaces; equal to
+// corr1(lookup) up to the f16 rounding of the output (tests/test_corr_gpu.py::test_lookup_fused_with_the_correlation_encoder).
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 lk_f16x8 __attribute__((ext_vector_type(8)));
+typedef float lk_f32x16 __attribute__((ext_vector_type(16)));
+#define ENC_K 208        // 196 lookup channels padded to 13 chunks of 16
+#define ENC_GROUPS 4     // 64-pixel groups per workgroup (the weight fragments are loaded once per workgroup)
+
+__global__ __launch_bounds__(512) void corr_lookup_enc_kernel(LookupLevels L, const float* __restrict__ coords, int interleaved,
+                                                              const lk_f16x8* __restrict__ wfrag, const float* __restrict__ bias,
+                                                              _Float16* __restrict__ out, int E, int HW1,
+                                                              const int* __restrict__ slot) {
+  __shared__ __attribute__((aligned(16))) uint16_t ob[ENC_K * COOP_PITCH];   // 30 KB: [channel][64 pixels]
+  const int t = threadIdx.x, pl = t >> 3;
+  const int lane = t & 63, wave = t >> 6, j = lane & 31, h = lane >> 5;
+  const int mt = wave & 1, nt = wave >> 1;             // the wave's output tile: pixels 32 mt.., channels 32 nt..
+  const long total_px = (long)E * HW1;
+  for (int e = t; e < (ENC_K - 196) * COOP_PITCH; e += 512) ob[196 * COOP_PITCH + e] = 0;   // the pad channels stay zero
+  lk_f16x8 Bf[13];
+#pragma unroll
+  for (int c = 0; c < 13; c++) Bf[c] = wfrag[(nt * 13 + c) * 64 + lane];
+  const float bj = bias[32 * nt + j];
+  for (int g = 0; g < ENC_GROUPS; g++) {
+    const long idx0 = ((long)blockIdx.x * ENC_GROUPS + g) * 64;
+    if (idx0 >= total_px) break;                       // (uniform)
+    const long idx = idx0 + pl;
+    const bool live = idx < total_px;
+    const long idc = live ? idx : total_px - 1;
+    const int n = (int)(idc / HW1);
+    const int p = (int)(idc - (long)n * HW1);
+    float cx, cy;
+    if (interleaved) {
+      const float2 c = *reinterpret_cast<const float2*>(coords + 2 * idc);
+      cx = c.x;
+      cy = c.y;
+    } else {
+      cx = coords[((long)n * 2 + 0) * HW1 + p];
+      cy = coords[((long)n * 2 + 1) * HW1 + p];
+    }
+    const long vidx = slot ? (long)slot[n] * HW1 + p : idc;
+    __syncthreads();                                   // the previous group's tiles have been read
+#pragma unroll 1
+    for (int lvl = 0; lvl < 4; lvl++) coop_level(L, lvl, cx, cy, live, vidx, t, ob + lvl * 49 * COOP_PITCH);
+    __syncthreads();
+    lk_f32x16 acc = (lk_f32x16)0.0f;
+    const uint16_t* xa = ob + 8 * h * COOP_PITCH + 32 * mt + j;      // A: row = pixel 32 mt + j, k = channel 16 c + 8 h + q
+#pragma unroll
+    for (int c = 0; c < 13; c++) {
+      lk_f16x8 a;
+#pragma unroll
+      for (int q = 0; q < 8; q++) a[q] = __builtin_bit_cast(_Float16, xa[(16 * c + q) * COOP_PITCH]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bf[c], acc, 0, 0, 0);
+    }
+    // acc[r]: pixel 32 mt + 4 h + (r & 3) + 8 (r >> 2) of the group, channel 32 nt + j
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const long px = idx0 + 32 * mt + 4 * h + (r & 3) + 8 * (r >> 2);
+      if (px < total_px) out[px * 128 + 32 * nt + j] = (_Float16)fmaxf(acc[r] + bj, 0.0f);
     }
   }
 }
@@ -499,6 +578,34 @@ extern "C" int ns_corr_lookup_pyramid_slots(const void* const* pyr_host, int num
                        (_Float16*)out, E, (int)HW1, slot);
     NS_CHECK_LAUNCH("corr_lookup_coop_kernel");
   }
+  return NS_OK;
+}
+
+extern "C" int ns_corr_lookup_encode_slots(const void* const* pyr_host, const float* coords, int coords_interleaved,
+                                           const void* wfrag, const float* bias, void* out, int E, int h1, int w1, int tiled,
+                                           const int* slot, int capacity, void* stream) {
+  if (E == 0) return NS_OK;
+  NS_REQUIRE(slot == nullptr || capacity >= 1, "ns_corr_lookup_encode_slots: capacity of the volume pool must be given");
+  NS_REQUIRE(pyr_host && coords && out && wfrag && bias, "ns_corr_lookup_encode_slots: null pointer");
+  NS_REQUIRE(E >= 0 && h1 > 0 && w1 > 0, "ns_corr_lookup_encode_slots: bad shape E=%d h1=%d w1=%d", E, h1, w1);
+  NS_REQUIRE(((uintptr_t)wfrag % 16) == 0, "ns_corr_lookup_encode_slots: the weight fragments must be 16-byte aligned");
+  LookupLevels L;
+  L.num_levels = 4;
+  const long HW1 = (long)h1 * w1;
+  for (int l = 0; l < 4; l++) {
+    L.vol[l] = (const _Float16*)pyr_host[l];
+    NS_REQUIRE(L.vol[l] != nullptr, "ns_corr_lookup_encode_slots: pyr[%d] is null", l);
+    L.h2[l] = h1 >> l;
+    L.w2[l] = w1 >> l;
+    L.scale[l] = 1.0f / (float)(1 << l);
+    L.ntx[l] = (tiled && l < 2) ? (L.w2[l] + 7) / 8 : 0;
+    L.slice_elems[l] = L.ntx[l] ? (long)((L.h2[l] + 7) / 8) * L.ntx[l] * 64 : (long)L.h2[l] * L.w2[l];
+    L.total_elems[l] = (long)(slot ? capacity : E) * HW1 * L.slice_elems[l];
+    NS_REQUIRE(L.h2[l] > 0 && L.w2[l] > 0, "ns_corr_lookup_encode_slots: level %d is empty (four levels are required)", l);
+  }
+  hipLaunchKernelGGL(corr_lookup_enc_kernel, dim3(ns_cdiv((long)E * HW1, 64 * ENC_GROUPS)), dim3(512), 0, (hipStream_t)stream, L,
+                     coords, coords_interleaved, (const lk_f16x8*)wfrag, bias, (_Float16*)out, E, (int)HW1, slot);
+  NS_CHECK_LAUNCH("corr_lookup_enc_kernel");
   return NS_OK;
 }
 

@@ -161,6 +161,15 @@ class CorrBlock:
         return corr.view(batch, num, ht, wd, ht, wd)
 
 
+class EncodedCorr:
+    """what CorrPool.lookup_encoded returns in place of the [1,E,196,ht,wd] lookup: the correlation encoder's first activation,
+    relu(conv1x1(lookup)), channels-last f16 [E,ht,wd,128] in `.c1`.  An update operator that advertises `corr_encoder`
+    (nerfslam.droid_nets.DroidNetworks on the HIP update operator) is handed this instead of the lookup."""
+
+    def __init__(self, c1):
+        self.c1 = c1
+
+
 class CorrPool:
     """Slot-addressed store of per-edge correlation pyramids (8x8-tiled levels 0 / 1): what TrackingFrontend keeps instead of
     one growing / shrinking CorrBlock.
@@ -217,6 +226,22 @@ class CorrPool:
             check(lib().ns_corr_lookup_pyramid_slots(self._ptrs(), self.num_levels, ptr(coords), 1, ptr(out), batch * E, ht, wd, 1,
                                                      ptr(slots), self.capacity, stream_ptr()), "corr_lookup_pyramid_slots")
         return out
+
+    def lookup_encoded(self, coords, slots, enc, out=None):
+        """lookup + the update operator's correlation encoder (Conv2d(196,128,1) + ReLU, networks/droid_net.py:83-87) in one
+        launch (csrc/corr_lookup.hip: corr_lookup_enc_kernel): coords [1, E, ht, wd, 2] f32, slots [E] int32, enc = the
+        `CorrEncoderWeights` of nerfslam.update_op -> `EncodedCorr` around [E, ht, wd, 128] f16 channels-last.  The
+        [1, E, 196, ht, wd] tensor of lookup() is never written."""
+        if self.num_levels != 4:
+            raise NerfSlamHipError("CorrPool.lookup_encoded: the encoder reads the 196 channels of a four-level pyramid")
+        batch, E, ht, wd, _ = coords.shape
+        coords = coords.contiguous().float()
+        if out is None:
+            out = torch.empty((batch * E, ht, wd, 128), dtype=torch.float16, device=coords.device)
+        with torch.cuda.device(self.device):
+            check(lib().ns_corr_lookup_encode_slots(self._ptrs(), ptr(coords), 1, ptr(enc.frags), ptr(enc.bias), ptr(out), batch * E,
+                                                    ht, wd, 1, ptr(slots), self.capacity, stream_ptr()), "corr_lookup_encode_slots")
+        return EncodedCorr(out)
 
     def block(self, slots):
         """the volumes of `slots` as a CorrBlock in the reference's layout (copies; tests / debugging)"""

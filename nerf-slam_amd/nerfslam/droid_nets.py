@@ -205,6 +205,9 @@ class DroidNetworks:
         if self.hip_update:
             from .update_op import HipUpdateOperator
             self.update_op = HipUpdateOperator(self.net.update_net)
+            # advertised to the frontend: with it, TrackingFrontend.update() calls the lookup-fused kernel and hands update() an
+            # EncodedCorr instead of the [1,E,196,ht,wd] lookup (NS_LOOKUP_UNFUSED=1: round 3's three launches)
+            self.corr_encoder = self.update_op.corr_enc
             self.ctx_cl, self.inp_cl = {}, {}
 
     def _normalize(self, img_u8):
@@ -277,8 +280,11 @@ class DroidNetworks:
         if self.hip_update:
             net = torch.stack([self.hidden.get((i, j), self.ctx_cl[i]) for i, j in zip(ih, jh)])
             inp = torch.stack([self.inp_cl[i] for i in ih])
-            c = corr[0] if corr.dim() == 5 else corr
-            net, delta, weight, eta, upmask = self.update_op(net, inp, c.half(), motion.reshape(-1, 4, *motion.shape[-2:]).float(), ih)
+            if hasattr(corr, "c1"):          # EncodedCorr (the frontend fused the lookup with the correlation encoder)
+                c = corr
+            else:
+                c = (corr[0] if corr.dim() == 5 else corr).half()
+            net, delta, weight, eta, upmask = self.update_op(net, inp, c, motion.reshape(-1, 4, *motion.shape[-2:]).float(), ih)
             for e, (i, j) in enumerate(zip(ih, jh)):
                 self.hidden[(i, j)] = net[e]
             live = set(zip(ih, jh))

@@ -20,6 +20,8 @@ weights (`droid.pth`) are missing from the reference tree; they are injected as 
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 
@@ -218,7 +220,11 @@ class TrackingFrontend:
         c = self._edges()
         coords1 = self.reproject(self.ii, self.jj)                                    # [E,ht,wd,2]
         motion = self.motion_features(coords1, self.target)
-        corr = self.corr.lookup(coords1[None], self.slots_dev)                        # [1,E,196,ht,wd]
+        enc = getattr(getattr(self.update_op, "__self__", None), "corr_encoder", None)
+        if enc is not None and not os.environ.get("NS_LOOKUP_UNFUSED"):
+            corr = self.corr.lookup_encoded(coords1[None], self.slots_dev, enc)       # lookup + Conv2d(196,128,1) + ReLU, one launch
+        else:
+            corr = self.corr.lookup(coords1[None], self.slots_dev)                    # [1,E,196,ht,wd]
         if getattr(self.update_op, "host_indices", False):
             res = self.update_op(corr, motion[None], self.ii, self.jj, ii_host=c["ii_list"], jj_host=c["jj_list"])
         else:

@@ -19,11 +19,24 @@ import torch.nn.functional as F
 from .conv import PackedConv, flow_im2col, group_mean, planes_to_nhwc
 
 
+class CorrEncoderWeights:
+    """Conv2d(196,128,1) of the correlation encoder as the MFMA fragments of the lookup-fused kernel (include/nerfslam_hip.h:
+    ns_corr_lookup_encode_slots): frags f16 [4][13][64][8], element q of lane l of fragment (nt, c) =
+    W[32 nt + (l & 31)][16 c + 8 (l >> 5) + q], inputs 196..207 zero; bias f32 [128]."""
+
+    def __init__(self, weight, bias):
+        w = torch.zeros((128, 208), dtype=torch.float32, device=weight.device)
+        w[:, :196] = weight.detach().float().reshape(128, 196)
+        self.frags = w.reshape(4, 32, 13, 2, 8).permute(0, 2, 3, 1, 4).contiguous().half()      # nt, c, h, i, q  (lane = 32 h + i)
+        self.bias = bias.detach().float().contiguous()
+
+
 class HipUpdateOperator:
     def __init__(self, um):
         P = PackedConv
         ce, fe, g, a = um.corr_encoder, um.flow_encoder, um.gru, um.agg
         self.corr1 = P(ce[0].weight, ce[0].bias, pad_cin_to=208)      # 196 lookup channels, padded to 13 chunks of 16
+        self.corr_enc = CorrEncoderWeights(ce[0].weight, ce[0].bias)   # the same layer for the lookup-fused kernel
         self.corr2 = P(ce[2].weight, ce[2].bias)
         self.flow1 = P(fe[0].weight.reshape(128, 196, 1, 1), fe[0].bias, pad_cin_to=208)   # 7x7 as a 1x1 over im2col patches
         self.flow2 = P(fe[2].weight, fe[2].bias)
@@ -44,7 +57,8 @@ class HipUpdateOperator:
 
     @torch.no_grad()
     def __call__(self, net, inp, corr, flow, ii_host):
-        """net, inp [E,ht,wd,128] f16 channels-last; corr [E,196,ht,wd] f16 (the lookup's layout); flow [E,4,ht,wd] f32;
+        """net, inp [E,ht,wd,128] f16 channels-last; corr [E,196,ht,wd] f16 (the lookup's layout) or an `EncodedCorr` (lookup and
+        first encoder convolution already fused: nerfslam.corr.CorrPool.lookup_encoded); flow [E,4,ht,wd] f32;
         ii_host: source keyframe of every edge (host ints).
         -> net' [E,ht,wd,128] f16, delta [E,ht,wd,2] f32, weight [E,ht,wd,2] f32, eta [k,ht,wd] f32, upmask [k,ht,wd,576] f16
         (channels-last; k = number of distinct source keyframes, in sorted order)"""
@@ -78,7 +92,10 @@ class HipUpdateOperator:
         E, ht, wd, _ = net.shape
         dev = net.device
         # ---- encoders: X = [corr features 128 | flow features 64] ----
-        c1 = self.corr1([planes_to_nhwc(corr.contiguous(), 208)], act="relu")
+        if hasattr(corr, "c1"):      # nerfslam.corr.EncodedCorr: the lookup kernel already applied corr1 + ReLU
+            c1 = corr.c1
+        else:
+            c1 = self.corr1([planes_to_nhwc(corr.contiguous(), 208)], act="relu")
         X = torch.empty((E, ht, wd, 192), dtype=torch.float16, device=dev)
         self.corr2([c1], act="relu", out=X, out_offset=0)
         f1 = self.flow1([flow_im2col(flow.float().contiguous())], act="relu")

@@ -377,3 +377,43 @@ def test_lookup_small_and_odd_shapes_against_oracle(oracle_mod, dev, shape):
                           for l in range(nl)], 1)
     got = outs[0][0].cpu().numpy()
     assert ((got.view(np.uint16) == ref.view(np.uint16)) | ((got == 0) & (ref == 0))).all()
+
+
+@pytest.mark.parametrize("shape", [(60, 80), (13, 21)])
+def test_lookup_fused_with_the_correlation_encoder(dev, shape):
+    """CorrPool.lookup_encoded (csrc/corr_lookup.hip: corr_lookup_enc_kernel) = relu(Conv2d(196,128,1)(lookup)) of the reference
+    chain corr.py:40-50 -> droid_net.py:83-87,133: against (a) the product's own unfused launches (lookup, transposition, the
+    MFMA 1x1 convolution) and (b) a float64 evaluation of the same layer on the bit-exact lookup -- equal up to the f16 rounding
+    of the output (f32 accumulation in both kernels, different summation order).  Slots permuted, pixels that leave the image,
+    a pixel count that is not a multiple of the 256-pixel workgroup tile."""
+    from nerfslam.conv import PackedConv, planes_to_nhwc
+    from nerfslam.corr import CorrPool
+    from nerfslam.update_op import CorrEncoderWeights
+    ht, wd = shape
+    g = torch.Generator().manual_seed(7 * ht + wd)
+    nf, E = 6, 5
+    bank = (torch.randn((nf, ht * wd, 128), generator=g) / 4.0).half().to(dev)
+    ii = torch.tensor([0, 1, 2, 3, 4], device=dev)
+    jj = torch.tensor([1, 2, 3, 4, 5], device=dev)
+    pool = CorrPool(ht, wd, 9, dev)
+    slots = torch.tensor([7, 2, 5, 0, 3], dtype=torch.int32, device=dev)
+    pool.build(bank, bank, ii, jj, slots)
+    gy, gx = torch.meshgrid(torch.arange(ht), torch.arange(wd), indexing="ij")
+    coords = (torch.stack([gx, gy], -1).float()[None, None] + 4.0 * torch.randn((1, E, ht, wd, 2), generator=g)).to(dev)
+    coords[0, 0, 0, 0] = float("nan")
+    coords[0, 1, 1, 1] = torch.tensor([-30.0, -30.0])
+    W = (torch.randn((128, 196, 1, 1), generator=g) / 14.0).to(dev)
+    b = (0.1 * torch.randn(128, generator=g)).to(dev)
+    enc = CorrEncoderWeights(W, b)
+    fused = pool.lookup_encoded(coords, slots, enc).c1
+    look = pool.lookup(coords, slots)                                         # [1,E,196,ht,wd] f16, bit-exact (tests above)
+    unfused = PackedConv(W, b, pad_cin_to=208)([planes_to_nhwc(look[0].contiguous(), 208)], act="relu")
+    assert fused.shape == unfused.shape == (E, ht, wd, 128) and fused.dtype == torch.float16
+    x = look[0].double().permute(0, 2, 3, 1)                                  # [E,ht,wd,196]
+    ref = torch.relu(x @ W.half().double().reshape(128, 196).t() + b.double())
+    scale = float(ref.abs().max())
+    for name, got in (("fused", fused), ("unfused", unfused)):
+        err = float((got.double() - ref).abs().max())
+        assert err <= 1.5e-3 * scale + 1e-3, (name, err, scale)                # one f16 ulp at the top of the range
+    assert float((fused.double() - unfused.double()).abs().max()) <= 2e-3 * scale + 1e-3
+    assert torch.isfinite(fused).all()
