@@ -294,6 +294,9 @@ def micro_benches(dev, hp, ngp_net):
     touched = int((gq != 0).sum())
     live = int((net.s_dfeat.view(-1)[:32 * S].view(32, S)[:, :n] != 0).any(dim=0).sum())
     del gq
+    # records the scatter emitted for this sample set (run lengths next to the slots: [256 B counters][levels x 64 bins x tiles])
+    ntiles = (S + 1023) // 1024
+    records = int(bws.view(torch.int32)[64:64 + cf.n_levels * 64 * ntiles].sum())
     frags, partial = net.mlp_frags, net.partial_fused
 
     def mlp_fwd():
@@ -313,7 +316,7 @@ def micro_benches(dev, hp, ngp_net):
                                                       "features per sample (the 192 B / sample of Jacobian rows the pose refinement "
                                                       "makes it write are not counted)")
     out["ngp_encode_bwd[step samples]"] = dict(
-        fn=enc_bwd, bound="hbm", per_launch=1100 * n + 52 * touched, keep=(bw, bws), samples=n, touched_entries=touched,
+        fn=enc_bwd, bound="hbm", per_launch=1100 * n + 52 * touched, keep=(bw, bws), samples=n, touched_entries=touched, records=records,
         parts={"ngp_enc_fscatter_direct_kernel": lambda: enc_bwd(1), "ngp_enc_faccum_kernel": lambda: enc_bwd(2)},
         in_step=["ngp_enc_fscatter_direct_kernel", "ngp_enc_faccum_kernel"],
         note=where + "; one call = 2 launches (round 4: every level, dense ones included, through the bins): ngp_enc_fscatter_direct "
@@ -358,7 +361,7 @@ def kernel_rooflines(dev, hp, ngp_net):
         else:
             out[k] = {"bound": "mfma", "avg_launch_us": us, "flop_per_launch": m["per_launch"], "achieved": m["per_launch"] / us / 1e6,
                       "unit": "TFLOP/s", "peak": MFMA_F16_PEAK_TFLOPS, "frac": m["per_launch"] / us / 1e6 / MFMA_F16_PEAK_TFLOPS}
-        for kk in ("note", "samples", "executed_flop_per_launch"):
+        for kk in ("note", "samples", "executed_flop_per_launch", "records"):
             if m.get(kk) is not None:
                 out[k][kk] = m[kk]
         if "touched_entries" in m:

@@ -1246,40 +1246,63 @@ __device__ __forceinline__ void fb_wave_merge(FbRun (&run)[NS_FB_RUN], int& nrun
   if (lane < 63 && nrecv) nrun--;           // the next lane carries this lane's last run on
 }
 
-// The runs of one lane: its FOUR CONSECUTIVE samples of tile `tile` on level l, neighbours that share a cell summed (exact).
-__device__ __forceinline__ void fb_build_runs(const GridLayout& g, int l, int tile, int tid, const float* __restrict__ pos,
-                                              const _Float16* __restrict__ dpu, long N, long nvalid, float fixed_scale, int vec,
-                                              FbRun (&run)[NS_FB_RUN], int& nrun_out) {
-  // ---- loads: 4 consecutive samples per lane ----
+// The inputs of one lane: its FOUR CONSECUTIVE samples of tile `tile` -- positions (level independent) and the two upstream
+// gradient values of level l.
+struct FbPos {
+  float px[NS_FB_RUN][3];
+};
+typedef _Float16 fb_h4_t __attribute__((ext_vector_type(4)));
+struct FbGrad {            // (halves as loaded: a workgroup holds the rows of several levels)
+  fb_h4_t ga, gb;
+};
+__device__ __forceinline__ void fb_load_pos(int tile, int tid, const float* __restrict__ pos, long nvalid, int vec, FbPos& P) {
   const long i0 = (long)tile * NS_BIN_TILE + (long)tid * NS_FB_RUN;
-  float px[NS_FB_RUN][3], d0[NS_FB_RUN], d1[NS_FB_RUN];
-  const _Float16* __restrict__ g0p = dpu + (long)(2 * l) * N;
-  const _Float16* __restrict__ g1p = g0p + N;
   if (vec && i0 + NS_FB_RUN <= nvalid) {
     const float4* __restrict__ p4 = reinterpret_cast<const float4*>(pos + i0 * 3);
     const float4 A = p4[0], B = p4[1], Cc = p4[2];
-    px[0][0] = A.x; px[0][1] = A.y; px[0][2] = A.z;
-    px[1][0] = A.w; px[1][1] = B.x; px[1][2] = B.y;
-    px[2][0] = B.z; px[2][1] = B.w; px[2][2] = Cc.x;
-    px[3][0] = Cc.y; px[3][1] = Cc.z; px[3][2] = Cc.w;
-    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-    const h4_t ga = *reinterpret_cast<const h4_t*>(g0p + i0), gb = *reinterpret_cast<const h4_t*>(g1p + i0);
-#pragma unroll
-    for (int j = 0; j < NS_FB_RUN; j++) {
-      d0[j] = (float)ga[j];
-      d1[j] = (float)gb[j];
-    }
+    P.px[0][0] = A.x; P.px[0][1] = A.y; P.px[0][2] = A.z;
+    P.px[1][0] = A.w; P.px[1][1] = B.x; P.px[1][2] = B.y;
+    P.px[2][0] = B.z; P.px[2][1] = B.w; P.px[2][2] = Cc.x;
+    P.px[3][0] = Cc.y; P.px[3][1] = Cc.z; P.px[3][2] = Cc.w;
   } else {
 #pragma unroll
     for (int j = 0; j < NS_FB_RUN; j++) {
       const long i = i0 + j;
       const bool ok = i < nvalid;
-      px[j][0] = ok ? pos[i * 3] : 0.0f;
-      px[j][1] = ok ? pos[i * 3 + 1] : 0.0f;
-      px[j][2] = ok ? pos[i * 3 + 2] : 0.0f;
-      d0[j] = ok ? (float)g0p[i] : 0.0f;
-      d1[j] = ok ? (float)g1p[i] : 0.0f;
+      P.px[j][0] = ok ? pos[i * 3] : 0.0f;
+      P.px[j][1] = ok ? pos[i * 3 + 1] : 0.0f;
+      P.px[j][2] = ok ? pos[i * 3 + 2] : 0.0f;
     }
+  }
+}
+__device__ __forceinline__ void fb_load_grad(int l, int tile, int tid, const _Float16* __restrict__ dpu, long N, long nvalid, int vec,
+                                             FbGrad& G) {
+  const long i0 = (long)tile * NS_BIN_TILE + (long)tid * NS_FB_RUN;
+  const _Float16* __restrict__ g0p = dpu + (long)(2 * l) * N;
+  const _Float16* __restrict__ g1p = g0p + N;
+  if (vec && i0 + NS_FB_RUN <= nvalid) {
+    G.ga = *reinterpret_cast<const fb_h4_t*>(g0p + i0);
+    G.gb = *reinterpret_cast<const fb_h4_t*>(g1p + i0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NS_FB_RUN; j++) {
+      const long i = i0 + j;
+      const bool ok = i < nvalid;
+      G.ga[j] = ok ? g0p[i] : (_Float16)0;
+      G.gb[j] = ok ? g1p[i] : (_Float16)0;
+    }
+  }
+}
+
+// The runs of one lane on level l from its loaded inputs: neighbours that share a cell summed (exact).
+__device__ __forceinline__ void fb_runs_of(const GridLayout& g, int l, const FbPos& P, const FbGrad& G, float fixed_scale,
+                                           FbRun (&run)[NS_FB_RUN], int& nrun_out) {
+  const float (&px)[NS_FB_RUN][3] = P.px;
+  float d0[NS_FB_RUN], d1[NS_FB_RUN];
+#pragma unroll
+  for (int j = 0; j < NS_FB_RUN; j++) {
+    d0[j] = (float)G.ga[j];
+    d1[j] = (float)G.gb[j];
   }
   // ---- merge neighbours that share a cell ----
 #pragma unroll
@@ -1291,7 +1314,12 @@ __device__ __forceinline__ void fb_build_runs(const GridLayout& g, int l, int ti
   const float lim = 16777215.0f;   // 25-bit signed record fields
 #pragma unroll
   for (int j = 0; j < NS_FB_RUN; j++) {
-    if (d0[j] == 0.0f && d1[j] == 0.0f) continue;   // zero upstream gradient: the sample contributes nothing (as bin_sample)
+    // A sample whose upstream gradient is below HALF a fixed-point unit in both features emits nothing: its 8 contributions are
+    // fl(fl(wt d) S) with 0 <= wt <= 1, and rounding is monotone, so |fl(wt d)| <= |d| and the product stays below 0.5 -> every
+    // one rounds to the integer 0, which is never a record.  Skipped before any weight is formed (exact: same sums, bit for
+    // bit).  In a converged scene that is most samples: the mapper's steps inside the pipeline carry a non-zero gradient on
+    // 93 % of their samples and emit records for a few per cent of their contributions (zero gradient: the same test).
+    if (fabsf(d0[j]) * fixed_scale < 0.5f && fabsf(d1[j]) * fixed_scale < 0.5f) continue;
     uint32_t c[3];
     float w[3];
 #pragma unroll
@@ -1343,6 +1371,18 @@ __device__ __forceinline__ void fb_build_runs(const GridLayout& g, int l, int ti
     }
   }
   nrun_out = nrun;
+}
+
+
+// (both steps in one: what the staged kernel calls)
+__device__ __forceinline__ void fb_build_runs(const GridLayout& g, int l, int tile, int tid, const float* __restrict__ pos,
+                                              const _Float16* __restrict__ dpu, long N, long nvalid, float fixed_scale, int vec,
+                                              FbRun (&run)[NS_FB_RUN], int& nrun_out) {
+  FbPos P;
+  FbGrad G;
+  fb_load_pos(tile, tid, pos, nvalid, vec, P);
+  fb_load_grad(l, tile, tid, dpu, N, nvalid, vec, G);
+  fb_runs_of(g, l, P, G, fixed_scale, run, nrun_out);
 }
 
 __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, FusedPlan fp, const float* __restrict__ pos,
@@ -1433,6 +1473,10 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
 // registers bound it: 4 waves per SIMD), the pass that wrote the records to LDS, the pass that copied them out and two of the
 // four barriers.  Records beyond a slot (rank >= slot: possible only when > 1/16 of a tile's records meet in one bin) go to
 // the overflow list as before, after the one barrier that makes the counts final (a bit per record remembers which).
+// (round 4, measured and not kept: ONE workgroup per tile and FOUR levels -- positions loaded once, the four gradient rows up
+//  front, the levels worked off from registers, 1024 workgroups instead of 4096: 174 registers (two waves per SIMD), scatter
+//  47 -> 72 us on a converged scene's gradients, 87 -> 105 us on dense ones, training step 0.277 -> 0.310 ms.  The many small
+//  workgroups hide each other's latencies better than the few long ones.)
 __global__ __launch_bounds__(256) void ngp_enc_fscatter_direct_kernel(GridLayout g, FusedPlan fp, const float* __restrict__ pos,
                                                                       const _Float16* __restrict__ dpu, long N, float fixed_scale,
                                                                       int* __restrict__ ctr, int* __restrict__ cnt,
@@ -1525,7 +1569,7 @@ __global__ __launch_bounds__(NS_FB_THREADS) void ngp_enc_faccum_kernel(GridLayou
                                                                        const int* __restrict__ n_dev, int* __restrict__ ctr_rw,
                                                                        int n_groups) {
   __shared__ unsigned long long tab[NS_FB_SLICE];
-  __shared__ int scnt[NS_FB_THREADS];
+  __shared__ int scnt[NS_FB_THREADS], spre[NS_FB_THREADS], swave[NS_FB_THREADS / 64];
   __shared__ int s_novf;
   const int k = blockIdx.y, l = fp.level[k], b = blockIdx.x, tid = threadIdx.x;
   if (b >= fp.nbins[k]) return;
@@ -1553,9 +1597,45 @@ __global__ __launch_bounds__(NS_FB_THREADS) void ngp_enc_faccum_kernel(GridLayou
   const int wave = tid >> 6, lane = tid & 63;
   for (int t0 = 0; t0 < ntv; t0 += NS_FB_THREADS) {
     __syncthreads();
-    scnt[tid] = t0 + tid < ntv ? cnt[row + t0 + tid] : 0;
+    const int mycnt = t0 + tid < ntv ? cnt[row + t0 + tid] : 0;
+    scnt[tid] = mycnt;
+    // inclusive prefix sums of the run lengths over the chunk's slots (wave scan, then the 8 wave totals)
+    int incl = mycnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) swave[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+#pragma unroll
+    for (int w = 0; w < NS_FB_THREADS / 64; w++) woff += (w < wave) ? swave[w] : 0;
+    spre[tid] = woff + incl - mycnt;                       // exclusive prefix: first record of slot tid in the chunk's order
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < NS_FB_THREADS / 64; w++) total += swave[w];
     __syncthreads();
     const int nt = min(NS_FB_THREADS, ntv - t0);
+    // SPARSE bin (a converged scene: a handful of records per slot).  The slot-by-slot loop below spends a load round trip on
+    // every group of four slots whatever they hold -- 7 dependent rounds per wave for a 213-tile step, most of a work item's
+    // time when the slots are nearly empty.  Here record k of the chunk (k < total) is found by binary search in the prefix
+    // sums, one record per lane and round: ceil(total / 512) rounds.
+    if (total < 8 * nt) {                                   // (uniform per workgroup)
+      for (int k0 = 0; k0 < total; k0 += NS_FB_THREADS) {
+        const int k = k0 + tid;
+        if (k < total) {
+          int lo = 0, hi = nt - 1;                          // last slot s with spre[s] <= k
+          while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (spre[mid] <= k) lo = mid; else hi = mid - 1;
+          }
+          const int e = k - spre[lo];
+          if (e < scnt[lo]) fb_add(tab, qbin[(long)(t0 + lo) * slot + e]);
+        }
+      }
+      continue;
+    }
     for (int tt = wave * NS_FB_GROUP; tt < nt; tt += (NS_FB_THREADS / 64) * NS_FB_GROUP) {
       int c[NS_FB_GROUP];
       unsigned long long r[NS_FB_GROUP][2];

@@ -27,6 +27,7 @@ def us(fn, n=20):
 def main():
     live = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
     uniform = len(sys.argv) > 2 and sys.argv[2] == "uniform"
+    gscale = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-3      # sigma of the upstream gradient (1e-3: dense records; 2e-6: a converged scene)
     dev = torch.device("cuda:0")
     c = NgpConfig(aabb_scale=int(os.environ.get("NS_AABB", "4")))
     args = (c.n_levels, 2, c.log2_hashmap, c.base_res, C.c_float(c.per_level_scale))
@@ -41,7 +42,7 @@ def main():
     pos = (o + t * d).clamp(0.0, 1.0).reshape(N, 3).contiguous()
     if uniform:
         pos = torch.rand((N, 3), device=dev, generator=g).contiguous()
-    dfeat = (torch.randn((32, N), device=dev, generator=g) * 1e-3).half()
+    dfeat = (torch.randn((32, N), device=dev, generator=g) * gscale).half()
     if live < 1.0:      # the tail of every ray carries no gradient (transmittance gone), as in training
         steps = N // R
         dead = (torch.arange(steps, device=dev)[None, :] >= (steps * (2 * live * torch.rand((R, 1), device=dev, generator=g))).clamp(max=steps)).reshape(N)
@@ -90,7 +91,7 @@ def main():
     t2 = us(lambda: fused(2))
     t48 = us(lambda: fused(12)) if nd else 0.0
     tall = us(lambda: fused(15))
-    print(f"   scatter {t1:7.1f}  accumulate+adam {t2:7.1f}  dense {t48:7.1f}  all four {tall:7.1f} us")
+    print(f"   gradient sigma {gscale:g}: scatter {t1:7.1f}  accumulate+adam {t2:7.1f}  dense {t48:7.1f}  all four {tall:7.1f} us")
     return 0 if same else 1
 
 
