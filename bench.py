@@ -633,7 +633,7 @@ def cpu_baseline_c1280(fe, NB, n_edges):
     """The oracle (C restatement of the reference kernels) on config #5's shapes, on a bounded sample: the on-the-fly correlation
     (K14, reference src/altcorr_kernel.cu: oracle `orc_altcorr_forward_f32`, a scalar loop -- one edge per host thread here) of 64
     edges x 4 levels at 160x90, and one dense-BA linearisation + Schur reduction + depth update (K1/K6/K9/K10/K11) at M = 96
-    edges of a 49-pose window; extrapolated LINEARLY in the edge count to one global-BA pass (every edge correlated once, 2 BA
+    edges of a 49-pose window (fewer in the reduced test configuration); extrapolated LINEARLY in the edge count to one global-BA pass (every edge correlated once, 2 BA
     iterations over all edges).  The update operator (conv nets) is not part of the CPU figure: an upper bound of a CPU pass."""
     import concurrent.futures as cf
     import oracle
@@ -661,9 +661,10 @@ def cpu_baseline_c1280(fe, NB, n_edges):
         list(ex.map(one_edge, range(E_s)))
     t_alt = time.time() - t0                                   # E_s edges on thr threads
     # dense BA on a 49-pose window with its 96 neighbour edges
-    P, M = 49, 96
-    bi = np.concatenate([np.arange(48), np.arange(1, 49)]).astype(np.int64)
-    bj = np.concatenate([np.arange(1, 49), np.arange(48)]).astype(np.int64)
+    P = min(49, NB)
+    M = 2 * (P - 1)
+    bi = np.concatenate([np.arange(P - 1), np.arange(1, P)]).astype(np.int64)
+    bj = np.concatenate([np.arange(1, P), np.arange(P - 1)]).astype(np.int64)
     tg = fe.reproject(torch.from_numpy(bi).to(fe.device), torch.from_numpy(bj).to(fe.device)).permute(0, 3, 1, 2).contiguous().cpu().numpy()
     a = [fe.cam0_T_world[:P].cpu().numpy(), fe.cam0_idepths[:P].cpu().numpy(), fe.intr8.cpu().numpy(), fe.cam0_T_body.cpu().numpy(),
          fe.cam0_idepths_sensed[:P].cpu().numpy(), tg, np.ones_like(tg), np.full((P, ht * wd), 1e-4, np.float32)]

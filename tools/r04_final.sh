@@ -32,7 +32,9 @@ done
 NS_BENCH_DIST_BACKEND=gloo NS_BENCH_ONE_DEVICE=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29610 bench.py --gpus 2 --steps 2 --warmup 1 --config c1280 2>/dev/null | grep '^{' | tail -1 > $o/bench_c1280_gpus2_one_device_gloo.json
 # the RCCL path with one rank
 timeout 300 python tests/rccl_worker.py 29655 2>/dev/null | grep '^{' | tail -1 > $o/rccl_one_rank.json
-rm -rf $o/bprof $o/ngp $o/c1280; find $o/pmc -name "*agent_info.csv" -delete
+# (the raw counter dumps are ~60 MB: over gpurun's 64-MiB merge limit the WHOLE directory is dropped; traffic.json holds what is used)
+mkdir -p $o/pmc_logs; for d in $o/pmc/*; do cp $d/trace.log $o/pmc_logs/$(basename $d).log 2>/dev/null; done
+rm -rf $o/bprof $o/ngp $o/c1280 $o/pmc
 ls -la $o; du -sh $o
 python - <<PY
 import json
