@@ -133,6 +133,14 @@ int ns_altcorr_pyramid(const float* const* fmaps_host, int num_levels, const int
 int ns_altcorr_pyramid_f16(const void* const* fmaps_host, int num_levels, const int64_t* ii, const int64_t* jj,
                            const float* coords, float* out, int E, int H1, int W1, int C, void* stream);
 
+/* On-the-fly correlation fused with the correlation encoder (round 4; config #5's counterpart of ns_corr_lookup_encode_slots):
+ * AltCorrBlock.__call__ over four levels (networks/modules/corr.py:107-131) followed by Conv2d(196,128,1) + ReLU
+ * (networks/droid_net.py:83-87,133) in one launch -- the 196 f32 planes per edge are never written.  fmaps: the half pyramid of
+ * ns_altcorr_pyramid_f16 (four levels required); wfrag / bias as ns_corr_lookup_encode_slots; out [E,H1,W1,128] f16 channels-last.
+ * The 196 correlation values are rounded to half before the convolution (what autocast hands it in the reference). */
+int ns_altcorr_pyramid_encode_f16(const void* const* fmaps_host, const int64_t* ii, const int64_t* jj, const float* coords,
+                                  const void* wfrag, const float* bias, void* out, int E, int H1, int W1, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Geometry
  * ---------------------------------------------------------------------------------------- */

@@ -533,6 +533,198 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_kernel(AltPyramidH P, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// On-the-fly correlation + correlation encoder in ONE launch (round 4; the config-#5 counterpart of corr_lookup_enc_kernel).
+// Reference chain: AltCorrBlock.__call__ (networks/modules/corr.py:107-131, four levels, `.float()` results concatenated) ->
+// UpdateModule.corr_encoder[0:2] = Conv2d(196,128,1) + ReLU (networks/droid_net.py:83-87,133, under autocast: half inputs).
+// The plain kernel writes 196 f32 planes per edge -- 96 % of its bytes at 160x90 -- which a transposition and a 1x1 convolution
+// then read twice.  Here a workgroup owns an 8x8 tile through ALL FOUR levels: per level the same bounding-region product on the
+// matrix cores and the same bilinear blend as altcorr_tile_mfma_kernel, the 49 results rounded to half (what autocast hands the
+// convolution) into an LDS tile [208 channels][64 pixels]; then X W^T on MFMA (13 k-chunks, each wave two 32x32 output tiles),
+// bias, ReLU, [E,H,W,128] f16 channels-last.  The source-pixel fragments (level independent) are loaded once per tile.
+// ---------------------------------------------------------------------------------------------
+#define AE_K 208
+#define AE_PITCH 72
+__global__ __launch_bounds__(256) void altcorr_tile_enc_kernel(AltPyramidH P, const int64_t* __restrict__ ii,
+                                                               const int64_t* __restrict__ jj, const float* __restrict__ coords,
+                                                               const h8_t* __restrict__ wfrag, const float* __restrict__ bias,
+                                                               _Float16* __restrict__ out, int E, int H1, int W1) {
+  __shared__ float taps[64 * AT_TAPP];
+  __shared__ __attribute__((aligned(16))) uint16_t X[AE_K * AE_PITCH];       // 30 KB: [channel][pixel of the tile]
+  __shared__ int bbox[4], sxb[64], syb[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int e = blockIdx.y, tile = blockIdx.x;
+  const int ntx = (W1 + 7) >> 3;
+  const int ty = tile / ntx, tx = tile - ty * ntx;
+  const long HW1 = (long)H1 * W1;
+  const long fi = ii[e], fj = jj[e];
+  const _Float16* __restrict__ f1 = P.fmap[0] + fi * HW1 * AM_C;
+  const int j = lane & 31, kg = lane >> 5;
+  const int mt = wave & 1;
+  for (int t = tid; t < (AE_K - 196) * AE_PITCH; t += 256) X[196 * AE_PITCH + t] = 0;     // pad channels stay zero
+  h8_t afrag[AM_C / 16];
+  {
+    const int m = 32 * mt + j;                                 // source pixel of the tile this lane supplies as A row
+    const int py = 8 * ty + (m >> 3), px = 8 * tx + (m & 7);
+    const bool ok = py < H1 && px < W1;
+    const _Float16* __restrict__ src = f1 + ((long)py * W1 + px) * AM_C + 8 * kg;
+#pragma unroll
+    for (int cc = 0; cc < AM_C / 16; cc++) afrag[cc] = ok ? *reinterpret_cast<const h8_t*>(src + 16 * cc) : (h8_t)(_Float16)0;
+  }
+#pragma unroll 1
+  for (int lvl = 0; lvl < 4; lvl++) {
+    const int H2 = H1 >> lvl, W2 = W1 >> lvl;
+    const float scale = 1.0f / (float)(1 << lvl);
+    const _Float16* __restrict__ f2 = P.fmap[lvl] + fj * (long)H2 * W2 * AM_C;
+    uint16_t* __restrict__ Xl = X + lvl * 49 * AE_PITCH;
+    __syncthreads();                                           // the previous level's taps / bbox have been consumed
+    if (tid < 4) bbox[tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;
+    for (int t = tid; t < 64 * AT_TAPP; t += 256) taps[t] = 0.0f;
+    __syncthreads();
+    if (tid < 64) {
+      const int py = 8 * ty + (tid >> 3), px = 8 * tx + (tid & 7);
+      const bool inimg = py < H1 && px < W1;
+      float x2 = 0.0f, y2 = 0.0f;
+      if (inimg) {
+        const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + (long)py * W1 + px) * 2);
+        x2 = c.x * scale;
+        y2 = c.y * scale;
+      }
+      const bool sane = inimg && (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
+      const float fx0 = floorf(x2), fy0 = floorf(y2);
+      const int xb = sane ? (int)fx0 - 3 : -100000, yb = sane ? (int)fy0 - 3 : -100000;
+      sxb[tid] = xb;
+      syb[tid] = yb;
+      if (sane && xb > -8 && xb < W2 && yb > -8 && yb < H2) {
+        atomicMin(&bbox[0], max(xb, 0));
+        atomicMin(&bbox[1], max(yb, 0));
+        atomicMax(&bbox[2], min(xb + 8, W2));
+        atomicMax(&bbox[3], min(yb + 8, H2));
+      }
+    }
+    __syncthreads();
+    const bool empty = bbox[0] == 0x7fffffff || bbox[2] == -0x7fffffff;
+    const int x0 = bbox[0], y0 = bbox[1], RW = empty ? 0 : bbox[2] - bbox[0], RH = empty ? 0 : bbox[3] - bbox[1];
+    const int R = RW * RH;
+    const bool wild = R > AM_MAXR;                             // (workgroup-uniform) wild flow -> wave per pixel, 49 outputs straight
+    if (RW > 0 && RH > 0 && wild) {                            //  into the tap table (row p, 49 entries: cs = 1)
+      for (int k = 0; k < 16; k++) {
+        const int pp = wave * 16 + k;
+        const int qy = 8 * ty + (pp >> 3), qx = 8 * tx + (pp & 7);
+        if (qy >= H1 || qx >= W1) continue;  // wave-uniform
+        const long qpix = (long)qy * W1 + qx;
+        const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + qpix) * 2);
+        altcorr_pixel_h(f1 + qpix * AM_C, f2, H2, W2, c.x * scale, c.y * scale, taps + pp * AT_TAPP, 1, lane);
+      }
+    } else if (RW > 0 && RH > 0) {
+      int wxb[16], wyb[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int m = 32 * mt + 4 * kg + (q & 3) + 8 * (q >> 2);
+        wxb[q] = sxb[m];
+        wyb[q] = syb[m];
+      }
+      const int nnt = (R + 31) >> 5;
+      for (int nt = wave >> 1; nt < nnt; nt += 2) {
+        const int r = 32 * nt + j;                             // region pixel this lane supplies as B column
+        const bool rok = r < R;
+        const int ry = rok ? r / RW : 0, rx = rok ? r - ry * RW : 0;
+        const _Float16* __restrict__ src = f2 + ((long)(y0 + ry) * W2 + (x0 + rx)) * AM_C + 8 * kg;
+        h8_t bfrag[AM_C / 16];
+#pragma unroll
+        for (int cc = 0; cc < AM_C / 16; cc++) bfrag[cc] = rok ? *reinterpret_cast<const h8_t*>(src + 16 * cc) : (h8_t)(_Float16)0;
+        f16acc_t acc = (f16acc_t)0.0f;
+#pragma unroll
+        for (int cc = 0; cc < AM_C / 16; cc++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[cc], bfrag[cc], acc, 0, 0, 0);
+        if (rok) {
+          const int gx = x0 + rx, gy = y0 + ry;
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            const int m = 32 * mt + 4 * kg + (q & 3) + 8 * (q >> 2);
+            const int tx8 = gx - wxb[q], ty8 = gy - wyb[q];
+            if ((unsigned)tx8 < 8u && (unsigned)ty8 < 8u) taps[m * AT_TAPP + ty8 * 8 + tx8] = acc[q];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- the level's 49 values of every pixel, rounded to half, into the encoder's input tile ----
+    {
+      const int p = tid >> 2, q4 = tid & 3;
+      const int py = 8 * ty + (p >> 3), px = 8 * tx + (p & 7);
+      const bool inimg = py < H1 && px < W1;
+      if (RW <= 0 || RH <= 0 || !inimg) {                      // nothing looks into the image (or padding pixel): zeros
+        for (int ch = q4; ch < 49; ch += 4) Xl[ch * AE_PITCH + p] = 0;
+      } else if (wild) {
+        for (int ch = q4; ch < 49; ch += 4) Xl[ch * AE_PITCH + p] = __builtin_bit_cast(uint16_t, (_Float16)taps[p * AT_TAPP + ch]);
+      } else {
+        const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + (long)py * W1 + px) * 2);
+        const float x2 = c.x * scale, y2 = c.y * scale;
+        const bool sane = (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
+        const float ddx = sane ? x2 - floorf(x2) : 0.0f, ddy = sane ? y2 - floorf(y2) : 0.0f;
+        const float w00 = (1.0f - ddy) * (1.0f - ddx), w01 = (1.0f - ddy) * ddx, w10 = ddy * (1.0f - ddx), w11 = ddy * ddx;
+#pragma unroll
+        for (int r2 = 0; r2 < 2; r2++) {
+          const int oy = 2 * q4 + r2;
+          if (oy >= 7) continue;
+          const float* T0 = taps + p * AT_TAPP + oy * 8;
+#pragma unroll
+          for (int ox = 0; ox < 7; ox++) {
+            const float v = T0[ox] * w00 + T0[ox + 1] * w01 + T0[8 + ox] * w10 + T0[8 + ox + 1] * w11;
+            Xl[(oy + 7 * ox) * AE_PITCH + p] = __builtin_bit_cast(uint16_t, (_Float16)v);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- out[64 px][128] = relu(X W^T + b): wave (mt, nt0 = wave >> 1) computes the tiles (mt, nt0) and (mt, nt0 + 2) ----
+  const uint16_t* xa = X + 8 * kg * AE_PITCH + 32 * mt + j;    // A: row = pixel 32 mt + j, k = channel 16 c + 8 kg + q
+  h8_t a[13];
+#pragma unroll
+  for (int c = 0; c < 13; c++)
+#pragma unroll
+    for (int q = 0; q < 8; q++) a[c][q] = __builtin_bit_cast(_Float16, xa[(16 * c + q) * AE_PITCH]);
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int nt = (wave >> 1) + 2 * u;
+    f16acc_t acc = (f16acc_t)0.0f;
+#pragma unroll
+    for (int c = 0; c < 13; c++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[c], wfrag[(nt * 13 + c) * 64 + lane], acc, 0, 0, 0);
+    const float bj = bias[32 * nt + j];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = 32 * mt + 4 * kg + (r & 3) + 8 * (r >> 2);
+      const int py = 8 * ty + (m >> 3), px = 8 * tx + (m & 7);
+      if (py < H1 && px < W1) out[((long)e * HW1 + (long)py * W1 + px) * 128 + 32 * nt + j] = (_Float16)fmaxf(acc[r] + bj, 0.0f);
+    }
+  }
+}
+
+extern "C" int ns_altcorr_pyramid_encode_f16(const void* const* fmaps_host, const int64_t* ii, const int64_t* jj, const float* coords,
+                                             const void* wfrag, const float* bias, void* out, int E, int H1, int W1, int C,
+                                             void* stream) {
+  if (E == 0) return NS_OK;
+  NS_REQUIRE(fmaps_host && ii && jj && coords && wfrag && bias && out, "ns_altcorr_pyramid_encode_f16: null pointer");
+  NS_REQUIRE(E >= 0 && H1 > 0 && W1 > 0 && (H1 >> 3) > 0 && (W1 >> 3) > 0, "ns_altcorr_pyramid_encode_f16: bad shape (four levels)");
+  NS_REQUIRE(((uintptr_t)wfrag % 16) == 0, "ns_altcorr_pyramid_encode_f16: the weight fragments must be 16-byte aligned");
+  if (C != AM_C || E > 65535) {
+    ns_set_error("ns_altcorr_pyramid_encode_f16: built for 128 channels and at most 65535 edges per call (C=%d, E=%d)", C, E);
+    return NS_ENOSUP;
+  }
+  AltPyramidH P;
+  P.num_levels = 4;
+  for (int l = 0; l < 4; l++) {
+    P.fmap[l] = (const _Float16*)fmaps_host[l];
+    NS_REQUIRE(P.fmap[l] != nullptr && ((uintptr_t)P.fmap[l] % 16) == 0, "ns_altcorr_pyramid_encode_f16: fmaps[%d] null or not 16-byte aligned", l);
+  }
+  dim3 grid(((H1 + 7) / 8) * ((W1 + 7) / 8), E);
+  hipLaunchKernelGGL(altcorr_tile_enc_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, (const h8_t*)wfrag, bias,
+                     (_Float16*)out, E, H1, W1);
+  NS_CHECK_LAUNCH("altcorr_tile_enc_kernel");
+  return NS_OK;
+}
+
 extern "C" int ns_altcorr_pyramid_f16(const void* const* fmaps_host, int num_levels, const int64_t* ii, const int64_t* jj,
                                       const float* coords, float* out, int E, int H1, int W1, int C, void* stream) {
   if (E == 0) return NS_OK;

@@ -302,3 +302,22 @@ class AltCorrBlock:
             outs.append(out)
         out = outs[0][None] if squeeze else torch.stack(outs, dim=-1)[None]
         return out.contiguous()
+
+    def encoded(self, coords, ii, jj, enc):
+        """on-the-fly correlation + the update operator's correlation encoder (Conv2d(196,128,1) + ReLU, networks/droid_net.py:
+        83-87) in one launch (csrc/altcorr.hip: altcorr_tile_enc_kernel): coords [1, E, H, W, 2], enc = `CorrEncoderWeights` of
+        nerfslam.update_op -> `EncodedCorr` around [E, H, W, 128] f16 channels-last; the [1, E, 196, H, W] f32 tensor of
+        __call__ is never written.  Half pyramids of four levels only (what RaftVisualFrontend holds)."""
+        N, Cc, H, W = self.shape
+        if not self.half or self.num_levels != 4 or coords.dim() != 5:
+            raise NerfSlamHipError("AltCorrBlock.encoded: needs the half pyramid of four levels and coords [1,E,H,W,2]")
+        E = coords.shape[1]
+        ii = torch.as_tensor(ii, dtype=torch.long, device=coords.device).contiguous()
+        jj = torch.as_tensor(jj, dtype=torch.long, device=coords.device).contiguous()
+        cs = coords[0].contiguous().float()
+        out = torch.empty((E, H, W, 128), dtype=torch.float16, device=coords.device)
+        arr = (C.c_void_p * 4)(*[self.pyramid[l].data_ptr() for l in range(4)])
+        with torch.cuda.device(coords.device):
+            check(lib().ns_altcorr_pyramid_encode_f16(arr, ptr(ii), ptr(jj), ptr(cs), ptr(enc.frags), ptr(enc.bias), ptr(out), E, H, W,
+                                                      Cc, stream_ptr()), "altcorr_pyramid_encode_f16")
+        return EncodedCorr(out)

@@ -485,6 +485,8 @@ class NgpNerf:
         table_read = None
         if mlp_mode == "split":
             fork1 = torch.cuda.Event()
+            # (round 4, measured again: ONE fork point after the activation gradients for both side branches: 0.280-0.283 ->
+            #  0.287-0.294 ms per step)
             fork1.record(main)
             mark(None)
             check(L.ns_ngp_mlp_dgrad_f_n(ptr(self.mlp_frags), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),

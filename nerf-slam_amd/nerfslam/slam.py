@@ -17,6 +17,8 @@ The learned networks are injected through `args.networks` (see nerfslam.frontend
 nerfslam.droid_nets.DroidNetworks provides all of them on top of the DROID architecture (random or loaded weights).
 The GTSAM Values / NonlinearFactorGraph the reference returns empty (:248-250) are returned as None.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -264,7 +266,13 @@ class TrackingSLAM:
                     v = torch.from_numpy(vh).to(self.device)
                     iv, jv = ii[v], jj[v]
                     with self._leg("on-the-fly correlation (altcorr)"):
-                        corr = corr_op(coords1[None, v], iv, jv)
+                        # (networks that advertise `corr_encoder` get the correlation with the encoder's 1x1 convolution + ReLU
+                        #  already applied, in one launch: the 196 f32 planes per edge are never written)
+                        enc = getattr(self.net, "corr_encoder", None)
+                        if enc is not None and corr_op.half and not os.environ.get("NS_LOOKUP_UNFUSED"):
+                            corr = corr_op.encoded(coords1[None, v], iv, jv, enc)
+                        else:
+                            corr = corr_op(coords1[None, v], iv, jv)
                     with self._leg("update operator"):
                         if getattr(self.net.update, "host_indices", False):
                             res = self.net.update(corr, motion[None, v], iv, jv, ii_host=ii_h[vh].tolist(), jj_host=jj_h[vh].tolist())

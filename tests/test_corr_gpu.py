@@ -417,3 +417,40 @@ def test_lookup_fused_with_the_correlation_encoder(dev, shape):
         assert err <= 1.5e-3 * scale + 1e-3, (name, err, scale)                # one f16 ulp at the top of the range
     assert float((fused.double() - unfused.double()).abs().max()) <= 2e-3 * scale + 1e-3
     assert torch.isfinite(fused).all()
+
+
+@pytest.mark.parametrize("shape", [(90, 160), (21, 35)])
+def test_altcorr_fused_with_the_correlation_encoder(dev, shape):
+    """AltCorrBlock.encoded (csrc/altcorr.hip: altcorr_tile_enc_kernel) = relu(Conv2d(196,128,1)(half(AltCorrBlock(...)))) -- the
+    reference chain corr.py:107-131 -> droid_net.py:83-87,133 under autocast -- against the product's unfused launches and a
+    float64 evaluation of the layer on the unfused correlation: equal up to the f16 rounding of the output.  Smooth flow, flow
+    that leaves the image, wild flow (the wave-per-pixel fallback), image sizes that are not multiples of the 8x8 tile."""
+    from nerfslam.conv import PackedConv, planes_to_nhwc
+    from nerfslam.corr import AltCorrBlock
+    from nerfslam.update_op import CorrEncoderWeights
+    H, W = shape
+    g = torch.Generator().manual_seed(H * 31 + W)
+    nf, E = 5, 4
+    fm = torch.randn((1, nf, 128, H, W), generator=g).half().to(dev)
+    alt = AltCorrBlock(fm)
+    gy, gx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    base = torch.stack([gx, gy], -1).float()
+    coords = base[None, None].repeat(1, E, 1, 1, 1)
+    coords[0, 0] += 1.5 * torch.randn((H, W, 2), generator=g)                   # smooth-ish
+    coords[0, 1] += torch.tensor([W * 0.9, -H * 0.7])                           # leaves the image
+    coords[0, 2] += 40.0 * torch.randn((H, W, 2), generator=g)                  # wild: region > 1024 pixels
+    coords[0, 3, 0, 0] = float("nan")
+    coords = coords.to(dev)
+    ii = torch.tensor([0, 1, 2, 3], device=dev)
+    jj = torch.tensor([1, 2, 3, 4], device=dev)
+    Wt = (torch.randn((128, 196, 1, 1), generator=g) / 14.0).to(dev)
+    b = (0.1 * torch.randn(128, generator=g)).to(dev)
+    fused = alt.encoded(coords, ii, jj, CorrEncoderWeights(Wt, b)).c1
+    look = alt(coords, ii, jj)[0].half()                                        # [E,196,H,W]: autocast's cast of the f32 result
+    unfused = PackedConv(Wt, b, pad_cin_to=208)([planes_to_nhwc(look.contiguous(), 208)], act="relu")
+    ref = torch.relu(look.double().permute(0, 2, 3, 1) @ Wt.half().double().reshape(128, 196).t() + b.double())
+    scale = float(ref.abs().max())
+    assert fused.shape == (E, H, W, 128) and torch.isfinite(fused).all()
+    for name, got in (("fused", fused), ("unfused", unfused)):
+        err = float((got.double() - ref).abs().max())
+        assert err <= 1.5e-3 * scale + 1e-3, (name, err, scale)

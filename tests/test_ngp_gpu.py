@@ -1082,3 +1082,65 @@ def test_fused_table_gradient_with_binned_dense_levels(dev):
     tool = os.path.join(os.path.dirname(__file__), "..", "tools", "check_dense_binned.py")
     r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "bit-identical" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("regime", ["converged", "mixed"])
+@pytest.mark.parametrize("aabb", [1, 4])
+def test_fused_table_gradient_in_the_converged_scene_regime(oracle_mod, dev, regime, aabb):
+    """Round 4's paths for a converged scene's gradients (most contributions round to zero in Q18 fixed point): samples below
+    half a unit are skipped before any weight is formed, sparse bins are read record by record through the prefix sums of their
+    run lengths, every dense level goes through the bins (wave-level merge, small bins) -- the packed sums must equal the round-2
+    path bit for bit, with 5 dense levels (aabb 1) and 4 (aabb 4), on tiny gradients and on a mix of tiny, ordinary and
+    near-saturating ones; and Adam in the sparse flush must equal the streaming pass."""
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    from nerfslam.ngp import NgpConfig
+    c = NgpConfig(aabb_scale=aabb)
+    L = c.n_levels
+    args = (L, 2, c.log2_hashmap, c.base_res, C.c_float(c.per_level_scale))
+    off = (C.c_uint32 * (L + 1))()
+    check(lib().ns_ngp_grid_layout(*args, None, None, off), "layout")
+    n_par = int(off[L]) * 2
+    N, R = 1 << 17, 1024
+    rng = np.random.default_rng(40 + aabb)
+    o = rng.uniform(0.3, 0.7, (R, 1, 3))
+    d = rng.standard_normal((R, 1, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    t = (0.02 + 0.0017 * np.arange(N // R))[None, :, None]
+    pos = np.clip(o + t * d, 0.0, 1.0).reshape(N, 3).astype(np.float32)
+    sigma = np.full(N, 2e-6)
+    if regime == "mixed":
+        sigma[rng.uniform(size=N) < 0.2] = 1e-3
+        sigma[rng.uniform(size=N) < 0.01] = 8.0                        # large contributions (> 2^21 units: never merged), 5 sigma
+                                                                       # still inside the records' 25-bit fields (64 gradient units)
+    dLT = (rng.standard_normal((2 * L, N)) * sigma[None, :]).astype(np.float16)
+    dLT[:, (np.arange(N) % (N // R)) > 100] = 0                        # the tail of every ray carries nothing
+    wsb = int(lib().ns_ngp_encode_backward_fused_workspace_bytes(*args, C.c_long(N)))
+    ws = torch.zeros(wsb // 8 + 1, dtype=torch.int64, device=dev)
+    d_pos, d_dl = T(pos, dev), T(dLT, dev)
+    S = 262144.0
+    nul = C.c_void_p(0)
+    ref = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
+    check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dl), 1, ptr(ref), None, C.c_size_t(0), C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
+    gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
+    check(lib().ns_ngp_encode_backward_fused_n(*args, ptr(d_pos), ptr(d_dl), ptr(gq), ptr(ws), C.c_size_t(wsb), C.c_float(S), C.c_long(N),
+                                               nul, nul, nul, nul, nul, 1, C.c_float(0), C.c_float(0), C.c_float(0), C.c_float(0),
+                                               C.c_float(1), nul, 15, stream_ptr()), "fused")
+    assert torch.equal(gq, ref)
+    touched = int((ref != 0).sum())
+    ntiles = (N + 1023) // 1024
+    records = int(ws.view(torch.int32)[64:64 + L * 64 * ntiles].sum())
+    assert 0 < touched <= records
+    if regime == "converged":          # a few records per slot: the sparse path of the accumulate pass is what ran
+        assert records < 4 * L * 64 * ntiles, records
+    # Adam in the flush == gradient buffer + streaming Adam, bit for bit
+    lr, b1, b2, eps, gs = 1e-2, 0.9, 0.99, 1e-15, 128.0
+    g = torch.Generator().manual_seed(9)
+    m0 = (torch.rand(n_par, generator=g) * 2e-4 - 1e-4).to(dev)
+    a = dict(master=m0.clone(), hp=m0.half(), m1=torch.zeros(n_par, device=dev), m2=torch.zeros(n_par, device=dev))
+    f = dict(master=m0.clone(), hp=m0.half(), m1=torch.zeros(n_par, device=dev), m2=torch.zeros(n_par, device=dev))
+    check(lib().ns_ngp_adam(ptr(a["master"]), ptr(a["hp"]), ptr(ref), ptr(a["m1"]), ptr(a["m2"]), C.c_long(n_par), 1, C.c_float(lr),
+                            C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(0.0), C.c_float(gs), C.c_float(S), stream_ptr()), "adam")
+    check(lib().ns_ngp_encode_backward_fused_n(*args, ptr(d_pos), ptr(d_dl), nul, ptr(ws), C.c_size_t(wsb), C.c_float(S), C.c_long(N),
+                                               nul, ptr(f["master"]), ptr(f["hp"]), ptr(f["m1"]), ptr(f["m2"]), 1, C.c_float(lr),
+                                               C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(gs), nul, 15, stream_ptr()), "fused adam")
+    for k in ("master", "m1", "m2", "hp"):
+        assert torch.equal(a[k], f[k]), (k, int((a[k] != f[k]).sum()))
