@@ -253,6 +253,22 @@ def micro_benches(dev, hp, ngp_net):
     from nerfslam._lib import check, lib, ptr, stream_ptr
     out = {"corr_lookup_coop_kernel[E=48]": dict(fn=hp.op_lookup48, bound="hbm", per_launch=ALG_BYTES["lookup48"]),
            "corr_volume_tiled_kernel[E=10]": dict(fn=lambda: hp.op_build(hp.new_i, hp.new_j), bound="hbm", per_launch=ALG_BYTES["build10"])}
+    # the kernel the product's update() actually launches since round 4: lookup + correlation encoder (1x1 conv + ReLU) fused
+    from nerfslam.update_op import CorrEncoderWeights
+    from hot_path_chain import TILED
+    gw = torch.Generator(device=dev).manual_seed(5)
+    enc = CorrEncoderWeights(torch.randn((128, 196, 1, 1), device=dev, generator=gw) / 14.0, torch.zeros(128, device=dev))
+    pyr = (C.c_void_p * 4)(*[hp.corr48.corr_pyramid[l].data_ptr() for l in range(4)])
+    c48 = hp.coords48[0].contiguous().float()
+    enc_out = torch.empty((E_ACTIVE, HT, WD, 128), dtype=torch.float16, device=dev)
+
+    def lookup_enc():
+        check(lib().ns_corr_lookup_encode_slots(pyr, ptr(c48), 1, ptr(enc.frags), ptr(enc.bias), ptr(enc_out), E_ACTIVE, HT, WD,
+                                                1 if TILED else 0, None, E_ACTIVE, stream_ptr()), "corr_lookup_encode_slots")
+    out["corr_lookup_enc_kernel[E=48]"] = dict(
+        fn=lookup_enc, bound="hbm", per_launch=E_ACTIVE * HT * WD * (4 * 128 + 8 + 256), keep=(enc, enc_out, c48),
+        note="lookup (4 levels x 64 taps x 2 B + 8 B coordinates per edge and pixel) + Conv2d(196,128,1) + ReLU, 256 B written per "
+             "pixel; what TrackingFrontend.update() launches (the unfused lookup above remains for the motion filter and droid_backends)")
     # ---- the NeRF trainer's kernels ON A TRAINED STEP'S OWN SAMPLE SET: `ngp_net` has just trained (the
     # pipeline's mapper, or the sphere-scene trainer of --microbench); its last step left the marched samples, the encoding, the
     # loss gradient and dL/dfeature in place, and every kernel below is re-launched on exactly those arrays.
@@ -833,7 +849,8 @@ def main():
         roofs = kernel_rooflines(dev, hp, ngp._net)
         # share of the timed region per candidate kernel (launch time x launches per timed frame)
         steps_pf = counts["nerf_train_steps"] / K
-        per_frame = {"corr_lookup_coop_kernel[E=48]": counts["updates"] / K, "corr_volume_tiled_kernel[E=10]": counts["keyframe_candidates"] / K,
+        per_frame = {"corr_lookup_coop_kernel[E=48]": 0.0, "corr_lookup_enc_kernel[E=48]": counts["updates"] / K,
+                     "corr_volume_tiled_kernel[E=10]": counts["keyframe_candidates"] / K,
                      "conv_nhwc_kernel<3x3,448->256>[E=48]": counts["updates"] / K}
         in_step_all = roofs.pop("_in_step_all", {})
         for k, r in roofs.items():

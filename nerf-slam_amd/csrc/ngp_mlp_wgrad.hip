@@ -66,8 +66,9 @@ __device__ __forceinline__ void relu_frag(const f32x16& acc, int it, f16x8* out,
     v = __builtin_elementwise_max(v, (f16x2)(_Float16)0);
     out[2 * it + (p >> 2)][2 * (p & 3)] = v[0];
     out[2 * it + (p >> 2)][2 * (p & 3) + 1] = v[1];
-    // (relu output >= +0, i.e. halves 0x0000 .. 0x7c00: adding 0x7fff sets bit 15 exactly when the half is non-zero, no carry out)
-    const uint32_t nz = ((__builtin_bit_cast(uint32_t, v) + 0x7fff7fffu) >> 15) & 0x00010001u;
+    // (relu output: halves 0x0000 .. 0x7c00, or 0x8000 if the packed max hands back the -0 a tiny negative sum rounds to; with
+    //  the sign cleared, adding 0x7fff sets bit 15 exactly when the half is non-zero, no carry out)
+    const uint32_t nz = (((__builtin_bit_cast(uint32_t, v) & 0x7fff7fffu) + 0x7fff7fffu) >> 15) & 0x00010001u;
     mask |= nz << (8 * it + p);
   }
 }

@@ -25,8 +25,12 @@ NOISE_PX, OUTLIER_FRAC, OUTLIER_PX, OUTLIER_W = 0.5, 0.05, 10.0, 0.01
 
 
 def _run(dev, n_frames, noisy, seed=0):
+    with torch.no_grad():       # (scoped: a global torch.set_grad_enabled(False) would leak into the tests that follow)
+        return _run_no_grad(dev, n_frames, noisy, seed)
+
+
+def _run_no_grad(dev, n_frames, noisy, seed):
     import bench
-    torch.set_grad_enabled(False)
     pipe = bench.Pipeline(dev, n_frames + 8, 96, fusion=False)
     nets = pipe.nets
     clean_update = nets.update

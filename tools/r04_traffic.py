@@ -26,6 +26,7 @@ ENTRIES = {
     "ngp_mlp_bwd_kernel[step samples]": ("mlp_bwd", ["ngp_mlp_bwd_kernel"]),
     "ngp_mlp_wgrad_tr_kernel[step samples]": ("mlp_wgrad", ["ngp_mlp_wgrad_tr_kernel", "ngp_mlp_wgrad_reduce_kernel"]),
     "corr_lookup_coop_kernel[E=48]": ("lookup", ["corr_lookup_coop_kernel"]),
+    "corr_lookup_enc_kernel[E=48]": ("lookup_enc", ["corr_lookup_enc_kernel"]),
     "corr_volume_tiled_kernel[E=10]": ("volume", ["corr_volume_tiled_kernel"]),
     "conv_nhwc_kernel<3x3,448->256>[E=48]": ("conv", ["conv_nhwc_kernel<3, 4, 4, 2>"]),
     "altcorr_tile_mfma_kernel[E=48, 160x90]": ("altcorr", ["altcorr_tile_mfma_kernel"]),
