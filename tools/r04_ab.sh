@@ -1,7 +1,4 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for v in "" 1 "" 1; do
-  echo "== NS_ENC_FWD_NT=$v"; NS_ENC_FWD_NT=$v NS_NGP_EXTRINSICS=1 python tools/ngp_bench.py 800 320 2>&1 | tail -2 | head -1
-  NS_ENC_FWD_NT=$v timeout 120 python bench.py --microbench ngp_encode_fwd --reps 20 2>&1 | tail -1 | cut -c1-120
-done
-timeout 300 python -m pytest tests/test_ngp_gpu.py -x -q -m gpu -k "converged or encode_forward" 2>&1 | tail -2
+for st in 0 1 2 3 4 0; do NS_FB_STAGE=$st python tools/r04_bwd_ab.py 0.9 rays 2e-6 2>&1 | grep "gradient sigma" | sed "s/^/STAGE=$st /"; done
+for st in 0 1 2 3 4; do NS_FB_STAGE=$st python tools/r04_bwd_ab.py 0.9 rays 1e-3 2>&1 | grep "gradient sigma" | sed "s/^/STAGE=$st dense /"; done
