@@ -1513,7 +1513,10 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_direct_kernel(GridLayout
   uint32_t spill = 0u;            // bit (8 r + corner): that record found its slot full
 #pragma unroll
   for (int r = 0; r < NS_FB_RUN; r++) {
-    if (r < nrun) {
+    int any = 0;                    // (a run whose 16 fields all rounded to zero -- common in a converged scene -- costs no hashes)
+#pragma unroll
+    for (int corner = 0; corner < 8; corner++) any |= run[r].a[corner] | run[r].b[corner];
+    if (r < nrun && any != 0) {
       uint32_t idx[8];
       fb_indices_any(hashed, run[r].c, hs, res, idx);
 #pragma unroll

@@ -1029,8 +1029,11 @@ extern "C" int ns_ngp_mlp_wgrad_recompute_n(const void* frags, const void* featT
     hipLaunchKernelGGL(ngp_mlp_wgrad_recompute_kernel, dim3(wgs), dim3(128), 0, (hipStream_t)stream, a);
     NS_CHECK_LAUNCH("ngp_mlp_wgrad_recompute_kernel");
   } else {
-    // one 4-wave workgroup per CU (every wave holds all twelve accumulator tiles), at most one per four 32-sample tiles
-    static const int cus = [] { const char* e = getenv("NS_NGP_WGRAD_WGS"); return e ? atoi(e) : 256; }();
+    // 4-wave workgroups, every wave holding all twelve accumulator tiles: a workgroup takes a whole CU's registers.  64 of them
+    // (a quarter of the chip for ~4 x as long, still well inside the step) instead of one per CU: in the step this kernel runs
+    // next to the table gradient's scatter, which then keeps 192 CUs to itself -- stand-alone step unchanged (0.275 ms), pipeline
+    // 129-131 -> 134-137 frames/s (32: 133, 96: 136, 128: 131).  NS_NGP_WGRAD_WGS overrides.
+    static const int cus = [] { const char* e = getenv("NS_NGP_WGRAD_WGS"); return e ? atoi(e) : 64; }();
     const long tiles4 = (N / 32 + 3) / 4;
     wgs = (int)std::max(1L, std::min((long)std::min(wgs, cus), tiles4));
     NS_REQUIRE(((uintptr_t)featT % 8) == 0 && ((uintptr_t)dLdout % 8) == 0 && ((uintptr_t)partial_ws % 16) == 0,

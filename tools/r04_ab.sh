@@ -1,4 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for st in 0 1 2 3 4 0; do NS_FB_STAGE=$st python tools/r04_bwd_ab.py 0.9 rays 2e-6 2>&1 | grep "gradient sigma" | sed "s/^/STAGE=$st /"; done
-for st in 0 1 2 3 4; do NS_FB_STAGE=$st python tools/r04_bwd_ab.py 0.9 rays 1e-3 2>&1 | grep "gradient sigma" | sed "s/^/STAGE=$st dense /"; done
+for w in 64 32 256 64 32 96; do
+  echo "== NS_NGP_WGRAD_WGS=$w"; NS_NGP_WGRAD_WGS=$w python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), [round(w['frames_per_s'],1) for w in d['windows']], d['breakdown']['ms_per_frame_by_leg'])"
+done
