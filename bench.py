@@ -106,6 +106,8 @@ class Pipeline:
         # --parallel_run: the tracker works on a stream of its own as well.  On the legacy default stream its kernels were
         # serialised against the branches of the mapper's HIP graphs (the null stream synchronises implicitly with every
         # blocking stream, and the graph executor's internal streams are blocking ones): 97 -> 104 frames/s.
+        # (round 4, measured again: the tracker's stream at HIGH priority -- its kernels are many and short -- 130-133 -> 114-117
+        #  frames/s: normal priority on both)
         # (created at the first --parallel_run frame, i.e. AFTER the mapper's graphs exist: a stream gets its hardware queue when it
         #  is first used, and one that was used before the graphs were instantiated ended up sharing a queue with a graph branch:
         #  103 -> 93 frames/s)

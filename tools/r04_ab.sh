@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for w in 64 32 256 64 32 96; do
-  echo "== NS_NGP_WGRAD_WGS=$w"; NS_NGP_WGRAD_WGS=$w python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
+for w in 0 -1 0 -1; do
+  echo "== NS_BENCH_TRACK_PRIO=$w"; NS_BENCH_TRACK_PRIO=$w python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), [round(w['frames_per_s'],1) for w in d['windows']], d['breakdown']['ms_per_frame_by_leg'])"
 done
