@@ -351,7 +351,9 @@ def micro_benches(dev, hp, ngp_net):
         executed_flop_per_launch=90 * 2.0 * 32 * 32 * 16 * ((n + 31) // 32),
         note=where + "; algorithmic = the weight-gradient contraction alone (10240 multiply-adds per sample); the kernel EXECUTES 90 "
         "32x32x16 MFMAs per 32 samples (forward and backward chains recomputed, 30 of them are the turn-arounds through the matrix "
-        "core): `executed_flop_per_launch`; the launch time includes the 256-slab reduce")
+        "core): `executed_flop_per_launch`; the launch time includes the slab reduce.  The kernel is launched on 64 workgroups -- a "
+        "quarter of the chip BY CHOICE: in the step it runs beside the table gradient's scatter, which then keeps the other CUs "
+        "(pipeline +3 %); on 256 workgroups the same launch takes 44 us stand-alone")
     out["ngp_encode_fwd_kernel[step samples]"]["in_step"] = ["ngp_encode_fwd_kernel"]
     # the update operator's gate convolution (the largest MFMA launch of an update)
     from nerfslam.conv import PackedConv, conv_nhwc
