@@ -1482,6 +1482,9 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
 // workgroups: zero 64 KB of LDS, run lengths, flush scan); a converged scene's 1.5 M records + 0.8 M touched entries add 36 us,
 // most of it the optimiser state: master / two moments / f16 copy are four arrays, so a sparsely touched entry costs seven
 // scattered 8-byte accesses.
+// (round 4, measured and not kept: d S formed once per sample instead of per corner -- exact for a power-of-two scale -- with the
+//  clamps and the merge bound hoisted to the sample: 112 -> 32 instructions per 16 contributions, scatter 46.5 vs 47 us: the
+//  "loads + runs" stage waits on its loads, not on the VALU)
 // (round 4, measured and not kept: ONE workgroup per tile and FOUR levels -- positions loaded once, the four gradient rows up
 //  front, the levels worked off from registers, 1024 workgroups instead of 4096: 174 registers (two waves per SIMD), scatter
 //  47 -> 72 us on a converged scene's gradients, 87 -> 105 us on dense ones, training step 0.277 -> 0.310 ms.  The many small
