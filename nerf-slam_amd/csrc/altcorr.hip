@@ -534,6 +534,178 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_kernel(AltPyramidH P, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same product with its operands STAGED through LDS (round 4).  In the kernel above a fragment load is 16 bytes per lane
+// from 32 different pixels: 32 cache lines per instruction for 1 KB, the two row-tile waves fetch every column tile twice,
+// and the L1's tag pipeline -- not HBM, not the matrix cores -- set the pace (1.06 ms per 48-edge launch at 160 x 90, 0.1 of
+// the HBM roof).  Here the workgroup copies whole feature vectors: 16 lanes x 16 bytes = one pixel's 256 bytes, a wave
+// instruction = 4 pixels = 8 full lines, every byte of the region fetched ONCE per workgroup; the fragments are then 16-byte
+// LDS reads at a 272-byte pixel pitch (17 sixteen-byte slots: conflict-free).  The region is walked in chunks of 64 pixels
+// (2 column tiles x 2 row tiles = one product per wave), double buffered: the next chunk's global loads are in flight while
+// the matrix cores work on this one.  The source-pixel fragments pass through the first buffer once and stay in registers.
+// Same sums in the same order as the kernel above (k = channels 0..127 in chunks of 16): bit-identical output.
+// ---------------------------------------------------------------------------------------------
+#define AS_PITCH 136   // halves per staged pixel (272 bytes)
+__global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH P, const int64_t* __restrict__ ii,
+                                                                    const int64_t* __restrict__ jj,
+                                                                    const float* __restrict__ coords, float* __restrict__ out,
+                                                                    int E, int H1, int W1, int xcd_order) {
+  __shared__ float taps[64 * AT_TAPP];
+  __shared__ __attribute__((aligned(16))) _Float16 stage[2][64 * AS_PITCH];
+  __shared__ int bbox[4], sxb[64], syb[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lvl = blockIdx.y, e = blockIdx.z;
+  const int ntx = (W1 + 7) >> 3;
+  int tile = blockIdx.x;
+  if (xcd_order && (gridDim.x & 7) == 0) {     // (every XCD owns a contiguous run of tiles: see altcorr_tile_mfma_kernel)
+    const int per = gridDim.x >> 3;
+    tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  }
+  const int ty = tile / ntx, tx = tile - ty * ntx;
+  const long HW1 = (long)H1 * W1;
+  const int H2 = H1 >> lvl, W2 = W1 >> lvl;
+  const float scale = 1.0f / (float)(1 << lvl);
+  const long fi = ii[e], fj = jj[e];
+  const _Float16* __restrict__ f1 = P.fmap[0] + fi * HW1 * AM_C;
+  const _Float16* __restrict__ f2 = P.fmap[lvl] + fj * (long)H2 * W2 * AM_C;
+  float* __restrict__ obase = out + ((long)e * P.num_levels * 49 + lvl * 49) * HW1;
+  // ---- source-pixel vectors on their way to LDS (independent of the flow: issued before anything else) ----
+  const int sp = tid >> 4, piece = tid & 15;
+  h8_t pre[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int m = sp + 16 * i;
+    const int py = 8 * ty + (m >> 3), px = 8 * tx + (m & 7);
+    pre[i] = (py < H1 && px < W1) ? *reinterpret_cast<const h8_t*>(f1 + ((long)py * W1 + px) * AM_C + 8 * piece) : (h8_t)(_Float16)0;
+  }
+  bool inimg = false;
+  long pix = 0;
+  if (tid < 4) bbox[tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;
+  for (int t = tid; t < 64 * AT_TAPP; t += 256) taps[t] = 0.0f;
+  __syncthreads();
+  if (tid < 64) {
+    const int py = 8 * ty + (tid >> 3), px = 8 * tx + (tid & 7);
+    inimg = py < H1 && px < W1;
+    pix = inimg ? (long)py * W1 + px : 0;
+    float x2 = 0.0f, y2 = 0.0f;
+    if (inimg) {
+      const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + pix) * 2);
+      x2 = c.x * scale;
+      y2 = c.y * scale;
+    }
+    const bool sane = inimg && (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
+    const float fx0 = floorf(x2), fy0 = floorf(y2);
+    const int xb = sane ? (int)fx0 - 3 : -100000, yb = sane ? (int)fy0 - 3 : -100000;
+    sxb[tid] = xb;
+    syb[tid] = yb;
+    if (sane && xb > -8 && xb < W2 && yb > -8 && yb < H2) {
+      atomicMin(&bbox[0], max(xb, 0));
+      atomicMin(&bbox[1], max(yb, 0));
+      atomicMax(&bbox[2], min(xb + 8, W2));
+      atomicMax(&bbox[3], min(yb + 8, H2));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) *reinterpret_cast<h8_t*>(&stage[0][(sp + 16 * i) * AS_PITCH + 8 * piece]) = pre[i];
+  __syncthreads();
+  const bool empty = bbox[0] == 0x7fffffff || bbox[2] == -0x7fffffff;
+  const int x0 = bbox[0], y0 = bbox[1], RW = empty ? 0 : bbox[2] - bbox[0], RH = empty ? 0 : bbox[3] - bbox[1];
+  if (RW <= 0 || RH <= 0) {  // nothing of this tile looks into the image: zeros
+    if (tid < 64 && inimg)
+      for (int ch = 0; ch < 49; ch++) obase[(long)ch * HW1 + pix] = 0.0f;
+    return;
+  }
+  const int R = RW * RH;
+  if (R > AM_MAXR) {         // workgroup-uniform: wild flow -> wave per pixel
+    for (int k = 0; k < 16; k++) {
+      const int pp = wave * 16 + k;
+      const int qy = 8 * ty + (pp >> 3), qx = 8 * tx + (pp & 7);
+      if (qy >= H1 || qx >= W1) continue;  // wave-uniform
+      const long qpix = (long)qy * W1 + qx;
+      const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + qpix) * 2);
+      altcorr_pixel_h(f1 + qpix * AM_C, f2, H2, W2, c.x * scale, c.y * scale, obase + qpix, HW1, lane);
+    }
+    return;
+  }
+  // region pixel r -> (row, column) of the bounding box.  (r + 0.5) / RW is at least 0.5 / RW away from an integer and the
+  // float product is off by < 2e-7 r / RW: the truncation is the exact quotient for every r < 2^20.
+  const float inv_rw = 1.0f / (float)RW;
+  auto fetch = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = 64 * chunk + sp + 16 * i;
+      const int ry = (int)(((float)r + 0.5f) * inv_rw), rx = r - ry * RW;
+      pre[i] = r < R ? *reinterpret_cast<const h8_t*>(f2 + ((long)(y0 + ry) * W2 + (x0 + rx)) * AM_C + 8 * piece) : (h8_t)(_Float16)0;
+    }
+  };
+  fetch(0);
+  const int j = lane & 31, kg = lane >> 5;
+  const int mt = wave & 1, ntw = wave >> 1;
+  h8_t afrag[AM_C / 16];
+#pragma unroll
+  for (int cc = 0; cc < AM_C / 16; cc++)
+    afrag[cc] = *reinterpret_cast<const h8_t*>(&stage[0][(32 * mt + j) * AS_PITCH + 16 * cc + 8 * kg]);
+  // window origins of the 16 accumulator rows of this lane (rows 4 kg + (q & 3) + 8 (q >> 2) of row tile mt)
+  int wxb[16], wyb[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const int m = 32 * mt + 4 * kg + (q & 3) + 8 * (q >> 2);
+    wxb[q] = sxb[m];
+    wyb[q] = syb[m];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) *reinterpret_cast<h8_t*>(&stage[1][(sp + 16 * i) * AS_PITCH + 8 * piece]) = pre[i];
+  __syncthreads();
+  const int nchunk = (R + 63) >> 6;
+  for (int c = 0; c < nchunk; c++) {
+    const int buf = (c + 1) & 1;                               // chunk c lives in stage[(c + 1) & 1]
+    const bool more = c + 1 < nchunk;                          // (uniform)
+    if (more) fetch(c + 1);
+    const int r = 64 * c + 32 * ntw + j;                       // region pixel this lane holds as column j of its product
+    if (64 * c + 32 * ntw < R) {                               // (wave-uniform: the last chunk may hold one column tile)
+      f16acc_t acc = (f16acc_t)0.0f;
+      const _Float16* __restrict__ bsrc = &stage[buf][(32 * ntw + j) * AS_PITCH + 8 * kg];
+#pragma unroll
+      for (int cc = 0; cc < AM_C / 16; cc++)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[cc], *reinterpret_cast<const h8_t*>(bsrc + 16 * cc), acc, 0, 0, 0);
+      if (r < R) {
+        const int ry = (int)(((float)r + 0.5f) * inv_rw), rx = r - ry * RW;
+        const int gx = x0 + rx, gy = y0 + ry;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const int m = 32 * mt + 4 * kg + (q & 3) + 8 * (q >> 2);
+          const int tx8 = gx - wxb[q], ty8 = gy - wyb[q];
+          if ((unsigned)tx8 < 8u && (unsigned)ty8 < 8u) taps[m * AT_TAPP + ty8 * 8 + tx8] = acc[q];
+        }
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) *reinterpret_cast<h8_t*>(&stage[buf ^ 1][(sp + 16 * i) * AS_PITCH + 8 * piece]) = pre[i];
+    }
+    __syncthreads();
+  }
+  // ---- bilinear blend: thread (pixel p, quarter q4) writes output rows 2 q4, 2 q4 + 1 ----
+  const int p = tid >> 2, q4 = tid & 3;
+  const int py = 8 * ty + (p >> 3), px = 8 * tx + (p & 7);
+  if (py >= H1 || px >= W1) return;
+  const long opix = (long)py * W1 + px;
+  const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + opix) * 2);
+  const float x2 = c.x * scale, y2 = c.y * scale;
+  const bool sane = (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
+  const float ddx = sane ? x2 - floorf(x2) : 0.0f, ddy = sane ? y2 - floorf(y2) : 0.0f;
+  const float w00 = (1.0f - ddy) * (1.0f - ddx), w01 = (1.0f - ddy) * ddx, w10 = ddy * (1.0f - ddx), w11 = ddy * ddx;
+#pragma unroll
+  for (int r2 = 0; r2 < 2; r2++) {
+    const int oy = 2 * q4 + r2;
+    if (oy >= 7) continue;
+    const float* T0 = taps + p * AT_TAPP + oy * 8;
+#pragma unroll
+    for (int ox = 0; ox < 7; ox++)
+      obase[(long)(oy + 7 * ox) * HW1 + opix] = T0[ox] * w00 + T0[ox + 1] * w01 + T0[8 + ox] * w10 + T0[8 + ox + 1] * w11;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // On-the-fly correlation + correlation encoder in ONE launch (round 4; the config-#5 counterpart of corr_lookup_enc_kernel).
 // Reference chain: AltCorrBlock.__call__ (networks/modules/corr.py:107-131, four levels, `.float()` results concatenated) ->
 // UpdateModule.corr_encoder[0:2] = Conv2d(196,128,1) + ReLU (networks/droid_net.py:83-87,133, under autocast: half inputs).
@@ -744,9 +916,16 @@ extern "C" int ns_altcorr_pyramid_f16(const void* const* fmaps_host, int num_lev
   }
   dim3 grid(((H1 + 7) / 8) * ((W1 + 7) / 8), num_levels, E);
   static const bool no_xcd = getenv("NS_ALTCORR_NO_XCD") != nullptr;   // A/B switch: linear tile order
-  hipLaunchKernelGGL(altcorr_tile_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, out, E, H1, W1,
-                     no_xcd ? 0 : 1);
-  NS_CHECK_LAUNCH("altcorr_tile_mfma_kernel");
+  static const bool direct = getenv("NS_ALTCORR_DIRECT") != nullptr;   // A/B switch: fragments straight from global memory
+  if (direct) {
+    hipLaunchKernelGGL(altcorr_tile_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, out, E, H1, W1,
+                       no_xcd ? 0 : 1);
+    NS_CHECK_LAUNCH("altcorr_tile_mfma_kernel");
+  } else {
+    hipLaunchKernelGGL(altcorr_tile_mfma_lds_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, out, E, H1, W1,
+                       no_xcd ? 0 : 1);
+    NS_CHECK_LAUNCH("altcorr_tile_mfma_lds_kernel");
+  }
   return NS_OK;
 }
 
