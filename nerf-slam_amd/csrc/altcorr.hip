@@ -535,23 +535,26 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_kernel(AltPyramidH P, c
 
 // ---------------------------------------------------------------------------------------------
 // The same product with its operands STAGED through LDS (round 4).  In the kernel above a fragment load is 16 bytes per lane
-// from 32 different pixels: 32 cache lines per instruction for 1 KB, the two row-tile waves fetch every column tile twice,
-// and the L1's tag pipeline -- not HBM, not the matrix cores -- set the pace (1.06 ms per 48-edge launch at 160 x 90, 0.1 of
-// the HBM roof).  Here the workgroup copies whole feature vectors: 16 lanes x 16 bytes = one pixel's 256 bytes, a wave
-// instruction = 4 pixels = 8 full lines, every byte of the region fetched ONCE per workgroup; the fragments are then 16-byte
-// LDS reads at a 272-byte pixel pitch (17 sixteen-byte slots: conflict-free).  The region is walked in chunks of 64 pixels
-// (2 column tiles x 2 row tiles = one product per wave), double buffered: the next chunk's global loads are in flight while
-// the matrix cores work on this one.  The source-pixel fragments pass through the first buffer once and stay in registers.
+// from 32 different pixels: 32 cache lines per instruction for 1 KB, the two row-tile waves fetch every column tile twice, and
+// a workgroup walks its region one column tile at a time, every step a full load round trip (1.08-1.37 ms per 48-edge launch
+// at 160 x 90, 0.1 of the HBM roof: neither HBM nor the matrix cores, but the L1's tag pipeline and a chain of ~10 dependent
+// round trips per workgroup at 12 waves per CU).  Here the workgroup copies whole feature vectors: 16 lanes x 16 bytes = one
+// pixel's 256 bytes, a wave instruction = 4 pixels = 8 full lines, every byte of the region fetched ONCE per workgroup and 128
+// pixels (32 KB) at a time: a typical 15 x 15 region is two round trips.  The fragments are then 16-byte LDS reads at a
+// 272-byte pixel pitch (17 sixteen-byte slots: conflict-free).  The next chunk's loads are in flight (in registers) while the
+// matrix cores work on this one; the source-pixel fragments pass through the buffer once and stay in registers.
 // Same sums in the same order as the kernel above (k = channels 0..127 in chunks of 16): bit-identical output.
 // ---------------------------------------------------------------------------------------------
 #define AS_PITCH 136   // halves per staged pixel (272 bytes)
+#define AS_CHUNK 128   // region pixels per chunk
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH P, const int64_t* __restrict__ ii,
                                                                     const int64_t* __restrict__ jj,
                                                                     const float* __restrict__ coords, float* __restrict__ out,
                                                                     int E, int H1, int W1, int xcd_order) {
   __shared__ float taps[64 * AT_TAPP];
-  __shared__ __attribute__((aligned(16))) _Float16 stage[2][64 * AS_PITCH];
-  __shared__ int bbox[4], sxb[64], syb[64];
+  __shared__ __attribute__((aligned(16))) _Float16 stage[AS_CHUNK * AS_PITCH];
+  __shared__ int bbox[4], sxy[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lvl = blockIdx.y, e = blockIdx.z;
   const int ntx = (W1 + 7) >> 3;
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH 
   float* __restrict__ obase = out + ((long)e * P.num_levels * 49 + lvl * 49) * HW1;
   // ---- source-pixel vectors on their way to LDS (independent of the flow: issued before anything else) ----
   const int sp = tid >> 4, piece = tid & 15;
-  h8_t pre[4];
+  h8_t pre[AS_CHUNK / 16];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int m = sp + 16 * i;
@@ -595,9 +598,11 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH 
     const bool sane = inimg && (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
     const float fx0 = floorf(x2), fy0 = floorf(y2);
     const int xb = sane ? (int)fx0 - 3 : -100000, yb = sane ? (int)fy0 - 3 : -100000;
-    sxb[tid] = xb;
-    syb[tid] = yb;
-    if (sane && xb > -8 && xb < W2 && yb > -8 && yb < H2) {
+    // window origin as two 16-bit halves (a window that touches the image has its origin in (-8, 32767); anything else is
+    // parked at -20000, where no region pixel is within 8 of it)
+    const bool touches = sane && xb > -8 && xb < W2 && yb > -8 && yb < H2;
+    sxy[tid] = touches ? ((xb & 0xffff) | (yb << 16)) : (int)0xb1e0b1e0u;
+    if (touches) {
       atomicMin(&bbox[0], max(xb, 0));
       atomicMin(&bbox[1], max(yb, 0));
       atomicMax(&bbox[2], min(xb + 8, W2));
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH 
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++) *reinterpret_cast<h8_t*>(&stage[0][(sp + 16 * i) * AS_PITCH + 8 * piece]) = pre[i];
+  for (int i = 0; i < 4; i++) *reinterpret_cast<h8_t*>(&stage[(sp + 16 * i) * AS_PITCH + 8 * piece]) = pre[i];
   __syncthreads();
   const bool empty = bbox[0] == 0x7fffffff || bbox[2] == -0x7fffffff;
   const int x0 = bbox[0], y0 = bbox[1], RW = empty ? 0 : bbox[2] - bbox[0], RH = empty ? 0 : bbox[3] - bbox[1];
@@ -631,8 +636,8 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH 
   const float inv_rw = 1.0f / (float)RW;
   auto fetch = [&](int chunk) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int r = 64 * chunk + sp + 16 * i;
+    for (int i = 0; i < AS_CHUNK / 16; i++) {
+      const int r = AS_CHUNK * chunk + sp + 16 * i;
       const int ry = (int)(((float)r + 0.5f) * inv_rw), rx = r - ry * RW;
       pre[i] = r < R ? *reinterpret_cast<const h8_t*>(f2 + ((long)(y0 + ry) * W2 + (x0 + rx)) * AM_C + 8 * piece) : (h8_t)(_Float16)0;
     }
@@ -643,46 +648,45 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH 
   h8_t afrag[AM_C / 16];
 #pragma unroll
   for (int cc = 0; cc < AM_C / 16; cc++)
-    afrag[cc] = *reinterpret_cast<const h8_t*>(&stage[0][(32 * mt + j) * AS_PITCH + 16 * cc + 8 * kg]);
+    afrag[cc] = *reinterpret_cast<const h8_t*>(&stage[(32 * mt + j) * AS_PITCH + 16 * cc + 8 * kg]);
   // window origins of the 16 accumulator rows of this lane (rows 4 kg + (q & 3) + 8 (q >> 2) of row tile mt)
-  int wxb[16], wyb[16];
+  s16x2_t wxy[16];
 #pragma unroll
-  for (int q = 0; q < 16; q++) {
-    const int m = 32 * mt + 4 * kg + (q & 3) + 8 * (q >> 2);
-    wxb[q] = sxb[m];
-    wyb[q] = syb[m];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; i++) *reinterpret_cast<h8_t*>(&stage[1][(sp + 16 * i) * AS_PITCH + 8 * piece]) = pre[i];
-  __syncthreads();
-  const int nchunk = (R + 63) >> 6;
+  for (int q = 0; q < 16; q++) wxy[q] = __builtin_bit_cast(s16x2_t, sxy[32 * mt + 4 * kg + (q & 3) + 8 * (q >> 2)]);
+  __syncthreads();                                             // (every wave has its source-pixel fragments: the buffer is free)
+  const int nchunk = (R + AS_CHUNK - 1) / AS_CHUNK;
   for (int c = 0; c < nchunk; c++) {
-    const int buf = (c + 1) & 1;                               // chunk c lives in stage[(c + 1) & 1]
-    const bool more = c + 1 < nchunk;                          // (uniform)
-    if (more) fetch(c + 1);
-    const int r = 64 * c + 32 * ntw + j;                       // region pixel this lane holds as column j of its product
-    if (64 * c + 32 * ntw < R) {                               // (wave-uniform: the last chunk may hold one column tile)
+#pragma unroll
+    for (int i = 0; i < AS_CHUNK / 16; i++) *reinterpret_cast<h8_t*>(&stage[(sp + 16 * i) * AS_PITCH + 8 * piece]) = pre[i];
+    __syncthreads();
+    if (c + 1 < nchunk) fetch(c + 1);                          // (uniform) in flight while the matrix cores work
+#pragma unroll
+    for (int h = 0; h < AS_CHUNK / 64; h++) {
+      const int col = 64 * h + 32 * ntw;                       // column tile of this wave inside the chunk
+      if (AS_CHUNK * c + col >= R) continue;                   // (wave-uniform)
+      const int r = AS_CHUNK * c + col + j;                    // region pixel this lane holds as column j of its product
       f16acc_t acc = (f16acc_t)0.0f;
-      const _Float16* __restrict__ bsrc = &stage[buf][(32 * ntw + j) * AS_PITCH + 8 * kg];
+      const _Float16* __restrict__ bsrc = &stage[(col + j) * AS_PITCH + 8 * kg];
 #pragma unroll
       for (int cc = 0; cc < AM_C / 16; cc++)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[cc], *reinterpret_cast<const h8_t*>(bsrc + 16 * cc), acc, 0, 0, 0);
       if (r < R) {
         const int ry = (int)(((float)r + 0.5f) * inv_rw), rx = r - ry * RW;
-        const int gx = x0 + rx, gy = y0 + ry;
+        s16x2_t gxy;
+        gxy[0] = (short)(x0 + rx);
+        gxy[1] = (short)(y0 + ry);
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-          const int m = 32 * mt + 4 * kg + (q & 3) + 8 * (q >> 2);
-          const int tx8 = gx - wxb[q], ty8 = gy - wyb[q];
-          if ((unsigned)tx8 < 8u && (unsigned)ty8 < 8u) taps[m * AT_TAPP + ty8 * 8 + tx8] = acc[q];
+          // both offsets from the window origin at once: inside [0, 8)^2 iff no bit above the low three of either half
+          const uint32_t d = __builtin_bit_cast(uint32_t, (s16x2_t)(gxy - wxy[q]));
+          if ((d & 0xfff8fff8u) == 0u) {
+            const int m = 32 * mt + 4 * kg + (q & 3) + 8 * (q >> 2);
+            taps[m * AT_TAPP + (d >> 13) + (d & 7u)] = acc[q];      // row offset * 8 + column offset
+          }
         }
       }
     }
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) *reinterpret_cast<h8_t*>(&stage[buf ^ 1][(sp + 16 * i) * AS_PITCH + 8 * piece]) = pre[i];
-    }
-    __syncthreads();
+    __syncthreads();                                           // (the taps are complete / the buffer is free)
   }
   // ---- bilinear blend: thread (pixel p, quarter q4) writes output rows 2 q4, 2 q4 + 1 ----
   const int p = tid >> 2, q4 = tid & 3;
