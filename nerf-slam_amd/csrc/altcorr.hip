@@ -534,20 +534,27 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_kernel(AltPyramidH P, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same product with its operands STAGED through LDS (round 4).  In the kernel above a fragment load is 16 bytes per lane
-// from 32 different pixels: 32 cache lines per instruction for 1 KB, the two row-tile waves fetch every column tile twice, and
-// a workgroup walks its region one column tile at a time, every step a full load round trip (1.08-1.37 ms per 48-edge launch
-// at 160 x 90, 0.1 of the HBM roof: neither HBM nor the matrix cores, but the L1's tag pipeline and a chain of ~10 dependent
-// round trips per workgroup at 12 waves per CU).  Here the workgroup copies whole feature vectors: 16 lanes x 16 bytes = one
-// pixel's 256 bytes, a wave instruction = 4 pixels = 8 full lines, every byte of the region fetched ONCE per workgroup and 128
-// pixels (32 KB) at a time: a typical 15 x 15 region is two round trips.  The fragments are then 16-byte LDS reads at a
-// 272-byte pixel pitch (17 sixteen-byte slots: conflict-free).  The next chunk's loads are in flight (in registers) while the
-// matrix cores work on this one; the source-pixel fragments pass through the buffer once and stay in registers.
-// Same sums in the same order as the kernel above (k = channels 0..127 in chunks of 16): bit-identical output.
+// The same product with its operands STAGED through LDS and its load round trips cut to two (round 4).  What the kernel above
+// waits for is neither HBM nor the matrix cores (1.08-1.37 ms per 48-edge launch at 160 x 90, 0.1 of the HBM roof):
+//   * a fragment load is 16 bytes per lane from 32 different pixels -- 32 cache lines per instruction for 1 KB -- and the two
+//     row-tile waves fetch every column tile twice;
+//   * a workgroup is a CHAIN of dependent round trips at 12 waves per CU: source vectors, flow, one per column tile, flow again
+//     for the blend, and every __syncthreads() in between drains the vector-memory counter.  Stage-by-stage early exits:
+//     prologue alone 0.56 ms, + blend and stores 0.71, + the column tiles 1.10 -- each round trip costs ~3 us under this load.
+// Here (1) the workgroup copies whole feature vectors: 16 lanes x 16 bytes = one pixel's 256 bytes, a wave instruction = 4
+// pixels = 8 full lines, every byte of the region fetched ONCE per workgroup; the fragments are 16-byte LDS reads at a
+// 272-byte pixel pitch (17 sixteen-byte slots: conflict-free).  (2) Source vectors and flow leave together; the first TWO
+// 128-pixel chunks of the region (a smooth flow's whole 15 x 15 .. 16 x 16 region) leave together into two register sets; the
+// blend weights wait in LDS.  (3) The barriers wait for LDS only (s_waitcnt lgkmcnt(0) + s_barrier), so loads stay in flight
+// across them.  Same sums in the same order as the kernel above (k = channels 0..127 in chunks of 16): bit-identical output.
 // ---------------------------------------------------------------------------------------------
 #define AS_PITCH 136   // halves per staged pixel (272 bytes)
 #define AS_CHUNK 128   // region pixels per chunk
 typedef short s16x2_t __attribute__((ext_vector_type(2)));
+
+// workgroup barrier that orders LDS traffic only: global loads issued before it may still be in flight behind it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH P, const int64_t* __restrict__ ii,
                                                                     const int64_t* __restrict__ jj,
                                                                     const float* __restrict__ coords, float* __restrict__ out,
@@ -555,6 +562,7 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH 
   __shared__ float taps[64 * AT_TAPP];
   __shared__ __attribute__((aligned(16))) _Float16 stage[AS_CHUNK * AS_PITCH];
   __shared__ int bbox[4], sxy[64];
+  __shared__ float2 sfr[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lvl = blockIdx.y, e = blockIdx.z;
   const int ntx = (W1 + 7) >> 3;
@@ -571,47 +579,57 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH 
   const _Float16* __restrict__ f1 = P.fmap[0] + fi * HW1 * AM_C;
   const _Float16* __restrict__ f2 = P.fmap[lvl] + fj * (long)H2 * W2 * AM_C;
   float* __restrict__ obase = out + ((long)e * P.num_levels * 49 + lvl * 49) * HW1;
-  // ---- source-pixel vectors on their way to LDS (independent of the flow: issued before anything else) ----
+  // ---- round trip 1: the flow of the tile's pixels and their feature vectors ----
   const int sp = tid >> 4, piece = tid & 15;
-  h8_t pre[AS_CHUNK / 16];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int m = sp + 16 * i;
-    const int py = 8 * ty + (m >> 3), px = 8 * tx + (m & 7);
-    pre[i] = (py < H1 && px < W1) ? *reinterpret_cast<const h8_t*>(f1 + ((long)py * W1 + px) * AM_C + 8 * piece) : (h8_t)(_Float16)0;
-  }
   bool inimg = false;
   long pix = 0;
-  if (tid < 4) bbox[tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;
-  for (int t = tid; t < 64 * AT_TAPP; t += 256) taps[t] = 0.0f;
-  __syncthreads();
+  float2 cf = make_float2(0.0f, 0.0f);
   if (tid < 64) {
     const int py = 8 * ty + (tid >> 3), px = 8 * tx + (tid & 7);
     inimg = py < H1 && px < W1;
     pix = inimg ? (long)py * W1 + px : 0;
-    float x2 = 0.0f, y2 = 0.0f;
-    if (inimg) {
-      const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + pix) * 2);
-      x2 = c.x * scale;
-      y2 = c.y * scale;
-    }
+    if (inimg) cf = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + pix) * 2);
+  }
+  h8_t pa[AS_CHUNK / 16], pb[AS_CHUNK / 16];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int m = sp + 16 * i;
+    const int py = 8 * ty + (m >> 3), px = 8 * tx + (m & 7);
+    // (pixels of the tile beyond the image edge: the address is clamped, their rows of the product are never stored)
+    pa[i] = *reinterpret_cast<const h8_t*>(f1 + ((long)min(py, H1 - 1) * W1 + min(px, W1 - 1)) * AM_C + 8 * piece);
+  }
+  for (int t = tid; t < 64 * AT_TAPP; t += 256) taps[t] = 0.0f;
+  lds_barrier();
+  if (tid < 64) {
+    const float x2 = cf.x * scale, y2 = cf.y * scale;
     const bool sane = inimg && (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
     const float fx0 = floorf(x2), fy0 = floorf(y2);
     const int xb = sane ? (int)fx0 - 3 : -100000, yb = sane ? (int)fy0 - 3 : -100000;
+    sfr[tid] = make_float2(sane ? x2 - fx0 : 0.0f, sane ? y2 - fy0 : 0.0f);      // the blend's weights
     // window origin as two 16-bit halves (a window that touches the image has its origin in (-8, 32767); anything else is
     // parked at -20000, where no region pixel is within 8 of it)
     const bool touches = sane && xb > -8 && xb < W2 && yb > -8 && yb < H2;
     sxy[tid] = touches ? ((xb & 0xffff) | (yb << 16)) : (int)0xb1e0b1e0u;
-    if (touches) {
-      atomicMin(&bbox[0], max(xb, 0));
-      atomicMin(&bbox[1], max(yb, 0));
-      atomicMax(&bbox[2], min(xb + 8, W2));
-      atomicMax(&bbox[3], min(yb + 8, H2));
+    // bounding box of the windows that touch the image: butterfly over the wave (these 64 threads are wave 0)
+    int bx0 = touches ? max(xb, 0) : 0x7fffffff, by0 = touches ? max(yb, 0) : 0x7fffffff;
+    int bx1 = touches ? min(xb + 8, W2) : -0x7fffffff, by1 = touches ? min(yb + 8, H2) : -0x7fffffff;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      bx0 = min(bx0, __shfl_xor(bx0, d, 64));
+      by0 = min(by0, __shfl_xor(by0, d, 64));
+      bx1 = max(bx1, __shfl_xor(bx1, d, 64));
+      by1 = max(by1, __shfl_xor(by1, d, 64));
+    }
+    if (tid == 0) {
+      bbox[0] = bx0;
+      bbox[1] = by0;
+      bbox[2] = bx1;
+      bbox[3] = by1;
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++) *reinterpret_cast<h8_t*>(&stage[(sp + 16 * i) * AS_PITCH + 8 * piece]) = pre[i];
-  __syncthreads();
+  for (int i = 0; i < 4; i++) *reinterpret_cast<h8_t*>(&stage[(sp + 16 * i) * AS_PITCH + 8 * piece]) = pa[i];
+  lds_barrier();
   const bool empty = bbox[0] == 0x7fffffff || bbox[2] == -0x7fffffff;
   const int x0 = bbox[0], y0 = bbox[1], RW = empty ? 0 : bbox[2] - bbox[0], RH = empty ? 0 : bbox[3] - bbox[1];
   if (RW <= 0 || RH <= 0) {  // nothing of this tile looks into the image: zeros
@@ -634,15 +652,18 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH 
   // region pixel r -> (row, column) of the bounding box.  (r + 0.5) / RW is at least 0.5 / RW away from an integer and the
   // float product is off by < 2e-7 r / RW: the truncation is the exact quotient for every r < 2^20.
   const float inv_rw = 1.0f / (float)RW;
-  auto fetch = [&](int chunk) {
+  auto fetch = [&](h8_t (&pre)[AS_CHUNK / 16], int chunk) {
 #pragma unroll
     for (int i = 0; i < AS_CHUNK / 16; i++) {
-      const int r = AS_CHUNK * chunk + sp + 16 * i;
+      const int r = min(AS_CHUNK * chunk + sp + 16 * i, R - 1);      // (columns past the region: clamped, never looked at)
       const int ry = (int)(((float)r + 0.5f) * inv_rw), rx = r - ry * RW;
-      pre[i] = r < R ? *reinterpret_cast<const h8_t*>(f2 + ((long)(y0 + ry) * W2 + (x0 + rx)) * AM_C + 8 * piece) : (h8_t)(_Float16)0;
+      pre[i] = *reinterpret_cast<const h8_t*>(f2 + ((long)(y0 + ry) * W2 + (x0 + rx)) * AM_C + 8 * piece);
     }
   };
-  fetch(0);
+  // ---- round trip 2: the first two chunks of the region ----
+  const int nchunk = (R + AS_CHUNK - 1) / AS_CHUNK;
+  fetch(pa, 0);
+  if (nchunk > 1) fetch(pb, 1);
   const int j = lane & 31, kg = lane >> 5;
   const int mt = wave & 1, ntw = wave >> 1;
   h8_t afrag[AM_C / 16];
@@ -653,13 +674,8 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH 
   s16x2_t wxy[16];
 #pragma unroll
   for (int q = 0; q < 16; q++) wxy[q] = __builtin_bit_cast(s16x2_t, sxy[32 * mt + 4 * kg + (q & 3) + 8 * (q >> 2)]);
-  __syncthreads();                                             // (every wave has its source-pixel fragments: the buffer is free)
-  const int nchunk = (R + AS_CHUNK - 1) / AS_CHUNK;
-  for (int c = 0; c < nchunk; c++) {
-#pragma unroll
-    for (int i = 0; i < AS_CHUNK / 16; i++) *reinterpret_cast<h8_t*>(&stage[(sp + 16 * i) * AS_PITCH + 8 * piece]) = pre[i];
-    __syncthreads();
-    if (c + 1 < nchunk) fetch(c + 1);                          // (uniform) in flight while the matrix cores work
+  lds_barrier();                                               // (every wave has its source-pixel fragments: the buffer is free)
+  auto products = [&](int c) {                                 // chunk c is in the buffer
 #pragma unroll
     for (int h = 0; h < AS_CHUNK / 64; h++) {
       const int col = 64 * h + 32 * ntw;                       // column tile of this wave inside the chunk
@@ -686,17 +702,29 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH 
         }
       }
     }
-    __syncthreads();                                           // (the taps are complete / the buffer is free)
+  };
+  for (int c = 0; c < nchunk; c += 2) {
+#pragma unroll
+    for (int i = 0; i < AS_CHUNK / 16; i++) *reinterpret_cast<h8_t*>(&stage[(sp + 16 * i) * AS_PITCH + 8 * piece]) = pa[i];
+    lds_barrier();
+    if (c + 2 < nchunk) fetch(pa, c + 2);                      // (uniform) in flight while the matrix cores work
+    products(c);
+    lds_barrier();                                             // (the buffer is free / the taps are complete)
+    if (c + 1 >= nchunk) break;
+#pragma unroll
+    for (int i = 0; i < AS_CHUNK / 16; i++) *reinterpret_cast<h8_t*>(&stage[(sp + 16 * i) * AS_PITCH + 8 * piece]) = pb[i];
+    lds_barrier();
+    if (c + 3 < nchunk) fetch(pb, c + 3);
+    products(c + 1);
+    lds_barrier();
   }
   // ---- bilinear blend: thread (pixel p, quarter q4) writes output rows 2 q4, 2 q4 + 1 ----
   const int p = tid >> 2, q4 = tid & 3;
   const int py = 8 * ty + (p >> 3), px = 8 * tx + (p & 7);
   if (py >= H1 || px >= W1) return;
   const long opix = (long)py * W1 + px;
-  const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + opix) * 2);
-  const float x2 = c.x * scale, y2 = c.y * scale;
-  const bool sane = (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
-  const float ddx = sane ? x2 - floorf(x2) : 0.0f, ddy = sane ? y2 - floorf(y2) : 0.0f;
+  const float2 fr = sfr[p];
+  const float ddx = fr.x, ddy = fr.y;
   const float w00 = (1.0f - ddy) * (1.0f - ddx), w01 = (1.0f - ddy) * ddx, w10 = ddy * (1.0f - ddx), w11 = ddy * ddx;
 #pragma unroll
   for (int r2 = 0; r2 < 2; r2++) {
