@@ -905,6 +905,260 @@ __global__ __launch_bounds__(256) void altcorr_tile_enc_kernel(AltPyramidH P, co
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The fused kernel with the LDS-staged operands of altcorr_tile_mfma_lds_kernel (round 4).  A workgroup owns an 8x8 tile
+// through all four levels and sees its work as ONE stream of 64-pixel chunks -- level 0's region, then level 1's, ... -- with
+// the loads of the next THREE chunks always in flight (three register sets; at two workgroups per CU a wave has 256 registers
+// to itself): after the first round trip (flow + source vectors; wave l prepares level l: window origins, blend weights,
+// bounding box by butterfly) the matrix cores never wait for a whole round trip again.  The tap table is not zero-filled:
+// the blend masks taps outside the image by their coordinates (same values: a zero tap contributes a zero term).  Encoder
+// input tile as [pixel][216 halves] so that its fragments are 16-byte LDS reads.  70 KB of LDS per workgroup.
+// ---------------------------------------------------------------------------------------------
+#define AE_XP 216      // halves per pixel of the encoder's input tile (208 channels + 8: 27 sixteen-byte slots)
+#define AE_CHUNK 64
+#define AE_DEPTH 3
+__global__ __launch_bounds__(256, 2) void altcorr_tile_enc_lds_kernel(AltPyramidH P, const int64_t* __restrict__ ii,
+                                                                      const int64_t* __restrict__ jj,
+                                                                      const float* __restrict__ coords,
+                                                                      const h8_t* __restrict__ wfrag, const float* __restrict__ bias,
+                                                                      _Float16* __restrict__ out, int E, int H1, int W1,
+                                                                      int xcd_order) {
+  __shared__ float taps[64 * AT_TAPP];
+  __shared__ __attribute__((aligned(16))) uint16_t X[64 * AE_XP];                  // 27 KB: [pixel of the tile][channel]
+  __shared__ __attribute__((aligned(16))) _Float16 stage[AE_CHUNK * AS_PITCH];     // 17 KB
+  __shared__ int sxy[4][64], lvp[4][4];
+  __shared__ float2 sfr[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int e = blockIdx.y;
+  int tile = blockIdx.x;
+  if (xcd_order && (gridDim.x & 7) == 0) {     // (every XCD owns a contiguous run of tiles: neighbours share their regions in L2)
+    const int per = gridDim.x >> 3;
+    tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  }
+  const int ntx = (W1 + 7) >> 3;
+  const int ty = tile / ntx, tx = tile - ty * ntx;
+  const long HW1 = (long)H1 * W1;
+  const long fi = ii[e], fj = jj[e];
+  const _Float16* __restrict__ f1 = P.fmap[0] + fi * HW1 * AM_C;
+  const int j = lane & 31, kg = lane >> 5;
+  const int mt = wave & 1, ntw = wave >> 1;
+  const int sp = tid >> 4, piece = tid & 15;
+  // ---- round trip 1: flow of the tile's pixels (every wave: lane = pixel) and their feature vectors ----
+  const int ppy = 8 * ty + (lane >> 3), ppx = 8 * tx + (lane & 7);
+  const bool inimg = ppy < H1 && ppx < W1;
+  const float2 cf = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + (long)min(ppy, H1 - 1) * W1 + min(ppx, W1 - 1)) * 2);
+  h8_t pre[AE_DEPTH][AE_CHUNK / 16];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int m = sp + 16 * i;
+    const int py = 8 * ty + (m >> 3), px = 8 * tx + (m & 7);
+    pre[0][i] = *reinterpret_cast<const h8_t*>(f1 + ((long)min(py, H1 - 1) * W1 + min(px, W1 - 1)) * AM_C + 8 * piece);
+  }
+  for (int t = tid; t < 64 * (AE_XP - 196); t += 256) X[(t / (AE_XP - 196)) * AE_XP + 196 + t % (AE_XP - 196)] = 0;   // pad channels
+  {
+    // wave l prepares level l
+    const int l = wave;
+    const int H2 = H1 >> l, W2 = W1 >> l;
+    const float scale = 1.0f / (float)(1 << l);
+    const float x2 = cf.x * scale, y2 = cf.y * scale;
+    const bool sane = inimg && (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
+    const float fx0 = floorf(x2), fy0 = floorf(y2);
+    const int xb = sane ? (int)fx0 - 3 : -100000, yb = sane ? (int)fy0 - 3 : -100000;
+    sfr[l][lane] = make_float2(sane ? x2 - fx0 : 0.0f, sane ? y2 - fy0 : 0.0f);
+    // window origin as two 16-bit halves; a window that does not touch the image is parked at -20000 (no tap of it is inside)
+    const bool touches = sane && xb > -8 && xb < W2 && yb > -8 && yb < H2;
+    sxy[l][lane] = touches ? ((xb & 0xffff) | (yb << 16)) : (int)0xb1e0b1e0u;
+    int bx0 = touches ? max(xb, 0) : 0x7fffffff, by0 = touches ? max(yb, 0) : 0x7fffffff;
+    int bx1 = touches ? min(xb + 8, W2) : -0x7fffffff, by1 = touches ? min(yb + 8, H2) : -0x7fffffff;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      bx0 = min(bx0, __shfl_xor(bx0, d, 64));
+      by0 = min(by0, __shfl_xor(by0, d, 64));
+      bx1 = max(bx1, __shfl_xor(bx1, d, 64));
+      by1 = max(by1, __shfl_xor(by1, d, 64));
+    }
+    if (lane == 0) {
+      const bool none = bx0 == 0x7fffffff || bx1 <= bx0 || by1 <= by0;
+      lvp[l][0] = none ? 0 : bx0;
+      lvp[l][1] = none ? 0 : by0;
+      lvp[l][2] = none ? 0 : bx1 - bx0;                        // RW
+      lvp[l][3] = none ? 0 : (bx1 - bx0) * (by1 - by0);       // R (0: nothing of this tile looks into the image)
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) *reinterpret_cast<h8_t*>(&stage[(sp + 16 * i) * AS_PITCH + 8 * piece]) = pre[0][i];
+  lds_barrier();
+  h8_t afrag[AM_C / 16];
+#pragma unroll
+  for (int cc = 0; cc < AM_C / 16; cc++)
+    afrag[cc] = *reinterpret_cast<const h8_t*>(&stage[(32 * mt + j) * AS_PITCH + 16 * cc + 8 * kg]);
+  // chunks per level: 0 for an empty level and for a wild one (R > AM_MAXR: wave per pixel, below)
+  int nch[4], nelem = 0;
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+    const int R = lvp[l][3];
+    nch[l] = (R > 0 && R <= AM_MAXR) ? (R + AE_CHUNK - 1) / AE_CHUNK : 0;
+    nelem += nch[l];
+  }
+  auto locate = [&](int k, int& l, int& c) {                   // element k of the stream -> (level, chunk)
+    l = 0;
+    c = k;
+    if (c >= nch[0]) { c -= nch[0]; l = 1;
+      if (c >= nch[1]) { c -= nch[1]; l = 2;
+        if (c >= nch[2]) { c -= nch[2]; l = 3; } } }
+  };
+  auto fetch = [&](h8_t (&pr)[AE_CHUNK / 16], int k) {
+    int l, c;
+    locate(k, l, c);
+    const int H2 = H1 >> l, W2 = W1 >> l;
+    const _Float16* __restrict__ fm = l == 0 ? P.fmap[0] : l == 1 ? P.fmap[1] : l == 2 ? P.fmap[2] : P.fmap[3];
+    const _Float16* __restrict__ f2 = fm + fj * (long)H2 * W2 * AM_C;
+    const int x0 = lvp[l][0], y0 = lvp[l][1], RW = lvp[l][2], R = lvp[l][3];
+    const float inv_rw = 1.0f / (float)RW;
+#pragma unroll
+    for (int i = 0; i < AE_CHUNK / 16; i++) {
+      const int r = min(AE_CHUNK * c + sp + 16 * i, R - 1);          // (columns past the region: clamped, never looked at)
+      const int ry = (int)(((float)r + 0.5f) * inv_rw), rx = r - ry * RW;
+      pr[i] = *reinterpret_cast<const h8_t*>(f2 + ((long)(y0 + ry) * W2 + (x0 + rx)) * AM_C + 8 * piece);
+    }
+  };
+  lds_barrier();                                               // (every wave has its source-pixel fragments: the buffer is free)
+  if (nelem > 0) fetch(pre[0], 0);
+  if (nelem > 1) fetch(pre[1], 1);
+  if (nelem > 2) fetch(pre[2], 2);
+  // ---- the blend of one level: thread (pixel p, quarter q4) -> rows 2 q4, 2 q4 + 1 of the 7 x 7 outputs, rounded to half ----
+  auto blend = [&](int l, bool wild) {
+    const int p = tid >> 2, q4 = tid & 3;
+    const int py = 8 * ty + (p >> 3), px = 8 * tx + (p & 7);
+    uint16_t* __restrict__ Xp = X + p * AE_XP + 49 * l;
+    if (py >= H1 || px >= W1) {                                // padding pixel of the tile
+      for (int ch = q4; ch < 49; ch += 4) Xp[ch] = 0;
+    } else if (wild) {                                         // the wave-per-pixel routine left the 49 finished values
+      for (int ch = q4; ch < 49; ch += 4) Xp[ch] = __builtin_bit_cast(uint16_t, (_Float16)taps[p * AT_TAPP + ch]);
+    } else {
+      const int H2 = H1 >> l, W2 = W1 >> l;
+      const float2 fr = sfr[l][p];
+      const int w = sxy[l][p];
+      const int xb = (int)(short)(w & 0xffff), yb = w >> 16;
+      const float ddx = fr.x, ddy = fr.y;
+      const float w00 = (1.0f - ddy) * (1.0f - ddx), w01 = (1.0f - ddy) * ddx, w10 = ddy * (1.0f - ddx), w11 = ddy * ddx;
+      float T[3][8];                                           // window rows 2 q4 .. 2 q4 + 2, taps outside the image as zeros
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const int wy = 2 * q4 + r;
+        const bool rowok = wy < 8 && (unsigned)(yb + wy) < (unsigned)H2;
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+          const float v = taps[p * AT_TAPP + min(wy, 7) * 8 + x];
+          T[r][x] = (rowok && (unsigned)(xb + x) < (unsigned)W2) ? v : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int r2 = 0; r2 < 2; r2++) {
+        const int oy = 2 * q4 + r2;
+        if (oy >= 7) continue;
+#pragma unroll
+        for (int ox = 0; ox < 7; ox++) {
+          const float v = T[r2][ox] * w00 + T[r2][ox + 1] * w01 + T[r2 + 1][ox] * w10 + T[r2 + 1][ox + 1] * w11;
+          Xp[oy + 7 * ox] = __builtin_bit_cast(uint16_t, (_Float16)v);
+        }
+      }
+    }
+  };
+  // ---- levels without chunks: empty (the blend's masks give zeros) or wild (wave per pixel into the tap table) ----
+#pragma unroll 1
+  for (int l = 0; l < 4; l++) {
+    if (nch[l] > 0) continue;                                  // (uniform)
+    const bool wild = lvp[l][3] > AM_MAXR;
+    if (wild) {
+      const int H2 = H1 >> l, W2 = W1 >> l;
+      const float scale = 1.0f / (float)(1 << l);
+      const _Float16* __restrict__ fm = l == 0 ? P.fmap[0] : l == 1 ? P.fmap[1] : l == 2 ? P.fmap[2] : P.fmap[3];
+      const _Float16* __restrict__ f2 = fm + fj * (long)H2 * W2 * AM_C;
+      for (int k = 0; k < 16; k++) {
+        const int pp = wave * 16 + k;
+        const int qy = 8 * ty + (pp >> 3), qx = 8 * tx + (pp & 7);
+        if (qy >= H1 || qx >= W1) continue;  // wave-uniform
+        const long qpix = (long)qy * W1 + qx;
+        const float2 c = *reinterpret_cast<const float2*>(coords + ((long)e * HW1 + qpix) * 2);
+        altcorr_pixel_h(f1 + qpix * AM_C, f2, H2, W2, c.x * scale, c.y * scale, taps + pp * AT_TAPP, 1, lane);
+      }
+      __syncthreads();
+    }
+    blend(l, wild);
+    __syncthreads();
+  }
+  // ---- the stream of chunks ----
+  s16x2_t wxy[16];
+  auto step = [&](h8_t (&pr)[AE_CHUNK / 16], int k) {
+    int l, c;
+    locate(k, l, c);
+#pragma unroll
+    for (int i = 0; i < AE_CHUNK / 16; i++) *reinterpret_cast<h8_t*>(&stage[(sp + 16 * i) * AS_PITCH + 8 * piece]) = pr[i];
+    if (c == 0) {                                              // (uniform) a new level: window origins of this lane's 16 rows
+#pragma unroll
+      for (int q = 0; q < 16; q++) wxy[q] = __builtin_bit_cast(s16x2_t, sxy[l][32 * mt + 4 * kg + (q & 3) + 8 * (q >> 2)]);
+    }
+    lds_barrier();
+    if (k + AE_DEPTH < nelem) fetch(pr, k + AE_DEPTH);         // (uniform) in flight for the next three steps
+    const int x0 = lvp[l][0], y0 = lvp[l][1], RW = lvp[l][2], R = lvp[l][3];
+    const int col = 32 * ntw;                                  // column tile of this wave inside the chunk
+    if (AE_CHUNK * c + col < R) {                              // (wave-uniform)
+      const int r = AE_CHUNK * c + col + j;                    // region pixel this lane holds as column j of its product
+      f16acc_t acc = (f16acc_t)0.0f;
+      const _Float16* __restrict__ bsrc = &stage[(col + j) * AS_PITCH + 8 * kg];
+#pragma unroll
+      for (int cc = 0; cc < AM_C / 16; cc++)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[cc], *reinterpret_cast<const h8_t*>(bsrc + 16 * cc), acc, 0, 0, 0);
+      if (r < R) {
+        const float inv_rw = 1.0f / (float)RW;
+        const int ry = (int)(((float)r + 0.5f) * inv_rw), rx = r - ry * RW;
+        s16x2_t gxy;
+        gxy[0] = (short)(x0 + rx);
+        gxy[1] = (short)(y0 + ry);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const uint32_t d = __builtin_bit_cast(uint32_t, (s16x2_t)(gxy - wxy[q]));
+          if ((d & 0xfff8fff8u) == 0u) {                       // both offsets from the window origin inside [0, 8)
+            const int m = 32 * mt + 4 * kg + (q & 3) + 8 * (q >> 2);
+            taps[m * AT_TAPP + (d >> 13) + (d & 7u)] = acc[q];
+          }
+        }
+      }
+    }
+    lds_barrier();                                             // (the buffer is free / this chunk's taps are in the table)
+    if (c == nch[l] - 1) {                                     // (uniform) the level is complete
+      blend(l, false);
+      lds_barrier();
+    }
+  };
+  for (int k = 0; k < nelem; k += AE_DEPTH) {
+    step(pre[0], k);
+    if (k + 1 < nelem) step(pre[1], k + 1);
+    if (k + 2 < nelem) step(pre[2], k + 2);
+  }
+  lds_barrier();
+  // ---- out[64 px][128] = relu(X W^T + b): wave (mt, nt0 = wave >> 1) computes the tiles (mt, nt0) and (mt, nt0 + 2) ----
+  const uint16_t* xa = X + (32 * mt + j) * AE_XP + 8 * kg;     // A: row = pixel 32 mt + j, k = channel 16 c + 8 kg + q
+  h8_t a[13];
+#pragma unroll
+  for (int c = 0; c < 13; c++) a[c] = *reinterpret_cast<const h8_t*>(xa + 16 * c);
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int nt = ntw + 2 * u;
+    f16acc_t acc = (f16acc_t)0.0f;
+#pragma unroll
+    for (int c = 0; c < 13; c++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[c], wfrag[(nt * 13 + c) * 64 + lane], acc, 0, 0, 0);
+    const float bj = bias[32 * nt + j];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = 32 * mt + 4 * kg + (r & 3) + 8 * (r >> 2);
+      const int py = 8 * ty + (m >> 3), px = 8 * tx + (m & 7);
+      if (py < H1 && px < W1) out[((long)e * HW1 + (long)py * W1 + px) * 128 + 32 * nt + j] = (_Float16)fmaxf(acc[r] + bj, 0.0f);
+    }
+  }
+}
+
 extern "C" int ns_altcorr_pyramid_encode_f16(const void* const* fmaps_host, const int64_t* ii, const int64_t* jj, const float* coords,
                                              const void* wfrag, const float* bias, void* out, int E, int H1, int W1, int C,
                                              void* stream) {
@@ -923,9 +1177,17 @@ extern "C" int ns_altcorr_pyramid_encode_f16(const void* const* fmaps_host, cons
     NS_REQUIRE(P.fmap[l] != nullptr && ((uintptr_t)P.fmap[l] % 16) == 0, "ns_altcorr_pyramid_encode_f16: fmaps[%d] null or not 16-byte aligned", l);
   }
   dim3 grid(((H1 + 7) / 8) * ((W1 + 7) / 8), E);
-  hipLaunchKernelGGL(altcorr_tile_enc_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, (const h8_t*)wfrag, bias,
-                     (_Float16*)out, E, H1, W1);
-  NS_CHECK_LAUNCH("altcorr_tile_enc_kernel");
+  static const bool direct = getenv("NS_ALTCORR_DIRECT") != nullptr;   // A/B switch: fragments straight from global memory
+  static const bool no_xcd = getenv("NS_ALTCORR_NO_XCD") != nullptr;   // A/B switch: linear tile order
+  if (direct) {
+    hipLaunchKernelGGL(altcorr_tile_enc_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, (const h8_t*)wfrag, bias,
+                       (_Float16*)out, E, H1, W1);
+    NS_CHECK_LAUNCH("altcorr_tile_enc_kernel");
+  } else {
+    hipLaunchKernelGGL(altcorr_tile_enc_lds_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, (const h8_t*)wfrag,
+                       bias, (_Float16*)out, E, H1, W1, no_xcd ? 0 : 1);
+    NS_CHECK_LAUNCH("altcorr_tile_enc_lds_kernel");
+  }
   return NS_OK;
 }
 
