@@ -424,14 +424,27 @@ def run_microbench(dev, name, reps):
         ii = torch.arange(0, E, device=dev) % NB
         jj = (ii + 1) % NB
         gy, gx = torch.meshgrid(torch.arange(ht, device=dev), torch.arange(wd, device=dev), indexing="ij")
-        coords = (torch.stack([gx, gy], -1).float()[None] + 3.0 * torch.randn((E, ht, wd, 2), device=dev, generator=g))[None].contiguous()
-        fn = lambda: alt(coords, ii, jj)
+        grid = torch.stack([gx, gy], -1).float()[None]
+        HWp = ht * wd
+        maps = HWp * 128 * 2 * (1 + 1 + 0.25 + 0.0625 + 0.015625)
+        if name == "altcorr":                # (rounds 3-4: 3 px of independent noise per pixel -- regions of 500-900 pixels)
+            coords = (grid + 3.0 * torch.randn((E, ht, wd, 2), device=dev, generator=g))[None].contiguous()
+        else:                                # a rigid scene's flow: shift + 2 % zoom + 0.3 px of noise (regions of ~18 x 18)
+            shift = 6.0 * torch.randn((E, 1, 1, 2), device=dev, generator=g)
+            coords = (grid + shift + 0.02 * (grid - grid.mean((1, 2), keepdim=True))
+                      + 0.3 * torch.randn((E, ht, wd, 2), device=dev, generator=g))[None].contiguous()
+        if name == "altcorr_enc":            # + the correlation encoder's 1x1 convolution (what the global BA launches)
+            from nerfslam.update_op import CorrEncoderWeights
+            enc = CorrEncoderWeights(torch.randn((128, 196, 1, 1), device=dev, generator=g) / 14.0, 0.1 * torch.randn(128, device=dev, generator=g))
+            fn = lambda: alt.encoded(coords, ii, jj, enc)
+            label, alg = "altcorr_tile_enc_lds_kernel[E=48, 160x90]", E * (maps + HWp * 128 * 2 + HWp * 8)
+        else:
+            fn = lambda: alt(coords, ii, jj)
+            label = "altcorr_tile_mfma_kernel[E=48, 160x90]" if name == "altcorr" else "altcorr_tile_mfma_lds_kernel[E=48, 160x90, smooth flow]"
+            alg = E * (maps + 196 * HWp * 4 + HWp * 8)
         fn(); torch.cuda.synchronize()
         us = _train_us(fn, reps)
-        HWp = ht * wd
-        alg = E * (HWp * 128 * 2 * (1 + 1 + 0.25 + 0.0625 + 0.015625) + 196 * HWp * 4 + HWp * 8)
-        print(json.dumps({"microbench": "altcorr_tile_mfma_kernel[E=48, 160x90]", "reps": reps, "avg_launch_us": us,
-                          "algorithmic_per_launch": alg, "bound": "hbm"}))
+        print(json.dumps({"microbench": label, "reps": reps, "avg_launch_us": us, "algorithmic_per_launch": alg, "bound": "hbm"}))
         return
     from hot_path_chain import HotPath
     hp = HotPath(dev, seed=0)

@@ -547,6 +547,8 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_kernel(AltPyramidH P, c
 // 128-pixel chunks of the region (a smooth flow's whole 15 x 15 .. 16 x 16 region) leave together into two register sets; the
 // blend weights wait in LDS.  (3) The barriers wait for LDS only (s_waitcnt lgkmcnt(0) + s_barrier), so loads stay in flight
 // across them.  Same sums in the same order as the kernel above (k = channels 0..127 in chunks of 16): bit-identical output.
+// Measured: 1.05 -> 0.49 ms per 48-edge launch on the global BA's own flow (0.24 of the HBM roof in algorithmic bytes; 4.6 GB
+// through the L1s at ~10 TB/s), 1.37 -> 0.71 ms on 3 px of independent noise per pixel (regions of 500-900 pixels).
 // ---------------------------------------------------------------------------------------------
 #define AS_PITCH 136   // halves per staged pixel (272 bytes)
 #define AS_CHUNK 128   // region pixels per chunk
@@ -912,7 +914,11 @@ __global__ __launch_bounds__(256) void altcorr_tile_enc_kernel(AltPyramidH P, co
 // to itself): after the first round trip (flow + source vectors; wave l prepares level l: window origins, blend weights,
 // bounding box by butterfly) the matrix cores never wait for a whole round trip again.  The tap table is not zero-filled:
 // the blend masks taps outside the image by their coordinates (same values: a zero tap contributes a zero term).  Encoder
-// input tile as [pixel][216 halves] so that its fragments are 16-byte LDS reads.  70 KB of LDS per workgroup.
+// input tile as [pixel][216 halves] so that its fragments are 16-byte LDS reads.  65 KB of LDS per workgroup.
+// Measured (48 edges, 160 x 90, a rigid scene's flow): 1.36 ms -> 0.63-0.65 ms per launch, the global BA's correlation leg
+// 112 -> 51 ms per pass.  Stage by stage: prologue alone 0.04 ms; the stream without products 0.45 (3.9 GB through the L1s at
+// ~10 TB/s: three chunks in flight cover a third of the ~2.5 us a load takes at that rate -- the L2 -> L1 fabric, not HBM, is
+// the roof of this kernel, and only larger tiles would move fewer bytes); products + 0.2, blends + 0.11, encoder + 0.1.
 // ---------------------------------------------------------------------------------------------
 #define AE_XP 216      // halves per pixel of the encoder's input tile (208 channels + 8: 27 sixteen-byte slots)
 #define AE_CHUNK 64
