@@ -427,7 +427,7 @@ def run_microbench(dev, name, reps):
         grid = torch.stack([gx, gy], -1).float()[None]
         HWp = ht * wd
         maps = HWp * 128 * 2 * (1 + 1 + 0.25 + 0.0625 + 0.015625)
-        if name == "altcorr":                # (rounds 3-4: 3 px of independent noise per pixel -- regions of 500-900 pixels)
+        if name == "altcorr_noise":          # (rounds 3-4: 3 px of independent noise per pixel -- regions of 500-900 pixels)
             coords = (grid + 3.0 * torch.randn((E, ht, wd, 2), device=dev, generator=g))[None].contiguous()
         else:                                # a rigid scene's flow: shift + 2 % zoom + 0.3 px of noise (regions of ~18 x 18)
             shift = 6.0 * torch.randn((E, 1, 1, 2), device=dev, generator=g)
@@ -440,7 +440,8 @@ def run_microbench(dev, name, reps):
             label, alg = "altcorr_tile_enc_lds_kernel[E=48, 160x90]", E * (maps + HWp * 128 * 2 + HWp * 8)
         else:
             fn = lambda: alt(coords, ii, jj)
-            label = "altcorr_tile_mfma_kernel[E=48, 160x90]" if name == "altcorr" else "altcorr_tile_mfma_lds_kernel[E=48, 160x90, smooth flow]"
+            label = "altcorr_tile_mfma_lds_kernel[E=48, 160x90]" + (", 3 px noise]" if name == "altcorr_noise" else "")
+            label = label.replace("], 3 px", ", 3 px")
             alg = E * (maps + 196 * HWp * 4 + HWp * 8)
         fn(); torch.cuda.synchronize()
         us = _train_us(fn, reps)
@@ -613,6 +614,13 @@ def bench_c1280(args, dev, rank=0, world=1, backend="nccl"):
     coords = fe.reproject(ii, jj)[None]
     us = _train_us(lambda: alt(coords, ii, jj), 5)
     HWp = fe.ht * fe.wd
+    fused = None
+    enc_w = getattr(getattr(nets, "corr_encoder", None), "frags", None)
+    if enc_w is not None:     # what the pass itself launches: correlation + the encoder's first convolution, [E,H,W,128] f16 out
+        us_f = _train_us(lambda: alt.encoded(coords, ii, jj, nets.corr_encoder), 5)
+        alg_f = E * (HWp * 128 * 2 * (1 + 1 + 0.25 + 0.0625 + 0.015625) + 128 * HWp * 2 + HWp * 8)
+        fused = {"kernel": "altcorr_tile_enc_lds_kernel[E=48, 160x90]", "avg_launch_us": us_f, "algorithmic_bytes_per_launch": alg_f,
+                 "frac": alg_f / us_f / 1e3 / HBM_PEAK_GBS}
     alg = E * (HWp * 128 * 2 * (1 + 1 + 0.25 + 0.0625 + 0.015625) + 196 * HWp * 4 + HWp * 8)     # f16 feature maps, f32 output
     out = {
         "metric": "frames/s tracked+mapped on Replica office0 640x480; PSNR + ATE-RMSE vs ref",
@@ -631,12 +639,14 @@ def bench_c1280(args, dev, rank=0, world=1, backend="nccl"):
                                       world, backend, [s_[2] for s_ in sums]),
                    "state_checksums": {"poses": pose_sum, "inverse_depths": depth_sum,
                                        "per_rank": None if world == 1 else [list(s_[:2]) for s_ in sums]}},
-        "roofline": {"bound": "hbm", "kernel": "altcorr_tile_mfma_kernel[E=48, 160x90]", "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "altcorr_tile_mfma_lds_kernel[E=48, 160x90]", "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": us,
                      "algorithmic_bytes_per_launch": alg,
                      "note": "per edge: both feature maps (f16, channels-last, pyramid of the target) read once + 196 f32 output planes "
-                             "(which are 96 % of the bytes); round 2's f32 FMA tile kernel ran this launch in 2.0 ms (0.085 of the "
-                             "HBM peak on twice the input bytes), the matrix-core kernel computes the dense tile x region product"},
+                             "(which are 96 % of the bytes), on the flow of the buffer's own edges; round 2's f32 FMA tile kernel ran "
+                             "this launch in 2.0 ms, round 3's matrix-core kernel with fragments straight from global memory in 1.05 ms, "
+                             "the LDS-staged one (round 4) computes the same dense tile x region product",
+                     "fused_with_encoder": fused},
         "cpu_baseline": cpu_base,
         "breakdown": breakdown,
     }
@@ -644,7 +654,7 @@ def bench_c1280(args, dev, rank=0, world=1, backend="nccl"):
         tf = os.path.join(ROOT, "profiles", "r04_traffic.json")
         if os.path.exists(tf):
             tr = json.load(open(tf))
-            e = tr.get("altcorr_tile_mfma_kernel[E=48, 160x90]")
+            e = tr.get("altcorr_tile_mfma_lds_kernel[E=48, 160x90]")
             if e:
                 r = out["roofline"]
                 r["traffic"] = e.get("traffic_bytes")

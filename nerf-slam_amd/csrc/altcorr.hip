@@ -554,8 +554,7 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_kernel(AltPyramidH P, c
 #define AS_CHUNK 128   // region pixels per chunk
 typedef short s16x2_t __attribute__((ext_vector_type(2)));
 
-// workgroup barrier that orders LDS traffic only: global loads issued before it may still be in flight behind it
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (lds_barrier(): common.h)
 
 __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH P, const int64_t* __restrict__ ii,
                                                                     const int64_t* __restrict__ jj,

@@ -32,6 +32,15 @@ void ns_set_error(const char* fmt, ...);
 static inline int ns_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which the compiler
+// implements as s_waitcnt vmcnt(0) lgkmcnt(0): every global load AND every global store of the wave has to be acknowledged
+// before the barrier -- a full memory round trip (~2-3 us on a busy chip) wherever a kernel has loads in flight for later use
+// or has just stored results nobody in the workgroup reads.  Use this where the two sides of the barrier communicate through
+// LDS alone; global loads issued before it stay in flight behind it (the compiler still waits for each where it is used).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---------------------------------------------------------------------------------------------
 // wave64 reductions on the VALU: six DPP-modified adds (quad swaps, half-row / row mirrors, then
 // the row broadcasts), no LDS crossbar traffic and no waitcnt per step -- `__shfl_xor` lowers to
 // ds_bpermute_b32 on gfx950, whose ~100-cycle latency per step made the 27- and 42-value epilogues

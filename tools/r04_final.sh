@@ -11,8 +11,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $o/bprof -o b -- python b
 cp $o/bprof/b_kernel_stats.csv $o/bench_kernel_stats.csv 2>/dev/null
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $o/ngp -o ngp -- env NS_NGP_EXTRINSICS=1 python tools/ngp_bench.py 160 320 > $o/ngp.log 2>&1; grep steps/s $o/ngp.log
 cp $o/ngp/ngp_kernel_stats.csv $o/ngp_kernel_stats.csv 2>/dev/null
-for name in ngp_bwd ngp_fwd mlp_fwd mlp_bwd mlp_wgrad lookup lookup_enc volume conv altcorr; do
-  case $name in ngp_bwd) mb="ngp_encode_bwd";; ngp_fwd) mb="ngp_encode_fwd";; mlp_fwd) mb="ngp_mlp_fwd";; mlp_bwd) mb="ngp_mlp_bwd";; mlp_wgrad) mb="ngp_mlp_wgrad";; lookup) mb="corr_lookup_coop";; lookup_enc) mb="corr_lookup_enc";; volume) mb="corr_volume";; conv) mb="conv_nhwc";; altcorr) mb="altcorr";; esac
+for name in ngp_bwd ngp_fwd mlp_fwd mlp_bwd mlp_wgrad lookup lookup_enc volume conv altcorr altcorr_enc; do
+  case $name in ngp_bwd) mb="ngp_encode_bwd";; ngp_fwd) mb="ngp_encode_fwd";; mlp_fwd) mb="ngp_mlp_fwd";; mlp_bwd) mb="ngp_mlp_bwd";; mlp_wgrad) mb="ngp_mlp_wgrad";; lookup) mb="corr_lookup_coop";; lookup_enc) mb="corr_lookup_enc";; volume) mb="corr_volume";; conv) mb="conv_nhwc";; altcorr) mb="altcorr";; altcorr_enc) mb="altcorr_enc";; esac
   d=$o/pmc/$name; mkdir -p $d
   timeout 200 rocprofv3 --kernel-trace -f csv -d $d/trace -o t -- python bench.py --microbench $mb --reps $REPS > $d/trace.log 2>&1
   timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $d/fetch -o f -- python bench.py --microbench $mb --reps $REPS > $d/fetch.log 2>&1

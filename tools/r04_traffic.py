@@ -29,7 +29,8 @@ ENTRIES = {
     "corr_lookup_enc_kernel[E=48]": ("lookup_enc", ["corr_lookup_enc_kernel"]),
     "corr_volume_tiled_kernel[E=10]": ("volume", ["corr_volume_tiled_kernel"]),
     "conv_nhwc_kernel<3x3,448->256>[E=48]": ("conv", ["conv_nhwc_kernel<3, 4, 4, 2>"]),
-    "altcorr_tile_mfma_kernel[E=48, 160x90]": ("altcorr", ["altcorr_tile_mfma"]),
+    "altcorr_tile_mfma_lds_kernel[E=48, 160x90]": ("altcorr", ["altcorr_tile_mfma"]),
+    "altcorr_tile_enc_lds_kernel[E=48, 160x90]": ("altcorr_enc", ["altcorr_tile_enc"]),
 }
 
 
