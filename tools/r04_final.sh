@@ -6,11 +6,10 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out/r04final; mkdir -p $o
 REPS=20
-timeout 600 python bench.py --steps 20 --warmup 5 > $o/bench.json 2> $o/bench.err; tail -c 300 $o/bench.err
+# (1) the kernel table of the product pipeline, (2) the counter passes, (3) traffic.json from both -- into profiles/ of THIS copy
+#     of the tree, so that (4) the bench line that follows carries the traffic of the library it runs (`traffic_stale` false)
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $o/bprof -o b -- python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $o/bench_under_rocprof.json 2> /dev/null
 cp $o/bprof/b_kernel_stats.csv $o/bench_kernel_stats.csv 2>/dev/null
-timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $o/ngp -o ngp -- env NS_NGP_EXTRINSICS=1 python tools/ngp_bench.py 160 320 > $o/ngp.log 2>&1; grep steps/s $o/ngp.log
-cp $o/ngp/ngp_kernel_stats.csv $o/ngp_kernel_stats.csv 2>/dev/null
 for name in ngp_bwd ngp_fwd mlp_fwd mlp_bwd mlp_wgrad lookup lookup_enc volume conv altcorr altcorr_enc; do
   case $name in ngp_bwd) mb="ngp_encode_bwd";; ngp_fwd) mb="ngp_encode_fwd";; mlp_fwd) mb="ngp_mlp_fwd";; mlp_bwd) mb="ngp_mlp_bwd";; mlp_wgrad) mb="ngp_mlp_wgrad";; lookup) mb="corr_lookup_coop";; lookup_enc) mb="corr_lookup_enc";; volume) mb="corr_volume";; conv) mb="conv_nhwc";; altcorr) mb="altcorr";; altcorr_enc) mb="altcorr_enc";; esac
   d=$o/pmc/$name; mkdir -p $d
@@ -21,6 +20,10 @@ for name in ngp_bwd ngp_fwd mlp_fwd mlp_bwd mlp_wgrad lookup lookup_enc volume c
   grep '^{' $d/trace.log | tail -1
 done
 python tools/r04_traffic.py $o/pmc $o/bench_kernel_stats.csv $REPS $o/traffic.json
+cp $o/traffic.json profiles/r04_traffic.json
+timeout 600 python bench.py --steps 20 --warmup 5 > $o/bench.json 2> $o/bench.err; tail -c 300 $o/bench.err
+timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $o/ngp -o ngp -- env NS_NGP_EXTRINSICS=1 python tools/ngp_bench.py 160 320 > $o/ngp.log 2>&1; grep steps/s $o/ngp.log
+cp $o/ngp/ngp_kernel_stats.csv $o/ngp_kernel_stats.csv 2>/dev/null
 # config #5
 timeout 400 python bench.py --config c1280 --steps 2 --warmup 1 > $o/bench_c1280.json 2> $o/bench_c1280.err
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $o/c1280 -o c -- python bench.py --config c1280 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
