@@ -347,7 +347,7 @@ def micro_benches(dev, hp, ngp_net):
     out["ngp_mlp_bwd_kernel[step samples]"] = dict(fn=mlp_bwd, bound="mfma", per_launch=20480.0 * n, samples=n, in_step=["ngp_mlp_bwd_kernel"],
                                                    note=where + "; activation gradients from the ReLU bit masks, dL/dfeature only")
     out["ngp_mlp_wgrad_tr_kernel[step samples]"] = dict(
-        fn=mlp_wgrad, bound="mfma", per_launch=20480.0 * n, samples=n, in_step=["ngp_mlp_wgrad_tr_kernel + ngp_mlp_wgrad_reduce_kernel"],
+        fn=mlp_wgrad, bound="mfma", per_launch=20480.0 * n, samples=n, in_step=["ngp_mlp_wgrad_tr_kernel", "ngp_mlp_step_kernel"],
         executed_flop_per_launch=90 * 2.0 * 32 * 32 * 16 * ((n + 31) // 32),
         note=where + "; algorithmic = the weight-gradient contraction alone (10240 multiply-adds per sample); the kernel EXECUTES 90 "
         "32x32x16 MFMAs per 32 samples (forward and backward chains recomputed, 30 of them are the turn-arounds through the matrix "

@@ -611,6 +611,20 @@ int ns_ngp_mlp_dgrad_f_n(const void* frags, const void* dLdout, const void* relu
 int ns_ngp_mlp_pack_fragments(const void* weights, void* frags, void* stream);
 int ns_ngp_mlp_wgrad_recompute_n(const void* frags, const void* featT, const float* dirs, const void* dLdout, float* partial_ws,
                                  int wgs, float* grad_weights, long N, const int* n_dev, void* stream);
+/* The same in pieces (round 4; the optimiser of the MLP has no counterpart file in the reference: tiny-cuda-nn's Adam inside
+ * the instant-ngp fork, [EXTERNAL]): ns_ngp_mlp_wgrad_partials_n is the weight-gradient launch alone -- it leaves
+ * ns_ngp_mlp_wgrad_slabs(wgs, N) slabs of 10240 floats in partial_ws; ns_ngp_mlp_reduce adds them to grad_weights (replicated
+ * trainers: the all-reduce follows); ns_ngp_mlp_step_fused is the MLP's whole optimiser step in ONE launch: slab reduce (same
+ * order, same bits) + Adam (grad_weights is added in and cleared; bias corrections of `step`, or of ctl when given) + the f16
+ * copy + both fragment tables updated in place (frags must have been packed once by ns_ngp_mlp_pack_fragments: the zero rows
+ * of the tables are not rewritten).  Bit-identical to ns_ngp_mlp_reduce + ns_ngp_adam_ctl + ns_ngp_mlp_pack_fragments.          */
+int ns_ngp_mlp_wgrad_slabs(int wgs, long N);
+int ns_ngp_mlp_wgrad_partials_n(const void* frags, const void* featT, const float* dirs, const void* dLdout, float* partial_ws,
+                                int wgs, long N, const int* n_dev, void* stream);
+int ns_ngp_mlp_reduce(const float* partial_ws, int slabs, float* grad_weights, void* stream);
+int ns_ngp_mlp_step_fused(const float* partial_ws, int slabs, float* grad_weights, float* master, void* half_params, float* m1,
+                          float* m2, void* frags, int step, float lr, float beta1, float beta2, float eps, float l2,
+                          float grad_scale, const int* ctl, void* stream);
 /* the two halves of ns_ngp_mlp_backward_n: activation gradients (writes dLdfeatT and the d*T buffers), then the weight
  * gradients (reads them).  Separate entries so that the caller can put the second half on another stream, next to the
  * hash-grid backward that consumes dLdfeatT (nerfslam/ngp.py).                                                       */

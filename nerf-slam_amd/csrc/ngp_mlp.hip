@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include "ngp_mlp_common.h"
+#include "ngp_adam.h"
 // store the 16 (tile 0, tile 1) pairs of one 32-unit tile unit-major: row acc_unit(it, h, r), samples np, np + 1
 __device__ __forceinline__ void store_tile(_Float16* __restrict__ dst, long N, uint32_t boff, int it, const f16x8* t0,
                                            const f16x8* t1) {  // t0/t1: chunks [2 it], [2 it + 1] of tile 0 / 1
@@ -1017,32 +1018,169 @@ extern "C" int ns_ngp_mlp_pack_fragments(const void* weights, void* frags, void*
 
 // weight gradients alone, forward and backward chains recomputed on chip from the features and the loss gradient: ADDS to
 // grad_weights; partial_ws: wgs * 10240 floats
+// ---------------------------------------------------------------------------------------------
+// The MLP's optimiser step in ONE launch (round 4): slab reduce + Adam + fragment tables.  The side stream of the training step
+// ran  weight gradients -> ngp_mlp_wgrad_reduce_kernel -> ngp_adam_kernel -> ngp_mlp_pack_frags_kernel : three launches of
+// microseconds of work each (11 + 13 + 21 us inside the pipeline, most of it waiting for a slot) at the tail of a chain that must
+// end before the next step's forward pass.  Every output depends on ONE weight: a lane owns weight i, adds its slabs in the order
+// of the reduce kernel (16 interleaved partial sums, then their sum: the same bits), applies adam_apply() (the one definition,
+// ngp_adam.h), writes the f32 master and the f16 copy, and drops the f16 value into its two places in the fragment tables --
+// forward table: A = W [nout][nin], transposed table: A = W^T -- by inverting fill_frags():
+//   element (row, k) of A lives in fragment (row / 32) nchunk + k / 16, lane (row % 32) + 32 h, element q,
+//   with k % 16 = 4 h + (q & 3) + 8 (q >> 2)   <=>   h = bit 2 of k, q = (k & 3) | (bit 3 of k) << 2.
+// Rows of a fragment beyond a layer's size are zeros written once by ngp_mlp_pack_frags_kernel and never touched here.
+// ---------------------------------------------------------------------------------------------
+struct MlpStepArgs {
+  const float* partial;   // [slabs][W_TOTAL]
+  int slabs;
+  float *grad, *master, *m1, *m2;
+  _Float16 *hp, *frags;   // f16 weights; fragment tables [FW_NFRAG + BW_NFRAG][64][8]
+  float c1, c2, lr, beta1, beta2, eps, l2, inv_grad_scale;
+  const int* ctl;
+};
+
+__device__ __forceinline__ void frag_place(_Float16* frags, int first, int nchunk, int row, int k, _Float16 v) {
+  const int f = first + (row >> 5) * nchunk + (k >> 4);
+  const int h = (k >> 2) & 1, q = (k & 3) | ((k >> 3) & 1) << 2;
+  frags[((long)f * 64 + (row & 31) + 32 * h) * 8 + q] = v;
+}
+
+__global__ __launch_bounds__(256) void ngp_mlp_step_kernel(MlpStepArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W_TOTAL) return;
+  // ---- the slabs, in ngp_mlp_wgrad_reduce_kernel's order ----
+  float t = 0.0f;
+  for (int grp = 0; grp < 16; grp++) {
+    float s = 0.0f;
+    for (int k0 = grp; k0 < a.slabs; k0 += 16 * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int k = k0 + 16 * u;
+        v[u] = k < a.slabs ? a.partial[(long)k * W_TOTAL + i] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++) s += v[u];
+    }
+    t += s;
+  }
+  // ---- Adam, as ngp_adam_kernel ----
+  const float c1 = a.ctl ? __int_as_float(a.ctl[NS_CTL_C1]) : a.c1, c2 = a.ctl ? __int_as_float(a.ctl[NS_CTL_C2]) : a.c2;
+  const float g = (a.grad[i] + t) * a.inv_grad_scale;
+  a.grad[i] = 0.0f;
+  float p = a.master[i];
+  if (!(g == 0.0f && a.l2 == 0.0f)) {
+    float m1 = a.m1[i], m2 = a.m2[i];
+    p = adam_apply(p, g, a.l2, m1, m2, c1, c2, a.lr, a.beta1, a.beta2, a.eps);
+    a.m1[i] = m1;
+    a.m2[i] = m2;
+    a.master[i] = p;
+  }
+  const _Float16 hv = (_Float16)p;
+  a.hp[i] = hv;
+  // ---- the weight's two places in the fragment tables ----
+  int off, nin, fw, bw, nout;
+  if (i < W2_OFF)      { off = W1_OFF; nout = 64; nin = 32; fw = FW_L1; bw = BW_L1; }
+  else if (i < W3_OFF) { off = W2_OFF; nout = 16; nin = 64; fw = FW_L2; bw = BW_L2; }
+  else if (i < W4_OFF) { off = W3_OFF; nout = 64; nin = 32; fw = FW_L3; bw = BW_L3; }
+  else if (i < W5_OFF) { off = W4_OFF; nout = 64; nin = 64; fw = FW_L4; bw = BW_L4; }
+  else                 { off = W5_OFF; nout = 16; nin = 64; fw = FW_L5; bw = BW_L5; }
+  const int o = (i - off) / nin, k = (i - off) - o * nin;
+  frag_place(a.frags, fw, nin / 16, o, k, hv);                              // A = W:   row o, column k
+  frag_place(a.frags + (long)FW_NFRAG * 64 * 8, bw, nout / 16, k, o, hv);   // A = W^T: row k, column o
+}
+
+// slabs the weight-gradient launch of ns_ngp_mlp_wgrad_recompute_n / _partials_n fills for a workspace of `wgs` slabs
+static int wgrad_slabs(int wgs, long N, bool& staged) {
+  static const bool st = [] { const char* e = getenv("NS_NGP_WGRAD"); return e != nullptr && e[0] == 's'; }();
+  staged = st;
+  if (st) return wgs;
+  static const int cus = [] { const char* e = getenv("NS_NGP_WGRAD_WGS"); return e ? atoi(e) : 64; }();
+  const long tiles4 = (N / 32 + 3) / 4;
+  return (int)std::max(1L, std::min((long)std::min(wgs, cus), tiles4));
+}
+
+extern "C" int ns_ngp_mlp_wgrad_slabs(int wgs, long N) {
+  bool staged;
+  return wgrad_slabs(wgs, N, staged);
+}
+
+static int wgrad_partials_launch(const void* frags, const void* featT, const float* dirs, const void* dLdout, float* partial_ws,
+                                 int wgs, long N, const int* n_dev, void* stream, int& slabs) {
+  MlpWgradArgs a{(const f16x8*)frags, (const _Float16*)featT, dirs, (const _Float16*)dLdout, partial_ws, N, n_dev};
+  bool staged;
+  slabs = wgrad_slabs(wgs, N, staged);
+  if (staged) {
+    hipLaunchKernelGGL(ngp_mlp_wgrad_recompute_kernel, dim3(slabs), dim3(128), 0, (hipStream_t)stream, a);
+    NS_CHECK_LAUNCH("ngp_mlp_wgrad_recompute_kernel");
+    return NS_OK;
+  }
+  // 4-wave workgroups, every wave holding all twelve accumulator tiles: a workgroup takes a whole CU's registers.  64 of them
+  // (a quarter of the chip for ~4 x as long, still well inside the step) instead of one per CU: in the step this kernel runs
+  // next to the table gradient's scatter, which then keeps 192 CUs to itself -- stand-alone step unchanged (0.275 ms), pipeline
+  // 129-131 -> 134-137 frames/s (32: 133, 96: 136, 128: 131).  NS_NGP_WGRAD_WGS overrides.
+  NS_REQUIRE(((uintptr_t)featT % 8) == 0 && ((uintptr_t)dLdout % 8) == 0 && ((uintptr_t)partial_ws % 16) == 0,
+             "ns_ngp_mlp_wgrad_recompute: featT / dLdout must be 8-byte, partial_ws 16-byte aligned");
+  return ngp_mlp_wgrad_tr_launch(a, slabs, (hipStream_t)stream);
+}
+
 extern "C" int ns_ngp_mlp_wgrad_recompute_n(const void* frags, const void* featT, const float* dirs, const void* dLdout,
                                             float* partial_ws, int wgs, float* grad_weights, long N, const int* n_dev,
                                             void* stream) {
   NS_REQUIRE(frags && featT && dirs && dLdout && partial_ws && grad_weights, "ns_ngp_mlp_wgrad_recompute: null pointer");
   NS_REQUIRE(wgs >= 1 && wgs <= 65535 && N % 8 == 0, "ns_ngp_mlp_wgrad_recompute: 1 <= wgs <= 65535 and N a multiple of 8 are required");
   if (N <= 0) return NS_OK;
-  MlpWgradArgs a{(const f16x8*)frags, (const _Float16*)featT, dirs, (const _Float16*)dLdout, partial_ws, N, n_dev};
-  static const bool staged = [] { const char* e = getenv("NS_NGP_WGRAD"); return e != nullptr && e[0] == 's'; }();
-  if (staged) {
-    hipLaunchKernelGGL(ngp_mlp_wgrad_recompute_kernel, dim3(wgs), dim3(128), 0, (hipStream_t)stream, a);
-    NS_CHECK_LAUNCH("ngp_mlp_wgrad_recompute_kernel");
-  } else {
-    // 4-wave workgroups, every wave holding all twelve accumulator tiles: a workgroup takes a whole CU's registers.  64 of them
-    // (a quarter of the chip for ~4 x as long, still well inside the step) instead of one per CU: in the step this kernel runs
-    // next to the table gradient's scatter, which then keeps 192 CUs to itself -- stand-alone step unchanged (0.275 ms), pipeline
-    // 129-131 -> 134-137 frames/s (32: 133, 96: 136, 128: 131).  NS_NGP_WGRAD_WGS overrides.
-    static const int cus = [] { const char* e = getenv("NS_NGP_WGRAD_WGS"); return e ? atoi(e) : 64; }();
-    const long tiles4 = (N / 32 + 3) / 4;
-    wgs = (int)std::max(1L, std::min((long)std::min(wgs, cus), tiles4));
-    NS_REQUIRE(((uintptr_t)featT % 8) == 0 && ((uintptr_t)dLdout % 8) == 0 && ((uintptr_t)partial_ws % 16) == 0,
-               "ns_ngp_mlp_wgrad_recompute: featT / dLdout must be 8-byte, partial_ws 16-byte aligned");
-    const int rc = ngp_mlp_wgrad_tr_launch(a, wgs, (hipStream_t)stream);
-    if (rc != NS_OK) return rc;
-  }
-  hipLaunchKernelGGL(ngp_mlp_wgrad_reduce_kernel, dim3(W_TOTAL / 16), dim3(256), 0, (hipStream_t)stream, partial_ws, wgs, grad_weights);
+  int slabs = 0;
+  const int rc = wgrad_partials_launch(frags, featT, dirs, dLdout, partial_ws, wgs, N, n_dev, stream, slabs);
+  if (rc != NS_OK) return rc;
+  hipLaunchKernelGGL(ngp_mlp_wgrad_reduce_kernel, dim3(W_TOTAL / 16), dim3(256), 0, (hipStream_t)stream, partial_ws, slabs, grad_weights);
   NS_CHECK_LAUNCH("ngp_mlp_wgrad_reduce_kernel");
+  return NS_OK;
+}
+
+// the weight-gradient launch alone: ns_ngp_mlp_wgrad_slabs(wgs, N) slabs of partial_ws are left for ns_ngp_mlp_reduce /
+// ns_ngp_mlp_step_fused
+extern "C" int ns_ngp_mlp_wgrad_partials_n(const void* frags, const void* featT, const float* dirs, const void* dLdout,
+                                           float* partial_ws, int wgs, long N, const int* n_dev, void* stream) {
+  NS_REQUIRE(frags && featT && dirs && dLdout && partial_ws, "ns_ngp_mlp_wgrad_partials: null pointer");
+  NS_REQUIRE(wgs >= 1 && wgs <= 65535 && N % 8 == 0, "ns_ngp_mlp_wgrad_partials: 1 <= wgs <= 65535 and N a multiple of 8 are required");
+  if (N <= 0) return NS_OK;
+  int slabs = 0;
+  return wgrad_partials_launch(frags, featT, dirs, dLdout, partial_ws, wgs, N, n_dev, stream, slabs);
+}
+
+extern "C" int ns_ngp_mlp_reduce(const float* partial_ws, int slabs, float* grad_weights, void* stream) {
+  NS_REQUIRE(partial_ws && grad_weights && slabs >= 1, "ns_ngp_mlp_reduce: null pointer or no slabs");
+  hipLaunchKernelGGL(ngp_mlp_wgrad_reduce_kernel, dim3(W_TOTAL / 16), dim3(256), 0, (hipStream_t)stream, partial_ws, slabs, grad_weights);
+  NS_CHECK_LAUNCH("ngp_mlp_wgrad_reduce_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_ngp_mlp_step_fused(const float* partial_ws, int slabs, float* grad_weights, float* master, void* half_params,
+                                     float* m1, float* m2, void* frags, int step, float lr, float beta1, float beta2, float eps,
+                                     float l2, float grad_scale, const int* ctl, void* stream) {
+  NS_REQUIRE(partial_ws && grad_weights && master && half_params && m1 && m2 && frags, "ns_ngp_mlp_step_fused: null pointer");
+  NS_REQUIRE(slabs >= 1 && (ctl || step >= 1) && grad_scale > 0.0f, "ns_ngp_mlp_step_fused: slabs >= 1, step >= 1 (or ctl), grad_scale > 0");
+  MlpStepArgs a;
+  a.partial = partial_ws;
+  a.slabs = slabs;
+  a.grad = grad_weights;
+  a.master = master;
+  a.m1 = m1;
+  a.m2 = m2;
+  a.hp = (_Float16*)half_params;
+  a.frags = (_Float16*)frags;
+  a.c1 = 1.0f - powf(beta1, (float)(step < 1 ? 1 : step));
+  a.c2 = 1.0f - powf(beta2, (float)(step < 1 ? 1 : step));
+  a.lr = lr;
+  a.beta1 = beta1;
+  a.beta2 = beta2;
+  a.eps = eps;
+  a.l2 = l2;
+  a.inv_grad_scale = 1.0f / grad_scale;
+  a.ctl = ctl;
+  hipLaunchKernelGGL(ngp_mlp_step_kernel, dim3(W_TOTAL / 256), dim3(256), 0, (hipStream_t)stream, a);
+  NS_CHECK_LAUNCH("ngp_mlp_step_kernel");
   return NS_OK;
 }
 

@@ -498,12 +498,13 @@ class NgpNerf:
                 st1 = stream_ptr()
                 self._side.wait_event(fork1)
                 mark(None)
-                check(L.ns_ngp_mlp_wgrad_recompute_n(ptr(self.mlp_frags), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]),
-                                                     ptr(self.partial_fused), self.mlp_wgs, ptr(self.mlp_grad), C.c_long(S), n_dev, st1),
-                      "ngp_mlp_wgrad_recompute")
-                mark("ngp_mlp_wgrad_tr_kernel + ngp_mlp_wgrad_reduce_kernel")
-                if single:
-                    mlp_adam(st1)
+                # (round 4: the launch alone; what follows it -- slab reduce, Adam, fragment tables -- WRITES the fragment table
+                #  the activation-gradient kernel on the main stream is reading, so it waits for fork 2 below.  It used to be
+                #  ordered only by the weight-gradient kernel taking longer than that kernel.)
+                check(L.ns_ngp_mlp_wgrad_partials_n(ptr(self.mlp_frags), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]),
+                                                    ptr(self.partial_fused), self.mlp_wgs, C.c_long(S), n_dev, st1),
+                      "ngp_mlp_wgrad_partials")
+                mark("ngp_mlp_wgrad_tr_kernel")
         elif mlp_mode == "fused":
             # (one workgroup of this kernel takes 145 KB of LDS: nothing LDS-using can run next to it, so it sits on this stream)
             check(L.ns_ngp_mlp_backward_fused_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]), ptr(self.s_dfeat),
@@ -557,6 +558,22 @@ class NgpNerf:
         with torch.cuda.stream(self._side):
             st1 = stream_ptr()
             self._side.wait_event(fork)
+            if mlp_mode == "split":
+                slabs = int(L.ns_ngp_mlp_wgrad_slabs(self.mlp_wgs, C.c_long(S)))
+                mark(None)
+                if single and not os.environ.get("NS_NGP_MLP_STEP_UNFUSED"):
+                    # the MLP's optimiser step in one launch: slab reduce + Adam + f16 copy + both fragment tables
+                    check(L.ns_ngp_mlp_step_fused(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), ptr(self.mlp_master),
+                                                  ptr(self.mlp_half), ptr(self.mlp_m1), ptr(self.mlp_m2), ptr(self.mlp_frags), 0,
+                                                  C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
+                                                  C.c_float(c.l2_mlp), C.c_float(c.loss_scale * self.world), ctl, st1),
+                          "ngp_mlp_step_fused")
+                    mark("ngp_mlp_step_kernel")
+                else:
+                    check(L.ns_ngp_mlp_reduce(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), st1), "ngp_mlp_reduce")
+                    if single:
+                        mlp_adam(st1)
+                    mark("ngp_mlp_wgrad_reduce_kernel (+ ngp_adam_kernel + ngp_mlp_pack_frags_kernel)")
             if mlp_mode == "r3a":
                 check(L.ns_ngp_mlp_wgrad_n(ptr(featT), ptr(h1T), ptr(cinT), ptr(h3T), ptr(h4T), ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT),
                                            ptr(d1T), ptr(self.partial), c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(S), n_dev, st1),

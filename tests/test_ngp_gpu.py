@@ -941,6 +941,45 @@ def test_fused_table_gradient_adam_is_bit_identical(oracle_mod, dev):
     assert not torch.equal(st["fused"]["master"], m0)
 
 
+@pytest.mark.parametrize("slabs", [64, 7, 300])
+def test_mlp_optimiser_step_in_one_launch_is_bit_identical(dev, slabs):
+    """ns_ngp_mlp_step_fused (slab reduce + Adam + f16 copy + both fragment tables, one launch) == ns_ngp_mlp_reduce +
+    ns_ngp_adam + ns_ngp_mlp_pack_fragments: master, moments, f16 weights, the cleared gradient buffer and every byte of the
+    fragment tables, over three steps (moments carried); weight decay on (every parameter moves) and off (zero gradients skip)."""
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    n = 10240
+    g = torch.Generator().manual_seed(11 + slabs)
+    W0 = (torch.rand(n, generator=g) - 0.5).to(dev) * 0.4
+    nb = int(lib().ns_ngp_mlp_fragment_table_bytes()) // 2
+    lr, b1, b2, eps, gs = 1e-2, 0.9, 0.99, 1e-15, 128.0
+    st = {}
+    for name in ("three", "one"):
+        d = dict(master=W0.clone(), hp=W0.half(), m1=torch.zeros(n, device=dev), m2=torch.zeros(n, device=dev),
+                 grad=torch.zeros(n, device=dev), frags=torch.zeros(nb, dtype=torch.float16, device=dev))
+        check(lib().ns_ngp_mlp_pack_fragments(ptr(d["hp"]), ptr(d["frags"]), stream_ptr()), "pack")
+        st[name] = d
+    for step, l2 in ((1, 0.0), (2, 1e-6), (3, 0.0)):
+        part = (torch.randn((slabs, n), generator=g) * 3.0).to(dev)
+        part[:, torch.rand(n, generator=g) < 0.3] = 0.0                       # parameters without a gradient this step
+        pre = (torch.randn(n, generator=g) * (step == 2)).to(dev)             # something already in the gradient buffer
+        a, f = st["three"], st["one"]
+        a["grad"].copy_(pre)
+        f["grad"].copy_(pre)
+        check(lib().ns_ngp_mlp_reduce(ptr(part), slabs, ptr(a["grad"]), stream_ptr()), "reduce")
+        check(lib().ns_ngp_adam(ptr(a["master"]), ptr(a["hp"]), ptr(a["grad"]), ptr(a["m1"]), ptr(a["m2"]), C.c_long(n), step, C.c_float(lr),
+                                C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(l2), C.c_float(gs), C.c_float(0.0), stream_ptr()),
+              "adam")
+        check(lib().ns_ngp_mlp_pack_fragments(ptr(a["hp"]), ptr(a["frags"]), stream_ptr()), "pack")
+        check(lib().ns_ngp_mlp_step_fused(ptr(part), slabs, ptr(f["grad"]), ptr(f["master"]), ptr(f["hp"]), ptr(f["m1"]), ptr(f["m2"]),
+                                          ptr(f["frags"]), step, C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(l2),
+                                          C.c_float(gs), None, stream_ptr()), "step_fused")
+        for k in ("master", "m1", "m2", "hp", "grad", "frags"):
+            assert torch.equal(a[k].view(torch.int16 if a[k].dtype == torch.float16 else torch.int32),
+                               f[k].view(torch.int16 if f[k].dtype == torch.float16 else torch.int32)), (step, k)
+        assert float(f["grad"].abs().max()) == 0.0
+    assert not torch.equal(st["one"]["master"], W0)
+
+
 def test_pose_gradient_from_forward_jacobian(oracle_mod, dev):
     """ns_ngp_encode_forward_j_n + ns_ngp_encode_jacobian_dot_n == ns_ngp_encode_backward_input_n (8 x 16 gathers per sample) up
     to the f16 rounding of the Jacobian rows; features unchanged by the extra output; device sample count honoured"""
