@@ -405,14 +405,24 @@ class NgpNerf:
         mlp_mode = os.environ.get("NS_NGP_MLP", "split")
         if mlp_mode != "r3a" and getattr(self, "partial_fused", None) is None:     # (first step after construction: eager)
             self.partial_fused = torch.zeros((self.mlp_wgs, MLP_TOTAL), dtype=torch.float32, device=dev)
-            self.mlp_frags = torch.zeros(int(L.ns_ngp_mlp_fragment_table_bytes()) // 2, dtype=torch.float16, device=dev)
-            # the weights in MFMA operand order (forward + transposed fragments): packed here once, then after every MLP Adam
-            check(L.ns_ngp_mlp_pack_fragments(ptr(self.mlp_half), ptr(self.mlp_frags), st), "ngp_mlp_pack_fragments")
+            # the weights in MFMA operand order (forward + transposed fragments), TWO tables: step k reads table k & 1 and its
+            # optimiser writes table (k + 1) & 1 -- the MLP's optimiser runs on a side stream while the activation-gradient
+            # kernel of the same step may still be reading the table on the main one (round 4, first form: ONE table, ordered
+            # only by the weight-gradient kernel in front of the optimiser taking longer than that kernel; making the optimiser
+            # wait for the main stream's event instead cost the pipeline 10 %: 133-134 -> 117-121 frames/s, step alone unchanged)
+            nfr = int(L.ns_ngp_mlp_fragment_table_bytes()) // 2
+            self.mlp_frags2 = torch.zeros((2, nfr), dtype=torch.float16, device=dev)
+            for k in (0, 1):
+                check(L.ns_ngp_mlp_pack_fragments(ptr(self.mlp_half), ptr(self.mlp_frags2[k]), st), "ngp_mlp_pack_fragments")
+        fr_r = fr_w = None
+        if mlp_mode != "r3a":
+            fr_r, fr_w = self.mlp_frags2[x], self.mlp_frags2[1 - x]      # read by this step / written for the next one
+            self.mlp_frags = fr_w                                         # (the table of the step that follows: bench.py, tools)
         if mlp_mode == "fused":
             check(L.ns_ngp_mlp_forward_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), None, None, None, None,
                                          C.c_long(S), n_dev, st), "ngp_mlp_forward")
         elif mlp_mode == "split":
-            check(L.ns_ngp_mlp_forward_f_n(ptr(self.mlp_frags), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), ptr(self.relu_masks),
+            check(L.ns_ngp_mlp_forward_f_n(ptr(fr_r), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), ptr(self.relu_masks),
                                            C.c_long(S), n_dev, st), "ngp_mlp_forward")
             mark("ngp_mlp_fwd_kernel")
         else:
@@ -437,7 +447,7 @@ class NgpNerf:
         def mlp_adam(stream):
             adam(*mlp, stream)
             if mlp_mode != "r3a":   # the fragment table follows the weights (read by the next step's forward / backward kernels)
-                check(L.ns_ngp_mlp_pack_fragments(ptr(self.mlp_half), ptr(self.mlp_frags), stream), "ngp_mlp_pack_fragments")
+                check(L.ns_ngp_mlp_pack_fragments(ptr(self.mlp_half), ptr(fr_w), stream), "ngp_mlp_pack_fragments")
 
         def camera_step(stream):
             check(L.ns_ngp_camera_step_ctl(ptr(self.c2w), ptr(self.cam_grad), ptr(self.cam_m1), ptr(self.cam_m2),
@@ -489,7 +499,7 @@ class NgpNerf:
             #  0.287-0.294 ms per step)
             fork1.record(main)
             mark(None)
-            check(L.ns_ngp_mlp_dgrad_f_n(ptr(self.mlp_frags), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
+            check(L.ns_ngp_mlp_dgrad_f_n(ptr(fr_r), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
                                          C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
             mark("ngp_mlp_bwd_kernel")
             # (round 4, measured and not kept: the weight gradients IN LINE on the main stream ahead of the scatter, so that the
@@ -498,13 +508,27 @@ class NgpNerf:
                 st1 = stream_ptr()
                 self._side.wait_event(fork1)
                 mark(None)
-                # (round 4: the launch alone; what follows it -- slab reduce, Adam, fragment tables -- WRITES the fragment table
-                #  the activation-gradient kernel on the main stream is reading, so it waits for fork 2 below.  It used to be
-                #  ordered only by the weight-gradient kernel taking longer than that kernel.)
-                check(L.ns_ngp_mlp_wgrad_partials_n(ptr(self.mlp_frags), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]),
+                # (the optimiser that follows writes the OTHER fragment table: the activation-gradient kernel on the main stream
+                #  may still be reading this one)
+                check(L.ns_ngp_mlp_wgrad_partials_n(ptr(fr_r), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]),
                                                     ptr(self.partial_fused), self.mlp_wgs, C.c_long(S), n_dev, st1),
                       "ngp_mlp_wgrad_partials")
                 mark("ngp_mlp_wgrad_tr_kernel")
+                slabs = int(L.ns_ngp_mlp_wgrad_slabs(self.mlp_wgs, C.c_long(S)))
+                if single and not os.environ.get("NS_NGP_MLP_STEP_UNFUSED"):
+                    # the MLP's optimiser step in one launch: slab reduce + Adam + f16 copy + both fragment tables (the zero rows
+                    # of the tables were written once by the pack above)
+                    check(L.ns_ngp_mlp_step_fused(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), ptr(self.mlp_master),
+                                                  ptr(self.mlp_half), ptr(self.mlp_m1), ptr(self.mlp_m2), ptr(fr_w), 0,
+                                                  C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
+                                                  C.c_float(c.l2_mlp), C.c_float(c.loss_scale * self.world), ctl, st1),
+                          "ngp_mlp_step_fused")
+                    mark("ngp_mlp_step_kernel")
+                else:
+                    check(L.ns_ngp_mlp_reduce(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), st1), "ngp_mlp_reduce")
+                    if single:
+                        mlp_adam(st1)
+                    mark("ngp_mlp_wgrad_reduce_kernel (+ ngp_adam_kernel + ngp_mlp_pack_frags_kernel)")
         elif mlp_mode == "fused":
             # (one workgroup of this kernel takes 145 KB of LDS: nothing LDS-using can run next to it, so it sits on this stream)
             check(L.ns_ngp_mlp_backward_fused_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]), ptr(self.s_dfeat),
@@ -558,22 +582,6 @@ class NgpNerf:
         with torch.cuda.stream(self._side):
             st1 = stream_ptr()
             self._side.wait_event(fork)
-            if mlp_mode == "split":
-                slabs = int(L.ns_ngp_mlp_wgrad_slabs(self.mlp_wgs, C.c_long(S)))
-                mark(None)
-                if single and not os.environ.get("NS_NGP_MLP_STEP_UNFUSED"):
-                    # the MLP's optimiser step in one launch: slab reduce + Adam + f16 copy + both fragment tables
-                    check(L.ns_ngp_mlp_step_fused(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), ptr(self.mlp_master),
-                                                  ptr(self.mlp_half), ptr(self.mlp_m1), ptr(self.mlp_m2), ptr(self.mlp_frags), 0,
-                                                  C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
-                                                  C.c_float(c.l2_mlp), C.c_float(c.loss_scale * self.world), ctl, st1),
-                          "ngp_mlp_step_fused")
-                    mark("ngp_mlp_step_kernel")
-                else:
-                    check(L.ns_ngp_mlp_reduce(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), st1), "ngp_mlp_reduce")
-                    if single:
-                        mlp_adam(st1)
-                    mark("ngp_mlp_wgrad_reduce_kernel (+ ngp_adam_kernel + ngp_mlp_pack_frags_kernel)")
             if mlp_mode == "r3a":
                 check(L.ns_ngp_mlp_wgrad_n(ptr(featT), ptr(h1T), ptr(cinT), ptr(h3T), ptr(h4T), ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT),
                                            ptr(d1T), ptr(self.partial), c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(S), n_dev, st1),
