@@ -43,6 +43,13 @@ for p in (ROOT, os.path.join(ROOT, "nerf-slam_amd"), os.path.join(ROOT, "tools")
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# The HIP runtime multiplexes streams (ours and the graph executor's internal ones) onto GPU_MAX_HW_QUEUES hardware queues; how the
+# branches of the mapper's step graph and the tracker's stream share them decides the step's time AND the pipeline's overlap.
+# Measured on MI355X / ROCm 7.2 (one box, bench.py --no-extras, frames/s parallel | sequential mapper ms per frame):
+#   3: 115-117 | 5.0 (no gain over the sequential mode)   4 (the runtime's default): 131-138 | 5.0   5: 101 | 7.4   6: 105-108 | 7.2
+#   8: 111 | 6.0   16: 98-99 | 5.6.   Pinned here so that a site-wide setting does not silently change the measurement.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+
 import numpy as np
 import torch
 
