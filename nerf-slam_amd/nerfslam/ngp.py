@@ -337,6 +337,11 @@ class NgpNerf:
                                  ptr(t["ray_start"]), ptr(t["ray_n"]), ptr(t["s_pos"]), ptr(t["s_dir"]), ptr(t["s_dt"]),
                                  ptr(t["s_t"]), ctl, st), "ngp_march")
 
+    @property
+    def mlp_frags(self):
+        """the fragment table the NEXT optimiser step reads (complete and current: written by the last step's optimiser)"""
+        return self.mlp_frags2[self.cur]
+
     def _enqueue_step(self, x, phase="all"):
         """one optimiser step on set `x` on the current stream (+ two side streams); no host synchronisation, no allocation.
         phase="pre" (replicated trainers): everything up to the gradient exchange; returns the closure that enqueues what follows it.
@@ -417,7 +422,6 @@ class NgpNerf:
         fr_r = fr_w = None
         if mlp_mode != "r3a":
             fr_r, fr_w = self.mlp_frags2[x], self.mlp_frags2[1 - x]      # read by this step / written for the next one
-            self.mlp_frags = fr_w                                         # (the table of the step that follows: bench.py, tools)
         if mlp_mode == "fused":
             check(L.ns_ngp_mlp_forward_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), None, None, None, None,
                                          C.c_long(S), n_dev, st), "ngp_mlp_forward")
