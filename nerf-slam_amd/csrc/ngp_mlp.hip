@@ -1048,21 +1048,41 @@ __device__ __forceinline__ void frag_place(_Float16* frags, int first, int nchun
 __global__ __launch_bounds__(256) void ngp_mlp_step_kernel(MlpStepArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= W_TOTAL) return;
-  // ---- the slabs, in ngp_mlp_wgrad_reduce_kernel's order ----
+  // ---- the slabs, in ngp_mlp_wgrad_reduce_kernel's order: 16 interleaved partial sums (slab k belongs to sum k % 16), then
+  //      their sum.  Up to 64 slabs (the trainer's: 64 weight-gradient workgroups) ALL loads leave before the first add --
+  //      written as the loop below it is 16 dependent load rounds, 37 us inside the pipeline for a kernel of 40 workgroups ----
   float t = 0.0f;
-  for (int grp = 0; grp < 16; grp++) {
-    float s = 0.0f;
-    for (int k0 = grp; k0 < a.slabs; k0 += 16 * 16) {
-      float v[16];
+  if (a.slabs <= 64) {
+    float v[4][16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int k = k0 + 16 * u;
-        v[u] = k < a.slabs ? a.partial[(long)k * W_TOTAL + i] : 0.0f;
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int grp = 0; grp < 16; grp++) {
+        const int k = grp + 16 * u;
+        v[u][grp] = k < a.slabs ? a.partial[(long)k * W_TOTAL + i] : 0.0f;
       }
 #pragma unroll
-      for (int u = 0; u < 16; u++) s += v[u];
+    for (int grp = 0; grp < 16; grp++) {
+      float s = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 4; u++) s += v[u][grp];
+      t += s;
     }
-    t += s;
+  } else {
+    for (int grp = 0; grp < 16; grp++) {
+      float s = 0.0f;
+      for (int k0 = grp; k0 < a.slabs; k0 += 16 * 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const int k = k0 + 16 * u;
+          v[u] = k < a.slabs ? a.partial[(long)k * W_TOTAL + i] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) s += v[u];
+      }
+      t += s;
+    }
   }
   // ---- Adam, as ngp_adam_kernel ----
   const float c1 = a.ctl ? __int_as_float(a.ctl[NS_CTL_C1]) : a.c1, c2 = a.ctl ? __int_as_float(a.ctl[NS_CTL_C2]) : a.c2;
