@@ -1049,8 +1049,9 @@ __global__ __launch_bounds__(256) void ngp_mlp_step_kernel(MlpStepArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= W_TOTAL) return;
   // ---- the slabs, in ngp_mlp_wgrad_reduce_kernel's order: 16 interleaved partial sums (slab k belongs to sum k % 16), then
-  //      their sum.  Up to 64 slabs (the trainer's: 64 weight-gradient workgroups) ALL loads leave before the first add --
-  //      written as the loop below it is 16 dependent load rounds, 37 us inside the pipeline for a kernel of 40 workgroups ----
+  //      their sum.  Up to 64 slabs (the trainer's: 64 weight-gradient workgroups) ALL loads leave before the first add
+  //      (the loop below is 16 dependent load rounds).  Inside the pipeline the kernel takes 37-38 us either way: its 40
+  //      workgroups wait for CU slots behind the accumulate pass of the table gradient, not for their loads ----
   float t = 0.0f;
   if (a.slabs <= 64) {
     float v[4][16];
