@@ -178,7 +178,10 @@ __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const
     const uint32_t i1 = grid_index_lvl(hashed, hs, res, c[0] + 1, c[1] + (yz & 1), c[2] + (yz >> 1));
     const uint32_t lo = min(i0, i1);
     // (round 4, measured: non-temporal gathers on the hashed levels -- no L1 allocation for lines of which 4 bytes are used --
-    //  59 -> 175 us: neighbouring samples of a ray DO share lines often enough for the L1 to matter)
+    //  59 -> 175 us: neighbouring samples of a ray DO share lines often enough for the L1 to matter.  Also measured: TWO
+    //  (block, level) items per workgroup, both positions and then both sets of gathers in flight together -- half the
+    //  workgroups, the same two round trips each: 59.7-61.1 -> 61.7 us.  The kernel is not a chain of round trips; it sits on
+    //  the rate at which the L1s take scattered 4- / 8-byte requests and fill lines.)
     if (max(i0, i1) - lo == 1u) {
       struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
       const Pair pr = *reinterpret_cast<const Pair*>(tab + lo);
