@@ -231,135 +231,6 @@ __global__ __launch_bounds__(256) void ngp_encode_fwd_kernel(GridLayout g, const
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// The same kernel with TWO (sample block, level) items per workgroup (round 4).  A lane of the kernel above is a chain of two
-// memory round trips -- its position, then its 4-8 gathers -- and at full occupancy the launch is ~7 rounds of workgroups per
-// CU: ~14 dependent round trips of ~3 us are its 56 us, not bytes.  Here workgroup (xcd, q) takes items q and q + ceil(I / 2)
-// of its XCD's list (I = items per XCD; with the default grid: one block of the level the XCD owns and one block of a shared
-// level): both positions leave together, then both sets of gathers -- half the workgroups, the same two round trips each.
-// Same arithmetic per (sample, level): bit-identical output.
-// ---------------------------------------------------------------------------------------------
-struct EncItem {
-  int l;
-  long i;
-  bool on;
-};
-
-__device__ __forceinline__ EncItem enc_item(const EncFwdSched& sc, int xcd, int item, int n_items, long N, const int* n_dev) {
-  EncItem t;
-  t.on = item < n_items;
-  int blk = 0;
-  t.l = 0;
-  if (t.on) {
-    if (item < sc.seg) {
-      t.l = sc.own[xcd];
-      blk = item;
-      if (t.l < 0) t.on = false;
-    } else {
-      const int k = item - sc.seg;
-      t.l = sc.shared[k / sc.nblk8];
-      blk = (k % sc.nblk8) * 8 + xcd;
-      if (blk >= sc.nblk) t.on = false;
-    }
-  }
-  t.i = (long)blk * 256 + threadIdx.x;
-  if (t.i >= N || (n_dev != nullptr && t.i >= (((long)*n_dev + 7) & ~7L))) t.on = false;
-  if (!t.on) { t.l = 0; t.i = 0; }
-  return t;
-}
-
-__device__ __forceinline__ void enc_gather(const GridLayout& g, const EncItem& t, const float (&pp)[3], const h2_t* __restrict__ params,
-                                           float (&w)[3], h2_t (&v)[8]) {
-  const uint32_t hs = g.offset[t.l + 1] - g.offset[t.l];
-  const float scale = g.scale[t.l];
-  const uint32_t res = (uint32_t)g.res[t.l];
-  const bool hashed = grid_level_hashed(hs, res);
-  uint32_t c[3];
-#pragma unroll
-  for (int d = 0; d < 3; d++) {
-    const float p = fmaf(scale, pp[d], 0.5f);
-    const float fl = floorf(p);
-    c[d] = (uint32_t)(int)fl;
-    w[d] = p - fl;
-  }
-  const h2_t* __restrict__ tab = params + g.offset[t.l];
-#pragma unroll
-  for (int yz = 0; yz < 4; yz++) {
-    const uint32_t i0 = grid_index_lvl(hashed, hs, res, c[0], c[1] + (yz & 1), c[2] + (yz >> 1));
-    const uint32_t i1 = grid_index_lvl(hashed, hs, res, c[0] + 1, c[1] + (yz & 1), c[2] + (yz >> 1));
-    const uint32_t lo = min(i0, i1);
-    if (max(i0, i1) - lo == 1u) {          // x-neighbours adjacent in the table: one 8-byte load (see the kernel above)
-      struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
-      const Pair pr = *reinterpret_cast<const Pair*>(tab + lo);
-      v[2 * yz] = __builtin_bit_cast(h2_t, i0 == lo ? pr.a : pr.b);
-      v[2 * yz + 1] = __builtin_bit_cast(h2_t, i0 == lo ? pr.b : pr.a);
-    } else {
-      v[2 * yz] = tab[i0];
-      v[2 * yz + 1] = tab[i1];
-    }
-  }
-}
-
-__device__ __forceinline__ void enc_finish(const EncItem& t, const float (&w)[3], const h2_t (&v)[8], h2_t* __restrict__ out, long N,
-                                           int L, int unit_major, _Float16* __restrict__ jacT) {
-  const int l = t.l;
-  const long i = t.i;
-  float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-  for (int corner = 0; corner < 8; corner++) {
-    float wt = 1.0f;
-    wt *= (corner & 1) ? w[0] : 1.0f - w[0];
-    wt *= (corner & 2) ? w[1] : 1.0f - w[1];
-    wt *= (corner & 4) ? w[2] : 1.0f - w[2];
-    a0 = fmaf(wt, (float)v[corner][0], a0);
-    a1 = fmaf(wt, (float)v[corner][1], a1);
-  }
-  if (jacT != nullptr) {
-    const float wx0 = 1.0f - w[0], wx1 = w[0], wy0 = 1.0f - w[1], wy1 = w[1], wz0 = 1.0f - w[2], wz1 = w[2];
-#pragma unroll
-    for (int f = 0; f < 2; f++) {
-      float s8[8];
-#pragma unroll
-      for (int corner = 0; corner < 8; corner++) s8[corner] = (float)v[corner][f];
-      const float jx = wy0 * wz0 * (s8[1] - s8[0]) + wy1 * wz0 * (s8[3] - s8[2]) + wy0 * wz1 * (s8[5] - s8[4]) + wy1 * wz1 * (s8[7] - s8[6]);
-      const float jy = wx0 * wz0 * (s8[2] - s8[0]) + wx1 * wz0 * (s8[3] - s8[1]) + wx0 * wz1 * (s8[6] - s8[4]) + wx1 * wz1 * (s8[7] - s8[5]);
-      const float jz = wx0 * wy0 * (s8[4] - s8[0]) + wx1 * wy0 * (s8[5] - s8[1]) + wx0 * wy1 * (s8[6] - s8[2]) + wx1 * wy1 * (s8[7] - s8[3]);
-      jacT[(long)(6 * l + 3 * f + 0) * N + i] = (_Float16)jx;
-      jacT[(long)(6 * l + 3 * f + 1) * N + i] = (_Float16)jy;
-      jacT[(long)(6 * l + 3 * f + 2) * N + i] = (_Float16)jz;
-    }
-  }
-  if (unit_major) {
-    _Float16* o = reinterpret_cast<_Float16*>(out);
-    o[(long)(2 * l) * N + i] = (_Float16)a0;
-    o[(long)(2 * l + 1) * N + i] = (_Float16)a1;
-  } else {
-    h2_t o = {(_Float16)a0, (_Float16)a1};
-    out[i * L + l] = o;
-  }
-}
-
-__global__ __launch_bounds__(256) void ngp_encode_fwd2_kernel(GridLayout g, const float* __restrict__ pos,
-                                                              const h2_t* __restrict__ params, h2_t* __restrict__ out, long N,
-                                                              int L, int unit_major, const int* __restrict__ n_dev,
-                                                              _Float16* __restrict__ jacT, EncFwdSched sc, int n_items, int half_items) {
-  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-  const EncItem ta = enc_item(sc, xcd, q, n_items, N, n_dev), tb = enc_item(sc, xcd, q + half_items, n_items, N, n_dev);
-  if (!ta.on && !tb.on) return;
-  float pa[3], pb[3];
-#pragma unroll
-  for (int d = 0; d < 3; d++) {
-    pa[d] = pos[ta.i * 3 + d];
-    pb[d] = pos[tb.i * 3 + d];
-  }
-  float wa[3], wb[3];
-  h2_t va[8], vb[8];
-  enc_gather(g, ta, pa, params, wa, va);
-  enc_gather(g, tb, pb, params, wb, vb);
-  if (ta.on) enc_finish(ta, wa, va, out, N, L, unit_major, jacT);
-  if (tb.on) enc_finish(tb, wb, vb, out, N, L, unit_major, jacT);
-}
-
 // Packed fixed-point gradient format (fixed_scale > 0): one 64-bit word per table entry holds both features
 // as signed Q(fixed_scale) 32-bit fields, word = round(g0 * S) + (round(g1 * S) << 32).  One 64-bit integer
 // atomic replaces two float atomics (the scatter is atomic-rate bound on the hashed levels), and integer
@@ -2636,19 +2507,10 @@ extern "C" int ns_ngp_encode_forward_j_n(int n_levels, int n_features, int log2_
     sc.nblk8 = (sc.nblk + 7) / 8;
     sc.seg = n_own > 0 ? sc.nblk : 0;
   }
-  const long n_items = sc.seg + (long)sc.n_shared * sc.nblk8;       // per XCD
-  static const bool single = getenv("NS_ENC_FWD_SINGLE") != nullptr;    // A/B switch: one item per workgroup (round 3)
-  if (single) {
-    hipLaunchKernelGGL(ngp_encode_fwd_kernel, dim3((unsigned)(8L * n_items)), dim3(256), 0, (hipStream_t)stream, g,
-                       positions, (const h2_t*)params, (h2_t*)out, N, n_levels, unit_major, n_dev, (_Float16*)jacT, sc);
-    NS_CHECK_LAUNCH("ngp_encode_fwd_kernel");
-  } else {
-    const long half_items = (n_items + 1) / 2;
-    hipLaunchKernelGGL(ngp_encode_fwd2_kernel, dim3((unsigned)(8L * half_items)), dim3(256), 0, (hipStream_t)stream, g,
-                       positions, (const h2_t*)params, (h2_t*)out, N, n_levels, unit_major, n_dev, (_Float16*)jacT, sc,
-                       (int)n_items, (int)half_items);
-    NS_CHECK_LAUNCH("ngp_encode_fwd2_kernel");
-  }
+  const long nwg = 8L * (sc.seg + (long)sc.n_shared * sc.nblk8);
+  hipLaunchKernelGGL(ngp_encode_fwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g,
+                     positions, (const h2_t*)params, (h2_t*)out, N, n_levels, unit_major, n_dev, (_Float16*)jacT, sc);
+  NS_CHECK_LAUNCH("ngp_encode_fwd_kernel");
   return NS_OK;
 }
 
