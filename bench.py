@@ -64,6 +64,7 @@ def _lib_sha256():
     return h.hexdigest()
 
 
+ENV_OVERRIDES = []         # NS_* kernel-selection variables present in the environment (main() refuses them by default)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak
 
@@ -81,7 +82,7 @@ class Pipeline:
                     mapper still does exactly ONE spin per input frame (ingest or 16 optimiser steps), so both modes do the
                     same work per frame."""
 
-    def __init__(self, dev, n_frames, buffer, fusion=True, on_packet=None, trainer_group=None):
+    def __init__(self, dev, n_frames, buffer, fusion=True, on_packet=None, trainer_group=None, queue_depth=8):
         import threading
         from nerfslam.pipeline import DataModule, FusionModule, SlamModule
         from synth_stream import RoomStream, grounded_networks
@@ -108,7 +109,12 @@ class Pipeline:
         self.parallel = False
         self._out = None
         from nerfslam.pipeline import StreamQueue
-        self.map_q = StreamQueue(maxsize=2)
+        # bounded like examples/slam_demo.py's --parallel_run queue (StreamQueue(maxsize=8); the reference's queues are unbounded,
+        # examples/slam_demo.py:75-86).  Rounds 1-4 ran this harness with a depth of 2: a keyframe candidate keeps the tracker busy
+        # for ~14 ms, the mapper finished its two queued frames in ~10 and starved until the candidate was through -- the
+        # pipeline measured the queue, not the GPU (`--queue-depth 2` reproduces it; profiles/r05_ab_records.json).
+        self.queue_depth = int(queue_depth)
+        self.map_q = StreamQueue(maxsize=self.queue_depth)
         self.map_stream = torch.cuda.Stream(device=dev)     # (normal priority: as a high-priority stream, 104 -> 70 frames/s)
         # --parallel_run: the tracker works on a stream of its own as well.  On the legacy default stream its kernels were
         # serialised against the branches of the mapper's HIP graphs (the null stream synchronises implicitly with every
@@ -137,7 +143,7 @@ class Pipeline:
             return
         if self.parallel:
             self.map_q.put(out)                      # StreamQueue: event on this (the tracker's) stream; blocks while the
-        else:                                        # mapper is two frames behind
+        else:                                        # mapper is `queue_depth` frames behind
             self._out = out
 
     def _mapper_loop(self):
@@ -746,7 +752,13 @@ def main():
     ap.add_argument("--microbench", default="", help="run ONE roofline micro-bench back to back (for rocprofv3 --pmc passes)")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--quality-only", action="store_true", help="extras: the quality block only (no rooflines, no chain figure)")
-    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps frames each; `value` is their median")
+    ap.add_argument("--windows", type=int, default=8,
+                    help="timed windows of --steps frames each; `value` = all their frames / all their time (the median window is printed beside it)")
+    ap.add_argument("--queue-depth", type=int, default=8,
+                    help="bound of the tracker -> mapper queue in the --parallel_run mode (examples/slam_demo.py uses 8; rounds 1-4 of this "
+                         "bench used 2)")
+    ap.add_argument("--allow-env-overrides", action="store_true",
+                    help="run although NS_* kernel-selection variables are set (they are then listed in `env_overrides`)")
     ap.add_argument("--config", default="c640", choices=["c640", "c1280"],
                     help="c640: BASELINE configs[2]/[3] (default, the headline metric); c1280: configs[4], global BA over a 256-keyframe buffer at 1280x720")
     args = ap.parse_args()
@@ -754,6 +766,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # The library and the host code read NS_* variables that select kernels / stream placements (A/B switches of the tools): a
+    # site-wide one would silently change what is measured.  The harness's own variables (NS_BENCH_*, NS_GIT_HEAD) are exempt.
+    global ENV_OVERRIDES
+    ENV_OVERRIDES = sorted(k for k in os.environ if k.startswith("NS_") and not k.startswith("NS_BENCH_") and k != "NS_GIT_HEAD")
+    if ENV_OVERRIDES and not args.allow_env_overrides:
+        raise SystemExit("bench.py: kernel-selection variables are set: %s -- unset them, or pass --allow-env-overrides (the line then "
+                         "carries them in `env_overrides`)" % ", ".join(ENV_OVERRIDES))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the HIP path")
     # NS_BENCH_DIST_BACKEND=gloo + NS_BENCH_ONE_DEVICE=1: run the N > 1 topology on a 1-GPU box (all ranks on device 0,
@@ -776,7 +795,7 @@ def main():
     if world > 1:
         return main_split(args, rank, world, dev, backend, n_frames, buffer)
 
-    pipe = Pipeline(dev, n_frames, buffer, fusion=True)
+    pipe = Pipeline(dev, n_frames, buffer, fusion=True, queue_depth=args.queue_depth)
     ngp = pipe.fusion.fusion.ngp
     init_frames = 0
     while not pipe.tracker.is_initialized:
@@ -813,7 +832,12 @@ def main():
         pipe.frame()
     wins = [timed(K) for _ in range(NW)]
     order = sorted(range(NW), key=lambda i: wins[i][0])
-    dt, counts = wins[order[NW // 2]]
+    dt_med, _ = wins[order[NW // 2]]
+    # `value` = ALL timed frames / ALL timed seconds (the median of a few 20-frame windows picked the windows with
+    # the fewest keyframe candidates); the median window is printed beside it.  `dt` below is the mean window: K frames' worth.
+    dt = sum(w[0] for w in wins) / NW
+    counts = {k: sum(w[1][k] for w in wins) for k in wins[0][1]}
+    counts["frames"] = NW * K
     counts.update({"active_edges_at_end": int(pipe.tracker.fe.ii.shape[0]), "nerf_samples_per_step": int(ngp._net.last_samples),
                    "nerf_rays_per_step": int(ngp._net.last_rays), "nerf_training_views": int(ngp.nerf.training.n_images_for_training)})
     windows = [{"frames_per_s": K / w[0], "ms_per_frame": 1e3 * w[0] / K, "keyframe_candidates": w[1]["keyframe_candidates"],
@@ -852,26 +876,31 @@ def main():
                                "steps on the others",
                    "mode": ("sequential (no --parallel_run)" if args.sequential else
                             "--parallel_run on one GPU: mapper in its own host thread on its own HIP stream, fed through a bounded "
-                            "queue (depth 2); same work per frame as the sequential mode, tracking of frame k+1 overlaps mapping of "
-                            "frame k; `sequential` below is the same stream without the overlap"),
-                   "value_is": "median of %d consecutive timed windows of %d frames each (all windows in `windows`)" % (NW, K),
+                            "queue (depth %d, examples/slam_demo.py's 8 by default); same work per frame as the sequential mode, "
+                            "tracking runs up to that many frames ahead of mapping; `sequential` below is the same stream without "
+                            "the overlap" % args.queue_depth),
+                   "value_is": "%d frames / the summed time of %d consecutive timed windows of %d frames each (device idle and mapper "
+                               "queue empty on both sides of every window; all windows in `windows`, their median in "
+                               "`windows_frames_per_s`); `ms_per_step` = that time / %d" % (NW * K, NW, K, NW * K),
                    "mapper_steps_per_frame": "16 NeRF optimiser steps per non-packet frame (pyngp `frame()`, nerf_fusion.py:298-307; "
                                              "the fork's own count is not in the reference tree): the mapping leg, hence `value`, "
                                              "scales ~1/steps_per_frame",
                    "stream": "640x480, 90 deg FOV, %.2f px mean flow per frame on the 1/8 grid" % 0.57,
-                   "keyframe_ratio_measured": {"candidates_per_frame": counts["keyframe_candidates"] / K,
-                                               "kept_per_frame": (counts["keyframe_candidates"] - counts["candidates_rejected_by_distance_test"]) / K},
+                   "keyframe_ratio_measured": {"candidates_per_frame": counts["keyframe_candidates"] / (NW * K),
+                                               "kept_per_frame": (counts["keyframe_candidates"] - counts["candidates_rejected_by_distance_test"]) / (NW * K)},
                    "init_frames_untimed": init_frames, "buffer": buffer, "parallelism": "single GPU",
                    "launch": "tracker: eager launches, no host synchronisation inside update(); mapper: one HIP-graph replay per optimiser step"},
         "counts": counts,
-        "harness": {"launches_per_frame": counts["harness_only_launches"] / K,
+        "env_overrides": ENV_OVERRIDES,
+        "harness": {"launches_per_frame": counts["harness_only_launches"] / (NW * K),
                     "note": "device launches of the synthetic HARNESS inside the timed region (tools/synth_stream.py: the scene's true flow "
                             "computed after the real networks ran -- 2 reprojections + subtract + fill per update, 6 small ones per "
                             "motion-filter pass); they are not product work and make `value` conservative"},
         "windows": windows,
-        "windows_frames_per_s": {"min": min(w["frames_per_s"] for w in windows), "median": K / dt,
-                                 "max": max(w["frames_per_s"] for w in windows)},
-        "nerf_train_steps_per_s": counts["nerf_train_steps"] / dt,
+        "windows_frames_per_s": {"min": min(w["frames_per_s"] for w in windows), "median": K / dt_med,
+                                 "max": max(w["frames_per_s"] for w in windows), "total_frames_over_total_time": K / dt},
+        "frames_per_s_total": K / dt,
+        "nerf_train_steps_per_s": counts["nerf_train_steps"] / (NW * dt),
         "sequential": sequential,
         "breakdown": breakdown,
     }
@@ -882,10 +911,10 @@ def main():
         hp, extra["hot_path_chain"] = hot_path_chain(dev, 10, 2)
         roofs = kernel_rooflines(dev, hp, ngp._net)
         # share of the timed region per candidate kernel (launch time x launches per timed frame)
-        steps_pf = counts["nerf_train_steps"] / K
-        per_frame = {"corr_lookup_coop_kernel[E=48]": 0.0, "corr_lookup_enc_kernel[E=48]": counts["updates"] / K,
-                     "corr_volume_tiled_kernel[E=10]": counts["keyframe_candidates"] / K,
-                     "conv_nhwc_kernel<3x3,448->256>[E=48]": counts["updates"] / K}
+        steps_pf = counts["nerf_train_steps"] / (NW * K)
+        per_frame = {"corr_lookup_coop_kernel[E=48]": 0.0, "corr_lookup_enc_kernel[E=48]": counts["updates"] / (NW * K),
+                     "corr_volume_tiled_kernel[E=10]": counts["keyframe_candidates"] / (NW * K),
+                     "conv_nhwc_kernel<3x3,448->256>[E=48]": counts["updates"] / (NW * K)}
         in_step_all = roofs.pop("_in_step_all", {})
         for k, r in roofs.items():
             r["launches_per_frame"] = steps_pf if k.startswith("ngp_") else per_frame.get(k, 0.0)
@@ -938,7 +967,7 @@ def main():
         if not args.no_cpu_baseline:
             from hot_path_chain import cpu_baseline
             cb = cpu_baseline(hp)
-            cand = max(counts["keyframe_candidates"] / K, 1e-9)
+            cand = max(counts["keyframe_candidates"] / (NW * K), 1e-9)
             cb["value"] = 1.0 / (cand * cb["seconds_per_keyframe_step"])
             cb["unit"] = "frames/s"
             cb["sample"] += "; converted to frames/s of this stream with the measured %.3f keyframe candidates per frame; the CPU figure " \
@@ -1028,6 +1057,11 @@ def main_split(args, rank, world, dev, backend, n_frames, buffer):
             "nerf_ray_batches_per_s_all_trainers": (sum(steps) / dt) if steps else 0.0,
             "rccl_bytes_per_frame": {"packet_broadcast": (b1 - b0) / K,
                                      "gradient_allreduce_per_trainer": (sum(s["bytes_allreduced_timed"] for s in tr) / max(len(tr), 1)) / K},
+            # per trainer: bytes it put on the wire per optimiser step (sharded all-to-all of the packed table gradient + all-gather
+            # of the f16 table + the MLP / pose all-reduces) and the rate that implies at the measured step rate -- to be read
+            # against one xGMI link (~153 GB/s; a trainer talks to its R-1 peers over R-1 links at once)
+            "rccl_per_trainer": [{"rank": s_["rank"], "wire_bytes_per_step": (s_["bytes_allreduced_timed"] / s_["steps_timed"]) if s_["steps_timed"] else 0.0,
+                                  "implied_GBps": s_["bytes_allreduced_timed"] / dt * 1e-9} for s_ in tr],
             "trainers": tr, "tracker_quality": ate, "roofline": None, "cpu_baseline": None,
         }
         print(json.dumps(out))

@@ -458,7 +458,10 @@ int ns_group_mean_nhwc_f16(const void* src, int src_stride, const int* starts, c
  *   a stride-2 3x3 convolution (extractor.py:16-17,158-159) becomes a 1x1 over 9C channels, and the block's stride-2 1x1
  *   shortcut (extractor.py:46-47) a 1x1 over the centre-tap slice [4C, 5C) of the same buffer.
  * ns_enc_in_stats: partial[n][p][0|1][c] = sum | sum of squares of x [N,HW,C] over part p of the pixels,
- *   p < ns_enc_in_parts(HW); C in {32, 64, 128}.  partial: f32 [N, parts, 2, C].
+ *   p < ns_enc_in_parts(HW); C in {32, 64, 128}.  partial: f32 [N, parts, 2, C]; the last workgroup of an image to arrive
+ *   leaves the totals in row 0.  ticket: N uint32 arrival counters owned by the CALLER, zero before the first launch (the
+ *   kernel leaves them zero); launches that may be in flight at the same time must not share a row (may be NULL when
+ *   ns_enc_in_parts(HW) == 1).
  * ns_enc_in_apply: out = relu(x' + relu(y')) with y' = (y - mean) / sqrt(var + eps) from ystats (nullptr: y' = y),
  *   x' likewise from xstats without the relu (x nullptr: out = relu(y')); biased variance, statistics combined in f64:
  *   InstanceNorm2d + relu, and the tail of a residual block (extractor.py:50-60), in one pass.                        */
@@ -466,7 +469,7 @@ int ns_enc_stem_im2col(const void* img, int img_is_u8, void* out, int N, int H, 
                        void* stream);
 int ns_enc_im2col_3x3s2(const void* x, void* out, int N, int H, int W, int C, void* stream);
 int ns_enc_in_parts(int HW);
-int ns_enc_in_stats(const void* x, float* partial, int N, int HW, int C, void* stream);
+int ns_enc_in_stats(const void* x, float* partial, unsigned int* ticket, int N, int HW, int C, void* stream);
 int ns_enc_in_apply(const void* y, const float* ystats, const void* x, const float* xstats, void* out, int N, int HW, int C,
                     float eps, void* stream);
 

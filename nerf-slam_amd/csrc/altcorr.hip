@@ -295,7 +295,7 @@ extern "C" int ns_altcorr_pyramid(const float* const* fmaps_host, int num_levels
     P.fmap[l] = fmaps_host[l < num_levels ? l : num_levels - 1];
     NS_REQUIRE(P.fmap[l] != nullptr, "ns_altcorr_pyramid: fmaps[%d] is null", l);
   }
-  static const bool per_pixel = getenv("NS_ALTCORR_PER_PIXEL") != nullptr;  // comparison switch: wave-per-pixel kernel
+  static const bool per_pixel = ns_variant_env("NS_ALTCORR_PER_PIXEL") != nullptr;  // comparison switch: wave-per-pixel kernel
   if (per_pixel || E > 65535) {
     const long ntask = (long)E * H1 * W1;
     dim3 grid(ns_cdiv(ntask, 4 * ALT_PIX_PER_WAVE), num_levels);
@@ -1182,8 +1182,8 @@ extern "C" int ns_altcorr_pyramid_encode_f16(const void* const* fmaps_host, cons
     NS_REQUIRE(P.fmap[l] != nullptr && ((uintptr_t)P.fmap[l] % 16) == 0, "ns_altcorr_pyramid_encode_f16: fmaps[%d] null or not 16-byte aligned", l);
   }
   dim3 grid(((H1 + 7) / 8) * ((W1 + 7) / 8), E);
-  static const bool direct = getenv("NS_ALTCORR_DIRECT") != nullptr;   // A/B switch: fragments straight from global memory
-  static const bool no_xcd = getenv("NS_ALTCORR_NO_XCD") != nullptr;   // A/B switch: linear tile order
+  static const bool direct = ns_variant_env("NS_ALTCORR_DIRECT") != nullptr;   // A/B switch: fragments straight from global memory
+  static const bool no_xcd = ns_variant_env("NS_ALTCORR_NO_XCD") != nullptr;   // A/B switch: linear tile order
   if (direct) {
     hipLaunchKernelGGL(altcorr_tile_enc_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, (const h8_t*)wfrag, bias,
                        (_Float16*)out, E, H1, W1);
@@ -1214,8 +1214,8 @@ extern "C" int ns_altcorr_pyramid_f16(const void* const* fmaps_host, int num_lev
     NS_REQUIRE(P.fmap[l] != nullptr && ((uintptr_t)P.fmap[l] % 16) == 0, "ns_altcorr_pyramid_f16: fmaps[%d] null or not 16-byte aligned", l);
   }
   dim3 grid(((H1 + 7) / 8) * ((W1 + 7) / 8), num_levels, E);
-  static const bool no_xcd = getenv("NS_ALTCORR_NO_XCD") != nullptr;   // A/B switch: linear tile order
-  static const bool direct = getenv("NS_ALTCORR_DIRECT") != nullptr;   // A/B switch: fragments straight from global memory
+  static const bool no_xcd = ns_variant_env("NS_ALTCORR_NO_XCD") != nullptr;   // A/B switch: linear tile order
+  static const bool direct = ns_variant_env("NS_ALTCORR_DIRECT") != nullptr;   // A/B switch: fragments straight from global memory
   if (direct) {
     hipLaunchKernelGGL(altcorr_tile_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, out, E, H1, W1,
                        no_xcd ? 0 : 1);

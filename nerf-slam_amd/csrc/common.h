@@ -32,6 +32,16 @@ void ns_set_error(const char* fmt, ...);
 static inline int ns_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------
+// A/B switches.  The tools and a few tests select comparison kernels / tunings through NS_* environment variables.  They are
+// honoured ONLY when the master switch NS_VARIANTS is set as well: a stray NS_... in a site-wide environment can then not
+// silently change which kernel the product (or bench.py, which refuses to run with either set) launches.
+// ---------------------------------------------------------------------------------------------
+#include <stdlib.h>
+static inline const char* ns_variant_env(const char* name) {
+  return getenv("NS_VARIANTS") != nullptr ? getenv(name) : nullptr;     // (not cached: tests switch it on and off in one process)
+}
+
+// ---------------------------------------------------------------------------------------------
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which the compiler
 // implements as s_waitcnt vmcnt(0) lgkmcnt(0): every global load AND every global store of the wave has to be acknowledged
 // before the barrier -- a full memory round trip (~2-3 us on a busy chip) wherever a kernel has loads in flight for later use

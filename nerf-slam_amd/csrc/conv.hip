@@ -415,19 +415,19 @@ static int cv_run(const void* const* src_host, const int* src_channels_host, con
   int mt = cv_cout_tile(cout) / 32;
   NS_REQUIRE((long)N * ns_cdiv(H, 16) * ns_cdiv(W, 16) * (ns_conv_packed_cout(cout) / 32) < (1L << 31), "ns_conv_nhwc_f16: too many tiles");
   hipStream_t st = (hipStream_t)stream;
-  const char* cg_env = getenv("NS_CONV_CG");        // 1 | 2 waves per SIMD for the 128-cout tile (experiments)
+  const char* cg_env = ns_variant_env("NS_CONV_CG");        // 1 | 2 waves per SIMD for the 128-cout tile (experiments)
   const bool two = cg_env ? atoi(cg_env) == 2 : true;
   // 3x3, 128-cout tile, images taller than one 16-row tile: 32-row tiles (4 column tiles per wave, 128 accumulator
   // registers, still 2 waves per SIMD) -- twice the MFMAs per barrier and per LDS-DMA: 865 / 968 vs 791 / 872 TFLOP/s on
   // the two ConvGRU gates; the 1x1 launches are load-bound and lose (61 vs 49 us).  NS_CONV_UT=2|4 overrides (tests).
-  const char* ut_env = getenv("NS_CONV_UT");
+  const char* ut_env = ns_variant_env("NS_CONV_UT");
   bool tall = H > 16 && (ut_env ? atoi(ut_env) == 4 : ksize == 3);
   // Few images (the motion filter's single edge, the encoders' N = 1): a 60x80 map is 10 of the 32-row x 128-cout tiles -- 10
   // workgroups on 256 CUs, each walking the whole K loop alone (36 us for 448 -> 256).  Shrink the tile until the launch
   // has ~200 workgroups: first 16-row tiles, then 64- and 32-cout tiles (the packed weight layout does not depend on the
   // cout tile: [chunk][tap][COP / 32][lane]).  The slab is then staged once per cout tile, which is latency well spent
   // here and bandwidth wasted for E = 48 -- that case never gets here.  NS_CONV_MT = 1|2|4 forces the cout tile (tests).
-  const char* mt_env = getenv("NS_CONV_MT");
+  const char* mt_env = ns_variant_env("NS_CONV_MT");
   auto wgs = [&](int m, bool t) { return (long)N * ns_cdiv(H, t ? 32 : 16) * ns_cdiv(W, CV_TC) * (a.COP / (32 * m)); };
   if (mt_env) {
     const int f = atoi(mt_env);

@@ -569,7 +569,7 @@ extern "C" int ns_corr_lookup_pyramid_slots(const void* const* pyr_host, int num
     L.total_elems[l] = (long)(slot ? capacity : E) * HW1 * L.slice_elems[l];
     NS_REQUIRE(L.h2[l] > 0 && L.w2[l] > 0, "ns_corr_lookup_pyramid: level %d is empty", ll);
   }
-  static const bool one_lane = getenv("NS_LOOKUP_ONE_LANE") != nullptr;  // comparison switch: one lane per pixel
+  static const bool one_lane = ns_variant_env("NS_LOOKUP_ONE_LANE") != nullptr;  // comparison switch: one lane per pixel
   if (one_lane && slot == nullptr) {
     dim3 grid(ns_cdiv((long)E * HW1, 256), num_levels);
     hipLaunchKernelGGL(corr_lookup_pyramid_kernel, grid, dim3(256), 0, (hipStream_t)stream, L, coords,

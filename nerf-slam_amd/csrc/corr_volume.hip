@@ -548,7 +548,7 @@ extern "C" int ns_corr_volume_pyramid_slots(const void* fmap1, const void* fmap2
     return NS_OK;
   }
   dim3 grid(ns_cdiv(HW, 128), E, zs);
-  static const int mode = getenv("NS_VOL_NT") ? atoi(getenv("NS_VOL_NT")) : 2;  // tuning switch: widest column chunk
+  static const int mode = ns_variant_env("NS_VOL_NT") ? atoi(ns_variant_env("NS_VOL_NT")) : 2;  // tuning switch: widest column chunk
   if (mode >= 3) {
     hipLaunchKernelGGL((corr_volume_pyramid_kernel<128, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);
   } else if (mode == 2) {

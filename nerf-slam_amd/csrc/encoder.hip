@@ -15,7 +15,6 @@
 // All activations are f16 channels-last, statistics f32 partials combined in f64, eps and the biased variance are
 // InstanceNorm2d's defaults (extractor.py:133-144 builds it without affine parameters).
 #include "common.h"
-#include <atomic>
 
 typedef _Float16 en_f16x8 __attribute__((ext_vector_type(8)));
 
@@ -77,14 +76,14 @@ __global__ __launch_bounds__(256) void enc_im2col_3x3s2_kernel(const _Float16* _
 // grid (P, N); thread = (pixel group g = tid / C8, piece = tid % C8): 16-byte loads, whole rows coalesced.
 // ---------------------------------------------------------------------------------------------
 #define ENC_IN_MAXN 4096
-#define ENC_IN_SLOTS 32
-// arrivals per image; the last arrival resets its entry.  One row of counters per LAUNCH, handed out round-robin by the host
-// entry point: two statistics launches in flight at once (feature and context net on different streams, parallel graph
-// branches) then never share a counter unless 32 further launches were issued in between.
-__device__ unsigned int enc_in_ticket[ENC_IN_SLOTS][ENC_IN_MAXN];
+// Arrivals per image are counted in a row of N counters that the CALLER owns (zeroed once; the last arrival resets its entry):
+// nerfslam/encoder_op.py keeps one row per normalised layer of an encoder instance, so two statistics launches can only meet
+// on a counter if the same layer of the same encoder ran concurrently with itself -- which stream order (and the
+// serialisation of replays of one graph) rules out.  (Round 4 handed out rows of a global table round-robin at LAUNCH time; a
+// captured graph then baked one row into every replay)
 
 __global__ __launch_bounds__(256) void enc_in_stats_kernel(const _Float16* __restrict__ x, float* __restrict__ partial, int HW, int C8,
-                                                           int P, int slot) {
+                                                           int P, unsigned int* __restrict__ ticket) {
   __shared__ float red[4][2][128];
   __shared__ double ps[256], pq[256];
   __shared__ unsigned int s_ticket;
@@ -141,7 +140,7 @@ __global__ __launch_bounds__(256) void enc_in_stats_kernel(const _Float16* __res
   __syncthreads();
   if (tid == 0) {
     __threadfence();
-    s_ticket = atomicAdd(&enc_in_ticket[slot][n], 1u);
+    s_ticket = atomicAdd(&ticket[n], 1u);
     __threadfence();
   }
   __syncthreads();
@@ -165,7 +164,7 @@ __global__ __launch_bounds__(256) void enc_in_stats_kernel(const _Float16* __res
     }
     __syncthreads();
     if (tid < ncol) rows[tid] = (float)pq[tid];     // totals -> row 0 (every row has been read)
-    if (tid == 0) enc_in_ticket[slot][n] = 0u;
+    if (tid == 0) ticket[n] = 0u;
   }
 }
 
@@ -261,17 +260,16 @@ extern "C" int ns_enc_in_parts(int HW) {
   return p < 1 ? 1 : (p > 64 ? 64 : p);
 }
 
-extern "C" int ns_enc_in_stats(const void* x, float* partial, int N, int HW, int C, void* stream) {
+extern "C" int ns_enc_in_stats(const void* x, float* partial, unsigned int* ticket, int N, int HW, int C, void* stream) {
   if (N == 0) return NS_OK;
   NS_REQUIRE(x && partial, "ns_enc_in_stats: null pointer");
   NS_REQUIRE(N > 0 && N <= ENC_IN_MAXN && HW > 0 && (C == 32 || C == 64 || C == 128),
              "ns_enc_in_stats: bad shape (N %d <= 4096, HW %d, C %d: 32, 64 or 128 channels)", N, HW, C);
   NS_REQUIRE(((uintptr_t)x % 16) == 0, "ns_enc_in_stats: 16-byte alignment");
   const int P = ns_enc_in_parts(HW);
-  static std::atomic<unsigned> next_slot{0};
-  const int slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) % ENC_IN_SLOTS);
+  NS_REQUIRE(P == 1 || ticket, "ns_enc_in_stats: %d partial rows per image need the caller's arrival counters (N zeroed uint32)", P);
   hipLaunchKernelGGL(enc_in_stats_kernel, dim3(P, N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, partial, HW, C / 8, P,
-                     slot);
+                     ticket);
   NS_CHECK_LAUNCH("enc_in_stats_kernel");
   return NS_OK;
 }

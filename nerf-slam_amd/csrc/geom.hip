@@ -447,7 +447,7 @@ extern "C" int ns_cvx_upsample_keyframes_nhwc(const float* data_a, const float* 
 template <typename MT>
 static void cvx_launch(const float* data_a, const float* data_b, const int64_t* kx, const void* mask, float* out_a, float* out_b,
                        int n, int ht, int wd, float pow_, void* stream) {
-  if (sizeof(MT) == 2 && wd % 2 == 0 && getenv("NS_CVX_ONE_PIXEL") == nullptr) {
+  if (sizeof(MT) == 2 && wd % 2 == 0 && ns_variant_env("NS_CVX_ONE_PIXEL") == nullptr) {
     dim3 g2(ns_cdiv((long)ht * wd / 2, 64), 4, n);
     if (data_b)
       hipLaunchKernelGGL((cvx_upsample_h2_kernel<true>), g2, dim3(256), 0, (hipStream_t)stream, data_a, data_b, kx,

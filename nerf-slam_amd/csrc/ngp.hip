@@ -1086,14 +1086,14 @@ static int fused_dense_levels(const GridLayout& g, int n_levels, int dense_mode)
 }
 static int fused_dense_mode() {
   static const int mode = [] {
-    const char* e = getenv("NS_ENC_DENSE_BINNED");
+    const char* e = ns_variant_env("NS_ENC_DENSE_BINNED");
     return e != nullptr && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 2;
   }();
   return mode;
 }
 // wave-level merge of single-cell lanes (fb_wave_merge) on levels up to this resolution (dense levels always; NS_FB_MERGE_RES)
 static int fused_merge_res() {
-  static const int r = [] { const char* e = getenv("NS_FB_MERGE_RES"); return e ? atoi(e) : 0; }();
+  static const int r = [] { const char* e = ns_variant_env("NS_FB_MERGE_RES"); return e ? atoi(e) : 0; }();
   return r;
 }
 
@@ -2495,7 +2495,7 @@ extern "C" int ns_ngp_encode_forward_j_n(int n_levels, int n_features, int log2_
     int hashed[16], nh = 0;
     for (int l = n_levels - 1; l >= 0; l--)
       if ((uint64_t)g.res[l] * g.res[l] * g.res[l] > (uint64_t)(g.offset[l + 1] - g.offset[l])) hashed[nh++] = l;   // finest first
-    static const bool no_own = getenv("NS_ENC_FWD_NO_XCD") != nullptr;   // A/B: every level shared (round 2's access pattern)
+    static const bool no_own = ns_variant_env("NS_ENC_FWD_NO_XCD") != nullptr;   // A/B: every level shared (round 2's access pattern)
     const int n_own = no_own ? 0 : (nh < 8 ? nh : 8);
     for (int x = 0; x < 8; x++) sc.own[x] = x < n_own ? hashed[x] : -1;
     sc.n_shared = 0;
@@ -2600,9 +2600,9 @@ extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_h
     return NS_ENOSUP;
   }
   if (N <= 0) return NS_OK;
-  static const bool atomic_path = getenv("NS_ENC_BWD_ATOMIC") != nullptr;  // round-1 kernel, kept for A/B profiling
+  static const bool atomic_path = ns_variant_env("NS_ENC_BWD_ATOMIC") != nullptr;  // round-1 kernel, kept for A/B profiling
   if (!atomic_path) {
-    static const bool no_bins = getenv("NS_ENC_BWD_NO_BINS") != nullptr;   // A/B switch: owner-computes kernel on every level
+    static const bool no_bins = ns_variant_env("NS_ENC_BWD_NO_BINS") != nullptr;   // A/B switch: owner-computes kernel on every level
     BinPlan bp;
     bin_plan_host(g, n_levels, N, bp);
     const bool binned = workspace != nullptr && fixed_scale > 0.0f && bin_plan_ok(bp) && !no_bins &&
@@ -2610,10 +2610,10 @@ extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_h
     EncBwdPlan plan;
     // run-length kernel for the dense levels (NS_ENC_BWD_NO_RL=1: the one-sample-per-lane kernel, A/B runs); fewer, longer
     // parts: its tasks are bound by the scan of the samples, not by LDS atomics (NS_ENC_RL_PARTS=coarse,multi overrides)
-    static const bool no_rl = getenv("NS_ENC_BWD_NO_RL") != nullptr;
+    static const bool no_rl = ns_variant_env("NS_ENC_BWD_NO_RL") != nullptr;
     static int rl_pc = 16, rl_pm = 8;
     static const bool rl_env = [] {
-      const char* e = getenv("NS_ENC_RL_PARTS");
+      const char* e = ns_variant_env("NS_ENC_RL_PARTS");
       int a = 0, b = 0;
       if (e && sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= NS_ENC_PARTS_COARSE && b >= 1 && b <= NS_ENC_PARTS_COARSE) {
         rl_pc = a;
@@ -2768,7 +2768,7 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
   const long nd = (long)g.offset[n_rl];
   if (parts & 1) {
     const int vec = (N % 4 == 0 && ((uintptr_t)positions % 16) == 0 && ((uintptr_t)dLdoutT % 8) == 0) ? 1 : 0;
-    static const bool staged = [] { const char* e = getenv("NS_FB_SCATTER"); return e != nullptr && e[0] == '1'; }();
+    static const bool staged = [] { const char* e = ns_variant_env("NS_FB_SCATTER"); return e != nullptr && e[0] == '1'; }();
     if (staged) {
       hipLaunchKernelGGL(ngp_enc_fscatter_kernel, dim3(fp.ntiles, fp.nh), dim3(256), 0, st, g, fp, positions, (const _Float16*)dLdoutT,
                          N, fixed_scale, ctr, cnt, queue, ovf, n_dev, vec);
@@ -2792,7 +2792,7 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
   static int rl_pc = 16, rl_pm = 8;      // parts of the single-slice / multi-slice dense levels (NS_ENC_RL_PARTS=coarse,multi)
   static bool rl_set = false;
   static const bool rl_env = [] {
-    const char* e = getenv("NS_ENC_RL_PARTS");
+    const char* e = ns_variant_env("NS_ENC_RL_PARTS");
     int a = 0, b = 0;
     if (e && sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= NS_ENC_PARTS_COARSE && b >= 1 && b <= NS_ENC_PARTS_COARSE) {
       rl_pc = a;
@@ -2806,7 +2806,7 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
   //  32 workgroups take 130 us when nothing runs next to them)
   // NS_ENC_RL_HALF=1: 8192-entry slices in 512-thread workgroups (64 KB of LDS: they fit next to a scatter workgroup).  Measured:
   // training step unchanged (0.385-0.389 ms either way), all-live micro-bench 279 -> 311 us (twice the slices scan the samples).
-  static const bool half_slices = getenv("NS_ENC_RL_HALF") != nullptr;
+  static const bool half_slices = ns_variant_env("NS_ENC_RL_HALF") != nullptr;
   const int tasks = rl ? enc_bwd_plan_host(g, n_levels, plan, true, dense_too && !rl_set ? NS_ENC_PARTS_COARSE : rl_pc, rl_pm, n_rl,
                                            half_slices ? NS_ENC_SLICE / 2 : NS_ENC_SLICE)
                        : enc_bwd_plan_host(g, n_levels, plan, true, NS_ENC_PARTS_COARSE, NS_ENC_PARTS_BINNED, n_rl);

@@ -1113,10 +1113,13 @@ __global__ __launch_bounds__(256) void ngp_mlp_step_kernel(MlpStepArgs a) {
 
 // slabs the weight-gradient launch of ns_ngp_mlp_wgrad_recompute_n / _partials_n fills for a workspace of `wgs` slabs
 static int wgrad_slabs(int wgs, long N, bool& staged) {
-  static const bool st = [] { const char* e = getenv("NS_NGP_WGRAD"); return e != nullptr && e[0] == 's'; }();
-  staged = st;
-  if (st) return wgs;
-  static const int cus = [] { const char* e = getenv("NS_NGP_WGRAD_WGS"); return e ? atoi(e) : 64; }();
+  static const bool st = [] { const char* e = ns_variant_env("NS_NGP_WGRAD"); return e != nullptr && e[0] == 's'; }();
+  // The matrix-core kernel fetches WHOLE 32-sample tiles of featT [32, N] (values past the live count are masked, the loads
+  // are not): with a row stride that is not a multiple of the tile, the last tile of the last row would read past the array
+  // (ADVICE r04).  Such budgets (the trainer's 2^18 never is one) take the staged kernel, which loads per 8 samples.
+  staged = st || (N % 32 != 0);
+  if (staged) return wgs;
+  static const int cus = [] { const char* e = ns_variant_env("NS_NGP_WGRAD_WGS"); return e ? atoi(e) : 64; }();
   const long tiles4 = (N / 32 + 3) / 4;
   return (int)std::max(1L, std::min((long)std::min(wgs, cus), tiles4));
 }

@@ -53,6 +53,14 @@ def lib():
     return _lib
 
 
+def variant_env(name, default=None):
+    """A/B switches of the tools (NS_* environment variables) are honoured ONLY together with the master switch NS_VARIANTS
+    (csrc/common.h: ns_variant_env does the same for the library): a stray variable cannot silently change what the product runs."""
+    if os.environ.get("NS_VARIANTS") is None:
+        return default
+    return os.environ.get(name, default)
+
+
 def check(status, what):
     if status != 0:
         msg = lib().ns_last_error().decode("utf-8", "replace")

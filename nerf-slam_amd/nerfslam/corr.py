@@ -14,7 +14,7 @@ import os as _os
 
 import torch
 
-from ._lib import NerfSlamHipError, check, lib, ptr, require_cuda, stream_ptr
+from ._lib import NerfSlamHipError, check, lib, ptr, require_cuda, stream_ptr, variant_env
 
 
 class CorrBlock:
@@ -272,7 +272,7 @@ class AltCorrBlock:
         # in that dtype; only the kernel call casts to float, :121).  Half features (what RaftVisualFrontend holds,
         # visual_frontend.py:209) therefore give a HALF pyramid, rounded to half after every pooling -- kept that way here and
         # correlated on the matrix cores (csrc/altcorr.hip: altcorr_tile_mfma_kernel); anything else takes the f32 kernels.
-        self.half = fmaps.dtype == torch.float16 and Cc == 128 and not _os.environ.get("NS_ALTCORR_F32")
+        self.half = fmaps.dtype == torch.float16 and Cc == 128 and not variant_env("NS_ALTCORR_F32")
         level = fmaps.reshape(N, Cc, H, W)
         level = (level / 4.0) if self.half else (level.float() / 4.0)  # corr.py:98
         self.pyramid = []

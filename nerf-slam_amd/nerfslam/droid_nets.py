@@ -191,7 +191,8 @@ class DroidNetworks:
             self.fnet_h = copy.deepcopy(self.net.feature_net).half()
             self.cnet_h = copy.deepcopy(self.net.context_net).half()
             # both encoders on the MFMA convolution (nerfslam/encoder_op.py); NS_TORCH_ENCODERS=1 keeps the MIOpen path (A/B runs)
-            if (hip_encoders is None and not os.environ.get("NS_TORCH_ENCODERS")) or hip_encoders:
+            from ._lib import variant_env
+            if (hip_encoders is None and not variant_env("NS_TORCH_ENCODERS")) or hip_encoders:
                 from .encoder_op import HipEncoder
                 self.fnet_hip = HipEncoder(self.net.feature_net, True, self.MEAN, self.STD)
                 self.cnet_hip = HipEncoder(self.net.context_net, False, self.MEAN, self.STD)

@@ -21,6 +21,7 @@ from ._lib import NerfSlamHipError, check, graph_capture, lib, ptr, require_cuda
 from .conv import PackedConv
 
 EPS = 1e-5   # nn.InstanceNorm2d default
+MAX_STAT_LAUNCHES, MAX_IMAGES = 32, 4096    # rows / columns of an encoder's arrival counters (BasicEncoder: 17 launches; csrc ENC_IN_MAXN)
 
 
 def _half_out(n):
@@ -55,12 +56,22 @@ class HipEncoder:
         self.std = (C.c_float * 3)(*[float(v) for v in std])
         self.use_graph = bool(use_graph)
         self._graphs = {}            # (N, H, W, dtype) -> (graph, static image, static output)
+        self._tickets = None         # [statistics launches per call, N] int32 arrival counters of enc_in_stats (zeroed once)
+        self._stat_calls = 0
 
     # ---- the pieces ----
     def _stats(self, y):
         N, H, W, Cc = y.shape
         part = torch.empty((N, int(lib().ns_enc_in_parts(H * W)), 2, Cc), dtype=torch.float32, device=y.device)
-        check(lib().ns_enc_in_stats(ptr(y), ptr(part), N, H * W, Cc, stream_ptr()), "enc_in_stats")
+        # arrival counters: one row per statistics launch of a call (csrc/encoder.hip) -- rows are handed out in call order, so
+        # a row is only ever reused by the SAME layer of this encoder, which stream order keeps apart (also under graph replay)
+        k = self._stat_calls
+        self._stat_calls += 1
+        if self._tickets is None or self._tickets.device != y.device:
+            self._tickets = torch.zeros((MAX_STAT_LAUNCHES, MAX_IMAGES), dtype=torch.int32, device=y.device)   # 512 KB, once
+        if k >= MAX_STAT_LAUNCHES or N > MAX_IMAGES:
+            raise NerfSlamHipError(f"HipEncoder: {k + 1} statistics launches / {N} images in one call (limits {MAX_STAT_LAUNCHES} / {MAX_IMAGES})")
+        check(lib().ns_enc_in_stats(ptr(y), ptr(part), ptr(self._tickets[k]), N, H * W, Cc, stream_ptr()), "enc_in_stats")
         return part
 
     def _apply(self, y, ystats, x=None, xstats=None):
@@ -95,6 +106,7 @@ class HipEncoder:
 
     def _forward(self, img):
         N, _, H, W = img.shape
+        self._stat_calls = 0
         patches = torch.empty((N, _half_out(H), _half_out(W), 160), dtype=torch.float16, device=img.device)
         check(lib().ns_enc_stem_im2col(ptr(img), 1 if img.dtype == torch.uint8 else 0, ptr(patches), N, H, W, self.mean, self.std,
                                        stream_ptr()), "enc_stem_im2col")

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import ba_plan, se3
-from ._lib import capture_lock, check, lib, ptr, stream_ptr
+from ._lib import capture_lock, check, lib, ptr, stream_ptr, variant_env
 from .corr import CorrPool
 from .factor_graph import FactorGraph
 
@@ -221,7 +221,7 @@ class TrackingFrontend:
         coords1 = self.reproject(self.ii, self.jj)                                    # [E,ht,wd,2]
         motion = self.motion_features(coords1, self.target)
         enc = getattr(getattr(self.update_op, "__self__", None), "corr_encoder", None)
-        if enc is not None and not os.environ.get("NS_LOOKUP_UNFUSED"):
+        if enc is not None and not variant_env("NS_LOOKUP_UNFUSED"):
             corr = self.corr.lookup_encoded(coords1[None], self.slots_dev, enc)       # lookup + Conv2d(196,128,1) + ReLU, one launch
         else:
             corr = self.corr.lookup(coords1[None], self.slots_dev)                    # [1,E,196,ht,wd]

@@ -17,7 +17,7 @@ from dataclasses import dataclass
 
 import torch
 
-from ._lib import NerfSlamHipError, check, lib, ptr, stream_ptr
+from ._lib import NerfSlamHipError, check, lib, ptr, stream_ptr, variant_env
 
 MLP_SHAPES = [(64, 32), (16, 64), (64, 32), (64, 64), (16, 64)]
 MLP_OFFS = [0, 2048, 3072, 5120, 9216]
@@ -173,14 +173,14 @@ class NgpNerf:
         self.act = [torch.zeros((u, S), **h) for u in (64, 32, 64, 64)]         # h1T cinT h3T h4T
         self.dact = [torch.zeros((u, S), **h) for u in (16, 64, 64, 16, 64)]    # d5T d4T d3T ddT d1T
         self.partial = torch.zeros((c.wgrad_ksplit, MLP_TOTAL), **f)
-        self.mlp_wgs = int(os.environ.get("NS_NGP_MLP_WGS", "512"))     # workgroups (= partial weight-gradient slabs) of the weight-gradient kernel (384 .. 1024 measured: within 2 %)
+        self.mlp_wgs = int(variant_env("NS_NGP_MLP_WGS", "512"))     # workgroups (= partial weight-gradient slabs) of the weight-gradient kernel (384 .. 1024 measured: within 2 %)
         self.relu_masks = torch.zeros(6 * S, dtype=torch.int32, device=dev)     # one bit per hidden unit and sample (csrc/ngp_mlp.hip)
         # Table gradient.  One trainer: the round-3 path (csrc/ngp.hip: no count pass, Adam applied to the touched entries in
         # the flush of the accumulation; the gradient buffer is not used).  Replicated trainers: gradient buffer + all-reduce
         # + streaming Adam, so the binned path that writes the buffer keeps its own workspace.
-        self.fused_adam = not self.replicated and c.grad_fixed_scale > 0 and not os.environ.get("NS_NGP_TWO_PASS_ADAM")
+        self.fused_adam = not self.replicated and c.grad_fixed_scale > 0 and not variant_env("NS_NGP_TWO_PASS_ADAM")
         self.enc_ws_bytes = int(lib().ns_ngp_encode_backward_fused_workspace_bytes(*self._grid_args(), C.c_long(c.max_samples)))
-        self.fused_ws = c.grad_fixed_scale > 0 and self.enc_ws_bytes > 0 and not os.environ.get("NS_NGP_R02_BACKWARD")
+        self.fused_ws = c.grad_fixed_scale > 0 and self.enc_ws_bytes > 0 and not variant_env("NS_NGP_R02_BACKWARD")
         if self.fused_ws:
             self.enc_ws = torch.zeros(self.enc_ws_bytes // 8 + 1, dtype=torch.int64, device=dev)   # zeroed once: overflow counter
         else:
@@ -376,8 +376,10 @@ class NgpNerf:
         #  same swap in the second step of a paired graph only: 0.43 -> 0.50 ms)
         # (round 4: the next step's rays go to the THIRD stream, which is idle until the pose chain forks after the activation
         #  gradients; on `side` the march (~95 us of latency-bound work in a handful of waves) held the weight-gradient kernel back
-        #  until the scatter had filled the CUs, and that kernel needs whole SIMDs.  NS_NGP_RAYS_ON_SIDE=1: round 3's placement)
-        ray_stream = self._side if os.environ.get("NS_NGP_RAYS_ON_SIDE") else self._side2
+        #  until the scatter had filled the CUs, and that kernel needs whole SIMDs.  The A/B switches that moved this branch and
+        #  the pose chain back to `side` are gone: with the rays on one side stream and the pose step on the other,
+        #  the next step's ray sampling read c2w unordered against camera_step's write.  Both sit on `side2`, in stream order.)
+        ray_stream = self._side2
         ray_stream.wait_stream(main)
         with torch.cuda.stream(ray_stream):
             check(L.ns_ngp_step_prepare(ptr(X["ctl"]), ptr(Y["ctl"]), ptr(X["counter"]), ptr(Y["counter"]), ptr(self.last),
@@ -391,7 +393,7 @@ class NgpNerf:
         n_dev = C.c_void_p(X["counter"].data_ptr() + 8)
         featT = self.s_feat.view(-1)[:32 * S].view(32, S)
         jac = None
-        if c.optimize_extrinsics and not os.environ.get("NS_NGP_POSE_GATHER"):
+        if c.optimize_extrinsics and not variant_env("NS_NGP_POSE_GATHER"):
             # the forward pass also writes d(feature)/d(position): the pose refinement's input gradient is then a dot product
             if getattr(self, "s_jac", None) is None:
                 self.s_jac = torch.zeros((6 * c.n_levels, S), dtype=torch.float16, device=dev)
@@ -407,7 +409,7 @@ class NgpNerf:
         # stores on this stream + the weight gradients recomputed on chip on a side stream next to the table gradient; "fused" =
         # everything in one kernel on this stream (NS_NGP_MLP=fused); "r3a" = round 3's first form, separate weight-gradient kernel
         # over stored activations / gradients (NS_NGP_MLP=r3a)
-        mlp_mode = os.environ.get("NS_NGP_MLP", "split")
+        mlp_mode = variant_env("NS_NGP_MLP", "split")
         if mlp_mode != "r3a" and getattr(self, "partial_fused", None) is None:     # (first step after construction: eager)
             self.partial_fused = torch.zeros((self.mlp_wgs, MLP_TOTAL), dtype=torch.float32, device=dev)
             # the weights in MFMA operand order (forward + transposed fragments), TWO tables: step k reads table k & 1 and its
@@ -519,7 +521,7 @@ class NgpNerf:
                       "ngp_mlp_wgrad_partials")
                 mark("ngp_mlp_wgrad_tr_kernel")
                 slabs = int(L.ns_ngp_mlp_wgrad_slabs(self.mlp_wgs, C.c_long(S)))
-                if single and not os.environ.get("NS_NGP_MLP_STEP_UNFUSED"):
+                if single and not variant_env("NS_NGP_MLP_STEP_UNFUSED"):
                     # the MLP's optimiser step in one launch: slab reduce + Adam + f16 copy + both fragment tables (the zero rows
                     # of the tables were written once by the pack above)
                     check(L.ns_ngp_mlp_step_fused(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), ptr(self.mlp_master),
@@ -566,14 +568,17 @@ class NgpNerf:
         #  form of the pose gradient no third stream either)
         dense_pass = self.fused_ws and int(L.ns_ngp_encode_backward_fused_dense_levels(*self._grid_args())) > 0
         # the pose refinement's chain (Jacobian dot, camera gradient, reduce, pose step: ~45 us of small kernels) runs on the third
-        # stream, next to the weight-gradient chain of `side` instead of behind it (NS_NGP_POSE_ON_SIDE=1: round 3's placement)
-        pose_on_side2 = pose and not gather_pose and not os.environ.get("NS_NGP_POSE_ON_SIDE")
+        # stream, next to the weight-gradient chain of `side` instead of behind it, and in stream order behind the ray sampling
+        # of the next step that reads the poses it rewrites
+        pose_on_side2 = pose and not gather_pose
         use_side2 = gather_pose or dense_pass or pose_on_side2 or ray_stream is self._side2
         if gather_pose or dense_pass or pose_on_side2:
             with torch.cuda.stream(self._side2):
                 self._side2.wait_event(fork)
                 if gather_pose:                      # reads the f16 table: before anything rewrites it
                     table_read = pose_gradient(stream_ptr())
+                    if single:                       # (same stream as the next step's ray sampling, which reads the poses)
+                        camera_step(stream_ptr())
                 if dense_pass:
                     table_gradient(4, stream_ptr())
                     table_gradient(8, stream_ptr())
@@ -592,10 +597,6 @@ class NgpNerf:
                       "ngp_mlp_wgrad")
             if single and mlp_mode != "split":
                 mlp_adam(st1)
-            if pose and not gather_pose and not pose_on_side2:
-                pose_gradient(st1)
-            if pose and single and not pose_on_side2:
-                camera_step(st1)
         if use_side2:
             main.wait_stream(self._side2)
         main.wait_stream(self._side)
@@ -630,7 +631,7 @@ class NgpNerf:
         two graph launches (join, launch, fork: 25-35 us on the device) is paid once per pair."""
         c = self.cfg
         i = 0
-        chain = int(os.environ.get("NS_NGP_CHAIN", "2"))      # steps per chained graph (even).  4 / 8 / 16 measured: 0.438 ->
+        chain = int(variant_env("NS_NGP_CHAIN", "2"))      # steps per chained graph (even).  4 / 8 / 16 measured: 0.438 ->
                                                               # 0.434 / 0.427 / 0.433 ms, inside the box-to-box spread: a pair it is
         while i < n:
             if n - i >= 2 and self._pair_ready():
@@ -663,7 +664,7 @@ class NgpNerf:
 
     def _pair_ready(self):
         c = self.cfg
-        if self.replicated or not c.use_graph or os.environ.get("NS_NGP_NO_PAIR") or self.n_images == 0:
+        if self.replicated or not c.use_graph or variant_env("NS_NGP_NO_PAIR") or self.n_images == 0:
             return False
         if not getattr(self, "_static", False) or not self._primed or self.cur != 0:
             return False
@@ -693,7 +694,7 @@ class NgpNerf:
                 X["loss"].zero_()
                 self._enqueue_rays(X)
                 self._primed = True
-            if self.replicated and c.use_graph and not os.environ.get("NS_NGP_REPL_EAGER"):
+            if self.replicated and c.use_graph and not variant_env("NS_NGP_REPL_EAGER"):
                 self._replicated_step(x)
             elif self.replicated or not c.use_graph or getattr(self, "_probe", None) is not None:
                 self._enqueue_step(x)
@@ -868,9 +869,9 @@ class NgpNerf:
         G, nc = c.grid_size, c.n_cascades
         G3 = G ** 3
         total = nc * G3
-        if n_cells is None and os.environ.get("NS_NGP_GRID_RULE", c.grid_rule) == "subset":
+        if n_cells is None and variant_env("NS_NGP_GRID_RULE", c.grid_rule) == "subset":
             n_cells = 1 << 18
-        if n_cells is not None and not os.environ.get("NS_NGP_GRID_TORCH"):
+        if n_cells is not None and not variant_env("NS_NGP_GRID_TORCH"):
             # the subset rule on the HIP kernels (csrc/ngp.hip, "occupancy-grid refresh"): 7 launches, no allocation
             n = min(int(n_cells), total) & ~1
             ws = getattr(self, "_grid_ws", None)
@@ -889,7 +890,7 @@ class NgpNerf:
                   "ngp_encode_forward")
             check(L.ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(feat), ptr(dirs), ptr(out), nul, nul, nul, nul, C.c_long(n), st),
                   "ngp_mlp_forward")
-            if os.environ.get("NS_NGP_GRID_DECAY_ALL", "1" if c.grid_decay_all else "") not in ("", "0"):
+            if variant_env("NS_NGP_GRID_DECAY_ALL", "1" if c.grid_decay_all else "") not in ("", "0"):
                 # (fading all cells at instant-ngp's 0.95 with 4 % of the grid drawn would empty the grid 12 x
                 #  faster than the rule it stands in for; not fading the undrawn cells at all leaves floaters for ever)
                 decay_all = float(c.grid_decay) ** min(1.0, n / (0.5 * total))

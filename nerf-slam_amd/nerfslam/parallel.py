@@ -115,8 +115,15 @@ def shard_size(n_entries, world):
 
 def _device_collectives(group=None):
     """True when the group's backend runs all-to-all / all-gather on device tensors (nccl = RCCL).  Decided from the backend
-    name, once per call and never from a caught exception: a failing RCCL collective must surface as what it is."""
-    return str(dist.get_backend(group)).lower() == "nccl"
+    name ('nccl' anywhere in it: a group created without an explicit backend reports 'cpu:gloo,cuda:nccl'), once per call and
+    never from a caught exception; an unknown backend raises instead of silently staging through the host: a failing RCCL collective must surface as what it is."""
+    name = str(dist.get_backend(group)).lower()
+    if "nccl" in name:           # "nccl", or a per-device map such as "cpu:gloo,cuda:nccl": device tensors go to RCCL
+        return True
+    if name == "gloo":
+        return False
+    raise RuntimeError(f"nerfslam.parallel: process-group backend {name!r} is neither RCCL ('nccl') nor 'gloo'; refusing to "
+                       "fall back to host staging silently")
 
 
 def exchange_sharded(send, recv, out_shard, group=None):

@@ -22,7 +22,7 @@ import os
 import numpy as np
 import torch
 
-from ._lib import capture_lock
+from ._lib import capture_lock, variant_env
 from .corr import AltCorrBlock, CorrBlock
 from .frontend import TrackingFrontend
 
@@ -269,7 +269,7 @@ class TrackingSLAM:
                         # (networks that advertise `corr_encoder` get the correlation with the encoder's 1x1 convolution + ReLU
                         #  already applied, in one launch: the 196 f32 planes per edge are never written)
                         enc = getattr(self.net, "corr_encoder", None)
-                        if enc is not None and corr_op.half and not os.environ.get("NS_LOOKUP_UNFUSED"):
+                        if enc is not None and corr_op.half and not variant_env("NS_LOOKUP_UNFUSED"):
                             corr = corr_op.encoded(coords1[None, v], iv, jv, enc)
                         else:
                             corr = corr_op(coords1[None, v], iv, jv)
@@ -312,12 +312,17 @@ class TrackingSLAM:
         src = np.unique(ii_h)
         mine = np.isin(src, np.unique(ii_h[own]))
         idx = torch.from_numpy(src).to(self.device)
-        m = torch.from_numpy(mine.astype(np.float32)).to(self.device)[:, None, None]
+        m = torch.from_numpy(mine).to(self.device)
         for buf in (fe.damping, fe.cam0_idepths_up, fe.cam0_depths_cov_up):
-            rows = buf[idx] * m.to(buf.dtype)
+            # a SELECT, not a multiply: a stale non-finite value in a non-owner's row (inf * 0 = NaN) must not reach the sum
+            rows = torch.where(m[:, None, None], buf[idx], torch.zeros((), dtype=buf.dtype, device=self.device))
             dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=group)
             buf[idx] = rows
-        fe.has_up[idx] = True
+        # a frame has upsampled maps only if its OWNER upsampled it (an update operator without an upmask leaves has_up unset
+        # and get_viz_out falls back to the bilinear maps): the flag travels owner-masked like the rows above
+        up = (fe.has_up[idx] & m).to(torch.int32)
+        dist.all_reduce(up, op=dist.ReduceOp.SUM, group=group)
+        fe.has_up[idx] = up > 0
 
     def terminate(self):
         """:1309-1335"""

@@ -53,6 +53,33 @@ def main():
     parallel.allreduce_reduced_system(H, v, None)
     ok["allreduce_reduced_system"] = bool(torch.equal(H, H0) and torch.equal(v, v0))
 
+    # ---- the same two collectives TIMED at the sizes of the default grid: one trainer's packed gradient is
+    #      12.6 M int64 words = 100 MB through the all-to-all, the f16 table 25 MB through the all-gather.  With one rank nothing
+    #      crosses xGMI -- the figures are the RCCL call's device-side floor (a copy) that the first N-GPU run is compared with.
+    def timed(fn, n=10):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    Nw = 12_582_912                                                      # 2 x 6.29 M table entries, one 64-bit word per pair
+    big_send = torch.randint(-2 ** 40, 2 ** 40, (Nw,), generator=g, dtype=torch.int64).to(dev)
+    big_recv = torch.zeros((1, Nw), dtype=torch.int64, device=dev)
+    big_out = torch.zeros(Nw, dtype=torch.int64, device=dev)
+    ms_a2a = timed(lambda: parallel.exchange_sharded(big_send, big_recv, big_out, None))
+    table = torch.randn(Nw, generator=g).half().to(dev)
+    ms_ag = timed(lambda: parallel.gather_shards(table, 0, None))
+    ok["timed_exchange_values"] = bool(torch.equal(big_out, big_send))
+    res["timed_self_exchange"] = {
+        "int64_all_to_all": {"bytes": Nw * 8, "ms": ms_a2a, "GBps": Nw * 8 / ms_a2a * 1e-6},
+        "f16_all_gather": {"bytes": Nw * 2, "ms": ms_ag, "GBps": Nw * 2 / ms_ag * 1e-6},
+        "note": "one rank: device-side cost of the RCCL entry points + the shard sum / clone around them, no bytes on xGMI; at R "
+                "trainers each moves bytes x (R-1)/R per step over R-1 links at once",
+    }
+    del big_send, big_recv, big_out, table
+
     # ---- nerfslam.transport: the SLAM -> mapper packet ----
     from test_transport import _make_packet
     pkt = {k: (t.to(dev) if isinstance(t, torch.Tensor) else t) for k, t in _make_packet(3, 48, 64).items()}
@@ -83,9 +110,10 @@ def main():
 
     def train(replicated, steps, eager=False):
         if eager:
-            os.environ["NS_NGP_REPL_EAGER"] = "1"
+            os.environ["NS_VARIANTS"] = os.environ["NS_NGP_REPL_EAGER"] = "1"     # (switches count only with the master one)
         else:
             os.environ.pop("NS_NGP_REPL_EAGER", None)
+            os.environ.pop("NS_VARIANTS", None)
         net = NgpNerf(NgpConfig(n_rays=2048, max_samples=1 << 17, optimize_extrinsics=True), dev, seed=0,
                       group=dist.group.WORLD if replicated else None, replicated=replicated)
         net.set_images(*scene)

@@ -43,9 +43,11 @@ def _case(dev, N, H, W, chans, cout, k, act, per_image_bias=False, out_stride=No
 @pytest.fixture(params=[2, 4])
 def ut(request):
     """both pixel-tile variants of the 128-cout kernels (16- and 32-row tiles; NS_CONV_UT is read at every launch)"""
+    os.environ["NS_VARIANTS"] = "1"            # A/B switches count only together with the master switch (csrc/common.h)
     os.environ["NS_CONV_UT"] = str(request.param)
     yield request.param
     os.environ.pop("NS_CONV_UT", None)
+    os.environ.pop("NS_VARIANTS", None)
 
 
 @pytest.fixture(params=[None, 1, 2])
@@ -53,9 +55,11 @@ def mt(request):
     """the cout tile: None = the launch heuristic (128-cout tiles unless the launch would have < 200 workgroups), 1 | 2 = forced
     32- / 64-cout tiles (what a single-edge launch gets)"""
     if request.param is not None:
+        os.environ["NS_VARIANTS"] = "1"
         os.environ["NS_CONV_MT"] = str(request.param)
     yield request.param
     os.environ.pop("NS_CONV_MT", None)
+    os.environ.pop("NS_VARIANTS", None)
 
 
 def test_single_image_launches(dev, mt):

@@ -97,9 +97,11 @@ def test_instance_norm_pieces_against_torch(dev):
         y = (torch.randn((N, H, W, Cc), generator=g) * 1.7 + 0.4).half().to(dev)
         x = torch.randn((N, H, W, Cc), generator=g).half().to(dev)
         P = int(lib().ns_enc_in_parts(H * W))
+        tickets = torch.zeros((N,), dtype=torch.int32, device=dev)       # caller-owned arrival counters: zero before, zero after
         def stats(t):
             p = torch.empty((N, P, 2, Cc), dtype=torch.float32, device=dev)
-            check(lib().ns_enc_in_stats(ptr(t), ptr(p), N, H * W, Cc, stream_ptr()), "stats")
+            check(lib().ns_enc_in_stats(ptr(t), ptr(p), ptr(tickets), N, H * W, Cc, stream_ptr()), "stats")
+            assert int(tickets.abs().sum()) == 0
             return p
         def apply(y, ys, x, xs):
             o = torch.empty_like(y)

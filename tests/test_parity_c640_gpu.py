@@ -92,13 +92,7 @@ def test_coop_lookup_bitexact_at_baseline_shape(oracle_mod, dev, tiled):
     blk = CorrBlock.from_pyramid(pyr, tiled=tiled, hw=(ht, wd))
     vols = [v.cpu().numpy() for v in (blk.untiled() if tiled else blk.corr_pyramid)]
     assert [v.shape for v in vols] == [(E, ht, wd, ht >> l, wd >> l) for l in range(4)]
-    _, coords = synth.lookup_inputs(E, ht, wd, seed=48, oob_frac=0.05, levels=0)
-    coords[0, 0, 0] = [-2.5, -2.25]
-    coords[-1, -1, -1] = [wd + 1.5, ht + 0.75]
-    coords[3, 10, 10] = [wd - 0.5, ht - 0.5]
-    coords[5, 1, 1] = [1e9, 3.0]
-    coords[5, 1, 2] = [3.0, -np.inf]
-    coords[7, 2, 2] = [np.nan, 1.0]
+    coords = _c640_lookup_coords(E, ht, wd)
     out = blk(torch.from_numpy(coords).to(dev)[None])[0].cpu().numpy()
     assert out.shape == (E, 196, ht, wd)
     cf = np.ascontiguousarray(coords.transpose(0, 3, 1, 2))
@@ -111,6 +105,66 @@ def test_coop_lookup_bitexact_at_baseline_shape(oracle_mod, dev, tiled):
     oob = (coords[..., 0] < -8) | (coords[..., 0] > wd + 8) | (coords[..., 1] < -8) | (coords[..., 1] > ht + 8)
     assert 0.03 < oob.mean() < 0.08
     assert (out.transpose(0, 2, 3, 1)[oob] == 0).all()
+
+
+def _c640_lookup_coords(E, ht, wd):
+    """the coordinate set of the bit-exactness test above: 5 % far out of bounds, border-straddling, NaN / inf"""
+    _, coords = synth.lookup_inputs(E, ht, wd, seed=48, oob_frac=0.05, levels=0)
+    coords[0, 0, 0] = [-2.5, -2.25]
+    coords[-1, -1, -1] = [wd + 1.5, ht + 0.75]
+    coords[3, 10, 10] = [wd - 0.5, ht - 0.5]
+    coords[5, 1, 1] = [1e9, 3.0]
+    coords[5, 1, 2] = [3.0, -np.inf]
+    coords[7, 2, 2] = [np.nan, 1.0]
+    return coords
+
+
+def test_fused_lookup_encoder_at_baseline_shape(oracle_mod, dev):
+    """corr_lookup_enc_kernel -- the PRODUCT DEFAULT of the c640 path (lookup of correlation_kernels.cu:20-70 x 4 levels +
+    Conv2d(196,128,1) + ReLU of droid_net.py:83-87 in one launch) -- on the exact E=48 / 60x80 / 5 %-OOB / border / NaN / inf
+    coordinate set the unfused kernel is held to above, through slot-permuted pooled volumes.
+    Chain of evidence: the ORACLE's four per-level lookups of the device-built volumes (bit-exact to the unfused kernel, asserted
+    again here) -> the layer evaluated in float64 on those 196 planes -> the fused output within one f16 rounding of it
+    (f32 MFMA accumulation, one rounding to half; same bound as test_lookup_fused_with_the_correlation_encoder).  Pixels whose
+    window lies wholly outside the volume must give exactly relu(bias)."""
+    from nerfslam.corr import CorrPool
+    from nerfslam.update_op import CorrEncoderWeights
+    ht, wd, E, nfr = 60, 80, 48, 16
+    g = torch.Generator().manual_seed(640)
+    bank = (torch.randn((nfr, ht * wd, 128), generator=g) / 4.0).half().to(dev)
+    ii = torch.randint(0, nfr, (E,), generator=g).to(dev)
+    jj = torch.randint(0, nfr, (E,), generator=g).to(dev)
+    pool = CorrPool(ht, wd, E + 5, dev)
+    slots = torch.randperm(E + 5, generator=g)[:E].to(torch.int32).to(dev)
+    pool.build(bank, bank, ii, jj, slots)
+    coords = _c640_lookup_coords(E, ht, wd)
+    cd = torch.from_numpy(coords).to(dev)[None]
+    W = (torch.randn((128, 196, 1, 1), generator=g) / 14.0).to(dev)
+    b = (0.1 * torch.randn(128, generator=g)).to(dev)
+    fused = pool.lookup_encoded(cd, slots, CorrEncoderWeights(W, b)).c1
+    assert fused.shape == (E, ht, wd, 128) and fused.dtype == torch.float16 and torch.isfinite(fused).all()
+    # oracle lookup of the same volumes
+    vols = [v.cpu().numpy() for v in pool.block(slots).corr_pyramid]
+    assert [v.shape for v in vols] == [(E, ht, wd, ht >> l, wd >> l) for l in range(4)]
+    cf = np.ascontiguousarray(coords.transpose(0, 3, 1, 2))
+    cf = np.where(np.isfinite(cf), cf, np.float32(-1e5))
+    ref = np.concatenate([oracle_mod.corr_index_forward(vols[l], cf / np.float32(2 ** l), 3).reshape(E, 49, ht, wd)
+                          for l in range(4)], 1)
+    look = pool.lookup(cd, slots)[0].cpu().numpy()
+    assert ((look.view(np.uint16) == ref.view(np.uint16)) | ((look == 0) & (ref == 0))).all()
+    x = torch.from_numpy(ref.astype(np.float64)).permute(0, 2, 3, 1)                       # [E,ht,wd,196]
+    want = torch.relu(x @ W.half().double().cpu().reshape(128, 196).t() + b.double().cpu())
+    scale = float(want.abs().max())
+    err = (fused.cpu().double() - want).abs()
+    assert float(err.max()) <= 1.5e-3 * scale + 1e-3, (float(err.max()), scale)
+    # per-element: within one f16 ulp of the float64 value (+ the f32 accumulation error of 196 products)
+    ulp = np.spacing(want.numpy().astype(np.float16)).astype(np.float64)
+    assert (err.numpy() <= ulp + 2e-3).all()
+    oob = (coords[..., 0] < -8) | (coords[..., 0] > wd + 8) | (coords[..., 1] < -8) | (coords[..., 1] > ht + 8)
+    oob |= ~np.isfinite(coords).all(-1)
+    assert 0.03 < oob.mean() < 0.08
+    rb = torch.relu(b).half().cpu()
+    assert torch.equal(fused.cpu()[torch.from_numpy(oob)], rb.expand(int(oob.sum()), 128))
 
 
 @pytest.mark.parametrize("tiled", [True, False])

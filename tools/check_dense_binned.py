@@ -10,7 +10,7 @@ import torch
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(root, "nerf-slam_amd")]
-os.environ["NS_ENC_DENSE_BINNED"] = "1"
+os.environ["NS_VARIANTS"] = os.environ["NS_ENC_DENSE_BINNED"] = "1"
 from nerfslam._lib import check, lib, ptr, stream_ptr  # noqa: E402
 from nerfslam.ngp import NgpConfig  # noqa: E402
 

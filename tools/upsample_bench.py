@@ -12,6 +12,7 @@ for rep in range(3):
   for dt, code in ((torch.float16, 1), (torch.float32, 2)):
     m = torch.randn((n, 576, ht, wd), device=dev).to(dt)
     for one in (False, True):
+        os.environ["NS_VARIANTS"] = "1"
         if one: os.environ["NS_CVX_ONE_PIXEL"] = "1"
         else: os.environ.pop("NS_CVX_ONE_PIXEL", None)
         def run():
