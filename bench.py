@@ -255,6 +255,47 @@ def _train_us(fn, n=20):
     return 1e3 * e0.elapsed_time(e1) / n
 
 
+def lookup_line_bytes(coords, ht, wd, tiled=True):
+    """HBM bytes the 4-level lookup of `coords` [E,ht,wd,2] CANNOT avoid on gfx950: the distinct 128-byte lines of its 8x8 windows.
+    tools/fetch_gran.hip (profiles/r05_fetch_granularity.json) shows that a touched line costs 128 B of HBM traffic whatever part
+    of it is read (64 B of every 128: same time as the full stream; 64 or 128 B of every 256: half), so a window of 128 B of taps
+    randomly aligned on 8x8-half tiles moves (1 + 7/8)^2 = 3.5 lines, and no re-tiling to sub-line tiles changes that.  Every
+    (edge, pixel) owns its own plane per level, so there is no reuse between windows.  Levels 0 / 1: planes of 8x8-half tiles
+    (line aligned); levels 2 / 3: row-major planes of (ht>>l) x (wd>>l) halves, packed back to back (not line aligned).
+    -> (bytes of tap lines, windows)"""
+    c = coords.detach().float().cpu().numpy().reshape(-1, 2)
+    n = c.shape[0]
+    pix = np.arange(n, dtype=np.int64)
+    total = 0
+    dx = np.arange(8)
+    for l in range(4):
+        h, w = ht >> l, wd >> l
+        x0 = np.floor(c[:, 0] / (1 << l)).astype(np.int64) - 3
+        y0 = np.floor(c[:, 1] / (1 << l)).astype(np.int64) - 3
+        ok = np.isfinite(c).all(1)
+        x0, y0 = np.where(ok, x0, -100), np.where(ok, y0, -100)
+        xs, ys = x0[:, None] + dx, y0[:, None] + dx                            # [n, 8] tap columns / rows
+        vx, vy = (xs >= 0) & (xs < w), (ys >= 0) & (ys < h)
+        if tiled and l < 2:
+            # distinct tile columns x distinct tile rows among the in-bounds taps
+            def distinct(v, valid):
+                t = np.where(valid, v >> 3, -1)
+                t.sort(axis=1)
+                return ((t[:, 1:] != t[:, :-1]) & (t[:, 1:] >= 0)).sum(1) + (t[:, 0] >= 0)
+            total += int((distinct(xs, vx) * distinct(ys, vy)).sum()) * 128
+        else:
+            plane = h * w * 2
+            lines = 0
+            for s0 in range(0, n, 1 << 16):                                     # bounded scratch
+                sl = slice(s0, s0 + (1 << 16))
+                off = pix[sl, None, None] * plane + (ys[sl, :, None] * w + xs[sl, None, :]) * 2      # [m, 8 rows, 8 cols]
+                ln = np.where(vy[sl, :, None] & vx[sl, None, :], off >> 7, -1).reshape(off.shape[0], 64)
+                ln.sort(axis=1)
+                lines += int((((ln[:, 1:] != ln[:, :-1]) & (ln[:, 1:] >= 0)).sum(1) + (ln[:, 0] >= 0)).sum())
+            total += lines * 128
+    return total, n
+
+
 def micro_benches(dev, hp, ngp_net):
     """-> {name: dict(fn=..., alt=None|fn on uniform-random positions, bound, per_launch (algorithmic bytes or flop), note)}: the
     launches `kernel_rooflines` times and `bench.py --microbench NAME` repeats under rocprofv3 --pmc (tools/r03_final.sh), so that
@@ -266,7 +307,12 @@ def micro_benches(dev, hp, ngp_net):
     import ctypes as C
     from hot_path_chain import ALG_BYTES, E_ACTIVE, HT, WD
     from nerfslam._lib import check, lib, ptr, stream_ptr
-    out = {"corr_lookup_coop_kernel[E=48]": dict(fn=hp.op_lookup48, bound="hbm", per_launch=ALG_BYTES["lookup48"]),
+    tap_lines, nwin = lookup_line_bytes(hp.coords48[0], HT, WD, tiled=TILED)
+    line_note = ("line_granular_bytes_per_launch = the distinct 128-B lines of the launch's own windows (%.0f B per edge-pixel for 512 B "
+                 "of taps) + coordinates + output: the traffic floor on gfx950, which fetches whole lines (tools/fetch_gran.hip, "
+                 "profiles/r05_fetch_granularity.json)" % (tap_lines / nwin))
+    out = {"corr_lookup_coop_kernel[E=48]": dict(fn=hp.op_lookup48, bound="hbm", per_launch=ALG_BYTES["lookup48"],
+                                                 line_bytes=tap_lines + nwin * (8 + 4 * 49 * 2), note=line_note),
            "corr_volume_tiled_kernel[E=10]": dict(fn=lambda: hp.op_build(hp.new_i, hp.new_j), bound="hbm", per_launch=ALG_BYTES["build10"])}
     # the kernel the product's update() actually launches since round 4: lookup + correlation encoder (1x1 conv + ReLU) fused
     from nerfslam.update_op import CorrEncoderWeights
@@ -282,6 +328,7 @@ def micro_benches(dev, hp, ngp_net):
                                                 1 if TILED else 0, None, E_ACTIVE, stream_ptr()), "corr_lookup_encode_slots")
     out["corr_lookup_enc_kernel[E=48]"] = dict(
         fn=lookup_enc, bound="hbm", per_launch=E_ACTIVE * HT * WD * (4 * 128 + 8 + 256), keep=(enc, enc_out, c48),
+        line_bytes=tap_lines + nwin * (8 + 256),
         note="lookup (4 levels x 64 taps x 2 B + 8 B coordinates per edge and pixel) + Conv2d(196,128,1) + ReLU, 256 B written per "
              "pixel; what TrackingFrontend.update() launches (the unfused lookup above remains for the motion filter and droid_backends)")
     # ---- the NeRF trainer's kernels ON A TRAINED STEP'S OWN SAMPLE SET: `ngp_net` has just trained (the
@@ -397,6 +444,9 @@ def kernel_rooflines(dev, hp, ngp_net):
         for kk in ("note", "samples", "executed_flop_per_launch", "records"):
             if m.get(kk) is not None:
                 out[k][kk] = m[kk]
+        if m.get("line_bytes"):
+            out[k]["line_granular_bytes_per_launch"] = int(m["line_bytes"])
+            out[k]["frac_line_granular"] = m["line_bytes"] / us / 1e3 / HBM_PEAK_GBS
         if "touched_entries" in m:
             out[k]["touched_table_entries"] = m["touched_entries"]
             out[k]["gradient_only_algorithmic_bytes"] = 1100 * m["samples"]

@@ -446,6 +446,13 @@ int ns_planes_to_nhwc_f16(const void* src, void* dst, int E, int C, int CP, int 
  * fine), starts [K+1] / members [E] i32 on the device, out [K,HW,channels] f16, f32 accumulation.                  */
 int ns_group_mean_nhwc_f16(const void* src, int src_stride, const int* starts, const int* members, void* out, int K, int HW,
                            int channels, void* stream);
+/* ConvGRU global context (networks/modules/gru.py:25-33): glo[e,c] = mean over the HW pixels of wg[e,p,c] * net[e,p,c] (wg =
+ * sigmoid(w(net)), both dense channels-last f16 [E,HW,128], f32 products and sums), then out[e,o] = bias[o] + sum_c glo[e,c]
+ * W[c,o] (W f32 [128,nout] row-major: the three conv*_glo 1x1 convolutions side by side, nout = 384; bias may be NULL).
+ * partial: f32 scratch [E, ns_gru_glo_parts(HW), 128]; out f32 [E,nout].  Two launches.                               */
+int ns_gru_glo_parts(int HW);
+int ns_gru_glo_bias(const void* wg, const void* net, const float* W, const float* bias, float* partial, float* out, int E, int HW,
+                    int nout, void* stream);
 
 /* ---- feature / context encoders on the MFMA convolution (networks/modules/extractor.py:118-198 `BasicEncoder`; host
  * side nerfslam/encoder_op.py).  Activations are dense channels-last f16 [N,H,W,C]; Ho = (H-1)/2+1, Wo = (W-1)/2+1.

@@ -598,3 +598,89 @@ extern "C" int ns_group_mean_nhwc_f16(const void* src, int src_stride, const int
   NS_CHECK_LAUNCH("group_mean_kernel");
   return NS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// ConvGRU global context (networks/modules/gru.py:25-33): glo = mean over the pixels of sigmoid(w(net)) * net, a per-edge vector
+// [E,128]; the three conv*_glo 1x1 convolutions of it are glo @ W [128,384] + b = per-image biases of the gate convolutions
+// (nerfslam/update_op.py).  torch ran this as an elementwise product (a third [E,HW,128] tensor written and read back), a
+// reduction and a hipBLASLt GEMM whose 42 us are launch latency: ~90 us per update for 100 kflop of matrix product.
+//   glo_partial: grid (P, E); thread = (pixel group, 16-byte piece of the 128 channels); f32 products and sums;
+//                partial[e][p][c] = sum over part p's pixels
+//   glo_finish : grid E, 384 threads: glo[c] = sum_p partial / HW (fixed order), out[e][o] = b[o] + sum_c glo[c] W[c][o]
+// ---------------------------------------------------------------------------------------------
+#define GLO_C 128
+__global__ __launch_bounds__(256) void glo_partial_kernel(const _Float16* __restrict__ wg, const _Float16* __restrict__ net,
+                                                          float* __restrict__ partial, int HW, int P) {
+  __shared__ float red[16][GLO_C];
+  const int tid = threadIdx.x, piece = tid & 15, g = tid >> 4;     // 16 pieces x 16 pixel groups
+  const int p = blockIdx.x, e = blockIdx.y;
+  const int chunk = (HW + P - 1) / P;
+  const int lo = p * chunk, hi = min(HW, lo + chunk);
+  const long base = (long)e * HW * GLO_C + piece * 8;
+  float s[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) s[q] = 0.0f;
+  for (int pix = lo + g; pix < hi; pix += 32) {                    // two pixels per iteration: four 16-byte loads in flight
+    cv_f16x8 a[2], b[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int px = pix + 16 * u;
+      const bool ok = px < hi;
+      a[u] = ok ? *reinterpret_cast<const cv_f16x8*>(wg + base + (long)px * GLO_C) : (cv_f16x8)(_Float16)0;
+      b[u] = ok ? *reinterpret_cast<const cv_f16x8*>(net + base + (long)px * GLO_C) : (cv_f16x8)(_Float16)0;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int q = 0; q < 8; q++) s[q] += (float)a[u][q] * (float)b[u][q];
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++) red[g][piece * 8 + q] = s[q];
+  __syncthreads();
+  if (tid < GLO_C) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += red[k][tid];
+    partial[((long)e * P + p) * GLO_C + tid] = t;
+  }
+}
+
+__global__ __launch_bounds__(384) void glo_finish_kernel(const float* __restrict__ partial, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int P, float inv_hw,
+                                                         int nout) {
+  __shared__ float glo[GLO_C];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  if (tid < GLO_C) {
+    float t = 0.0f;
+    for (int p = 0; p < P; p++) t += partial[((long)e * P + p) * GLO_C + tid];
+    glo[tid] = t * inv_hw;
+  }
+  __syncthreads();
+  for (int o = tid; o < nout; o += 384) {
+    float acc = bias ? bias[o] : 0.0f;
+#pragma unroll 8
+    for (int c = 0; c < GLO_C; c++) acc += glo[c] * W[(long)c * nout + o];
+    out[(long)e * nout + o] = acc;
+  }
+}
+
+extern "C" int ns_gru_glo_parts(int HW) {
+  const int p = (HW + 511) / 512;
+  return p < 1 ? 1 : (p > 32 ? 32 : p);
+}
+
+extern "C" int ns_gru_glo_bias(const void* wg, const void* net, const float* W, const float* bias, float* partial, float* out, int E,
+                               int HW, int nout, void* stream) {
+  if (E == 0) return NS_OK;
+  NS_REQUIRE(wg && net && W && partial && out, "ns_gru_glo_bias: null pointer");
+  NS_REQUIRE(E > 0 && E <= 65535 && HW > 0 && nout > 0, "ns_gru_glo_bias: bad shape");
+  NS_REQUIRE(((uintptr_t)wg % 16) == 0 && ((uintptr_t)net % 16) == 0, "ns_gru_glo_bias: 16-byte alignment");
+  const int P = ns_gru_glo_parts(HW);
+  hipLaunchKernelGGL(glo_partial_kernel, dim3(P, E), dim3(256), 0, (hipStream_t)stream, (const _Float16*)wg, (const _Float16*)net,
+                     partial, HW, P);
+  NS_CHECK_LAUNCH("glo_partial_kernel");
+  hipLaunchKernelGGL(glo_finish_kernel, dim3(E), dim3(384), 0, (hipStream_t)stream, (const float*)partial, W, bias, out, P,
+                     1.0f / (float)HW, nout);
+  NS_CHECK_LAUNCH("glo_finish_kernel");
+  return NS_OK;
+}

@@ -151,3 +151,25 @@ def group_mean(src, groups_host):
         check(lib().ns_group_mean_nhwc_f16(ptr(src), stride, ptr(csr), C.c_void_p(csr.data_ptr() + 4 * (K + 1)), ptr(out), K,
                                            ht * wd, Cc, stream_ptr()), "group_mean_nhwc_f16")
     return out, K
+
+
+def gru_glo_bias(wg, net, glo_w, glo_b):
+    """ConvGRU global context -> per-edge biases of the gate convolutions (csrc/conv.hip: ns_gru_glo_bias; networks/modules/
+    gru.py:25-33): wg = sigmoid(w(net)), net: dense channels-last f16 [E,ht,wd,128]; glo_w f32 [128,nout]; glo_b f32 [nout]
+    -> f32 [E,nout] = mean_p(wg * net) @ glo_w + glo_b."""
+    require_cuda(wg, net, glo_w, glo_b)
+    E, ht, wd, Cc = net.shape
+    if Cc != 128 or wg.shape != net.shape or wg.dtype != torch.float16 or net.dtype != torch.float16 or \
+            not wg.is_contiguous() or not net.is_contiguous():
+        raise RuntimeError("gru_glo_bias: wg / net must be contiguous channels-last f16 [E,ht,wd,128] tensors of one shape")
+    if glo_w.dtype != torch.float32 or glo_w.dim() != 2 or glo_w.shape[0] != 128 or not glo_w.is_contiguous() or \
+            glo_b.dtype != torch.float32 or tuple(glo_b.shape) != (glo_w.shape[1],) or not glo_b.is_contiguous():
+        raise RuntimeError("gru_glo_bias: glo_w must be a contiguous f32 [128,nout] tensor, glo_b f32 [nout]")
+    nout = int(glo_w.shape[1])
+    P = int(lib().ns_gru_glo_parts(ht * wd))
+    partial = torch.empty((E, P, 128), dtype=torch.float32, device=net.device)
+    out = torch.empty((E, nout), dtype=torch.float32, device=net.device)
+    with torch.cuda.device(net.device):
+        check(lib().ns_gru_glo_bias(ptr(wg), ptr(net), ptr(glo_w), ptr(glo_b), ptr(partial), ptr(out), E, ht * wd, nout, stream_ptr()),
+              "gru_glo_bias")
+    return out

@@ -198,6 +198,8 @@ class DroidNetworks:
                 self.cnet_hip = HipEncoder(self.net.context_net, False, self.MEAN, self.STD)
         self.ctx, self.inp = {}, {}          # per keyframe: tanh / relu halves of the context encoder
         self.hidden = {}                     # per edge (i, j): ConvGRU hidden state [128, ht, wd]
+        self._stacked = None                 # ((ii, jj, keyframe epoch), stacked hidden states, stacked context) of the last update
+        self._kf_epoch = 0                   # bumped whenever a keyframe's context features are (re)assigned or shifted
         self._pending = None
         # update operator on the MFMA convolution kernel (nerfslam/update_op.py); hidden / context states are then kept
         # channels-last [ht, wd, 128].  Default: on whenever the HIP device is there.
@@ -235,6 +237,7 @@ class DroidNetworks:
     @torch.no_grad()
     def begin_keyframe(self, k, img_u8):
         """hook of TrackingSLAM._store: context features of the frame that just became keyframe k"""
+        self._kf_epoch += 1
         if self.cnet_hip is not None:
             img = self._pending
             if img is None:
@@ -255,6 +258,8 @@ class DroidNetworks:
 
     def remove_keyframe(self, k):
         """hook of TrackingSLAM.rm_keyframe: keyframe k+1 slides onto k, edges touching k disappear"""
+        self._kf_epoch += 1
+        self._stacked = None
         for d in (self.ctx, self.inp) + ((self.ctx_cl, self.inp_cl) if self.hip_update else ()):
             if k + 1 in d:
                 d[k] = d.pop(k + 1)
@@ -279,8 +284,17 @@ class DroidNetworks:
         callable advertises `host_indices`): without them ii.tolist() is a device read-back, i.e. a synchronisation per update"""
         ih, jh = (ii.tolist(), jj.tolist()) if ii_host is None else (list(ii_host), list(jj_host))
         if self.hip_update:
-            net = torch.stack([self.hidden.get((i, j), self.ctx_cl[i]) for i, j in zip(ih, jh)])
-            inp = torch.stack([self.inp_cl[i] for i in ih])
+            # The hidden states of an UNCHANGED edge list are the previous call's output tensor, already stacked in edge order,
+            # and its context features the previous call's stack: only a call that follows a change of the graph (or of the
+            # keyframes behind it) gathers E x [ht,wd,128] tensors again.  (Rounds 1-4 re-stacked both on every update: two
+            # copies of 59 MB at E = 48, and six updates per keyframe see the same list.)
+            key = (tuple(ih), tuple(jh), self._kf_epoch)
+            cache = self._stacked
+            if cache is not None and cache[0] == key:
+                net, inp = cache[1], cache[2]
+            else:
+                net = torch.stack([self.hidden.get((i, j), self.ctx_cl[i]) for i, j in zip(ih, jh)])
+                inp = torch.stack([self.inp_cl[i] for i in ih])
             if hasattr(corr, "c1"):          # EncodedCorr (the frontend fused the lookup with the correlation encoder)
                 c = corr
             else:
@@ -288,6 +302,7 @@ class DroidNetworks:
             net, delta, weight, eta, upmask = self.update_op(net, inp, c, motion.reshape(-1, 4, *motion.shape[-2:]).float(), ih)
             for e, (i, j) in enumerate(zip(ih, jh)):
                 self.hidden[(i, j)] = net[e]
+            self._stacked = (key, net, inp)
             live = set(zip(ih, jh))
             if len(self.hidden) > 4 * max(len(live), 64):
                 self.hidden = {e: h for e, h in self.hidden.items() if e in live}

@@ -55,7 +55,6 @@ class NgpConfig:
                                          # only the drawn cells decay (a once-occupied cell then never fades unless it is drawn)
     min_optical_thickness: float = 0.01
     near: float = 0.05
-    wgrad_ksplit: int = 256
     optimize_extrinsics: bool = False    # nerf_fusion.py:99 sets it; refine c2w of the training views
     extrinsic_lr_pos: float = 1e-4       # scene units per step (Adam)
     extrinsic_lr_rot: float = 1e-4       # radians per step (Adam)
@@ -170,17 +169,16 @@ class NgpNerf:
         # never hold NaN bits -- see csrc/ngp.hip:ngp_encode_fwd_kernel)
         self.s_feat, self.s_out = torch.zeros((S, 32), **h), torch.zeros((S, 4), **h)
         self.s_dfeat = torch.zeros((S, 32), **h)
-        self.act = [torch.zeros((u, S), **h) for u in (64, 32, 64, 64)]         # h1T cinT h3T h4T
-        self.dact = [torch.zeros((u, S), **h) for u in (16, 64, 64, 16, 64)]    # d5T d4T d3T ddT d1T
-        self.partial = torch.zeros((c.wgrad_ksplit, MLP_TOTAL), **f)
-        self.mlp_wgs = int(variant_env("NS_NGP_MLP_WGS", "512"))     # workgroups (= partial weight-gradient slabs) of the weight-gradient kernel (384 .. 1024 measured: within 2 %)
+        # (rounds 3-4 also kept [units][S] buffers of every hidden activation / gradient here -- 235 MB -- for the superseded
+        #  weight-gradient kernel over STORED activations; the product recomputes them on chip, csrc/ngp_mlp_wgrad.hip)
+        self.mlp_wgs = 512               # slabs of partial weight gradients the workspace holds (384 .. 1024 measured: within 2 %)
         self.relu_masks = torch.zeros(6 * S, dtype=torch.int32, device=dev)     # one bit per hidden unit and sample (csrc/ngp_mlp.hip)
         # Table gradient.  One trainer: the round-3 path (csrc/ngp.hip: no count pass, Adam applied to the touched entries in
         # the flush of the accumulation; the gradient buffer is not used).  Replicated trainers: gradient buffer + all-reduce
         # + streaming Adam, so the binned path that writes the buffer keeps its own workspace.
-        self.fused_adam = not self.replicated and c.grad_fixed_scale > 0 and not variant_env("NS_NGP_TWO_PASS_ADAM")
+        self.fused_adam = not self.replicated and c.grad_fixed_scale > 0
         self.enc_ws_bytes = int(lib().ns_ngp_encode_backward_fused_workspace_bytes(*self._grid_args(), C.c_long(c.max_samples)))
-        self.fused_ws = c.grad_fixed_scale > 0 and self.enc_ws_bytes > 0 and not variant_env("NS_NGP_R02_BACKWARD")
+        self.fused_ws = c.grad_fixed_scale > 0 and self.enc_ws_bytes > 0
         if self.fused_ws:
             self.enc_ws = torch.zeros(self.enc_ws_bytes // 8 + 1, dtype=torch.int64, device=dev)   # zeroed once: overflow counter
         else:
@@ -393,7 +391,7 @@ class NgpNerf:
         n_dev = C.c_void_p(X["counter"].data_ptr() + 8)
         featT = self.s_feat.view(-1)[:32 * S].view(32, S)
         jac = None
-        if c.optimize_extrinsics and not variant_env("NS_NGP_POSE_GATHER"):
+        if c.optimize_extrinsics:
             # the forward pass also writes d(feature)/d(position): the pose refinement's input gradient is then a dot product
             if getattr(self, "s_jac", None) is None:
                 self.s_jac = torch.zeros((6 * c.n_levels, S), dtype=torch.float16, device=dev)
@@ -402,15 +400,11 @@ class NgpNerf:
         check(L.ns_ngp_encode_forward_j_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.grid_half), ptr(featT), 1, ptr(jac),
                                           C.c_long(S), n_dev, st), "ngp_encode_forward")
         mark("ngp_encode_fwd_kernel")
-        acts, dacts = self.act, self.dact
-        h1T, cinT, h3T, h4T = acts
-        d5T, d4T, d3T, ddT, d1T = dacts
-        # MLP backward, three forms: "split" (default) = bit-mask activation gradients WITHOUT their five gradient
-        # stores on this stream + the weight gradients recomputed on chip on a side stream next to the table gradient; "fused" =
-        # everything in one kernel on this stream (NS_NGP_MLP=fused); "r3a" = round 3's first form, separate weight-gradient kernel
-        # over stored activations / gradients (NS_NGP_MLP=r3a)
-        mlp_mode = variant_env("NS_NGP_MLP", "split")
-        if mlp_mode != "r3a" and getattr(self, "partial_fused", None) is None:     # (first step after construction: eager)
+        # MLP backward: bit-mask activation gradients WITHOUT their five gradient stores on this stream + the weight
+        # gradients recomputed on chip on a side stream next to the table gradient.  (The forms this replaced -- everything in one
+        # kernel on this stream; a weight-gradient kernel over stored activations -- live on as reference kernels of
+        # tests/test_ngp_gpu.py::test_mlp_forward_backward only.)
+        if getattr(self, "partial_fused", None) is None:     # (first step after construction: eager)
             self.partial_fused = torch.zeros((self.mlp_wgs, MLP_TOTAL), dtype=torch.float32, device=dev)
             # the weights in MFMA operand order (forward + transposed fragments), TWO tables: step k reads table k & 1 and its
             # optimiser writes table (k + 1) & 1 -- the MLP's optimiser runs on a side stream while the activation-gradient
@@ -421,19 +415,10 @@ class NgpNerf:
             self.mlp_frags2 = torch.zeros((2, nfr), dtype=torch.float16, device=dev)
             for k in (0, 1):
                 check(L.ns_ngp_mlp_pack_fragments(ptr(self.mlp_half), ptr(self.mlp_frags2[k]), st), "ngp_mlp_pack_fragments")
-        fr_r = fr_w = None
-        if mlp_mode != "r3a":
-            fr_r, fr_w = self.mlp_frags2[x], self.mlp_frags2[1 - x]      # read by this step / written for the next one
-        if mlp_mode == "fused":
-            check(L.ns_ngp_mlp_forward_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), None, None, None, None,
-                                         C.c_long(S), n_dev, st), "ngp_mlp_forward")
-        elif mlp_mode == "split":
-            check(L.ns_ngp_mlp_forward_f_n(ptr(fr_r), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), ptr(self.relu_masks),
-                                           C.c_long(S), n_dev, st), "ngp_mlp_forward")
-            mark("ngp_mlp_fwd_kernel")
-        else:
-            check(L.ns_ngp_mlp_forward_m_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out),
-                                           *[ptr(a) for a in acts], ptr(self.relu_masks), C.c_long(S), n_dev, st), "ngp_mlp_forward")
+        fr_r, fr_w = self.mlp_frags2[x], self.mlp_frags2[1 - x]      # read by this step / written for the next one
+        check(L.ns_ngp_mlp_forward_f_n(ptr(fr_r), ptr(featT), ptr(X["s_dir"]), ptr(self.s_out), ptr(self.relu_masks),
+                                       C.c_long(S), n_dev, st), "ngp_mlp_forward")
+        mark("ngp_mlp_fwd_kernel")
         check(L.ns_ngp_composite_rays(ptr(self.s_out), ptr(X["s_dt"]), ptr(X["s_t"]), ptr(X["ray_start"]), ptr(X["ray_n"]), Rc,
                                       ptr(X["r_rgb"]), ptr(X["r_depth"]), ptr(X["r_cov"]), C.c_float(c.depth_lambda),
                                       C.c_float(c.loss_scale), ptr(self.out_rgb), ptr(self.out_depth), None, ptr(X["loss"]),
@@ -441,7 +426,6 @@ class NgpNerf:
         mark("ngp_composite_kernel")
         single = not self.replicated
         pose = c.optimize_extrinsics
-        gather_pose = pose and jac is None          # A/B form: second gather of the table (reads what Adam rewrites)
 
         # ---- the pieces ----
         def adam(m, hp, g, m1, m2, l2, fxs, stream):
@@ -452,8 +436,8 @@ class NgpNerf:
 
         def mlp_adam(stream):
             adam(*mlp, stream)
-            if mlp_mode != "r3a":   # the fragment table follows the weights (read by the next step's forward / backward kernels)
-                check(L.ns_ngp_mlp_pack_fragments(ptr(self.mlp_half), ptr(fr_w), stream), "ngp_mlp_pack_fragments")
+            # the fragment table follows the weights (read by the next step's forward / backward kernels)
+            check(L.ns_ngp_mlp_pack_fragments(ptr(self.mlp_half), ptr(fr_w), stream), "ngp_mlp_pack_fragments")
 
         def camera_step(stream):
             check(L.ns_ngp_camera_step_ctl(ptr(self.c2w), ptr(self.cam_grad), ptr(self.cam_m1), ptr(self.cam_m2),
@@ -462,22 +446,15 @@ class NgpNerf:
                                            C.c_float(c.loss_scale * self.world), ctl, stream), "ngp_camera_step")
 
         def pose_gradient(stream):
-            """input gradient of the encoding -> per-ray / per-image 6-dof gradients; -> event after the last read of the table"""
-            ev = None
-            if jac is not None:
-                check(L.ns_ngp_encode_jacobian_dot_n(*self._grid_args(), ptr(jac), ptr(self.s_dfeat), ptr(self.dpos),
-                                                     C.c_long(S), n_dev, stream), "ngp_encode_jacobian_dot")
-            else:
-                check(L.ns_ngp_encode_backward_input_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.grid_half),
-                                                       ptr(self.s_dfeat), ptr(self.dpos), C.c_long(S), n_dev, stream),
-                      "ngp_encode_backward_input")
-                ev = torch.cuda.Event()
-                ev.record()
+            """input gradient of the encoding (a dot product with the Jacobian rows the forward pass wrote) -> per-ray / per-image
+            6-dof gradients.  (The form that gathered the table a second time -- and had to be ordered against the optimiser
+            rewriting it -- is gone; its kernel stays a reference of tests/test_ngp_gpu.py.)"""
+            check(L.ns_ngp_encode_jacobian_dot_n(*self._grid_args(), ptr(jac), ptr(self.s_dfeat), ptr(self.dpos),
+                                                 C.c_long(S), n_dev, stream), "ngp_encode_jacobian_dot")
             n_cam = self.cam_grad.shape[0]
             check(L.ns_ngp_camera_gradient_2stage(ptr(self.dpos), ptr(X["s_t"]), ptr(X["r_d"]), ptr(X["ray_start"]),
                                                   ptr(X["ray_n"]), ptr(X["r_img"]), C.c_float(1.0 / s), ptr(self.cam_grad), Rc,
                                                   ctl, ptr(self.ray_g) if n_cam <= 4096 else None, n_cam, stream), "ngp_camera_gradient")
-            return ev
 
         def table_gradient(parts, stream):
             # one trainer: Adam in the flushes (no gradient buffer); replicated trainers: the packed sums into the gradient buffer
@@ -494,109 +471,75 @@ class NgpNerf:
         #      queue with the main one and the table gradient waited behind the pose refinement, +100 us).  Every fork costs the
         #      main stream ~10 us; ONE two-way fork after the activation gradients cost it 29 us and started all three branches'
         #      heaviest kernels at the same instant (0.46 -> 0.50 ms), so the two forks stay apart:
-        #   main  : [fork 1] activation gradients [fork 2] table gradient of the hashed levels (scatter, accumulate + Adam)
-        #   side  : (the next step's rays, from the start of the step) [1] MLP weight gradients + the MLP's Adam, then [2] the
-        #           pose refinement's chain + the pose step
-        #   side2 : [2] dense levels of the table gradient
-        table_read = None
-        if mlp_mode == "split":
-            fork1 = torch.cuda.Event()
-            # (round 4, measured again: ONE fork point after the activation gradients for both side branches: 0.280-0.283 ->
-            #  0.287-0.294 ms per step)
-            fork1.record(main)
+        #   main  : [fork 1] activation gradients [fork 2] table gradient (scatter, accumulate + Adam)
+        #   side  : [1] MLP weight gradients + the MLP's optimiser step
+        #   side2 : (the next step's rays, from the start of the step) [2] the pose refinement's chain + the pose step
+        fork1 = torch.cuda.Event()
+        # (round 4, measured again: ONE fork point after the activation gradients for both side branches: 0.280-0.283 ->
+        #  0.287-0.294 ms per step)
+        fork1.record(main)
+        mark(None)
+        check(L.ns_ngp_mlp_dgrad_f_n(ptr(fr_r), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
+                                     C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
+        mark("ngp_mlp_bwd_kernel")
+        # (round 4, measured and not kept: the weight gradients IN LINE on the main stream ahead of the scatter, so that the
+        #  scatter does not share the CUs with a kernel that takes whole SIMDs: step 0.288 -> 0.312 ms, 130 -> 121 frames/s)
+        with torch.cuda.stream(self._side):
+            st1 = stream_ptr()
+            self._side.wait_event(fork1)
             mark(None)
-            check(L.ns_ngp_mlp_dgrad_f_n(ptr(fr_r), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
-                                         C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
-            mark("ngp_mlp_bwd_kernel")
-            # (round 4, measured and not kept: the weight gradients IN LINE on the main stream ahead of the scatter, so that the
-            #  scatter does not share the CUs with a kernel that takes whole SIMDs: step 0.288 -> 0.312 ms, 130 -> 121 frames/s)
-            with torch.cuda.stream(self._side):
-                st1 = stream_ptr()
-                self._side.wait_event(fork1)
-                mark(None)
-                # (the optimiser that follows writes the OTHER fragment table: the activation-gradient kernel on the main stream
-                #  may still be reading this one)
-                check(L.ns_ngp_mlp_wgrad_partials_n(ptr(fr_r), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]),
-                                                    ptr(self.partial_fused), self.mlp_wgs, C.c_long(S), n_dev, st1),
-                      "ngp_mlp_wgrad_partials")
-                mark("ngp_mlp_wgrad_tr_kernel")
-                slabs = int(L.ns_ngp_mlp_wgrad_slabs(self.mlp_wgs, C.c_long(S)))
-                if single and not variant_env("NS_NGP_MLP_STEP_UNFUSED"):
-                    # the MLP's optimiser step in one launch: slab reduce + Adam + f16 copy + both fragment tables (the zero rows
-                    # of the tables were written once by the pack above)
-                    check(L.ns_ngp_mlp_step_fused(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), ptr(self.mlp_master),
-                                                  ptr(self.mlp_half), ptr(self.mlp_m1), ptr(self.mlp_m2), ptr(fr_w), 0,
-                                                  C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
-                                                  C.c_float(c.l2_mlp), C.c_float(c.loss_scale * self.world), ctl, st1),
-                          "ngp_mlp_step_fused")
-                    mark("ngp_mlp_step_kernel")
-                else:
-                    check(L.ns_ngp_mlp_reduce(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), st1), "ngp_mlp_reduce")
-                    if single:
-                        mlp_adam(st1)
-                    mark("ngp_mlp_wgrad_reduce_kernel (+ ngp_adam_kernel + ngp_mlp_pack_frags_kernel)")
-        elif mlp_mode == "fused":
-            # (one workgroup of this kernel takes 145 KB of LDS: nothing LDS-using can run next to it, so it sits on this stream)
-            check(L.ns_ngp_mlp_backward_fused_n(ptr(self.mlp_half), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]), ptr(self.s_dfeat),
-                                                ptr(self.partial_fused), self.mlp_wgs, ptr(self.mlp_grad), C.c_long(S), n_dev, st),
-                  "ngp_mlp_backward_fused")
-        else:
-            check(L.ns_ngp_mlp_dgrad_m_n(ptr(self.mlp_half), ptr(X["s_dout"]), ptr(self.relu_masks), ptr(self.s_dfeat),
-                                         ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT), ptr(d1T), C.c_long(S), n_dev, st), "ngp_mlp_dgrad")
+            # (the optimiser that follows writes the OTHER fragment table: the activation-gradient kernel on the main stream
+            #  may still be reading this one)
+            check(L.ns_ngp_mlp_wgrad_partials_n(ptr(fr_r), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]),
+                                                ptr(self.partial_fused), self.mlp_wgs, C.c_long(S), n_dev, st1),
+                  "ngp_mlp_wgrad_partials")
+            mark("ngp_mlp_wgrad_tr_kernel")
+            slabs = int(L.ns_ngp_mlp_wgrad_slabs(self.mlp_wgs, C.c_long(S)))
+            if single:
+                # the MLP's optimiser step in one launch: slab reduce + Adam + f16 copy + both fragment tables (the zero rows
+                # of the tables were written once by the pack above); bit-identical to reduce + ns_ngp_adam_ctl + pack
+                # (tests/test_ngp_gpu.py::test_mlp_optimiser_step_in_one_launch_is_bit_identical)
+                check(L.ns_ngp_mlp_step_fused(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), ptr(self.mlp_master),
+                                              ptr(self.mlp_half), ptr(self.mlp_m1), ptr(self.mlp_m2), ptr(fr_w), 0,
+                                              C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
+                                              C.c_float(c.l2_mlp), C.c_float(c.loss_scale * self.world), ctl, st1),
+                      "ngp_mlp_step_fused")
+                mark("ngp_mlp_step_kernel")
+            else:       # replicated trainers: the summed gradient is all-reduced first, the optimiser follows the exchange (post())
+                check(L.ns_ngp_mlp_reduce(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), st1), "ngp_mlp_reduce")
+                mark("ngp_mlp_wgrad_reduce_kernel")
         fork = torch.cuda.Event()
         fork.record(main)
         # (enqueue order matters under capture although the dependencies do not change: the graph executor keeps the FIRST
         #  successor created for a node on that node's hardware queue and hands later ones to other queues -- enqueued after the
         #  side branches, the scatter landed on the side stream's queue BEHIND the pose refinement, 0.49 ms)
-        def hashed_levels():
-            if self.fused_ws:
-                mark(None)
-                table_gradient(1, st)
-                mark("ngp_enc_fscatter_direct_kernel")
-                if table_read is not None and self.fused_adam:
-                    main.wait_event(table_read)
-                table_gradient(2, st)
-                mark("ngp_enc_faccum_kernel")
-            else:
-                check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
-                                                 ptr(self.enc_ws), C.c_size_t(self.enc_ws_bytes), C.c_float(c.grad_fixed_scale),
-                                                 C.c_long(S), n_dev, st),
-                      "ngp_encode_backward")
-        if not gather_pose:
-            hashed_levels()
-        # (round 4: every dense level goes through the bins by default -- no owner-computes pass, and without the A/B gather
-        #  form of the pose gradient no third stream either)
+        if self.fused_ws:
+            mark(None)
+            table_gradient(1, st)
+            mark("ngp_enc_fscatter_direct_kernel")
+            table_gradient(2, st)
+            mark("ngp_enc_faccum_kernel")
+        else:       # (no workspace / f32-atomic configuration of the tests: grad_fixed_scale = 0)
+            check(L.ns_ngp_encode_backward_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat), 1, ptr(self.grid_grad),
+                                             ptr(self.enc_ws), C.c_size_t(self.enc_ws_bytes), C.c_float(c.grad_fixed_scale),
+                                             C.c_long(S), n_dev, st),
+                  "ngp_encode_backward")
+        # (round 4: every dense level goes through the bins by default -- no owner-computes pass)
         dense_pass = self.fused_ws and int(L.ns_ngp_encode_backward_fused_dense_levels(*self._grid_args())) > 0
         # the pose refinement's chain (Jacobian dot, camera gradient, reduce, pose step: ~45 us of small kernels) runs on the third
         # stream, next to the weight-gradient chain of `side` instead of behind it, and in stream order behind the ray sampling
         # of the next step that reads the poses it rewrites
-        pose_on_side2 = pose and not gather_pose
-        use_side2 = gather_pose or dense_pass or pose_on_side2 or ray_stream is self._side2
-        if gather_pose or dense_pass or pose_on_side2:
+        use_side2 = True                      # (the next step's rays were enqueued there at the start of the step)
+        if dense_pass or pose:
             with torch.cuda.stream(self._side2):
                 self._side2.wait_event(fork)
-                if gather_pose:                      # reads the f16 table: before anything rewrites it
-                    table_read = pose_gradient(stream_ptr())
-                    if single:                       # (same stream as the next step's ray sampling, which reads the poses)
-                        camera_step(stream_ptr())
                 if dense_pass:
                     table_gradient(4, stream_ptr())
                     table_gradient(8, stream_ptr())
-                if pose_on_side2:
+                if pose:
                     pose_gradient(stream_ptr())
                     if single:
                         camera_step(stream_ptr())
-        if gather_pose:
-            hashed_levels()
-        with torch.cuda.stream(self._side):
-            st1 = stream_ptr()
-            self._side.wait_event(fork)
-            if mlp_mode == "r3a":
-                check(L.ns_ngp_mlp_wgrad_n(ptr(featT), ptr(h1T), ptr(cinT), ptr(h3T), ptr(h4T), ptr(d5T), ptr(d4T), ptr(d3T), ptr(ddT),
-                                           ptr(d1T), ptr(self.partial), c.wgrad_ksplit, ptr(self.mlp_grad), C.c_long(S), n_dev, st1),
-                      "ngp_mlp_wgrad")
-            if single and mlp_mode != "split":
-                mlp_adam(st1)
         if use_side2:
             main.wait_stream(self._side2)
         main.wait_stream(self._side)
@@ -631,8 +574,8 @@ class NgpNerf:
         two graph launches (join, launch, fork: 25-35 us on the device) is paid once per pair."""
         c = self.cfg
         i = 0
-        chain = int(variant_env("NS_NGP_CHAIN", "2"))      # steps per chained graph (even).  4 / 8 / 16 measured: 0.438 ->
-                                                              # 0.434 / 0.427 / 0.433 ms, inside the box-to-box spread: a pair it is
+        chain = 2      # steps per chained graph (even).  4 / 8 / 16 measured: 0.438 -> 0.434 / 0.427 / 0.433 ms, inside the
+                       # box-to-box spread: a pair it is
         while i < n:
             if n - i >= 2 and self._pair_ready():
                 left = c.grid_update_every - self.step % c.grid_update_every      # steps until the next occupancy update
@@ -664,7 +607,7 @@ class NgpNerf:
 
     def _pair_ready(self):
         c = self.cfg
-        if self.replicated or not c.use_graph or variant_env("NS_NGP_NO_PAIR") or self.n_images == 0:
+        if self.replicated or not c.use_graph or self.n_images == 0:
             return False
         if not getattr(self, "_static", False) or not self._primed or self.cur != 0:
             return False
@@ -858,20 +801,20 @@ class NgpNerf:
         every 16 steps): during the first 256 steps EVERY cell of every cascade is re-evaluated, afterwards G^3/4 cells per
         cascade drawn uniformly plus G^3/4 per cascade drawn among the currently OCCUPIED cells (up to 8 tries per sample);
         density at a jittered point of the cell, grid = max(decay * grid, new), a cell is occupied when density * min_step
-        exceeds min(mean, threshold).  That is `grid_rule = "ngp"` (NS_NGP_GRID_RULE overrides).  The default "subset" draws
+        exceeds min(mean, threshold).  That is `grid_rule = "ngp"`.  The default "subset" draws
         2^18 cells uniformly per update instead: as implemented here (torch glue around the density evaluation) the
         published rule costs 0.35 ms per step (3.1 M density evaluations every 16 steps: 0.57 -> 0.92 ms) and did not train
         better on the sphere scene (PSNR after 500 steps 27.1-37.9 dB over 6 runs against 34.3-36.3 dB).  `n_cells`: a uniform
         draw of that many cells (tests).  The subset rule runs on the HIP kernels of csrc/ngp.hip ("occupancy-grid refresh":
         cells + jittered points, encode + density network, decay / max / mean / bit packing: 7 launches instead of ~35 torch
-        ones; NS_NGP_GRID_TORCH=1 keeps the torch form for A/B runs)."""
+        ones)."""
         c, dev = self.cfg, self.device
         G, nc = c.grid_size, c.n_cascades
         G3 = G ** 3
         total = nc * G3
-        if n_cells is None and variant_env("NS_NGP_GRID_RULE", c.grid_rule) == "subset":
+        if n_cells is None and c.grid_rule == "subset":
             n_cells = 1 << 18
-        if n_cells is not None and not variant_env("NS_NGP_GRID_TORCH"):
+        if n_cells is not None:
             # the subset rule on the HIP kernels (csrc/ngp.hip, "occupancy-grid refresh"): 7 launches, no allocation
             n = min(int(n_cells), total) & ~1
             ws = getattr(self, "_grid_ws", None)
@@ -890,7 +833,7 @@ class NgpNerf:
                   "ngp_encode_forward")
             check(L.ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(feat), ptr(dirs), ptr(out), nul, nul, nul, nul, C.c_long(n), st),
                   "ngp_mlp_forward")
-            if variant_env("NS_NGP_GRID_DECAY_ALL", "1" if c.grid_decay_all else "") not in ("", "0"):
+            if c.grid_decay_all:
                 # (fading all cells at instant-ngp's 0.95 with 4 % of the grid drawn would empty the grid 12 x
                 #  faster than the rule it stands in for; not fading the undrawn cells at all leaves floaters for ever)
                 decay_all = float(c.grid_decay) ** min(1.0, n / (0.5 * total))

@@ -7,7 +7,8 @@ Same arithmetic as `nerfslam.droid_nets.UpdateModule` (whose weights it is built
     write their halves of one [E,ht,wd,192] buffer;
   * convz | convr are one 448 -> 256 convolution whose epilogue also forms r * net, and the convq launch's epilogue is
     the GRU blend (1 - z) net + z q: no elementwise kernels between the gates; the global-context terms conv*_glo(glo) are 1x1 convolutions of a
-    per-edge vector, i.e. a per-image bias of that launch (one small matmul for all three);
+    per-edge vector, i.e. a per-image bias of that launch (`gru_glo_bias`: pixel mean of sigmoid(w(net)) * net and the [E,128] x
+    [128,384] product for all three in two small launches);
   * the first convolutions of the delta head, the weight head and GraphAgg share their input: one 128 -> 384 launch,
     whose channel slices feed the second convolutions directly.
 The 7x7 convolution of the flow encoder (4 input channels) is an im2col kernel + a 1x1 launch over 208 channels.
@@ -16,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .conv import PackedConv, flow_im2col, group_mean, planes_to_nhwc
+from .conv import PackedConv, flow_im2col, group_mean, gru_glo_bias, planes_to_nhwc
 
 
 class CorrEncoderWeights:
@@ -102,8 +103,9 @@ class HipUpdateOperator:
         self.flow2([f1], act="relu", out=X, out_offset=128)
         # ---- ConvGRU ----
         wg = self.gw([net], act="sigmoid")
-        glo = (wg * net).sum((1, 2), dtype=torch.float32) / float(ht * wd)    # [E,128]
-        gb = torch.addmm(self.glo_b, glo, self.glo_w)                         # [E,384] per-edge biases of z | r | q
+        # [E,384] per-edge biases of z | r | q = mean_p(wg * net) @ glo_w + glo_b: two small launches (csrc/conv.hip) instead of an
+        # elementwise product (a third [E,ht,wd,128] tensor), a reduction and a library GEMM
+        gb = gru_glo_bias(wg, net.contiguous(), self.glo_w, self.glo_b.contiguous())
         zrh = self.zr([net, inp, X], act="sigmoid", bias=gb[:, :256].contiguous(), fuse=("mul_hi", net))   # [z | r * net]
         net2 = self.q([zrh[..., 128:], inp, X], act="tanh", bias=gb[:, 256:].contiguous(),
                       fuse=("gru", zrh[..., :128], net))                      # (1 - z) net + z q
