@@ -82,14 +82,14 @@ class Pipeline:
                     mapper still does exactly ONE spin per input frame (ingest or 16 optimiser steps), so both modes do the
                     same work per frame."""
 
-    def __init__(self, dev, n_frames, buffer, fusion=True, on_packet=None, trainer_group=None, queue_depth=8):
+    def __init__(self, dev, n_frames, buffer, fusion=True, on_packet=None, trainer_group=None, queue_depth=8, encoder_graphs=True):
         import threading
         from nerfslam.pipeline import DataModule, FusionModule, SlamModule
         from synth_stream import RoomStream, grounded_networks
         self.dev = dev
         self.stream = RoomStream(n_frames, device=dev, flow_px=0.45)
         self.images = [self.stream.image(i) for i in range(n_frames)]      # resident in HBM
-        self.nets = grounded_networks(self.stream, dev, buffer)
+        self.nets = grounded_networks(self.stream, dev, buffer, encoder_graphs=encoder_graphs)
         args = argparse.Namespace(buffer=buffer, networks=self.nets, slam=True, global_ba=False, parallel_run=False,
                                   mask_type="ours", stop_iters=10 ** 9, network="", trainer_group=trainer_group)
         self.data_q = Queue()
@@ -807,6 +807,9 @@ def main():
     ap.add_argument("--queue-depth", type=int, default=8,
                     help="bound of the tracker -> mapper queue in the --parallel_run mode (examples/slam_demo.py uses 8; rounds 1-4 of this "
                          "bench used 2)")
+    ap.add_argument("--eager-encoders", action="store_true",
+                    help="A/B: launch the feature / context encoders eagerly (DroidNetworks(encoder_graphs=False)); the product default "
+                         "since round 5 replays them from HIP graphs")
     ap.add_argument("--allow-env-overrides", action="store_true",
                     help="run although NS_* kernel-selection variables are set (they are then listed in `env_overrides`)")
     ap.add_argument("--config", default="c640", choices=["c640", "c1280"],
@@ -845,7 +848,7 @@ def main():
     if world > 1:
         return main_split(args, rank, world, dev, backend, n_frames, buffer)
 
-    pipe = Pipeline(dev, n_frames, buffer, fusion=True, queue_depth=args.queue_depth)
+    pipe = Pipeline(dev, n_frames, buffer, fusion=True, queue_depth=args.queue_depth, encoder_graphs=not args.eager_encoders)
     ngp = pipe.fusion.fusion.ngp
     init_frames = 0
     while not pipe.tracker.is_initialized:

@@ -174,7 +174,7 @@ class DroidNetworks:
     MEAN = (0.485, 0.456, 0.406)
     STD = (0.229, 0.224, 0.225)
 
-    def __init__(self, device, weights=None, buffer=512, seed=0, hip_update=None, hip_encoders=None):
+    def __init__(self, device, weights=None, buffer=512, seed=0, hip_update=None, hip_encoders=None, encoder_graphs=True):
         self.device = torch.device(device)
         torch.manual_seed(seed)
         self.net = DroidNet()
@@ -194,8 +194,11 @@ class DroidNetworks:
             from ._lib import variant_env
             if (hip_encoders is None and not variant_env("NS_TORCH_ENCODERS")) or hip_encoders:
                 from .encoder_op import HipEncoder
-                self.fnet_hip = HipEncoder(self.net.feature_net, True, self.MEAN, self.STD)
-                self.cnet_hip = HipEncoder(self.net.context_net, False, self.MEAN, self.STD)
+                # encoder_graphs: replay each encoder's ~50 fixed-shape launches from a HIP graph (captured at the first call per
+                # image size; nerfslam/encoder_op.py).  Round 5, six bench runs per arm on one box: tracking leg 3.24 -> 3.04 ms
+                # (6 of 6), pipeline 132.4 +- 2.4 -> 135.7 +- 1.5 frames/s (profiles/r05_ab_records.json): on by default.
+                self.fnet_hip = HipEncoder(self.net.feature_net, True, self.MEAN, self.STD, use_graph=encoder_graphs)
+                self.cnet_hip = HipEncoder(self.net.context_net, False, self.MEAN, self.STD, use_graph=encoder_graphs)
         self.ctx, self.inp = {}, {}          # per keyframe: tanh / relu halves of the context encoder
         self.hidden = {}                     # per edge (i, j): ConvGRU hidden state [128, ht, wd]
         self._stacked = None                 # ((ii, jj, keyframe epoch), stacked hidden states, stacked context) of the last update

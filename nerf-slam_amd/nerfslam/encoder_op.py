@@ -7,17 +7,17 @@ instance-norm statistics in f32/f64), different plumbing -- see csrc/encoder.hip
     a block's stride-2 1x1 shortcut reads the centre-tap slice of the same patch buffer;
   * InstanceNorm2d + relu (+ the residual add + relu of a block's tail) is a statistics pass and ONE apply pass instead of
     three batch-norm kernels, a clamp and an add; the context encoder (no norm) has bias + relu in the convolution's epilogue;
-  * a call is ~50 launches of fixed shape.  `use_graph=True` captures them once per image size in a HIP graph and replays it;
-    measured at 640x480 the replay takes the same 0.68 ms as the eager launches (the kernels, not the launches, are the
-    time), and a capture in the tracker thread while the mapper thread synchronises the device is an illegal-state error
-    on ROCm 7.2 -- so the default is eager.
+  * a call is ~50 launches of fixed shape.  `use_graph=True` (what nerfslam.droid_nets.DroidNetworks asks for since round 5)
+    captures them once per image size in a HIP graph and replays it: alone on the device a replay takes the same 0.68 ms as the
+    eager launches (the kernels, not the launches, are the time), but in the pipeline -- the tracker thread issuing ~130
+    launches per frame next to the mapper thread -- it shortens the tracking leg by 0.2 ms per frame (6 of 6 paired runs).
 The output is channels-last [N, H/8, W/8, C] f16.
 """
 import ctypes as C
 
 import torch
 
-from ._lib import NerfSlamHipError, check, graph_capture, lib, ptr, require_cuda, stream_ptr
+from ._lib import NerfSlamHipError, capture_lock, check, graph_capture, lib, ptr, require_cuda, stream_ptr
 from .conv import PackedConv
 
 EPS = 1e-5   # nn.InstanceNorm2d default
@@ -130,10 +130,13 @@ class HipEncoder:
             if entry is None:
                 static_in = img.clone()
                 self._forward(static_in)                                   # warm-up outside the capture (lazy initialisation)
-                torch.cuda.current_stream().synchronize()
-                g = torch.cuda.CUDAGraph()
-                with graph_capture(g, capture_error_mode="thread_local"):
-                    static_out = self._forward(static_in)
+                # (the lock the mapper thread holds around ITS captures and the tracker around its host read-backs: a
+                #  synchronising call of one thread while another captures is an illegal-state error on ROCm 7.2, _lib.py)
+                with capture_lock:
+                    torch.cuda.current_stream().synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with graph_capture(g, capture_error_mode="thread_local"):
+                        static_out = self._forward(static_in)
                 entry = self._graphs[key] = (g, static_in, static_out)
             g, static_in, static_out = entry
             static_in.copy_(img)

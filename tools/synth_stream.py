@@ -112,14 +112,14 @@ def _reproject(poses, disps, intr8, ii, jj, ht, wd):
     return out
 
 
-def grounded_networks(stream, device, buffer, seed=0):
+def grounded_networks(stream, device, buffer, seed=0, encoder_graphs=True):
     """-> DroidNetworks subclass instance whose flow corrections are replaced (AFTER the real nets ran) by the flow the
     stream's geometry induces.  `nets.frame` must be set to the stream index of the frame being processed."""
     from nerfslam.droid_nets import DroidNetworks
 
     class GroundedNetworks(DroidNetworks):
         def __init__(self):
-            super().__init__(device, weights=None, buffer=buffer, seed=seed)
+            super().__init__(device, weights=None, buffer=buffer, seed=seed, encoder_graphs=encoder_graphs)
             self.stream, self.frame, self.fe = stream, 0, None
             ht, wd = stream.H // 8, stream.W // 8
             self.ht, self.wd = ht, wd
