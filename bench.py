@@ -54,7 +54,7 @@ import numpy as np
 import torch
 
 def _lib_sha256():
-    """sha256 of the HIP library this process runs (what profiles/r04_traffic.json is checked against)"""
+    """sha256 of the HIP library this process runs (what profiles/r05_traffic.json is checked against)"""
     import hashlib
     from nerfslam._lib import LIB_PATH
     h = hashlib.sha256()
@@ -64,6 +64,7 @@ def _lib_sha256():
     return h.hexdigest()
 
 
+TRAFFIC_FILE = "r05_traffic.json"      # PMC traffic of the roofline micro-benches (tools/r05_final.sh -> tools/traffic.py)
 ENV_OVERRIDES = []         # NS_* kernel-selection variables present in the environment (main() refuses them by default)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak
@@ -305,7 +306,7 @@ def micro_benches(dev, hp, ngp_net):
     588 B per sample; hash encode backward 16 x 8 x 8 B (64-bit packed RMW) + 12 + 64 = 1100 B per sample; update-operator gate
     convolution (448 -> 256, 3x3) 2*9*448*256 flop per pixel."""
     import ctypes as C
-    from hot_path_chain import ALG_BYTES, E_ACTIVE, HT, WD
+    from hot_path_chain import ALG_BYTES, E_ACTIVE, HT, TILED, WD
     from nerfslam._lib import check, lib, ptr, stream_ptr
     tap_lines, nwin = lookup_line_bytes(hp.coords48[0], HT, WD, tiled=TILED)
     line_note = ("line_granular_bytes_per_launch = the distinct 128-B lines of the launch's own windows (%.0f B per edge-pixel for 512 B "
@@ -316,7 +317,6 @@ def micro_benches(dev, hp, ngp_net):
            "corr_volume_tiled_kernel[E=10]": dict(fn=lambda: hp.op_build(hp.new_i, hp.new_j), bound="hbm", per_launch=ALG_BYTES["build10"])}
     # the kernel the product's update() actually launches since round 4: lookup + correlation encoder (1x1 conv + ReLU) fused
     from nerfslam.update_op import CorrEncoderWeights
-    from hot_path_chain import TILED
     gw = torch.Generator(device=dev).manual_seed(5)
     enc = CorrEncoderWeights(torch.randn((128, 196, 1, 1), device=dev, generator=gw) / 14.0, torch.zeros(128, device=dev))
     pyr = (C.c_void_p * 4)(*[hp.corr48.corr_pyramid[l].data_ptr() for l in range(4)])
@@ -477,7 +477,7 @@ def _sphere_trainer(dev, steps=208):
 
 def run_microbench(dev, name, reps):
     """`bench.py --microbench NAME [--reps n]`: n back-to-back launches of ONE roofline micro-bench and nothing else timed -- the
-    command tools/r04_final.sh wraps in rocprofv3 --kernel-trace --stats / --pmc passes"""
+    command tools/r05_final.sh wraps in rocprofv3 --kernel-trace --stats / --pmc passes"""
     if name.startswith("altcorr"):           # config #5's on-the-fly correlation: 48 edges x 4 levels at 160x90, half features
         from nerfslam.corr import AltCorrBlock
         g = torch.Generator(device=dev).manual_seed(0)
@@ -714,7 +714,7 @@ def bench_c1280(args, dev, rank=0, world=1, backend="nccl"):
         "breakdown": breakdown,
     }
     if world == 1:
-        tf = os.path.join(ROOT, "profiles", "r04_traffic.json")
+        tf = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
         if os.path.exists(tf):
             tr = json.load(open(tf))
             e = tr.get("altcorr_tile_mfma_lds_kernel[E=48, 160x90]")
@@ -727,7 +727,7 @@ def bench_c1280(args, dev, rank=0, world=1, backend="nccl"):
                     if kk in e:
                         r[kk] = e[kk]
                 meta = tr.get("_meta", {})
-                r["traffic_source"] = {"file": "profiles/r04_traffic.json", "git_head": meta.get("git_head"),
+                r["traffic_source"] = {"file": "profiles/" + TRAFFIC_FILE, "git_head": meta.get("git_head"),
                                        "traffic_stale": meta.get("lib_sha256") != _lib_sha256()}
     print(json.dumps(out))
     if world > 1:
@@ -990,15 +990,15 @@ def main():
                 "note": "latency-bound, not bandwidth-bound: %d rays x up to 1024 dependent DDA steps through the occupancy bits, 32 B "
                         "written per emitted sample; runs on the third stream from the start of the step, beside the forward pass "
                         "(duration measured in the step: there is no stand-alone launch of it)" % n_r}
-        # rocprofv3 evidence of the SAME kernels (tools/r04_final.sh): HBM bytes per launch from separate --pmc passes over
+        # rocprofv3 evidence of the SAME kernels (tools/r05_final.sh): HBM bytes per launch from separate --pmc passes over
         # `bench.py --microbench NAME` (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md), their rocprof average duration, and the
-        # average duration of the same kernels INSIDE the timed pipeline (profiles/r04_bench_kernel_stats.csv).  The file carries
+        # average duration of the same kernels INSIDE the timed pipeline (profiles/r05_bench_kernel_stats.csv).  The file carries
         # the commit and the sha256 of the library it was measured on: `traffic_stale` says whether that is the library running now.
-        tf = os.path.join(ROOT, "profiles", "r04_traffic.json")
+        tf = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
         if os.path.exists(tf):
             tr = json.load(open(tf))
             meta = tr.get("_meta", {})
-            out["roofline"]["traffic_source"] = {"file": "profiles/r04_traffic.json", "git_head": meta.get("git_head"),
+            out["roofline"]["traffic_source"] = {"file": "profiles/" + TRAFFIC_FILE, "git_head": meta.get("git_head"),
                                                  "lib_sha256": meta.get("lib_sha256"),
                                                  "traffic_stale": meta.get("lib_sha256") != _lib_sha256()}
             for k in roofs:
@@ -1014,6 +1014,8 @@ def main():
                         # system actually moved per launch / launch time / peak -- next to `frac`, which prices only the
                         # ALGORITHMIC bytes (traffic / algorithmic = the re-read factor)
                         e["hbm_utilisation"] = e["traffic"] / (e["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                        if tr[k].get("rocprof_avg_launch_us"):     # the same bytes over the rocprofv3 duration of the same launches
+                            e["hbm_utilisation_rocprof"] = tr[k]["traffic_bytes"] / (tr[k]["rocprof_avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
                     for kk in ("rocprof_avg_launch_us", "in_pipeline_avg_us", "l2_hit_rate", "traffic_by_kernel", "mfma_busy"):
                         if kk in tr[k]:
                             e[kk] = tr[k][kk]

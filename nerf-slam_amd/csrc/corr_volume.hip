@@ -540,9 +540,28 @@ extern "C" int ns_corr_volume_pyramid_slots(const void* fmap1, const void* fmap2
   if (zs < 1) zs = 1;
   if (tiled) {
     const int ngroups = ((nby + 1) / 2) * ((((wd + 7) / 8) + 1) / 2);
-    int zt = ns_cdiv(1024, (long)ns_cdiv(HW, 128) * E);
-    if (zt > ngroups) zt = ngroups;
-    if (zt < 1) zt = 1;
+    // z slices: every workgroup walks ceil(ngroups / zt) groups of 2x2 tiles, and the device runs them in ROUNDS of `slots`
+    // resident workgroups (two per CU: 72 KB of LDS, 4 waves of ~230 registers).  Round 4 aimed at ~1024 workgroups whatever
+    // that meant in rounds -- E = 10 at 60x80: zt = 3, 1140 workgroups = 2.2 rounds, the last one on a fifth of the chip for
+    // as long as the first two.  Pick the zt that minimises rounds x (tiles per workgroup + prologue): same work, same bits.
+    static const int slots = [] {
+      int dev = 0, cus = 256;
+      hipDeviceProp_t pr;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+        cus = pr.multiProcessorCount;
+      return 2 * cus;
+    }();
+    const long per_z = (long)ns_cdiv(HW, 128) * E;
+    int zt = 1;
+    long best = -1;
+    for (int z = 1; z <= ngroups; z++) {
+      const long rounds = (per_z * z + slots - 1) / slots;
+      const long cost = rounds * (4L * ((ngroups + z - 1) / z) + 3);      // (+3: source fragments + the first tile's staging)
+      if (best < 0 || cost < best) {
+        best = cost;
+        zt = z;
+      }
+    }
     hipLaunchKernelGGL(corr_volume_tiled_kernel<128>, dim3(ns_cdiv(HW, 128), E, zt), dim3(256), 0, (hipStream_t)stream, a);
     NS_CHECK_LAUNCH("corr_volume_tiled_kernel");
     return NS_OK;

@@ -59,6 +59,50 @@ __global__ __launch_bounds__(256) void read_windows(const uint2* __restrict__ bu
   if (acc == 0x9e3779b9u) sink[0] = 1;
 }
 
+// ---- the volume build's store pattern: a wave owns 32 output slices (one per source pixel, SLICE bytes apart) and visits their
+// lines in order, CH consecutive 128-byte lines of every slice per step (lane pair = one line, as corr_volume_tiled_kernel
+// stores them: CH = 1).  Does the write bandwidth depend on how many consecutive lines a slice receives at a time?
+template <int CH>
+__global__ __launch_bounds__(256) void write_slices(uint4* __restrict__ buf, long slice_bytes, int lines_per_slice, long nslices) {
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const long s0 = wave * 32;
+  if (s0 >= nslices) return;
+  const uint4 v = make_uint4(lane, wave, 3, 4);
+  // 64 lanes x 16 B = 1 KiB per store instruction = 8 lines: 8 / CH slices x CH lines each
+  for (int t = 0; t < lines_per_slice; t += CH) {
+#pragma unroll
+    for (int r = 0; r < 4 * CH; r++) {                     // 32 slices x CH lines = 4 CH KiB per step
+      const int piece = r * 64 + lane;                     // 16-byte piece of this step
+      const int line = piece >> 3;                         // 0 .. 32 CH - 1
+      const int sl = line / CH, li = line - sl * CH;
+      char* dst = (char*)buf + (s0 + sl) * slice_bytes + ((long)(t + li) << 7) + ((piece & 7) << 4);
+      *reinterpret_cast<uint4*>(dst) = v;
+    }
+  }
+}
+
+template <int CH>
+static void run_write(uint4* buf, size_t bytes) {
+  const long slice_bytes = 80 * 128;                       // a 60x80 level-0 slice: 80 tiles of 128 B
+  const int lines = 80;
+  const long nslices = (long)(bytes / slice_bytes) / 32 * 32;
+  const long waves = nslices / 32;
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; rep++) {
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((write_slices<CH>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, 0, buf, slice_bytes, lines, nslices);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    if (rep > 0 && ms < best) best = ms;
+  }
+  const double wr = (double)nslices * slice_bytes;
+  printf("{\"pattern\": \"write: a wave owns 32 slices 10 KiB apart, %d consecutive 128-B line(s) per slice and step\", \"lines_per_step\": %d, "
+         "\"written_bytes\": %.0f, \"ms\": %.4f, \"GBps\": %.1f}\n", CH, CH, wr, best, wr / best * 1e-6);
+}
+
 template <int CHUNK, int STRIDE>
 static void run(const uint4* buf, size_t bytes, unsigned* sink, const char* what) {
   const long nchunks = (long)(bytes / STRIDE);
@@ -115,6 +159,10 @@ int main(int argc, char** argv) {
   run<32, 64>(buf, bytes, sink, "first 32 B of every 64-B half line");
   run_windows<8>((const uint2*)buf, bytes, sink);
   run_windows<4>((const uint2*)buf, bytes, sink);
+  run_write<1>(buf, bytes);
+  run_write<2>(buf, bytes);
+  run_write<4>(buf, bytes);
+  run_write<8>(buf, bytes);
   CK(hipDeviceSynchronize());
   return 0;
 }
