@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include <utility>
 
 #include "ngp_adam.h"
 
@@ -1120,6 +1121,20 @@ static bool fused_plan_host(const GridLayout& g, int n_levels, long N, FusedPlan
     f.slot[f.nh] = sl < 8 * NS_BIN_TILE ? sl : 8 * NS_BIN_TILE;      // (a tile has at most 8 x 1024 records)
     f.nh++;
   }
+  // FINEST level first (round 5).  Both passes launch grid.y = k, so the order of the plan is the order in which the levels'
+  // workgroups are dispatched; the workspace is addressed by k in both and any order gives the same sums.  With the coarse
+  // levels' few, merged records last the tail of each pass is light: mapping leg 4.92 -> 4.84 ms per frame in 3 of 3 paired
+  // bench runs (profiles/r05_ab_records.json); the step alone does not move.  NS_VARIANTS=1 NS_FB_LEVEL_ORDER=fwd: coarsest first.
+  static const bool rev = [] { const char* e = ns_variant_env("NS_FB_LEVEL_ORDER"); return !(e != nullptr && e[0] == 'f'); }();
+  if (rev)
+    for (int a = 0, b = f.nh - 1; a < b; a++, b--) {
+      std::swap(f.shift[a], f.shift[b]);
+      std::swap(f.level[a], f.level[b]);
+      std::swap(f.nbins[a], f.nbins[b]);
+      std::swap(f.hashed[a], f.hashed[b]);
+      std::swap(f.merge[a], f.merge[b]);
+      std::swap(f.slot[a], f.slot[b]);
+    }
   for (int k = f.nh; k < 16; k++) f.level[k] = f.nbins[k] = f.slot[k] = f.hashed[k] = f.merge[k] = f.shift[k] = 0;
   f.ntiles = (int)((N + NS_BIN_TILE - 1) / NS_BIN_TILE);
   f.ovf_cap = (long)f.ntiles * NS_BIN_TILE * 8 * (f.nh > 0 ? f.nh : 1);
