@@ -5,7 +5,8 @@ re-times the WHOLE step (HIP-graph replay, as the product runs it) with individu
 no-ops, by wrapping the ctypes library object the trainer calls through -- the product code is not touched and none of the
 ablated variants trains correctly (they are timing probes, nothing else).
 usage: python tools/r05_step_ablation.py [steps]      -> one JSON line per variant, ms per step (median of 5 blocks)"""
-import json
+import faulthandler, json
+faulthandler.enable()
 import os
 import sys
 import time
