@@ -271,10 +271,10 @@ def lookup_line_bytes(coords, ht, wd, tiled=True):
     dx = np.arange(8)
     for l in range(4):
         h, w = ht >> l, wd >> l
-        x0 = np.floor(c[:, 0] / (1 << l)).astype(np.int64) - 3
-        y0 = np.floor(c[:, 1] / (1 << l)).astype(np.int64) - 3
-        ok = np.isfinite(c).all(1)
-        x0, y0 = np.where(ok, x0, -100), np.where(ok, y0, -100)
+        ok = np.isfinite(c).all(1) & (np.abs(c) < 1e6).all(1)                    # (non-finite / absurd coordinates: outside)
+        cs = np.where(ok[:, None], c, -1000.0)
+        x0 = np.floor(cs[:, 0] / (1 << l)).astype(np.int64) - 3
+        y0 = np.floor(cs[:, 1] / (1 << l)).astype(np.int64) - 3
         xs, ys = x0[:, None] + dx, y0[:, None] + dx                            # [n, 8] tap columns / rows
         vx, vy = (xs >= 0) & (xs < w), (ys >= 0) & (ys < h)
         if tiled and l < 2:

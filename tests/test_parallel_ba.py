@@ -183,3 +183,52 @@ def test_sharded_gradient_exchange_equals_allreduce(world):
     for p in ps:
         p.join(timeout=60)
     assert res == [(r, True, True) for r in range(world)]
+
+
+def _state_worker(rank, world, port, q):
+    """TrackingSLAM._replicate_source_frame_state on a stand-in frontend (CPU tensors, gloo): every source frame has one owner;
+    the non-owner's rows hold STALE garbage -- inf / NaN included -- and its has_up flags are whatever they were."""
+    import types
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nerfslam.slam import TrackingSLAM
+    nbuf, ht, wd = 8, 3, 4
+    g = torch.Generator().manual_seed(7)
+    truth = {k: torch.rand((nbuf,) + shp, generator=g) + 0.1 for k, shp in
+             (("damping", (ht, wd)), ("cam0_idepths_up", (8 * ht, 8 * wd)), ("cam0_depths_cov_up", (8 * ht, 8 * wd)))}
+    ii_h = np.array([1, 1, 2, 3, 3, 5, 5, 6])                      # sources 1, 2, 3, 5, 6
+    own = np.array([0, 1, 2, 3, 4]) if rank == 0 else np.array([5, 6, 7])      # rank 0 owns sources 1, 2, 3; rank 1 owns 5, 6
+    mine = np.unique(ii_h[own])
+    upsampled = {1, 2, 5}                                          # frames whose owner ran the upsampling (3 and 6: no upmask)
+    fe = types.SimpleNamespace(has_up=torch.zeros(nbuf, dtype=torch.bool))
+    for k, t in truth.items():
+        buf = torch.full_like(t, float("nan"))                     # stale everywhere ...
+        buf[::2] = float("inf")
+        buf[torch.from_numpy(mine)] = t[torch.from_numpy(mine)]    # ... except the rows this rank owns
+        setattr(fe, k, buf)
+    fe.has_up[:] = rank == 1                                       # stale flags on the non-owner: all set on rank 1, none on rank 0
+    for f in mine:
+        fe.has_up[f] = int(f) in upsampled
+    me = types.SimpleNamespace(fe=fe, device=torch.device("cpu"))
+    TrackingSLAM._replicate_source_frame_state(me, ii_h, own, None)
+    src = torch.tensor([1, 2, 3, 5, 6])
+    ok = all(torch.equal(getattr(fe, k)[src], t[src]) for k, t in truth.items())
+    ok = ok and fe.has_up[src].tolist() == [True, True, False, True, False]
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_source_frame_state_exchange_ignores_stale_rows():
+    """the owner-masked all-reduce must SELECT the owner's rows (a stale inf / NaN times 0 is NaN and would poison
+    every rank), and a frame counts as upsampled only if its owner upsampled it."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_state_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
