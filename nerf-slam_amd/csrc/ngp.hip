@@ -2092,6 +2092,7 @@ struct MarchArgs {
   float* tmid;           // [max_samples]
   int R;
   const int* ctl;
+  unsigned long long* order;   // optional [1 + ceil(R / 16)], all zero between launches: ranges handed out in WORKGROUP ORDER
 };
 
 // Ray marching, 16 lanes per ray (one DPP row), 4 rays per wave.
@@ -2200,11 +2201,59 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(MarchArgs a) {
   const int row = threadIdx.x >> 4;
   if (sub == 0) row_n[row] = live ? n : 0;
   __syncthreads();
+  // Ordered mode (round 5: a.order != nullptr, what the training step uses).  With one atomicAdd per workgroup (the legacy mode
+  // below) the base of a workgroup's range is whatever the arrival order made it: the samples of a batch land in a different order on every run -- and, at a full
+  // budget, a different set of rays is refused -- so nothing downstream (f32 weight-gradient sums over sample tiles) repeats
+  // bit for bit.  Here workgroup b's base is the sum of the counts of workgroups 0 .. b-1: every workgroup publishes its count
+  // (flag in bit 63), the first wave reads its predecessors' words 64 at a time, spinning on the ones not yet there (a workgroup
+  // only ever waits for LOWER ids, which were dispatched before it and wait for nobody above them); the last workgroup through
+  // clears the words.  The counts are ready at about the same time, so the look-back is a couple of L2 round trips.
+  __shared__ int s_prefix;
+  if (a.order != nullptr) {
+    const int nwg = (R + 15) >> 4;
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      int tot = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) tot += row_n[k];
+      if (lane == 0)
+        __hip_atomic_store(&a.order[1 + blockIdx.x], (1ull << 63) | (unsigned long long)(unsigned)tot, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      int sum = 0;
+      for (int j0 = 0; j0 < (int)blockIdx.x; j0 += 64) {
+        const int j = j0 + lane;
+        unsigned long long v = 1ull << 63;
+        if (j < (int)blockIdx.x) {
+          do {
+            v = __hip_atomic_load(&a.order[1 + j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          } while (!(v >> 63));
+        }
+        sum += (int)(v & 0x7fffffffull);
+      }
+      sum = wave_sum_i(sum);
+      if (lane == 0) s_prefix = sum;
+      // every predecessor's word has been read: count this workgroup out; the last one out zeroes the words for the next launch
+      unsigned long long out = 0;
+      if (lane == 0) out = atomicAdd(&a.order[0], 1ull);
+      out = __shfl(out, 0, 64);
+      if (out == (unsigned long long)(nwg - 1)) {
+        for (int j = lane; j < nwg; j += 64) a.order[1 + j] = 0ull;
+        if (lane == 0) a.order[0] = 0ull;
+      }
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     int tot = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) tot += row_n[k];
-    int b = tot > 0 ? atomicAdd(&a.counter[0], tot) : 0;
+    int b;
+    if (a.order != nullptr) {
+      b = s_prefix;
+      if (tot > 0) atomicAdd(&a.counter[0], tot);      // (the total requested: a sum, whatever the order)
+    } else {
+      b = tot > 0 ? atomicAdd(&a.counter[0], tot) : 0;
+    }
     int accepted = 0, end = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -2992,8 +3041,22 @@ extern "C" int ns_ngp_march_ctl(const uint8_t* bits, int G, int ncasc, const flo
              "ns_ngp_march: null pointer");
   NS_REQUIRE(G > 0 && ncasc >= 1 && ncasc <= 8 && min_step > 0.0f, "ns_ngp_march: bad grid");
   if (R <= 0) return NS_OK;
+  return ns_ngp_march_ordered(bits, G, ncasc, rays_o, rays_d, t_range, R, cone, min_step, max_step, pos_lo, pos_inv, max_per_ray,
+                              max_samples, counter, ray_start, ray_n, pos, dirs, dt, tmid, ctl, nullptr, stream);
+}
+
+extern "C" int ns_ngp_march_ordered(const uint8_t* bits, int G, int ncasc, const float* rays_o, const float* rays_d,
+                                    const float* t_range, int R, float cone, float min_step, float max_step, float pos_lo,
+                                    float pos_inv, int max_per_ray, long max_samples, int* counter, int* ray_start, int* ray_n,
+                                    float* pos, float* dirs, float* dt, float* tmid, const int* ctl, unsigned long long* order_ws,
+                                    void* stream) {
+  NS_REQUIRE(bits && rays_o && rays_d && t_range && counter && ray_start && ray_n && pos && dirs && dt && tmid,
+             "ns_ngp_march: null pointer");
+  NS_REQUIRE(G > 0 && ncasc >= 1 && ncasc <= 8 && min_step > 0.0f, "ns_ngp_march: bad grid");
+  NS_REQUIRE(order_ws == nullptr || ((uintptr_t)order_ws % 8) == 0, "ns_ngp_march_ordered: order_ws must be 8-byte aligned");
+  if (R <= 0) return NS_OK;
   MarchArgs a{bits, rays_o, rays_d, t_range, cone, min_step, max_step, pos_lo, pos_inv, G, ncasc, max_per_ray, max_samples, counter,
-              ray_start, ray_n, pos, dirs, dt, tmid, R, ctl};
+              ray_start, ray_n, pos, dirs, dt, tmid, R, ctl, order_ws};
   hipLaunchKernelGGL(ngp_march_kernel, dim3(ns_cdiv(R, 16)), dim3(256), 0, (hipStream_t)stream, a);
   NS_CHECK_LAUNCH("ngp_march_kernel");
   return NS_OK;

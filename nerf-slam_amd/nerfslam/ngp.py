@@ -284,6 +284,7 @@ class NgpNerf:
                      s_pos=torch.full((S, 3), 0.5, **f), s_dir=torch.zeros((S, 3), **f), s_dt=torch.zeros(S, **f),
                      s_t=torch.zeros(S, **f), s_dout=torch.zeros((S, 4), **h), counter=torch.zeros(3, **i32),
                      loss=torch.zeros(Rc, **f),       # per ray (summed when the loss is read)
+                     order=torch.zeros(Rc // 16 + 2, dtype=torch.int64, device=dev),     # the marcher's ordered-range words
                      ctl=torch.tensor([self.step, min(self.rays_per_batch, Rc), self.seed & 0x7FFFFFFF, max(self.n_images, 1),
                                        fbits(1.0 - c.beta1 ** (self.step + 1)), fbits(1.0 - c.beta2 ** (self.step + 1)), 0, 0], **i32))
             self.sets.append(t)
@@ -329,11 +330,12 @@ class NgpNerf:
                                        C.c_float(0.5 - 0.5 * s), C.c_float(0.5 + 0.5 * s), C.c_float(c.near), C.c_uint32(0), Rc,
                                        ptr(t["r_o"]), ptr(t["r_d"]), ptr(t["r_tr"]), ptr(t["r_rgb"]), ptr(t["r_depth"]),
                                        ptr(t["r_cov"]), ptr(t["r_img"]), ctl, 0, st), "ngp_sample_rays")
-        check(L.ns_ngp_march_ctl(ptr(self.bits), c.grid_size, c.n_cascades, ptr(t["r_o"]), ptr(t["r_d"]), ptr(t["r_tr"]), Rc,
-                                 C.c_float(c.cone_angle), C.c_float(c.min_step), C.c_float(c.max_step),
-                                 C.c_float(0.5 - 0.5 * s), C.c_float(1.0 / s), c.max_steps_per_ray, C.c_long(S), ptr(t["counter"]),
-                                 ptr(t["ray_start"]), ptr(t["ray_n"]), ptr(t["s_pos"]), ptr(t["s_dir"]), ptr(t["s_dt"]),
-                                 ptr(t["s_t"]), ctl, st), "ngp_march")
+        # (ranges in workgroup order: the batch is the same on every run, csrc/ngp.hip: ngp_march_kernel's ordered mode)
+        check(L.ns_ngp_march_ordered(ptr(self.bits), c.grid_size, c.n_cascades, ptr(t["r_o"]), ptr(t["r_d"]), ptr(t["r_tr"]), Rc,
+                                     C.c_float(c.cone_angle), C.c_float(c.min_step), C.c_float(c.max_step),
+                                     C.c_float(0.5 - 0.5 * s), C.c_float(1.0 / s), c.max_steps_per_ray, C.c_long(S), ptr(t["counter"]),
+                                     ptr(t["ray_start"]), ptr(t["ray_n"]), ptr(t["s_pos"]), ptr(t["s_dir"]), ptr(t["s_dt"]),
+                                     ptr(t["s_t"]), ctl, ptr(t["order"]), st), "ngp_march")
 
     @property
     def mlp_frags(self):

@@ -139,6 +139,14 @@ def main():
     # (training is not bit-reproducible from run to run -- f32 LDS atomics in the marcher's compaction order the samples -- and
     #  after 120 steps the loss of two runs of the SAME trainer differs by tens of per cent: same level within a factor of 2)
     ok["replicated_tracks_one_trainer"] = bool(0.5 * l1[-10:].mean() <= l2[-10:].mean() <= 2.0 * l1[-10:].mean())
+    # round 5: the step is bit-reproducible (sample ranges in workgroup order), so the comparisons above can be made exact
+    same = lambda x, y: bool(torch.equal(x.grid_half[:x.n_grid], y.grid_half[:y.n_grid]) and torch.equal(x.mlp_master, y.mlp_master)
+                             and torch.equal(x.c2w, y.c2w))
+    ok["replicated_graphs_equal_eager_bitwise"] = same(repl, repl_e) and bool((l2 == l3).all())
+    # ... and the replicated trainer (gradient buffer, all-to-all of the whole table with itself, streaming Adam on the "shard",
+    # reduce + Adam + fragment pack for the MLP) IS the one-trainer step (Adam in the flushes, one-launch MLP optimiser): same
+    # parameters, same poses, the same loss on every one of the 120 steps
+    ok["replicated_equals_one_trainer_bitwise"] = same(repl, single) and bool((l1 == l2).all())
     res["bytes_exchanged"] = int(getattr(repl, "bytes_allreduced", 0))
     dist.barrier()
     dist.destroy_process_group()
