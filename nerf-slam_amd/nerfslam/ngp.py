@@ -335,7 +335,7 @@ class NgpNerf:
                                      C.c_float(c.cone_angle), C.c_float(c.min_step), C.c_float(c.max_step),
                                      C.c_float(0.5 - 0.5 * s), C.c_float(1.0 / s), c.max_steps_per_ray, C.c_long(S), ptr(t["counter"]),
                                      ptr(t["ray_start"]), ptr(t["ray_n"]), ptr(t["s_pos"]), ptr(t["s_dir"]), ptr(t["s_dt"]),
-                                     ptr(t["s_t"]), ctl, ptr(t["order"]), st), "ngp_march")
+                                     ptr(t["s_t"]), ctl, None if variant_env("NS_MARCH_UNORDERED") else ptr(t["order"]), st), "ngp_march")
 
     @property
     def mlp_frags(self):
