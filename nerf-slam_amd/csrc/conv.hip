@@ -28,6 +28,14 @@ typedef float cv_f32x16 __attribute__((ext_vector_type(16)));
 #define CV_TC 16       // tile columns
 #define CV_SP 24       // slab pixel stride in halves (48 B)
 #define CV_MAXSRC 4
+// Taps of a chunk over which the NEXT chunk's weight LDS-DMAs are issued.  Rounds 2-4 spread them over all nine; issued with the
+// first tap they have the whole chunk to land before the vmcnt(0) that publishes the stage (round 5, two runs per arm on one
+// box, E = 48: 448 -> 256 539 / 539 -> 529 / 523 us, 448 -> 128 249 / 248 -> 238 / 242, 128 -> 128 92.2 / 91.7 -> 89.9 / 90.9;
+// three taps: in between; writing the next slab to LDS two taps before the end instead of after the last MFMA: no further
+// gain at 256 registers) -- a 2-3 % effect: the chunk boundary is not where this kernel's other 60 % of the matrix core goes.
+#ifndef CV_WTAPS
+#define CV_WTAPS 1
+#endif
 
 struct ConvArgs {
   const _Float16* src[CV_MAXSRC];  // virtual concatenation along channels, each [N,H,W,src_ch[s]]
@@ -205,7 +213,9 @@ __global__ __launch_bounds__(256 * CG) void conv_nhwc_kernel(ConvArgs a) {
         for (int m = 0; m < MTW; m++) af[nxt][m] = w[((t + 1) * MT + cg * MTW + m) * 64 + lane];
       }
       // this tap's share of the next chunk's loads
-      const int w0 = t * NPW / T, w1 = (t + 1) * NPW / T;                       // weights: spread over the taps
+      constexpr int TW = T < CV_WTAPS ? T : CV_WTAPS;                            // weights: spread over the first TW taps
+      const int tw0 = t < TW ? t : TW, tw1 = t + 1 < TW ? t + 1 : TW;
+      const int w0 = tw0 * NPW / TW, w1 = tw1 * NPW / TW;
       const int s0 = t < NPS ? t : NPS, s1 = (T == 1) ? NPS : (t + 1 < NPS ? t + 1 : NPS);   // slab: first taps (longest time to land)
       if (MORE) {
 #pragma unroll

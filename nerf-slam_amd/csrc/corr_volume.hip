@@ -148,7 +148,9 @@ __device__ __forceinline__ void row_chunk(const char* tile, const f16x8* src, in
       const f16x8 tgt = *reinterpret_cast<const f16x8*>(rows[t] + kk * 32);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tgt, src[kk], acc[t], 0, 0, 0);
     }
-    if (kk & 1) __builtin_amdgcn_sched_barrier(0);  // at most two k-steps of LDS fragments in flight (register budget)
+    // at most two k-steps of LDS fragments in flight (register budget).  (round 5, measured: all 16 fragment reads of a tile
+    // issued before its first MFMA, 196 registers instead of 164: 228-230 us per 10-edge launch either way)
+    if (kk & 1) __builtin_amdgcn_sched_barrier(0);
   }
   // accumulator r of tile t (this lane's half h): i = (r&3) + 8*(r>>2) + 4*h  ->  x - x0 - 16*NT*h = r + 16*t
 #pragma unroll
@@ -288,7 +290,21 @@ __global__ __launch_bounds__(256) void corr_volume_pyramid_kernel(VolArgs a) {
 // (through a wave-private LDS transposition) because the kernel is bound by the number of L2 write requests, not
 // by bytes: 335 -> 230 us for 10 edges when the 16-byte-per-lane stores became 8-lanes-per-line stores.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stage_tile_load(const _Float16* __restrict__ F2, int ty, int tx, int ht, int wd, int tid,
+typedef uint32_t vol_u32x4 __attribute__((ext_vector_type(4)));
+
+// Raw-buffer addressing for the tile loop (round 5).  The loop prefetches the target tile two iterations ahead and ends every
+// iteration with stores nobody in the kernel reads.  gfx950 has ONE counter for vector loads and stores (vmcnt, in issue order),
+// so "the prefetched tile has arrived" is `s_waitcnt vmcnt(n)` with n = the memory instructions issued after those loads.  With
+// flat loads / stores under per-lane `if`s the compiler branches around them (s_cbranch_execz), can no longer count, and emits
+// vmcnt(0): every iteration then also waited for the PREVIOUS tile's stores to be acknowledged by the L2.  Buffer instructions
+// need no branch: a lane outside the image gets an offset past num_records (loads return 0, stores are dropped), so the level-0
+// stores are exactly four instructions on every path and the compiler's own count comes out as vmcnt(7..4): the tile's stores
+// stay in flight behind the next tile's MFMAs.  Measured on one box, same bits: 235-237 -> 228-230 us per 10-edge launch --
+// 3 %, so the store acknowledgement was a small part of the tile iteration, not the chain that bounds it (two workgroups
+// of 72 KB of LDS per CU already overlap one another's waits).
+#define VOL_OOB 0x80000000u
+
+__device__ __forceinline__ void stage_tile_load(__amdgpu_buffer_rsrc_t F2, int ty, int tx, int ht, int wd, int tid,
                                                 uint4* regs) {
   // 64 pixels x 16 pieces of 16 B; LDS row o = 8 * (row in tile) + (column in tile)
 #pragma unroll
@@ -296,8 +312,9 @@ __device__ __forceinline__ void stage_tile_load(const _Float16* __restrict__ F2,
     const int piece = tid + 256 * k;
     const int o = piece >> 4, sl = piece & 15;
     const int y = 8 * ty + (o >> 3), x = 8 * tx + (o & 7);
-    regs[k] = (y < ht && x < wd) ? *reinterpret_cast<const uint4*>(F2 + ((long)y * wd + x) * 128 + sl * 8)
-                                 : make_uint4(0, 0, 0, 0);
+    const uint32_t off = (y < ht && x < wd) ? (uint32_t)(y * wd + x) * 256u + sl * 16u : VOL_OOB;
+    const vol_u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(F2, off, 0, 0);
+    regs[k] = make_uint4(d[0], d[1], d[2], d[3]);
   }
 }
 
@@ -338,7 +355,8 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
   const long fi = a.ii ? a.ii[e] : e, fj = a.jj ? a.jj[e] : e;
   const int eo = a.slot ? a.slot[e] : e;  // output volume index
   const _Float16* __restrict__ F1 = a.f1 + fi * (long)HW * C;
-  const _Float16* __restrict__ F2 = a.f2 + fj * (long)HW * C;
+  const __amdgpu_buffer_rsrc_t F2 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.f2 + fj * (long)HW * C), 0, HW * C * 2, 0x00027000);
   const int p = p0 + col;
   const bool pok = p < HW;
   f16x8 src[KS];
@@ -353,6 +371,12 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
   const long pp = (long)eo * HW + (pok ? p : 0);
   _Float16* o2 = a.num_levels > 2 ? a.pyr[2] + pp * (long)h2 * w2 : nullptr;
   _Float16* o3 = a.num_levels > 3 ? a.pyr[3] + pp * (long)h3 * w3 : nullptr;
+  // this edge's level-0 / level-1 slices as buffers of exactly HW lines-of-tiles: source pixels >= HW fall off the end
+  // (the host checks that a slice set stays under 2 GiB)
+  const __amdgpu_buffer_rsrc_t O0 =
+      __builtin_amdgcn_make_buffer_rsrc(a.pyr[0] + (long)eo * HW * slice0, 0, (int)(HW * slice0 * 2), 0x00027000);
+  const __amdgpu_buffer_rsrc_t O1 = __builtin_amdgcn_make_buffer_rsrc(
+      a.num_levels > 1 ? a.pyr[1] + (long)eo * HW * slice1 : a.pyr[0], 0, a.num_levels > 1 ? (int)(HW * slice1 * 2) : 0, 0x00027000);
   char* xp0 = xpose[wave][0];
   char* xp1 = xpose[wave][1];
 
@@ -369,18 +393,12 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
   stage_store<2>(lds, tid, regs);
   bool have_next = ld.next(lty, ltx);
   if (have_next) stage_tile_load(F2, lty, ltx, ht, wd, tid, regs);
-  __syncthreads();
+  lds_barrier();  // (not __syncthreads(): the second tile's loads stay in flight)
   int buf = 0;
   f16x4 l2g[2] = {(f16x4)(_Float16)0, (f16x4)(_Float16)0};  // level-2 rows (half, 2 + half) of the group, 4 columns
   f16x2 l3g[2] = {(f16x2)(_Float16)0, (f16x2)(_Float16)0};  // level-3 rows 0, 1 of the group (held by half == 0)
   while (cp.next(ty, tx)) {
     const char* cur = lds + buf * TILEB;
-    if (have_next) {
-      stage_store<2>(lds + (buf ^ 1) * TILEB, tid, regs);           // tile t+1 -> LDS
-      have_next = ld.next(lty, ltx);
-      if (have_next) stage_tile_load(F2, lty, ltx, ht, wd, tid, regs);  // tile t+2 in flight
-    }
-    buf ^= 1;
     f16x2 v[16];  // v[k] = tile-local offsets 32*half + 2k, +1  (rows 4*half .. 4*half+3, 8 columns each)
     row_chunk<C, 2>(cur, src, col, half, v);
     const int dy = ty & 1, dx = tx & 1, gy = ty >> 1, gx = tx >> 1;
@@ -418,24 +436,34 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private areas: LDS ops of one wave complete in order
     {
-      const long tile_off = (long)(ty * ntx0 + tx) * 64;
+      const uint32_t tile_off = (uint32_t)(ty * ntx0 + tx) * 128u;  // bytes
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int line = 8 * k + (lane >> 3), piece = lane & 7;
-        const uint4 d = *reinterpret_cast<const uint4*>(xp0 + line * XPITCH + 16 * piece);
-        const int pl = p0 + line;
-        if (pl < HW) *reinterpret_cast<uint4*>(a.pyr[0] + ((long)eo * HW + pl) * slice0 + tile_off + 8 * piece) = d;
+        const vol_u32x4 d = *reinterpret_cast<const vol_u32x4*>(xp0 + line * XPITCH + 16 * piece);
+        const uint32_t pl = p0 + line;  // pl >= HW: past num_records, dropped
+        __builtin_amdgcn_raw_buffer_store_b128(d, O0, pl * (uint32_t)(slice0 * 2) + tile_off + 16u * piece, 0, 0);
       }
     }
+    // Staging for the next two tiles sits HERE, right behind the four level-0 stores that every path issues: "tile t+1 has
+    // arrived" is then vmcnt(4) -- everything older than this tile's own level-0 stores, which stay in flight.  The
+    // group's level-1 / 2 / 3 stores (every fourth tile) follow the prefetch, so the wait never covers stores issued less than
+    // a whole iteration ago.  buf ^ 1 was read during tile t-1; every wave is past that iteration's barrier.
+    if (have_next) {
+      stage_store<2>(lds + (buf ^ 1) * TILEB, tid, regs);                 // tile t+1 -> LDS
+      have_next = ld.next(lty, ltx);
+      if (have_next) stage_tile_load(F2, lty, ltx, ht, wd, tid, regs);    // tile t+2 in flight
+    }
+    buf ^= 1;
     if (a.num_levels > 1 && last_in_group && gy < nty1 && gx < ntx1) {
       // the group's level-1 tile of every source pixel is complete (parts from tiles outside the grid are padding)
-      const long tile_off = (long)(gy * ntx1 + gx) * 64;
+      const uint32_t tile_off = (uint32_t)(gy * ntx1 + gx) * 128u;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int line = 8 * k + (lane >> 3), piece = lane & 7;
-        const uint4 d = *reinterpret_cast<const uint4*>(xp1 + line * XPITCH + 16 * piece);
-        const int pl = p0 + line;
-        if (pl < HW) *reinterpret_cast<uint4*>(a.pyr[1] + ((long)eo * HW + pl) * slice1 + tile_off + 8 * piece) = d;
+        const vol_u32x4 d = *reinterpret_cast<const vol_u32x4*>(xp1 + line * XPITCH + 16 * piece);
+        const uint32_t pl = p0 + line;
+        __builtin_amdgcn_raw_buffer_store_b128(d, O1, pl * (uint32_t)(slice1 * 2) + tile_off + 16u * piece, 0, 0);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next tile overwrites the areas
@@ -489,10 +517,10 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
         }
       }
     }
-    // (round 4, measured: lds_barrier() here -- no wait for the acknowledgement of the tile's stores or for the tile that was
-    //  just requested -- 243.5 vs 242.1 us per 10-edge launch: this kernel sits on the L2's write-request rate, not on a chain
-    //  of round trips)
-    __syncthreads();
+    // LDS-only barrier: the two sides communicate through the staging buffers alone, and __syncthreads() would drain vmcnt
+    // (round 4 tried only this and measured nothing, 243.5 vs 242.1 us: the vmcnt(0) in front of the staging store at the top
+    // of the loop, see VOL_OOB above, did the same draining one instruction later)
+    lds_barrier();
   }
 }
 
@@ -539,6 +567,13 @@ extern "C" int ns_corr_volume_pyramid_slots(const void* fmap1, const void* fmap2
   if (zs > nby) zs = nby;
   if (zs < 1) zs = 1;
   if (tiled) {
+    // the tiled kernel addresses one edge's level-0 slices with 32-bit buffer offsets
+    const long slice_bytes = (long)HW * nby * ((wd + 7) / 8) * 128;
+    if (slice_bytes >= (1L << 31)) {
+      ns_set_error("ns_corr_volume_pyramid: a %dx%d grid makes %ld-byte level-0 volumes per edge; the tiled layout is built "
+                   "for < 2 GiB per edge", ht, wd, slice_bytes);
+      return NS_ENOSUP;
+    }
     const int ngroups = ((nby + 1) / 2) * ((((wd + 7) / 8) + 1) / 2);
     // z slices: every workgroup walks ceil(ngroups / zt) groups of 2x2 tiles, and the device runs them in ROUNDS of `slots`
     // resident workgroups (two per CU: 72 KB of LDS, 4 waves of ~230 registers).  Round 4 aimed at ~1024 workgroups whatever
