@@ -353,7 +353,13 @@ def micro_benches(dev, hp, ngp_net):
                                           stream_ptr()), "ngp_encode_forward")
 
     # table gradient WITH the optimiser step on the touched entries, on scratch copies of the parameters / moments
-    bw = {k: torch.zeros_like(net.grid_master) for k in ("master", "m1", "m2")}
+    # (in the product's layout: one 32-byte record per entry, nerfslam/ngp.py: new_grid_state; NS_ADAM_SEPARATE=1 with the master
+    #  switch: three dense arrays, rounds 2-4's layout, for the A/B)
+    from nerfslam._lib import variant_env
+    if variant_env("NS_ADAM_SEPARATE"):
+        bw = {k: torch.zeros(net.n_grid, dtype=torch.float32, device=dev) for k in ("master", "m1", "m2")}
+    else:
+        bw = dict(zip(("rec", "master", "m1", "m2"), type(net).new_grid_state(net.n_grid // 2, dev)))
     bw["hp"] = torch.zeros_like(net.grid_half)
     wsb = int(L.ns_ngp_encode_backward_fused_workspace_bytes(*args, C.c_long(S)))
     bws = torch.zeros(wsb // 8 + 1, dtype=torch.int64, device=dev)

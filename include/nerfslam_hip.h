@@ -353,7 +353,12 @@ int ns_ngp_mlp_backward(const void* weights, const void* dLdout, const void* fea
                         void* stream);
 
 /* Adam on f32 master parameters with an f16 working copy; zeroes `grad` behind itself. step >= 1.
- * fixed_scale > 0: `grad` is in the packed fixed-point format of ns_ngp_encode_backward.             */
+ * fixed_scale > 0: `grad` is in the packed fixed-point format of ns_ngp_encode_backward.
+ * Layout of the state (this entry point and ns_ngp_encode_backward_fused*): master, m1, m2 are either three dense f32 [n] arrays,
+ * or -- told from the pointers, m1 == master + 2 floats and m2 == master + 4 floats -- the fields of ONE 32-byte record per table
+ * entry (two parameters): record e at master + 8 e floats = [master.xy | m1.xy | m2.xy | 8 bytes unused]; n even.  A sparsely
+ * touched entry then costs one 128-byte line instead of three; ns_ngp_adam leaves a record whose gradient is zero (and l2 = 0)
+ * unread and its working copy as it is (every writer of the master writes the working copy too).     */
 int ns_ngp_adam(float* master, void* half_params, float* grad, float* m1, float* m2, long n, int step, float lr,
                 float beta1, float beta2, float eps, float l2, float grad_scale, float fixed_scale, void* stream);
 
@@ -573,7 +578,8 @@ int ns_ngp_encode_jacobian_dot_n(int n_levels, int n_features, int log2_hashmap,
  *   dLdoutT: unit-major [2 n_levels][N] f16 (what ns_ngp_mlp_dgrad_n writes); fixed_scale > 0 (packed Q fixed point);
  *   workspace: ns_ngp_encode_backward_fused_workspace_bytes(..., max_samples >= N) bytes of device memory, ZEROED ONCE by
  *     the caller and private to this entry point afterwards (it leaves its overflow counter cleared); the size is checked;
- *   master != NULL: Adam is applied to every touched table entry in the flush of the accumulation (master / m1 / m2 f32,
+ *   master != NULL: Adam is applied to every touched table entry in the flush of the accumulation (master / m1 / m2 f32, dense
+ *     arrays or interleaved 32-byte records as ns_ngp_adam describes -- the trainer keeps records;
  *     half_params the f16 working copy; bias corrections from `step`, or from the device control block `ctl` as
  *     ns_ngp_adam_ctl); grad_params is then not written and may be NULL;
  *   master == NULL: the packed sums are ADDED to grad_params (same bits as ns_ngp_encode_backward).

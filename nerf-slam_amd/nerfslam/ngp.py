@@ -120,7 +120,14 @@ class NgpNerf:
         self.n_grid = int(off[c.n_levels]) * 2
         g = torch.Generator(device="cpu").manual_seed(base_seed)
         f = dict(dtype=torch.float32, device=dev)
-        self.grid_master = (torch.rand(self.n_grid, generator=g) * 2e-4 - 1e-4).to(dev)
+        # Optimiser state of the table: ONE 32-byte record per entry, [master.xy | m1.xy | m2.xy | 8 B unused] (csrc/ngp.hip:
+        # adam_entry_stride).  grid_master / grid_m1 / grid_m2 are [entries, 2] VIEWS of it: the kernels recognise the layout
+        # from the three pointers, and an entry the step touches costs one 128-byte line instead of three.
+        self.grid_state, self.grid_master, self.grid_m1, self.grid_m2 = self.new_grid_state(self.n_grid // 2, dev)
+        if variant_env("NS_ADAM_SEPARATE"):      # A/B: rounds 2-4's three dense arrays (same arithmetic, same bits)
+            self.grid_state = None
+            self.grid_master, self.grid_m1, self.grid_m2 = (torch.zeros((self.n_grid // 2, 2), **f) for _ in range(3))
+        self.grid_master.copy_((torch.rand(self.n_grid, generator=g) * 2e-4 - 1e-4).view(-1, 2))
         w = []
         for (o, i) in MLP_SHAPES:  # Xavier uniform
             lim = math.sqrt(6.0 / (o + i))
@@ -138,13 +145,12 @@ class NgpNerf:
         self.shard_entries = shard_size(n_entries, self.world)
         pad_params = 2 * self.shard_entries * self.world if self.world > 1 else self.n_grid
         self.grid_half = torch.zeros(pad_params, dtype=torch.float16, device=dev)
-        self.grid_half[:self.n_grid] = self.grid_master.half()
+        self.grid_half[:self.n_grid] = self.grid_master.reshape(-1).half()
         self.mlp_half = self.mlp_master.half()
         self.grid_grad, self.mlp_grad = torch.zeros(pad_params, **f), torch.zeros(MLP_TOTAL, **f)
         if self.replicated:
             self._recv = torch.zeros((self.world, self.shard_entries), dtype=torch.int64, device=dev)
             self._gshard = torch.zeros(self.shard_entries, dtype=torch.int64, device=dev)
-        self.grid_m1, self.grid_m2 = torch.zeros(self.n_grid, **f), torch.zeros(self.n_grid, **f)
         self.mlp_m1, self.mlp_m2 = torch.zeros(MLP_TOTAL, **f), torch.zeros(MLP_TOTAL, **f)
         G, nc = c.grid_size, c.n_cascades
         self.density_grid = torch.zeros(nc * G ** 3, **f)
@@ -189,6 +195,13 @@ class NgpNerf:
         self.samples_requested = 0
 
     # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def new_grid_state(n_entries, device):
+        """(records [n_entries, 8] f32, and the master / m1 / m2 views [n_entries, 2] into them) -- the interleaved optimiser
+        state ns_ngp_encode_backward_fused / ns_ngp_adam recognise by m1 == master + 2 floats, m2 == master + 4 floats"""
+        rec = torch.zeros((int(n_entries), 8), dtype=torch.float32, device=device)
+        return rec, rec[:, 0:2], rec[:, 2:4], rec[:, 4:6]
+
     def _grid_args(self):
         c = self.cfg
         return (c.n_levels, 2, c.log2_hashmap, c.base_res, C.c_float(c.per_level_scale))
@@ -555,9 +568,10 @@ class NgpNerf:
                     Ns = self.shard_entries
                     lo = 2 * Ns * self.rank
                     n = max(0, min(2 * Ns, self.n_grid - lo))
-                    if n > 0:
-                        adam(self.grid_master[lo:lo + n], self.grid_half[lo:lo + n], self._gshard.view(torch.float32)[:n],
-                             self.grid_m1[lo:lo + n], self.grid_m2[lo:lo + n], 0.0, c.grad_fixed_scale, stream)
+                    if n > 0:       # (the state's views are indexed by ENTRY: two parameters each)
+                        e0, e1 = lo // 2, (lo + n) // 2
+                        adam(self.grid_master[e0:e1], self.grid_half[lo:lo + n], self._gshard.view(torch.float32)[:n],
+                             self.grid_m1[e0:e1], self.grid_m2[e0:e1], 0.0, c.grad_fixed_scale, stream)
                 else:
                     adam(self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale, stream)
                 mlp_adam(stream)

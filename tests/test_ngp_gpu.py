@@ -941,6 +941,55 @@ def test_fused_table_gradient_adam_is_bit_identical(oracle_mod, dev):
     assert not torch.equal(st["fused"]["master"], m0)
 
 
+def test_interleaved_optimiser_records_are_bit_identical(oracle_mod, dev):
+    """The table's optimiser state as ONE 32-byte record per entry ([master.xy | m1.xy | m2.xy | unused], what the trainer keeps:
+    nerfslam.ngp.NgpNerf.new_grid_state; the library tells it from m1 == master + 2, m2 == master + 4) against three dense
+    arrays: the fused flush (ns_ngp_encode_backward_fused_n) and the streaming pass (ns_ngp_adam, which then leaves untouched
+    records alone) give the same master / moments / f16 copy bit for bit over three steps, and the unused 8 bytes stay zero."""
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    from nerfslam.ngp import NgpNerf
+    N = 1 << 17
+    c, args, n_par, pos, dLT, ws, wsb = _fused_setup(oracle_mod, dev, N, 12)
+    S, lr, b1, b2, eps, gs = 262144.0, 1e-2, 0.9, 0.99, 1e-15, 128.0
+    g = torch.Generator().manual_seed(3)
+    m0 = (torch.rand(n_par, generator=g) * 2e-4 - 1e-4).to(dev)
+    st = {}
+    for name in ("dense_fused", "rec_fused", "rec_stream"):
+        if name.startswith("rec"):
+            rec, ma, m1, m2 = NgpNerf.new_grid_state(n_par // 2, dev)
+            ma.copy_(m0.view(-1, 2))
+            assert m1.data_ptr() == ma.data_ptr() + 8 and m2.data_ptr() == ma.data_ptr() + 16 and rec.stride(0) == 8
+            st[name] = dict(rec=rec, master=ma, m1=m1, m2=m2, hp=m0.half())
+        else:
+            st[name] = dict(master=m0.clone(), hp=m0.half(), m1=torch.zeros(n_par, device=dev), m2=torch.zeros(n_par, device=dev))
+    rng = np.random.default_rng(5)
+    nul = C.c_void_p(0)
+    d_pos = T(pos, dev)
+    for step in (1, 2, 3):
+        dl = dLT.copy()
+        dl[:, rng.uniform(size=N) < 0.5] = 0
+        d_dl = T(dl, dev)
+        for name in ("dense_fused", "rec_fused"):
+            f = st[name]
+            check(lib().ns_ngp_encode_backward_fused_n(*args, ptr(d_pos), ptr(d_dl), nul, ptr(ws), C.c_size_t(wsb), C.c_float(S), C.c_long(N),
+                                                       nul, ptr(f["master"]), ptr(f["hp"]), ptr(f["m1"]), ptr(f["m2"]), step, C.c_float(lr),
+                                                       C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(gs), nul, 15, stream_ptr()), "fused")
+        r = st["rec_stream"]
+        gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
+        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dl), 1, ptr(gq), None, C.c_size_t(0), C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
+        check(lib().ns_ngp_adam(ptr(r["master"]), ptr(r["hp"]), ptr(gq), ptr(r["m1"]), ptr(r["m2"]), C.c_long(n_par), step, C.c_float(lr),
+                                C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(0.0), C.c_float(gs), C.c_float(S), stream_ptr()), "adam")
+        assert int((gq != 0).sum()) == 0                      # the streaming pass clears the gradient behind itself
+        a = st["dense_fused"]
+        for name in ("rec_fused", "rec_stream"):
+            f = st[name]
+            for k in ("master", "m1", "m2"):
+                assert torch.equal(a[k], f[k].reshape(-1)), (name, step, k, int((a[k] != f[k].reshape(-1)).sum()))
+            assert torch.equal(a["hp"], f["hp"]), (name, step)
+            assert float(f["rec"][:, 6:].abs().max()) == 0.0
+    assert not torch.equal(st["rec_fused"]["master"].reshape(-1), m0)
+
+
 @pytest.mark.parametrize("slabs", [64, 7, 300])
 def test_mlp_optimiser_step_in_one_launch_is_bit_identical(dev, slabs):
     """ns_ngp_mlp_step_fused (slab reduce + Adam + f16 copy + both fragment tables, one launch) == ns_ngp_mlp_reduce +

@@ -25,7 +25,10 @@ X = net.sets[1 - net.cur]
 n_dev = C.c_void_p(X["counter"].data_ptr() + 8)
 args = net._grid_args()
 L = lib()
-bw = {k: torch.zeros_like(net.grid_master) for k in ("master", "m1", "m2")}
+if len(sys.argv) > 1 and sys.argv[1] == "separate":      # three dense arrays (rounds 2-4) instead of the 32-byte records
+    bw = {k: torch.zeros(net.n_grid, dtype=torch.float32, device=dev) for k in ("master", "m1", "m2")}
+else:
+    bw = dict(zip(("rec", "master", "m1", "m2"), type(net).new_grid_state(net.n_grid // 2, dev)))
 bw["hp"] = torch.zeros_like(net.grid_half)
 wsb = int(L.ns_ngp_encode_backward_fused_workspace_bytes(*args, C.c_long(S)))
 bws = torch.zeros(wsb // 8 + 1, dtype=torch.int64, device=dev)
