@@ -390,6 +390,7 @@ __device__ __forceinline__ void altcorr_pixel_h(const _Float16* __restrict__ f1,
                                     s11 * (dy * dx);
 }
 
+#ifdef NS_TEST_VARIANTS   // comparison kernel: libnerfslam_hip_variants.so only (common.h)
 __global__ __launch_bounds__(256) void altcorr_tile_mfma_kernel(AltPyramidH P, const int64_t* __restrict__ ii,
                                                                 const int64_t* __restrict__ jj,
                                                                 const float* __restrict__ coords, float* __restrict__ out,
@@ -532,6 +533,7 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_kernel(AltPyramidH P, c
       obase[(long)(oy + 7 * ox) * HW1 + opix] = T0[ox] * w00 + T0[ox + 1] * w01 + T0[8 + ox] * w10 + T0[8 + ox + 1] * w11;
   }
 }
+#endif  // NS_TEST_VARIANTS
 
 // ---------------------------------------------------------------------------------------------
 // The same product with its operands STAGED through LDS and its load round trips cut to two (round 4).  What the kernel above
@@ -750,6 +752,7 @@ __global__ __launch_bounds__(256) void altcorr_tile_mfma_lds_kernel(AltPyramidH 
 // ---------------------------------------------------------------------------------------------
 #define AE_K 208
 #define AE_PITCH 72
+#ifdef NS_TEST_VARIANTS   // comparison kernel: libnerfslam_hip_variants.so only (common.h)
 __global__ __launch_bounds__(256) void altcorr_tile_enc_kernel(AltPyramidH P, const int64_t* __restrict__ ii,
                                                                const int64_t* __restrict__ jj, const float* __restrict__ coords,
                                                                const h8_t* __restrict__ wfrag, const float* __restrict__ bias,
@@ -905,6 +908,7 @@ __global__ __launch_bounds__(256) void altcorr_tile_enc_kernel(AltPyramidH P, co
     }
   }
 }
+#endif  // NS_TEST_VARIANTS
 
 // ---------------------------------------------------------------------------------------------
 // The fused kernel with the LDS-staged operands of altcorr_tile_mfma_lds_kernel (round 4).  A workgroup owns an 8x8 tile
@@ -1184,15 +1188,18 @@ extern "C" int ns_altcorr_pyramid_encode_f16(const void* const* fmaps_host, cons
   dim3 grid(((H1 + 7) / 8) * ((W1 + 7) / 8), E);
   static const bool direct = ns_variant_env("NS_ALTCORR_DIRECT") != nullptr;   // A/B switch: fragments straight from global memory
   static const bool no_xcd = ns_variant_env("NS_ALTCORR_NO_XCD") != nullptr;   // A/B switch: linear tile order
+#ifdef NS_TEST_VARIANTS
   if (direct) {
     hipLaunchKernelGGL(altcorr_tile_enc_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, (const h8_t*)wfrag, bias,
                        (_Float16*)out, E, H1, W1);
     NS_CHECK_LAUNCH("altcorr_tile_enc_kernel");
-  } else {
-    hipLaunchKernelGGL(altcorr_tile_enc_lds_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, (const h8_t*)wfrag,
-                       bias, (_Float16*)out, E, H1, W1, no_xcd ? 0 : 1);
-    NS_CHECK_LAUNCH("altcorr_tile_enc_lds_kernel");
+    return NS_OK;
   }
+#endif
+  (void)direct;
+  hipLaunchKernelGGL(altcorr_tile_enc_lds_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, (const h8_t*)wfrag,
+                     bias, (_Float16*)out, E, H1, W1, no_xcd ? 0 : 1);
+  NS_CHECK_LAUNCH("altcorr_tile_enc_lds_kernel");
   return NS_OK;
 }
 
@@ -1216,15 +1223,18 @@ extern "C" int ns_altcorr_pyramid_f16(const void* const* fmaps_host, int num_lev
   dim3 grid(((H1 + 7) / 8) * ((W1 + 7) / 8), num_levels, E);
   static const bool no_xcd = ns_variant_env("NS_ALTCORR_NO_XCD") != nullptr;   // A/B switch: linear tile order
   static const bool direct = ns_variant_env("NS_ALTCORR_DIRECT") != nullptr;   // A/B switch: fragments straight from global memory
+#ifdef NS_TEST_VARIANTS
   if (direct) {
     hipLaunchKernelGGL(altcorr_tile_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, out, E, H1, W1,
                        no_xcd ? 0 : 1);
     NS_CHECK_LAUNCH("altcorr_tile_mfma_kernel");
-  } else {
-    hipLaunchKernelGGL(altcorr_tile_mfma_lds_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, out, E, H1, W1,
-                       no_xcd ? 0 : 1);
-    NS_CHECK_LAUNCH("altcorr_tile_mfma_lds_kernel");
+    return NS_OK;
   }
+#endif
+  (void)direct;
+  hipLaunchKernelGGL(altcorr_tile_mfma_lds_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, ii, jj, coords, out, E, H1, W1,
+                     no_xcd ? 0 : 1);
+  NS_CHECK_LAUNCH("altcorr_tile_mfma_lds_kernel");
   return NS_OK;
 }
 

@@ -32,14 +32,22 @@ void ns_set_error(const char* fmt, ...);
 static inline int ns_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------
-// A/B switches.  The tools and a few tests select comparison kernels / tunings through NS_* environment variables.  They are
-// honoured ONLY when the master switch NS_VARIANTS is set as well: a stray NS_... in a site-wide environment can then not
-// silently change which kernel the product (or bench.py, which refuses to run with either set) launches.
+// A/B switches and comparison kernels.  The sources build TWO libraries (Makefile):
+//   libnerfslam_hip.so            the product: ns_variant_env() is the constant nullptr, every switch folds to its default and
+//                                 the superseded / comparison kernels (everything inside `#ifdef NS_TEST_VARIANTS`) are not in it;
+//   libnerfslam_hip_variants.so   -DNS_TEST_VARIANTS: the same entry points plus the comparison kernels, selected through NS_*
+//                                 environment variables -- honoured only together with the master switch NS_VARIANTS.  The tests
+//                                 and tools that compare kernels load THIS library (nerfslam/_lib.py: lib() while NS_VARIANTS is
+//                                 set); bench.py and the product never do.
 // ---------------------------------------------------------------------------------------------
 #include <stdlib.h>
+#ifdef NS_TEST_VARIANTS
 static inline const char* ns_variant_env(const char* name) {
   return getenv("NS_VARIANTS") != nullptr ? getenv(name) : nullptr;     // (not cached: tests switch it on and off in one process)
 }
+#else
+static inline constexpr const char* ns_variant_env(const char*) { return nullptr; }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which the compiler

@@ -458,17 +458,27 @@ static int cv_run(const void* const* src_host, const int* src_channels_host, con
     if (!ut_env && tall && wgs(mt, true) < want) tall = false;
     while (mt > 1 && wgs(mt, tall && mt == 4) < want) mt >>= 1;
   }
+  // (the product library holds the seven tilings its own dispatch reaches; the 32-row 1x1 tile and the one-wave-per-SIMD
+  //  128-cout tiles exist for NS_CONV_UT / NS_CONV_CG in the variants library only)
   if (mt == 4 && two && tall) {
     if (ksize == 3) cv_launch<3, 4, 4, 2>(a, st);
+#ifdef NS_TEST_VARIANTS
     else cv_launch<1, 4, 4, 2>(a, st);
+#else
+    else cv_launch<1, 4, 2, 2>(a, st);      // (unreachable: tall implies ksize == 3 without NS_CONV_UT)
+#endif
   } else if (ksize == 3) {
     if (mt == 4 && two) cv_launch<3, 4, 2, 2>(a, st);
+#ifdef NS_TEST_VARIANTS
     else if (mt == 4) cv_launch<3, 4, 2, 1>(a, st);
+#endif
     else if (mt == 2) cv_launch<3, 2, 2, 1>(a, st);
     else cv_launch<3, 1, 2, 1>(a, st);
   } else {
     if (mt == 4 && two) cv_launch<1, 4, 2, 2>(a, st);
+#ifdef NS_TEST_VARIANTS
     else if (mt == 4) cv_launch<1, 4, 2, 1>(a, st);
+#endif
     else if (mt == 2) cv_launch<1, 2, 2, 1>(a, st);
     else cv_launch<1, 1, 2, 1>(a, st);
   }

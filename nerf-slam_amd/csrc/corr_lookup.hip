@@ -569,18 +569,20 @@ extern "C" int ns_corr_lookup_pyramid_slots(const void* const* pyr_host, int num
     L.total_elems[l] = (long)(slot ? capacity : E) * HW1 * L.slice_elems[l];
     NS_REQUIRE(L.h2[l] > 0 && L.w2[l] > 0, "ns_corr_lookup_pyramid: level %d is empty", ll);
   }
+#ifdef NS_TEST_VARIANTS
   static const bool one_lane = ns_variant_env("NS_LOOKUP_ONE_LANE") != nullptr;  // comparison switch: one lane per pixel
   if (one_lane && slot == nullptr) {
-    dim3 grid(ns_cdiv((long)E * HW1, 256), num_levels);
-    hipLaunchKernelGGL(corr_lookup_pyramid_kernel, grid, dim3(256), 0, (hipStream_t)stream, L, coords,
+    dim3 grid1(ns_cdiv((long)E * HW1, 256), num_levels);
+    hipLaunchKernelGGL(corr_lookup_pyramid_kernel, grid1, dim3(256), 0, (hipStream_t)stream, L, coords,
                        coords_interleaved, (_Float16*)out, E, (int)HW1);
     NS_CHECK_LAUNCH("corr_lookup_pyramid_kernel");
-  } else {
-    dim3 grid(ns_cdiv((long)E * HW1, 64), num_levels);
-    hipLaunchKernelGGL(corr_lookup_coop_kernel, grid, dim3(512), 0, (hipStream_t)stream, L, coords, coords_interleaved,
-                       (_Float16*)out, E, (int)HW1, slot);
-    NS_CHECK_LAUNCH("corr_lookup_coop_kernel");
+    return NS_OK;
   }
+#endif
+  dim3 grid(ns_cdiv((long)E * HW1, 64), num_levels);
+  hipLaunchKernelGGL(corr_lookup_coop_kernel, grid, dim3(512), 0, (hipStream_t)stream, L, coords, coords_interleaved,
+                     (_Float16*)out, E, (int)HW1, slot);
+  NS_CHECK_LAUNCH("corr_lookup_coop_kernel");
   return NS_OK;
 }
 

@@ -602,6 +602,7 @@ extern "C" int ns_corr_volume_pyramid_slots(const void* fmap1, const void* fmap2
     return NS_OK;
   }
   dim3 grid(ns_cdiv(HW, 128), E, zs);
+#ifdef NS_TEST_VARIANTS
   static const int mode = ns_variant_env("NS_VOL_NT") ? atoi(ns_variant_env("NS_VOL_NT")) : 2;  // tuning switch: widest column chunk
   if (mode >= 3) {
     hipLaunchKernelGGL((corr_volume_pyramid_kernel<128, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -610,6 +611,9 @@ extern "C" int ns_corr_volume_pyramid_slots(const void* fmap1, const void* fmap2
   } else {
     hipLaunchKernelGGL((corr_volume_pyramid_kernel<128, 1>), grid, dim3(256), 0, (hipStream_t)stream, a);
   }
+#else
+  hipLaunchKernelGGL((corr_volume_pyramid_kernel<128, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+#endif
   NS_CHECK_LAUNCH("corr_volume_pyramid_kernel");
   return NS_OK;
 }

@@ -256,6 +256,7 @@ __device__ __forceinline__ void unpack_fixed(unsigned long long w, float inv_S, 
 // therefore run-length-reduces first: lanes with equal cell coordinates form a run (heads from one
 // ballot), a segmented scan sums the 16 weighted contributions inside each run and only the run's last
 // lane issues the 16 atomics.  Waves with (almost) no sharing skip the scan (wave-uniform decision).
+#ifdef NS_TEST_VARIANTS   // comparison kernel: libnerfslam_hip_variants.so only (common.h)
 __global__ __launch_bounds__(256) void ngp_encode_bwd_kernel(GridLayout g, const float* __restrict__ pos,
                                                              const h2_t* __restrict__ dLdout,
                                                              float* __restrict__ grad, long N, int L, int level0,
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(256) void ngp_encode_bwd_kernel(GridLayout g, const
     atomicAdd(&tab[(long)idx * 2 + 1], v[corner * 2 + 1]);
   }
 }
+#endif  // NS_TEST_VARIANTS
 
 // ---------------------------------------------------------------------------------------------
 // Encode backward WITHOUT global atomics (round 2; what ns_ngp_encode_backward launches).
@@ -1401,6 +1403,7 @@ __device__ __forceinline__ void fb_build_runs(const GridLayout& g, int l, int ti
   fb_runs_of(g, l, P, G, fixed_scale, run, nrun_out);
 }
 
+#ifdef NS_TEST_VARIANTS   // comparison kernel: libnerfslam_hip_variants.so only (common.h)
 __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, FusedPlan fp, const float* __restrict__ pos,
                                                                const _Float16* __restrict__ dpu, long N, float fixed_scale,
                                                                int* __restrict__ ctr, int* __restrict__ cnt,
@@ -1481,6 +1484,7 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
     }
   }
 }
+#endif  // NS_TEST_VARIANTS
 
 // The scatter WITHOUT the LDS staging (round 4, default; NS_FB_SCATTER=1 selects the staged kernel above).  A record's place
 // in its (bin, tile) slot is the value its LDS rank atomic returns -- no prefix sum over the bins is needed for that -- so every
@@ -2625,6 +2629,7 @@ extern "C" int ns_ngp_encode_jacobian_dot_n(int n_levels, int n_features, int lo
 }
 
 // sum the replicas into the gradient and clear them (only entries that were touched are written back)
+#ifdef NS_TEST_VARIANTS   // comparison kernel: libnerfslam_hip_variants.so only (common.h)
 __global__ __launch_bounds__(256) void ngp_encode_bwd_reduce_kernel(GridLayout g, ReplicaPlan rp, int n_levels,
                                                                     float* __restrict__ ws, float* __restrict__ grad,
                                                                     float fixed_scale) {
@@ -2654,6 +2659,7 @@ __global__ __launch_bounds__(256) void ngp_encode_bwd_reduce_kernel(GridLayout g
     }
   }
 }
+#endif  // NS_TEST_VARIANTS
 
 extern "C" long ns_ngp_encode_backward_workspace_bytes(int n_levels, int n_features, int log2_hashmap, int base_res,
                                                        float per_level_scale, long max_samples) {
@@ -2766,6 +2772,7 @@ extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_h
     NS_CHECK_LAUNCH("ngp_encode_bwd_lds_kernel");
     return NS_OK;
   }
+#ifdef NS_TEST_VARIANTS    // round 1's atomic scatter (NS_ENC_BWD_ATOMIC): comparison path, variants library only
   ReplicaPlan rp;
   replica_plan_host(g, n_levels, rp);
   if (workspace_bytes < rp.total_floats * sizeof(float)) workspace = nullptr;   // (then: global atomics on every level)
@@ -2777,6 +2784,7 @@ extern "C" int ns_ngp_encode_backward_n(int n_levels, int n_features, int log2_h
                        n_levels, workspace, grad_params, fixed_scale);
     NS_CHECK_LAUNCH("ngp_encode_bwd_reduce_kernel");
   }
+#endif
   return NS_OK;
 }
 
@@ -2861,12 +2869,17 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
   const long nd = (long)g.offset[n_rl];
   if (parts & 1) {
     const int vec = (N % 4 == 0 && ((uintptr_t)positions % 16) == 0 && ((uintptr_t)dLdoutT % 8) == 0) ? 1 : 0;
-    static const bool staged = [] { const char* e = ns_variant_env("NS_FB_SCATTER"); return e != nullptr && e[0] == '1'; }();
+    bool staged = false;
+#ifdef NS_TEST_VARIANTS
+    static const bool staged_env = [] { const char* e = ns_variant_env("NS_FB_SCATTER"); return e != nullptr && e[0] == '1'; }();
+    staged = staged_env;
     if (staged) {
       hipLaunchKernelGGL(ngp_enc_fscatter_kernel, dim3(fp.ntiles, fp.nh), dim3(256), 0, st, g, fp, positions, (const _Float16*)dLdoutT,
                          N, fixed_scale, ctr, cnt, queue, ovf, n_dev, vec);
       NS_CHECK_LAUNCH("ngp_enc_fscatter_kernel");
-    } else {
+    }
+#endif
+    if (!staged) {
       hipLaunchKernelGGL(ngp_enc_fscatter_direct_kernel, dim3(fp.ntiles, fp.nh), dim3(256), 0, st, g, fp, positions,
                          (const _Float16*)dLdoutT, N, fixed_scale, ctr, cnt, queue, ovf, n_dev, vec);
       NS_CHECK_LAUNCH("ngp_enc_fscatter_direct_kernel");
@@ -2906,11 +2919,14 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
   const int blocks = (tasks + 7) / 8 * 8;
   // the dense levels always go through their partial planes here (the reduce pass is where Adam is applied)
   if (parts & 4) {
+#ifdef NS_TEST_VARIANTS
     if (rl && half_slices) {
       hipLaunchKernelGGL((ngp_encode_bwd_dense_rl_kernel<NS_ENC_SLICE / 2, 512>), dim3(blocks), dim3(512), 0, st, g, plan, positions,
                          (const _Float16*)dLdoutT, grad_params, N, fixed_scale, partial, n_dev);
       NS_CHECK_LAUNCH("ngp_encode_bwd_dense_rl_kernel<half>");
-    } else if (rl) {
+    } else
+#endif
+    if (rl) {
       hipLaunchKernelGGL((ngp_encode_bwd_dense_rl_kernel<NS_ENC_SLICE, 1024>), dim3(blocks), dim3(1024), 0, st, g, plan, positions,
                          (const _Float16*)dLdoutT, grad_params, N, fixed_scale, partial, n_dev);
       NS_CHECK_LAUNCH("ngp_encode_bwd_dense_rl_kernel");

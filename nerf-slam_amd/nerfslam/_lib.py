@@ -13,9 +13,13 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libnerfslam_hip.so")
+# The same sources built with -DNS_TEST_VARIANTS (csrc/common.h, csrc/Makefile): the product's entry points PLUS the superseded /
+# comparison kernels and the NS_* tuning switches that select them.  Only code that sets the master switch NS_VARIANTS -- the
+# bit-identity tests and the A/B tools -- ever loads it; the product library has neither the kernels nor the switches.
+VARIANTS_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libnerfslam_hip_variants.so")
 
 _lock = threading.Lock()
-_lib = None
+_libs = {}
 # Held while a HIP graph is being captured; host threads that synchronise with the device (the tracker's read-backs under
 # --parallel_run) take it around those calls: ROCm 7.2 answered a synchronising call made by one thread while another was
 # capturing with hipErrorIllegalState even in thread-local capture mode.
@@ -31,26 +35,34 @@ class NerfSlamHipError(RuntimeError):
         self.status = status
 
 
+def _load(path):
+    if not os.path.exists(path):
+        raise NerfSlamHipError(
+            f"{path} is missing: build it with `make -C nerf-slam_amd/csrc` "
+            "(or __graft_entry__.build()). There is no CPU fallback.")
+    L = C.CDLL(path)
+    L.ns_last_error.restype = C.c_char_p
+    L.ns_arch.restype = C.c_char_p
+    for name in [n for n in ("ns_ba_plan_index_count", "ns_ba_workspace_bytes") if hasattr(L, n)]:
+        getattr(L, name).restype = C.c_size_t
+    L.ns_ngp_encode_backward_workspace_bytes.restype = C.c_long
+    L.ns_ngp_encode_backward_fused_workspace_bytes.restype = C.c_size_t
+    L.ns_ba_solve_large_workspace_bytes.restype = C.c_size_t
+    L.ns_ngp_mlp_fragment_table_bytes.restype = C.c_size_t
+    return L
+
+
 def lib():
-    global _lib
-    if _lib is None:
+    """The C ABI: the product library -- or, while the master switch NS_VARIANTS is set in the environment (tests / A/B tools
+    only; bench.py refuses to run with it), the variants build of the same sources."""
+    path = LIB_PATH if os.environ.get("NS_VARIANTS") is None else VARIANTS_LIB_PATH
+    L = _libs.get(path)
+    if L is None:
         with _lock:
-            if _lib is None:
-                if not os.path.exists(LIB_PATH):
-                    raise NerfSlamHipError(
-                        f"{LIB_PATH} is missing: build it with `make -C nerf-slam_amd/csrc` "
-                        "(or __graft_entry__.build()). There is no CPU fallback.")
-                L = C.CDLL(LIB_PATH)
-                L.ns_last_error.restype = C.c_char_p
-                L.ns_arch.restype = C.c_char_p
-                for name in [n for n in ("ns_ba_plan_index_count", "ns_ba_workspace_bytes") if hasattr(L, n)]:
-                    getattr(L, name).restype = C.c_size_t
-                L.ns_ngp_encode_backward_workspace_bytes.restype = C.c_long
-                L.ns_ngp_encode_backward_fused_workspace_bytes.restype = C.c_size_t
-                L.ns_ba_solve_large_workspace_bytes.restype = C.c_size_t
-                L.ns_ngp_mlp_fragment_table_bytes.restype = C.c_size_t
-                _lib = L
-    return _lib
+            L = _libs.get(path)
+            if L is None:
+                L = _libs[path] = _load(path)
+    return L
 
 
 def variant_env(name, default=None):

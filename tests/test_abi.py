@@ -33,6 +33,33 @@ def test_library_exports_every_declared_symbol():
     assert L.ns_arch().decode() == "gfx950" and L.ns_version() == 1
 
 
+# kernels that exist only for comparisons / tuning runs (csrc: inside `#ifdef NS_TEST_VARIANTS`)
+COMPARISON_KERNELS = ("altcorr_tile_mfma_kernel", "altcorr_tile_enc_kernel", "ngp_enc_fscatter_kernel", "ngp_encode_bwd_reduce_kernel")
+
+
+def test_product_library_has_no_comparison_kernels_and_no_switches(monkeypatch):
+    """The sources build two libraries (csrc/Makefile, csrc/common.h): the product has neither the superseded / comparison
+    kernels nor the NS_* tuning switches that select them (variant sprawl); the variants build -- loaded only while
+    the master switch NS_VARIANTS is set -- exports the same entry points and has both."""
+    import __graft_entry__
+    __graft_entry__.build()
+    from nerfslam import _lib
+    prod, var = open(_lib.LIB_PATH, "rb").read(), open(_lib.VARIANTS_LIB_PATH, "rb").read()
+    for k in COMPARISON_KERNELS:
+        assert k.encode() not in prod and k.encode() in var, k       # (mangled names: _Z..<name>...)
+    for switch in (b"NS_VARIANTS", b"NS_ALTCORR_DIRECT", b"NS_CONV_CG", b"NS_ENC_BWD_ATOMIC", b"NS_FB_SCATTER", b"NS_VOL_NT"):
+        assert switch not in prod and switch in var, switch
+    monkeypatch.delenv("NS_VARIANTS", raising=False)
+    p = _lib.lib()
+    monkeypatch.setenv("NS_VARIANTS", "1")
+    v = _lib.lib()
+    assert p is not v and p._name == _lib.LIB_PATH and v._name == _lib.VARIANTS_LIB_PATH
+    missing = [n for n in _declared() if not hasattr(v, n)]
+    assert not missing, missing
+    monkeypatch.delenv("NS_VARIANTS")
+    assert _lib.lib() is p
+
+
 def test_shim_has_the_reference_operator_table():
     import droid_backends
     ref_ops = ["ba", "reduced_camera_matrix", "solve_depth", "solve_poses", "frame_distance", "projmap",
