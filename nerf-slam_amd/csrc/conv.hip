@@ -239,7 +239,8 @@ __global__ __launch_bounds__(256 * CG) void conv_nhwc_kernel(ConvArgs a) {
 #pragma unroll
         for (int u = 0; u < UT; u++)
           acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][m], bf[cur][u], acc[m][u], 0, 0, 0);
-      // issue order inside the tap: MFMA, one memory instruction, MFMA, ...
+      // issue order inside the tap: MFMA, one memory instruction, MFMA, ...  (round 5, measured: 1, 3 or all 6 of the next tap's
+      // fragment reads behind each MFMA instead of 2 -- 512-535 us on the 448 -> 256 gate in every arm, inside the run-to-run spread)
       const int nds = (t + 1 < T) ? UT + MTW : 0, nvm = MORE ? (w1 - w0) + (s1 - s0) : 0;
 #pragma unroll
       for (int i = 0; i < MTW * UT; i++) {
