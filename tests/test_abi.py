@@ -76,6 +76,11 @@ def test_error_reporting_without_a_gpu():
     assert rc == -1 and b"null pointer" in L.ns_last_error()
     rc = L.ns_altcorr_forward(C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 1, 4, 4, 4, 4, 8, 1, 2, None)
     assert rc == -3  # radius != 3: NS_ENOSUP
+    # the tiled volume build addresses one edge's level-0 slices with 32-bit buffer offsets: a grid whose slices reach 2 GiB per
+    # edge is refused before anything is launched (csrc/corr_volume.hip)
+    pyr = (C.c_void_p * 4)(8, 8, 8, 8)
+    rc = L.ns_corr_volume_pyramid(C.c_void_p(8), C.c_void_p(8), None, None, pyr, 4, 1, 128, 192, 256, 1, None)
+    assert rc == -3 and b"2 GiB" in L.ns_last_error()
 
 
 @pytest.mark.parametrize("seed", range(4))
