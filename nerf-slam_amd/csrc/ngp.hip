@@ -1178,7 +1178,8 @@ static size_t fused_ws_bytes(const FusedPlan& f, const GridLayout& g, int n_leve
 
 // one merged run of a lane: the cell and the summed integer contributions of its 8 corners
 struct FbRun {
-  uint32_t c[3];
+  uint32_t cx, cy, cz;   // (three scalars, not c[3]: as an array member the cell was the one part of a run the compiler kept in
+                         //  SCRATCH memory -- 64 bytes per lane, 33 scratch stores and 64 scratch loads in the scatter kernel)
   int a[8], b[8];
 };
 
@@ -1213,10 +1214,24 @@ __device__ __forceinline__ void fb_indices_any(bool hashed, const uint32_t c[3],
 __device__ __forceinline__ void fb_wave_merge(FbRun (&run)[NS_FB_RUN], int& nrun) {
   const int lane = threadIdx.x & 63;
   // the last run (run[nrun - 1], static indexing only) in registers of its own
-  FbRun v = run[0];
+  // (member by member: an aggregate copy of an FbRun is what made the compiler keep the runs' cells in scratch memory)
+  FbRun v;
+  v.cx = run[0].cx; v.cy = run[0].cy; v.cz = run[0].cz;
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) {
+    v.a[corner] = run[0].a[corner];
+    v.b[corner] = run[0].b[corner];
+  }
 #pragma unroll
   for (int r = 1; r < NS_FB_RUN; r++)
-    if (r == nrun - 1) v = run[r];
+    if (r == nrun - 1) {
+      v.cx = run[r].cx; v.cy = run[r].cy; v.cz = run[r].cz;
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) {
+        v.a[corner] = run[r].a[corner];
+        v.b[corner] = run[r].b[corner];
+      }
+    }
   int big_f = 0, big_l = 0;
 #pragma unroll
   for (int corner = 0; corner < 8; corner++) {
@@ -1224,10 +1239,10 @@ __device__ __forceinline__ void fb_wave_merge(FbRun (&run)[NS_FB_RUN], int& nrun
     big_l |= abs(v.a[corner]) | abs(v.b[corner]);
   }
   const bool can_f = nrun >= 1 && big_f < (1 << 17), can_l = nrun >= 1 && big_l < (1 << 17);
-  const uint32_t p0 = __shfl_up(v.c[0], 1, 64), p1 = __shfl_up(v.c[1], 1, 64), p2 = __shfl_up(v.c[2], 1, 64);
+  const uint32_t p0 = __shfl_up(v.cx, 1, 64), p1 = __shfl_up(v.cy, 1, 64), p2 = __shfl_up(v.cz, 1, 64);
   const int pcan = __shfl_up((int)can_l, 1, 64);
   // recv: this lane's first run continues the previous lane's last run; cont: and it is this lane's only run
-  const bool recv = lane > 0 && can_f && pcan && p0 == run[0].c[0] && p1 == run[0].c[1] && p2 == run[0].c[2];
+  const bool recv = lane > 0 && can_f && pcan && p0 == run[0].cx && p1 == run[0].cy && p2 == run[0].cz;
   const bool cont = recv && nrun == 1;
   int head = cont ? 0 : lane;
 #pragma unroll
@@ -1325,7 +1340,7 @@ __device__ __forceinline__ void fb_runs_of(const GridLayout& g, int l, const FbP
   // ---- merge neighbours that share a cell ----
 #pragma unroll
   for (int corner = 0; corner < 8; corner++) run[0].a[corner] = run[0].b[corner] = 0;   // (read by fb_wave_merge's shuffles)
-  run[0].c[0] = run[0].c[1] = run[0].c[2] = 0u;
+  run[0].cx = run[0].cy = run[0].cz = 0u;
   int nrun = 0;
   bool open = false, open_small = false;
   const float scale = g.scale[l];
@@ -1362,7 +1377,7 @@ __device__ __forceinline__ void fb_runs_of(const GridLayout& g, int l, const FbP
     bool merged = false;
 #pragma unroll
     for (int r = 0; r < NS_FB_RUN; r++) {
-      if (r == nrun - 1 && open && open_small && small && run[r].c[0] == c[0] && run[r].c[1] == c[1] && run[r].c[2] == c[2]) {
+      if (r == nrun - 1 && open && open_small && small && run[r].cx == c[0] && run[r].cy == c[1] && run[r].cz == c[2]) {
 #pragma unroll
         for (int corner = 0; corner < 8; corner++) {
           run[r].a[corner] += ca[corner];
@@ -1375,7 +1390,7 @@ __device__ __forceinline__ void fb_runs_of(const GridLayout& g, int l, const FbP
 #pragma unroll
       for (int r = 0; r < NS_FB_RUN; r++) {
         if (r == nrun) {
-          run[r].c[0] = c[0]; run[r].c[1] = c[1]; run[r].c[2] = c[2];
+          run[r].cx = c[0]; run[r].cy = c[1]; run[r].cz = c[2];
 #pragma unroll
           for (int corner = 0; corner < 8; corner++) {
             run[r].a[corner] = ca[corner];
@@ -1431,7 +1446,10 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
   for (int r = 0; r < NS_FB_RUN; r++) {
     if (r < nrun) {
       uint32_t idx[8];
-      fb_indices_any(hashed, run[r].c, hs, res, idx);
+      {
+        const uint32_t rc[3] = {run[r].cx, run[r].cy, run[r].cz};
+        fb_indices_any(hashed, rc, hs, res, idx);
+      }
 #pragma unroll
       for (int corner = 0; corner < 8; corner++)   // (a contribution that rounds to zero in both fields is not a record: most
         rank[r][corner] = (run[r].a[corner] | run[r].b[corner]) != 0   //  corners of a converged scene's tiny gradients)
@@ -1457,7 +1475,10 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_kernel(GridLayout g, Fus
   for (int r = 0; r < NS_FB_RUN; r++) {
     if (r < nrun) {
       uint32_t idx[8];
-      fb_indices_any(hashed, run[r].c, hs, res, idx);
+      {
+        const uint32_t rc[3] = {run[r].cx, run[r].cy, run[r].cz};
+        fb_indices_any(hashed, rc, hs, res, idx);
+      }
 #pragma unroll
       for (int corner = 0; corner < 8; corner++)
         if (rank[r][corner] >= 0)
@@ -1539,7 +1560,10 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_direct_kernel(GridLayout
     for (int corner = 0; corner < 8; corner++) any |= run[r].a[corner] | run[r].b[corner];
     if (r < nrun && any != 0) {
       uint32_t idx[8];
-      fb_indices_any(hashed, run[r].c, hs, res, idx);
+      {
+        const uint32_t rc[3] = {run[r].cx, run[r].cy, run[r].cz};
+        fb_indices_any(hashed, rc, hs, res, idx);
+      }
 #pragma unroll
       for (int corner = 0; corner < 8; corner++) {
         if ((run[r].a[corner] | run[r].b[corner]) == 0) continue;   // rounds to zero in both fields: not a record
@@ -1569,7 +1593,10 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_direct_kernel(GridLayout
   for (int r = 0; r < NS_FB_RUN; r++) {
     if (r < nrun && ((spill >> (8 * r)) & 0xffu)) {
       uint32_t idx[8];
-      fb_indices_any(hashed, run[r].c, hs, res, idx);
+      {
+        const uint32_t rc[3] = {run[r].cx, run[r].cy, run[r].cz};
+        fb_indices_any(hashed, rc, hs, res, idx);
+      }
 #pragma unroll
       for (int corner = 0; corner < 8; corner++) {
         if (!((spill >> (8 * r + corner)) & 1u)) continue;
