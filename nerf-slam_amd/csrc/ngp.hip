@@ -1162,6 +1162,7 @@ static bool fused_plan_host(const GridLayout& g, int n_levels, long N, FusedPlan
   for (int k = f.nh; k < 16; k++) f.level[k] = f.nbins[k] = f.slot[k] = f.hashed[k] = f.merge[k] = f.shift[k] = 0;
   f.ntiles = (int)((N + NS_BIN_TILE - 1) / NS_BIN_TILE);
   f.ovf_cap = (long)f.ntiles * NS_BIN_TILE * 8 * (f.nh > 0 ? f.nh : 1);
+  if ((long)f.ntiles * NS_FB_SLOT >= (1L << 24)) return false;   // (the scatter's 24-bit record addressing: N < 33.5 M samples per call)
   return f.nh > 0;
 }
 // workspace: [ctr: {overflow count, error flag}] [cnt: nh*64*ntiles run lengths] [queue: nh*64*ntiles slots of NS_FB_SLOT
@@ -1183,11 +1184,16 @@ struct FbRun {
   int a[8], b[8];
 };
 
+// (round 5: 24-bit multiplies.  v_mul_lo_u32 issues at a quarter of the rate of v_mul_u32_u24, and the scatter pass is vector-ALU
+//  bound.  Hashed level: only the low log2(hs) <= 24 bits of y P1 and z P2 survive the mask, and those are the low
+//  bits of y (P1 mod 2^24) -- exact for cell coordinates below 2^24.  Dense level: res^3 <= hs <= 2^24, so every factor of
+//  x + (y + z res) res is below 2^24 as well.  Same indices, bit for bit: the bit-identity tests compare with kernels that use
+//  grid_index_lvl.)
 __device__ __forceinline__ void fb_indices(const uint32_t c[3], uint32_t hs, uint32_t idx[8]) {
   const uint32_t hx[2] = {c[0], c[0] + 1u};
-  const uint32_t hy0 = c[1] * 2654435761u, hz0 = c[2] * 805459861u;
-  const uint32_t hy[2] = {hy0, hy0 + 2654435761u};
-  const uint32_t hz[2] = {hz0, hz0 + 805459861u};
+  const uint32_t hy0 = (uint32_t)__umul24(c[1], 2654435761u & 0xffffffu), hz0 = (uint32_t)__umul24(c[2], 805459861u & 0xffffffu);
+  const uint32_t hy[2] = {hy0, hy0 + (2654435761u & 0xffffffu)};
+  const uint32_t hz[2] = {hz0, hz0 + (805459861u & 0xffffffu)};
 #pragma unroll
   for (int corner = 0; corner < 8; corner++) idx[corner] = (hx[corner & 1] ^ hy[(corner >> 1) & 1] ^ hz[corner >> 2]) & (hs - 1u);
 }
@@ -1196,9 +1202,16 @@ __device__ __forceinline__ void fb_indices_any(bool hashed, const uint32_t c[3],
   if (hashed) {
     fb_indices(c, hs, idx);
   } else {
+    // grid_index_lvl(false, ...) of the 8 corners: clamp, x + (y + z res) res, one conditional subtraction
+    auto mn = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+    const uint32_t x[2] = {mn(c[0], res), mn(c[0] + 1u, res)};
+    const uint32_t y[2] = {mn(c[1], res), mn(c[1] + 1u, res)};
+    const uint32_t zr[2] = {(uint32_t)__umul24(mn(c[2], res), res), (uint32_t)__umul24(mn(c[2] + 1u, res), res)};
 #pragma unroll
-    for (int corner = 0; corner < 8; corner++)
-      idx[corner] = grid_index_lvl(false, hs, res, c[0] + (corner & 1), c[1] + ((corner >> 1) & 1), c[2] + (corner >> 2));
+    for (int corner = 0; corner < 8; corner++) {
+      const uint32_t i = x[corner & 1] + (uint32_t)__umul24(y[(corner >> 1) & 1] + zr[corner >> 2], res);
+      idx[corner] = i >= hs ? i - hs : i;
+    }
   }
 }
 
@@ -1551,7 +1564,10 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_direct_kernel(GridLayout
   if (fp.merge[k]) fb_wave_merge(run, nrun);     // (uniform per workgroup)
   __syncthreads();
   unsigned long long* __restrict__ qlev = queue + (long)k * NS_FB_BINS * fp.ntiles * NS_FB_SLOT + (long)tile * slot;
-  const long bstride = (long)fp.ntiles * slot;
+  // record (bin b, rank) of this tile's slots sits at qlev[b * bstride + rank].  In 32 bits -- b < 64, bstride = tiles x slot < 2^24
+  // (checked by the host) -- it is ONE full-rate v_mad_u32_u24; as `(long)b * bstride + rank` it was two v_mul_lo_u32 and a
+  // v_mad_u64_u32 per record store, quarter-rate instructions in a pass whose vector ALU is two thirds busy.
+  const uint32_t bstride = (uint32_t)fp.ntiles * (uint32_t)slot;
   uint32_t spill = 0u;            // bit (8 r + corner): that record found its slot full
 #pragma unroll
   for (int r = 0; r < NS_FB_RUN; r++) {
@@ -1570,7 +1586,7 @@ __global__ __launch_bounds__(256) void ngp_enc_fscatter_direct_kernel(GridLayout
         const int b = (int)(idx[corner] >> shift);
         const int rank = atomicAdd(&lcnt[b], 1);
         if (rank < slot)
-          qlev[(long)b * bstride + rank] = ((unsigned long long)(idx[corner] & bmask) << 50) |
+          qlev[__umul24((uint32_t)b, bstride) + (uint32_t)rank] = ((unsigned long long)(idx[corner] & bmask) << 50) |
                                            ((unsigned long long)((uint32_t)run[r].b[corner] & 0x1ffffffu) << 25) |
                                            (unsigned long long)((uint32_t)run[r].a[corner] & 0x1ffffffu);
         else
