@@ -60,6 +60,46 @@ def test_product_library_has_no_comparison_kernels_and_no_switches(monkeypatch):
     assert _lib.lib() is p
 
 
+# kernels that may keep a private (scratch) segment: cold paths only (the f32 / oversized-E altcorr fallbacks, the sigma kernel
+# of the large solve, the superseded weight-gradient reference entry)
+SCRATCH_ALLOWED = ("altcorr_forward_kernel", "altcorr_pyramid_kernel", "bsl_sigma_kernel", "ngp_mlp_wgrad_recompute_kernel")
+
+
+def test_no_hot_kernel_spills_to_scratch(tmp_path):
+    """Round 5 found the table gradient's scatter pass keeping 64 bytes per lane in scratch memory (an aggregate struct copy the
+    compiler could not take apart: 97 scratch instructions per thread, 13-22 % of the kernel): every kernel of the product library
+    is checked here -- from the code objects' own metadata -- for a private segment, with the cold fallbacks listed by name."""
+    import shutil
+    import subprocess
+    import __graft_entry__
+    __graft_entry__.build()
+    from nerfslam import _lib
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(os.path.join(tools, "llvm-objdump")) and os.path.exists(os.path.join(tools, "llvm-readelf"))):
+        pytest.skip("llvm-objdump / llvm-readelf of the ROCm toolchain not found")
+    so = os.path.join(str(tmp_path), "l.so")
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([os.path.join(tools, "llvm-objdump"), "--offloading", so], cwd=str(tmp_path), capture_output=True, check=True)
+    objs = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
+    assert len(objs) >= 10, objs
+    seen, bad = 0, []
+    for f in objs:
+        notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", os.path.join(str(tmp_path), f)], capture_output=True,
+                               text=True, check=True).stdout
+        name = None
+        for line in notes.splitlines():
+            line = line.strip()
+            if line.startswith(".name:"):
+                name = line.split(":", 1)[1].strip()
+            elif line.startswith(".private_segment_fixed_size:") and name is not None:
+                seen += 1
+                if int(line.split(":", 1)[1]) != 0 and not any(a in name for a in SCRATCH_ALLOWED):
+                    bad.append((name, int(line.split(":", 1)[1])))
+                name = None
+    assert seen >= 80, seen
+    assert not bad, bad
+
+
 def test_shim_has_the_reference_operator_table():
     import droid_backends
     ref_ops = ["ba", "reduced_camera_matrix", "solve_depth", "solve_poses", "frame_distance", "projmap",
