@@ -1162,7 +1162,12 @@ static bool fused_plan_host(const GridLayout& g, int n_levels, long N, FusedPlan
   for (int k = f.nh; k < 16; k++) f.level[k] = f.nbins[k] = f.slot[k] = f.hashed[k] = f.merge[k] = f.shift[k] = 0;
   f.ntiles = (int)((N + NS_BIN_TILE - 1) / NS_BIN_TILE);
   f.ovf_cap = (long)f.ntiles * NS_BIN_TILE * 8 * (f.nh > 0 ? f.nh : 1);
-  if ((long)f.ntiles * NS_FB_SLOT >= (1L << 24)) return false;   // (the scatter's 24-bit record addressing: N < 33.5 M samples per call)
+  // the scatter addresses a record as __umul24(bin, ntiles * slot[k]) + rank: the stride of the LARGEST slot of the plan has to
+  // stay below 2^24 (a level of few bins has slots of up to 8 x NS_BIN_TILE records, not NS_FB_SLOT: N < 2.1 M samples per call
+  // with an 8192-record slot, 4.2 M with the dense levels' 4096)
+  int max_slot = NS_FB_SLOT;
+  for (int k = 0; k < f.nh; k++) max_slot = f.slot[k] > max_slot ? f.slot[k] : max_slot;
+  if ((long)f.ntiles * max_slot >= (1L << 24)) return false;
   return f.nh > 0;
 }
 // workspace: [ctr: {overflow count, error flag}] [cnt: nh*64*ntiles run lengths] [queue: nh*64*ntiles slots of NS_FB_SLOT
@@ -2897,6 +2902,8 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
     ad.m1 = m1;
     ad.m2 = m2;
     ad.es = adam_entry_stride(master, m1, m2);
+    NS_REQUIRE(ad.es == 2 || ((uintptr_t)master & 15) == 0,
+               "ns_ngp_encode_backward_fused: interleaved optimiser records need a 16-byte aligned base (float4 accesses)");
     ad.c1 = 1.0f - powf(beta1, (float)(step < 1 ? 1 : step));
     ad.c2 = 1.0f - powf(beta2, (float)(step < 1 ? 1 : step));
     ad.lr = lr;
@@ -3003,6 +3010,7 @@ extern "C" int ns_ngp_adam_ctl(float* master, void* half_params, float* grad, fl
   const float c1 = 1.0f - powf(beta1, (float)(step < 1 ? 1 : step)), c2 = 1.0f - powf(beta2, (float)(step < 1 ? 1 : step));
   const int es = adam_entry_stride(master, m1, m2);
   NS_REQUIRE(es == 2 || n % 2 == 0, "ns_ngp_adam: interleaved records hold two parameters each");
+  NS_REQUIRE(es == 2 || ((uintptr_t)master & 15) == 0, "ns_ngp_adam: interleaved optimiser records need a 16-byte aligned base");
   hipLaunchKernelGGL(ngp_adam_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, master,
                      (_Float16*)half_params, grad, m1, m2, n, c1, c2, lr, beta1, beta2, eps, l2, 1.0f / grad_scale,
                      fixed_scale > 0.0f ? 1.0f / fixed_scale : 0.0f, ctl, es);

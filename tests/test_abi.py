@@ -166,3 +166,28 @@ def test_ba_plan_matches_oracle_index_logic(seed):
     rp, rows = idx[o[6]:o[6] + plan.K + 1], idx[o[7]:o[7] + NE]
     for k in range(plan.K):
         np.testing.assert_array_equal(rows[rp[k]:rp[k + 1]], np.nonzero(kk == k)[0])
+
+
+def test_scatter_plan_refuses_sample_counts_beyond_its_24_bit_record_addressing():
+    """the table-gradient scatter addresses a record as __umul24(bin, ntiles * slot[k]) + rank, so the
+    stride of the plan's LARGEST slot has to stay below 2^24.  The default grid's dense levels have 8 bins -> slots of
+    64 * 512 / 8 = 4096 records: the plan holds up to ntiles * 4096 < 2^24, i.e. N < 4.19 M samples per call (the host check
+    used the 512-record slot of the hashed levels and passed up to 33.5 M).  A refused plan reports a workspace of 0 bytes
+    and ns_ngp_encode_backward_fused returns NS_ENOSUP instead of corrupting records."""
+    import __graft_entry__
+    __graft_entry__.build()
+    from nerfslam._lib import lib
+    L = lib()
+    L.ns_ngp_encode_backward_fused_workspace_bytes.restype = C.c_size_t
+    args = (16, 2, 19, 16, C.c_float(1.5157166))
+
+    def ws(n):
+        return int(L.ns_ngp_encode_backward_fused_workspace_bytes(*args, C.c_long(n)))
+    assert ws(1 << 18) > 0                                  # the trainer's budget
+    tile = 1024
+    limit = ((1 << 24) // 4096) * tile                      # first sample count whose tiles x 4096 reaches 2^24
+    assert ws(limit - tile) > 0 and ws(limit - tile + 1) == 0 and ws(limit + 5 * tile) == 0 and ws(8 << 20) == 0
+    # a grid whose dense levels are small enough for 8192-record slots halves the bound
+    small = (4, 2, 19, 4, C.c_float(1.3))
+    got = [int(L.ns_ngp_encode_backward_fused_workspace_bytes(*small, C.c_long(n))) for n in (1 << 18, 3 << 20)]
+    assert got[0] > 0 and got[1] == 0
