@@ -714,33 +714,50 @@ int orc_reduced_camera_matrix(const float* poses, const float* disps, const floa
   /* Ei = accum(Eiz, ii, ts) (:1757) */
   accum(Eiz, ii, M, ts, P, (long)6 * HW, E);
 
-  /* schur_block (:1349-1438) */
+  /* schur_block (:1349-1438).  Three passes so that the pixel sums (the only expensive part: one per ordered row pair of a
+   * depth slot, ~68 k of them at P = 256 / M = 3912) can run on all host cores while the accumulation into S keeps the
+   * serial enumeration order of the reference's pair list (:1368-1402) -- the result is bit-identical to the plain double
+   * loop this replaces, for any thread count. */
   double* S = (double*)calloc((size_t)n6 * n6 + 1, 8);
   double* s = (double*)calloc((size_t)n6 + 1, 8);
+  long n_pairs = 0;
   for (int n = 0; n < NE; n++) {
-    long tn = jj_exp[n] - kf0;
     if (!(jj_exp[n] >= kf0 && jj_exp[n] < kf1)) continue; /* (:1375; j==kf1 would overflow graph[P]) */
-    for (int m = 0; m < NE; m++) {
-      long tm = jj_exp[m] - kf0;
-      if (!(jj_exp[m] >= kf0 && jj_exp[m] < kf1)) continue;
-      if (kk[n] != kk[m]) continue;
-      /* EEt6x6: dS[a][b] = sum_px (E[n][a]*q) * E[m][b]  (:1142-1157), float products, reduced here in double */
-      double dS[36];
-      for (int q = 0; q < 36; q++) dS[q] = 0;
-      const float* Qk = Q + kk[n] * HW;
-      for (int p = 0; p < HW; p++) {
-        float ei[6], ej[6];
-        for (int c = 0; c < 6; c++) {
-          ei[c] = E[((long)n * 6 + c) * HW + p] * Qk[p];
-          ej[c] = E[((long)m * 6 + c) * HW + p];
-        }
-        for (int c = 0; c < 6; c++)
-          for (int d = 0; d < 6; d++) dS[c * 6 + d] += (double)(ei[c] * ej[d]);
+    for (int m = 0; m < NE; m++)
+      if (jj_exp[m] >= kf0 && jj_exp[m] < kf1 && kk[n] == kk[m]) n_pairs++;
+  }
+  int* pn = (int*)malloc(sizeof(int) * (size_t)(n_pairs + 1));
+  int* pm = (int*)malloc(sizeof(int) * (size_t)(n_pairs + 1));
+  float* dSf = (float*)malloc(sizeof(float) * (size_t)(n_pairs + 1) * 36);
+  float* bbf = (float*)calloc((size_t)NE * 6 + 1, 4);
+  n_pairs = 0;
+  for (int n = 0; n < NE; n++) {
+    if (!(jj_exp[n] >= kf0 && jj_exp[n] < kf1)) continue;
+    for (int m = 0; m < NE; m++)
+      if (jj_exp[m] >= kf0 && jj_exp[m] < kf1 && kk[n] == kk[m]) { pn[n_pairs] = n; pm[n_pairs] = m; n_pairs++; }
+  }
+#pragma omp parallel for schedule(dynamic, 16)
+  for (long t = 0; t < n_pairs; t++) {
+    const int n = pn[t], m = pm[t];
+    /* EEt6x6: dS[a][b] = sum_px (E[n][a]*q) * E[m][b]  (:1142-1157), float products, reduced here in double */
+    double dS[36];
+    for (int q = 0; q < 36; q++) dS[q] = 0;
+    const float* Qk = Q + kk[n] * HW;
+    for (int p = 0; p < HW; p++) {
+      float ei[6], ej[6];
+      for (int c = 0; c < 6; c++) {
+        ei[c] = E[((long)n * 6 + c) * HW + p] * Qk[p];
+        ej[c] = E[((long)m * 6 + c) * HW + p];
       }
       for (int c = 0; c < 6; c++)
-        for (int d = 0; d < 6; d++) S[(6 * tn + c) * n6 + (6 * tm + d)] += (double)(float)dS[c * 6 + d];
+        for (int d = 0; d < 6; d++) dS[c * 6 + d] += (double)(ei[c] * ej[d]);
     }
-    /* Ev6x1 (:1191-1197) then update_rhs(v, jj_exp-kf0) (:1435) */
+    for (int q = 0; q < 36; q++) dSf[t * 36 + q] = (float)dS[q];
+  }
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int n = 0; n < NE; n++) {
+    if (!(jj_exp[n] >= kf0 && jj_exp[n] < kf1)) continue;
+    /* Ev6x1 (:1191-1197) */
     double bb[6] = {0, 0, 0, 0, 0, 0};
     const float* Qk = Q + kk[n] * HW;
     const float* wk = w + kk[n] * HW;
@@ -748,8 +765,19 @@ int orc_reduced_camera_matrix(const float* poses, const float* disps, const floa
       float q_w = Qk[p] * wk[p];
       for (int c = 0; c < 6; c++) bb[c] += (double)(q_w * E[((long)n * 6 + c) * HW + p]);
     }
-    for (int c = 0; c < 6; c++) s[tn * 6 + c] += (double)(float)bb[c];
+    for (int c = 0; c < 6; c++) bbf[(long)n * 6 + c] = (float)bb[c];
   }
+  for (long t = 0; t < n_pairs; t++) {
+    const long tn = jj_exp[pn[t]] - kf0, tm = jj_exp[pm[t]] - kf0;
+    for (int c = 0; c < 6; c++)
+      for (int d = 0; d < 6; d++) S[(6 * tn + c) * n6 + (6 * tm + d)] += (double)dSf[t * 36 + c * 6 + d];
+  }
+  for (int n = 0; n < NE; n++) { /* update_rhs(v, jj_exp-kf0) (:1435) */
+    if (!(jj_exp[n] >= kf0 && jj_exp[n] < kf1)) continue;
+    const long tn = jj_exp[n] - kf0;
+    for (int c = 0; c < 6; c++) s[tn * 6 + c] += (double)bbf[(long)n * 6 + c];
+  }
+  free(pn); free(pm); free(dSf); free(bbf);
   /* rcm = A - S; get_dense(): column-major data read row-major (:1305-1316) => transpose */
   for (int r = 0; r < n6; r++)
     for (int c = 0; c < n6; c++) H[(long)r * n6 + c] = (float)(A[(long)c * n6 + r] - S[(long)c * n6 + r]);
