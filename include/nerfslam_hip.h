@@ -211,20 +211,29 @@ typedef struct ns_ba_plan {
   int kf0, kf1;
   int n_pairs;  /* Schur pairs (row n, row m, depth slot), n,m in window, same depth slot     */
   int n_rows;   /* P + M rows of E                                                            */
+  int n_jobs;   /* Gram jobs of the Schur kernel (index part [10])                            */
+  int max_src;  /* most edges leaving one source frame                                        */
 } ns_ba_plan;
+
+#define NS_BA_PLAN_PARTS 11   /* parts of the index block = entries of offsets_host           */
+#define NS_GRAM_BLOCK 8       /* tiles of 16 values per block of a slot's Gram matrix         */
 
 /* Sizes of the int32 index block the plan needs (in int32 elements).                          */
 size_t ns_ba_plan_index_count(const int64_t* ii_host, const int64_t* jj_host, int M, int kf0, int kf1);
 
 /* Fills `plan` and `index_host` (int32[ns_ba_plan_index_count]).  Layout of the index block
- * (all int32, offsets returned in `offsets_host[8]`):
+ * (all int32, offsets returned in `offsets_host[NS_BA_PLAN_PARTS]`):
  *   [0] kx[K]            sorted unique source-frame ids           (droid_kernels.cu:1706-1710)
  *   [1] kk[P+M]          depth slot of every E row
  *   [2] row_pose[P+M]    jj_expanded - kf0  (window pose of the row, may be <0 or >=P)
  *   [3] src_ptr[K+1]     CSR over edges grouped by depth slot      (accum_cuda :1065-1103)
  *   [4] src_edge[M]      edge ids in CSR order (stable: ascending edge id inside a slot)
  *   [5] pairs[3*n_pairs] (row n, row m, slot) in the reference's enumeration order (:1384-1399)
- *   [6] slot_rows_ptr[K+1], [7] slot_rows[...]  E rows (self loop + edges) per slot, any pose  */
+ *   [6] slot_rows_ptr[K+1], [7] slot_rows[...]  E rows (self loop + edges) per slot, any pose
+ *   [8] win_rows_ptr[K+1],  [9] win_rows[...]   the rows of [7] whose pose lies in the window (what the Schur complement sums
+ *                                                over, droid_kernels.cu:1375), same order
+ *   [10] gram_jobs[4*n_jobs] (slot, first A tile, A tiles, first B tile): the slot's window rows x 6 values, in tiles of 16,
+ *        blocks of NS_GRAM_BLOCK tiles; first A tile == first B tile marks a diagonal block (upper triangle)        */
 int ns_ba_plan_build(const int64_t* ii_host, const int64_t* jj_host, int M, int kf0, int kf1,
                      ns_ba_plan* plan, int32_t* index_host, size_t* offsets_host);
 

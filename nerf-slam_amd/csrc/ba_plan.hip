@@ -12,7 +12,7 @@
 namespace {
 
 struct PlanData {
-  std::vector<int32_t> kx, kk, row_pose, src_ptr, src_edge, pairs, slot_rows_ptr, slot_rows;
+  std::vector<int32_t> kx, kk, row_pose, src_ptr, src_edge, pairs, slot_rows_ptr, slot_rows, win_rows_ptr, win_rows, gram_jobs;
   int K = 0;
 };
 
@@ -75,12 +75,40 @@ int build(const int64_t* ii, const int64_t* jj, int M, int kf0, int kf1, PlanDat
       }
     }
   }
+  // Schur complement as one Gram matrix per depth slot (ba_schur_gram_kernel): the slot's WINDOW rows (pose inside [0, P): the
+  // only ones schur_block admits, :1375) in slot_rows order, six values each, cut into tiles of 16 values; blocks of
+  // NS_GRAM_BLOCK tiles.  A job is (slot, first A tile, number of A tiles, first B tile): the diagonal job of a block computes the
+  // upper triangle of its <= 8 x 8 tile pairs; a pair of blocks bi < bj is two jobs of <= 4 x 8 tile pairs (the accumulators
+  // of a job have to fit one wave's registers).  A slot of <= 21 rows -- every slot of a tracking window -- is ONE job.
+  d.win_rows_ptr.assign(d.K + 1, 0);
+  d.win_rows.clear();
+  d.gram_jobs.clear();
+  for (int k = 0; k < d.K; k++) {
+    for (int a = d.slot_rows_ptr[k]; a < d.slot_rows_ptr[k + 1]; a++) {
+      const int n = d.slot_rows[a];
+      if (d.row_pose[n] >= 0 && d.row_pose[n] < P) d.win_rows.push_back(n);
+    }
+    d.win_rows_ptr[k + 1] = (int32_t)d.win_rows.size();
+    const int nr = d.win_rows_ptr[k + 1] - d.win_rows_ptr[k];
+    const int nt = (6 * nr + 15) / 16;
+    const int nblk = (nt + NS_GRAM_BLOCK - 1) / NS_GRAM_BLOCK;
+    for (int bi = 0; bi < nblk; bi++) {
+      const int a0 = bi * NS_GRAM_BLOCK, na = std::min(NS_GRAM_BLOCK, nt - a0);
+      const int32_t diag[4] = {k, a0, na, a0};
+      d.gram_jobs.insert(d.gram_jobs.end(), diag, diag + 4);
+      for (int bj = bi + 1; bj < nblk; bj++)
+        for (int h = 0; h < na; h += NS_GRAM_BLOCK / 2) {
+          const int32_t off[4] = {k, a0 + h, std::min(NS_GRAM_BLOCK / 2, na - h), bj * NS_GRAM_BLOCK};
+          d.gram_jobs.insert(d.gram_jobs.end(), off, off + 4);
+        }
+    }
+  }
   return NS_OK;
 }
 
 size_t total_count(const PlanData& d) {
   return d.kx.size() + d.kk.size() + d.row_pose.size() + d.src_ptr.size() + d.src_edge.size() + d.pairs.size() +
-         d.slot_rows_ptr.size() + d.slot_rows.size();
+         d.slot_rows_ptr.size() + d.slot_rows.size() + d.win_rows_ptr.size() + d.win_rows.size() + d.gram_jobs.size();
 }
 
 }  // namespace
@@ -106,10 +134,14 @@ extern "C" int ns_ba_plan_build(const int64_t* ii_host, const int64_t* jj_host, 
   plan->kf1 = kf1;
   plan->n_pairs = (int)(d.pairs.size() / 3);
   plan->n_rows = plan->P + M;
-  const std::vector<int32_t>* parts[8] = {&d.kx,       &d.kk,    &d.row_pose,      &d.src_ptr,
-                                          &d.src_edge, &d.pairs, &d.slot_rows_ptr, &d.slot_rows};
+  plan->n_jobs = (int)(d.gram_jobs.size() / 4);
+  plan->max_src = 0;
+  for (int k = 0; k < d.K; k++) plan->max_src = std::max(plan->max_src, (int)(d.src_ptr[k + 1] - d.src_ptr[k]));
+  const std::vector<int32_t>* parts[NS_BA_PLAN_PARTS] = {&d.kx,           &d.kk,        &d.row_pose,      &d.src_ptr,
+                                                         &d.src_edge,     &d.pairs,     &d.slot_rows_ptr, &d.slot_rows,
+                                                         &d.win_rows_ptr, &d.win_rows,  &d.gram_jobs};
   size_t off = 0;
-  for (int i = 0; i < 8; i++) {
+  for (int i = 0; i < NS_BA_PLAN_PARTS; i++) {
     offsets_host[i] = off;
     std::copy(parts[i]->begin(), parts[i]->end(), index_host + off);
     off += parts[i]->size();

@@ -15,7 +15,10 @@ from ._lib import NerfSlamHipError, check, lib, ptr, stream_ptr
 
 class _CPlan(C.Structure):
     _fields_ = [("M", C.c_int), ("P", C.c_int), ("K", C.c_int), ("kf0", C.c_int), ("kf1", C.c_int),
-                ("n_pairs", C.c_int), ("n_rows", C.c_int)]
+                ("n_pairs", C.c_int), ("n_rows", C.c_int), ("n_jobs", C.c_int), ("max_src", C.c_int)]
+
+
+PLAN_PARTS = 11   # include/nerfslam_hip.h: NS_BA_PLAN_PARTS
 
 
 class BaPlan:
@@ -33,7 +36,7 @@ class BaPlan:
         count = L.ns_ba_plan_index_count(pi, pj, M, int(kf0), int(kf1))
         self.c = _CPlan()
         idx = np.zeros((max(int(count), 1),), np.int32)
-        self.offsets = (C.c_size_t * 8)()
+        self.offsets = (C.c_size_t * PLAN_PARTS)()
         check(L.ns_ba_plan_build(pi, pj, M, int(kf0), int(kf1), C.byref(self.c), idx.ctypes.data_as(C.c_void_p),
                                  self.offsets), "ns_ba_plan_build")
         self.index_host = idx
