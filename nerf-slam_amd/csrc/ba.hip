@@ -9,21 +9,32 @@
 //   K7  pose_retr_kernel                     :1015-1048
 // and the GTSAM solve/retract of RaftVisualFrontend.ba() (visual_frontend.py:1123-1158).
 //
-// Structure of one linearisation (4 launches + 1 memset, 0 host syncs):
-//   linearize   grid (edge, pixel chunk).  Prologue: per-edge constants G_ij and the two 6x6 maps A_i, A_j
-//               with J_i = J_raw A_i, J_j = J_raw A_j (the reference applies them per pixel, :376-403;
-//               they are linear) into LDS.  Per pixel residual/weights/J_raw, writes Ejz/Eiz/C/b,
-//               accumulates only G = sum w J_raw^T J_raw (21) and g = sum w r J_raw (6) per lane
-//               instead of the reference's 78+12 (Hii = A_i^T G A_i, Hij = A_i^T G A_j, ...),
-//               block-reduces them with wave shuffles and adds the transformed 6x6 blocks into a
-//               dense fp64 system with fp64 atomics (the reference: 90 serial block reductions,
-//               then a D2H copy and Eigen triplets)
-//   accum       per (depth slot, pixel): CSR sum of C/b/Eiz over the slot's edges -> Q, w, Ei
-//   schur       one workgroup per row pair of a slot (upper half only), subtracts E Q E^T / E Q w
-//               from the same fp64 system
+// Structure of one linearisation (3 launches, 0 host syncs; round 6 -- SURVEY 7 steps 4-5):
+//   linearize_slot  grid (depth slot, pixel chunk): ALL edges of one source frame in one workgroup, each lane owning a
+//               few pixels.  Per edge the constants G_ij and the two 6x6 maps A_i, A_j with J_i = J_raw A_i,
+//               J_j = J_raw A_j (the reference applies them per pixel, :376-403; they are linear) are staged in LDS, 16
+//               edges at a time.  Per (edge, pixel): residual / weights / J_raw, the Ejz row is written, and
+//               C, b, Eiz are summed over the slot's edges IN REGISTERS (the reference's three accum_cuda round trips,
+//               :1065-1115, :1750-1757; rounds 1-5 here: a separate kernel re-reading 1.8 GB of per-edge C / b / Eiz at
+//               config #5) -> Q = 1 / (C + prior or damping), w, and the slot's own E row.  Only G = sum w J_raw^T J_raw (21)
+//               and g = sum w r J_raw (6) are accumulated per edge instead of the reference's 78+12 (Hii = A_i^T G A_i,
+//               Hij = A_i^T G A_j, ...), reduced per wave with DPP adds and written as (edge, chunk, wave) partials
+//   schur_gram  the Schur complement of one depth slot is ONE Gram matrix: its window rows X (6 values each, [6 rows, HW])
+//               give S = X diag(Q) X^T and s = X (Q o w).  A workgroup takes (slot, block of <= 8 x 8 tiles of 16 values, pixel
+//               split), streams the rows ONCE (float4 per lane, two steps ahead in registers) and forms the tile products
+//               on the matrix cores with v_mfma_f32_16x16x4_f32 -- exact f32, a k-ordered fmaf chain -- 36 accumulator
+//               tiles per wave; partials of the pixel splits are summed in fixed order by the last workgroup of a job to
+//               arrive, which subtracts the block from the dense fp64 system (fp64 atomics).  Rounds 1-5: one
+//               workgroup per ROW PAIR (the reference's EEt6x6 structure, :1118-1173), 37 k pairs re-reading 13 planes each
+//               = 18x the operand set, 2.28 ms at config #5.
+//               Further blocks of the same launch: per edge, sum the linearize partials (fixed order), transform with
+//               A_i, A_j and add the four 6x6 blocks / two 6-vectors (the reference: 90 serial block reductions, then
+//               a D2H copy and Eigen triplets)
 //   finalize    fp64 -> fp32 H, v  (transposed like SparseBlock::get_dense, :1305-1316)
 #include "common.h"
 #include "se3.h"
+
+#include <type_traits>
 
 #define ET_STRIDE 80  // floats per edge in the edge table
 #define ET_T 0
@@ -45,64 +56,69 @@ __device__ __forceinline__ void reorder_wt(float* J) {  // [t,w] -> [w,t]   (:38
   J[5] = c;
 }
 
-// Per-edge constants, computed by the first lanes of every workgroup of that edge into LDS:
+// Per-edge constants in LDS:
 //   Ts[0..2] t_ij, Ts[3..6] q_ij, Ts[7] stereo flag, Ts[8..43] A_i, Ts[44..79] A_j   (row-major 6x6)
+// edge_rel: one lane per edge; edge_maps: six lanes per edge (k = column of the identity pushed through the adjoints).
+__device__ __forceinline__ void edge_rel(const float* __restrict__ poses, int ix, int jx, float* Ts) {
+  float tij[3], qij[4];
+  float stereo = 0.0f;
+  if (ix == jx) {  // stereo pair (:249-259)
+    tij[0] = -0.1f;
+    tij[1] = 0.0f;
+    tij[2] = 0.0f;
+    qij[0] = qij[1] = qij[2] = 0.0f;
+    qij[3] = 1.0f;
+    stereo = 1.0f;
+  } else {
+    se3::rel_se3(poses + (long)ix * 7, poses + (long)ix * 7 + 3, poses + (long)jx * 7, poses + (long)jx * 7 + 3, tij,
+                 qij);
+  }
+  Ts[ET_T + 0] = tij[0];
+  Ts[ET_T + 1] = tij[1];
+  Ts[ET_T + 2] = tij[2];
+  Ts[ET_Q + 0] = qij[0];
+  Ts[ET_Q + 1] = qij[1];
+  Ts[ET_Q + 2] = qij[2];
+  Ts[ET_Q + 3] = qij[3];
+  Ts[ET_STEREO] = stereo;
+}
+
+__device__ __forceinline__ void edge_maps(const float* __restrict__ extr, int k, float* Ts) {
+  const float tij[3] = {Ts[ET_T], Ts[ET_T + 1], Ts[ET_T + 2]};
+  const float qij[4] = {Ts[ET_Q], Ts[ET_Q + 1], Ts[ET_Q + 2], Ts[ET_Q + 3]};
+  const float ext_t[3] = {extr[0], extr[1], extr[2]};
+  const float ext_q[4] = {extr[3], extr[4], extr[5], extr[6]};
+  float X[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int n = 0; n < 6; n++) X[n] = (n == k) ? 1.0f : 0.0f;
+  float Ji[6], Jj[6], tmp[6];
+  // Ji = -adj(G_ij, Jj)                        (:376-377)
+  se3::adj_se3(tij, qij, X, Ji, false);
+#pragma unroll
+  for (int n = 0; n < 6; n++) Ji[n] = -Ji[n];
+  // camera-to-body adjoint, applied in place by the reference (:380-381)
+  se3::adj_se3(ext_t, ext_q, X, tmp, true);
+#pragma unroll
+  for (int n = 0; n < 6; n++) Jj[n] = -tmp[n];  // (:384)
+  se3::adj_se3(ext_t, ext_q, Ji, tmp, true);
+#pragma unroll
+  for (int n = 0; n < 6; n++) Ji[n] = -tmp[n];  // (:385)
+  reorder_wt(Jj);
+  reorder_wt(Ji);
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    Ts[ET_AI + k * 6 + c] = Ji[c];
+    Ts[ET_AJ + k * 6 + c] = Jj[c];
+  }
+}
+
+// one edge per workgroup: the first lanes compute its constants
 __device__ __forceinline__ void edge_constants(const float* __restrict__ poses, const float* __restrict__ extr,
                                                int ix, int jx, float* Ts) {
   const int tid = threadIdx.x;
-  if (tid == 0) {
-    float tij[3], qij[4];
-    float stereo = 0.0f;
-    if (ix == jx) {  // stereo pair (:249-259)
-      tij[0] = -0.1f;
-      tij[1] = 0.0f;
-      tij[2] = 0.0f;
-      qij[0] = qij[1] = qij[2] = 0.0f;
-      qij[3] = 1.0f;
-      stereo = 1.0f;
-    } else {
-      se3::rel_se3(poses + (long)ix * 7, poses + (long)ix * 7 + 3, poses + (long)jx * 7, poses + (long)jx * 7 + 3,
-                   tij, qij);
-    }
-    Ts[ET_T + 0] = tij[0];
-    Ts[ET_T + 1] = tij[1];
-    Ts[ET_T + 2] = tij[2];
-    Ts[ET_Q + 0] = qij[0];
-    Ts[ET_Q + 1] = qij[1];
-    Ts[ET_Q + 2] = qij[2];
-    Ts[ET_Q + 3] = qij[3];
-    Ts[ET_STEREO] = stereo;
-  }
+  if (tid == 0) edge_rel(poses, ix, jx, Ts);
   __syncthreads();
-  if (tid < 6) {
-    const int k = tid;
-    const float tij[3] = {Ts[ET_T], Ts[ET_T + 1], Ts[ET_T + 2]};
-    const float qij[4] = {Ts[ET_Q], Ts[ET_Q + 1], Ts[ET_Q + 2], Ts[ET_Q + 3]};
-    const float ext_t[3] = {extr[0], extr[1], extr[2]};
-    const float ext_q[4] = {extr[3], extr[4], extr[5], extr[6]};
-    float X[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int n = 0; n < 6; n++) X[n] = (n == k) ? 1.0f : 0.0f;
-    float Ji[6], Jj[6], tmp[6];
-    // Ji = -adj(G_ij, Jj)                        (:376-377)
-    se3::adj_se3(tij, qij, X, Ji, false);
-#pragma unroll
-    for (int n = 0; n < 6; n++) Ji[n] = -Ji[n];
-    // camera-to-body adjoint, applied in place by the reference (:380-381)
-    se3::adj_se3(ext_t, ext_q, X, tmp, true);
-#pragma unroll
-    for (int n = 0; n < 6; n++) Jj[n] = -tmp[n];  // (:384)
-    se3::adj_se3(ext_t, ext_q, Ji, tmp, true);
-#pragma unroll
-    for (int n = 0; n < 6; n++) Ji[n] = -tmp[n];  // (:385)
-    reorder_wt(Jj);
-    reorder_wt(Ji);
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-      Ts[ET_AI + k * 6 + c] = Ji[c];
-      Ts[ET_AJ + k * 6 + c] = Jj[c];
-    }
-  }
+  if (tid < 6) edge_maps(extr, tid, Ts);
   __syncthreads();
 }
 
@@ -291,6 +307,519 @@ __global__ __launch_bounds__(256, 4) void ba_linearize_kernel(LinArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// linearize + accumulate in one launch (K1 + K6 x3 + the depth block, droid_kernels.cu:192-536, 971-991, 1750-1757):
+// grid (depth slot, pixel chunk); a lane owns PPL pixels of the chunk for ALL edges of the slot's source frame.
+// ---------------------------------------------------------------------------------------------
+#define LS_EB 16  // edges whose constants are staged in LDS at once
+
+struct LinSlotArgs {
+  const float* target;      // [M,2,HW]
+  const float* weight;      // [M,2,HW]
+  const float* disps;       // [*,HW]
+  const float* disps_sens;  // [*,HW]
+  const float* eta;         // [K,HW]
+  const float* intr;        // [4]
+  const float* poses;       // [*,7]
+  const float* extr;        // [7]
+  const int64_t* jj;
+  const int32_t* kx;        // [K] source frame of the slot
+  const int32_t* src_ptr;   // [K+1] CSR over the slot's edges
+  const int32_t* src_edge;  // [M]
+  float* E;                 // [P+M,6,HW]: rows [0,P) the slots' own rows, rows P+e the edges' Ejz
+  float* Q;                 // [K,HW]
+  float* w;                 // [K,HW]
+  float* partial;           // [M, nch*4, 32]: per (edge, chunk, wave) sums G(21), g(6)
+  int M, HW, wd, nch, kf0, P;
+};
+
+template <int PPL>
+__global__ __launch_bounds__(256, PPL == 1 ? 3 : 2) void ba_linearize_slot_kernel(LinSlotArgs a) {
+  const int k = blockIdx.x;
+  const int ch = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int HW = a.HW;
+  const int fid = a.kx[k];
+  const int t = fid - a.kf0;
+  const bool in_window = (t >= 0 && t < a.P);
+  __shared__ __attribute__((aligned(16))) float T[LS_EB][ET_STRIDE];
+  __shared__ int Te[LS_EB][2];  // edge id, target frame
+
+  const float fx = a.intr[0], fy = a.intr[1], cx = a.intr[2], cy = a.intr[3];
+  const float* __restrict__ disp = a.disps + (long)fid * HW;
+
+  unsigned px[PPL];   // (unsigned: a uniform plane pointer + a zero-extended 32-bit lane offset is ONE address register per
+  bool ok[PPL];       //  access; as `(long)c * HW + p` every plane's 64-bit offset was hoisted out of the edge loop: ~70 registers per pixel)
+  float X0[PPL], X1[PPL], dsp[PPL];
+  float C[PPL], b[PPL], Ei[PPL][6];
+#pragma unroll
+  for (int i = 0; i < PPL; i++) {
+    const int p = ch * (256 * PPL) + i * 256 + tid;
+    ok[i] = p < HW;
+    px[i] = (unsigned)(ok[i] ? p : HW - 1);
+    const int row = (int)px[i] / a.wd, col = (int)px[i] - row * a.wd;
+    X0[i] = ((float)col - cx) / fx;
+    X1[i] = ((float)row - cy) / fy;
+    dsp[i] = disp[px[i]];
+    C[i] = 0.0f;
+    b[i] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 6; c++) Ei[i][c] = 0.0f;
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  const int s0 = a.src_ptr[k], s1 = a.src_ptr[k + 1];
+  for (int sb = s0; sb < s1; sb += LS_EB) {
+    const int nb = min(LS_EB, s1 - sb);
+    __syncthreads();  // the previous batch's constants are no longer read
+    if (tid < nb) {
+      const int e = a.src_edge[sb + tid];
+      const int jx = (int)a.jj[e];
+      Te[tid][0] = e;
+      Te[tid][1] = jx;
+      edge_rel(a.poses, fid, jx, T[tid]);
+    }
+    __syncthreads();
+    if (tid < nb * 6) edge_maps(a.extr, tid % 6, T[tid / 6]);
+    __syncthreads();
+    // the four input planes of edge q+1 are requested before edge q is computed (PPL x 4 more requests per lane in flight:
+    // with two waves per SIMD the loads of ONE edge do not cover the ~300 instructions per pixel that follow them)
+    float ntu[PPL], ntv[PPL], nwu[PPL], nwv[PPL];
+    auto request = [&](int q) __attribute__((always_inline)) {
+      const long e = Te[q][0];
+      const float* __restrict__ tu = a.target + (e * 2 + 0) * HW;
+      const float* __restrict__ tv = a.target + (e * 2 + 1) * HW;
+      const float* __restrict__ wu_ = a.weight + (e * 2 + 0) * HW;
+      const float* __restrict__ wv_ = a.weight + (e * 2 + 1) * HW;
+#pragma unroll
+      for (int i = 0; i < PPL; i++) {
+        ntu[i] = tu[px[i]];
+        ntv[i] = tv[px[i]];
+        nwu[i] = wu_[px[i]];
+        nwv[i] = wv_[px[i]];
+      }
+    };
+    request(0);
+    for (int q = 0; q < nb; q++) {
+      const float* __restrict__ Tq = T[q];
+      const int e = Te[q][0];
+      const float tij[3] = {Tq[ET_T], Tq[ET_T + 1], Tq[ET_T + 2]};
+      const float qij[4] = {Tq[ET_Q], Tq[ET_Q + 1], Tq[ET_Q + 2], Tq[ET_Q + 3]};
+      const bool stereo = Tq[ET_STEREO] != 0.0f;
+      float* __restrict__ oEj = a.E + ((long)a.P + e) * 6 * HW;
+      float ltu[PPL], ltv[PPL], lwu[PPL], lwv[PPL];
+#pragma unroll
+      for (int i = 0; i < PPL; i++) {
+        ltu[i] = ntu[i];
+        ltv[i] = ntv[i];
+        lwu[i] = nwu[i];
+        lwv[i] = nwv[i];
+      }
+      request(min(q + 1, nb - 1));  // (always issued: no branch between a load and its use; the last edge is read twice)
+      float G[21];
+      float g[6];
+#pragma unroll
+      for (int l = 0; l < 21; l++) G[l] = 0.0f;
+#pragma unroll
+      for (int l = 0; l < 6; l++) g[l] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < PPL; i++) {
+        // keep the 72 entries of A_i/A_j in LDS (broadcast reads) instead of letting the compiler hoist
+        // them into 72 VGPRs per lane
+        asm volatile("" ::: "memory");
+        if (ok[i]) {  // ONE divergent region per pixel (only the last chunk has lanes outside the map)
+          float Xi[4], Xj[4];
+          Xi[0] = X0[i];
+          Xi[1] = X1[i];
+          Xi[2] = 1.0f;
+          Xi[3] = dsp[i];
+          se3::act_se3(tij, qij, Xi, Xj);
+          const float x = Xj[0], y = Xj[1], h = Xj[3];
+          const bool zok = !(Xj[2] < NS_MIN_DEPTH);
+          const float d = zok ? 1.0f / Xj[2] : 0.0f;
+          const float d2 = d * d;
+          // `.001 * weight` is a double product in the reference (:344-345)
+          float wu = zok ? (float)(0.001 * (double)lwu[i]) : 0.0f;
+          float wv = zok ? (float)(0.001 * (double)lwv[i]) : 0.0f;
+          const float ru = ltu[i] - (fx * d * x + cx);
+          const float rv = ltv[i] - (fy * d * y + cy);
+          const float Jzu = fx * (tij[0] * d - tij[2] * (x * d2));
+          const float Jzv = fy * (tij[1] * d - tij[2] * (y * d2));
+          const float ce = wu * Jzu * Jzu + wv * Jzv * Jzv;
+          const float be = wu * ru * Jzu + wv * rv * Jzv;
+          C[i] += ce;
+          b[i] += be;
+          if (stereo) {  // pose weights are zeroed for stereo pairs (:367,432)
+            wu = 0.0f;
+            wv = 0.0f;
+          }
+          // raw Jacobians wrt the target pose, [t,w] order (:369-374, 434-439)
+          const float Ju[6] = {fx * (h * d), 0.0f, fx * (-x * h * d2), fx * (-x * y * d2), fx * (1.0f + x * x * d2),
+                               fx * (-y * d)};
+          const float Jv[6] = {0.0f, fy * (h * d), fy * (-y * h * d2), fy * (-1.0f - y * y * d2), fy * (x * y * d2),
+                               fy * (x * d)};
+          float wJu[6], wJv[6], qq[6];
+#pragma unroll
+          for (int m = 0; m < 6; m++) {
+            wJu[m] = wu * Ju[m];
+            wJv[m] = wv * Jv[m];
+            qq[m] = wJu[m] * Jzu + wJv[m] * Jzv;
+            g[m] += wJu[m] * ru + wJv[m] * rv;
+          }
+          int l = 0;
+#pragma unroll
+          for (int m = 0; m < 6; m++)
+#pragma unroll
+            for (int n = m; n < 6; n++) {
+              G[l] += wJu[m] * Ju[n] + wJv[m] * Jv[n];
+              l++;
+            }
+          // E rows: q A_i (summed over the slot's edges), q A_j (written)
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            float ei = 0.0f, ej = 0.0f;
+#pragma unroll
+            for (int m = 0; m < 6; m++) {
+              ei += qq[m] * Tq[ET_AI + m * 6 + c];
+              ej += qq[m] * Tq[ET_AJ + m * 6 + c];
+            }
+            Ei[i][c] += ei;
+            float* __restrict__ plane = oEj + (long)c * HW;  // (uniform)
+            plane[px[i]] = ej;
+          }
+        }
+      }
+      // per-wave sums of G, g (fixed DPP order) gathered into lanes 0..26 and stored once; the assembly blocks of the Schur
+      // launch add the (chunk, wave) partials in order
+      float mine = 0.0f;
+#pragma unroll
+      for (int l = 0; l < 21; l++) {
+        const float sum = wave_sum(G[l]);
+        mine = (lane == l) ? sum : mine;
+      }
+#pragma unroll
+      for (int l = 0; l < 6; l++) {
+        const float sum = wave_sum(g[l]);
+        mine = (lane == 21 + l) ? sum : mine;
+      }
+      if (lane < 27) a.partial[(((long)e * a.nch + ch) * 4 + wave) * 32 + lane] = mine;
+    }
+  }
+  // depth block of the slot (:1750-1754) and its own E row (:1757)
+  const float alpha = 0.05f;
+#pragma unroll
+  for (int i = 0; i < PPL; i++) {
+    if (!ok[i]) continue;
+    const unsigned p = px[i];
+    const float ds = (a.disps_sens + (long)fid * HW)[p];
+    const float m = ds > 0.0f ? 1.0f : 0.0f;
+    const float Cf = C[i] + m * alpha + (1.0f - m) * (a.eta + (long)k * HW)[p];
+    const float wf = b[i] - m * alpha * (dsp[i] - ds);
+    (a.Q + (long)k * HW)[p] = 1.0f / Cf;
+    (a.w + (long)k * HW)[p] = wf;
+    if (in_window) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) (a.E + ((long)t * 6 + c) * HW)[p] = Ei[i][c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Schur complement (K9 + K10, droid_kernels.cu:1118-1210, 1349-1438) as one Gram matrix per depth slot, on the matrix
+// cores in exact f32, + the pose-block assembly of the linearisation, one launch:
+//   blocks [0, n_jobs*S)      : job (slot, A tiles, B tiles) x pixel split s
+//   blocks [n_jobs*S, +M)     : edge e: sum its linearize partials (fixed order), transform with A_i, A_j, add to the system
+// ---------------------------------------------------------------------------------------------
+typedef float gr_f4 __attribute__((ext_vector_type(4)));
+typedef float gr_f4u __attribute__((ext_vector_type(4), aligned(4)));  // a row of E is only 4-byte aligned when HW % 4 != 0
+
+#define GR_NACC 36                      // accumulator tiles of a job: 8x8 upper triangle, or 4 x 8
+#define GR_PART (GR_NACC * 256 + 128)   // floats of one (job, split) partial: the tiles + 8 x 16 entries of X (Q o w)
+#define GR_ROUND 12                     // tiles per LDS round of the cross-wave sum
+
+struct GramArgs {
+  const float* E;
+  const float* Q;
+  const float* w;
+  const float* zrow;  // HW zeros: what the padding rows of a slot's last tile read
+  const int32_t* kk;  // unused by the kernel (kept for debugging dumps)
+  const int32_t* win_rows_ptr;
+  const int32_t* win_rows;
+  const int32_t* row_pose;
+  const int32_t* jobs;
+  float* part;   // [n_jobs * S][GR_PART]
+  int* counter;  // [n_jobs], zero between launches
+  double* Hd;
+  double* vd;
+  // edge assembly
+  const float* partial;
+  const float* poses;
+  const float* extr;
+  const int64_t* ii;
+  const int64_t* jj;
+  int HW, P, kf0, n_jobs, S, npart, M;
+};
+
+// index of tile pair (ta <= tb) in the upper triangle of an 8 x 8 block
+__device__ __forceinline__ constexpr int gr_pair(int ta, int tb) { return ta * 8 - ta * (ta - 1) / 2 + (tb - ta); }
+
+template <bool DIAG>
+__device__ __forceinline__ void gram_job(const GramArgs& a, const int job, const int split, float* lds, float* lds_v,
+                                         int* hA, int* hB, int* flag) {
+  constexpr int NA = DIAG ? 8 : 4;  // A tiles a job may have
+  constexpr int NB = DIAG ? 0 : 8;  // separately loaded B tiles (a diagonal job's B operand is Q o its A tiles)
+  constexpr int NBX = DIAG ? 1 : 8;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int HW = a.HW;
+  const int slot = a.jobs[4 * job + 0];
+  const int a0 = a.jobs[4 * job + 1];
+  const int na = __builtin_amdgcn_readfirstlane(a.jobs[4 * job + 2]);
+  const int b0 = a.jobs[4 * job + 3];
+  const int rbase = a.win_rows_ptr[slot];
+  const int R = 6 * (a.win_rows_ptr[slot + 1] - rbase);  // values of the slot
+  const int nt = (R + 15) >> 4;
+  const int nb = __builtin_amdgcn_readfirstlane(DIAG ? na : min(8, nt - b0));
+
+  // this lane's row of every tile: value index v = tile*16 + r16 -> (row, component) -> plane of E
+  const float* pa[NA];
+  const float* pb[NBX];
+#pragma unroll
+  for (int t = 0; t < NA; t++) {
+    const int v = (a0 + t) * 16 + r16;
+    pa[t] = (t < na && v < R) ? a.E + ((long)a.win_rows[rbase + v / 6] * 6 + v % 6) * HW : a.zrow;
+  }
+#pragma unroll
+  for (int t = 0; t < NBX; t++) {
+    const int v = (b0 + t) * 16 + r16;
+    pb[t] = (!DIAG && t < nb && v < R) ? a.E + ((long)a.win_rows[rbase + v / 6] * 6 + v % 6) * HW : a.zrow;
+  }
+  const float* __restrict__ Qk = a.Q + (long)slot * HW;
+  const float* __restrict__ wk = a.w + (long)slot * HW;
+
+  // pixel range of the split, in rounds of 64 pixels (16 per wave)
+  const int NR = (HW + 63) >> 6;
+  const int r0 = (int)((long)NR * split / a.S), r1 = (int)((long)NR * (split + 1) / a.S);
+  const int n = r1 - r0;
+
+  gr_f4 acc[GR_NACC];
+#pragma unroll
+  for (int i = 0; i < GR_NACC; i++) acc[i] = gr_f4{0.0f, 0.0f, 0.0f, 0.0f};
+  float vs[8];
+#pragma unroll
+  for (int t = 0; t < 8; t++) vs[t] = 0.0f;
+
+  // three register stages: the loads of rounds i+1 and i+2 are in flight while round i is on the matrix core (one wave per
+  // SIMD, 512 registers: latency is covered inside the wave).  A stage's loads are ALWAYS issued -- past the range they repeat the
+  // last round -- so that no branch sits between a load and its use and the compiler keeps counting vmcnt.
+  gr_f4 sx[3][NA], sb[3][NBX], sq[3], sw[3];
+  auto load = [&](auto stage_c, int i) __attribute__((always_inline)) {
+    constexpr int st = decltype(stage_c)::value;
+    const int rr = r0 + min(i, n - 1);
+    const int p = rr * 64 + wave * 16 + kg * 4;
+    const int pl = min(p, HW - 4);
+    gr_f4 q = *reinterpret_cast<const gr_f4u*>(Qk + pl);
+    // element j of the lane's float4 is pixel pl + j: it is this lane's iff pl + j >= p (pl < p only at the end of a row
+    // whose length is no multiple of 4, or past it; then the earlier pixels belong to the neighbour lane / nobody).  A round
+    // past the split's range (the loop runs in threes) contributes nothing either: Q = 0 there.
+    const int first = i < n ? p : 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 4; j++) q[j] = (pl + j >= first) ? q[j] : 0.0f;
+    sq[st] = q;
+    sw[st] = *reinterpret_cast<const gr_f4u*>(wk + pl);
+#pragma unroll
+    for (int t = 0; t < NA; t++) sx[st][t] = *reinterpret_cast<const gr_f4u*>(pa[t] + pl);
+#pragma unroll
+    for (int t = 0; t < NB; t++) sb[st][t] = *reinterpret_cast<const gr_f4u*>(pb[t] + pl);
+  };
+  auto compute = [&](auto stage_c) __attribute__((always_inline)) {
+    constexpr int st = decltype(stage_c)::value;
+    const gr_f4 q = sq[st];
+    gr_f4 y[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) y[t] = (DIAG ? sx[st][t < NA ? t : 0] : sb[st][t < NBX ? t : 0]) * q;
+    // ONE uniform branch per B tile, the MFMAs of a column back to back behind it (a guard per MFMA -- `break`s in the unrolled
+    // loops -- put an s_cbranch between every two matrix instructions and the conditions into spilled SGPRs: 1.40 ms at config #5).
+    // An off-diagonal job's absent A tiles read the zero row: up to 3 wasted MFMAs per column instead of a branch each.
+#pragma unroll
+    for (int tb = 0; tb < 8; tb++) {
+      if (tb < nb) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if constexpr (DIAG) {
+#pragma unroll
+            for (int ta = 0; ta <= tb; ta++)
+              acc[gr_pair(ta, tb)] = __builtin_amdgcn_mfma_f32_16x16x4f32(sx[st][ta][j], y[tb][j], acc[gr_pair(ta, tb)], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int ta = 0; ta < 4; ta++)
+              acc[ta * 8 + tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(sx[st][ta][j], y[tb][j], acc[ta * 8 + tb], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if constexpr (DIAG) {  // s = X (Q o w) of the block's own rows
+      const gr_f4 wv = sw[st];
+#pragma unroll
+      for (int t = 0; t < 8; t++)
+        vs[t] += (y[t][0] * wv[0] + y[t][1] * wv[1]) + (y[t][2] * wv[2] + y[t][3] * wv[3]);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  if (n > 0) {
+    // straight-line body, three rounds per trip (rounds past the range run on Q = 0): with a branch around any of the stages
+    // the compiler's load counter gave up and the loop header waited for vmcnt(0) -- no prefetch at all
+    load(S0{}, 0);
+    load(S1{}, 1);
+    for (int i = 0; i < n; i += 3) {
+      load(S2{}, i + 2);
+      compute(S0{});
+      load(S0{}, i + 3);
+      compute(S1{});
+      load(S1{}, i + 4);
+      compute(S2{});
+    }
+  }
+
+  // ---- the four waves' tiles summed through LDS (fixed order), GR_ROUND tiles at a time -> this split's partial ----
+  float* __restrict__ part = a.part + ((long)job * a.S + split) * GR_PART;
+  auto tile_live = [&](int tile) -> bool {  // (uniform) does the job compute accumulator tile `tile`
+    if (DIAG) {
+      int ta = 0, rem = tile;  // invert gr_pair
+      while (rem >= 8 - ta) {
+        rem -= 8 - ta;
+        ta++;
+      }
+      return ta + rem < nb;
+    }
+    return tile < 32 && (tile >> 3) < na && (tile & 7) < nb;
+  };
+#pragma unroll
+  for (int rd = 0; rd < GR_NACC / GR_ROUND; rd++) {
+#pragma unroll
+    for (int i = 0; i < GR_ROUND; i++)
+      if (tile_live(rd * GR_ROUND + i))
+        *reinterpret_cast<gr_f4*>(lds + ((wave * GR_ROUND + i) * 64 + lane) * 4) = acc[rd * GR_ROUND + i];
+    if (DIAG && rd == 0) {
+#pragma unroll
+      for (int t = 0; t < 8; t++) lds_v[(wave * 8 + t) * 64 + lane] = vs[t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < GR_ROUND; i++)
+      if (tile_live(rd * GR_ROUND + i)) {
+        const float* __restrict__ l0 = lds + i * 256 + tid;
+        part[(rd * GR_ROUND + i) * 256 + tid] =
+            ((l0[0] + l0[GR_ROUND * 256]) + l0[2 * GR_ROUND * 256]) + l0[3 * GR_ROUND * 256];
+      }
+    if (DIAG && rd == 0 && tid < 128) {
+      const int t = tid >> 4, r = tid & 15;
+      float sum = 0.0f;
+#pragma unroll
+      for (int wv = 0; wv < 4; wv++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) sum += lds_v[(wv * 8 + t) * 64 + g4 * 16 + r];
+      part[GR_NACC * 256 + tid] = sum;
+    }
+    __syncthreads();
+  }
+
+  // ---- the last split of the job to arrive adds the job's block to the system ----
+  if (a.S > 1) {
+    __threadfence();  // release: this workgroup's partial is visible device-wide before its ticket
+    __syncthreads();
+    if (tid == 0) flag[0] = (atomicAdd(a.counter + job, 1) == a.S - 1) ? 1 : 0;
+    __syncthreads();
+    if (!flag[0]) return;
+    __threadfence();  // acquire: the other splits' partials
+  }
+  if (tid < 128) {
+    const int va = a0 * 16 + tid, vb = b0 * 16 + tid;
+    hA[tid] = (tid < na * 16 && va < R) ? 6 * a.row_pose[a.win_rows[rbase + va / 6]] + va % 6 : -1;
+    hB[tid] = (tid < nb * 16 && vb < R) ? 6 * a.row_pose[a.win_rows[rbase + vb / 6]] + vb % 6 : -1;
+  }
+  __syncthreads();
+  const long n6 = 6L * a.P;
+  const float* __restrict__ pj = a.part + (long)job * a.S * GR_PART;
+  const int el = tid >> 2, rg = tid & 3;              // element `tid` of a tile: accumulator register rg of lane el
+  const int ti = 4 * (el >> 4) + rg, tj = el & 15;    // row (A value) and column (B value) inside the tile
+#pragma unroll 1
+  for (int tile = 0; tile < GR_NACC; tile++) {
+    if (!tile_live(tile)) continue;
+    int ta, tb;
+    if (DIAG) {
+      ta = 0;
+      int rem = tile;
+      while (rem >= 8 - ta) {
+        rem -= 8 - ta;
+        ta++;
+      }
+      tb = ta + rem;
+    } else {
+      ta = tile >> 3;
+      tb = tile & 7;
+    }
+    double sum = 0.0;
+    for (int s = 0; s < a.S; s++) sum += (double)pj[(long)s * GR_PART + tile * 256 + tid];
+    const int ha = hA[ta * 16 + ti], hb = hB[tb * 16 + tj];
+    const bool same_tile = DIAG && ta == tb;
+    // upper triangle of the slot's Gram matrix only; the mirror image is added explicitly: H stays exactly symmetric
+    if (ha >= 0 && hb >= 0 && (!same_tile || ti <= tj)) {
+      atomicAdd(&a.Hd[(long)ha * n6 + hb], -sum);
+      if (!(same_tile && ti == tj)) atomicAdd(&a.Hd[(long)hb * n6 + ha], -sum);
+    }
+  }
+  if (DIAG && tid < 128 && hA[tid] >= 0) {
+    double sum = 0.0;
+    for (int s = 0; s < a.S; s++) sum += (double)pj[(long)s * GR_PART + GR_NACC * 256 + tid];
+    atomicAdd(&a.vd[hA[tid]], -sum);
+  }
+  if (a.S > 1 && tid == 0) a.counter[job] = 0;  // ready for the next launch
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ba_schur_gram_kernel(GramArgs a) {
+  const int tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float lds[4 * GR_ROUND * 256];
+  __shared__ float lds_v[4 * 8 * 64];
+  __shared__ int hA[128], hB[128], flag[1];
+  if ((int)blockIdx.x >= a.n_jobs * a.S) {
+    // ---------------- edge assembly ----------------
+    const long n6 = 6L * a.P;
+    const int e = blockIdx.x - a.n_jobs * a.S;
+    const int ix = (int)a.ii[e], jx = (int)a.jj[e];
+    float* T = lds;
+    double* Gs = reinterpret_cast<double*>(lds + 128);
+    edge_constants(a.poses, a.extr, ix, jx, T);
+    if (tid < 27) {
+      double s = 0.0;
+      for (int c = 0; c < a.npart; c++) s += (double)a.partial[((long)e * a.npart + c) * 32 + tid];
+      Gs[tid] = s;
+    }
+    __syncthreads();
+    if (tid < 156) {
+      const double val = edge_block_entry(T + ET_AI, T + ET_AJ, Gs, tid);
+      if (tid < 144) {
+        const int blk = tid / 36, r = (tid % 36) / 6, c = tid % 6;
+        const int rp = ((blk < 2) ? ix : jx) - a.kf0;
+        const int cp = ((blk % 2 == 0) ? ix : jx) - a.kf0;
+        if (rp >= 0 && rp < a.P && cp >= 0 && cp < a.P) atomicAdd(&a.Hd[(long)(6 * rp + r) * n6 + 6 * cp + c], val);
+      } else {
+        const int side = (tid - 144) / 6, r = (tid - 144) % 6;
+        const int rp = (side == 0 ? ix : jx) - a.kf0;
+        if (rp >= 0 && rp < a.P) atomicAdd(&a.vd[6 * rp + r], val);
+      }
+    }
+    return;
+  }
+  const int job = blockIdx.x / a.S, split = blockIdx.x % a.S;
+  if (a.jobs[4 * job + 1] == a.jobs[4 * job + 3])
+    gram_job<true>(a, job, split, lds, lds_v, hA, hB, flag);
+  else
+    gram_job<false>(a, job, split, lds, lds_v, hA, hB, flag);
+}
+
+#ifdef NS_TEST_VARIANTS   // rounds 1-5: separate accumulate kernel and one workgroup per row pair (NS_BA_UNFUSED=1: the A/B baseline)
+// ---------------------------------------------------------------------------------------------
 // accum (K6 x3 + the depth block, droid_kernels.cu:1750-1757)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_accum_kernel(const float* __restrict__ Cii, const float* __restrict__ bz,
@@ -451,6 +980,8 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(SchurArgs a) {
   }
 }
 
+#endif  // NS_TEST_VARIANTS
+
 // fp64 -> fp32, and re-zero the accumulators for the next linearisation (every element is read by
 // exactly one thread, so the system buffer needs a memset only once, when it is allocated)
 __global__ void ba_finalize_kernel(double* __restrict__ Hd, double* __restrict__ vd, int n6,
@@ -575,36 +1106,64 @@ __global__ void pose_retr_kernel(float* __restrict__ poses, const float* __restr
 // C ABI
 // ---------------------------------------------------------------------------------------------
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-static int max_nch(int HW);
+
+// pixels per lane of the fused lineariser: as many as still leave ~1024 workgroups (the per-edge wave reductions of G, g
+// are paid once per (edge, chunk, wave): 190 DPP adds against ~300 instructions per pixel)
+static int choose_ppl(int K, int HW) {
+  if ((long)K * ns_cdiv(HW, 1024) >= 1024) return 4;
+  if ((long)K * ns_cdiv(HW, 512) >= 1024) return 2;
+  return 1;
+}
+// pixel splits of a Gram job: ~1024 workgroups (one per CU at a time: 512 registers per lane), at least 4 rounds of 64 pixels each
+static int choose_splits(int n_jobs, int HW) {
+  const int NR = ns_cdiv(HW, 64);
+  int S = ns_cdiv(1024, n_jobs > 0 ? n_jobs : 1);
+  const int cap = NR / 6 > 1 ? NR / 6 : 1;   // (the kernel's loop takes three rounds per trip: at least two trips per split)
+  if (S > cap) S = cap;
+  return S < 1 ? 1 : S;
+}
 
 struct WsLayout {
-  size_t Hd, vd, partial, Eiz, Cii, bz, total;
+  size_t Hd, vd, counter, zrow, zero_end, partial, part, Eiz, Cii, bz, total;
 };
 
-static WsLayout ws_layout(int M, int P, int HW) {
+static WsLayout ws_layout(const ns_ba_plan* plan, int HW) {
+  const int M = plan->M, P = plan->P;
   WsLayout L;
   size_t off = 0;
   L.Hd = off;
   off += align256(sizeof(double) * (size_t)36 * P * P + 8);
   L.vd = off;
   off += align256(sizeof(double) * (size_t)6 * P + 8);
+  L.counter = off;
+  off += align256(sizeof(int) * (size_t)(plan->n_jobs + 1));
+  L.zrow = off;
+  off += align256(sizeof(float) * (size_t)(HW + 4));
+  L.zero_end = off;  // [Hd, zero_end) is zero between calls
+  const int nch = ns_cdiv(HW, 256 * choose_ppl(plan->K, HW));
   L.partial = off;
-  off += align256(sizeof(float) * (size_t)32 * (M > 0 ? M : 1) * max_nch(HW));
+  off += align256(sizeof(float) * (size_t)32 * 4 * (M > 0 ? M : 1) * nch);
+  L.part = off;
+  off += align256(sizeof(float) * (size_t)GR_PART * (plan->n_jobs > 0 ? plan->n_jobs : 1) * choose_splits(plan->n_jobs, HW));
+  L.Eiz = L.Cii = L.bz = off;
+#ifdef NS_TEST_VARIANTS
   L.Eiz = off;
   off += align256(sizeof(float) * (size_t)M * 6 * HW + 4);
   L.Cii = off;
   off += align256(sizeof(float) * (size_t)M * HW + 4);
   L.bz = off;
   off += align256(sizeof(float) * (size_t)M * HW + 4);
+#endif
   L.total = off;
   return L;
 }
 
 extern "C" size_t ns_ba_workspace_bytes(const ns_ba_plan* plan, int HW) {
   if (!plan) return 0;
-  return ws_layout(plan->M, plan->P, HW).total;
+  return ws_layout(plan, HW).total;
 }
 
+#ifdef NS_TEST_VARIANTS
 static int max_nch(int HW) { return (HW + 511) / 512; }
 
 static int choose_nch(int M, int HW) {
@@ -622,6 +1181,7 @@ static int choose_sch(int n_pairs, int HW) {
   if (sch < 1) sch = 1;
   return sch;
 }
+#endif
 
 // K1 as its own op (per-edge outputs, exactly the reference kernel's contract).
 extern "C" int ns_projective_transform(const float* targets, const float* weights, const float* poses,
@@ -677,80 +1237,157 @@ extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, 
   NS_REQUIRE(((uintptr_t)workspace & 255) == 0, "ns_reduced_camera_matrix: workspace must be 256-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int M = plan->M, P = plan->P, K = plan->K, HW = ht * wd, n6 = 6 * P;
-  const WsLayout L = ws_layout(M, P, HW);
+  NS_REQUIRE(HW >= 4, "ns_reduced_camera_matrix: maps of fewer than 4 pixels");
+  const WsLayout L = ws_layout(plan, HW);
   char* ws = (char*)workspace;
   double* Hd = (double*)(ws + L.Hd);
   double* vd = (double*)(ws + L.vd);
-  float* Eiz = (float*)(ws + L.Eiz);
-  float* Cii = (float*)(ws + L.Cii);
-  float* bz = (float*)(ws + L.bz);
   float* partial = (float*)(ws + L.partial);
-  // Hd and vd are adjacent in the layout: one memset, needed only the first time a workspace is used
-  // (ba_finalize_kernel re-zeroes what it reads)
-  if (!ws_zeroed && hipMemsetAsync(Hd, 0, L.partial - L.Hd, st) != hipSuccess) {
+  // Hd, vd, the job counters and the zero row are adjacent in the layout: one memset, needed only the first time a workspace
+  // is used (ba_finalize_kernel re-zeroes what it reads, the last split of a Gram job its counter)
+  if (!ws_zeroed && hipMemsetAsync(Hd, 0, L.zero_end - L.Hd, st) != hipSuccess) {
     ns_set_error("ns_reduced_camera_matrix: hipMemsetAsync failed");
     return NS_ELAUNCH;
-  }
-  int nch = 1;
-  if (M > 0) {
-    LinArgs a;
-    a.target = targets;
-    a.weight = weights;
-    a.disps = disps;
-    a.intr = intrinsics;
-    a.ii = ii;
-    a.jj = jj;
-    a.poses = poses;
-    a.extr = extrinsics;
-    a.Eiz = Eiz;
-    a.Ejz = E + (long)P * 6 * HW;
-    a.Cii = Cii;
-    a.bz = bz;
-    a.partial = partial;
-    a.Hs = nullptr;
-    a.vs = nullptr;
-    a.M = M;
-    a.HW = HW;
-    a.wd = wd;
-    a.nch = nch = choose_nch(M, HW);
-    a.kf0 = plan->kf0;
-    a.P = P;
-    hipLaunchKernelGGL(ba_linearize_kernel<false>, dim3(M, a.nch), dim3(256), 0, st, a);
-    NS_CHECK_LAUNCH("ba_linearize_kernel");
   }
   const int32_t* kx = index + off[0];
   const int32_t* row_pose = index + off[2];
   const int32_t* src_ptr = index + off[3];
   const int32_t* src_edge = index + off[4];
-  const int32_t* pairs = index + off[5];
-  if (K > 0) {
-    hipLaunchKernelGGL(ba_accum_kernel, dim3(K, ns_cdiv(HW, 256)), dim3(256), 0, st, Cii, bz, Eiz, disps, disps_sens,
-                       eta, kx, src_ptr, src_edge, HW, plan->kf0, P, Q, w, E);
-    NS_CHECK_LAUNCH("ba_accum_kernel");
+#ifdef NS_TEST_VARIANTS
+  static const bool unfused = [] { const char* e = ns_variant_env("NS_BA_UNFUSED"); return e != nullptr && e[0] == '1'; }();
+  if (ns_variant_env("NS_BA_UNFUSED") != nullptr ? ns_variant_env("NS_BA_UNFUSED")[0] == '1' : unfused) {
+    // rounds 1-5: linearise per edge -> accumulate per slot -> one workgroup per row pair
+    float* Eiz = (float*)(ws + L.Eiz);
+    float* Cii = (float*)(ws + L.Cii);
+    float* bz = (float*)(ws + L.bz);
+    const int32_t* pairs = index + off[5];
+    int nch = 1;
+    if (M > 0) {
+      LinArgs a;
+      a.target = targets;
+      a.weight = weights;
+      a.disps = disps;
+      a.intr = intrinsics;
+      a.ii = ii;
+      a.jj = jj;
+      a.poses = poses;
+      a.extr = extrinsics;
+      a.Eiz = Eiz;
+      a.Ejz = E + (long)P * 6 * HW;
+      a.Cii = Cii;
+      a.bz = bz;
+      a.partial = partial;
+      a.Hs = nullptr;
+      a.vs = nullptr;
+      a.M = M;
+      a.HW = HW;
+      a.wd = wd;
+      a.nch = nch = choose_nch(M, HW);
+      a.kf0 = plan->kf0;
+      a.P = P;
+      hipLaunchKernelGGL(ba_linearize_kernel<false>, dim3(M, a.nch), dim3(256), 0, st, a);
+      NS_CHECK_LAUNCH("ba_linearize_kernel");
+    }
+    if (K > 0) {
+      hipLaunchKernelGGL(ba_accum_kernel, dim3(K, ns_cdiv(HW, 256)), dim3(256), 0, st, Cii, bz, Eiz, disps, disps_sens,
+                         eta, kx, src_ptr, src_edge, HW, plan->kf0, P, Q, w, E);
+      NS_CHECK_LAUNCH("ba_accum_kernel");
+    }
+    if (plan->n_pairs + M > 0) {
+      SchurArgs sa;
+      sa.E = E;
+      sa.Q = Q;
+      sa.w = w;
+      sa.pairs = pairs;
+      sa.row_pose = row_pose;
+      sa.partial = partial;
+      sa.poses = poses;
+      sa.extr = extrinsics;
+      sa.ii = ii;
+      sa.jj = jj;
+      sa.Hd = Hd;
+      sa.vd = vd;
+      sa.HW = HW;
+      sa.P = P;
+      sa.kf0 = plan->kf0;
+      sa.n_pairs = plan->n_pairs;
+      sa.sch = choose_sch(plan->n_pairs, HW);
+      sa.nch = nch;
+      sa.M = M;
+      hipLaunchKernelGGL(ba_schur_kernel, dim3(plan->n_pairs * sa.sch + M), dim3(256), 0, st, sa);
+      NS_CHECK_LAUNCH("ba_schur_kernel");
+    }
+    if (n6 > 0) {
+      hipLaunchKernelGGL(ba_finalize_kernel, dim3(ns_cdiv((long)n6 * n6, 256)), dim3(256), 0, st, Hd, vd, n6, H, v);
+      NS_CHECK_LAUNCH("ba_finalize_kernel");
+    }
+    return NS_OK;
   }
-  if (plan->n_pairs + M > 0) {
-    SchurArgs sa;
-    sa.E = E;
-    sa.Q = Q;
-    sa.w = w;
-    sa.pairs = pairs;
-    sa.row_pose = row_pose;
-    sa.partial = partial;
-    sa.poses = poses;
-    sa.extr = extrinsics;
-    sa.ii = ii;
-    sa.jj = jj;
-    sa.Hd = Hd;
-    sa.vd = vd;
-    sa.HW = HW;
-    sa.P = P;
-    sa.kf0 = plan->kf0;
-    sa.n_pairs = plan->n_pairs;
-    sa.sch = choose_sch(plan->n_pairs, HW);
-    sa.nch = nch;
-    sa.M = M;
-    hipLaunchKernelGGL(ba_schur_kernel, dim3(plan->n_pairs * sa.sch + M), dim3(256), 0, st, sa);
-    NS_CHECK_LAUNCH("ba_schur_kernel");
+#endif
+  const int ppl = choose_ppl(K, HW);
+  const int nch = ns_cdiv(HW, 256 * ppl);
+  if (K > 0) {
+    LinSlotArgs a;
+    a.target = targets;
+    a.weight = weights;
+    a.disps = disps;
+    a.disps_sens = disps_sens;
+    a.eta = eta;
+    a.intr = intrinsics;
+    a.poses = poses;
+    a.extr = extrinsics;
+    a.jj = jj;
+    a.kx = kx;
+    a.src_ptr = src_ptr;
+    a.src_edge = src_edge;
+    a.E = E;
+    a.Q = Q;
+    a.w = w;
+    a.partial = partial;
+    a.M = M;
+    a.HW = HW;
+    a.wd = wd;
+    a.nch = nch;
+    a.kf0 = plan->kf0;
+    a.P = P;
+    const dim3 grid(K, nch);
+    if (ppl == 4)
+      hipLaunchKernelGGL(ba_linearize_slot_kernel<4>, grid, dim3(256), 0, st, a);
+    else if (ppl == 2)
+      hipLaunchKernelGGL(ba_linearize_slot_kernel<2>, grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(ba_linearize_slot_kernel<1>, grid, dim3(256), 0, st, a);
+    NS_CHECK_LAUNCH("ba_linearize_slot_kernel");
+  }
+  if (plan->n_jobs + M > 0) {
+    GramArgs g;
+    g.E = E;
+    g.Q = Q;
+    g.w = w;
+    g.zrow = (const float*)(ws + L.zrow);
+    g.kk = index + off[1];
+    g.win_rows_ptr = index + off[8];
+    g.win_rows = index + off[9];
+    g.row_pose = row_pose;
+    g.jobs = index + off[10];
+    g.part = (float*)(ws + L.part);
+    g.counter = (int*)(ws + L.counter);
+    g.Hd = Hd;
+    g.vd = vd;
+    g.partial = partial;
+    g.poses = poses;
+    g.extr = extrinsics;
+    g.ii = ii;
+    g.jj = jj;
+    g.HW = HW;
+    g.P = P;
+    g.kf0 = plan->kf0;
+    g.n_jobs = plan->n_jobs;
+    g.S = choose_splits(plan->n_jobs, HW);
+    g.npart = nch * 4;
+    g.M = M;
+    hipLaunchKernelGGL(ba_schur_gram_kernel, dim3(plan->n_jobs * g.S + M), dim3(256), 0, st, g);
+    NS_CHECK_LAUNCH("ba_schur_gram_kernel");
   }
   if (n6 > 0) {
     hipLaunchKernelGGL(ba_finalize_kernel, dim3(ns_cdiv((long)n6 * n6, 256)), dim3(256), 0, st, Hd, vd, n6, H, v);

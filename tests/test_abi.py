@@ -129,18 +129,18 @@ def test_ba_plan_matches_oracle_index_logic(seed):
     droid_kernels.cu:1702-1710 (unique), :1065-1103 (accum pointers) and :1368-1399 (pairs)."""
     import torch  # noqa: F401
     from nerfslam._lib import lib
-    from nerfslam.ba_plan import _CPlan
+    from nerfslam.ba_plan import PLAN_PARTS, _CPlan
     import synth
     rng = np.random.default_rng(seed)
     kf0 = int(rng.integers(0, 4))
-    P = int(rng.integers(2, 7))
-    ii, jj = synth.make_graph(P, int(rng.integers(4, 30)), rng, kf0=kf0, extra_fixed=min(kf0, 2))
+    P = int(rng.integers(2, 7)) if seed < 3 else 40
+    ii, jj = synth.make_graph(P, int(rng.integers(4, 30)) if seed < 3 else 1500, rng, kf0=kf0, extra_fixed=min(kf0, 2))
     kf1 = kf0 + P
     L = lib()
     pi, pj = ii.ctypes.data_as(C.c_void_p), jj.ctypes.data_as(C.c_void_p)
     n = L.ns_ba_plan_index_count(pi, pj, len(ii), kf0, kf1)
     idx = np.zeros(n, np.int32)
-    off = (C.c_size_t * 8)()
+    off = (C.c_size_t * PLAN_PARTS)()
     plan = _CPlan()
     assert L.ns_ba_plan_build(pi, pj, len(ii), kf0, kf1, C.byref(plan), idx.ctypes.data_as(C.c_void_p), off) == 0
     M, NE = len(ii), P + len(ii)
@@ -166,6 +166,28 @@ def test_ba_plan_matches_oracle_index_logic(seed):
     rp, rows = idx[o[6]:o[6] + plan.K + 1], idx[o[7]:o[7] + NE]
     for k in range(plan.K):
         np.testing.assert_array_equal(rows[rp[k]:rp[k + 1]], np.nonzero(kk == k)[0])
+    # round 6: the Schur complement as one Gram matrix per slot -- window rows and the (slot, A tiles, B tiles) jobs.  The jobs'
+    # tile pairs must cover the upper triangle of every slot's ceil(6 rows / 16)^2 tile grid exactly once.
+    wp = idx[o[8]:o[8] + plan.K + 1]
+    wr = idx[o[9]:o[9] + wp[-1]]
+    jobs = idx[o[10]:o[10] + 4 * plan.n_jobs].reshape(-1, 4)
+    assert n == o[10] + 4 * plan.n_jobs and plan.max_src == np.bincount(kk[P:], minlength=plan.K).max()
+    for k in range(plan.K):
+        mine = np.nonzero(kk == k)[0]
+        np.testing.assert_array_equal(wr[wp[k]:wp[k + 1]], mine[(jj_e[mine] >= kf0) & (jj_e[mine] < kf1)])
+        nt = (6 * (wp[k + 1] - wp[k]) + 15) // 16
+        cover = np.zeros((nt, nt), int)
+        for _, a0, na, b0 in jobs[jobs[:, 0] == k]:
+            if a0 == b0:
+                assert 1 <= na <= 8
+                for ta in range(na):
+                    cover[a0 + ta, a0 + ta:a0 + na] += 1
+            else:
+                assert 1 <= na <= 4 and b0 > a0 and b0 % 8 == 0
+                cover[a0:a0 + na, b0:min(b0 + 8, nt)] += 1
+        np.testing.assert_array_equal(cover, np.triu(np.ones((nt, nt), int)))
+    if seed == 3:
+        assert (np.diff(wp) > 21).any() and plan.n_jobs > plan.K          # multi-block slots
 
 
 def test_scatter_plan_refuses_sample_counts_beyond_its_24_bit_record_addressing():

@@ -54,7 +54,11 @@ def test_reduced_camera_matrix_full_scale(oracle_mod, dev):
     assert deg.max() + 1 > 21                       # slots of more than 21 rows: beyond one 8-tile block of the Gram kernel
     assert H.shape == (6 * P, 6 * P) and v.shape == (6 * P, 1) and E.shape == (P + M, 6, HW)
     flips = _close_but_for_depth_threshold_flips(Q, rQ, 2e-5, "Q", 8)
-    flips += _close_but_for_depth_threshold_flips(w, rw, 2e-5, "w", 8)
+    # w carries the residuals r = target - projection: a difference of two numbers of up to ~400 pixels whose f32 ulp is 3e-5,
+    # i.e. ~5e-5 of a half-pixel residual wherever the kernel contracts the projection into fused multiply-adds and the oracle
+    # (built with -ffp-contract=off) does not.  Over 3.7 M sums the largest such difference is 1.5e-5 at max|w| = 0.51: 3e-5
+    # (the smaller windows of tests/test_parity_c1280_gpu.py, with 10x fewer elements, stay inside 2e-5)
+    flips += _close_but_for_depth_threshold_flips(w, rw, 6e-5, "w", 8)
     # E (1.4 GB) element by element, and row by row against the ROW's own magnitude, so that a row written to the wrong slot
     # cannot hide under the global maximum
     En = E.cpu().numpy()
