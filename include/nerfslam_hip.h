@@ -215,7 +215,8 @@ typedef struct ns_ba_plan {
   int max_src;  /* most edges leaving one source frame                                        */
 } ns_ba_plan;
 
-#define NS_BA_PLAN_PARTS 11   /* parts of the index block = entries of offsets_host           */
+#define NS_BA_PLAN_PARTS 13   /* parts of the index block = entries of offsets_host           */
+#define NS_GRAM_JOB_INTS 6    /* int32 per Gram job header                                    */
 #define NS_GRAM_BLOCK 8       /* tiles of 16 values per block of a slot's Gram matrix         */
 
 /* Sizes of the int32 index block the plan needs (in int32 elements).                          */
@@ -232,8 +233,10 @@ size_t ns_ba_plan_index_count(const int64_t* ii_host, const int64_t* jj_host, in
  *   [6] slot_rows_ptr[K+1], [7] slot_rows[...]  E rows (self loop + edges) per slot, any pose
  *   [8] win_rows_ptr[K+1],  [9] win_rows[...]   the rows of [7] whose pose lies in the window (what the Schur complement sums
  *                                                over, droid_kernels.cu:1375), same order
- *   [10] gram_jobs[4*n_jobs] (slot, first A tile, A tiles, first B tile): the slot's window rows x 6 values, in tiles of 16,
- *        blocks of NS_GRAM_BLOCK tiles; first A tile == first B tile marks a diagonal block (upper triangle)        */
+ *   [10] gram_jobs[NS_GRAM_JOB_INTS*n_jobs] (slot, first A tile, A tiles, first B tile, B tiles, 0): the slot's window rows x 6
+ *        values, in tiles of 16, blocks of NS_GRAM_BLOCK tiles; first A tile == first B tile marks a diagonal block (upper triangle)
+ *   [11] job_plane[256*n_jobs], [12] job_hrow[256*n_jobs]: per job the plane of E (row * 6 + component) and the row of H
+ *        (6 * pose + component) of its 128 A and 128 B values, -1 for padding                                        */
 int ns_ba_plan_build(const int64_t* ii_host, const int64_t* jj_host, int M, int kf0, int kf1,
                      ns_ba_plan* plan, int32_t* index_host, size_t* offsets_host);
 

@@ -9,7 +9,9 @@
 //   K7  pose_retr_kernel                     :1015-1048
 // and the GTSAM solve/retract of RaftVisualFrontend.ba() (visual_frontend.py:1123-1158).
 //
-// Structure of one linearisation (3 launches, 0 host syncs; round 6 -- SURVEY 7 steps 4-5):
+// Structure of one linearisation (5 launches, 0 host syncs; round 6 -- SURVEY 7 steps 4-5):
+//   edge_table  per edge: G_ij and the two 6x6 maps A_i, A_j with J_i = J_raw A_i, J_j = J_raw A_j (the reference applies them
+//               per pixel, :376-403; they are linear)
 //   linearize_slot  grid (depth slot, pixel chunk): ALL edges of one source frame in one workgroup, each lane owning a
 //               few pixels.  Per edge the constants G_ij and the two 6x6 maps A_i, A_j with J_i = J_raw A_i,
 //               J_j = J_raw A_j (the reference applies them per pixel, :376-403; they are linear) are staged in LDS, 16
@@ -23,13 +25,12 @@
 //               give S = X diag(Q) X^T and s = X (Q o w).  A workgroup takes (slot, block of <= 8 x 8 tiles of 16 values, pixel
 //               split), streams the rows ONCE (float4 per lane, two steps ahead in registers) and forms the tile products
 //               on the matrix cores with v_mfma_f32_16x16x4_f32 -- exact f32, a k-ordered fmaf chain -- 36 accumulator
-//               tiles per wave; partials of the pixel splits are summed in fixed order by the last workgroup of a job to
-//               arrive, which subtracts the block from the dense fp64 system (fp64 atomics).  Rounds 1-5: one
+//               tiles per wave; the pixel splits write partials.  Rounds 1-5: one
 //               workgroup per ROW PAIR (the reference's EEt6x6 structure, :1118-1173), 37 k pairs re-reading 13 planes each
 //               = 18x the operand set, 2.28 ms at config #5.
-//               Further blocks of the same launch: per edge, sum the linearize partials (fixed order), transform with
-//               A_i, A_j and add the four 6x6 blocks / two 6-vectors (the reference: 90 serial block reductions, then
-//               a D2H copy and Eigen triplets)
+//   schur_reduce  per job: the splits' partials summed in fixed order (f64) and subtracted from the dense fp64 system (fp64
+//               atomics); per edge: the linearize partials summed (fixed order), transformed with A_i, A_j and the four 6x6
+//               blocks / two 6-vectors added (the reference: 90 serial block reductions, then a D2H copy and Eigen triplets)
 //   finalize    fp64 -> fp32 H, v  (transposed like SparseBlock::get_dense, :1305-1316)
 #include "common.h"
 #include "se3.h"
@@ -307,10 +308,36 @@ __global__ __launch_bounds__(256, 4) void ba_linearize_kernel(LinArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// edge table: the per-edge constants of one linearisation, [M][ET_STRIDE] floats, one launch of M x 8 lanes (lane k < 6 of an
+// edge computes column k of both maps; every lane repeats the cheap relative pose instead of waiting for a neighbour).
+// Rounds 1-5 computed them in the first lanes of EVERY workgroup of an edge, behind two barriers; with a workgroup per
+// (depth slot, pixel chunk) that staging was ~40 % of a workgroup's time at config #5.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_edge_table_kernel(const float* __restrict__ poses, const float* __restrict__ extr,
+                                                           const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
+                                                           int M, float* __restrict__ table) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int e = idx >> 3, k = idx & 7;
+  if (e >= M || k >= 6) return;
+  float Ts[ET_STRIDE];
+  edge_rel(poses, (int)ii[e], (int)jj[e], Ts);
+  edge_maps(extr, k, Ts);
+  float* __restrict__ o = table + (long)e * ET_STRIDE;
+  if (k == 0) {
+#pragma unroll
+    for (int n = 0; n < 8; n++) o[n] = Ts[n];
+  }
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    o[ET_AI + k * 6 + c] = Ts[ET_AI + k * 6 + c];
+    o[ET_AJ + k * 6 + c] = Ts[ET_AJ + k * 6 + c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // linearize + accumulate in one launch (K1 + K6 x3 + the depth block, droid_kernels.cu:192-536, 971-991, 1750-1757):
 // grid (depth slot, pixel chunk); a lane owns PPL pixels of the chunk for ALL edges of the slot's source frame.
 // ---------------------------------------------------------------------------------------------
-#define LS_EB 16  // edges whose constants are staged in LDS at once
 
 struct LinSlotArgs {
   const float* target;      // [M,2,HW]
@@ -321,39 +348,45 @@ struct LinSlotArgs {
   const float* intr;        // [4]
   const float* poses;       // [*,7]
   const float* extr;        // [7]
-  const int64_t* jj;
+  const float* table;       // [M,ET_STRIDE] edge constants (ba_edge_table_kernel)
   const int32_t* kx;        // [K] source frame of the slot
   const int32_t* src_ptr;   // [K+1] CSR over the slot's edges
   const int32_t* src_edge;  // [M]
   float* E;                 // [P+M,6,HW]: rows [0,P) the slots' own rows, rows P+e the edges' Ejz
   float* Q;                 // [K,HW]
   float* w;                 // [K,HW]
-  float* partial;           // [M, nch*4, 32]: per (edge, chunk, wave) sums G(21), g(6)
+  float* partial;           // [M, nch, 32]: per (edge, chunk) sums G(21), g(6)
   int M, HW, wd, nch, kf0, P;
 };
 
 template <int PPL>
-__global__ __launch_bounds__(256, PPL == 1 ? 3 : 2) void ba_linearize_slot_kernel(LinSlotArgs a) {
+__global__ __launch_bounds__(256, PPL == 1 ? 4 : 2) void ba_linearize_slot_kernel(LinSlotArgs a) {
+  // A workgroup owns 64 * PPL pixels of one depth slot; its four WAVES take the slot's edges in turn (edge q of a batch goes to
+  // wave q % 4), every lane owning the same PPL pixels for all of them.  So the per-edge sums G, g are complete after one wave
+  // reduction, four edges are in flight per workgroup (a tracking window's ~10 edges per slot: three serial edge bodies instead
+  // of ten), and the slot's C, b, Eiz meet once at the end, through LDS, in wave order.
+  constexpr int NPX = 64 * PPL;
   const int k = blockIdx.x;
   const int ch = blockIdx.y;
   const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
   const int HW = a.HW;
   const int fid = a.kx[k];
   const int t = fid - a.kf0;
   const bool in_window = (t >= 0 && t < a.P);
-  __shared__ __attribute__((aligned(16))) float T[LS_EB][ET_STRIDE];
-  __shared__ int Te[LS_EB][2];  // edge id, target frame
+  __shared__ __attribute__((aligned(16))) float T[4][2][ET_STRIDE + 16];  // per wave: the constants of its current and next edge
+  __shared__ float red[4][8][NPX];
 
   const float fx = a.intr[0], fy = a.intr[1], cx = a.intr[2], cy = a.intr[3];
   const float* __restrict__ disp = a.disps + (long)fid * HW;
 
-  unsigned px[PPL];   // (unsigned: a uniform plane pointer + a zero-extended 32-bit lane offset is ONE address register per
-  bool ok[PPL];       //  access; as `(long)c * HW + p` every plane's 64-bit offset was hoisted out of the edge loop: ~70 registers per pixel)
+  unsigned px[PPL];   // (unsigned: a uniform plane pointer + a zero-extended 32-bit lane offset is ONE address register per access)
+  bool ok[PPL];
   float X0[PPL], X1[PPL], dsp[PPL];
   float C[PPL], b[PPL], Ei[PPL][6];
 #pragma unroll
   for (int i = 0; i < PPL; i++) {
-    const int p = ch * (256 * PPL) + i * 256 + tid;
+    const int p = ch * NPX + i * 64 + lane;
     ok[i] = p < HW;
     px[i] = (unsigned)(ok[i] ? p : HW - 1);
     const int row = (int)px[i] / a.wd, col = (int)px[i] - row * a.wd;
@@ -365,30 +398,24 @@ __global__ __launch_bounds__(256, PPL == 1 ? 3 : 2) void ba_linearize_slot_kerne
 #pragma unroll
     for (int c = 0; c < 6; c++) Ei[i][c] = 0.0f;
   }
-  const int wave = tid >> 6, lane = tid & 63;
   const int s0 = a.src_ptr[k], s1 = a.src_ptr[k + 1];
-  for (int sb = s0; sb < s1; sb += LS_EB) {
-    const int nb = min(LS_EB, s1 - sb);
-    __syncthreads();  // the previous batch's constants are no longer read
-    if (tid < nb) {
-      const int e = a.src_edge[sb + tid];
-      const int jx = (int)a.jj[e];
-      Te[tid][0] = e;
-      Te[tid][1] = jx;
-      edge_rel(a.poses, fid, jx, T[tid]);
-    }
-    __syncthreads();
-    if (tid < nb * 6) edge_maps(a.extr, tid % 6, T[tid / 6]);
-    __syncthreads();
-    // the four input planes of edge q+1 are requested before edge q is computed (PPL x 4 more requests per lane in flight:
-    // with two waves per SIMD the loads of ONE edge do not cover the ~300 instructions per pixel that follow them)
-    float ntu[PPL], ntv[PPL], nwu[PPL], nwv[PPL];
+  {
+    const int nb = s1 - s0;
+    // The four input planes AND the constants of this wave's next edge are requested before the current one is computed (PPL x 4
+    // more requests per lane in flight: with two waves per SIMD the loads of ONE edge do not cover the ~300 instructions per
+    // pixel that follow them).  No workgroup barrier inside the edge loop: a wave's constants live in its own LDS rows.
+    float ntu[PPL], ntv[PPL], nwu[PPL], nwv[PPL], ntab[2];
+    int ne;
     auto request = [&](int q) __attribute__((always_inline)) {
-      const long e = Te[q][0];
+      ne = a.src_edge[s0 + q];
+      const long e = ne;
       const float* __restrict__ tu = a.target + (e * 2 + 0) * HW;
       const float* __restrict__ tv = a.target + (e * 2 + 1) * HW;
       const float* __restrict__ wu_ = a.weight + (e * 2 + 0) * HW;
       const float* __restrict__ wv_ = a.weight + (e * 2 + 1) * HW;
+      const float* __restrict__ tb = a.table + e * ET_STRIDE;
+      ntab[0] = tb[lane];
+      ntab[1] = tb[lane < ET_STRIDE - 64 ? 64 + lane : 0];
 #pragma unroll
       for (int i = 0; i < PPL; i++) {
         ntu[i] = tu[px[i]];
@@ -397,14 +424,13 @@ __global__ __launch_bounds__(256, PPL == 1 ? 3 : 2) void ba_linearize_slot_kerne
         nwv[i] = wv_[px[i]];
       }
     };
-    request(0);
-    for (int q = 0; q < nb; q++) {
-      const float* __restrict__ Tq = T[q];
-      const int e = Te[q][0];
-      const float tij[3] = {Tq[ET_T], Tq[ET_T + 1], Tq[ET_T + 2]};
-      const float qij[4] = {Tq[ET_Q], Tq[ET_Q + 1], Tq[ET_Q + 2], Tq[ET_Q + 3]};
-      const bool stereo = Tq[ET_STEREO] != 0.0f;
-      float* __restrict__ oEj = a.E + ((long)a.P + e) * 6 * HW;
+    if (wave < nb) request(wave);
+    int flip = 0;
+    for (int q = wave; q < nb; q += 4, flip ^= 1) {
+      float* __restrict__ Tw = T[wave][flip];
+      Tw[lane] = ntab[0];
+      if (lane < ET_STRIDE - 64) Tw[64 + lane] = ntab[1];
+      const int e = ne;
       float ltu[PPL], ltv[PPL], lwu[PPL], lwv[PPL];
 #pragma unroll
       for (int i = 0; i < PPL; i++) {
@@ -413,7 +439,13 @@ __global__ __launch_bounds__(256, PPL == 1 ? 3 : 2) void ba_linearize_slot_kerne
         lwu[i] = nwu[i];
         lwv[i] = nwv[i];
       }
-      request(min(q + 1, nb - 1));  // (always issued: no branch between a load and its use; the last edge is read twice)
+      request(q + 4 < nb ? q + 4 : q);  // (always issued: no branch between a load and its use; the last edge is read twice)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS row is written (wave-private: no barrier)
+      const float* __restrict__ Tq = Tw;
+      const float tij[3] = {Tq[ET_T], Tq[ET_T + 1], Tq[ET_T + 2]};
+      const float qij[4] = {Tq[ET_Q], Tq[ET_Q + 1], Tq[ET_Q + 2], Tq[ET_Q + 3]};
+      const bool stereo = Tq[ET_STEREO] != 0.0f;
+      float* __restrict__ oEj = a.E + ((long)a.P + e) * 6 * HW;
       float G[21];
       float g[6];
 #pragma unroll
@@ -487,8 +519,8 @@ __global__ __launch_bounds__(256, PPL == 1 ? 3 : 2) void ba_linearize_slot_kerne
           }
         }
       }
-      // per-wave sums of G, g (fixed DPP order) gathered into lanes 0..26 and stored once; the assembly blocks of the Schur
-      // launch add the (chunk, wave) partials in order
+      // the wave's sums of G, g ARE the (edge, chunk) sums (fixed DPP order), gathered into lanes 0..26 and stored once; the
+      // assembly blocks of the Schur-reduce launch add the chunks in order
       float mine = 0.0f;
 #pragma unroll
       for (int l = 0; l < 21; l++) {
@@ -500,24 +532,36 @@ __global__ __launch_bounds__(256, PPL == 1 ? 3 : 2) void ba_linearize_slot_kerne
         const float sum = wave_sum(g[l]);
         mine = (lane == 21 + l) ? sum : mine;
       }
-      if (lane < 27) a.partial[(((long)e * a.nch + ch) * 4 + wave) * 32 + lane] = mine;
+      if (lane < 27) a.partial[((long)e * a.nch + ch) * 32 + lane] = mine;
     }
   }
-  // depth block of the slot (:1750-1754) and its own E row (:1757)
-  const float alpha = 0.05f;
+  // the four waves' sums over their edges meet in LDS; depth block of the slot (:1750-1754) and its own E row (:1757)
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < PPL; i++) {
-    if (!ok[i]) continue;
-    const unsigned p = px[i];
-    const float ds = (a.disps_sens + (long)fid * HW)[p];
-    const float m = ds > 0.0f ? 1.0f : 0.0f;
-    const float Cf = C[i] + m * alpha + (1.0f - m) * (a.eta + (long)k * HW)[p];
-    const float wf = b[i] - m * alpha * (dsp[i] - ds);
-    (a.Q + (long)k * HW)[p] = 1.0f / Cf;
-    (a.w + (long)k * HW)[p] = wf;
-    if (in_window) {
+    red[wave][0][i * 64 + lane] = C[i];
+    red[wave][1][i * 64 + lane] = b[i];
 #pragma unroll
-      for (int c = 0; c < 6; c++) (a.E + ((long)t * 6 + c) * HW)[p] = Ei[i][c];
+    for (int c = 0; c < 6; c++) red[wave][2 + c][i * 64 + lane] = Ei[i][c];
+  }
+  __syncthreads();
+  if (tid < NPX) {
+    const int p = ch * NPX + tid;
+    if (p < HW) {
+      float sum[8];
+#pragma unroll
+      for (int v = 0; v < 8; v++) sum[v] = ((red[0][v][tid] + red[1][v][tid]) + red[2][v][tid]) + red[3][v][tid];
+      const float alpha = 0.05f;
+      const float ds = (a.disps_sens + (long)fid * HW)[p];
+      const float m = ds > 0.0f ? 1.0f : 0.0f;
+      const float Cf = sum[0] + m * alpha + (1.0f - m) * (a.eta + (long)k * HW)[p];
+      const float wf = sum[1] - m * alpha * (disp[p] - ds);
+      (a.Q + (long)k * HW)[p] = 1.0f / Cf;
+      (a.w + (long)k * HW)[p] = wf;
+      if (in_window) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) (a.E + ((long)t * 6 + c) * HW)[p] = sum[2 + c];
+      }
     }
   }
 }
@@ -534,25 +578,23 @@ typedef float gr_f4u __attribute__((ext_vector_type(4), aligned(4)));  // a row 
 #define GR_NACC 36                      // accumulator tiles of a job: 8x8 upper triangle, or 4 x 8
 #define GR_PART (GR_NACC * 256 + 128)   // floats of one (job, split) partial: the tiles + 8 x 16 entries of X (Q o w)
 #define GR_ROUND 12                     // tiles per LDS round of the cross-wave sum
+#define GR_RG 4                         // tiles per workgroup of the reduce launch
+#define GR_NRG (GR_NACC / GR_RG)
 
 struct GramArgs {
   const float* E;
   const float* Q;
   const float* w;
   const float* zrow;  // HW zeros: what the padding rows of a slot's last tile read
-  const int32_t* kk;  // unused by the kernel (kept for debugging dumps)
-  const int32_t* win_rows_ptr;
-  const int32_t* win_rows;
-  const int32_t* row_pose;
-  const int32_t* jobs;
+  const int32_t* jobs;       // [n_jobs][NS_GRAM_JOB_INTS]
+  const int32_t* job_plane;  // [n_jobs][2][128]
+  const int32_t* job_hrow;   // [n_jobs][2][128]
   float* part;   // [n_jobs * S][GR_PART]
-  int* counter;  // [n_jobs], zero between launches
   double* Hd;
   double* vd;
   // edge assembly
   const float* partial;
-  const float* poses;
-  const float* extr;
+  const float* table;   // [M,ET_STRIDE] edge constants
   const int64_t* ii;
   const int64_t* jj;
   int HW, P, kf0, n_jobs, S, npart, M;
@@ -562,35 +604,31 @@ struct GramArgs {
 __device__ __forceinline__ constexpr int gr_pair(int ta, int tb) { return ta * 8 - ta * (ta - 1) / 2 + (tb - ta); }
 
 template <bool DIAG>
-__device__ __forceinline__ void gram_job(const GramArgs& a, const int job, const int split, float* lds, float* lds_v,
-                                         int* hA, int* hB, int* flag) {
+__device__ __forceinline__ void gram_job(const GramArgs& a, const int job, const int split, float* lds, float* lds_v) {
   constexpr int NA = DIAG ? 8 : 4;  // A tiles a job may have
   constexpr int NB = DIAG ? 0 : 8;  // separately loaded B tiles (a diagonal job's B operand is Q o its A tiles)
   constexpr int NBX = DIAG ? 1 : 8;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r16 = lane & 15, kg = lane >> 4;
   const int HW = a.HW;
-  const int slot = a.jobs[4 * job + 0];
-  const int a0 = a.jobs[4 * job + 1];
-  const int na = __builtin_amdgcn_readfirstlane(a.jobs[4 * job + 2]);
-  const int b0 = a.jobs[4 * job + 3];
-  const int rbase = a.win_rows_ptr[slot];
-  const int R = 6 * (a.win_rows_ptr[slot + 1] - rbase);  // values of the slot
-  const int nt = (R + 15) >> 4;
-  const int nb = __builtin_amdgcn_readfirstlane(DIAG ? na : min(8, nt - b0));
+  const int32_t* __restrict__ hdr = a.jobs + (long)job * NS_GRAM_JOB_INTS;
+  const int slot = hdr[0];
+  const int na = __builtin_amdgcn_readfirstlane(hdr[2]);
+  const int nb = __builtin_amdgcn_readfirstlane(hdr[4]);
 
-  // this lane's row of every tile: value index v = tile*16 + r16 -> (row, component) -> plane of E
+  // this lane's row of every tile: plane of E of value tile*16 + r16 (from the plan), the zero row for padding
+  const int32_t* __restrict__ jp = a.job_plane + (long)job * 256;
   const float* pa[NA];
   const float* pb[NBX];
 #pragma unroll
   for (int t = 0; t < NA; t++) {
-    const int v = (a0 + t) * 16 + r16;
-    pa[t] = (t < na && v < R) ? a.E + ((long)a.win_rows[rbase + v / 6] * 6 + v % 6) * HW : a.zrow;
+    const int pl = jp[t * 16 + r16];
+    pa[t] = pl >= 0 ? a.E + (long)pl * HW : a.zrow;
   }
 #pragma unroll
   for (int t = 0; t < NBX; t++) {
-    const int v = (b0 + t) * 16 + r16;
-    pb[t] = (!DIAG && t < nb && v < R) ? a.E + ((long)a.win_rows[rbase + v / 6] * 6 + v % 6) * HW : a.zrow;
+    const int pl = DIAG ? -1 : jp[128 + t * 16 + r16];
+    pb[t] = pl >= 0 ? a.E + (long)pl * HW : a.zrow;
   }
   const float* __restrict__ Qk = a.Q + (long)slot * HW;
   const float* __restrict__ wk = a.w + (long)slot * HW;
@@ -723,29 +761,32 @@ __device__ __forceinline__ void gram_job(const GramArgs& a, const int job, const
     }
     __syncthreads();
   }
+}
 
-  // ---- the last split of the job to arrive adds the job's block to the system ----
-  if (a.S > 1) {
-    __threadfence();  // release: this workgroup's partial is visible device-wide before its ticket
-    __syncthreads();
-    if (tid == 0) flag[0] = (atomicAdd(a.counter + job, 1) == a.S - 1) ? 1 : 0;
-    __syncthreads();
-    if (!flag[0]) return;
-    __threadfence();  // acquire: the other splits' partials
-  }
-  if (tid < 128) {
-    const int va = a0 * 16 + tid, vb = b0 * 16 + tid;
-    hA[tid] = (tid < na * 16 && va < R) ? 6 * a.row_pose[a.win_rows[rbase + va / 6]] + va % 6 : -1;
-    hB[tid] = (tid < nb * 16 && vb < R) ? 6 * a.row_pose[a.win_rows[rbase + vb / 6]] + vb % 6 : -1;
-  }
+// A job's block of the system: the S pixel-split partials summed in fixed order (f64), mapped from (tile, element) to the rows /
+// columns of H through the slot's window rows, subtracted with fp64 atomics.  One workgroup per job, in the launch that follows
+// the Gram kernel: the kernel boundary is the only device-wide synchronisation (a last-arriver reduction inside the Gram kernel
+// needs an agent-scope release per workgroup -- an L2 write-back on this 8-XCD part -- and cost 60 us at C640).
+template <bool DIAG>
+__device__ __forceinline__ void gram_reduce(const GramArgs& a, const int job, const int group, int* hA, int* hB) {
+  const int tid = threadIdx.x;
+  const int na = a.jobs[(long)job * NS_GRAM_JOB_INTS + 2];
+  const int nb = a.jobs[(long)job * NS_GRAM_JOB_INTS + 4];
+  hA[tid & 127] = a.job_hrow[(long)job * 256 + (tid & 127)];   // (both halves of the workgroup write the same values: no branch)
+  hB[tid & 127] = a.job_hrow[(long)job * 256 + 128 + (tid & 127)];
   __syncthreads();
   const long n6 = 6L * a.P;
   const float* __restrict__ pj = a.part + (long)job * a.S * GR_PART;
   const int el = tid >> 2, rg = tid & 3;              // element `tid` of a tile: accumulator register rg of lane el
   const int ti = 4 * (el >> 4) + rg, tj = el & 15;    // row (A value) and column (B value) inside the tile
-#pragma unroll 1
-  for (int tile = 0; tile < GR_NACC; tile++) {
-    if (!tile_live(tile)) continue;
+  // this block's GR_RG tiles: all their partial loads are requested before the first sum (a job's tiles one after the other, in
+  // one workgroup, were a chain of ~2-us round trips: 39 us at C640)
+  int ta_[GR_RG], tb_[GR_RG];
+  bool live[GR_RG];
+  double sum[GR_RG];
+#pragma unroll
+  for (int u = 0; u < GR_RG; u++) {
+    const int tile = group * GR_RG + u;
     int ta, tb;
     if (DIAG) {
       ta = 0;
@@ -759,63 +800,96 @@ __device__ __forceinline__ void gram_job(const GramArgs& a, const int job, const
       ta = tile >> 3;
       tb = tile & 7;
     }
-    double sum = 0.0;
-    for (int s = 0; s < a.S; s++) sum += (double)pj[(long)s * GR_PART + tile * 256 + tid];
-    const int ha = hA[ta * 16 + ti], hb = hB[tb * 16 + tj];
-    const bool same_tile = DIAG && ta == tb;
-    // upper triangle of the slot's Gram matrix only; the mirror image is added explicitly: H stays exactly symmetric
+    ta_[u] = ta;
+    tb_[u] = tb;
+    live[u] = tile < (DIAG ? GR_NACC : 32) && tb < nb && (DIAG || ta < na);   // (uniform)
+    sum[u] = 0.0;
+  }
+  for (int s = 0; s < a.S; s++) {
+#pragma unroll
+    for (int u = 0; u < GR_RG; u++)
+      if (live[u]) sum[u] += (double)pj[(long)s * GR_PART + (group * GR_RG + u) * 256 + tid];
+  }
+#pragma unroll
+  for (int u = 0; u < GR_RG; u++) {
+    if (!live[u]) continue;
+    const int ha = hA[ta_[u] * 16 + ti], hb = hB[tb_[u] * 16 + tj];
+    const bool same_tile = DIAG && ta_[u] == tb_[u];
+    // upper triangle of the slot's Gram matrix, into the upper triangle of the system (ba_finalize_kernel mirrors it: H is exactly
+    // symmetric and the fp64 atomics -- executed at the memory side on this part, what bounds this launch -- are halved): an
+    // off-diagonal value pair {a, b} stands for both G[a][b] and G[b][a]; where both values map to the SAME row of H (two edges
+    // of one slot to one pose) that is twice the value on H's diagonal
     if (ha >= 0 && hb >= 0 && (!same_tile || ti <= tj)) {
-      atomicAdd(&a.Hd[(long)ha * n6 + hb], -sum);
-      if (!(same_tile && ti == tj)) atomicAdd(&a.Hd[(long)hb * n6 + ha], -sum);
+      const bool diag_val = same_tile && ti == tj;
+      const int lo = ha < hb ? ha : hb, hi = ha < hb ? hb : ha;
+      atomicAdd(&a.Hd[(long)lo * n6 + hi], (!diag_val && ha == hb) ? -2.0 * sum[u] : -sum[u]);
     }
   }
+  if (group != 0) return;
   if (DIAG && tid < 128 && hA[tid] >= 0) {
     double sum = 0.0;
     for (int s = 0; s < a.S; s++) sum += (double)pj[(long)s * GR_PART + GR_NACC * 256 + tid];
     atomicAdd(&a.vd[hA[tid]], -sum);
   }
-  if (a.S > 1 && tid == 0) a.counter[job] = 0;  // ready for the next launch
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ba_schur_gram_kernel(GramArgs a) {
-  const int tid = threadIdx.x;
   __shared__ __attribute__((aligned(16))) float lds[4 * GR_ROUND * 256];
   __shared__ float lds_v[4 * 8 * 64];
-  __shared__ int hA[128], hB[128], flag[1];
-  if ((int)blockIdx.x >= a.n_jobs * a.S) {
-    // ---------------- edge assembly ----------------
-    const long n6 = 6L * a.P;
-    const int e = blockIdx.x - a.n_jobs * a.S;
-    const int ix = (int)a.ii[e], jx = (int)a.jj[e];
-    float* T = lds;
-    double* Gs = reinterpret_cast<double*>(lds + 128);
-    edge_constants(a.poses, a.extr, ix, jx, T);
-    if (tid < 27) {
-      double s = 0.0;
-      for (int c = 0; c < a.npart; c++) s += (double)a.partial[((long)e * a.npart + c) * 32 + tid];
-      Gs[tid] = s;
-    }
-    __syncthreads();
-    if (tid < 156) {
-      const double val = edge_block_entry(T + ET_AI, T + ET_AJ, Gs, tid);
-      if (tid < 144) {
-        const int blk = tid / 36, r = (tid % 36) / 6, c = tid % 6;
-        const int rp = ((blk < 2) ? ix : jx) - a.kf0;
-        const int cp = ((blk % 2 == 0) ? ix : jx) - a.kf0;
-        if (rp >= 0 && rp < a.P && cp >= 0 && cp < a.P) atomicAdd(&a.Hd[(long)(6 * rp + r) * n6 + 6 * cp + c], val);
-      } else {
-        const int side = (tid - 144) / 6, r = (tid - 144) % 6;
-        const int rp = (side == 0 ? ix : jx) - a.kf0;
-        if (rp >= 0 && rp < a.P) atomicAdd(&a.vd[6 * rp + r], val);
-      }
-    }
+  const int job = blockIdx.x / a.S, split = blockIdx.x % a.S;
+  if (a.jobs[(long)job * NS_GRAM_JOB_INTS + 1] == a.jobs[(long)job * NS_GRAM_JOB_INTS + 3])
+    gram_job<true>(a, job, split, lds, lds_v);
+  else
+    gram_job<false>(a, job, split, lds, lds_v);
+}
+
+//   blocks [0, n_jobs * GR_NRG) : GR_RG tiles of a Gram job's partials -> the system
+//   blocks [.., +M)             : edge e: sum its linearize partials (fixed order), transform with A_i, A_j, add to the system
+__global__ __launch_bounds__(256) void ba_schur_reduce_kernel(GramArgs a) {
+  const int tid = threadIdx.x;
+  __shared__ int hA[128], hB[128];
+  __shared__ float T[ET_STRIDE];
+  __shared__ double Gs[27], Gp[8][32];
+  if ((int)blockIdx.x < a.n_jobs * GR_NRG) {
+    const int job = blockIdx.x / GR_NRG, group = blockIdx.x % GR_NRG;
+    if (a.jobs[(long)job * NS_GRAM_JOB_INTS + 1] == a.jobs[(long)job * NS_GRAM_JOB_INTS + 3])
+      gram_reduce<true>(a, job, group, hA, hB);
+    else
+      gram_reduce<false>(a, job, group, hA, hB);
     return;
   }
-  const int job = blockIdx.x / a.S, split = blockIdx.x % a.S;
-  if (a.jobs[4 * job + 1] == a.jobs[4 * job + 3])
-    gram_job<true>(a, job, split, lds, lds_v, hA, hB, flag);
-  else
-    gram_job<false>(a, job, split, lds, lds_v, hA, hB, flag);
+  // ---------------- edge assembly ----------------
+  const long n6 = 6L * a.P;
+  const int e = blockIdx.x - a.n_jobs * GR_NRG;
+  const int ix = (int)a.ii[e], jx = (int)a.jj[e];
+  if (tid < ET_STRIDE) T[tid] = a.table[(long)e * ET_STRIDE + tid];
+  // the (edge, chunk) partials of the lineariser: eight lanes per value take every eighth chunk, then the eight are added in order
+  // (a fixed order; one lane per value walking all chunks was a chain of up to 75 dependent round trips at C640)
+  {
+    const int v = tid & 31, c0 = tid >> 5;
+    double s = 0.0;
+    if (v < 27)
+      for (int c = c0; c < a.npart; c += 8) s += (double)a.partial[((long)e * a.npart + c) * 32 + v];
+    Gp[c0][v] = s;
+  }
+  __syncthreads();
+  if (tid < 27) Gs[tid] = ((Gp[0][tid] + Gp[1][tid]) + (Gp[2][tid] + Gp[3][tid])) + ((Gp[4][tid] + Gp[5][tid]) + (Gp[6][tid] + Gp[7][tid]));
+  __syncthreads();
+  if (tid < 156) {
+    const double val = edge_block_entry(T + ET_AI, T + ET_AJ, Gs, tid);
+    if (tid < 144) {
+      const int blk = tid / 36, r = (tid % 36) / 6, c = tid % 6;
+      const int rp = ((blk < 2) ? ix : jx) - a.kf0;
+      const int cp = ((blk % 2 == 0) ? ix : jx) - a.kf0;
+      // upper triangle of the system only: of H_ij / H_ji = H_ij^T the one above the diagonal, of a diagonal block its upper half
+      if (rp >= 0 && rp < a.P && cp >= 0 && cp < a.P && (rp < cp || (rp == cp && r <= c)))
+        atomicAdd(&a.Hd[(long)(6 * rp + r) * n6 + 6 * cp + c], val);
+    } else {
+      const int side = (tid - 144) / 6, r = (tid - 144) % 6;
+      const int rp = (side == 0 ? ix : jx) - a.kf0;
+      if (rp >= 0 && rp < a.P) atomicAdd(&a.vd[6 * rp + r], val);
+    }
+  }
 }
 
 #ifdef NS_TEST_VARIANTS   // rounds 1-5: separate accumulate kernel and one workgroup per row pair (NS_BA_UNFUSED=1: the A/B baseline)
@@ -983,14 +1057,24 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(SchurArgs a) {
 #endif  // NS_TEST_VARIANTS
 
 // fp64 -> fp32, and re-zero the accumulators for the next linearisation (every element is read by
-// exactly one thread, so the system buffer needs a memset only once, when it is allocated)
-__global__ void ba_finalize_kernel(double* __restrict__ Hd, double* __restrict__ vd, int n6,
-                                   float* __restrict__ H, float* __restrict__ v) {
+// exactly one thread, so the system buffer needs a memset only once, when it is allocated).
+// upper = 1: only the upper triangle of Hd was accumulated; H gets it mirrored.
+__global__ void ba_finalize_kernel(double* __restrict__ Hd, double* __restrict__ vd, int n6, float* __restrict__ H,
+                                   float* __restrict__ v, int upper) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < n6 * n6) {
     const int r = idx / n6, c = idx - r * n6;
-    H[idx] = (float)Hd[(long)c * n6 + r];  // get_dense() hands the column-major data over as row-major (:1305-1316)
-    Hd[(long)c * n6 + r] = 0.0;
+    if (upper) {
+      if (r <= c) {
+        const float val = (float)Hd[(long)r * n6 + c];
+        Hd[(long)r * n6 + c] = 0.0;
+        H[idx] = val;
+        if (r < c) H[(long)c * n6 + r] = val;
+      }
+    } else {
+      H[idx] = (float)Hd[(long)c * n6 + r];  // get_dense() hands the column-major data over as row-major (:1305-1316)
+      Hd[(long)c * n6 + r] = 0.0;
+    }
   }
   if (idx < n6) {
     v[idx] = (float)vd[idx];
@@ -1107,24 +1191,29 @@ __global__ void pose_retr_kernel(float* __restrict__ poses, const float* __restr
 // ---------------------------------------------------------------------------------------------
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// pixels per lane of the fused lineariser: as many as still leave ~1024 workgroups (the per-edge wave reductions of G, g
-// are paid once per (edge, chunk, wave): 190 DPP adds against ~300 instructions per pixel)
+// pixels per lane of the fused lineariser (a workgroup = 64 x PPL pixels of a slot): as many as still leave ~2048 workgroups
+// (the per-edge wave reductions of G, g are paid once per (edge, chunk): 190 DPP adds against ~300 instructions per pixel)
 static int choose_ppl(int K, int HW) {
-  if ((long)K * ns_cdiv(HW, 1024) >= 1024) return 4;
-  if ((long)K * ns_cdiv(HW, 512) >= 1024) return 2;
+  if ((long)K * ns_cdiv(HW, 256) >= 2048) return 4;
+  if ((long)K * ns_cdiv(HW, 128) >= 2048) return 2;
   return 1;
 }
-// pixel splits of a Gram job: ~1024 workgroups (one per CU at a time: 512 registers per lane), at least 4 rounds of 64 pixels each
+// pixel splits of a Gram job: ~2048 workgroups (one per CU at a time: 512 registers per lane; 8 rounds of the chip lose 4 % to the
+// last, partly filled one, 4.4 lost 12 %), each an integral number of the kernel's three-round trips where that is possible
+// (C640: 75 rounds of 64 pixels -> 25 splits of exactly one trip; config #5: 225 rounds -> 7 splits of 32 / 33 rounds)
 static int choose_splits(int n_jobs, int HW) {
   const int NR = ns_cdiv(HW, 64);
-  int S = ns_cdiv(1024, n_jobs > 0 ? n_jobs : 1);
-  const int cap = NR / 6 > 1 ? NR / 6 : 1;   // (the kernel's loop takes three rounds per trip: at least two trips per split)
+  int S = ns_cdiv(2048, n_jobs > 0 ? n_jobs : 1);
+  const int cap = NR / 3 > 1 ? NR / 3 : 1;
   if (S > cap) S = cap;
+  if (S < 1) S = 1;
+  const int rounds = ns_cdiv(ns_cdiv(NR, S), 3) * 3;   // rounds per split, a multiple of three
+  S = ns_cdiv(NR, rounds);
   return S < 1 ? 1 : S;
 }
 
 struct WsLayout {
-  size_t Hd, vd, counter, zrow, zero_end, partial, part, Eiz, Cii, bz, total;
+  size_t Hd, vd, zrow, zero_end, table, partial, part, Eiz, Cii, bz, total;
 };
 
 static WsLayout ws_layout(const ns_ba_plan* plan, int HW) {
@@ -1135,14 +1224,14 @@ static WsLayout ws_layout(const ns_ba_plan* plan, int HW) {
   off += align256(sizeof(double) * (size_t)36 * P * P + 8);
   L.vd = off;
   off += align256(sizeof(double) * (size_t)6 * P + 8);
-  L.counter = off;
-  off += align256(sizeof(int) * (size_t)(plan->n_jobs + 1));
   L.zrow = off;
   off += align256(sizeof(float) * (size_t)(HW + 4));
   L.zero_end = off;  // [Hd, zero_end) is zero between calls
-  const int nch = ns_cdiv(HW, 256 * choose_ppl(plan->K, HW));
+  L.table = off;
+  off += align256(sizeof(float) * (size_t)ET_STRIDE * (M > 0 ? M : 1));
+  const int nch = ns_cdiv(HW, 64 * choose_ppl(plan->K, HW));
   L.partial = off;
-  off += align256(sizeof(float) * (size_t)32 * 4 * (M > 0 ? M : 1) * nch);
+  off += align256(sizeof(float) * (size_t)32 * (M > 0 ? M : 1) * nch);
   L.part = off;
   off += align256(sizeof(float) * (size_t)GR_PART * (plan->n_jobs > 0 ? plan->n_jobs : 1) * choose_splits(plan->n_jobs, HW));
   L.Eiz = L.Cii = L.bz = off;
@@ -1243,17 +1332,17 @@ extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, 
   double* Hd = (double*)(ws + L.Hd);
   double* vd = (double*)(ws + L.vd);
   float* partial = (float*)(ws + L.partial);
-  // Hd, vd, the job counters and the zero row are adjacent in the layout: one memset, needed only the first time a workspace
-  // is used (ba_finalize_kernel re-zeroes what it reads, the last split of a Gram job its counter)
+  // Hd, vd and the zero row are adjacent in the layout: one memset, needed only the first time a workspace is used
+  // (ba_finalize_kernel re-zeroes what it reads)
   if (!ws_zeroed && hipMemsetAsync(Hd, 0, L.zero_end - L.Hd, st) != hipSuccess) {
     ns_set_error("ns_reduced_camera_matrix: hipMemsetAsync failed");
     return NS_ELAUNCH;
   }
   const int32_t* kx = index + off[0];
-  const int32_t* row_pose = index + off[2];
   const int32_t* src_ptr = index + off[3];
   const int32_t* src_edge = index + off[4];
 #ifdef NS_TEST_VARIANTS
+  const int32_t* row_pose = index + off[2];
   static const bool unfused = [] { const char* e = ns_variant_env("NS_BA_UNFUSED"); return e != nullptr && e[0] == '1'; }();
   if (ns_variant_env("NS_BA_UNFUSED") != nullptr ? ns_variant_env("NS_BA_UNFUSED")[0] == '1' : unfused) {
     // rounds 1-5: linearise per edge -> accumulate per slot -> one workgroup per row pair
@@ -1318,14 +1407,19 @@ extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, 
       NS_CHECK_LAUNCH("ba_schur_kernel");
     }
     if (n6 > 0) {
-      hipLaunchKernelGGL(ba_finalize_kernel, dim3(ns_cdiv((long)n6 * n6, 256)), dim3(256), 0, st, Hd, vd, n6, H, v);
+      hipLaunchKernelGGL(ba_finalize_kernel, dim3(ns_cdiv((long)n6 * n6, 256)), dim3(256), 0, st, Hd, vd, n6, H, v, 0);
       NS_CHECK_LAUNCH("ba_finalize_kernel");
     }
     return NS_OK;
   }
 #endif
   const int ppl = choose_ppl(K, HW);
-  const int nch = ns_cdiv(HW, 256 * ppl);
+  const int nch = ns_cdiv(HW, 64 * ppl);
+  float* table = (float*)(ws + L.table);
+  if (M > 0) {
+    hipLaunchKernelGGL(ba_edge_table_kernel, dim3(ns_cdiv((long)M * 8, 256)), dim3(256), 0, st, poses, extrinsics, ii, jj, M, table);
+    NS_CHECK_LAUNCH("ba_edge_table_kernel");
+  }
   if (K > 0) {
     LinSlotArgs a;
     a.target = targets;
@@ -1336,7 +1430,7 @@ extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, 
     a.intr = intrinsics;
     a.poses = poses;
     a.extr = extrinsics;
-    a.jj = jj;
+    a.table = table;
     a.kx = kx;
     a.src_ptr = src_ptr;
     a.src_edge = src_edge;
@@ -1365,18 +1459,14 @@ extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, 
     g.Q = Q;
     g.w = w;
     g.zrow = (const float*)(ws + L.zrow);
-    g.kk = index + off[1];
-    g.win_rows_ptr = index + off[8];
-    g.win_rows = index + off[9];
-    g.row_pose = row_pose;
     g.jobs = index + off[10];
+    g.job_plane = index + off[11];
+    g.job_hrow = index + off[12];
     g.part = (float*)(ws + L.part);
-    g.counter = (int*)(ws + L.counter);
     g.Hd = Hd;
     g.vd = vd;
     g.partial = partial;
-    g.poses = poses;
-    g.extr = extrinsics;
+    g.table = table;
     g.ii = ii;
     g.jj = jj;
     g.HW = HW;
@@ -1384,13 +1474,17 @@ extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, 
     g.kf0 = plan->kf0;
     g.n_jobs = plan->n_jobs;
     g.S = choose_splits(plan->n_jobs, HW);
-    g.npart = nch * 4;
+    g.npart = nch;
     g.M = M;
-    hipLaunchKernelGGL(ba_schur_gram_kernel, dim3(plan->n_jobs * g.S + M), dim3(256), 0, st, g);
-    NS_CHECK_LAUNCH("ba_schur_gram_kernel");
+    if (plan->n_jobs > 0) {
+      hipLaunchKernelGGL(ba_schur_gram_kernel, dim3(plan->n_jobs * g.S), dim3(256), 0, st, g);
+      NS_CHECK_LAUNCH("ba_schur_gram_kernel");
+    }
+    hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(plan->n_jobs * GR_NRG + M), dim3(256), 0, st, g);
+    NS_CHECK_LAUNCH("ba_schur_reduce_kernel");
   }
   if (n6 > 0) {
-    hipLaunchKernelGGL(ba_finalize_kernel, dim3(ns_cdiv((long)n6 * n6, 256)), dim3(256), 0, st, Hd, vd, n6, H, v);
+    hipLaunchKernelGGL(ba_finalize_kernel, dim3(ns_cdiv((long)n6 * n6, 256)), dim3(256), 0, st, Hd, vd, n6, H, v, 1);
     NS_CHECK_LAUNCH("ba_finalize_kernel");
   }
   return NS_OK;

@@ -12,7 +12,7 @@
 namespace {
 
 struct PlanData {
-  std::vector<int32_t> kx, kk, row_pose, src_ptr, src_edge, pairs, slot_rows_ptr, slot_rows, win_rows_ptr, win_rows, gram_jobs;
+  std::vector<int32_t> kx, kk, row_pose, src_ptr, src_edge, pairs, slot_rows_ptr, slot_rows, win_rows_ptr, win_rows, gram_jobs, job_plane, job_hrow;
   int K = 0;
 };
 
@@ -77,7 +77,7 @@ int build(const int64_t* ii, const int64_t* jj, int M, int kf0, int kf1, PlanDat
   }
   // Schur complement as one Gram matrix per depth slot (ba_schur_gram_kernel): the slot's WINDOW rows (pose inside [0, P): the
   // only ones schur_block admits, :1375) in slot_rows order, six values each, cut into tiles of 16 values; blocks of
-  // NS_GRAM_BLOCK tiles.  A job is (slot, first A tile, number of A tiles, first B tile): the diagonal job of a block computes the
+  // NS_GRAM_BLOCK tiles.  A job is (slot, first A tile, A tiles, first B tile, B tiles, 0): the diagonal job of a block computes the
   // upper triangle of its <= 8 x 8 tile pairs; a pair of blocks bi < bj is two jobs of <= 4 x 8 tile pairs (the accumulators
   // of a job have to fit one wave's registers).  A slot of <= 21 rows -- every slot of a tracking window -- is ONE job.
   d.win_rows_ptr.assign(d.K + 1, 0);
@@ -92,15 +92,29 @@ int build(const int64_t* ii, const int64_t* jj, int M, int kf0, int kf1, PlanDat
     const int nr = d.win_rows_ptr[k + 1] - d.win_rows_ptr[k];
     const int nt = (6 * nr + 15) / 16;
     const int nblk = (nt + NS_GRAM_BLOCK - 1) / NS_GRAM_BLOCK;
+    // per job: the plane of E (row * 6 + component) and the row of H (6 * pose + component) of each of its <= 128 A and <= 128 B
+    // values, -1 for padding -- the kernels read these instead of walking win_rows_ptr -> win_rows -> row_pose (three dependent
+    // round trips in front of a 3-us main loop at tracking sizes)
+    auto emit = [&](int a0, int na, int b0, int nb) {
+      const int32_t hdr[NS_GRAM_JOB_INTS] = {k, a0, na, b0, nb, 0};
+      d.gram_jobs.insert(d.gram_jobs.end(), hdr, hdr + NS_GRAM_JOB_INTS);
+      for (int side = 0; side < 2; side++) {
+        const int t0 = side == 0 ? a0 : b0, ntl = side == 0 ? na : nb;
+        for (int i = 0; i < 128; i++) {
+          const int v = t0 * 16 + i;
+          const bool live = i < ntl * 16 && v < 6 * nr;
+          const int n = live ? d.win_rows[d.win_rows_ptr[k] + v / 6] : 0;
+          d.job_plane.push_back(live ? n * 6 + v % 6 : -1);
+          d.job_hrow.push_back(live ? 6 * d.row_pose[n] + v % 6 : -1);
+        }
+      }
+    };
     for (int bi = 0; bi < nblk; bi++) {
       const int a0 = bi * NS_GRAM_BLOCK, na = std::min(NS_GRAM_BLOCK, nt - a0);
-      const int32_t diag[4] = {k, a0, na, a0};
-      d.gram_jobs.insert(d.gram_jobs.end(), diag, diag + 4);
+      emit(a0, na, a0, na);
       for (int bj = bi + 1; bj < nblk; bj++)
-        for (int h = 0; h < na; h += NS_GRAM_BLOCK / 2) {
-          const int32_t off[4] = {k, a0 + h, std::min(NS_GRAM_BLOCK / 2, na - h), bj * NS_GRAM_BLOCK};
-          d.gram_jobs.insert(d.gram_jobs.end(), off, off + 4);
-        }
+        for (int h = 0; h < na; h += NS_GRAM_BLOCK / 2)
+          emit(a0 + h, std::min(NS_GRAM_BLOCK / 2, na - h), bj * NS_GRAM_BLOCK, std::min(NS_GRAM_BLOCK, nt - bj * NS_GRAM_BLOCK));
     }
   }
   return NS_OK;
@@ -108,7 +122,8 @@ int build(const int64_t* ii, const int64_t* jj, int M, int kf0, int kf1, PlanDat
 
 size_t total_count(const PlanData& d) {
   return d.kx.size() + d.kk.size() + d.row_pose.size() + d.src_ptr.size() + d.src_edge.size() + d.pairs.size() +
-         d.slot_rows_ptr.size() + d.slot_rows.size() + d.win_rows_ptr.size() + d.win_rows.size() + d.gram_jobs.size();
+         d.slot_rows_ptr.size() + d.slot_rows.size() + d.win_rows_ptr.size() + d.win_rows.size() + d.gram_jobs.size() +
+         d.job_plane.size() + d.job_hrow.size();
 }
 
 }  // namespace
@@ -134,12 +149,13 @@ extern "C" int ns_ba_plan_build(const int64_t* ii_host, const int64_t* jj_host, 
   plan->kf1 = kf1;
   plan->n_pairs = (int)(d.pairs.size() / 3);
   plan->n_rows = plan->P + M;
-  plan->n_jobs = (int)(d.gram_jobs.size() / 4);
+  plan->n_jobs = (int)(d.gram_jobs.size() / NS_GRAM_JOB_INTS);
   plan->max_src = 0;
   for (int k = 0; k < d.K; k++) plan->max_src = std::max(plan->max_src, (int)(d.src_ptr[k + 1] - d.src_ptr[k]));
   const std::vector<int32_t>* parts[NS_BA_PLAN_PARTS] = {&d.kx,           &d.kk,        &d.row_pose,      &d.src_ptr,
                                                          &d.src_edge,     &d.pairs,     &d.slot_rows_ptr, &d.slot_rows,
-                                                         &d.win_rows_ptr, &d.win_rows,  &d.gram_jobs};
+                                                         &d.win_rows_ptr, &d.win_rows,  &d.gram_jobs,     &d.job_plane,
+                                                         &d.job_hrow};
   size_t off = 0;
   for (int i = 0; i < NS_BA_PLAN_PARTS; i++) {
     offsets_host[i] = off;

@@ -18,7 +18,7 @@ class _CPlan(C.Structure):
                 ("n_pairs", C.c_int), ("n_rows", C.c_int), ("n_jobs", C.c_int), ("max_src", C.c_int)]
 
 
-PLAN_PARTS = 11   # include/nerfslam_hip.h: NS_BA_PLAN_PARTS
+PLAN_PARTS = 13   # include/nerfslam_hip.h: NS_BA_PLAN_PARTS
 
 
 class BaPlan:

@@ -170,21 +170,31 @@ def test_ba_plan_matches_oracle_index_logic(seed):
     # tile pairs must cover the upper triangle of every slot's ceil(6 rows / 16)^2 tile grid exactly once.
     wp = idx[o[8]:o[8] + plan.K + 1]
     wr = idx[o[9]:o[9] + wp[-1]]
-    jobs = idx[o[10]:o[10] + 4 * plan.n_jobs].reshape(-1, 4)
-    assert n == o[10] + 4 * plan.n_jobs and plan.max_src == np.bincount(kk[P:], minlength=plan.K).max()
+    jobs = idx[o[10]:o[10] + 6 * plan.n_jobs].reshape(-1, 6)
+    planes = idx[o[11]:o[11] + 256 * plan.n_jobs].reshape(-1, 2, 128)
+    hrows = idx[o[12]:o[12] + 256 * plan.n_jobs].reshape(-1, 2, 128)
+    assert n == o[12] + 256 * plan.n_jobs and plan.max_src == np.bincount(kk[P:], minlength=plan.K).max()
     for k in range(plan.K):
         mine = np.nonzero(kk == k)[0]
         np.testing.assert_array_equal(wr[wp[k]:wp[k + 1]], mine[(jj_e[mine] >= kf0) & (jj_e[mine] < kf1)])
         nt = (6 * (wp[k + 1] - wp[k]) + 15) // 16
         cover = np.zeros((nt, nt), int)
-        for _, a0, na, b0 in jobs[jobs[:, 0] == k]:
+        rows_k = wr[wp[k]:wp[k + 1]]
+        for j in np.nonzero(jobs[:, 0] == k)[0]:
+            _, a0, na, b0, nb, _ = jobs[j]
             if a0 == b0:
-                assert 1 <= na <= 8
+                assert 1 <= na <= 8 and nb == na
                 for ta in range(na):
                     cover[a0 + ta, a0 + ta:a0 + na] += 1
             else:
-                assert 1 <= na <= 4 and b0 > a0 and b0 % 8 == 0
-                cover[a0:a0 + na, b0:min(b0 + 8, nt)] += 1
+                assert 1 <= na <= 4 and b0 > a0 and b0 % 8 == 0 and nb == min(8, nt - b0)
+                cover[a0:a0 + na, b0:b0 + nb] += 1
+            for side, (t0, ntl) in enumerate(((a0, na), (b0, nb))):
+                v = t0 * 16 + np.arange(128)
+                live = (np.arange(128) < ntl * 16) & (v < 6 * len(rows_k))
+                rr = rows_k[np.minimum(v // 6, len(rows_k) - 1)]
+                np.testing.assert_array_equal(planes[j, side], np.where(live, rr * 6 + v % 6, -1))
+                np.testing.assert_array_equal(hrows[j, side], np.where(live, 6 * (jj_e[rr] - kf0) + v % 6, -1))
         np.testing.assert_array_equal(cover, np.triu(np.ones((nt, nt), int)))
     if seed == 3:
         assert (np.diff(wp) > 21).any() and plan.n_jobs > plan.K          # multi-block slots
