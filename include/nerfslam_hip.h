@@ -611,6 +611,24 @@ int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int log2_hashma
                                    size_t workspace_bytes, float fixed_scale, long N, const int* n_dev, float* master,
                                    void* half_params, float* m1, float* m2, int step, float lr, float beta1, float beta2,
                                    float eps, float grad_scale, const int* ctl, int parts, void* stream);
+
+/* Replicated trainers (`--multi_gpu` with more than one mapper; reference boundary examples/slam_demo.py:63-77): what
+ * the trainers exchange is the LIST of table entries a step touched, not the table.
+ *   ns_ngp_encode_backward_fused_emit_n   parts 1 | 2 of ns_ngp_encode_backward_fused_n whose flush appends (entry, packed
+ *       fixed-point sum) pairs -- 16 bytes each, at most one per entry -- to `list` and adds their number to *list_count (device
+ *       int, zeroed by the caller); needs every level on the binned path (ns_ngp_encode_backward_fused_dense_levels() == 0).
+ *   ns_ngp_sparse_table_update   `n_lists` lists of `stride` pairs each (list r holds counts[r] <= max_count valid pairs: the
+ *       trainers' lists after the all-gather): 64-bit integer sums per entry in `acc` (int64 per table entry, zero on entry and
+ *       zero again on return), then Adam ONCE per touched entry with the complete sum -- exactly ns_ngp_encode_backward_fused_n's
+ *       fused update, from sums over all trainers.  Every trainer runs it on the same lists and obtains the same table bit for
+ *       bit; no parameter travels back.                                                                              */
+int ns_ngp_encode_backward_fused_emit_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                                        const float* positions, const void* dLdoutT, void* workspace, size_t workspace_bytes,
+                                        float fixed_scale, long N, const int* n_dev, void* list, int* list_count, int parts,
+                                        void* stream);
+int ns_ngp_sparse_table_update(const void* lists, const int* counts, int n_lists, long stride, long max_count, void* acc,
+                               float* master, void* half_params, float* m1, float* m2, int step, float lr, float beta1,
+                               float beta2, float eps, float grad_scale, float fixed_scale, const int* ctl, void* stream);
 int ns_ngp_mlp_forward_n(const void* weights, const void* featT, const float* dirs, void* out, void* h1T, void* cinT, void* h3T,
                          void* h4T, long N, const int* n_dev, void* stream);
 int ns_ngp_mlp_backward_n(const void* weights, const void* dLdout, const void* featT, const void* h1T, const void* cinT,

@@ -339,6 +339,30 @@ __global__ __launch_bounds__(256) void ba_edge_table_kernel(const float* __restr
 // grid (depth slot, pixel chunk); a lane owns PPL pixels of the chunk for ALL edges of the slot's source frame.
 // ---------------------------------------------------------------------------------------------
 
+typedef float ls_f2 __attribute__((ext_vector_type(2)));
+
+// packed f32 with ONE half of the second operand broadcast to both lanes (VOP3P op_sel): a * b[H] (+ c).  The compiler forms
+// such operands by copying the scalar into a fresh register pair (two v_mov per use: 85 moves per (edge, pixel) in the
+// lineariser); the instruction can select the half itself.
+template <int H>
+__device__ __forceinline__ ls_f2 pk_fma_b(ls_f2 a, ls_f2 b, ls_f2 c) {
+  ls_f2 d;
+  if (H == 0)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+template <int H>
+__device__ __forceinline__ ls_f2 pk_mul_b(ls_f2 a, ls_f2 b) {
+  ls_f2 d;
+  if (H == 0)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+  else
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 struct LinSlotArgs {
   const float* target;      // [M,2,HW]
   const float* weight;      // [M,2,HW]
@@ -360,7 +384,7 @@ struct LinSlotArgs {
 };
 
 template <int PPL>
-__global__ __launch_bounds__(256, PPL == 1 ? 4 : 2) void ba_linearize_slot_kernel(LinSlotArgs a) {
+__global__ __launch_bounds__(256, PPL == 1 ? 3 : 2) void ba_linearize_slot_kernel(LinSlotArgs a) {
   // A workgroup owns 64 * PPL pixels of one depth slot; its four WAVES take the slot's edges in turn (edge q of a batch goes to
   // wave q % 4), every lane owning the same PPL pixels for all of them.  So the per-edge sums G, g are complete after one wave
   // reduction, four edges are in flight per workgroup (a tracking window's ~10 edges per slot: three serial edge bodies instead
@@ -380,8 +404,8 @@ __global__ __launch_bounds__(256, PPL == 1 ? 4 : 2) void ba_linearize_slot_kerne
   const float fx = a.intr[0], fy = a.intr[1], cx = a.intr[2], cy = a.intr[3];
   const float* __restrict__ disp = a.disps + (long)fid * HW;
 
-  unsigned px[PPL];   // (unsigned: a uniform plane pointer + a zero-extended 32-bit lane offset is ONE address register per access)
-  bool ok[PPL];
+  unsigned px[PPL], pxb[PPL];   // pixel and its BYTE offset (unsigned: a uniform plane pointer + a zero-extended 32-bit lane
+  bool ok[PPL];                 //  offset is ONE address register per access)
   float X0[PPL], X1[PPL], dsp[PPL];
   float C[PPL], b[PPL], Ei[PPL][6];
 #pragma unroll
@@ -389,6 +413,7 @@ __global__ __launch_bounds__(256, PPL == 1 ? 4 : 2) void ba_linearize_slot_kerne
     const int p = ch * NPX + i * 64 + lane;
     ok[i] = p < HW;
     px[i] = (unsigned)(ok[i] ? p : HW - 1);
+    pxb[i] = px[i] * 4u;
     const int row = (int)px[i] / a.wd, col = (int)px[i] - row * a.wd;
     X0[i] = ((float)col - cx) / fx;
     X1[i] = ((float)row - cy) / fy;
@@ -406,9 +431,9 @@ __global__ __launch_bounds__(256, PPL == 1 ? 4 : 2) void ba_linearize_slot_kerne
     // pixel that follow them).  No workgroup barrier inside the edge loop: a wave's constants live in its own LDS rows.
     float ntu[PPL], ntv[PPL], nwu[PPL], nwv[PPL], ntab[2];
     int ne;
-    auto request = [&](int q) __attribute__((always_inline)) {
-      ne = a.src_edge[s0 + q];
-      const long e = ne;
+    auto request = [&](int eid) __attribute__((always_inline)) {
+      ne = eid;
+      const long e = eid;
       const float* __restrict__ tu = a.target + (e * 2 + 0) * HW;
       const float* __restrict__ tv = a.target + (e * 2 + 1) * HW;
       const float* __restrict__ wu_ = a.weight + (e * 2 + 0) * HW;
@@ -418,18 +443,28 @@ __global__ __launch_bounds__(256, PPL == 1 ? 4 : 2) void ba_linearize_slot_kerne
       ntab[1] = tb[lane < ET_STRIDE - 64 ? 64 + lane : 0];
 #pragma unroll
       for (int i = 0; i < PPL; i++) {
-        ntu[i] = tu[px[i]];
-        ntv[i] = tv[px[i]];
-        nwu[i] = wu_[px[i]];
-        nwv[i] = wv_[px[i]];
+        ntu[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(tu) + pxb[i]);
+        ntv[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(tv) + pxb[i]);
+        nwu[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(wu_) + pxb[i]);
+        nwv[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(wv_) + pxb[i]);
       }
     };
-    if (wave < nb) request(wave);
+    // edge ids run TWO edges ahead of the arithmetic: the planes of edge q+4 are requested with an id that was loaded while edge
+    // q-4 was computed (an id loaded inside `request` put a dependent round trip -- id, then planes -- in front of every edge
+    // body: the waves sat parked 49 % of their cycles)
+    int id_next = wave < nb ? a.src_edge[s0 + wave] : 0;
+    int id_next2 = a.src_edge[s0 + min(wave + 4, nb > 0 ? nb - 1 : 0)];
+    if (wave < nb) request(id_next);
     int flip = 0;
     for (int q = wave; q < nb; q += 4, flip ^= 1) {
+      // this wave's LDS row: [0,8) t_ij, q_ij, stereo flag; then the 36 entries of the two maps INTERLEAVED, (A_i[m][c], A_j[m][c])
+      // at 8 + 2 (6 m + c): one packed multiply-add per entry forms both E rows
       float* __restrict__ Tw = T[wave][flip];
-      Tw[lane] = ntab[0];
-      if (lane < ET_STRIDE - 64) Tw[64 + lane] = ntab[1];
+      {
+        const int v0 = lane, v1 = 64 + lane;
+        Tw[v0 < 8 ? v0 : (v0 < ET_AJ ? 8 + 2 * (v0 - ET_AI) : 9 + 2 * (v0 - ET_AJ))] = ntab[0];
+        if (v1 < ET_STRIDE) Tw[9 + 2 * (v1 - ET_AJ)] = ntab[1];
+      }
       const int e = ne;
       float ltu[PPL], ltv[PPL], lwu[PPL], lwv[PPL];
 #pragma unroll
@@ -439,19 +474,25 @@ __global__ __launch_bounds__(256, PPL == 1 ? 4 : 2) void ba_linearize_slot_kerne
         lwu[i] = nwu[i];
         lwv[i] = nwv[i];
       }
-      request(q + 4 < nb ? q + 4 : q);  // (always issued: no branch between a load and its use; the last edge is read twice)
+      request(q + 4 < nb ? id_next2 : e);  // (always issued: no branch between a load and its use; the last edge is read twice)
+      id_next2 = a.src_edge[s0 + min(q + 8, nb - 1)];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS row is written (wave-private: no barrier)
       const float* __restrict__ Tq = Tw;
       const float tij[3] = {Tq[ET_T], Tq[ET_T + 1], Tq[ET_T + 2]};
       const float qij[4] = {Tq[ET_Q], Tq[ET_Q + 1], Tq[ET_Q + 2], Tq[ET_Q + 3]};
       const bool stereo = Tq[ET_STEREO] != 0.0f;
       float* __restrict__ oEj = a.E + ((long)a.P + e) * 6 * HW;
-      float G[21];
-      float g[6];
+      // The per-pixel arithmetic in PACKED f32 (v_pk_mul_f32 / v_pk_fma_f32: two lanes of a 64-bit register pair per instruction).
+      // SQ counters of the scalar form: 410 vector instructions per (edge, pixel), the SIMDs issuing 98 % of the time -- the
+      // kernel was instruction-bound at 2.7 TB/s.  Pairs run along the Jacobian index (J[2k], J[2k+1]); the 21 upper-triangle
+      // sums of G are kept as 12 aligned pairs (an odd row starts one entry early: three redundant lower-triangle entries
+      // cost no instruction), the two E rows as pairs (E_i[c], E_j[c]).
+      ls_f2 G2[12];
+      ls_f2 g2[3];
 #pragma unroll
-      for (int l = 0; l < 21; l++) G[l] = 0.0f;
+      for (int l = 0; l < 12; l++) G2[l] = ls_f2{0.0f, 0.0f};
 #pragma unroll
-      for (int l = 0; l < 6; l++) g[l] = 0.0f;
+      for (int l = 0; l < 3; l++) g2[l] = ls_f2{0.0f, 0.0f};
 #pragma unroll
       for (int i = 0; i < PPL; i++) {
         // keep the 72 entries of A_i/A_j in LDS (broadcast reads) instead of letting the compiler hoist
@@ -466,11 +507,19 @@ __global__ __launch_bounds__(256, PPL == 1 ? 4 : 2) void ba_linearize_slot_kerne
           se3::act_se3(tij, qij, Xi, Xj);
           const float x = Xj[0], y = Xj[1], h = Xj[3];
           const bool zok = !(Xj[2] < NS_MIN_DEPTH);
-          const float d = zok ? 1.0f / Xj[2] : 0.0f;
+          // 1 / Z: reciprocal + one Newton step (correctly rounded but for rare last-bit cases; the IEEE division sequence is ten
+          // instructions)
+          float rz = __builtin_amdgcn_rcpf(Xj[2]);
+          rz = fmaf(rz, fmaf(-Xj[2], rz, 1.0f), rz);
+          const float d = zok ? rz : 0.0f;
           const float d2 = d * d;
-          // `.001 * weight` is a double product in the reference (:344-345)
-          float wu = zok ? (float)(0.001 * (double)lwu[i]) : 0.0f;
-          float wv = zok ? (float)(0.001 * (double)lwv[i]) : 0.0f;
+          // `.001 * weight` is a double product in the reference (:344-345): float(0.001 w) from the two-term split of the double
+          // constant -- one multiply and one fused multiply-add instead of two conversions and a double multiply; the results
+          // agree except where the double product lies within 2^-48 of a rounding boundary
+          constexpr float C_HI = 0.001f;
+          constexpr float C_LO = (float)(0.001 - (double)C_HI);
+          float wu = zok ? fmaf(lwu[i], C_HI, lwu[i] * C_LO) : 0.0f;
+          float wv = zok ? fmaf(lwv[i], C_HI, lwv[i] * C_LO) : 0.0f;
           const float ru = ltu[i] - (fx * d * x + cx);
           const float rv = ltv[i] - (fy * d * y + cy);
           const float Jzu = fx * (tij[0] * d - tij[2] * (x * d2));
@@ -483,53 +532,77 @@ __global__ __launch_bounds__(256, PPL == 1 ? 4 : 2) void ba_linearize_slot_kerne
             wu = 0.0f;
             wv = 0.0f;
           }
-          // raw Jacobians wrt the target pose, [t,w] order (:369-374, 434-439)
-          const float Ju[6] = {fx * (h * d), 0.0f, fx * (-x * h * d2), fx * (-x * y * d2), fx * (1.0f + x * x * d2),
-                               fx * (-y * d)};
-          const float Jv[6] = {0.0f, fy * (h * d), fy * (-y * h * d2), fy * (-1.0f - y * y * d2), fy * (x * y * d2),
-                               fy * (x * d)};
-          float wJu[6], wJv[6], qq[6];
+          // raw Jacobians wrt the target pose, [t,w] order (:369-374, 434-439), as pairs (J[2k], J[2k+1])
+          const ls_f2 Ju2[3] = {ls_f2{fx * (h * d), 0.0f}, ls_f2{fx * (-x * h * d2), fx * (-x * y * d2)},
+                                ls_f2{fx * (1.0f + x * x * d2), fx * (-y * d)}};
+          const ls_f2 Jv2[3] = {ls_f2{0.0f, fy * (h * d)}, ls_f2{fy * (-y * h * d2), fy * (-1.0f - y * y * d2)},
+                                ls_f2{fy * (x * y * d2), fy * (x * d)}};
+          const ls_f2 w2 = ls_f2{wu, wv}, Jz2 = ls_f2{Jzu, Jzv}, r2 = ls_f2{ru, rv};
+          ls_f2 wJu2[3], wJv2[3], qq2[3];
 #pragma unroll
-          for (int m = 0; m < 6; m++) {
-            wJu[m] = wu * Ju[m];
-            wJv[m] = wv * Jv[m];
-            qq[m] = wJu[m] * Jzu + wJv[m] * Jzv;
-            g[m] += wJu[m] * ru + wJv[m] * rv;
+          for (int k2 = 0; k2 < 3; k2++) {
+            wJu2[k2] = pk_mul_b<0>(Ju2[k2], w2);
+            wJv2[k2] = pk_mul_b<1>(Jv2[k2], w2);
+            qq2[k2] = pk_fma_b<1>(wJv2[k2], Jz2, pk_mul_b<0>(wJu2[k2], Jz2));
+            g2[k2] = pk_fma_b<1>(wJv2[k2], r2, pk_fma_b<0>(wJu2[k2], r2, g2[k2]));
           }
-          int l = 0;
-#pragma unroll
-          for (int m = 0; m < 6; m++)
-#pragma unroll
-            for (int n = m; n < 6; n++) {
-              G[l] += wJu[m] * Ju[n] + wJv[m] * Jv[n];
-              l++;
-            }
-          // E rows: q A_i (summed over the slot's edges), q A_j (written)
-#pragma unroll
-          for (int c = 0; c < 6; c++) {
-            float ei = 0.0f, ej = 0.0f;
+          // G: row m, column pairs from the (even) pair that holds column m
+          {
+            int l = 0;
 #pragma unroll
             for (int m = 0; m < 6; m++) {
-              ei += qq[m] * Tq[ET_AI + m * 6 + c];
-              ej += qq[m] * Tq[ET_AJ + m * 6 + c];
+#pragma unroll
+              for (int k2 = m >> 1; k2 < 3; k2++) {
+                if (m & 1)
+                  G2[l] = pk_fma_b<1>(Jv2[k2], wJv2[m >> 1], pk_fma_b<1>(Ju2[k2], wJu2[m >> 1], G2[l]));
+                else
+                  G2[l] = pk_fma_b<0>(Jv2[k2], wJv2[m >> 1], pk_fma_b<0>(Ju2[k2], wJu2[m >> 1], G2[l]));
+                l++;
+              }
             }
-            Ei[i][c] += ei;
-            float* __restrict__ plane = oEj + (long)c * HW;  // (uniform)
-            plane[px[i]] = ej;
+          }
+          // E rows: q A_i (summed over the slot's edges), q A_j (written), one packed multiply-add per map entry
+          const ls_f2* __restrict__ A2 = reinterpret_cast<const ls_f2*>(Tq + 8);
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            ls_f2 e2 = ls_f2{0.0f, 0.0f};
+#pragma unroll
+            for (int m = 0; m < 6; m++) {
+              if (m & 1)
+                e2 = pk_fma_b<1>(A2[m * 6 + c], qq2[m >> 1], e2);
+              else
+                e2 = pk_fma_b<0>(A2[m * 6 + c], qq2[m >> 1], e2);
+            }
+            Ei[i][c] += e2[0];
+            // (uniform plane pointer + this lane's 32-bit BYTE offset: one address register, no 64-bit add per access)
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(oEj + (long)c * HW) + pxb[i]) = e2[1];
           }
         }
       }
       // the wave's sums of G, g ARE the (edge, chunk) sums (fixed DPP order), gathered into lanes 0..26 and stored once; the
       // assembly blocks of the Schur-reduce launch add the chunks in order
       float mine = 0.0f;
+      {
+        int l = 0, lp = 0;
 #pragma unroll
-      for (int l = 0; l < 21; l++) {
-        const float sum = wave_sum(G[l]);
-        mine = (lane == l) ? sum : mine;
+        for (int m = 0; m < 6; m++)
+#pragma unroll
+          for (int k2 = m >> 1; k2 < 3; k2++) {
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+              const int n = 2 * k2 + hh;
+              if (n >= m) {   // (compile time: the entry before an odd row's diagonal is the redundant one)
+                const float sum = wave_sum(G2[lp][hh]);
+                mine = (lane == l) ? sum : mine;
+                l++;
+              }
+            }
+            lp++;
+          }
       }
 #pragma unroll
       for (int l = 0; l < 6; l++) {
-        const float sum = wave_sum(g[l]);
+        const float sum = wave_sum(g2[l >> 1][l & 1]);
         mine = (lane == 21 + l) ? sum : mine;
       }
       if (lane < 27) a.partial[((long)e * a.nch + ch) * 32 + lane] = mine;
@@ -805,10 +878,18 @@ __device__ __forceinline__ void gram_reduce(const GramArgs& a, const int job, co
     live[u] = tile < (DIAG ? GR_NACC : 32) && tb < nb && (DIAG || ta < na);   // (uniform)
     sum[u] = 0.0;
   }
-  for (int s = 0; s < a.S; s++) {
+  // (eight splits' loads requested together, summed in split order: at C640 a job has 25 splits)
+  for (int s0 = 0; s0 < a.S; s0 += 8) {
+    float v[8][GR_RG];
 #pragma unroll
-    for (int u = 0; u < GR_RG; u++)
-      if (live[u]) sum[u] += (double)pj[(long)s * GR_PART + (group * GR_RG + u) * 256 + tid];
+    for (int ds = 0; ds < 8; ds++)
+#pragma unroll
+      for (int u = 0; u < GR_RG; u++)
+        v[ds][u] = (live[u] && s0 + ds < a.S) ? pj[(long)(s0 + ds) * GR_PART + (group * GR_RG + u) * 256 + tid] : 0.0f;
+#pragma unroll
+    for (int ds = 0; ds < 8; ds++)
+#pragma unroll
+      for (int u = 0; u < GR_RG; u++) sum[u] += (double)v[ds][u];
   }
 #pragma unroll
   for (int u = 0; u < GR_RG; u++) {
@@ -1194,6 +1275,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // pixels per lane of the fused lineariser (a workgroup = 64 x PPL pixels of a slot): as many as still leave ~2048 workgroups
 // (the per-edge wave reductions of G, g are paid once per (edge, chunk): 190 DPP adds against ~300 instructions per pixel)
 static int choose_ppl(int K, int HW) {
+  if (const char* e = ns_variant_env("NS_BA_PPL")) return e[0] == '4' ? 4 : e[0] == '2' ? 2 : 1;   // (variants build: A/B)
   if ((long)K * ns_cdiv(HW, 256) >= 2048) return 4;
   if ((long)K * ns_cdiv(HW, 128) >= 2048) return 2;
   return 1;

@@ -703,6 +703,10 @@ struct AdamFuse {
   float c1, c2, lr, beta1, beta2, eps, inv_grad_scale, inv_fixed_scale;
   const int* ctl;
   int es;   // floats from one table entry to the next in master / m1 / m2: 2 = three dense arrays, 8 = one 32-byte record per entry
+  // replicated trainers (master == nullptr): the flush APPENDS the touched entries, (entry, packed sum), to this list instead
+  // of updating or adding to a dense buffer -- what the trainers exchange (ns_ngp_encode_backward_fused_emit_n)
+  ulonglong2* emit_list;
+  int* emit_count;
 };
 
 // Layout of the optimiser state, told from the pointers (include/nerfslam_hip.h, ns_ngp_adam): m1 == master + 2 and m2 == master + 4
@@ -1755,12 +1759,70 @@ __global__ __launch_bounds__(NS_FB_THREADS) void ngp_enc_faccum_kernel(GridLayou
       const unsigned long long word = tab[e];
       if (word != 0ull) adam_entry(ad, base + e, word, c1, c2);
     }
+  } else if (ad.emit_list != nullptr) {
+    // compact the bin's touched entries into the trainer's list: per-lane counts -> workgroup prefix sums (the arrays of the tile
+    // loop are free again) -> ONE atomic per workgroup reserves the range -> (entry, sum) pairs.  The list's order depends on
+    // the workgroups' arrival; what is done with it (integer sums per entry) does not.
+    int mine = 0;
+    for (uint32_t e = tid; e < n_e; e += NS_FB_THREADS) mine += tab[e] != 0ull ? 1 : 0;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    __syncthreads();
+    if (lane == 63) swave[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NS_FB_THREADS / 64; w++) {
+      woff += (w < wave) ? swave[w] : 0;
+      total += swave[w];
+    }
+    if (tid == 0) s_novf = total > 0 ? atomicAdd(ad.emit_count, total) : 0;
+    __syncthreads();
+    int pos = s_novf + woff + incl - mine;
+    for (uint32_t e = tid; e < n_e; e += NS_FB_THREADS) {
+      const unsigned long long word = tab[e];
+      if (word != 0ull) ad.emit_list[pos++] = make_ulonglong2((unsigned long long)(base + e), word);
+    }
   } else {
     unsigned long long* __restrict__ g64 = reinterpret_cast<unsigned long long*>(grad) + base;
     for (uint32_t e = tid; e < n_e; e += NS_FB_THREADS) {
       const unsigned long long word = tab[e];
       if (word != 0ull) g64[e] += word;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Replicated trainers: the exchanged lists -> the table.  `lists` holds `n_lists` lists of `stride` (entry, packed sum) pairs each
+// (list r = what trainer r's flush emitted, counts[r] of them valid).
+//   accumulate: acc[entry] += sum, 64-bit integer atomics (exact and order-free: the same word whatever the lists' order)
+//   apply:      the first lane to exchange an entry's accumulator for 0 applies Adam with the complete sum (every other pair of
+//               the same entry finds 0 and does nothing): every trainer computes the same update from the same sums, no
+//               parameter has to travel back, and acc is zero again for the next step
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ngp_sparse_accumulate_kernel(const ulonglong2* __restrict__ lists, const int* __restrict__ counts,
+                                                                    long stride, unsigned long long* __restrict__ acc) {
+  const int r = blockIdx.y;
+  const int n = counts[r];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const ulonglong2 it = lists[(long)r * stride + i];
+    atomicAdd(acc + it.x, it.y);
+  }
+}
+
+__global__ __launch_bounds__(256) void ngp_sparse_apply_kernel(const ulonglong2* __restrict__ lists, const int* __restrict__ counts,
+                                                               long stride, unsigned long long* __restrict__ acc, AdamFuse ad) {
+  const int r = blockIdx.y;
+  const int n = counts[r];
+  const float c1 = ad.ctl ? __int_as_float(ad.ctl[NS_CTL_C1]) : ad.c1, c2 = ad.ctl ? __int_as_float(ad.ctl[NS_CTL_C2]) : ad.c2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long entry = (long)lists[(long)r * stride + i].x;
+    const unsigned long long word = atomicExch(acc + entry, 0ull);
+    if (word != 0ull) adam_entry(ad, entry, word, c1, c2);
   }
 }
 
@@ -2854,17 +2916,17 @@ extern "C" int ns_ngp_encode_backward_fused_dense_levels(int n_levels, int n_fea
   return fused_dense_levels(g, n_levels, fused_dense_mode());
 }
 
-extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int log2_hashmap, int base_res,
-                                              float per_level_scale, const float* positions, const void* dLdoutT,
-                                              float* grad_params, void* workspace, size_t workspace_bytes, float fixed_scale,
-                                              long N, const int* n_dev, float* master, void* half_params, float* m1,
-                                              float* m2, int step, float lr, float beta1, float beta2, float eps,
-                                              float grad_scale, const int* ctl, int parts, void* stream) {
+static int fused_backward_impl(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                               const float* positions, const void* dLdoutT, float* grad_params, void* workspace,
+                               size_t workspace_bytes, float fixed_scale, long N, const int* n_dev, float* master,
+                               void* half_params, float* m1, float* m2, int step, float lr, float beta1, float beta2, float eps,
+                               float grad_scale, const int* ctl, int parts, void* stream, ulonglong2* emit_list, int* emit_count) {
   NS_REQUIRE(positions && dLdoutT && workspace, "ns_ngp_encode_backward_fused: null pointer");
   NS_REQUIRE(parts >= 1 && parts <= 15, "ns_ngp_encode_backward_fused: parts is a mask of 1 | 2 | 4 | 8");
   NS_REQUIRE(fixed_scale > 0.0f, "ns_ngp_encode_backward_fused: packed fixed-point sums only (fixed_scale > 0)");
   const bool adam = master != nullptr;
-  NS_REQUIRE(adam || grad_params, "ns_ngp_encode_backward_fused: neither a gradient buffer nor Adam state");
+  NS_REQUIRE(adam || grad_params || emit_list, "ns_ngp_encode_backward_fused: neither a gradient buffer nor Adam state nor a list");
+  NS_REQUIRE(!emit_list || (emit_count && !adam && !(parts & 12)), "ns_ngp_encode_backward_fused: the list form is parts 1 | 2 without Adam");
   NS_REQUIRE(!adam || (half_params && m1 && m2 && grad_scale > 0.0f && (ctl || step >= 1)),
              "ns_ngp_encode_backward_fused: incomplete Adam state");
   GridCfg c{n_levels, n_features, log2_hashmap, base_res, per_level_scale};
@@ -2914,7 +2976,11 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
     ad.inv_fixed_scale = 1.0f / fixed_scale;
     ad.ctl = ctl;
   }
+  ad.emit_list = emit_list;
+  ad.emit_count = emit_count;
   NS_REQUIRE(dense_prefix_entries(g, n_levels) >= 0, "ns_ngp_encode_backward_fused: dense levels above hashed ones");
+  NS_REQUIRE(!emit_list || fused_dense_levels(g, n_levels, dense_too) == 0,
+             "ns_ngp_encode_backward_fused: the list form needs every level on the binned path");
   const int n_rl = fused_dense_levels(g, n_levels, dense_too);     // dense levels that keep the owner-computes path
   const long nd = (long)g.offset[n_rl];
   if (parts & 1) {
@@ -2990,6 +3056,64 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
   hipLaunchKernelGGL(ngp_enc_dense_reduce_kernel, dim3(ns_cdiv(nd, 256)), dim3(256), 0, st, g, plan, n_levels, partial, nd,
                      grad_params, ad, (int*)nullptr);
   NS_CHECK_LAUNCH("ngp_enc_dense_reduce_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                              float per_level_scale, const float* positions, const void* dLdoutT,
+                                              float* grad_params, void* workspace, size_t workspace_bytes, float fixed_scale,
+                                              long N, const int* n_dev, float* master, void* half_params, float* m1,
+                                              float* m2, int step, float lr, float beta1, float beta2, float eps,
+                                              float grad_scale, const int* ctl, int parts, void* stream) {
+  return fused_backward_impl(n_levels, n_features, log2_hashmap, base_res, per_level_scale, positions, dLdoutT, grad_params, workspace,
+                             workspace_bytes, fixed_scale, N, n_dev, master, half_params, m1, m2, step, lr, beta1, beta2, eps,
+                             grad_scale, ctl, parts, stream, nullptr, nullptr);
+}
+
+extern "C" int ns_ngp_encode_backward_fused_emit_n(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                                   float per_level_scale, const float* positions, const void* dLdoutT,
+                                                   void* workspace, size_t workspace_bytes, float fixed_scale, long N,
+                                                   const int* n_dev, void* list, int* list_count, int parts, void* stream) {
+  NS_REQUIRE(list && list_count, "ns_ngp_encode_backward_fused_emit: null list");
+  NS_REQUIRE(((uintptr_t)list & 15) == 0, "ns_ngp_encode_backward_fused_emit: the list holds 16-byte pairs");
+  return fused_backward_impl(n_levels, n_features, log2_hashmap, base_res, per_level_scale, positions, dLdoutT, nullptr, workspace,
+                             workspace_bytes, fixed_scale, N, n_dev, nullptr, nullptr, nullptr, nullptr, 1, 0.0f, 0.0f, 0.0f, 0.0f,
+                             1.0f, nullptr, parts, stream, reinterpret_cast<ulonglong2*>(list), list_count);
+}
+
+extern "C" int ns_ngp_sparse_table_update(const void* lists, const int* counts, int n_lists, long stride, long max_count, void* acc,
+                                          float* master, void* half_params, float* m1, float* m2, int step, float lr, float beta1,
+                                          float beta2, float eps, float grad_scale, float fixed_scale, const int* ctl,
+                                          void* stream) {
+  NS_REQUIRE(lists && counts && acc && master && half_params && m1 && m2, "ns_ngp_sparse_table_update: null pointer");
+  NS_REQUIRE(n_lists >= 1 && stride >= max_count && max_count >= 0, "ns_ngp_sparse_table_update: bad sizes");
+  NS_REQUIRE(grad_scale > 0.0f && fixed_scale > 0.0f && (ctl || step >= 1), "ns_ngp_sparse_table_update: incomplete Adam state");
+  if (max_count == 0) return NS_OK;
+  AdamFuse ad{};
+  ad.master = master;
+  ad.hp = (_Float16*)half_params;
+  ad.m1 = m1;
+  ad.m2 = m2;
+  ad.es = adam_entry_stride(master, m1, m2);
+  NS_REQUIRE(ad.es == 2 || ((uintptr_t)master & 15) == 0, "ns_ngp_sparse_table_update: interleaved optimiser records need a 16-byte aligned base");
+  ad.c1 = 1.0f - powf(beta1, (float)(step < 1 ? 1 : step));
+  ad.c2 = 1.0f - powf(beta2, (float)(step < 1 ? 1 : step));
+  ad.lr = lr;
+  ad.beta1 = beta1;
+  ad.beta2 = beta2;
+  ad.eps = eps;
+  ad.inv_grad_scale = 1.0f / grad_scale;
+  ad.inv_fixed_scale = 1.0f / fixed_scale;
+  ad.ctl = ctl;
+  hipStream_t st = (hipStream_t)stream;
+  const int bx = (int)((max_count + 1023) / 1024 < 4096 ? (max_count + 1023) / 1024 : 4096);   // four pairs per lane and sweep
+  const dim3 grid(bx < 1 ? 1 : bx, n_lists);
+  hipLaunchKernelGGL(ngp_sparse_accumulate_kernel, grid, dim3(256), 0, st, (const ulonglong2*)lists, counts, stride,
+                     (unsigned long long*)acc);
+  NS_CHECK_LAUNCH("ngp_sparse_accumulate_kernel");
+  hipLaunchKernelGGL(ngp_sparse_apply_kernel, grid, dim3(256), 0, st, (const ulonglong2*)lists, counts, stride,
+                     (unsigned long long*)acc, ad);
+  NS_CHECK_LAUNCH("ngp_sparse_apply_kernel");
   return NS_OK;
 }
 

@@ -133,24 +133,25 @@ class NgpNerf:
             lim = math.sqrt(6.0 / (o + i))
             w.append((torch.rand(o * i, generator=g) * 2 - 1) * lim)
         self.mlp_master = torch.cat(w).to(dev)
-        # Replicated trainers exchange the table gradient SHARDED (round 3): the table's entries are cut into `world` equal
-        # shards; after the backward pass every trainer sends shard r of its packed-integer gradient to trainer r (one
-        # all-to-all: xGMI is a full mesh, every pair has its own link), sums what it receives (exact: int64), runs Adam on ITS
-        # shard only and all-gathers the f16 working copy.  Per trainer and step: (R-1)/R x (8 + 4) B per entry on the wire and 1/R
-        # of the optimiser traffic, against 2 (R-1)/R x 8 B per entry of a ring all-reduce (which is bound by ONE link) and R
-        # identical optimiser passes.  The f32 master copy and the moments of the other shards are not kept current (nothing
-        # reads them: every kernel of the step reads the f16 copy).
+        # Replicated trainers exchange WHAT A STEP TOUCHED (round 6; rounds 3-5: the dense packed gradient, 100 MB per trainer and
+        # step through an all-to-all, then the 25-MB f16 table through an all-gather -- a one-rank replicated step cost 2.07 x the
+        # one-trainer step before a byte reached xGMI).  The table gradient's flush appends (entry, packed integer sum) pairs to
+        # `_emit_list` -- at most one per entry: ~0.9 M of the default grid's 12.6 M in a converged scene -- the lists' agreed-length
+        # prefixes are all-gathered (one link per pair of trainers on the xGMI mesh), and EVERY trainer adds the lists per entry
+        # (64-bit integer atomics: exact, order-free) and applies Adam to every touched entry (ns_ngp_sparse_table_update): the same
+        # sums, the same update, the same bits everywhere -- no parameter travels back.  `grid_grad`, viewed as one int64 word per
+        # entry, is the accumulator (zero between steps).
         n_entries = self.n_grid // 2
-        from .parallel import shard_size
-        self.shard_entries = shard_size(n_entries, self.world)
-        pad_params = 2 * self.shard_entries * self.world if self.world > 1 else self.n_grid
-        self.grid_half = torch.zeros(pad_params, dtype=torch.float16, device=dev)
-        self.grid_half[:self.n_grid] = self.grid_master.reshape(-1).half()
+        self.grid_half = self.grid_master.reshape(-1).half()
         self.mlp_half = self.mlp_master.half()
-        self.grid_grad, self.mlp_grad = torch.zeros(pad_params, **f), torch.zeros(MLP_TOTAL, **f)
-        if self.replicated:
-            self._recv = torch.zeros((self.world, self.shard_entries), dtype=torch.int64, device=dev)
-            self._gshard = torch.zeros(self.shard_entries, dtype=torch.int64, device=dev)
+        self.grid_grad, self.mlp_grad = torch.zeros(self.n_grid, **f), torch.zeros(MLP_TOTAL, **f)
+        self.sparse_exchange = self.replicated and c.grad_fixed_scale > 0
+        if self.sparse_exchange:
+            from .parallel import list_class
+            self._emit_list = torch.zeros((list_class(n_entries), 2), dtype=torch.int64, device=dev)   # (worst case: every entry touched)
+            self._emit_count = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._lists = None               # [world, class, 2] int64, grown on demand
+            self.wire_log = []               # pairs exchanged per step (bench.py: rccl_per_trainer)
         self.mlp_m1, self.mlp_m2 = torch.zeros(MLP_TOTAL, **f), torch.zeros(MLP_TOTAL, **f)
         G, nc = c.grid_size, c.n_cascades
         self.density_grid = torch.zeros(nc * G ** 3, **f)
@@ -472,8 +473,14 @@ class NgpNerf:
                                                   ctl, ptr(self.ray_g) if n_cam <= 4096 else None, n_cam, stream), "ngp_camera_gradient")
 
         def table_gradient(parts, stream):
-            # one trainer: Adam in the flushes (no gradient buffer); replicated trainers: the packed sums into the gradient buffer
+            # one trainer: Adam in the flushes (no gradient buffer); replicated trainers: the touched entries into the list
             fa = self.fused_adam
+            if self.sparse_exchange:
+                check(L.ns_ngp_encode_backward_fused_emit_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat), ptr(self.enc_ws),
+                                                            C.c_size_t(self.enc_ws_bytes), C.c_float(c.grad_fixed_scale), C.c_long(S),
+                                                            n_dev, ptr(self._emit_list), ptr(self._emit_count), parts, stream),
+                      "ngp_encode_backward_fused_emit")
+                return
             check(L.ns_ngp_encode_backward_fused_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat),
                                                    None if fa else ptr(self.grid_grad), ptr(self.enc_ws),
                                                    C.c_size_t(self.enc_ws_bytes), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev,
@@ -530,6 +537,8 @@ class NgpNerf:
         #  side branches, the scatter landed on the side stream's queue BEHIND the pose refinement, 0.49 ms)
         if self.fused_ws:
             mark(None)
+            if self.sparse_exchange:
+                self._emit_count.zero_()
             table_gradient(1, st)
             mark("ngp_enc_fscatter_direct_kernel")
             table_gradient(2, st)
@@ -564,23 +573,13 @@ class NgpNerf:
                 `_gshard`), the MLP's Adam.  Fixed arguments: captured as the second graph of the replicated step."""
                 if pose:   # after the all-reduce: every replica applies the SAME pose update (ADVICE r01)
                     camera_step(stream)
-                if c.grad_fixed_scale > 0:
-                    Ns = self.shard_entries
-                    lo = 2 * Ns * self.rank
-                    n = max(0, min(2 * Ns, self.n_grid - lo))
-                    if n > 0:       # (the state's views are indexed by ENTRY: two parameters each)
-                        e0, e1 = lo // 2, (lo + n) // 2
-                        adam(self.grid_master[e0:e1], self.grid_half[lo:lo + n], self._gshard.view(torch.float32)[:n],
-                             self.grid_m1[e0:e1], self.grid_m2[e0:e1], 0.0, c.grad_fixed_scale, stream)
-                else:
+                if not self.sparse_exchange:     # (f32 gradient: dense all-reduce, streaming Adam; the list form's update follows
+                    #                                     the exchange, outside the captured part: its length changes per step)
                     adam(self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale, stream)
                 mlp_adam(stream)
             if phase == "pre":          # (replicated step from two graphs: the caller runs the collectives between them)
                 return post
-            self._exchange_gradients()
-            post(st)
-            if c.grad_fixed_scale > 0:
-                self._gather_parameters()   # the f16 copies of all shards
+            self._exchange_gradients(x, lambda: post(st))
         elif not self.fused_adam:
             adam(self.grid_master, self.grid_half, self.grid_grad, self.grid_m1, self.grid_m2, 0.0, c.grad_fixed_scale, st)
 
@@ -712,10 +711,11 @@ class NgpNerf:
 
     def _replicated_step(self, x):
         """One step of a replicated trainer from TWO HIP graphs with the collectives between them:
-            graph A: forward, backward, packed table gradient into the gradient buffer, MLP / pose gradients (three streams)
-            eager  : all-to-all of the packed table gradient, all-reduce of the MLP and pose gradients (RCCL, this stream)
-            graph B: pose step, Adam on this trainer's shard, MLP Adam + fragment pack
-            eager  : all-gather of the f16 table
+            graph A: forward, backward, table gradient -> the list of touched entries, MLP / pose gradients (three streams)
+            eager  : all-gather of the lists' lengths (started; read below), all-reduce of the MLP and pose gradients
+            graph B: pose step, MLP Adam + fragment pack -- on the device while the host waits for the lengths (the step's one
+                     host synchronisation: an event behind the 4-byte all-gather)
+            eager  : all-gather of the lists, the per-entry sums + Adam on every touched entry (ns_ngp_sparse_table_update)
         The collectives are stream-ordered behind graph A and ahead of graph B (RCCL waits for the current stream); nothing
         synchronises with the host (under gloo the staging copies do).  Eager steps first, as in the one-trainer path."""
         key = self._step_key()
@@ -738,10 +738,7 @@ class NgpNerf:
             self._graphs[x] = (ga, gb)
         ga, gb = self._graphs[x]
         ga.replay()
-        self._exchange_gradients()
-        gb.replay()
-        if self.cfg.grad_fixed_scale > 0:
-            self._gather_parameters()
+        self._exchange_gradients(x, gb.replay)
 
     @property
     def loss_tensor(self):
@@ -761,28 +758,43 @@ class NgpNerf:
     def samples_requested_last(self):
         return int(self.last[0].item()) if getattr(self, "_static", False) else 0
 
-    def _exchange_gradients(self):
-        """replicated trainers: the table gradient summed over the replicas lands SHARDED (this trainer's shard in `_gshard`),
-        the small MLP / pose gradients are all-reduced; Adam then divides by loss_scale * world (mean gradient)"""
+    def _exchange_gradients(self, x, between=None):
+        """replicated trainers, after the gradients of a step: the lists of touched table entries are all-gathered and applied
+        (every trainer: the same integer sums, the same Adam update), the small MLP / pose gradients are all-reduced; Adam divides
+        by loss_scale * world (mean gradient).  `between()` enqueues what depends on the small all-reduces only (the pose step and
+        the MLP's optimiser: graph B): it runs on the device while the host waits for the lists' lengths -- the one host
+        synchronisation of the step, on an event behind a 4-byte-per-trainer all-gather -- and enqueues the list exchange."""
         import torch.distributed as dist
-        R, Ns = self.world, self.shard_entries
-        if self.cfg.grad_fixed_scale > 0:
-            from .parallel import exchange_sharded
-            # [R * Ns] packed words, shard r = entries [r Ns, (r+1) Ns): one all-to-all, exact integer sum in rank order
-            wire = exchange_sharded(self.grid_grad.view(torch.int64), self._recv, self._gshard, self.group)
-            self.grid_grad.zero_()                                       # (the streaming Adam pass that used to clear it is gone)
+        R = self.world
+        c = self.cfg
+        handle = None
+        if self.sparse_exchange:
+            from .parallel import gather_counts_begin, gather_counts_end, gather_lists, list_class
+            handle = gather_counts_begin(self._emit_count, self.group)
         else:
             dist.all_reduce(self.grid_grad, op=dist.ReduceOp.SUM, group=self.group)
-            wire = 2 * (R - 1) * self.grid_grad.numel() * 4 // R
         dist.all_reduce(self.mlp_grad, op=dist.ReduceOp.SUM, group=self.group)
         if self.cfg.optimize_extrinsics and getattr(self, "cam_grad", None) is not None:
             dist.all_reduce(self.cam_grad, op=dist.ReduceOp.SUM, group=self.group)   # 24 B per training view
-        self.bytes_allreduced = getattr(self, "bytes_allreduced", 0) + wire + self.mlp_grad.numel() * 4
-
-    def _gather_parameters(self):
-        """every trainer's freshly updated shard of the f16 table -> all trainers"""
-        from .parallel import gather_shards
-        self.bytes_allreduced = getattr(self, "bytes_allreduced", 0) + gather_shards(self.grid_half, self.rank, self.group)
+        if between is not None:
+            between()
+        if self.sparse_exchange:
+            counts_dev, counts = gather_counts_end(handle)
+            n_pairs = list_class(max(counts))
+            if self._lists is None or self._lists.numel() < R * n_pairs * 2:
+                self._lists = torch.zeros((R * n_pairs * 2,), dtype=torch.int64, device=self.device)
+            recv = self._lists[:R * n_pairs * 2].view(R, n_pairs, 2)
+            wire = gather_lists(self._emit_list, recv, n_pairs, self.group) + (R - 1) * 4
+            self.wire_log.append(n_pairs)
+            with torch.cuda.device(self.device):
+                check(lib().ns_ngp_sparse_table_update(ptr(recv), ptr(counts_dev), R, C.c_long(n_pairs), C.c_long(max(counts)),
+                                                       ptr(self.grid_grad), ptr(self.grid_master), ptr(self.grid_half), ptr(self.grid_m1),
+                                                       ptr(self.grid_m2), 0, C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2),
+                                                       C.c_float(c.eps), C.c_float(c.loss_scale * self.world), C.c_float(c.grad_fixed_scale),
+                                                       ptr(self.sets[x]["ctl"]), stream_ptr()), "ngp_sparse_table_update")
+        else:
+            wire = 2 * (R - 1) * self.grid_grad.numel() * 4 // R
+        self.bytes_allreduced = getattr(self, "bytes_allreduced", 0) + wire + (2 * (R - 1) * self.mlp_grad.numel() * 4) // R
 
     def _grow_camera_state(self, n):
         """per-view Adam moments of the pose refinement: GROWN when keyframes are added (a reset would restart the bias

@@ -2,8 +2,8 @@
 
 Every collective the --multi_gpu split issues (examples/slam_demo.py:63-77; the CPU bounce of
 slam/visual_frontends/visual_frontend.py:1355-1360 is what they replace) is driven through RCCL here exactly as the
-N-GPU run drives it -- same call sites (nerfslam.parallel / nerfslam.transport / NgpNerf), same dtypes (int64 all-to-all of
-the packed table gradient, f16 all-gather of the table, f32 all-reduces, uint8 broadcast) -- in a group of one, which is what
+N-GPU run drives it -- same call sites (nerfslam.parallel / nerfslam.transport / NgpNerf), same dtypes (int32 / int64 all-gathers of
+the touched-entry lists, f32 all-reduces, uint8 broadcast) -- in a group of one, which is what
 a one-GPU box can execute.  A one-rank collective moves no bytes over xGMI; what this pins is that the RCCL entry points accept
 these tensors, are stream-ordered with the HIP-graph replays around them, and leave the right values.
 
@@ -36,26 +36,26 @@ def main():
     from nerfslam import parallel, transport
     assert parallel._device_collectives(None)
 
-    # ---- nerfslam.parallel: the replicated trainers' table exchange ----
+    # ---- nerfslam.parallel: the replicated trainers' exchange of touched-entry lists ----
     g = torch.Generator(device="cpu").manual_seed(1)
-    Ns = 1 << 20
-    send = torch.randint(-2 ** 40, 2 ** 40, (Ns,), generator=g, dtype=torch.int64).to(dev)
-    recv = torch.zeros((1, Ns), dtype=torch.int64, device=dev)
-    out = torch.zeros(Ns, dtype=torch.int64, device=dev)
-    wire = parallel.exchange_sharded(send, recv, out, None)
-    ok["exchange_sharded_int64_all_to_all"] = bool(torch.equal(out, send)) and wire == 0
-    full = torch.randn(1 << 20, generator=g).half().to(dev)
-    ref = full.clone()
-    parallel.gather_shards(full, 0, None)
-    ok["gather_shards_f16_all_gather"] = bool(torch.equal(full, ref))
+    n_items = 900_000
+    mine = torch.zeros((1 << 20, 2), dtype=torch.int64)
+    mine[:n_items, 0] = torch.randperm(12_582_912 // 2, generator=g)[:n_items]
+    mine[:n_items, 1] = torch.randint(-2 ** 40, 2 ** 40, (n_items,), generator=g, dtype=torch.int64)
+    mine = mine.to(dev)
+    counts_dev, counts = parallel.gather_counts(torch.tensor([n_items], dtype=torch.int32, device=dev), None)
+    n_pairs = parallel.list_class(max(counts))
+    lists = torch.zeros((1, n_pairs, 2), dtype=torch.int64, device=dev)
+    wire = parallel.gather_lists(mine, lists, n_pairs, None)
+    ok["gather_lists_int64_all_gather"] = counts == [n_items] and bool(torch.equal(lists[0], mine[:n_pairs])) and wire == 0
     H, v = torch.randn((60, 60), generator=g).to(dev), torch.randn(60, generator=g).to(dev)
     H0, v0 = H.clone(), v.clone()
     parallel.allreduce_reduced_system(H, v, None)
     ok["allreduce_reduced_system"] = bool(torch.equal(H, H0) and torch.equal(v, v0))
 
-    # ---- the same two collectives TIMED at the sizes of the default grid: one trainer's packed gradient is
-    #      12.6 M int64 words = 100 MB through the all-to-all, the f16 table 25 MB through the all-gather.  With one rank nothing
-    #      crosses xGMI -- the figures are the RCCL call's device-side floor (a copy) that the first N-GPU run is compared with.
+    # ---- the same collective TIMED at a converged step's size on the default grid (0.9 M touched entries of 12.6 M: 14.7 MB of
+    #      pairs; rounds 3-5 moved the 100.7-MB dense packed gradient + the 25-MB f16 table).  With one rank nothing crosses xGMI --
+    #      the figure is the RCCL call's device-side floor that the first N-GPU run is compared with.
     def timed(fn, n=10):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -64,21 +64,15 @@ def main():
             fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
-    Nw = 12_582_912                                                      # 2 x 6.29 M table entries, one 64-bit word per pair
-    big_send = torch.randint(-2 ** 40, 2 ** 40, (Nw,), generator=g, dtype=torch.int64).to(dev)
-    big_recv = torch.zeros((1, Nw), dtype=torch.int64, device=dev)
-    big_out = torch.zeros(Nw, dtype=torch.int64, device=dev)
-    ms_a2a = timed(lambda: parallel.exchange_sharded(big_send, big_recv, big_out, None))
-    table = torch.randn(Nw, generator=g).half().to(dev)
-    ms_ag = timed(lambda: parallel.gather_shards(table, 0, None))
-    ok["timed_exchange_values"] = bool(torch.equal(big_out, big_send))
+    ms_ag = timed(lambda: parallel.gather_lists(mine, lists, n_pairs, None))
+    ms_cnt = timed(lambda: parallel.gather_counts(counts_dev[:1], None))
     res["timed_self_exchange"] = {
-        "int64_all_to_all": {"bytes": Nw * 8, "ms": ms_a2a, "GBps": Nw * 8 / ms_a2a * 1e-6},
-        "f16_all_gather": {"bytes": Nw * 2, "ms": ms_ag, "GBps": Nw * 2 / ms_ag * 1e-6},
-        "note": "one rank: device-side cost of the RCCL entry points + the shard sum / clone around them, no bytes on xGMI; at R "
-                "trainers each moves bytes x (R-1)/R per step over R-1 links at once",
+        "pair_list_all_gather": {"pairs": n_pairs, "bytes": n_pairs * 16, "ms": ms_ag, "GBps": n_pairs * 16 / ms_ag * 1e-6},
+        "count_all_gather_with_host_read": {"ms": ms_cnt},
+        "note": "one rank: device-side cost of the RCCL entry points, no bytes on xGMI; at R trainers each puts pairs x 16 B on each "
+                "of its R-1 links per step",
     }
-    del big_send, big_recv, big_out, table
+    del mine, lists
 
     # ---- nerfslam.transport: the SLAM -> mapper packet ----
     from test_transport import _make_packet
@@ -143,11 +137,16 @@ def main():
     same = lambda x, y: bool(torch.equal(x.grid_half[:x.n_grid], y.grid_half[:y.n_grid]) and torch.equal(x.mlp_master, y.mlp_master)
                              and torch.equal(x.c2w, y.c2w))
     ok["replicated_graphs_equal_eager_bitwise"] = same(repl, repl_e) and bool((l2 == l3).all())
-    # ... and the replicated trainer (gradient buffer, all-to-all of the whole table with itself, streaming Adam on the "shard",
-    # reduce + Adam + fragment pack for the MLP) IS the one-trainer step (Adam in the flushes, one-launch MLP optimiser): same
-    # parameters, same poses, the same loss on every one of the 120 steps
-    ok["replicated_equals_one_trainer_bitwise"] = same(repl, single) and bool((l1 == l2).all())
+    # ... and the replicated trainer (touched-entry list, all-gather with itself, per-entry integer sums + Adam on the touched
+    # entries, reduce + Adam + fragment pack for the MLP) IS the one-trainer step (Adam in the flushes, one-launch MLP
+    # optimiser): same parameters -- f16 working copy AND f32 masters / moments of every entry --, same poses, the same loss on
+    # every one of the 120 steps
+    ok["replicated_equals_one_trainer_bitwise"] = same(repl, single) and bool((l1 == l2).all()) and \
+        bool(torch.equal(repl.grid_state, single.grid_state)) and int(repl.grid_grad.view(torch.int64).abs().max()) == 0
     res["bytes_exchanged"] = int(getattr(repl, "bytes_allreduced", 0))
+    wl = np.array(repl.wire_log[-64:])
+    res["list_exchange"] = {"pairs_per_step_mean_last64": float(wl.mean()), "bytes_per_link_and_step": float(wl.mean() * 16),
+                            "touched_entries_last_step": int(repl._emit_count.item()), "table_entries": int(repl.n_grid // 2)}
     dist.barrier()
     dist.destroy_process_group()
     res["ok"] = all(ok.values())

@@ -140,39 +140,43 @@ def test_sharded_iteration_touches_only_owned_depth_maps(dev):
     assert np.array_equal(np.union1d(owned[0], owned[1]), kx)
 
 
-# ---- replicated NeRF trainers: sharded gradient exchange (nerfslam.parallel.exchange_sharded / gather_shards) ----
+# ---- replicated NeRF trainers: exchange of the touched-entry lists (nerfslam.parallel.gather_counts / gather_lists) ----
 def _exchange_worker(rank, world, port, n_entries, q):
-    from nerfslam.parallel import exchange_sharded, gather_shards, shard_size
+    from nerfslam.parallel import LIST_CLASS, gather_counts, gather_lists, list_class
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        Ns = shard_size(n_entries, world)
         g = torch.Generator().manual_seed(100 + rank)
-        # packed words as the trainers hold them: two signed 32-bit fixed-point fields per entry, zero beyond the table
-        lo = torch.randint(-2 ** 20, 2 ** 20, (n_entries,), generator=g, dtype=torch.int64)
-        hi = torch.randint(-2 ** 20, 2 ** 20, (n_entries,), generator=g, dtype=torch.int64)
-        send = torch.zeros(world * Ns, dtype=torch.int64)
-        send[:n_entries] = lo + (hi << 32)
-        recv, shard = torch.zeros((world, Ns), dtype=torch.int64), torch.zeros(Ns, dtype=torch.int64)
-        wire = exchange_sharded(send, recv, shard)
-        ref = send.clone()
-        dist.all_reduce(ref)                                      # what a dense all-reduce would have given everybody
-        ok = torch.equal(shard, ref[rank * Ns:(rank + 1) * Ns]) and wire == (world - 1) * Ns * 8
-        # every trainer "updates" its shard of the f16 table, then the shards are gathered
-        full = torch.zeros(world * 2 * Ns, dtype=torch.float16)
-        full[rank * 2 * Ns:(rank + 1) * 2 * Ns] = float(rank + 1)
-        gather_shards(full, rank)
-        want = torch.cat([torch.full((2 * Ns,), float(r + 1), dtype=torch.float16) for r in range(world)])
-        q.put((rank, bool(ok), bool(torch.equal(full, want))))
+        # (entry, packed word) pairs as a trainer's flush emits them: distinct entries, two signed 32-bit fixed-point fields per word
+        n_mine = 700 + 300 * rank
+        entries = torch.randperm(n_entries, generator=g)[:n_mine]
+        lo = torch.randint(-2 ** 20, 2 ** 20, (n_mine,), generator=g, dtype=torch.int64)
+        hi = torch.randint(-2 ** 20, 2 ** 20, (n_mine,), generator=g, dtype=torch.int64)
+        mine = torch.zeros((list_class(n_entries), 2), dtype=torch.int64)   # capacity: every entry, in whole exchange units
+        mine[:n_mine, 0], mine[:n_mine, 1] = entries, lo + (hi << 32)
+        counts_dev, counts = gather_counts(torch.tensor([n_mine], dtype=torch.int32))
+        n_pairs = list_class(max(counts))
+        recv = torch.zeros((world, n_pairs, 2), dtype=torch.int64)
+        wire = gather_lists(mine, recv, n_pairs)
+        # what every trainer then does with the lists (ns_ngp_sparse_table_update on the device): integer sums per entry
+        acc = torch.zeros(n_entries, dtype=torch.int64)
+        for r in range(world):
+            acc.index_add_(0, recv[r, :counts[r], 0], recv[r, :counts[r], 1])
+        dense = torch.zeros(n_entries, dtype=torch.int64)                # what a dense all-reduce of packed words would have given
+        dense[entries] = lo + (hi << 32)
+        dist.all_reduce(dense)
+        ok = counts == [700 + 300 * r for r in range(world)] and counts_dev.tolist() == counts and n_pairs == LIST_CLASS and \
+            wire == (world - 1) * n_pairs * 16 and torch.equal(acc, dense)
+        q.put((rank, bool(ok), bool(torch.equal(recv[rank, :n_mine], mine[:n_mine]))))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_gradient_exchange_equals_allreduce(world):
-    """the all-to-all of packed int64 gradient shards + the sum in rank order gives every trainer exactly its slice of the dense
-    all-reduce; the all-gather returns every trainer's updated parameter shard to all of them (table size not a multiple of
-    world x 1024: the last shard is padded)"""
+def test_touched_entry_list_exchange_equals_allreduce(world):
+    """the all-gather of the trainers' (entry, packed sum) lists -- agreed length, a multiple of 65536 pairs -- followed by integer
+    sums per entry gives every trainer exactly the dense all-reduce of the packed gradient; wire bytes per trainer are
+    (world - 1) x length x 16 B"""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
