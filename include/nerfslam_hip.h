@@ -258,6 +258,16 @@ int ns_reduced_camera_matrix(const float* poses, const float* disps, const float
                              int wd, float* H, float* v, float* Q, float* E, float* w, void* workspace,
                              int ws_zeroed, void* stream);
 
+/* ns_reduced_camera_matrix `reps` times with HIP events between its five launches (edge table, fused lineariser, Gram kernel,
+ * reduce / assembly, finalisation): us_out[5] = their mean durations in microseconds.  Synchronises the stream.  (bench.py's
+ * BA roofline entries.)                                                                                              */
+int ns_reduced_camera_matrix_timed(const float* poses, const float* disps, const float* intrinsics,
+                                   const float* extrinsics, const float* disps_sens, const float* targets,
+                                   const float* weights, const float* eta, const int64_t* ii, const int64_t* jj,
+                                   const ns_ba_plan* plan, const int32_t* index, const size_t* offsets_host, int ht, int wd,
+                                   float* H, float* v, float* Q, float* E, float* w, void* workspace, int ws_zeroed, void* stream,
+                                   int reps, float* us_out);
+
 /* solve_depth (src/droid.cpp:198-218 -> droid_kernels.cu:1772-1825): EvT6x1 (:1213-1238),
  * accum, dz = Q*(w - .), disp_retr (:1050-1063); disps updated in place, then optionally
  * clamped to >= clamp_min (visual_frontend.py:1162; pass a negative value to skip).           */

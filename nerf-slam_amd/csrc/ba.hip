@@ -1282,12 +1282,12 @@ static int choose_ppl(int K, int HW) {
 }
 // pixel splits of a Gram job: ~2048 workgroups (one per CU at a time: 512 registers per lane; 8 rounds of the chip lose 4 % to the
 // last, partly filled one, 4.4 lost 12 %), each an integral number of the kernel's three-round trips where that is possible
-// (C640: 75 rounds of 64 pixels -> 25 splits of exactly one trip; config #5: 225 rounds -> 7 splits of 32 / 33 rounds)
+// (C640: 75 rounds of 64 pixels -> 9 splits of 8 / 9 rounds; config #5: 225 rounds -> 7 splits of 32 / 33 rounds)
 static int choose_splits(int n_jobs, int HW) {
   const int NR = ns_cdiv(HW, 64);
   int S = ns_cdiv(2048, n_jobs > 0 ? n_jobs : 1);
-  const int cap = NR / 3 > 1 ? NR / 3 : 1;
-  if (S > cap) S = cap;
+  const int cap = NR / 6 > 1 ? NR / 6 : 1;   // at least two trips per split: at C640 25 one-trip splits made the Gram kernel 3 us
+  if (S > cap) S = cap;                       // faster and the reduce launch, which reads every split's partial, 15 us slower
   if (S < 1) S = 1;
   const int rounds = ns_cdiv(ns_cdiv(NR, S), 3) * 3;   // rounds per split, a multiple of three
   S = ns_cdiv(NR, rounds);
@@ -1394,12 +1394,11 @@ extern "C" int ns_projective_transform(const float* targets, const float* weight
   return NS_OK;
 }
 
-extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, const float* intrinsics,
-                                        const float* extrinsics, const float* disps_sens, const float* targets,
-                                        const float* weights, const float* eta, const int64_t* ii, const int64_t* jj,
-                                        const ns_ba_plan* plan, const int32_t* index, const size_t* off, int ht,
-                                        int wd, float* H, float* v, float* Q, float* E, float* w, void* workspace,
-                                        int ws_zeroed, void* stream) {
+// `ev`: nullptr, or six events recorded around the five launches of the product path (ns_reduced_camera_matrix_timed)
+static int rcm_impl(const float* poses, const float* disps, const float* intrinsics, const float* extrinsics,
+                    const float* disps_sens, const float* targets, const float* weights, const float* eta, const int64_t* ii,
+                    const int64_t* jj, const ns_ba_plan* plan, const int32_t* index, const size_t* off, int ht, int wd, float* H,
+                    float* v, float* Q, float* E, float* w, void* workspace, int ws_zeroed, void* stream, hipEvent_t* ev) {
   NS_REQUIRE(plan && index && off, "ns_reduced_camera_matrix: null plan");
   NS_REQUIRE(poses && disps && intrinsics && extrinsics && disps_sens && eta, "ns_reduced_camera_matrix: null input");
   NS_REQUIRE(H && v && Q && E && w && workspace, "ns_reduced_camera_matrix: null output/workspace");
@@ -1498,10 +1497,12 @@ extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, 
   const int ppl = choose_ppl(K, HW);
   const int nch = ns_cdiv(HW, 64 * ppl);
   float* table = (float*)(ws + L.table);
+  if (ev) (void)hipEventRecord(ev[0], st);
   if (M > 0) {
     hipLaunchKernelGGL(ba_edge_table_kernel, dim3(ns_cdiv((long)M * 8, 256)), dim3(256), 0, st, poses, extrinsics, ii, jj, M, table);
     NS_CHECK_LAUNCH("ba_edge_table_kernel");
   }
+  if (ev) (void)hipEventRecord(ev[1], st);
   if (K > 0) {
     LinSlotArgs a;
     a.target = targets;
@@ -1535,6 +1536,7 @@ extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, 
       hipLaunchKernelGGL(ba_linearize_slot_kernel<1>, grid, dim3(256), 0, st, a);
     NS_CHECK_LAUNCH("ba_linearize_slot_kernel");
   }
+  if (ev) (void)hipEventRecord(ev[2], st);
   if (plan->n_jobs + M > 0) {
     GramArgs g;
     g.E = E;
@@ -1562,14 +1564,65 @@ extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, 
       hipLaunchKernelGGL(ba_schur_gram_kernel, dim3(plan->n_jobs * g.S), dim3(256), 0, st, g);
       NS_CHECK_LAUNCH("ba_schur_gram_kernel");
     }
+    if (ev) (void)hipEventRecord(ev[3], st);
     hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(plan->n_jobs * GR_NRG + M), dim3(256), 0, st, g);
     NS_CHECK_LAUNCH("ba_schur_reduce_kernel");
   }
+  if (ev) (void)hipEventRecord(ev[4], st);
   if (n6 > 0) {
     hipLaunchKernelGGL(ba_finalize_kernel, dim3(ns_cdiv((long)n6 * n6, 256)), dim3(256), 0, st, Hd, vd, n6, H, v, 1);
     NS_CHECK_LAUNCH("ba_finalize_kernel");
   }
+  if (ev) (void)hipEventRecord(ev[5], st);
   return NS_OK;
+}
+
+extern "C" int ns_reduced_camera_matrix(const float* poses, const float* disps, const float* intrinsics,
+                                        const float* extrinsics, const float* disps_sens, const float* targets,
+                                        const float* weights, const float* eta, const int64_t* ii, const int64_t* jj,
+                                        const ns_ba_plan* plan, const int32_t* index, const size_t* off, int ht,
+                                        int wd, float* H, float* v, float* Q, float* E, float* w, void* workspace,
+                                        int ws_zeroed, void* stream) {
+  return rcm_impl(poses, disps, intrinsics, extrinsics, disps_sens, targets, weights, eta, ii, jj, plan, index, off, ht, wd, H, v,
+                  Q, E, w, workspace, ws_zeroed, stream, nullptr);
+}
+
+// The same call `reps` times with HIP events between its five launches: us_out[0..4] = mean microseconds of the edge table, the
+// fused lineariser, the Gram kernel, the reduce / assembly launch, the finalisation (bench.py: the BA roofline entries are
+// timed on the stream the kernels run on, live, not taken from a profile).  Synchronises the stream.
+extern "C" int ns_reduced_camera_matrix_timed(const float* poses, const float* disps, const float* intrinsics,
+                                              const float* extrinsics, const float* disps_sens, const float* targets,
+                                              const float* weights, const float* eta, const int64_t* ii, const int64_t* jj,
+                                              const ns_ba_plan* plan, const int32_t* index, const size_t* off, int ht, int wd,
+                                              float* H, float* v, float* Q, float* E, float* w, void* workspace, int ws_zeroed,
+                                              void* stream, int reps, float* us_out) {
+  NS_REQUIRE(reps >= 1 && us_out, "ns_reduced_camera_matrix_timed: bad arguments");
+  hipEvent_t ev[6];
+  for (int i = 0; i < 6; i++)
+    if (hipEventCreate(&ev[i]) != hipSuccess) {
+      ns_set_error("ns_reduced_camera_matrix_timed: hipEventCreate failed");
+      return NS_ELAUNCH;
+    }
+  double acc[5] = {0, 0, 0, 0, 0};
+  int rc = NS_OK;
+  for (int r = 0; r < reps && rc == NS_OK; r++) {
+    rc = rcm_impl(poses, disps, intrinsics, extrinsics, disps_sens, targets, weights, eta, ii, jj, plan, index, off, ht, wd, H, v, Q,
+                  E, w, workspace, r == 0 ? ws_zeroed : 1, stream, ev);
+    if (rc != NS_OK) break;
+    if (hipEventSynchronize(ev[5]) != hipSuccess) {
+      ns_set_error("ns_reduced_camera_matrix_timed: hipEventSynchronize failed");
+      rc = NS_ELAUNCH;
+      break;
+    }
+    for (int i = 0; i < 5; i++) {
+      float ms = 0.0f;
+      (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+      acc[i] += (double)ms * 1e3;
+    }
+  }
+  for (int i = 0; i < 6; i++) (void)hipEventDestroy(ev[i]);
+  for (int i = 0; i < 5; i++) us_out[i] = (float)(acc[i] / reps);
+  return rc;
 }
 
 extern "C" int ns_solve_depth(const float* dx, float* disps, const float* Q, const float* E, const float* w,

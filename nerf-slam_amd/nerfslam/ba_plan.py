@@ -93,6 +93,27 @@ def reduced_camera_matrix(plan, poses, disps, intrinsics, extrinsics, disps_sens
     return H, v, Q, E, w
 
 
+def reduced_camera_matrix_timed(plan, poses, disps, intrinsics, extrinsics, disps_sens, targets, weights, eta, ii, jj, reps=10):
+    """-> ((H, v, Q, E, w), {kernel: mean microseconds}) -- the same call with HIP events between its five launches"""
+    dev = poses.device
+    _, ht, wd = disps.shape
+    HW = ht * wd
+    P, M, K = plan.P, plan.M, plan.K
+    H = torch.empty((6 * P, 6 * P), dtype=torch.float32, device=dev)
+    v = torch.empty((6 * P, 1), dtype=torch.float32, device=dev)
+    Q = torch.empty((K, HW), dtype=torch.float32, device=dev)
+    w = torch.empty((K, HW), dtype=torch.float32, device=dev)
+    E = torch.empty((P + M, 6, HW), dtype=torch.float32, device=dev)
+    us = (C.c_float * 5)()
+    with torch.cuda.device(dev):
+        check(lib().ns_reduced_camera_matrix_timed(ptr(poses), ptr(disps), ptr(intrinsics), ptr(extrinsics), ptr(disps_sens),
+                                                   ptr(targets), ptr(weights), ptr(eta), ptr(ii), ptr(jj), C.byref(plan.c),
+                                                   ptr(plan.index), plan.offsets, ht, wd, ptr(H), ptr(v), ptr(Q), ptr(E), ptr(w),
+                                                   plan.workspace(HW), 1, stream_ptr(), int(reps), us), "reduced_camera_matrix_timed")
+    names = ("ba_edge_table_kernel", "ba_linearize_slot_kernel", "ba_schur_gram_kernel", "ba_schur_reduce_kernel", "ba_finalize_kernel")
+    return (H, v, Q, E, w), {n: float(us[i]) for i, n in enumerate(names)}
+
+
 def solve_depth(plan, dx, disps, Q, E, w, clamp_min=-1.0):
     _, ht, wd = disps.shape
     with torch.cuda.device(disps.device):

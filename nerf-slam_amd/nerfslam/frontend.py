@@ -81,6 +81,7 @@ class TrackingFrontend:
         self.compute_covariances = compute_covariances
         self._plan, self._plan_key = None, None
         self.n_updates = 0
+        self.n_update_edges = 0        # active edges summed over the updates (bench.py: mean edges per update)
         self.beta = 0.3
         self.keyframe_thresh, self.frontend_thresh = 4.0, 16.0
         self.frontend_window, self.frontend_radius, self.frontend_nms, self.max_age = 25, 2, 1, 25
@@ -243,6 +244,7 @@ class TrackingFrontend:
         self.graph.age += 1
         self.viz_idx[c["kf0"]:self.kf_idx + 1] = True
         self.n_updates += 1
+        self.n_update_edges += int(self.target.shape[0])
         return out
 
     def ba(self, target, weight, ii_h, jj_h, kf0, kf1=None, itrs=2, lm=0.0, ep=0.0, compute_covariances=None):

@@ -287,6 +287,8 @@ class TrackingSLAM:
                             fe.upsample(kxv, res[3])
                 with self._leg("dense BA (2 iterations)"):
                     tg, wg = target.permute(0, 3, 1, 2).contiguous(), weight.permute(0, 3, 1, 2).contiguous()
+                    if getattr(self, "keep_backend_ba_inputs", False):     # (bench.py: the BA roofline entries re-run this linearisation)
+                        self.last_backend_ba = (tg, wg, ii_h, jj_h)
                     if sba is None:
                         fe.ba(tg, wg, ii_h, jj_h, kf0=0, itrs=2, compute_covariances=False)   # :523-526 (its lm / ep arguments are
                     else:                                                                      #  dead: ba() never reads them)

@@ -144,6 +144,24 @@ def main():
     ok["replicated_equals_one_trainer_bitwise"] = same(repl, single) and bool((l1 == l2).all()) and \
         bool(torch.equal(repl.grid_state, single.grid_state)) and int(repl.grid_grad.view(torch.int64).abs().max()) == 0
     res["bytes_exchanged"] = int(getattr(repl, "bytes_allreduced", 0))
+    # what ONE more trainer's list costs every trainer: the per-entry sums + Adam of the last step's list on scratch state
+    # (bench.py's `predicted` block: step(R) = this step + (R - 1) further lists + the wire)
+    import ctypes as C
+    from nerfslam._lib import check, lib, ptr, stream_ptr
+    n_ent, cnt = repl.n_grid // 2, int(repl._emit_count.item())
+    n_pairs_l = int(repl.wire_log[-1])
+    scr_state, scr_m, scr_m1, scr_m2 = NgpNerf.new_grid_state(n_ent, dev)
+    scr_hp, scr_acc = torch.zeros(repl.n_grid, dtype=torch.float16, device=dev), torch.zeros(n_ent, dtype=torch.int64, device=dev)
+    lists_l = repl._lists[:n_pairs_l * 2].view(1, n_pairs_l, 2)
+    cdev = torch.tensor([cnt], dtype=torch.int32, device=dev)
+    cf = repl.cfg
+
+    def one_list():
+        check(lib().ns_ngp_sparse_table_update(ptr(lists_l), ptr(cdev), 1, C.c_long(n_pairs_l), C.c_long(cnt), ptr(scr_acc), ptr(scr_m),
+                                               ptr(scr_hp), ptr(scr_m1), ptr(scr_m2), 1, C.c_float(cf.lr), C.c_float(cf.beta1),
+                                               C.c_float(cf.beta2), C.c_float(cf.eps), C.c_float(cf.loss_scale), C.c_float(cf.grad_fixed_scale),
+                                               None, stream_ptr()), "ngp_sparse_table_update")
+    res["sparse_table_update_ms_per_list"] = timed(one_list)
     wl = np.array(repl.wire_log[-64:])
     res["list_exchange"] = {"pairs_per_step_mean_last64": float(wl.mean()), "bytes_per_link_and_step": float(wl.mean() * 16),
                             "touched_entries_last_step": int(repl._emit_count.item()), "table_entries": int(repl.n_grid // 2)}

@@ -98,3 +98,11 @@ def test_bench_c1280_sharded_global_ba_on_one_device():
     assert abs(c1["poses"] - c2["poses"]) <= 1e-4 * abs(c1["poses"]) and abs(c1["inverse_depths"] - c2["inverse_depths"]) <= 1e-4 * abs(c1["inverse_depths"])
     e = two["config"]["keyframe_centre_rmse_before_after"]
     assert e[1] < e[0]
+    # round 6: the line names the pass's dominant kernel (the gate convolution) and carries live-timed roofline entries of the
+    # dense BA's kernels with SURVEY 8(d)'s bytes
+    r = one["roofline"]
+    assert r["kernel"].startswith("conv_nhwc_kernel<3x3,448->256>") and r["bound"] == "mfma" and 0 < r["frac"] < 1
+    ba = {k: v for k, v in r["other"].items() if k.startswith("ba_")}
+    assert {k.split("[")[0] for k in ba} == {"ba_linearize_slot_kernel", "ba_schur_gram_kernel", "ba_solve_depth_kernel"}
+    assert all(v["bound"] == "hbm" and v["avg_launch_us"] > 0 and 0 < v["frac"] < 1 for v in ba.values())
+    assert any(k.startswith("altcorr_tile_enc_lds_kernel") for k in r["other"]) and one["dense_ba"]["us_per_linearisation"] > 0
