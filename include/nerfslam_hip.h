@@ -527,8 +527,9 @@ int ns_ngp_march_ctl(const uint8_t* bits, int G, int ncasc, const float* rays_o,
                      const int* ctl, void* stream);
 /* The same with the sample ranges handed out in WORKGROUP ORDER (16 rays per workgroup) instead of arrival order: the batch's
  * sample arrays -- and, at a full budget, the set of refused rays -- are then the same on every run, which makes the optimiser
- * step bit-reproducible (tests/test_ngp_gpu.py::test_training_is_bit_reproducible).  order_ws: 1 + ceil(R / 16) 64-bit words,
- * zero before the first launch (the kernel leaves them zero); one per set of sample arrays that may be marched concurrently.
+ * step bit-reproducible (tests/test_ngp_gpu.py::test_training_is_bit_reproducible).  order_ws: 2 + ceil(R / 16) 64-bit words
+ * (a workgroup's ray block is a ticket it draws on entry -- word 1 -- so the look-back never waits for a workgroup that has not
+ * started), zero before the first launch (the kernel leaves them zero); one per set of sample arrays that may be marched concurrently.
  * NULL = ns_ngp_march_ctl.                                                                                                  */
 int ns_ngp_march_ordered(const uint8_t* bits, int G, int ncasc, const float* rays_o, const float* rays_d, const float* t_range,
                          int R, float cone, float min_step, float max_step, float pos_lo, float pos_inv, int max_per_ray,

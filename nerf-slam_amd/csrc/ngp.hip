@@ -2308,9 +2308,28 @@ __device__ __forceinline__ int row_inclusive_sum(int v, int sub) {  // over the 
 
 __global__ __launch_bounds__(256) void ngp_march_kernel(MarchArgs a) {
   const int sub = threadIdx.x & 15;
-  const int r = blockIdx.x * 16 + (threadIdx.x >> 4);
+  // Ordered mode: the ray block of a workgroup is the TICKET it draws on entry, not blockIdx.x.  The look-back below
+  // waits for the words of all LOWER blocks; with tickets those belong to workgroups that are already running, whatever order the
+  // dispatcher starts workgroups in and whatever else occupies the CUs (a graph's other branches): deadlock-free by construction.
+  // Block b still marches rays [16 b, 16 b + 16) and gets the range after blocks 0 .. b-1: the batch is the same on every run.
+  __shared__ int s_block;
+  if (a.order != nullptr) {
+    if (threadIdx.x == 0) s_block = (int)atomicAdd(&a.order[1], 1ull);
+    __syncthreads();
+  }
+  const int vb = a.order != nullptr ? s_block : (int)blockIdx.x;
+  const int r = vb * 16 + (threadIdx.x >> 4);
   const int R = a.ctl ? min(a.ctl[NS_CTL_RAYS], a.R) : a.R;
-  if ((int)blockIdx.x * 16 >= R) return;  // workgroup-uniform: the grid is sized for the capacity
+  if (vb * 16 >= R) {  // workgroup-uniform: the grid is sized for the capacity
+    // (an idle workgroup still counts out: the last of ALL workgroups of the launch clears the words and the two counters)
+    if (a.order != nullptr && threadIdx.x == 0 && atomicAdd(&a.order[0], 1ull) == (unsigned long long)(gridDim.x - 1)) {
+      const int nwg = (R + 15) >> 4;
+      for (int j = 0; j < nwg; j++) a.order[2 + j] = 0ull;
+      a.order[0] = 0ull;
+      a.order[1] = 0ull;
+    }
+    return;
+  }
   const bool live = r < R;            // row-uniform; dead rows run with an empty interval
   const int rr = live ? r : R - 1;
   MarchRay ry{a.rays_o[rr * 3], a.rays_o[rr * 3 + 1], a.rays_o[rr * 3 + 2],
@@ -2348,7 +2367,7 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(MarchArgs a) {
   // budget, a different set of rays is refused -- so nothing downstream (f32 weight-gradient sums over sample tiles) repeats
   // bit for bit.  Here workgroup b's base is the sum of the counts of workgroups 0 .. b-1: every workgroup publishes its count
   // (flag in bit 63), the first wave reads its predecessors' words 64 at a time, spinning on the ones not yet there (a workgroup
-  // only ever waits for LOWER ids, which were dispatched before it and wait for nobody above them); the last workgroup through
+  // only ever waits for LOWER tickets, whose holders are running and wait for nobody above them); the last workgroup through
   // clears the words.  The counts are ready at about the same time, so the look-back is a couple of L2 round trips.
   __shared__ int s_prefix;
   if (a.order != nullptr) {
@@ -2359,28 +2378,32 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(MarchArgs a) {
 #pragma unroll
       for (int k = 0; k < 16; k++) tot += row_n[k];
       if (lane == 0)
-        __hip_atomic_store(&a.order[1 + blockIdx.x], (1ull << 63) | (unsigned long long)(unsigned)tot, __ATOMIC_RELEASE,
+        __hip_atomic_store(&a.order[2 + vb], (1ull << 63) | (unsigned long long)(unsigned)tot, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_AGENT);
       int sum = 0;
-      for (int j0 = 0; j0 < (int)blockIdx.x; j0 += 64) {
+      for (int j0 = 0; j0 < vb; j0 += 64) {
         const int j = j0 + lane;
         unsigned long long v = 1ull << 63;
-        if (j < (int)blockIdx.x) {
+        if (j < vb) {
           do {
-            v = __hip_atomic_load(&a.order[1 + j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_load(&a.order[2 + j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
           } while (!(v >> 63));
         }
         sum += (int)(v & 0x7fffffffull);
       }
       sum = wave_sum_i(sum);
       if (lane == 0) s_prefix = sum;
-      // every predecessor's word has been read: count this workgroup out; the last one out zeroes the words for the next launch
+      // every predecessor's word has been read: count this workgroup out; the last one out of the whole launch zeroes the words
+      // and the counters for the next launch
       unsigned long long out = 0;
       if (lane == 0) out = atomicAdd(&a.order[0], 1ull);
       out = __shfl(out, 0, 64);
-      if (out == (unsigned long long)(nwg - 1)) {
-        for (int j = lane; j < nwg; j += 64) a.order[1 + j] = 0ull;
-        if (lane == 0) a.order[0] = 0ull;
+      if (out == (unsigned long long)(gridDim.x - 1)) {
+        for (int j = lane; j < nwg; j += 64) a.order[2 + j] = 0ull;
+        if (lane == 0) {
+          a.order[0] = 0ull;
+          a.order[1] = 0ull;
+        }
       }
     }
     __syncthreads();

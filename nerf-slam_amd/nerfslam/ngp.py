@@ -58,7 +58,12 @@ class NgpConfig:
     optimize_extrinsics: bool = False    # nerf_fusion.py:99 sets it; refine c2w of the training views
     extrinsic_lr_pos: float = 1e-4       # scene units per step (Adam)
     extrinsic_lr_rot: float = 1e-4       # radians per step (Adam)
-    grad_fixed_scale: float = 262144.0   # hash-grid gradients accumulate as packed Q18 fixed point (0: f32 atomics)
+    # hash-grid gradients accumulate as packed fixed point, 2^-22 of the 128x loss-scaled gradient per unit (0: f32 atomics).
+    # Rounds 2-5 used 2^18: a corner contribution below 1.5e-8 of the real gradient was dropped -- ~90 % of them in a converged
+    # scene -- which cost 1.3-2.2 dB of PSNR and 0.25-0.7 mm of depth against the f32 gradient (tools/q_scale_sweep.py, three
+    # seeds: profiles/r06_ab_records.json); at 2^22 the step costs the same 0.27 ms and trains within the seeds' spread of f32.
+    # A single contribution saturates at |g| >= 2^24 / scale = 4 (scaled), an entry's sum at 2^31 / scale = 512.
+    grad_fixed_scale: float = 4194304.0
     use_graph: bool = True               # replay the training step from a HIP graph (False: same launch sequence, eager)
 
     @property
@@ -298,7 +303,7 @@ class NgpNerf:
                      s_pos=torch.full((S, 3), 0.5, **f), s_dir=torch.zeros((S, 3), **f), s_dt=torch.zeros(S, **f),
                      s_t=torch.zeros(S, **f), s_dout=torch.zeros((S, 4), **h), counter=torch.zeros(3, **i32),
                      loss=torch.zeros(Rc, **f),       # per ray (summed when the loss is read)
-                     order=torch.zeros(Rc // 16 + 2, dtype=torch.int64, device=dev),     # the marcher's ordered-range words
+                     order=torch.zeros(Rc // 16 + 4, dtype=torch.int64, device=dev),     # the marcher's ordered-range words (+ out / ticket counters)
                      ctl=torch.tensor([self.step, min(self.rays_per_batch, Rc), self.seed & 0x7FFFFFFF, max(self.n_images, 1),
                                        fbits(1.0 - c.beta1 ** (self.step + 1)), fbits(1.0 - c.beta2 ** (self.step + 1)), 0, 0], **i32))
             self.sets.append(t)
