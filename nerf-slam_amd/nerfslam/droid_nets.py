@@ -216,6 +216,29 @@ class DroidNetworks:
             self.corr_encoder = self.update_op.corr_enc
             self.ctx_cl, self.inp_cl = {}, {}
 
+    # ---- the ONE place that writes per-keyframe context features / per-edge hidden states from outside an update:
+    #      the stacked tensors of the last update are a cache of exactly these, so every such write drops them
+    def _invalidate_stacked(self):
+        self._kf_epoch += 1
+        self._stacked = None
+
+    def set_context(self, k, ctx_chw, inp_chw):
+        """context features of keyframe k: tanh / relu halves, [128, ht, wd]"""
+        self._invalidate_stacked()
+        self.ctx[k], self.inp[k] = ctx_chw, inp_chw
+        if self.hip_update:
+            self.ctx_cl[k] = ctx_chw.permute(1, 2, 0).contiguous().half()
+            self.inp_cl[k] = inp_chw.permute(1, 2, 0).contiguous().half()
+
+    def set_hidden(self, i, j, h):
+        """ConvGRU hidden state of edge (i, j) -- channels-last [ht, wd, 128] f16 on the HIP operator, [128, ht, wd] otherwise;
+        None forgets it (the next update starts the edge from its source frame's context features)"""
+        self._invalidate_stacked()
+        if h is None:
+            self.hidden.pop((i, j), None)
+        else:
+            self.hidden[(i, j)] = h
+
     def _normalize(self, img_u8):
         x = img_u8.to(self.device).float()[:3] / 255.0
         m = torch.tensor(self.MEAN, device=self.device)[:, None, None]
@@ -240,7 +263,7 @@ class DroidNetworks:
     @torch.no_grad()
     def begin_keyframe(self, k, img_u8):
         """hook of TrackingSLAM._store: context features of the frame that just became keyframe k"""
-        self._kf_epoch += 1
+        self._invalidate_stacked()
         if self.cnet_hip is not None:
             img = self._pending
             if img is None:
@@ -261,8 +284,7 @@ class DroidNetworks:
 
     def remove_keyframe(self, k):
         """hook of TrackingSLAM.rm_keyframe: keyframe k+1 slides onto k, edges touching k disappear"""
-        self._kf_epoch += 1
-        self._stacked = None
+        self._invalidate_stacked()
         for d in (self.ctx, self.inp) + ((self.ctx_cl, self.inp_cl) if self.hip_update else ()):
             if k + 1 in d:
                 d[k] = d.pop(k + 1)
@@ -293,7 +315,9 @@ class DroidNetworks:
             # copies of 59 MB at E = 48, and six updates per keyframe see the same list.)
             key = (tuple(ih), tuple(jh), self._kf_epoch)
             cache = self._stacked
-            if cache is not None and cache[0] == key:
+            # (a list that names an edge twice is never served from the stack: the re-stack path gives BOTH copies the state the
+            #  later one wrote, and the two paths must not differ)
+            if cache is not None and cache[0] == key and len(set(zip(ih, jh))) == len(ih):
                 net, inp = cache[1], cache[2]
             else:
                 net = torch.stack([self.hidden.get((i, j), self.ctx_cl[i]) for i, j in zip(ih, jh)])
@@ -305,6 +329,7 @@ class DroidNetworks:
             net, delta, weight, eta, upmask = self.update_op(net, inp, c, motion.reshape(-1, 4, *motion.shape[-2:]).float(), ih)
             for e, (i, j) in enumerate(zip(ih, jh)):
                 self.hidden[(i, j)] = net[e]
+            # (`net` is this call's OUTPUT and the next call's input: the operator never writes its inputs in place)
             self._stacked = (key, net, inp)
             live = set(zip(ih, jh))
             if len(self.hidden) > 4 * max(len(live), 64):

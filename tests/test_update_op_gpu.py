@@ -130,3 +130,37 @@ def test_hidden_state_cache_across_changing_edge_lists(dev):
         for x, y, tol in zip(ra, rb, (5e-2, 3e-2, 5e-2, 5e-2)):
             assert x.shape == y.shape and _rel(x, y) < tol, (it, x.shape, _rel(x, y))
     assert hits == 2                              # L1 -> L1 before and after the removal; every other call re-stacks
+
+
+def test_hidden_state_written_between_updates_is_not_served_from_the_stack(dev):
+    """the stacked hidden / context tensors of an unchanged edge list are a cache; a state written between two
+    updates (DroidNetworks.set_hidden / set_context -- the one place such writes go through) must reach the next update, and a
+    list that names an edge twice must behave like the re-stack path.  Reference: the same sequence with the cache dropped before
+    every call (what rounds 1-4 did), bit for bit."""
+    from nerfslam.droid_nets import DroidNetworks
+    ht, wd = 24, 32
+    a = DroidNetworks(dev, seed=7, hip_update=True)
+    b = DroidNetworks(dev, seed=7, hip_update=True)
+    g = torch.Generator().manual_seed(3)
+    for k in range(3):
+        img = torch.randint(0, 255, (3, 8 * ht, 8 * wd), generator=g, dtype=torch.uint8)
+        for n in (a, b):
+            n.features(img); n.begin_keyframe(k, img)
+    lists = [([0, 1, 1, 2], [1, 0, 2, 1]), ([0, 1, 1, 2], [1, 0, 2, 1]), ([0, 1, 1, 2], [1, 0, 2, 1]), ([0, 1, 0, 2], [1, 0, 1, 1]),
+             ([0, 1, 0, 2], [1, 0, 1, 1])]
+    for it, (il, jl) in enumerate(lists):
+        ii, jj = torch.tensor(il, device=dev), torch.tensor(jl, device=dev)
+        corr = torch.randn((1, len(il), 196, ht, wd), generator=g).half().to(dev)
+        motion = torch.randn((len(il), 4, ht, wd), generator=g).to(dev)
+        if it == 1:                              # a hidden state replaced from outside between two updates of the SAME list
+            h = torch.tanh(torch.randn((ht, wd, 128), generator=g)).half().to(dev)
+            a.set_hidden(1, 2, h); b.set_hidden(1, 2, h.clone())
+        if it == 2:                              # ... and a keyframe's context features
+            c = torch.tanh(torch.randn((128, ht, wd), generator=g)).to(dev)
+            r = torch.relu(torch.randn((128, ht, wd), generator=g)).to(dev)
+            a.set_context(1, c, r); b.set_context(1, c.clone(), r.clone())
+        b._stacked = None                        # the reference arm re-stacks on every call
+        ra, rb = a.update(corr, motion, ii, jj), b.update(corr, motion, ii, jj)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), it
+        assert all(torch.equal(a.hidden[e], b.hidden[e]) for e in a.hidden)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # counters of the c1280-scale BA kernels: separate rocprofv3 passes (kernel trace; FETCH_SIZE; WRITE_SIZE + L2; SQ split; MFMA / clock)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-o=gpurun_out/r06pmc${1:-}; mkdir -p $o; N=8
+o=gpurun_out/r06pmc${1:-}; mkdir -p $o; N=8   # $1: suffix of the output directory, $2: "c640" for the tracking-window size
 timeout 300 python tools/ba_c1280_bench.py $N $2 > $o/bench.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace -f csv -d $o/trace -o t -- python tools/ba_c1280_bench.py $N $2 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $o/fetch -o f -- python tools/ba_c1280_bench.py $N $2 > /dev/null 2>&1
