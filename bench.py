@@ -965,16 +965,26 @@ def main():
                          "carries them in `env_overrides`)" % ", ".join(ENV_OVERRIDES))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the HIP path")
-    if os.environ.get("NS_BENCH_GRAD_Q"):      # A/B of the table gradient's fixed-point resolution (tools/q_scale_sweep.py's pipeline arm)
+    if os.environ.get("NS_BENCH_GRAD_Q") or os.environ.get("NS_BENCH_NGP_CFG"):
+        # A/B hooks of the trainer's configuration (the line lists them in `env_overrides`): NS_BENCH_GRAD_Q=q -> fixed-point scale
+        # 2^q of the table gradient; NS_BENCH_NGP_CFG="field=value,..." -> any NgpConfig field (ints / floats / 0-1 booleans)
         from nerfslam import ngp as _ngp
-        _q, _init0 = float(2 ** int(os.environ["NS_BENCH_GRAD_Q"])), _ngp.NgpNerf.__init__
+        _over, _init0 = {}, _ngp.NgpNerf.__init__
+        if os.environ.get("NS_BENCH_GRAD_Q"):
+            _over["grad_fixed_scale"] = float(2 ** int(os.environ["NS_BENCH_GRAD_Q"]))
+            ENV_OVERRIDES.append("NS_BENCH_GRAD_Q=" + os.environ["NS_BENCH_GRAD_Q"])
+        for kv in filter(None, os.environ.get("NS_BENCH_NGP_CFG", "").split(",")):
+            k_, v_ = kv.split("=")
+            cur = getattr(_ngp.NgpConfig(), k_)
+            _over[k_] = bool(int(v_)) if isinstance(cur, bool) else type(cur)(v_)
+            ENV_OVERRIDES.append("NS_BENCH_NGP_CFG:" + kv)
 
         def _init(self, cfg=None, *a, **k):
             cfg = cfg or _ngp.NgpConfig()
-            cfg.grad_fixed_scale = _q
+            for k_, v_ in _over.items():
+                setattr(cfg, k_, v_)
             _init0(self, cfg, *a, **k)
         _ngp.NgpNerf.__init__ = _init
-        ENV_OVERRIDES.append("NS_BENCH_GRAD_Q=" + os.environ["NS_BENCH_GRAD_Q"])
     # NS_BENCH_DIST_BACKEND=gloo + NS_BENCH_ONE_DEVICE=1: run the N > 1 topology on a 1-GPU box (all ranks on device 0,
     # collectives over gloo) -- tests/test_multigpu_bench_gpu.py; the driver's runs use one GPU per rank over RCCL.
     backend = os.environ.get("NS_BENCH_DIST_BACKEND", "nccl")

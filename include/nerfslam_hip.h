@@ -709,6 +709,10 @@ int ns_ngp_mlp_wgrad_n(const void* featT, const void* h1T, const void* cinT, con
  *                       partial_ws: 256 doubles.  Order-independent (integer atomicMax on the float bits, fixed-order mean).  */
 int ns_ngp_grid_cells(int grid_size, int n_cascades, unsigned seed, int n, float box_lo, float box_hi, int* cells, float* pos_unit,
                       void* stream);
+/* the same with the seed completed on the device from the step's control block (seed ^ pcg(steps completed + 1)): a refresh captured
+ * into the optimiser step's HIP graph draws new cells on every replay                                                      */
+int ns_ngp_grid_cells_ctl(int grid_size, int n_cascades, unsigned seed, int n, float box_lo, float box_hi, int* cells,
+                          float* pos_unit, const int* ctl, void* stream);
 int ns_ngp_grid_update(const void* net_out, const int* cells, int n, float min_step, float decay, float max_threshold,
                        float* density_grid, long n_cells_total, double* partial_ws, unsigned char* bits, void* stream);
 /* The same refresh with the decay applied ONLY to the cells drawn in this update (grid[c] = max(decay grid[c], new maximum of c);

@@ -3446,10 +3446,15 @@ extern "C" int ns_ngp_step_advance(int* ctl, int* counter, int* last, float fill
 //   ngp_grid_sum / ngp_grid_bits   mean of the grid (two-stage, fixed order), occupied = grid > min(mean, threshold),
 //                      8 cells per output byte (bit i of byte j = cell 8 j + i, the marcher's layout).
 // ---------------------------------------------------------------------------------------------
+// ctl != nullptr: the draw's seed comes from the step's control block -- seed ^ pcg(optimiser steps completed + 1) -- so that a
+// refresh CAPTURED into the step graph (nerfslam/ngp.py: the refresh rides on the step before an update, round 6) draws new
+// cells on every replay
 __global__ __launch_bounds__(256) void ngp_grid_cells_kernel(int G, int ncasc, uint32_t seed, int n, float box_lo, float inv_box,
-                                                             int* __restrict__ cells, float* __restrict__ pos_unit) {
+                                                             int* __restrict__ cells, float* __restrict__ pos_unit,
+                                                             const int* __restrict__ ctl) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  if (ctl != nullptr) seed ^= ns_pcg((uint32_t)ctl[NS_CTL_STEP] + 1u);
   const uint32_t G3 = (uint32_t)G * G * G, total = G3 * (uint32_t)ncasc;
   const uint32_t base = seed + 4u * (uint32_t)i;
   const uint32_t cell = ns_pcg(base) % total;
@@ -3550,7 +3555,19 @@ extern "C" int ns_ngp_grid_cells(int grid_size, int n_cascades, unsigned seed, i
              "ns_ngp_grid_cells: bad grid / box");
   if (n == 0) return NS_OK;
   hipLaunchKernelGGL(ngp_grid_cells_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, grid_size, n_cascades,
-                     (uint32_t)seed, n, box_lo, 1.0f / (box_hi - box_lo), cells, pos_unit);
+                     (uint32_t)seed, n, box_lo, 1.0f / (box_hi - box_lo), cells, pos_unit, (const int*)nullptr);
+  NS_CHECK_LAUNCH("ngp_grid_cells_kernel");
+  return NS_OK;
+}
+
+extern "C" int ns_ngp_grid_cells_ctl(int grid_size, int n_cascades, unsigned seed, int n, float box_lo, float box_hi, int* cells,
+                                     float* pos_unit, const int* ctl, void* stream) {
+  NS_REQUIRE(cells && pos_unit && ctl, "ns_ngp_grid_cells_ctl: null pointer");
+  NS_REQUIRE(grid_size > 0 && grid_size <= 512 && n_cascades >= 1 && n_cascades <= 8 && box_hi > box_lo && n >= 0,
+             "ns_ngp_grid_cells_ctl: bad grid / box");
+  if (n == 0) return NS_OK;
+  hipLaunchKernelGGL(ngp_grid_cells_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, grid_size, n_cascades,
+                     (uint32_t)seed, n, box_lo, 1.0f / (box_hi - box_lo), cells, pos_unit, ctl);
   NS_CHECK_LAUNCH("ngp_grid_cells_kernel");
   return NS_OK;
 }

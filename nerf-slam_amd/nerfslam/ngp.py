@@ -47,6 +47,10 @@ class NgpConfig:
     loss_scale: float = 128.0
     depth_lambda: float = 1.0            # nerf_fusion.py:100
     grid_update_every: int = 16
+    # round 6: the occupancy refresh rides on the LAST step before an update, on the ray stream ahead of the next step's rays, from
+    # parameters one step older than the eager refresh saw -- instead of ~150 us of refresh + ~110 us of re-marching between two
+    # graph replays once per 16 steps (5 % of the mapping leg).  False: refresh eagerly after the step, re-march the next rays.
+    refresh_in_step: bool = True
     grid_rule: str = "subset"            # occupancy refresh: "subset" (2^18 uniform cells per update) | "ngp" (instant-ngp's rule)
     grid_decay: float = 0.95
     grid_decay_all: bool = True          # subset rule: EVERY cell decays on every update, as in instant-ngp's rule (max(prev * decay,
@@ -313,6 +317,8 @@ class NgpNerf:
         self.ray_g = torch.zeros((Rc, 6), **f)
         self.last = torch.zeros(4, **i32)
         self._graphs, self._graph_key, self._pair, self._chains = [None, None], None, None, {}
+        self._graphs_r, self._pair_r, self._refresh_seen = [None, None], None, False     # the variants that carry the occupancy refresh
+        self._grid_scratch()
         self._side = torch.cuda.Stream(device=dev)       # next step's ray marching, then weight / pose gradients
         self._side2 = torch.cuda.Stream(device=dev)      # dense levels of the table gradient
         self._primed = False
@@ -361,7 +367,7 @@ class NgpNerf:
         """the fragment table the NEXT optimiser step reads (complete and current: written by the last step's optimiser)"""
         return self.mlp_frags2[self.cur]
 
-    def _enqueue_step(self, x, phase="all"):
+    def _enqueue_step(self, x, phase="all", refresh=False):
         """one optimiser step on set `x` on the current stream (+ two side streams); no host synchronisation, no allocation.
         phase="pre" (replicated trainers): everything up to the gradient exchange; returns the closure that enqueues what follows it.
 
@@ -404,6 +410,15 @@ class NgpNerf:
             check(L.ns_ngp_step_prepare(ptr(X["ctl"]), ptr(Y["ctl"]), ptr(X["counter"]), ptr(Y["counter"]), ptr(self.last),
                                         C.c_float(0.9), C.c_long(S), 256, Rc, C.c_float(c.beta1), C.c_float(c.beta2), None,
                                         stream_ptr()), "ngp_step_prepare")
+            ev_params_read = None
+            if refresh:
+                # the occupancy refresh of the update that follows this step, AHEAD of the next step's rays (they are marched on
+                # the refreshed bits: nothing to march again) and beside this step's forward / backward passes; it reads the table
+                # and the MLP as the previous step left them -- this step's optimiser kernels wait for `ev_params_read`
+                mark(None)
+                ev_params_read = torch.cuda.Event()
+                self._enqueue_grid_refresh(stream_ptr(), ctl=ptr(X["ctl"]), after_params_read=ev_params_read.record)
+                mark("occupancy refresh (in step)")
             mark(None)
             self._enqueue_rays(Y)
             mark("ngp_sample_rays + ngp_march (next step's rays)")
@@ -522,6 +537,8 @@ class NgpNerf:
                   "ngp_mlp_wgrad_partials")
             mark("ngp_mlp_wgrad_tr_kernel")
             slabs = int(L.ns_ngp_mlp_wgrad_slabs(self.mlp_wgs, C.c_long(S)))
+            if ev_params_read is not None:
+                self._side.wait_event(ev_params_read)    # (the MLP's optimiser rewrites the weights the refresh evaluates)
             if single:
                 # the MLP's optimiser step in one launch: slab reduce + Adam + f16 copy + both fragment tables (the zero rows
                 # of the tables were written once by the pack above); bit-identical to reduce + ns_ngp_adam_ctl + pack
@@ -546,6 +563,8 @@ class NgpNerf:
                 self._emit_count.zero_()
             table_gradient(1, st)
             mark("ngp_enc_fscatter_direct_kernel")
+            if ev_params_read is not None:
+                main.wait_event(ev_params_read)          # (the flush rewrites the table the refresh encodes from)
             table_gradient(2, st)
             mark("ngp_enc_faccum_kernel")
         else:       # (no workspace / f32-atomic configuration of the tests: grad_fixed_scale = 0)
@@ -597,11 +616,14 @@ class NgpNerf:
         chain = 2      # steps per chained graph (even).  4 / 8 / 16 measured: 0.438 -> 0.434 / 0.427 / 0.433 ms, inside the
                        # box-to-box spread: a pair it is
         while i < n:
-            if n - i >= 2 and self._pair_ready():
-                left = c.grid_update_every - self.step % c.grid_update_every      # steps until the next occupancy update
+            left = c.grid_update_every - self.step % c.grid_update_every          # steps until the next occupancy update
+            first_ride = left <= 2 and c.refresh_in_step and c.grid_rule == "subset" and not getattr(self, "_refresh_seen", False)
+            if n - i >= 2 and self._pair_ready() and not first_ride:      # (the first refresh-carrying step runs singly, eagerly)
                 m = min(chain, n - i, left) // 2 * 2
+                # the pair that ends on an update carries the refresh in its second step (cfg.refresh_in_step)
+                rides = m == 2 and left == 2 and c.refresh_in_step and c.grid_rule == "subset" and self._refresh_seen
                 with torch.cuda.device(self.device):
-                    g = self._pair if m == 2 else self._chains.get(m)
+                    g = (self._pair_r if rides else self._pair) if m == 2 else self._chains.get(m)
                     if g is None:
                         from ._lib import capture_lock, graph_capture
                         with capture_lock:
@@ -609,14 +631,16 @@ class NgpNerf:
                             g = torch.cuda.CUDAGraph()
                             with graph_capture(g, capture_error_mode="thread_local"):
                                 for k in range(m):
-                                    self._enqueue_step(k & 1)
-                        if m == 2:
+                                    self._enqueue_step(k & 1, refresh=rides and k == m - 1)
+                        if m == 2 and rides:
+                            self._pair_r = g
+                        elif m == 2:
                             self._pair = g
                         else:
                             self._chains[m] = g
                     g.replay()
                     self.step += m
-                    if self.step % c.grid_update_every == 0:
+                    if self.step % c.grid_update_every == 0 and not rides:
                         self.update_density_grid()
                         self._primed = False
                 i += m
@@ -657,39 +681,45 @@ class NgpNerf:
                 X["loss"].zero_()
                 self._enqueue_rays(X)
                 self._primed = True
+            rides = self._refresh_rides()      # this step carries the occupancy refresh of the update that follows it
             if self.replicated and c.use_graph and not variant_env("NS_NGP_REPL_EAGER"):
-                self._replicated_step(x)
+                self._replicated_step(x, rides)
             elif self.replicated or not c.use_graph or getattr(self, "_probe", None) is not None:
-                self._enqueue_step(x)
+                self._enqueue_step(x, refresh=rides)
             else:
                 key = self._step_key()
                 if self._graph_key != key:
                     # (re)capture: the first steps after a (re)allocation run eagerly -- they are also the warm-up
                     self._graphs, self._graph_key, self._pair, self._chains = [None, None], key, None, {}
+                    self._graphs_r, self._pair_r = [None, None], None
                     self._eager_left = 2
-                if self._eager_left > 0:
-                    self._eager_left -= 1
-                    self._enqueue_step(x)
-                elif self._graphs[x] is None:
+                graphs = self._graphs_r if rides else self._graphs
+                if self._eager_left > 0 or (rides and not self._refresh_seen):      # (the refresh's kernels run eagerly once too)
+                    self._eager_left = max(self._eager_left - 1, 0)
+                    self._enqueue_step(x, refresh=rides)
+                elif graphs[x] is None:
                     from ._lib import capture_lock, graph_capture
                     with capture_lock:          # the tracker thread takes the same lock around its host read-backs
                         torch.cuda.synchronize(dev)
                         g = torch.cuda.CUDAGraph()
                         with graph_capture(g, capture_error_mode="thread_local"):
-                            self._enqueue_step(x)
-                    self._graphs[x] = g         # (capturing does not execute: the step runs with the first replay)
+                            self._enqueue_step(x, refresh=rides)
+                    graphs[x] = g               # (capturing does not execute: the step runs with the first replay)
                     g.replay()
                 else:
-                    self._graphs[x].replay()
+                    graphs[x].replay()
+            if rides:
+                self._refresh_seen = True
             self.cur = 1 - x
             self.step += 1
-            if self.step % c.grid_update_every == 0:
+            if self.step % c.grid_update_every == 0 and not rides:
                 self.update_density_grid()
                 # The next step's rays were marched ahead (side branch of this step's launch sequence) on the grid as it was
                 # BEFORE this update: drop them, the next step marches its rays again on the updated grid (same seed, same
                 # pixels).  Training on the stale march one step in 16 made the result a coin toss: PSNR after 500 steps on
                 # the sphere scene 19-31 dB in a third of the runs instead of 34-36 dB (10 of 10 runs with this line; 10 of
                 # 10 on the tree before the rays moved ahead).  Cost: one eager sample + march per update, < 1 % of a step.
+                # (round 6, cfg.refresh_in_step: the refresh ran INSIDE the step, ahead of the next step's rays: nothing to redo)
                 self._primed = False
         return self.loss_tensor if return_loss else None
 
@@ -714,7 +744,7 @@ class NgpNerf:
                 self._probe = None
         return {k: acc[k] / cnt[k] for k in acc}
 
-    def _replicated_step(self, x):
+    def _replicated_step(self, x, rides=False):
         """One step of a replicated trainer from TWO HIP graphs with the collectives between them:
             graph A: forward, backward, table gradient -> the list of touched entries, MLP / pose gradients (three streams)
             eager  : all-gather of the lists' lengths (started; read below), all-reduce of the MLP and pose gradients
@@ -726,22 +756,24 @@ class NgpNerf:
         key = self._step_key()
         if self._graph_key != key:
             self._graphs, self._graph_key, self._pair, self._chains = [None, None], key, None, {}
+            self._graphs_r, self._pair_r = [None, None], None
             self._eager_left = 2
-        if self._eager_left > 0:
-            self._eager_left -= 1
-            self._enqueue_step(x)
+        if self._eager_left > 0 or (rides and not self._refresh_seen):      # (the refresh's kernels run eagerly once too)
+            self._eager_left = max(self._eager_left - 1, 0)
+            self._enqueue_step(x, refresh=rides)
             return
-        if self._graphs[x] is None:
+        graphs = self._graphs_r if rides else self._graphs
+        if graphs[x] is None:
             from ._lib import capture_lock, graph_capture
             with capture_lock:
                 torch.cuda.synchronize(self.device)
                 ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with graph_capture(ga, capture_error_mode="thread_local"):
-                    post = self._enqueue_step(x, phase="pre")
+                    post = self._enqueue_step(x, phase="pre", refresh=rides)
                 with graph_capture(gb, capture_error_mode="thread_local"):
                     post(stream_ptr())
-            self._graphs[x] = (ga, gb)
-        ga, gb = self._graphs[x]
+            graphs[x] = (ga, gb)
+        ga, gb = graphs[x]
         ga.replay()
         self._exchange_gradients(x, gb.replay)
 
@@ -829,6 +861,66 @@ class NgpNerf:
                                        C.c_long(N), stream_ptr()), "ngp_mlp_forward")
         return out[:, 3].float().exp()
 
+    def _grid_scratch(self, n=None):
+        """scratch of the subset refresh (cells, points, features, network output, directions, partial sums), allocated once"""
+        c, dev = self.cfg, self.device
+        total = c.n_cascades * c.grid_size ** 3
+        n = min(int(n if n is not None else (1 << 18)), total) & ~1
+        if getattr(self, "_grid_ws", None) is None:
+            self._grid_ws = {}                 # per draw size: the default size's buffers are part of captured graphs and never move
+        ws = self._grid_ws.get(n)
+        if ws is None:
+            f = dict(dtype=torch.float32, device=dev)
+            ws = self._grid_ws[n] = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty((n, 3), **f),
+                                     torch.zeros((32, n), dtype=torch.float16, device=dev), torch.zeros((n, 4), dtype=torch.float16, device=dev),
+                                     torch.zeros((n, 3), **f), torch.zeros(256, dtype=torch.float64, device=dev))
+            if not c.grid_decay_all and getattr(self, "_grid_tmp", None) is None:
+                self._grid_tmp = torch.zeros(total, **f)
+        return ws
+
+    def _enqueue_grid_refresh(self, st, seed=None, ctl=None, n_cells=None, after_params_read=None):
+        """the subset refresh's launch sequence on stream `st`: draw cells + jittered points, encode, density network, decay / max /
+        mean / bit packing.  `ctl`: the seed is completed on the device from the step's control block (the captured form);
+        `after_params_read()` is called behind the last kernel that reads the table / the MLP."""
+        c = self.cfg
+        G, nc = c.grid_size, c.n_cascades
+        total = nc * G ** 3
+        cells, pos, feat, out, dirs, part = self._grid_scratch(n_cells)
+        n = cells.shape[0]
+        s_box = float(c.aabb_scale)
+        L, nul = lib(), C.c_void_p(0)
+        if ctl is not None:
+            seed0 = (self.base_seed * 0x9E3779B1 + 0x27D4EB2F) & 0xFFFFFFFF                                # same on every replica
+            check(L.ns_ngp_grid_cells_ctl(G, nc, C.c_uint32(seed0), n, C.c_float(0.5 - 0.5 * s_box), C.c_float(0.5 + 0.5 * s_box),
+                                          ptr(cells), ptr(pos), ctl, st), "ngp_grid_cells")
+        else:
+            check(L.ns_ngp_grid_cells(G, nc, C.c_uint32(seed), n, C.c_float(0.5 - 0.5 * s_box), C.c_float(0.5 + 0.5 * s_box), ptr(cells),
+                                      ptr(pos), st), "ngp_grid_cells")
+        check(L.ns_ngp_encode_forward(*self._grid_args(), ptr(pos), ptr(self.grid_half), ptr(feat), 1, C.c_long(n), st),
+              "ngp_encode_forward")
+        check(L.ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(feat), ptr(dirs), ptr(out), nul, nul, nul, nul, C.c_long(n), st),
+              "ngp_mlp_forward")
+        if after_params_read is not None:
+            after_params_read()
+        if c.grid_decay_all:
+            # (ADVICE r02 / r03: fading all cells at instant-ngp's 0.95 with 4 % of the grid drawn would empty the grid 12 x
+            #  faster than the rule it stands in for; not fading the undrawn cells at all leaves floaters for ever)
+            decay_all = float(c.grid_decay) ** min(1.0, n / (0.5 * total))
+            check(L.ns_ngp_grid_update(ptr(out), ptr(cells), n, C.c_float(c.min_step), C.c_float(decay_all),
+                                       C.c_float(c.min_optical_thickness), ptr(self.density_grid), C.c_long(total), ptr(part),
+                                       ptr(self.bits), st), "ngp_grid_update")
+        else:
+            # decay only what was re-evaluated (ADVICE r02): a draw of 4 % of the grid per update must not fade the other 96 %
+            check(L.ns_ngp_grid_update_sampled(ptr(out), ptr(cells), n, C.c_float(c.min_step), C.c_float(c.grid_decay),
+                                               C.c_float(c.min_optical_thickness), ptr(self.density_grid), ptr(self._grid_tmp),
+                                               C.c_long(total), ptr(part), ptr(self.bits), st), "ngp_grid_update_sampled")
+
+    def _refresh_rides(self):
+        """does the step about to run carry the occupancy refresh (cfg.refresh_in_step: the last step before an update)"""
+        c = self.cfg
+        return bool(c.refresh_in_step and c.grid_rule == "subset" and getattr(self, "_static", False)
+                    and (self.step + 1) % c.grid_update_every == 0)
+
     def update_density_grid(self, n_cells=None):
         """Occupancy update, instant-ngp's rule (testbed_nerf.cu `update_density_grid_nerf`, called from its training loop
         every 16 steps): during the first 256 steps EVERY cell of every cascade is re-evaluated, afterwards G^3/4 cells per
@@ -849,37 +941,9 @@ class NgpNerf:
             n_cells = 1 << 18
         if n_cells is not None:
             # the subset rule on the HIP kernels (csrc/ngp.hip, "occupancy-grid refresh"): 7 launches, no allocation
-            n = min(int(n_cells), total) & ~1
-            ws = getattr(self, "_grid_ws", None)
-            if ws is None or ws[0].shape[0] != n:
-                ws = self._grid_ws = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty((n, 3), dtype=torch.float32, device=dev),
-                                      torch.zeros((32, n), dtype=torch.float16, device=dev), torch.zeros((n, 4), dtype=torch.float16, device=dev),
-                                      torch.zeros((n, 3), dtype=torch.float32, device=dev), torch.zeros(256, dtype=torch.float64, device=dev))
-            cells, pos, feat, out, dirs, part = ws
             self._grid_updates = getattr(self, "_grid_updates", 0) + 1
             seed = (self.base_seed * 0x9E3779B1 + self._grid_updates * 0x85EBCA77 + 0x27D4EB2F) & 0xFFFFFFFF   # same on every replica
-            s_box = float(c.aabb_scale)
-            L, nul, st = lib(), C.c_void_p(0), stream_ptr()
-            check(L.ns_ngp_grid_cells(G, nc, C.c_uint32(seed), n, C.c_float(0.5 - 0.5 * s_box), C.c_float(0.5 + 0.5 * s_box), ptr(cells),
-                                      ptr(pos), st), "ngp_grid_cells")
-            check(L.ns_ngp_encode_forward(*self._grid_args(), ptr(pos), ptr(self.grid_half), ptr(feat), 1, C.c_long(n), st),
-                  "ngp_encode_forward")
-            check(L.ns_ngp_mlp_forward(ptr(self.mlp_half), ptr(feat), ptr(dirs), ptr(out), nul, nul, nul, nul, C.c_long(n), st),
-                  "ngp_mlp_forward")
-            if c.grid_decay_all:
-                # (fading all cells at instant-ngp's 0.95 with 4 % of the grid drawn would empty the grid 12 x
-                #  faster than the rule it stands in for; not fading the undrawn cells at all leaves floaters for ever)
-                decay_all = float(c.grid_decay) ** min(1.0, n / (0.5 * total))
-                check(L.ns_ngp_grid_update(ptr(out), ptr(cells), n, C.c_float(c.min_step), C.c_float(decay_all),
-                                           C.c_float(c.min_optical_thickness), ptr(self.density_grid), C.c_long(total), ptr(part),
-                                           ptr(self.bits), st), "ngp_grid_update")
-            else:
-                # decay only what was re-evaluated: a draw of 4 % of the grid per update must not fade the other 96 %
-                if getattr(self, "_grid_tmp", None) is None:
-                    self._grid_tmp = torch.zeros(total, dtype=torch.float32, device=dev)
-                check(L.ns_ngp_grid_update_sampled(ptr(out), ptr(cells), n, C.c_float(c.min_step), C.c_float(c.grid_decay),
-                                                   C.c_float(c.min_optical_thickness), ptr(self.density_grid), ptr(self._grid_tmp),
-                                                   C.c_long(total), ptr(part), ptr(self.bits), st), "ngp_grid_update_sampled")
+            self._enqueue_grid_refresh(stream_ptr(), seed=seed, n_cells=n_cells)
             return
         if n_cells is not None:
             cells = torch.randint(0, total, (min(int(n_cells), total),), device=dev, generator=self.gen)

@@ -417,17 +417,26 @@ def test_training_converges_on_a_synthetic_scene(dev):
     assert np.mean(losses[-10:]) < 0.5 * np.mean(losses[:5]), (losses[:5], losses[-10:])
     rgb, dep = net.render(torch.tensor(np.array(poses[0])), H, W)
     assert torch.isfinite(rgb).all() and rgb.shape == (H, W, 3)
-    # the rays of a step are marched at the end of the previous one; an occupancy update in between invalidates them: the
-    # step after an update must march on the UPDATED grid (training on the stale march made the result a coin toss)
+    # the rays of a step are marched during the previous one; an occupancy update in between would invalidate them (training on
+    # the stale march made the result a coin toss).  Round 6 (cfg.refresh_in_step): the refresh RIDES on the step before the
+    # update, ahead of the next step's rays on the same stream -- they are marched on the refreshed grid and stay valid ...
     while net.step % cfg.grid_update_every != cfg.grid_update_every - 1:
         net.train_step(return_loss=False)
-    assert net._primed
-    net.train_step(return_loss=False)                       # this step ends with the occupancy update
-    assert net.step % cfg.grid_update_every == 0 and not net._primed
-    net.bits.zero_()                                        # an (artificial) update that empties the grid ...
-    net.train_step(return_loss=False)
+    assert net._primed and cfg.refresh_in_step
+    bits0 = net.bits.clone()
+    net.train_step(return_loss=False)                       # this step carries the occupancy update
+    assert net.step % cfg.grid_update_every == 0 and net._primed and net._refresh_seen
+    assert not torch.equal(bits0, net.bits)                 # (the grid did change)
+    # ... and with the refresh AFTER the step (rounds 2-5's form) the next step has to march again
+    old = NgpNerf(NgpConfig(n_rays=2048, max_samples=1 << 17, refresh_in_step=False), dev, seed=0)
+    old.set_images(torch.tensor(np.array(imgs)), torch.tensor(np.array(deps)), torch.tensor(np.array(covs)),
+                   torch.tensor(np.array(poses)), (f, f, W / 2, H / 2))
+    lo = [float(old.train_step()) for _ in range(cfg.grid_update_every)]
+    assert old.step % cfg.grid_update_every == 0 and not old._primed and np.isfinite(lo).all()
+    old.bits.zero_()                                        # an (artificial) update that empties the grid ...
+    old.train_step(return_loss=False)
     torch.cuda.synchronize()
-    assert net.last_samples == 0 and net._primed            # ... is what the next step marches on: no samples at all
+    assert old.last_samples == 0 and old._primed            # ... is what the next step marches on: no samples at all
 
 
 def test_pyngp_surface_as_nerf_fusion_drives_it(dev):
