@@ -51,6 +51,10 @@ class NgpConfig:
     # parameters one step older than the eager refresh saw -- instead of ~150 us of refresh + ~110 us of re-marching between two
     # graph replays once per 16 steps (5 % of the mapping leg).  False: refresh eagerly after the step, re-march the next rays.
     refresh_in_step: bool = True
+    steps_per_graph: int = 8             # optimiser steps replayed per HIP-graph launch of train_steps() (even; <= grid_update_every).
+                                         # Pipeline, two runs per arm in one call: 2: 134.5 / 135.8, 4: 138.8 / 137.6, 8: 137.5 / 139.9,
+                                         # 16: 137.2 / 140.0 frames/s (profiles/r06_ab_records.json); 8 = 2.8 ms between two polls of
+                                         # the packet queue
     grid_rule: str = "subset"            # occupancy refresh: "subset" (2^18 uniform cells per update) | "ngp" (instant-ngp's rule)
     grid_decay: float = 0.95
     grid_decay_all: bool = True          # subset rule: EVERY cell decays on every update, as in instant-ngp's rule (max(prev * decay,
@@ -613,17 +617,18 @@ class NgpNerf:
         two graph launches (join, launch, fork: 25-35 us on the device) is paid once per pair."""
         c = self.cfg
         i = 0
-        chain = 2      # steps per chained graph (even).  4 / 8 / 16 measured: 0.438 -> 0.434 / 0.427 / 0.433 ms, inside the
-                       # box-to-box spread: a pair it is
+        chain = max(2, int(c.steps_per_graph)) // 2 * 2      # steps per chained graph (even).  Trainer alone, 4 / 8 / 16 against 2:
+                       # 0.438 -> 0.434 / 0.427 / 0.433 ms, inside the box-to-box spread; in the PIPELINE the mapper thread's replays
+                       # compete with the tracker thread for the interpreter (cfg.steps_per_graph)
         while i < n:
             left = c.grid_update_every - self.step % c.grid_update_every          # steps until the next occupancy update
-            first_ride = left <= 2 and c.refresh_in_step and c.grid_rule == "subset" and not getattr(self, "_refresh_seen", False)
+            first_ride = left <= chain and c.refresh_in_step and c.grid_rule == "subset" and not getattr(self, "_refresh_seen", False)
             if n - i >= 2 and self._pair_ready() and not first_ride:      # (the first refresh-carrying step runs singly, eagerly)
                 m = min(chain, n - i, left) // 2 * 2
-                # the pair that ends on an update carries the refresh in its second step (cfg.refresh_in_step)
-                rides = m == 2 and left == 2 and c.refresh_in_step and c.grid_rule == "subset" and self._refresh_seen
+                # the chain that ends on an update carries the refresh in its last step (cfg.refresh_in_step)
+                rides = m == left and c.refresh_in_step and c.grid_rule == "subset" and self._refresh_seen
                 with torch.cuda.device(self.device):
-                    g = (self._pair_r if rides else self._pair) if m == 2 else self._chains.get(m)
+                    g = (self._pair_r if rides else self._pair) if m == 2 else self._chains.get((m, rides))
                     if g is None:
                         from ._lib import capture_lock, graph_capture
                         with capture_lock:
@@ -637,7 +642,7 @@ class NgpNerf:
                         elif m == 2:
                             self._pair = g
                         else:
-                            self._chains[m] = g
+                            self._chains[(m, rides)] = g
                     g.replay()
                     self.step += m
                     if self.step % c.grid_update_every == 0 and not rides:
