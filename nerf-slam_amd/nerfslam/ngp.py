@@ -55,6 +55,7 @@ class NgpConfig:
                                          # Pipeline, two runs per arm in one call: 2: 134.5 / 135.8, 4: 138.8 / 137.6, 8: 137.5 / 139.9,
                                          # 16: 137.2 / 140.0 frames/s (profiles/r06_ab_records.json); 8 = 2.8 ms between two polls of
                                          # the packet queue
+    wgrad_after_scatter: bool = False    # A/B hook: the MLP weight-gradient chain forks AFTER the scatter pass instead of beside it
     grid_rule: str = "subset"            # occupancy refresh: "subset" (2^18 uniform cells per update) | "ngp" (instant-ngp's rule)
     grid_decay: float = 0.95
     grid_decay_all: bool = True          # subset rule: EVERY cell decays on every update, as in instant-ngp's rule (max(prev * decay,
@@ -530,32 +531,35 @@ class NgpNerf:
         mark("ngp_mlp_bwd_kernel")
         # (round 4, measured and not kept: the weight gradients IN LINE on the main stream ahead of the scatter, so that the
         #  scatter does not share the CUs with a kernel that takes whole SIMDs: step 0.288 -> 0.312 ms, 130 -> 121 frames/s)
-        with torch.cuda.stream(self._side):
-            st1 = stream_ptr()
-            self._side.wait_event(fork1)
-            mark(None)
-            # (the optimiser that follows writes the OTHER fragment table: the activation-gradient kernel on the main stream
-            #  may still be reading this one)
-            check(L.ns_ngp_mlp_wgrad_partials_n(ptr(fr_r), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]),
-                                                ptr(self.partial_fused), self.mlp_wgs, C.c_long(S), n_dev, st1),
-                  "ngp_mlp_wgrad_partials")
-            mark("ngp_mlp_wgrad_tr_kernel")
-            slabs = int(L.ns_ngp_mlp_wgrad_slabs(self.mlp_wgs, C.c_long(S)))
-            if ev_params_read is not None:
-                self._side.wait_event(ev_params_read)    # (the MLP's optimiser rewrites the weights the refresh evaluates)
-            if single:
-                # the MLP's optimiser step in one launch: slab reduce + Adam + f16 copy + both fragment tables (the zero rows
-                # of the tables were written once by the pack above); bit-identical to reduce + ns_ngp_adam_ctl + pack
-                # (tests/test_ngp_gpu.py::test_mlp_optimiser_step_in_one_launch_is_bit_identical)
-                check(L.ns_ngp_mlp_step_fused(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), ptr(self.mlp_master),
-                                              ptr(self.mlp_half), ptr(self.mlp_m1), ptr(self.mlp_m2), ptr(fr_w), 0,
-                                              C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
-                                              C.c_float(c.l2_mlp), C.c_float(c.loss_scale * self.world), ctl, st1),
-                      "ngp_mlp_step_fused")
-                mark("ngp_mlp_step_kernel")
-            else:       # replicated trainers: the summed gradient is all-reduced first, the optimiser follows the exchange (post())
-                check(L.ns_ngp_mlp_reduce(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), st1), "ngp_mlp_reduce")
-                mark("ngp_mlp_wgrad_reduce_kernel")
+        def weight_gradients(after):
+            with torch.cuda.stream(self._side):
+                st1 = stream_ptr()
+                self._side.wait_event(after)
+                mark(None)
+                # (the optimiser that follows writes the OTHER fragment table: the activation-gradient kernel on the main stream
+                #  may still be reading this one)
+                check(L.ns_ngp_mlp_wgrad_partials_n(ptr(fr_r), ptr(featT), ptr(X["s_dir"]), ptr(X["s_dout"]),
+                                                    ptr(self.partial_fused), self.mlp_wgs, C.c_long(S), n_dev, st1),
+                      "ngp_mlp_wgrad_partials")
+                mark("ngp_mlp_wgrad_tr_kernel")
+                slabs = int(L.ns_ngp_mlp_wgrad_slabs(self.mlp_wgs, C.c_long(S)))
+                if ev_params_read is not None:
+                    self._side.wait_event(ev_params_read)    # (the MLP's optimiser rewrites the weights the refresh evaluates)
+                if single:
+                    # the MLP's optimiser step in one launch: slab reduce + Adam + f16 copy + both fragment tables (the zero rows
+                    # of the tables were written once by the pack above); bit-identical to reduce + ns_ngp_adam_ctl + pack
+                    # (tests/test_ngp_gpu.py::test_mlp_optimiser_step_in_one_launch_is_bit_identical)
+                    check(L.ns_ngp_mlp_step_fused(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), ptr(self.mlp_master),
+                                                  ptr(self.mlp_half), ptr(self.mlp_m1), ptr(self.mlp_m2), ptr(fr_w), 0,
+                                                  C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
+                                                  C.c_float(c.l2_mlp), C.c_float(c.loss_scale * self.world), ctl, st1),
+                          "ngp_mlp_step_fused")
+                    mark("ngp_mlp_step_kernel")
+                else:       # replicated trainers: the summed gradient is all-reduced first, the optimiser follows the exchange (post())
+                    check(L.ns_ngp_mlp_reduce(ptr(self.partial_fused), slabs, ptr(self.mlp_grad), st1), "ngp_mlp_reduce")
+                    mark("ngp_mlp_wgrad_reduce_kernel")
+        if not c.wgrad_after_scatter:
+            weight_gradients(fork1)
         fork = torch.cuda.Event()
         fork.record(main)
         # (enqueue order matters under capture although the dependencies do not change: the graph executor keeps the FIRST
@@ -567,6 +571,10 @@ class NgpNerf:
                 self._emit_count.zero_()
             table_gradient(1, st)
             mark("ngp_enc_fscatter_direct_kernel")
+            if c.wgrad_after_scatter:      # A/B: the weight gradients beside the accumulate pass only
+                ev_sc = torch.cuda.Event()
+                ev_sc.record(main)
+                weight_gradients(ev_sc)
             if ev_params_read is not None:
                 main.wait_event(ev_params_read)          # (the flush rewrites the table the refresh encodes from)
             table_gradient(2, st)
