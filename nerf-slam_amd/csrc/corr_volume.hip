@@ -49,6 +49,36 @@ __device__ __forceinline__ _Float16 pool4(_Float16 a, _Float16 b, _Float16 c, _F
   return (_Float16)(acc / 4.0f);
 }
 
+// The same pooling on PACKED pairs, two results at a time, for the tiled kernel (round 6).  The plain form costs 13 vector
+// instructions per result (the compiler re-rounds the f32 accumulators to f16, converts back, adds 0, ...), 150 of the ~280 a
+// wave issues per tile, and the kernel is bound by instruction issue (rocprofv3 --pmc: each SIMD issues 60 % of the time at two
+// waves, LDS 21 % busy, matrix core 14 %).  v_fma_mix_f32 reads an f16 HALF of a packed register as an f32 operand:
+//   t = lo(p) * 1 + hi(p);  t = lo(q) * 1 + t;  t = hi(q) * 1 + t      == ((0 + a) + b) + c) + d in f32, the same three roundings
+//   v_fma_mixlo/hi_f16: half = f16(t * 0.25 + 0)                        == f16(t / 4): the product is exact, ONE rounding to f16;
+//                                                                          the +0 addend turns a -0 sum into the +0 that 0 + a gives
+// 4 instructions per result, no unpacking, bit-identical (tests/test_corr_gpu.py compares every level with the plain form's bits).
+__device__ __forceinline__ float pool_sum(f16x2 p, f16x2 q) {
+  float t;
+  asm("v_fma_mix_f32 %0, %1, 1.0, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(p));
+  asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(q), "v"(t));
+  asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(q), "v"(t));
+  return t;
+}
+// {pool(p0.lo, p0.hi, q0.lo, q0.hi), pool(p1.lo, p1.hi, q1.lo, q1.hi)}
+__device__ __forceinline__ f16x2 pool4x2(f16x2 p0, f16x2 q0, f16x2 p1, f16x2 q1, float quarter) {
+  const float t0 = pool_sum(p0, q0), t1 = pool_sum(p1, q1);
+  f16x2 d;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(d) : "v"(t0), "v"(quarter));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(t1), "v"(quarter));
+  return d;
+}
+__device__ __forceinline__ _Float16 pool4x1(f16x2 p, f16x2 q, float quarter) {
+  const float t = pool_sum(p, q);
+  f16x2 d;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(d) : "v"(t), "v"(quarter));
+  return d[0];
+}
+
 // f16 values travel in PACKED pairs (one VGPR per two values): the row, its three pooling carries and the
 // pooled rows would otherwise take one VGPR per half and push the kernel to one wave per SIMD.
 __device__ __forceinline__ f16x2 mk2(_Float16 a, _Float16 b) {
@@ -320,33 +350,57 @@ __device__ __forceinline__ void stage_tile_load(__amdgpu_buffer_rsrc_t F2, int t
 
 struct TileWalk {  // tiles of a z-slice in 2x2-group order, skipping the ones outside the tile grid
   int t, t_end, ngx, nty, ntx;
-  __device__ __forceinline__ bool decode(int tt, int& ty, int& tx) const {
-    const int g = tt >> 2, sub = tt & 3;
-    ty = 2 * (g / ngx) + (sub >> 1);
-    tx = 2 * (g % ngx) + (sub & 1);
-    return ty < nty && tx < ntx;
+  int gy, gx, sub;  // the group and the tile inside it that t names (kept incrementally: a division per tile and walker was
+                    // ~60 of the ~160 scalar instructions of a tile iteration)
+  __device__ __forceinline__ void start(int t0) {  // t0: a multiple of 4
+    t = t0;
+    gy = (t0 >> 2) / ngx;
+    gx = (t0 >> 2) % ngx;
+    sub = 0;
   }
   __device__ __forceinline__ bool next(int& ty, int& tx) {  // advances to the next valid tile; false at the end
     while (t < t_end) {
-      const bool ok = decode(t, ty, tx);
+      ty = 2 * gy + (sub >> 1);
+      tx = 2 * gx + (sub & 1);
+      const bool ok = ty < nty && tx < ntx;
       t++;
+      if (++sub == 4) {
+        sub = 0;
+        if (++gx == ngx) {
+          gx = 0;
+          gy++;
+        }
+      }
       if (ok) return true;
     }
     return false;
   }
 };
 
-template <int C>
+// BAND (round 6): levels 2 and 3 are row-major and small (a 4x4 / 2x2 block per source pixel and tile group), and rounds 3-5 stored
+// each block from registers as it completed: 8- and 4-byte pieces, every one its own partial-line write -- 48 of the 88 write
+// requests of a tile, 757 MB at the memory for 611 MB of pyramid, 45 of the 205 us of a 10-edge launch
+// (tools/vol_levels_bench.py: 4 / 3 / 2 / 1 levels = 205 / 211 / 178 / 155 us).  BAND = 1 collects the blocks of up to VOL_RUN
+// consecutive groups of one band (two tile rows) per wave in LDS and writes them when the band -- or the workgroup's share of it --
+// ends: at 60x80 a band is the whole width, i.e. 4 level-2 rows = 160 contiguous bytes and 2 level-3 rows = 40 bytes per source
+// pixel, stored as runs of consecutive lanes.  The LDS for it comes from the staging: ONE tile buffer and a second barrier per
+// tile (measured alone, 3 workgroups per CU: 202 vs 203 us -- neither a gain nor a loss).
+#define VOL_RUN 5        // groups per run: 4 x 20 level-2 values, 2 x 10 level-3 values per source pixel
+#define VOL_P2 168       // bytes per source pixel in the level-2 run buffer (160 + 8)
+#define VOL_P3 44        // level 3 (40 + 4)
+
+template <int C, int BAND>
 __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
   static_assert(C == 128, "staging assumes 128 channels");
   constexpr int KS = C / 16;
   constexpr int TILEB = 64 * ROWB;
   constexpr int XPITCH = 144;  // 128-byte output line + 16: conflict-free 16-byte slots for both access patterns
-  // Two staging buffers are enough with one barrier per tile: iteration t fills the buffer that was read in
-  // iteration t-1 (all waves are past that barrier) and reads the one filled during t-1.
-  __shared__ __attribute__((aligned(16))) char lds[2 * TILEB];
+  // BAND = 0: two staging buffers and one barrier per tile: iteration t fills the buffer that was read in iteration t-1 (all
+  // waves are past that barrier) and reads the one filled during t-1.  BAND = 1: one buffer, filled between two barriers.
+  __shared__ __attribute__((aligned(16))) char lds[(BAND ? 1 : 2) * TILEB];
   // per wave: 32 level-0 lines of the current tile + 32 level-1 lines of the current 2x2 tile group
   __shared__ __attribute__((aligned(16))) char xpose[4][2][32 * XPITCH];
+  __shared__ __attribute__((aligned(16))) char runbuf[BAND ? 4 : 1][BAND ? 32 * (VOL_P2 + VOL_P3) : 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int ht = a.ht, wd = a.wd, HW = ht * wd;
@@ -383,7 +437,7 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
   TileWalk ld;   // walks ahead of the compute: issues the global loads
   ld.ngx = (ntx0 + 1) >> 1; ld.nty = nty0; ld.ntx = ntx0;
   const int ngroups = ((nty0 + 1) >> 1) * ld.ngx;
-  ld.t = 4 * (int)((long)blockIdx.z * ngroups / gridDim.z);
+  ld.start(4 * (int)((long)blockIdx.z * ngroups / gridDim.z));
   ld.t_end = 4 * (int)((long)(blockIdx.z + 1) * ngroups / gridDim.z);
   TileWalk cp = ld;  // compute cursor
   uint4 regs[4];
@@ -397,10 +451,16 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
   int buf = 0;
   f16x4 l2g[2] = {(f16x4)(_Float16)0, (f16x4)(_Float16)0};  // level-2 rows (half, 2 + half) of the group, 4 columns
   f16x2 l3g[2] = {(f16x2)(_Float16)0, (f16x2)(_Float16)0};  // level-3 rows 0, 1 of the group (held by half == 0)
+  const float quarter = 0.25f;
+  int run_n = 0, run_gx0 = 0, run_gy = 0;  // BAND: groups in the run buffers, the run's first group column, its band
   while (cp.next(ty, tx)) {
-    const char* cur = lds + buf * TILEB;
+    const char* cur = lds + (BAND ? 0 : buf) * TILEB;
     f16x2 v[16];  // v[k] = tile-local offsets 32*half + 2k, +1  (rows 4*half .. 4*half+3, 8 columns each)
     row_chunk<C, 2>(cur, src, col, half, v);
+    if (BAND) lds_barrier();  // every wave has its fragments: the buffer takes the next tile below
+#pragma unroll
+    for (int k = 0; k < 16; k++) asm("" : "+v"(v[k]));  // (the packed pairs are values, not recipes: without this the compiler
+                                                        //  converts half of the accumulators a second time for the pooling)
     const int dy = ty & 1, dx = tx & 1, gy = ty >> 1, gx = tx >> 1;
     // last tile of its 2x2 group in walk order (the others are outside the tile grid)?
     const bool last_in_group = !((dx == 0 && tx + 1 < ntx0) || (dy == 0 && ty + 1 < nty0));
@@ -425,7 +485,7 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
         for (int cc = 0; cc < 2; cc++) {
           const f16x2 u0 = v[8 * rr + 2 * cc], u1 = v[8 * rr + 2 * cc + 1];          // upper row, columns 4cc..4cc+3
           const f16x2 d0_ = v[8 * rr + 4 + 2 * cc], d1_ = v[8 * rr + 4 + 2 * cc + 1];  // lower row
-          l1[rr][cc] = mk2(pool4(u0[0], u0[1], d0_[0], d0_[1]), pool4(u1[0], u1[1], d1_[0], d1_[1]));
+          l1[rr][cc] = pool4x2(u0, d0_, u1, d1_, quarter);
         }
       // into the group's level-1 line of this source pixel: row 4 dy + 2 half + rr, columns 4 dx .. 4 dx + 3
 #pragma unroll
@@ -450,7 +510,7 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
     // group's level-1 / 2 / 3 stores (every fourth tile) follow the prefetch, so the wait never covers stores issued less than
     // a whole iteration ago.  buf ^ 1 was read during tile t-1; every wave is past that iteration's barrier.
     if (have_next) {
-      stage_store<2>(lds + (buf ^ 1) * TILEB, tid, regs);                 // tile t+1 -> LDS
+      stage_store<2>(lds + (BAND ? 0 : (buf ^ 1)) * TILEB, tid, regs);    // tile t+1 -> LDS
       have_next = ld.next(lty, ltx);
       if (have_next) stage_tile_load(F2, lty, ltx, ht, wd, tid, regs);    // tile t+2 in flight
     }
@@ -470,8 +530,7 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
     if (a.num_levels > 2) {
       // level 2: this tile gives one row (2 dy + half of the group's 4) and two columns (2 dx, 2 dx + 1); kept in
       // registers until the group is complete, then two 8-byte stores per lane instead of four 4-byte ones
-      const f16x2 l2 = mk2(pool4(l1[0][0][0], l1[0][0][1], l1[1][0][0], l1[1][0][1]),
-                           pool4(l1[0][1][0], l1[0][1][1], l1[1][1][0], l1[1][1][1]));
+      const f16x2 l2 = pool4x2(l1[0][0], l1[1][0], l1[0][1], l1[1][1], quarter);
 #pragma unroll
       for (int ry = 0; ry < 2; ry++)
         if (dy == ry) {
@@ -482,14 +541,65 @@ __global__ __launch_bounds__(256) void corr_volume_tiled_kernel(VolArgs a) {
         // level 3: the tile's single value needs both halves' level-2 rows
         const uint32_t mine = __builtin_bit_cast(uint32_t, l2);
         const f16x2 other = __builtin_bit_cast(f16x2, (uint32_t)__shfl_xor((int)mine, 32));
-        const _Float16 l3 = pool4(l2[0], l2[1], other[0], other[1]);  // meaningful on half == 0
+        const _Float16 l3 = pool4x1(l2, other, quarter);  // meaningful on half == 0
 #pragma unroll
         for (int ry = 0; ry < 2; ry++)
           if (dy == ry) l3g[ry][dx] = l3;
       }
-      if (last_in_group && pok) {
-        struct __attribute__((packed, aligned(2))) U4 { f16x4 v; };
-        struct __attribute__((packed, aligned(2))) U2 { f16x2 v; };
+      struct __attribute__((packed, aligned(2))) U4 { f16x4 v; };
+      struct __attribute__((packed, aligned(2))) U2 { f16x2 v; };
+      if (BAND && last_in_group) {
+        // the group's blocks into the run buffers (rows / columns outside the image are dropped when the run is written)
+        char* b2 = runbuf[wave];
+        char* b3 = b2 + 32 * VOL_P2;
+        if (run_n == 0) { run_gx0 = gx; run_gy = gy; }
+#pragma unroll
+        for (int ry = 0; ry < 2; ry++) {
+          *reinterpret_cast<f16x4*>(b2 + col * VOL_P2 + (2 * ry + half) * (VOL_RUN * 8) + run_n * 8) = l2g[ry];
+          if (a.num_levels > 3 && half == 0) *reinterpret_cast<f16x2*>(b3 + col * VOL_P3 + ry * (VOL_RUN * 4) + run_n * 4) = l3g[ry];
+        }
+        run_n++;
+        // the run ends with the band, with this workgroup's share of the slice, or when the buffer is full
+        if (run_n == VOL_RUN || gx + 1 == cp.ngx || 4 * (((cp.t - 1) >> 2) + 1) >= cp.t_end) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const long h2w2 = (long)h2 * w2, h3w3 = (long)h3 * w3;
+#pragma unroll 2
+          for (int it = 0; it < (32 * 4 * VOL_RUN) / 64; it++) {
+            const int q = it * 64 + lane, px = q / (4 * VOL_RUN), rem = q % (4 * VOL_RUN), r = rem / VOL_RUN, g = rem % VOL_RUN;
+            const int Y2 = 4 * run_gy + r, X2 = 4 * (run_gx0 + g);
+            if (g < run_n && p0 + px < HW && Y2 < h2 && X2 < w2) {
+              const f16x4 d = *reinterpret_cast<const f16x4*>(b2 + px * VOL_P2 + r * (VOL_RUN * 8) + g * 8);
+              _Float16* d2p = a.pyr[2] + ((long)eo * HW + p0 + px) * h2w2 + (long)Y2 * w2 + X2;
+              if (X2 + 4 <= w2) {
+                reinterpret_cast<U4*>(d2p)->v = d;
+              } else {
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                  if (X2 + c < w2) d2p[c] = d[c];
+              }
+            }
+          }
+          if (a.num_levels > 3) {
+#pragma unroll 1
+            for (int it = 0; it < (32 * 2 * VOL_RUN) / 64; it++) {
+              const int q = it * 64 + lane, px = q / (2 * VOL_RUN), rem = q % (2 * VOL_RUN), ry = rem / VOL_RUN, g = rem % VOL_RUN;
+              const int Y3 = 2 * run_gy + ry, X3 = 2 * (run_gx0 + g);
+              if (g < run_n && p0 + px < HW && Y3 < h3 && X3 < w3) {
+                const f16x2 d = *reinterpret_cast<const f16x2*>(b3 + px * VOL_P3 + ry * (VOL_RUN * 4) + g * 4);
+                _Float16* d3p = a.pyr[3] + ((long)eo * HW + p0 + px) * h3w3 + (long)Y3 * w3 + X3;
+                if (X3 + 2 <= w3) {
+                  reinterpret_cast<U2*>(d3p)->v = d;
+                } else {
+                  d3p[0] = d[0];
+                }
+              }
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next run overwrites the buffers)
+          run_n = 0;
+        }
+      }
+      if (!BAND && last_in_group && pok) {
 #pragma unroll
         for (int ry = 0; ry < 2; ry++) {
           const int Y2 = 4 * gy + 2 * ry + half, X2 = 4 * gx;
@@ -597,7 +707,13 @@ extern "C" int ns_corr_volume_pyramid_slots(const void* fmap1, const void* fmap2
         zt = z;
       }
     }
-    hipLaunchKernelGGL(corr_volume_tiled_kernel<128>, dim3(ns_cdiv(HW, 128), E, zt), dim3(256), 0, (hipStream_t)stream, a);
+#ifdef NS_TEST_VARIANTS
+    if (ns_variant_env("NS_VOL_Z")) zt = atoi(ns_variant_env("NS_VOL_Z"));
+    if (ns_variant_env("NS_VOL_NO_BAND"))
+      hipLaunchKernelGGL((corr_volume_tiled_kernel<128, 0>), dim3(ns_cdiv(HW, 128), E, zt), dim3(256), 0, (hipStream_t)stream, a);
+    else
+#endif
+    hipLaunchKernelGGL((corr_volume_tiled_kernel<128, 1>), dim3(ns_cdiv(HW, 128), E, zt), dim3(256), 0, (hipStream_t)stream, a);
     NS_CHECK_LAUNCH("corr_volume_tiled_kernel");
     return NS_OK;
   }
