@@ -231,43 +231,83 @@ __global__ __launch_bounds__(256) void corr_lookup_pyramid_kernel(LookupLevels L
 #define COOP_PITCH 72  // halves per LDS plane row (64 pixels + pad; 144 B keeps 16-byte reads aligned)
 
 // one level of one (edge, pixel) by its 8-lane group: lane r owns one window row; the 49 outputs of the pixel land in
-// ob[(a * 7 + b) * COOP_PITCH + pl] (49 planes of 64 pixels).  Shared by the plain kernel and the encoder-fused one below.
-__device__ __forceinline__ void coop_level(const LookupLevels& L, int lvl, float cx, float cy, bool live, long vidx, int t,
-                                           uint16_t* __restrict__ ob) {
-  const int r = t & 7, pl = t >> 3;
+// ob[(a * 7 + b) * CS + pl * PS] (plain kernel: 49 planes of 64 pixels, CS = COOP_PITCH, PS = 1; encoder-fused kernel: 64 pixel
+// rows of 208 channels, CS = 1, PS = ENC_PP).  In three parts since round 6 -- geometry, loads, blend -- so that the fused kernel
+// can have the NEXT level's (and the next pixel group's) loads in flight while it blends this one; the plain kernel calls them
+// back to back (same instructions as the one-piece form it replaces, same bits).
+struct CoopGeo {
+  const _Float16* vol;
+  long slice_off, total;
+  float dx, dy;
+  int h2, w2, ntx, xb, yb, j, y1;
+  bool any_col, rowvalid;
+};
+struct CoopRaw {
+  u32x4 A, B;   // tiled level: the two 8-value tile rows under the window row; row-major level: A = the 8-value run
+};
+__device__ __forceinline__ CoopGeo coop_geo(const LookupLevels& L, int lvl, float cx, float cy, bool live, long vidx, int t) {
+  CoopGeo G;
+  const int r = t & 7;
   const float sc = L.scale[lvl];
   const float x0 = cx * sc, y0 = cy * sc;
-  const int h2 = L.h2[lvl], w2 = L.w2[lvl], ntx = L.ntx[lvl];
-  const _Float16* __restrict__ vol = L.vol[lvl];
-  const long slice_off = vidx * L.slice_elems[lvl], total = L.total_elems[lvl];
+  G.h2 = L.h2[lvl];
+  G.w2 = L.w2[lvl];
+  G.ntx = L.ntx[lvl];
+  G.vol = L.vol[lvl];
+  G.slice_off = vidx * L.slice_elems[lvl];
+  G.total = L.total_elems[lvl];
   const float fx0 = floorf(x0), fy0 = floorf(y0);
   const bool sane = live && (fabsf(x0) < 1.0e6f) && (fabsf(y0) < 1.0e6f);
-  const float dx = sane ? x0 - fx0 : 0.0f, dy = sane ? y0 - fy0 : 0.0f;
-  const int xb = sane ? (int)fx0 - 3 : -100000;
-  const int yb = sane ? (int)fy0 - 3 : -100000;
+  G.dx = sane ? x0 - fx0 : 0.0f;
+  G.dy = sane ? y0 - fy0 : 0.0f;
+  G.xb = sane ? (int)fx0 - 3 : -100000;
+  G.yb = sane ? (int)fy0 - 3 : -100000;
+  G.any_col = (G.xb > -8) && (G.xb < G.w2);
+  // the window row this lane owns
+  G.j = G.ntx > 0 ? ((r - G.yb) & 7) : r;
+  G.y1 = G.yb + G.j;
+  G.rowvalid = G.any_col && G.y1 >= 0 && G.y1 < G.h2;
+  return G;
+}
+// the loads of the lane's window row: unconditional, from an address that is always inside the tensor
+__device__ __forceinline__ void coop_issue(const CoopGeo& G, CoopRaw& raw) {
+  if (G.ntx > 0) {
+    const int tx0 = G.xb >> 3;
+    const bool okA = G.rowvalid && tx0 >= 0 && tx0 < G.ntx, okB = G.rowvalid && tx0 + 1 >= 0 && tx0 + 1 < G.ntx;
+    const long base = G.slice_off + ((long)(G.y1 >> 3) * G.ntx + tx0) * 64 + (G.y1 & 7) * 8;
+    raw.A = *reinterpret_cast<const u32x4*>(G.vol + (okA ? base : G.slice_off));
+    raw.B = *reinterpret_cast<const u32x4*>(G.vol + (okB ? base + 64 : G.slice_off));
+  } else {
+    const long g0 = G.slice_off + (long)G.y1 * G.w2 + G.xb;
+    const bool inb = g0 >= 0 && g0 + 8 <= G.total;
+    raw.A = (u32x4)0u;
+    if (G.total >= 8) {      // (uniform)
+      const long safe = G.slice_off + 8 <= G.total ? G.slice_off : G.total - 8;
+      const Run16 rr = *reinterpret_cast<const Run16*>(G.vol + ((G.rowvalid && inb) ? g0 : safe));
+      raw.A = (u32x4){rr.d[0], rr.d[1], rr.d[2], rr.d[3]};
+    }
+  }
+}
+template <int CS, int PS>
+__device__ __forceinline__ void coop_finish(const CoopGeo& G, const CoopRaw& raw, int t, uint16_t* __restrict__ ob) {
+  const int r = t & 7, pl = t >> 3;
+  const int w2 = G.w2, xb = G.xb, j = G.j;
+  const float dx = G.dx, dy = G.dy;
   uint32_t cm[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int xl = xb + 2 * k, xh = xl + 1;
     cm[k] = ((xl >= 0 && xl < w2) ? 0x0000ffffu : 0u) | ((xh >= 0 && xh < w2) ? 0xffff0000u : 0u);
   }
-  const bool any_col = (xb > -8) && (xb < w2);
-  // the window row this lane owns
-  const int j = ntx > 0 ? ((r - yb) & 7) : r;
-  const int y1 = yb + j;
-  const bool rowvalid = any_col && y1 >= 0 && y1 < h2;
   uint32_t row[4];
-  if (ntx > 0) {
+  if (G.ntx > 0) {
     const int tx0 = xb >> 3, c0 = xb & 7;
-    const bool okA = rowvalid && tx0 >= 0 && tx0 < ntx, okB = rowvalid && tx0 + 1 >= 0 && tx0 + 1 < ntx;
-    const long base = slice_off + ((long)(y1 >> 3) * ntx + tx0) * 64 + (y1 & 7) * 8;
-    const u32x4 A = *reinterpret_cast<const u32x4*>(vol + (okA ? base : slice_off));
-    const u32x4 B = *reinterpret_cast<const u32x4*>(vol + (okB ? base + 64 : slice_off));
+    const bool okA = G.rowvalid && tx0 >= 0 && tx0 < G.ntx, okB = G.rowvalid && tx0 + 1 >= 0 && tx0 + 1 < G.ntx;
     uint32_t D[9];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      D[k] = okA ? A[k] : 0u;
-      D[4 + k] = okB ? B[k] : 0u;
+      D[k] = okA ? raw.A[k] : 0u;
+      D[4 + k] = okB ? raw.B[k] : 0u;
     }
     D[8] = 0u;
     const uint32_t sel1 = (c0 & 2) ? ~0u : 0u, sel2 = (c0 & 4) ? ~0u : 0u, sh16 = (c0 & 1) ? 16u : 0u;
@@ -279,14 +319,13 @@ __device__ __forceinline__ void coop_level(const LookupLevels& L, int lvl, float
 #pragma unroll
     for (int k = 0; k < 4; k++) row[k] = __builtin_amdgcn_alignbit(F[k + 1], F[k], sh16) & cm[k];
   } else {
-    const long g0 = slice_off + (long)y1 * w2 + xb;
-    const bool inb = g0 >= 0 && g0 + 8 <= total;
-    if (rowvalid && inb) {
-      const Run16 rr = *reinterpret_cast<const Run16*>(vol + g0);
+    const long g0 = G.slice_off + (long)G.y1 * w2 + xb;
+    const bool inb = g0 >= 0 && g0 + 8 <= G.total;
+    if (G.rowvalid && inb) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) row[k] = rr.d[k] & cm[k];
-    } else if (rowvalid) {  // the run pokes outside the tensor (first / last slice only): element-wise, bounds-checked
-      const uint16_t* v16 = reinterpret_cast<const uint16_t*>(vol);
+      for (int k = 0; k < 4; k++) row[k] = raw.A[k] & cm[k];
+    } else if (G.rowvalid) {  // the run pokes outside the tensor (first / last slice only): element-wise, bounds-checked
+      const uint16_t* v16 = reinterpret_cast<const uint16_t*>(G.vol);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int xl = xb + 2 * k;
@@ -325,10 +364,17 @@ __device__ __forceinline__ void coop_level(const LookupLevels& L, int lvl, float
       acc = acc + as_h2(shn[k]) * W11;       // tap (a+1, b+1)
       const uint32_t u = as_u32(acc);
       const int a0 = 2 * k;
-      ob[(a0 * 7 + j) * COOP_PITCH + pl] = (uint16_t)(u & 0xffffu);
-      if (a0 + 1 < 7) ob[((a0 + 1) * 7 + j) * COOP_PITCH + pl] = (uint16_t)(u >> 16);
+      ob[(a0 * 7 + j) * CS + pl * PS] = (uint16_t)(u & 0xffffu);
+      if (a0 + 1 < 7) ob[((a0 + 1) * 7 + j) * CS + pl * PS] = (uint16_t)(u >> 16);
     }
   }
+}
+__device__ __forceinline__ void coop_level(const LookupLevels& L, int lvl, float cx, float cy, bool live, long vidx, int t,
+                                           uint16_t* __restrict__ ob) {
+  const CoopGeo G = coop_geo(L, lvl, cx, cy, live, vidx, t);
+  CoopRaw raw;
+  coop_issue(G, raw);
+  coop_finish<COOP_PITCH, 1>(G, raw, t, ob);
 }
 
 __global__ __launch_bounds__(512) void corr_lookup_coop_kernel(LookupLevels L, const float* __restrict__ coords,
@@ -399,53 +445,70 @@ typedef _Float16 lk_f16x8 __attribute__((ext_vector_type(8)));
 typedef float lk_f32x16 __attribute__((ext_vector_type(16)));
 #define ENC_K 208        // 196 lookup channels padded to 13 chunks of 16
 #define ENC_GROUPS 4     // 64-pixel groups per workgroup (the weight fragments are loaded once per workgroup)
+#define ENC_PP 216       // halves per pixel row of the LDS tile: 208 channels + 8 (432 B = 27 x 16 B: the 16-byte fragment reads of
+                         // 32 consecutive pixel rows fall on different bank groups)
 
-__global__ __launch_bounds__(512) void corr_lookup_enc_kernel(LookupLevels L, const float* __restrict__ coords, int interleaved,
+// Round 6 (91 us against a 57-us traffic floor, 0.51 of the HBM peak).  The tile is [pixel][channel] now: an
+// A fragment of the matrix-core phase is ONE 16-byte LDS read (round 4 kept [channel][pixel], the plain kernel's output order,
+// and gathered a fragment with eight two-byte reads: 104 LDS instructions per lane and group): 92.2 / 92.4 / 96.4 -> 88.6 / 86.3 /
+// 89.0 us per 48-edge launch, same box, interleaved, same bits.  Measured with it and NOT kept: the loads of level l + 1 in
+// flight while level l is blended, and the next group's coordinates, slot and level-0 loads requested before the matrix-core
+// phase (coop_geo / coop_issue / coop_finish exist for that; barriers waiting for LDS only): 128 registers + 32 B of scratch,
+// 96.4-98.3 us -- the kernel is not waiting on a chain of round trips (round 4 found the same with all four levels up front).
+__global__ __launch_bounds__(512, 4) void corr_lookup_enc_kernel(LookupLevels L, const float* __restrict__ coords, int interleaved,
                                                               const lk_f16x8* __restrict__ wfrag, const float* __restrict__ bias,
                                                               _Float16* __restrict__ out, int E, int HW1,
                                                               const int* __restrict__ slot) {
-  __shared__ __attribute__((aligned(16))) uint16_t ob[ENC_K * COOP_PITCH];   // 30 KB: [channel][64 pixels]
+  __shared__ __attribute__((aligned(16))) uint16_t ob[64 * ENC_PP];   // 27 KB: [64 pixels][208 channels + pad]
   const int t = threadIdx.x, pl = t >> 3;
   const int lane = t & 63, wave = t >> 6, j = lane & 31, h = lane >> 5;
   const int mt = wave & 1, nt = wave >> 1;             // the wave's output tile: pixels 32 mt.., channels 32 nt..
   const long total_px = (long)E * HW1;
-  for (int e = t; e < (ENC_K - 196) * COOP_PITCH; e += 512) ob[196 * COOP_PITCH + e] = 0;   // the pad channels stay zero
+  for (int e = t; e < 64 * (ENC_PP - 196); e += 512) ob[(e / (ENC_PP - 196)) * ENC_PP + 196 + e % (ENC_PP - 196)] = 0;   // pad channels
   lk_f16x8 Bf[13];
 #pragma unroll
   for (int c = 0; c < 13; c++) Bf[c] = wfrag[(nt * 13 + c) * 64 + lane];
   const float bj = bias[32 * nt + j];
+  // the lane's pixel of a group: coordinates + volume index
+  struct Px { float cx, cy; long vidx; bool live; };
+  auto pixel_of = [&](int g) {
+    Px P;
+    const long idx = ((long)blockIdx.x * ENC_GROUPS + g) * 64 + pl;
+    P.live = idx < total_px;
+    const long idc = P.live ? idx : total_px - 1;
+    const int n = (int)(idc / HW1);
+    const int p = (int)(idc - (long)n * HW1);
+    if (interleaved) {
+      const float2 c = *reinterpret_cast<const float2*>(coords + 2 * idc);
+      P.cx = c.x;
+      P.cy = c.y;
+    } else {
+      P.cx = coords[((long)n * 2 + 0) * HW1 + p];
+      P.cy = coords[((long)n * 2 + 1) * HW1 + p];
+    }
+    // slot-addressed pools: edge n reads volume index slot[n] (the edge list is reordered / shrunk without moving volumes)
+    P.vidx = slot ? (long)slot[n] * HW1 + p : idc;
+    return P;
+  };
+  CoopRaw raw;
   for (int g = 0; g < ENC_GROUPS; g++) {
     const long idx0 = ((long)blockIdx.x * ENC_GROUPS + g) * 64;
     if (idx0 >= total_px) break;                       // (uniform)
-    const long idx = idx0 + pl;
-    const bool live = idx < total_px;
-    const long idc = live ? idx : total_px - 1;
-    const int n = (int)(idc / HW1);
-    const int p = (int)(idc - (long)n * HW1);
-    float cx, cy;
-    if (interleaved) {
-      const float2 c = *reinterpret_cast<const float2*>(coords + 2 * idc);
-      cx = c.x;
-      cy = c.y;
-    } else {
-      cx = coords[((long)n * 2 + 0) * HW1 + p];
-      cy = coords[((long)n * 2 + 1) * HW1 + p];
-    }
-    const long vidx = slot ? (long)slot[n] * HW1 + p : idc;
-    __syncthreads();                                   // the previous group's tiles have been read
-    // (round 4, measured and not kept: the loads of all four levels issued before the first blend -- one memory round trip per
-    //  group instead of four: 100 -> 120 us per 48-edge launch; 32 more live registers, and the kernel sits on the L2 request
-    //  rate, not on a chain of round trips)
+    const Px cur = pixel_of(g);
+    lds_barrier();                                     // the previous group's fragments have been read (and the pad zeroed); its
+                                                       // output stores stay in flight (LDS-only barrier)
 #pragma unroll 1
-    for (int lvl = 0; lvl < 4; lvl++) coop_level(L, lvl, cx, cy, live, vidx, t, ob + lvl * 49 * COOP_PITCH);
-    __syncthreads();
+    for (int lvl = 0; lvl < 4; lvl++) {
+      const CoopGeo G = coop_geo(L, lvl, cur.cx, cur.cy, cur.live, cur.vidx, t);
+      coop_issue(G, raw);
+      coop_finish<1, ENC_PP>(G, raw, t, ob + lvl * 49);
+    }
+    lds_barrier();
     lk_f32x16 acc = (lk_f32x16)0.0f;
-    const uint16_t* xa = ob + 8 * h * COOP_PITCH + 32 * mt + j;      // A: row = pixel 32 mt + j, k = channel 16 c + 8 h + q
+    const uint16_t* xa = ob + (32 * mt + j) * ENC_PP + 8 * h;        // A: row = pixel 32 mt + j, k = channel 16 c + 8 h + q
 #pragma unroll
     for (int c = 0; c < 13; c++) {
-      lk_f16x8 a;
-#pragma unroll
-      for (int q = 0; q < 8; q++) a[q] = __builtin_bit_cast(_Float16, xa[(16 * c + q) * COOP_PITCH]);
+      const lk_f16x8 a = *reinterpret_cast<const lk_f16x8*>(xa + 16 * c);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bf[c], acc, 0, 0, 0);
     }
     // acc[r]: pixel 32 mt + 4 h + (r & 3) + 8 (r >> 2) of the group, channel 32 nt + j
