@@ -172,7 +172,13 @@ __global__ __launch_bounds__(256 * CG) void conv_nhwc_kernel(ConvArgs a) {
     cwsrc = a.wp + ((long)c * T * ctiles + cz * MT) * 64;
   };
   auto load_slab_piece = [&](int q) __attribute__((always_inline)) {   // unconditional: no branch inside the MFMA stream
-    ps[q] = *reinterpret_cast<const uint4*>(cbase + g_pix[q] * csch + ccoff);
+    // Through an address-space-1 pointer: `cbase` is rebuilt from integers (above), so a plain dereference is a FLAT load -- and
+    // flat loads count on lgkmcnt as well as vmcnt (they might hit LDS): every `s_waitcnt lgkmcnt(0)` in front of a tap's first
+    // MFMA then also waited for the next chunk's slab pieces to come back from L2 / HBM (round 6, found in the ISA).
+    typedef uint32_t cv_u32x4 __attribute__((ext_vector_type(4)));
+    const cv_u32x4 d = *reinterpret_cast<const __attribute__((address_space(1))) cv_u32x4*>(
+        reinterpret_cast<uintptr_t>(cbase + g_pix[q] * csch + ccoff));
+    ps[q] = make_uint4(d[0], d[1], d[2], d[3]);
   };
   // The LDS-DMA is issued from inline asm, invisible to the compiler: as a builtin it is a pending LDS write that the
   // waitcnt pass cannot tell apart from the other stage (one array, dynamic index), so every fragment read waited for
