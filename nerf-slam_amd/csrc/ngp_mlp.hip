@@ -43,17 +43,32 @@ struct MlpFwdArgs {
 // activations for that cost 384 B per sample and put three rounds of 16 dependent loads on the critical path of the
 // activation-gradient kernel.  The forward pass therefore also writes ONE BIT per unit: lane (j, h) holds, for its two samples,
 // the 32 units {acc_unit(it, h, r)} of each 64-wide layer -- exactly the units the backward lane (j, h) will hold in its
-// accumulators (same instruction, same layout) -- so its word for sample n is  bit (16 it + r) = [h(unit) > 0],  stored at
-// masks[layer][h][n]: the two words of a lane are adjacent (8 B per lane, 256 contiguous bytes per half-wave).  24 B per sample
-// written by the forward pass, 24 B read by the backward pass at its very start.
-__device__ __forceinline__ uint32_t relu_bits(const f16x8& lo, const f16x8& hi, int it) {
-  uint32_t m = 0;
+// accumulators (same instruction, same layout).  Its word for sample n (round 6 layout: the two halves of a PACKED pair of
+// accumulator registers 2p, 2p + 1 of tile `it` sit 16 bits apart, so that both kernels work on packed halves):
+//     bit (8 it + p) = [h(unit of register 2p) > 0],   bit (16 + 8 it + p) = [h(unit of register 2p + 1) > 0]
+// stored at masks[layer][h][n]: the two words of a lane are adjacent (8 B per lane, 256 contiguous bytes per half-wave).  24 B per
+// sample written by the forward pass, 24 B read by the backward pass at its very start.
+//
+// relu_tile: ReLU + f16 rounding + mask bits of one 32-unit accumulator tile, 7 vector instructions per PAIR of values (v_max_i32
+// x 2, v_cvt_pk_f16_f32, add / shift / and = "is the half non-zero", v_lshl_or_b32).  The plain form -- fmaxf (a
+// canonicalising second v_max_f32 each), a compare + select + shift-or per value for the bit -- was 11 per pair, and with 1342
+// vector instructions against 48 MFMAs per 64 samples the forward kernel is bound by exactly these (round 6).  Same values, same
+// bits: the integer max of a negative value's or -0's bits with 0 is +0, so "non-zero half" is "activation > 0".
+__device__ __forceinline__ void relu_tile(const f32x16& acc, int it, f16x8* out, uint32_t& mask) {
 #pragma unroll
-  for (int r = 0; r < 8; r++) {
-    m |= ((float)lo[r] > 0.0f ? 1u : 0u) << (16 * it + r);
-    m |= ((float)hi[r] > 0.0f ? 1u : 0u) << (16 * it + 8 + r);
+  for (int p = 0; p < 8; p++) {
+    // (no inline asm on an accumulator: the compiler places the MFMA -> VALU wait states only for instructions it can see)
+    // ReLU on the float's bits as a signed integer (negative values and -0 have the sign bit set -> +0): ONE v_max_i32; fmaxf
+    // and fmed3 are each emitted with a canonicalising second v_max_f32
+    const int ia = __builtin_bit_cast(int, (float)acc[2 * p]), ib = __builtin_bit_cast(int, (float)acc[2 * p + 1]);
+    const float a = __builtin_bit_cast(float, ia > 0 ? ia : 0), b = __builtin_bit_cast(float, ib > 0 ? ib : 0);
+    const f16x2 v = {(_Float16)a, (_Float16)b};
+    // both halves are >= +0: adding 0x7fff carries into bit 15 exactly when a half is non-zero
+    const uint32_t nz = ((__builtin_bit_cast(uint32_t, v) + 0x7fff7fffu) >> 15) & 0x00010001u;
+    mask |= nz << (8 * it + p);
+    out[p >> 2][2 * (p & 3)] = v[0];
+    out[p >> 2][2 * (p & 3) + 1] = v[1];
   }
-  return m;
 }
 __device__ __forceinline__ uint2* mask_at(uint32_t* masks, int layer, int h, long N, long np) {
   return reinterpret_cast<uint2*>(masks + ((long)(layer * 2 + h) * N + np));
@@ -63,7 +78,7 @@ __device__ __forceinline__ uint2* mask_at(uint32_t* masks, int layer, int h, lon
 // test: the trainer's form (masks only) then is compiled without the store path's 64-bit row addresses -- 204 -> 148 registers,
 // three waves per SIMD instead of two, 31 -> 26 us (four waves: 128 registers + 44 B of scratch, 24 us, not taken).
 template <bool SAVE>
-__global__ __launch_bounds__(256, SAVE ? 2 : 3) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
+__global__ __launch_bounds__(256, SAVE ? 2 : 4) void ngp_mlp_fwd_kernel(MlpFwdArgs a) {
   __shared__ f16x8 Wf[FW_NFRAG * 64];
   if (a.frags != nullptr) {      // (workgroup-uniform)
 #pragma unroll
@@ -99,19 +114,15 @@ __global__ __launch_bounds__(256, SAVE ? 2 : 3) void ngp_mlp_fwd_kernel(MlpFwdAr
     const bool st = save && ok;
     _Float16 res[2][4];
     f16x8 h1[2][4], cin[2][2];
+    uint32_t mk_h1[2] = {0u, 0u}, mk_h3[2] = {0u, 0u}, mk_h4[2] = {0u, 0u};
 #pragma unroll
     for (int it = 0; it < 2; it++) {  // L1 32 -> 64, ReLU
 #pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const f32x16 acc = layer_tile<2>(Wf, FW_L1, it, lane, x[t]);
-#pragma unroll
-        for (int r = 0; r < 16; r++) h1[t][2 * it + (r >> 3)][r & 7] = (_Float16)fmaxf(acc[r], 0.0f);
-      }
+      for (int t = 0; t < 2; t++) relu_tile(layer_tile<2>(Wf, FW_L1, it, lane, x[t]), it, &h1[t][2 * it], mk_h1[t]);
       if (st) store_tile(a.h1T, N, boff, it, &h1[0][2 * it], &h1[1][2 * it]);
     }
     if (ok && a.masks)
-      *mask_at(a.masks, 0, h, N, np) = make_uint2(relu_bits(h1[0][0], h1[0][1], 0) | relu_bits(h1[0][2], h1[0][3], 1),
-                                                  relu_bits(h1[1][0], h1[1][1], 0) | relu_bits(h1[1][2], h1[1][3], 1));
+      *mask_at(a.masks, 0, h, N, np) = make_uint2(mk_h1[0], mk_h1[1]);
 #pragma unroll
     for (int t = 0; t < 2; t++) {  // L2 64 -> 16 (rows 16..31 of the tile are padding) + direction encoding
       const f32x16 acc = layer_tile<4>(Wf, FW_L2, 0, lane, h1[t]);
@@ -126,30 +137,20 @@ __global__ __launch_bounds__(256, SAVE ? 2 : 3) void ngp_mlp_fwd_kernel(MlpFwdAr
 #pragma unroll
     for (int it = 0; it < 2; it++) {  // L3 32 -> 64, ReLU
 #pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const f32x16 acc = layer_tile<2>(Wf, FW_L3, it, lane, cin[t]);
-#pragma unroll
-        for (int r = 0; r < 16; r++) h3[t][2 * it + (r >> 3)][r & 7] = (_Float16)fmaxf(acc[r], 0.0f);
-      }
+      for (int t = 0; t < 2; t++) relu_tile(layer_tile<2>(Wf, FW_L3, it, lane, cin[t]), it, &h3[t][2 * it], mk_h3[t]);
       if (st) store_tile(a.h3T, N, boff, it, &h3[0][2 * it], &h3[1][2 * it]);
     }
     if (ok && a.masks)
-      *mask_at(a.masks, 1, h, N, np) = make_uint2(relu_bits(h3[0][0], h3[0][1], 0) | relu_bits(h3[0][2], h3[0][3], 1),
-                                                  relu_bits(h3[1][0], h3[1][1], 0) | relu_bits(h3[1][2], h3[1][3], 1));
+      *mask_at(a.masks, 1, h, N, np) = make_uint2(mk_h3[0], mk_h3[1]);
     f16x8 h4[2][4];
 #pragma unroll
     for (int it = 0; it < 2; it++) {  // L4 64 -> 64, ReLU
 #pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const f32x16 acc = layer_tile<4>(Wf, FW_L4, it, lane, h3[t]);
-#pragma unroll
-        for (int r = 0; r < 16; r++) h4[t][2 * it + (r >> 3)][r & 7] = (_Float16)fmaxf(acc[r], 0.0f);
-      }
+      for (int t = 0; t < 2; t++) relu_tile(layer_tile<4>(Wf, FW_L4, it, lane, h3[t]), it, &h4[t][2 * it], mk_h4[t]);
       if (st) store_tile(a.h4T, N, boff, it, &h4[0][2 * it], &h4[1][2 * it]);
     }
     if (ok && a.masks)
-      *mask_at(a.masks, 2, h, N, np) = make_uint2(relu_bits(h4[0][0], h4[0][1], 0) | relu_bits(h4[0][2], h4[0][3], 1),
-                                                  relu_bits(h4[1][0], h4[1][1], 0) | relu_bits(h4[1][2], h4[1][3], 1));
+      *mask_at(a.masks, 2, h, N, np) = make_uint2(mk_h4[0], mk_h4[1]);
 #pragma unroll
     for (int t = 0; t < 2; t++) {  // L5 64 -> 16
       const f32x16 acc = layer_tile<4>(Wf, FW_L5, 0, lane, h4[t]);
@@ -192,21 +193,34 @@ __device__ __forceinline__ void mask_tile(const f32x16& acc0, const f32x16& acc1
   }
 }
 
-// the same with the ReLU derivative taken from the forward pass's bit mask (bit 16 it + r of the lane's word): no loads
+// the same with the ReLU derivative taken from the forward pass's bit mask (layout: see relu_tile): no loads, and on PACKED pairs
+// -- v_cvt_pk_f16_f32, then the pair's two mask bits (16 apart) widened to 0x0000 / 0xffff per half with one 24-bit multiply and
+// applied with one AND: 5 vector instructions per pair where the per-value select took 9 (round 6)
 __device__ __forceinline__ void mask_tile_bits(const f32x16& acc0, const f32x16& acc1, uint32_t m0, uint32_t m1,
                                                _Float16* __restrict__ dT, long N, uint32_t boff, bool ok, int it, f16x8* o0,
                                                f16x8* o1) {
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const _Float16 v0 = (m0 >> (16 * it + r)) & 1u ? (_Float16)acc0[r] : (_Float16)0;
-    const _Float16 v1 = (m1 >> (16 * it + r)) & 1u ? (_Float16)acc1[r] : (_Float16)0;
-    o0[r >> 3][r & 7] = v0;
-    o1[r >> 3][r & 7] = v1;
-    if (ok && dT != nullptr) *um_at(dT + (long)urow(it, r) * N, boff) = pack2(v0, v1);   // (dT: wave-uniform)
+  for (int p = 0; p < 8; p++) {
+    const f16x2 a = {(_Float16)acc0[2 * p], (_Float16)acc0[2 * p + 1]};
+    const f16x2 b = {(_Float16)acc1[2 * p], (_Float16)acc1[2 * p + 1]};
+    const uint32_t k0 = __umul24((m0 >> (8 * it + p)) & 0x00010001u, 0xffffu);
+    const uint32_t k1 = __umul24((m1 >> (8 * it + p)) & 0x00010001u, 0xffffu);
+    const f16x2 v0 = __builtin_bit_cast(f16x2, __builtin_bit_cast(uint32_t, a) & k0);
+    const f16x2 v1 = __builtin_bit_cast(f16x2, __builtin_bit_cast(uint32_t, b) & k1);
+    o0[p >> 2][2 * (p & 3)] = v0[0];
+    o0[p >> 2][2 * (p & 3) + 1] = v0[1];
+    o1[p >> 2][2 * (p & 3)] = v1[0];
+    o1[p >> 2][2 * (p & 3) + 1] = v1[1];
+    if (ok && dT != nullptr) {   // (dT: wave-uniform)
+      *um_at(dT + (long)urow(it, 2 * p) * N, boff) = pack2(v0[0], v1[0]);
+      *um_at(dT + (long)urow(it, 2 * p + 1) * N, boff) = pack2(v0[1], v1[1]);
+    }
   }
 }
 
-template <bool BITS>
+// LEAN (round 6): the trainer's form -- bit masks in, dL/dfeature out, none of the five unit-major gradient tensors -- compiled
+// without their store paths: as run-time tests of wave-uniform null pointers they were ~100 scalar branches through the chain.
+template <bool BITS, bool LEAN = false>
 __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
   __shared__ f16x8 Wf[BW_NFRAG * 64];
   if (a.frags != nullptr) {      // (workgroup-uniform)
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < 8; q++)
-      if (ok && a.d5T != nullptr) *um_at(a.d5T + (long)ufrag(0, q) * N, boff) = pack2(d5[0][q], d5[1][q]);
+      if (!LEAN && ok && a.d5T != nullptr) *um_at(a.d5T + (long)ufrag(0, q) * N, boff) = pack2(d5[0][q], d5[1][q]);
     // layer 5^T (K = 16) -> d(h4), ReLU' of layer 4
     f16x8 d4[2][4], d3[2][4], dd[2], d1[2][4];
 #pragma unroll
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
       const f32x16 a0 = layer_tile<1>(Wf, BW_L5, it, lane, &d5[0]);
       const f32x16 a1 = layer_tile<1>(Wf, BW_L5, it, lane, &d5[1]);
       if (BITS) {
-        mask_tile_bits(a0, a1, mk4.x, mk4.y, a.d4T, N, boff, ok, it, &d4[0][2 * it], &d4[1][2 * it]);
+        mask_tile_bits(a0, a1, mk4.x, mk4.y, LEAN ? nullptr : a.d4T, N, boff, ok, it, &d4[0][2 * it], &d4[1][2 * it]);
       } else {
         asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
         mask_tile(a0, a1, a.h4T, a.d4T, N, boff, ok, it, &d4[0][2 * it], &d4[1][2 * it]);
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
       const f32x16 a0 = layer_tile<4>(Wf, BW_L4, it, lane, d4[0]);
       const f32x16 a1 = layer_tile<4>(Wf, BW_L4, it, lane, d4[1]);
       if (BITS) {
-        mask_tile_bits(a0, a1, mk3.x, mk3.y, a.d3T, N, boff, ok, it, &d3[0][2 * it], &d3[1][2 * it]);
+        mask_tile_bits(a0, a1, mk3.x, mk3.y, LEAN ? nullptr : a.d3T, N, boff, ok, it, &d3[0][2 * it], &d3[1][2 * it]);
       } else {
         asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
         mask_tile(a0, a1, a.h3T, a.d3T, N, boff, ok, it, &d3[0][2 * it], &d3[1][2 * it]);
@@ -292,14 +306,14 @@ __global__ __launch_bounds__(256, 4) void ngp_mlp_bwd_kernel(MlpBwdArgs a) {
       }
 #pragma unroll
       for (int q = 0; q < 8; q++)
-        if (ok && a.ddT != nullptr) *um_at(a.ddT + (long)ufrag(0, q) * N, boff) = pack2(dd[0][q], dd[1][q]);
+        if (!LEAN && ok && a.ddT != nullptr) *um_at(a.ddT + (long)ufrag(0, q) * N, boff) = pack2(dd[0][q], dd[1][q]);
     }
 #pragma unroll
     for (int it = 0; it < 2; it++) {
       const f32x16 a0 = layer_tile<1>(Wf, BW_L2, it, lane, &dd[0]);
       const f32x16 a1 = layer_tile<1>(Wf, BW_L2, it, lane, &dd[1]);
       if (BITS) {
-        mask_tile_bits(a0, a1, mk1.x, mk1.y, a.d1T, N, boff, ok, it, &d1[0][2 * it], &d1[1][2 * it]);
+        mask_tile_bits(a0, a1, mk1.x, mk1.y, LEAN ? nullptr : a.d1T, N, boff, ok, it, &d1[0][2 * it], &d1[1][2 * it]);
       } else {
         asm volatile("" ::: "memory");  // keep the mask loads of later tiles / layers from being hoisted up here
         mask_tile(a0, a1, a.h1T, a.d1T, N, boff, ok, it, &d1[0][2 * it], &d1[1][2 * it]);
@@ -703,7 +717,9 @@ static int mlp_dgrad_launch(const void* weights, const void* dLdout, const void*
                (const _Float16*)h4T,     (_Float16*)dLdfeatT,     (_Float16*)d5T,       (_Float16*)d4T,
                (_Float16*)d3T,           (_Float16*)ddT,          (_Float16*)d1T,       N,
                n_dev,                    (const uint32_t*)relu_masks, (const f16x8*)frags};
-  if (relu_masks != nullptr)
+  if (relu_masks != nullptr && !d5T && !d4T && !d3T && !ddT && !d1T)
+    hipLaunchKernelGGL((ngp_mlp_bwd_kernel<true, true>), dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, st, b);
+  else if (relu_masks != nullptr)
     hipLaunchKernelGGL(ngp_mlp_bwd_kernel<true>, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, st, b);
   else
     hipLaunchKernelGGL(ngp_mlp_bwd_kernel<false>, dim3(ns_cdiv(N, 256 * MLP_ITERS)), dim3(256), 0, st, b);

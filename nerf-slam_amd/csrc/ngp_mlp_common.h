@@ -15,6 +15,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define W_TOTAL 10240
 
 __device__ __forceinline__ void sh16(float x, float y, float z, float* o) {
+#pragma clang fp contract(off)          // (see sh_term)
   const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
   o[0] = 0.28209479177387814f;
   o[1] = -0.48860251190291987f * y;
@@ -39,6 +40,11 @@ __device__ __forceinline__ void sh16(float x, float y, float z, float* o) {
 // workgroup, where the private array could be promoted) and came back with a per-lane offset.  One term by compile-time index
 // instead (the switch folds away after unrolling, the shared products are CSE'd): no array at all.
 __device__ __forceinline__ float sh_term(int k, float x, float y, float z) {
+  // No contraction: with the default (fast) mode whether `c * (z * z) - d` becomes an fma depends on what ELSE the kernel around
+  // this inline function does with z * z -- round 6 changed the ReLU of the forward kernel and 3 of 262 144 outputs moved by an
+  // ulp, because the direction encoding had been compiled differently.  Separately rounded products are what the oracle
+  // computes (-ffp-contract=off) and what every kernel that includes this header now computes, whatever surrounds the call.
+#pragma clang fp contract(off)
   switch (k) {
     case 0: return 0.28209479177387814f;
     case 1: return -0.48860251190291987f * y;
