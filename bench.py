@@ -356,21 +356,22 @@ def micro_benches(dev, hp, ngp_net):
                                           stream_ptr()), "ngp_encode_forward")
 
     # table gradient WITH the optimiser step on the touched entries, on scratch copies of the parameters / moments
-    # (in the product's layout: one 32-byte record per entry, nerfslam/ngp.py: new_grid_state; NS_ADAM_SEPARATE=1 with the master
+    # (in the product's layout: one 24-byte record per entry, nerfslam/ngp.py: new_grid_state; NS_ADAM_SEPARATE=1 with the master
     #  switch: three dense arrays, rounds 2-4's layout, for the A/B)
     from nerfslam._lib import variant_env
     if variant_env("NS_ADAM_SEPARATE"):
         bw = {k: torch.zeros(net.n_grid, dtype=torch.float32, device=dev) for k in ("master", "m1", "m2")}
     else:
-        bw = dict(zip(("rec", "master", "m1", "m2"), type(net).new_grid_state(net.n_grid // 2, dev)))
+        bw = dict(zip(("rec", "master", "m1", "m2"), type(net).new_grid_state(net.n_grid // 2, dev, net.state_rec)))
+    rec_floats = 2 if variant_env("NS_ADAM_SEPARATE") else net.state_rec
     bw["hp"] = torch.zeros_like(net.grid_half)
     wsb = int(L.ns_ngp_encode_backward_fused_workspace_bytes(*args, C.c_long(S)))
     bws = torch.zeros(wsb // 8 + 1, dtype=torch.int64, device=dev)
 
     def enc_bwd(parts=15):
-        check(L.ns_ngp_encode_backward_fused_n(*args, ptr(X["s_pos"]), ptr(net.s_dfeat), None, ptr(bws), C.c_size_t(wsb),
+        check(L.ns_ngp_encode_backward_fused_rec_n(*args, ptr(X["s_pos"]), ptr(net.s_dfeat), None, ptr(bws), C.c_size_t(wsb),
                                                C.c_float(cf.grad_fixed_scale), C.c_long(S), n_dev, ptr(bw["master"]), ptr(bw["hp"]),
-                                               ptr(bw["m1"]), ptr(bw["m2"]), 7, C.c_float(cf.lr), C.c_float(cf.beta1),
+                                               ptr(bw["m1"]), ptr(bw["m2"]), rec_floats, 7, C.c_float(cf.lr), C.c_float(cf.beta1),
                                                C.c_float(cf.beta2), C.c_float(cf.eps), C.c_float(cf.loss_scale), None, parts, stream_ptr()),
               "ngp_encode_backward_fused")
     # table entries the call touches (their optimiser step is part of the call): one gradient-only run, non-zero words counted

@@ -558,6 +558,13 @@ int ns_ngp_camera_step_ctl(float* c2w, float* cam_grad, float* m1, float* m2, in
                            float beta1, float beta2, float eps, float grad_scale, const int* ctl, void* stream);
 int ns_ngp_adam_ctl(float* master, void* half_params, float* grad, float* m1, float* m2, long n, int step, float lr, float beta1,
                     float beta2, float eps, float l2, float grad_scale, float fixed_scale, const int* ctl, void* stream);
+/* ns_ngp_adam_ctl with the layout of the optimiser state TOLD (round 6; ADVICE r05: not inferred from the pointers): record_floats
+ * = 2 (three dense arrays), 8 (round 5's 32-byte record per table entry: [master.xy | m1.xy | m2.xy | unused], base 16-byte
+ * aligned) or 6 (24-byte record, base 8-byte aligned); for 6 / 8, m1 == master + 2 and m2 == master + 4 floats is REQUIRED
+ * (checked).  The entry points without `_rec` pass 0 = "tell from the pointers" (8 or 2), as rounds 2-5 did.            */
+int ns_ngp_adam_rec_ctl(float* master, void* half_params, float* grad, float* m1, float* m2, int record_floats, long n, int step,
+                        float lr, float beta1, float beta2, float eps, float l2, float grad_scale, float fixed_scale,
+                        const int* ctl, void* stream);
 int ns_ngp_step_advance(int* ctl, int* counter, int* last, float fill, long max_samples, int min_rays, int max_rays,
                         float beta1, float beta2, void* stream);
 /* Double-buffered form of the above (round 3; nerfslam/ngp.py): opens the side branch of step k that samples and marches the
@@ -622,6 +629,12 @@ int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int log2_hashma
                                    size_t workspace_bytes, float fixed_scale, long N, const int* n_dev, float* master,
                                    void* half_params, float* m1, float* m2, int step, float lr, float beta1, float beta2,
                                    float eps, float grad_scale, const int* ctl, int parts, void* stream);
+/* the same with the record layout told (see ns_ngp_adam_rec_ctl): what the trainer calls */
+int ns_ngp_encode_backward_fused_rec_n(int n_levels, int n_features, int log2_hashmap, int base_res, float per_level_scale,
+                                       const float* positions, const void* dLdoutT, float* grad_params, void* workspace,
+                                       size_t workspace_bytes, float fixed_scale, long N, const int* n_dev, float* master,
+                                       void* half_params, float* m1, float* m2, int record_floats, int step, float lr, float beta1,
+                                       float beta2, float eps, float grad_scale, const int* ctl, int parts, void* stream);
 
 /* Replicated trainers (`--multi_gpu` with more than one mapper; reference boundary examples/slam_demo.py:63-77): what
  * the trainers exchange is the LIST of table entries a step touched, not the table.
@@ -640,6 +653,10 @@ int ns_ngp_encode_backward_fused_emit_n(int n_levels, int n_features, int log2_h
 int ns_ngp_sparse_table_update(const void* lists, const int* counts, int n_lists, long stride, long max_count, void* acc,
                                float* master, void* half_params, float* m1, float* m2, int step, float lr, float beta1,
                                float beta2, float eps, float grad_scale, float fixed_scale, const int* ctl, void* stream);
+int ns_ngp_sparse_table_update_rec(const void* lists, const int* counts, int n_lists, long stride, long max_count, void* acc,
+                                   float* master, void* half_params, float* m1, float* m2, int record_floats, int step, float lr,
+                                   float beta1, float beta2, float eps, float grad_scale, float fixed_scale, const int* ctl,
+                                   void* stream);
 int ns_ngp_mlp_forward_n(const void* weights, const void* featT, const float* dirs, void* out, void* h1T, void* cinT, void* h3T,
                          void* h4T, long N, const int* n_dev, void* stream);
 int ns_ngp_mlp_backward_n(const void* weights, const void* dLdout, const void* featT, const void* h1T, const void* cinT,

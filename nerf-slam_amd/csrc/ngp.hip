@@ -702,19 +702,28 @@ struct AdamFuse {
   float* m2;
   float c1, c2, lr, beta1, beta2, eps, inv_grad_scale, inv_fixed_scale;
   const int* ctl;
-  int es;   // floats from one table entry to the next in master / m1 / m2: 2 = three dense arrays, 8 = one 32-byte record per entry
+  int es;   // floats from one table entry to the next in master / m1 / m2: 2 = three dense arrays, 8 / 6 = one 32- / 24-byte record per entry
   // replicated trainers (master == nullptr): the flush APPENDS the touched entries, (entry, packed sum), to this list instead
   // of updating or adding to a dense buffer -- what the trainers exchange (ns_ngp_encode_backward_fused_emit_n)
   ulonglong2* emit_list;
   int* emit_count;
 };
 
-// Layout of the optimiser state, told from the pointers (include/nerfslam_hip.h, ns_ngp_adam): m1 == master + 2 and m2 == master + 4
-// is the interleaved form -- table entry e keeps [master.xy | m1.xy | m2.xy | 8 B unused] in ONE 32-byte record at master + 8 e.
-// A sparsely touched entry then costs one 128-byte line (four entries per line) instead of three (sixteen entries per line in
-// each of three arrays, of which a step touches 13 % on a fine level: 89 % of all lines against 43 %).
-static inline int adam_entry_stride(const float* master, const float* m1, const float* m2) {
-  return (m1 == master + 2 && m2 == master + 4) ? 8 : 2;
+// Layout of the optimiser state.  Three dense arrays, or ONE record per table entry, [master.xy | m1.xy | m2.xy (| 8 B unused)]:
+// a sparsely touched entry then costs one 128-byte line instead of three (sixteen entries per line in each of three arrays, of
+// which a step touched 13 % on a fine level at the 2^18 resolution: 89 % of all lines against 43 %).  Round 6: the `_rec` entry
+// points are TOLD the record size (not inferred) -- 8 floats (round 5's 32-byte record) or 6: at the 2^22 resolution
+// a step touches 45 % of a fine level's entries, nearly every line of the state, and the 8 unused bytes were a quarter of the
+// flush's traffic.  record_floats == 0 (the older entry points): told from the pointers as before -- m1 == master + 2 and
+// m2 == master + 4 means 32-byte records, anything else three arrays.  A record's fields are read as 16 + 8 bytes (8 floats:
+// base 16-byte aligned) or 8 + 8 + 8 (6 floats: 8-byte aligned).  -1: invalid.
+static inline int adam_entry_stride(const float* master, const float* m1, const float* m2, int record_floats = 0) {
+  const bool inter = (m1 == master + 2 && m2 == master + 4);
+  if (record_floats == 0) return inter ? 8 : 2;
+  if (record_floats == 2) return inter ? -1 : 2;
+  if ((record_floats != 6 && record_floats != 8) || !inter) return -1;
+  if (((uintptr_t)master & (record_floats == 8 ? 15 : 7)) != 0) return -1;
+  return record_floats;
 }
 
 // Adam on the two parameters of table entry `entry` from the packed fixed-point sum `word` (!= 0); parameters whose own
@@ -725,7 +734,15 @@ __device__ __forceinline__ void adam_entry(const AdamFuse& ad, long entry, unsig
   g0 *= ad.inv_grad_scale;
   g1 *= ad.inv_grad_scale;
   float2 p, a, b;
-  if (ad.es == 8) {       // (uniform) one record: 16 + 8 bytes of one line in, the same out
+  if (ad.es == 6) {       // (uniform) one 24-byte record: three 8-byte fields in, the same out
+    float2* __restrict__ rec = reinterpret_cast<float2*>(ad.master + entry * 6);
+    p = rec[0], a = rec[1], b = rec[2];
+    if (g0 != 0.0f) p.x = adam_apply(p.x, g0, 0.0f, a.x, b.x, c1, c2, ad.lr, ad.beta1, ad.beta2, ad.eps);
+    if (g1 != 0.0f) p.y = adam_apply(p.y, g1, 0.0f, a.y, b.y, c1, c2, ad.lr, ad.beta1, ad.beta2, ad.eps);
+    rec[0] = p;
+    rec[1] = a;
+    rec[2] = b;
+  } else if (ad.es == 8) {       // (uniform) one record: 16 + 8 bytes of one line in, the same out
     float* __restrict__ rec = ad.master + entry * 8;
     const float4 pa = *reinterpret_cast<const float4*>(rec);
     b = *reinterpret_cast<const float2*>(rec + 4);
@@ -2106,7 +2123,7 @@ __global__ __launch_bounds__(256) void ngp_adam_kernel(float* __restrict__ maste
   }
   __builtin_amdgcn_wave_barrier();
   grad[i] = 0.0f;  // leaves the gradient buffer ready for the next step (each lane clears its half of the word)
-  // es = 2: dense arrays, parameter i at [i].  es = 8 (adam_entry_stride): parameter i is field (i & 1) of entry i >> 1's record;
+  // es = 2: dense arrays, parameter i at [i].  es = 8 / 6 (adam_entry_stride): parameter i is field (i & 1) of entry i >> 1's record;
   // an untouched parameter's record is then not read at all -- its working copy already is the rounded master (every writer
   // of one writes the other) -- so that a sparse gradient costs the touched records, not a sweep over 32 B per entry.
   const long k = es == 2 ? i : (i >> 1) * es + (i & 1);
@@ -2947,7 +2964,8 @@ static int fused_backward_impl(int n_levels, int n_features, int log2_hashmap, i
                                const float* positions, const void* dLdoutT, float* grad_params, void* workspace,
                                size_t workspace_bytes, float fixed_scale, long N, const int* n_dev, float* master,
                                void* half_params, float* m1, float* m2, int step, float lr, float beta1, float beta2, float eps,
-                               float grad_scale, const int* ctl, int parts, void* stream, ulonglong2* emit_list, int* emit_count) {
+                               float grad_scale, const int* ctl, int parts, void* stream, ulonglong2* emit_list, int* emit_count,
+                               int record_floats = 0) {
   NS_REQUIRE(positions && dLdoutT && workspace, "ns_ngp_encode_backward_fused: null pointer");
   NS_REQUIRE(parts >= 1 && parts <= 15, "ns_ngp_encode_backward_fused: parts is a mask of 1 | 2 | 4 | 8");
   NS_REQUIRE(fixed_scale > 0.0f, "ns_ngp_encode_backward_fused: packed fixed-point sums only (fixed_scale > 0)");
@@ -2990,8 +3008,10 @@ static int fused_backward_impl(int n_levels, int n_features, int log2_hashmap, i
     ad.hp = (_Float16*)half_params;
     ad.m1 = m1;
     ad.m2 = m2;
-    ad.es = adam_entry_stride(master, m1, m2);
-    NS_REQUIRE(ad.es == 2 || ((uintptr_t)master & 15) == 0,
+    ad.es = adam_entry_stride(master, m1, m2, record_floats);
+    NS_REQUIRE(ad.es > 0, "ns_ngp_encode_backward_fused: record_floats = %d does not describe master / m1 / m2 (6 or 8: m1 == master + 2, "
+               "m2 == master + 4 floats, base 8- / 16-byte aligned; 2: three arrays)", record_floats);
+    NS_REQUIRE(ad.es != 8 || ((uintptr_t)master & 15) == 0,
                "ns_ngp_encode_backward_fused: interleaved optimiser records need a 16-byte aligned base (float4 accesses)");
     ad.c1 = 1.0f - powf(beta1, (float)(step < 1 ? 1 : step));
     ad.c2 = 1.0f - powf(beta2, (float)(step < 1 ? 1 : step));
@@ -3097,6 +3117,18 @@ extern "C" int ns_ngp_encode_backward_fused_n(int n_levels, int n_features, int 
                              grad_scale, ctl, parts, stream, nullptr, nullptr);
 }
 
+extern "C" int ns_ngp_encode_backward_fused_rec_n(int n_levels, int n_features, int log2_hashmap, int base_res,
+                                                  float per_level_scale, const float* positions, const void* dLdoutT,
+                                                  float* grad_params, void* workspace, size_t workspace_bytes, float fixed_scale,
+                                                  long N, const int* n_dev, float* master, void* half_params, float* m1,
+                                                  float* m2, int record_floats, int step, float lr, float beta1, float beta2,
+                                                  float eps, float grad_scale, const int* ctl, int parts, void* stream) {
+  NS_REQUIRE(record_floats == 2 || record_floats == 6 || record_floats == 8, "ns_ngp_encode_backward_fused_rec: record_floats is 2, 6 or 8");
+  return fused_backward_impl(n_levels, n_features, log2_hashmap, base_res, per_level_scale, positions, dLdoutT, grad_params, workspace,
+                             workspace_bytes, fixed_scale, N, n_dev, master, half_params, m1, m2, step, lr, beta1, beta2, eps,
+                             grad_scale, ctl, parts, stream, nullptr, nullptr, record_floats);
+}
+
 extern "C" int ns_ngp_encode_backward_fused_emit_n(int n_levels, int n_features, int log2_hashmap, int base_res,
                                                    float per_level_scale, const float* positions, const void* dLdoutT,
                                                    void* workspace, size_t workspace_bytes, float fixed_scale, long N,
@@ -3112,6 +3144,14 @@ extern "C" int ns_ngp_sparse_table_update(const void* lists, const int* counts, 
                                           float* master, void* half_params, float* m1, float* m2, int step, float lr, float beta1,
                                           float beta2, float eps, float grad_scale, float fixed_scale, const int* ctl,
                                           void* stream) {
+  return ns_ngp_sparse_table_update_rec(lists, counts, n_lists, stride, max_count, acc, master, half_params, m1, m2, 0, step, lr, beta1,
+                                        beta2, eps, grad_scale, fixed_scale, ctl, stream);
+}
+
+extern "C" int ns_ngp_sparse_table_update_rec(const void* lists, const int* counts, int n_lists, long stride, long max_count, void* acc,
+                                              float* master, void* half_params, float* m1, float* m2, int record_floats, int step,
+                                              float lr, float beta1, float beta2, float eps, float grad_scale, float fixed_scale,
+                                              const int* ctl, void* stream) {
   NS_REQUIRE(lists && counts && acc && master && half_params && m1 && m2, "ns_ngp_sparse_table_update: null pointer");
   NS_REQUIRE(n_lists >= 1 && stride >= max_count && max_count >= 0, "ns_ngp_sparse_table_update: bad sizes");
   NS_REQUIRE(grad_scale > 0.0f && fixed_scale > 0.0f && (ctl || step >= 1), "ns_ngp_sparse_table_update: incomplete Adam state");
@@ -3121,8 +3161,9 @@ extern "C" int ns_ngp_sparse_table_update(const void* lists, const int* counts, 
   ad.hp = (_Float16*)half_params;
   ad.m1 = m1;
   ad.m2 = m2;
-  ad.es = adam_entry_stride(master, m1, m2);
-  NS_REQUIRE(ad.es == 2 || ((uintptr_t)master & 15) == 0, "ns_ngp_sparse_table_update: interleaved optimiser records need a 16-byte aligned base");
+  ad.es = adam_entry_stride(master, m1, m2, record_floats);
+  NS_REQUIRE(ad.es > 0, "ns_ngp_sparse_table_update: record_floats = %d does not describe master / m1 / m2", record_floats);
+  NS_REQUIRE(ad.es != 8 || ((uintptr_t)master & 15) == 0, "ns_ngp_sparse_table_update: interleaved optimiser records need a 16-byte aligned base");
   ad.c1 = 1.0f - powf(beta1, (float)(step < 1 ? 1 : step));
   ad.c2 = 1.0f - powf(beta2, (float)(step < 1 ? 1 : step));
   ad.lr = lr;
@@ -3154,14 +3195,21 @@ extern "C" int ns_ngp_adam(float* master, void* half_params, float* grad, float*
 extern "C" int ns_ngp_adam_ctl(float* master, void* half_params, float* grad, float* m1, float* m2, long n, int step,
                                float lr, float beta1, float beta2, float eps, float l2, float grad_scale,
                                float fixed_scale, const int* ctl, void* stream) {
+  return ns_ngp_adam_rec_ctl(master, half_params, grad, m1, m2, 0, n, step, lr, beta1, beta2, eps, l2, grad_scale, fixed_scale, ctl, stream);
+}
+
+extern "C" int ns_ngp_adam_rec_ctl(float* master, void* half_params, float* grad, float* m1, float* m2, int record_floats, long n,
+                                   int step, float lr, float beta1, float beta2, float eps, float l2, float grad_scale,
+                                   float fixed_scale, const int* ctl, void* stream) {
   NS_REQUIRE(master && half_params && grad && m1 && m2, "ns_ngp_adam: null pointer");
   NS_REQUIRE((ctl || step >= 1) && grad_scale > 0.0f, "ns_ngp_adam: step must be >= 1 and grad_scale > 0");
   NS_REQUIRE(fixed_scale == 0.0f || n % 2 == 0, "ns_ngp_adam: packed gradients come in pairs");
   if (n <= 0) return NS_OK;
   const float c1 = 1.0f - powf(beta1, (float)(step < 1 ? 1 : step)), c2 = 1.0f - powf(beta2, (float)(step < 1 ? 1 : step));
-  const int es = adam_entry_stride(master, m1, m2);
+  const int es = adam_entry_stride(master, m1, m2, record_floats);
+  NS_REQUIRE(es > 0, "ns_ngp_adam: record_floats = %d does not describe master / m1 / m2", record_floats);
   NS_REQUIRE(es == 2 || n % 2 == 0, "ns_ngp_adam: interleaved records hold two parameters each");
-  NS_REQUIRE(es == 2 || ((uintptr_t)master & 15) == 0, "ns_ngp_adam: interleaved optimiser records need a 16-byte aligned base");
+  NS_REQUIRE(es != 8 || ((uintptr_t)master & 15) == 0, "ns_ngp_adam: interleaved optimiser records need a 16-byte aligned base");
   hipLaunchKernelGGL(ngp_adam_kernel, dim3(ns_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, master,
                      (_Float16*)half_params, grad, m1, m2, n, c1, c2, lr, beta1, beta2, eps, l2, 1.0f / grad_scale,
                      fixed_scale > 0.0f ? 1.0f / fixed_scale : 0.0f, ctl, es);

@@ -55,6 +55,10 @@ class NgpConfig:
                                          # Pipeline, two runs per arm in one call: 2: 134.5 / 135.8, 4: 138.8 / 137.6, 8: 137.5 / 139.9,
                                          # 16: 137.2 / 140.0 frames/s (profiles/r06_ab_records.json); 8 = 2.8 ms between two polls of
                                          # the packet queue
+    state_record_floats: int = 6         # the table's optimiser state: one record of 6 floats (24 B: master.xy, m1.xy, m2.xy) per
+                                         # entry -- or 8 (round 5's 32-byte record; its 8 unused bytes were a quarter of the flush's
+                                         # traffic once a step touches nearly every line of the state: 2^22 gradient resolution) --
+                                         # told to the library through the `_rec` entry points (include/nerfslam_hip.h)
     wgrad_after_scatter: bool = False    # A/B hook: the MLP weight-gradient chain forks AFTER the scatter pass instead of beside it
     grid_rule: str = "subset"            # occupancy refresh: "subset" (2^18 uniform cells per update) | "ngp" (instant-ngp's rule)
     grid_decay: float = 0.95
@@ -134,12 +138,16 @@ class NgpNerf:
         self.n_grid = int(off[c.n_levels]) * 2
         g = torch.Generator(device="cpu").manual_seed(base_seed)
         f = dict(dtype=torch.float32, device=dev)
-        # Optimiser state of the table: ONE 32-byte record per entry, [master.xy | m1.xy | m2.xy | 8 B unused] (csrc/ngp.hip:
-        # adam_entry_stride).  grid_master / grid_m1 / grid_m2 are [entries, 2] VIEWS of it: the kernels recognise the layout
-        # from the three pointers, and an entry the step touches costs one 128-byte line instead of three.
-        self.grid_state, self.grid_master, self.grid_m1, self.grid_m2 = self.new_grid_state(self.n_grid // 2, dev)
+        # Optimiser state of the table: ONE record per entry, [master.xy | m1.xy | m2.xy] (24 bytes; round 5: 32 with 8 unused)
+        # (csrc/ngp.hip: adam_entry_stride).  grid_master / grid_m1 / grid_m2 are [entries, 2] VIEWS of it; the library is told the
+        # record size (`_rec` entry points), and an entry the step touches costs one 128-byte line instead of three.
+        self.state_rec = int(c.state_record_floats)
+        if self.state_rec not in (6, 8):
+            raise ValueError("NgpConfig.state_record_floats is 6 or 8")
+        self.grid_state, self.grid_master, self.grid_m1, self.grid_m2 = self.new_grid_state(self.n_grid // 2, dev, self.state_rec)
         if variant_env("NS_ADAM_SEPARATE"):      # A/B: rounds 2-4's three dense arrays (same arithmetic, same bits)
             self.grid_state = None
+            self.state_rec = 2
             self.grid_master, self.grid_m1, self.grid_m2 = (torch.zeros((self.n_grid // 2, 2), **f) for _ in range(3))
         self.grid_master.copy_((torch.rand(self.n_grid, generator=g) * 2e-4 - 1e-4).view(-1, 2))
         w = []
@@ -211,10 +219,13 @@ class NgpNerf:
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
-    def new_grid_state(n_entries, device):
-        """(records [n_entries, 8] f32, and the master / m1 / m2 views [n_entries, 2] into them) -- the interleaved optimiser
-        state ns_ngp_encode_backward_fused / ns_ngp_adam recognise by m1 == master + 2 floats, m2 == master + 4 floats"""
-        rec = torch.zeros((int(n_entries), 8), dtype=torch.float32, device=device)
+    def new_grid_state(n_entries, device, record_floats=8):
+        """(records [n_entries, record_floats] f32, and the master / m1 / m2 views [n_entries, 2] into them) -- the interleaved
+        optimiser state: m1 == master + 2 floats, m2 == master + 4 floats.  record_floats = 8 is what the entry points WITHOUT
+        `_rec` recognise from the pointers (rounds 5's layout: the default here, for their callers); 6 (the trainer's) has to be
+        passed to the `_rec` entry points."""
+        assert record_floats in (6, 8)
+        rec = torch.zeros((int(n_entries), int(record_floats)), dtype=torch.float32, device=device)
         return rec, rec[:, 0:2], rec[:, 2:4], rec[:, 4:6]
 
     def _grid_args(self):
@@ -470,9 +481,10 @@ class NgpNerf:
 
         # ---- the pieces ----
         def adam(m, hp, g, m1, m2, l2, fxs, stream):
-            check(L.ns_ngp_adam_ctl(ptr(m), ptr(hp), ptr(g), ptr(m1), ptr(m2), C.c_long(m.numel()), 0, C.c_float(c.lr),
-                                    C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps), C.c_float(l2),
-                                    C.c_float(c.loss_scale * self.world), C.c_float(fxs), ctl, stream), "ngp_adam")
+            rec = self.state_rec if m is self.grid_master else 2          # (the MLP's state: three dense arrays)
+            check(L.ns_ngp_adam_rec_ctl(ptr(m), ptr(hp), ptr(g), ptr(m1), ptr(m2), rec, C.c_long(m.numel()), 0, C.c_float(c.lr),
+                                        C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps), C.c_float(l2),
+                                        C.c_float(c.loss_scale * self.world), C.c_float(fxs), ctl, stream), "ngp_adam")
         mlp = (self.mlp_master, self.mlp_half, self.mlp_grad, self.mlp_m1, self.mlp_m2, c.l2_mlp, 0.0)
 
         def mlp_adam(stream):
@@ -506,13 +518,14 @@ class NgpNerf:
                                                             n_dev, ptr(self._emit_list), ptr(self._emit_count), parts, stream),
                       "ngp_encode_backward_fused_emit")
                 return
-            check(L.ns_ngp_encode_backward_fused_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat),
-                                                   None if fa else ptr(self.grid_grad), ptr(self.enc_ws),
-                                                   C.c_size_t(self.enc_ws_bytes), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev,
-                                                   ptr(self.grid_master) if fa else None, ptr(self.grid_half) if fa else None,
-                                                   ptr(self.grid_m1) if fa else None, ptr(self.grid_m2) if fa else None,
-                                                   0, C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2), C.c_float(c.eps),
-                                                   C.c_float(c.loss_scale * self.world), ctl, parts, stream), "ngp_encode_backward_fused")
+            check(L.ns_ngp_encode_backward_fused_rec_n(*self._grid_args(), ptr(X["s_pos"]), ptr(self.s_dfeat),
+                                                       None if fa else ptr(self.grid_grad), ptr(self.enc_ws),
+                                                       C.c_size_t(self.enc_ws_bytes), C.c_float(c.grad_fixed_scale), C.c_long(S), n_dev,
+                                                       ptr(self.grid_master) if fa else None, ptr(self.grid_half) if fa else None,
+                                                       ptr(self.grid_m1) if fa else None, ptr(self.grid_m2) if fa else None,
+                                                       self.state_rec, 0, C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2),
+                                                       C.c_float(c.eps), C.c_float(c.loss_scale * self.world), ctl, parts, stream),
+                  "ngp_encode_backward_fused")
 
         # ---- THREE streams (a HIP graph runs its branches on a handful of hardware queues: a fourth concurrent branch shared a
         #      queue with the main one and the table gradient waited behind the pose refinement, +100 us).  Every fork costs the
@@ -837,9 +850,9 @@ class NgpNerf:
             wire = gather_lists(self._emit_list, recv, n_pairs, self.group) + (R - 1) * 4
             self.wire_log.append(n_pairs)
             with torch.cuda.device(self.device):
-                check(lib().ns_ngp_sparse_table_update(ptr(recv), ptr(counts_dev), R, C.c_long(n_pairs), C.c_long(max(counts)),
+                check(lib().ns_ngp_sparse_table_update_rec(ptr(recv), ptr(counts_dev), R, C.c_long(n_pairs), C.c_long(max(counts)),
                                                        ptr(self.grid_grad), ptr(self.grid_master), ptr(self.grid_half), ptr(self.grid_m1),
-                                                       ptr(self.grid_m2), 0, C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2),
+                                                       ptr(self.grid_m2), self.state_rec, 0, C.c_float(c.lr), C.c_float(c.beta1), C.c_float(c.beta2),
                                                        C.c_float(c.eps), C.c_float(c.loss_scale * self.world), C.c_float(c.grad_fixed_scale),
                                                        ptr(self.sets[x]["ctl"]), stream_ptr()), "ngp_sparse_table_update")
         else:

@@ -1012,11 +1012,14 @@ def test_interleaved_optimiser_records_are_bit_identical(oracle_mod, dev):
     g = torch.Generator().manual_seed(3)
     m0 = (torch.rand(n_par, generator=g) * 2e-4 - 1e-4).to(dev)
     st = {}
-    for name in ("dense_fused", "rec_fused", "rec_stream"):
+    # (round 6: "rec6_*" = 24-byte records, the trainer's layout since then, TOLD to the library through the `_rec` entry points;
+    #  "rec_*" = 32-byte records recognised from the pointers by the older entry points)
+    for name in ("dense_fused", "rec_fused", "rec_stream", "rec6_fused", "rec6_stream"):
         if name.startswith("rec"):
-            rec, ma, m1, m2 = NgpNerf.new_grid_state(n_par // 2, dev)
+            rf = 6 if name.startswith("rec6") else 8
+            rec, ma, m1, m2 = NgpNerf.new_grid_state(n_par // 2, dev, rf)
             ma.copy_(m0.view(-1, 2))
-            assert m1.data_ptr() == ma.data_ptr() + 8 and m2.data_ptr() == ma.data_ptr() + 16 and rec.stride(0) == 8
+            assert m1.data_ptr() == ma.data_ptr() + 8 and m2.data_ptr() == ma.data_ptr() + 16 and rec.stride(0) == rf
             st[name] = dict(rec=rec, master=ma, m1=m1, m2=m2, hp=m0.half())
         else:
             st[name] = dict(master=m0.clone(), hp=m0.half(), m1=torch.zeros(n_par, device=dev), m2=torch.zeros(n_par, device=dev))
@@ -1032,6 +1035,16 @@ def test_interleaved_optimiser_records_are_bit_identical(oracle_mod, dev):
             check(lib().ns_ngp_encode_backward_fused_n(*args, ptr(d_pos), ptr(d_dl), nul, ptr(ws), C.c_size_t(wsb), C.c_float(S), C.c_long(N),
                                                        nul, ptr(f["master"]), ptr(f["hp"]), ptr(f["m1"]), ptr(f["m2"]), step, C.c_float(lr),
                                                        C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(gs), nul, 15, stream_ptr()), "fused")
+        f = st["rec6_fused"]
+        check(lib().ns_ngp_encode_backward_fused_rec_n(*args, ptr(d_pos), ptr(d_dl), nul, ptr(ws), C.c_size_t(wsb), C.c_float(S), C.c_long(N),
+                                                       nul, ptr(f["master"]), ptr(f["hp"]), ptr(f["m1"]), ptr(f["m2"]), 6, step, C.c_float(lr),
+                                                       C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(gs), nul, 15, stream_ptr()), "fused rec6")
+        r = st["rec6_stream"]
+        gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
+        check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dl), 1, ptr(gq), None, C.c_size_t(0), C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
+        check(lib().ns_ngp_adam_rec_ctl(ptr(r["master"]), ptr(r["hp"]), ptr(gq), ptr(r["m1"]), ptr(r["m2"]), 6, C.c_long(n_par), step,
+                                        C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(0.0), C.c_float(gs), C.c_float(S),
+                                        nul, stream_ptr()), "adam rec6")
         r = st["rec_stream"]
         gq = torch.zeros(n_par // 2, dtype=torch.int64, device=dev)
         check(lib().ns_ngp_encode_backward(*args, ptr(d_pos), ptr(d_dl), 1, ptr(gq), None, C.c_size_t(0), C.c_float(S), C.c_long(N), stream_ptr()), "bwd")
@@ -1039,12 +1052,17 @@ def test_interleaved_optimiser_records_are_bit_identical(oracle_mod, dev):
                                 C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(0.0), C.c_float(gs), C.c_float(S), stream_ptr()), "adam")
         assert int((gq != 0).sum()) == 0                      # the streaming pass clears the gradient behind itself
         a = st["dense_fused"]
-        for name in ("rec_fused", "rec_stream"):
+        for name in ("rec_fused", "rec_stream", "rec6_fused", "rec6_stream"):
             f = st[name]
             for k in ("master", "m1", "m2"):
                 assert torch.equal(a[k], f[k].reshape(-1)), (name, step, k, int((a[k] != f[k].reshape(-1)).sum()))
             assert torch.equal(a["hp"], f["hp"]), (name, step)
-            assert float(f["rec"][:, 6:].abs().max()) == 0.0
+            assert f["rec"].shape[1] == 6 or float(f["rec"][:, 6:].abs().max()) == 0.0
+    # a record size that does not describe the pointers is refused, not guessed
+    f = st["rec_fused"]
+    rc = lib().ns_ngp_adam_rec_ctl(ptr(f["master"]), ptr(f["hp"]), ptr(gq), ptr(f["m1"]), ptr(f["m2"]), 2, C.c_long(n_par), 1, C.c_float(lr),
+                                   C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(0.0), C.c_float(gs), C.c_float(S), nul, stream_ptr())
+    assert rc != 0
     assert not torch.equal(st["rec_fused"]["master"].reshape(-1), m0)
 
 

@@ -12,6 +12,10 @@ warm = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 dev = torch.device("cuda:0")
 cfg = NgpConfig(optimize_extrinsics=bool(os.environ.get("NS_NGP_EXTRINSICS")),      # NerfFusion switches this on
                 use_graph=not os.environ.get("NS_NGP_NO_GRAPH"))
+for kv in filter(None, os.environ.get("NS_NGP_CFG", "").split(",")):      # A/B hook: "field=value,..." (ints / floats / 0-1 booleans)
+    k_, v_ = kv.split("=")
+    cur = getattr(cfg, k_)
+    setattr(cfg, k_, bool(int(v_)) if isinstance(cur, bool) else type(cur)(v_))
 net = NgpNerf(cfg, dev, seed=0)
 import importlib.util
 spec = importlib.util.spec_from_file_location("ngp_scene", os.path.join(root, "tools", "ngp_scene.py"))
